@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Extract small fixtures from /root/reference and pin the oracle against them.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    python scripts/make_golden.py
+
+Writes
+  tests/golden/sac_mlp_best_model.npz     SAC-MLP parameter set shipped by the reference
+                                          (trained_models/SAC_encoder_1mbuffer/best_model/best_model.zip)
+  tests/golden/vecnorm_encoder.npz        its VecNormalize statistics + the 2 real 101-d observations
+  tests/golden/depth_frames.npz           the six real 64x64 depth frames preserved in vecnormalize.pkl files
+  tests/golden/ae_new_gripper_encoder.npz encoder half of encoder_files/new_gripper_encoder/model.h5
+  tests/golden/oracle_pins.json           results of the SURVEY.md B.5 known-relationship checks +
+                                          oracle outputs on the real inputs (golden vectors for the kernels)
+  deep-rl-grasping_amd/grasp_rl/data/obs_stats_{depth,rgbd}.npz   per-pixel observation statistics used
+                                          to draw synthetic replay contents
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import autoencoder as ae            # noqa: E402
+from oracle import fixtures as fx               # noqa: E402
+from oracle import sac as osac                  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "deep-rl-grasping_amd", "grasp_rl", "data")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    os.makedirs(DATA, exist_ok=True)
+    pins = {}
+
+    # ---------------------------------------------------------------- SAC-MLP fixture
+    zpath = REF + "/trained_models/SAC_encoder_1mbuffer/best_model/best_model.zip"
+    data, params = fx.load_sb_zip(zpath)
+    np.savez_compressed(GOLD + "/sac_mlp_best_model.npz", **{k: v for k, v in params.items()})
+    pins["sac_mlp_zip"] = {
+        "source": zpath[len(REF) + 1:],
+        "param_names": list(params.keys()),
+        "hyper": {k: data[k] for k in ("gamma", "tau", "batch_size", "buffer_size", "learning_starts",
+                                       "train_freq", "ent_coef", "n_envs")},
+    }
+    vn = fx.load_vecnormalize_pkl(REF + "/trained_models/SAC_encoder_1mbuffer/best_model/vecnormalize.pkl")
+    vn2 = fx.load_vecnormalize_pkl(REF + "/trained_models/SAC_encoder_1mbuffer/vecnormalize.pkl")
+    real_obs = np.concatenate([vn["old_obs"], vn2["old_obs"]], 0).astype(np.float32)
+    np.savez_compressed(GOLD + "/vecnorm_encoder.npz", mean=vn["obs_rms"]["mean"], var=vn["obs_rms"]["var"],
+                        count=vn["obs_rms"]["count"], ret_var=vn["ret_rms"]["var"],
+                        clip_obs=vn["clip_obs"], clip_reward=vn["clip_reward"], epsilon=vn["epsilon"],
+                        gamma=vn["gamma"], real_obs=real_obs)
+
+    # B.5 check 1: V(s) ~= min(Q1,Q2)(s, pi(s)) - alpha*logp for the trained parameter set
+    spec = osac.SacSpec(extractor="mlp", obs_dim=101, act_dim=5, layers=[64, 64])
+    assert list(osac.param_shapes(spec).keys()) == list(params.keys()), "TF name/order mismatch"
+    for k, shp in osac.param_shapes(spec).items():
+        assert tuple(params[k].shape) == tuple(shp), (k, params[k].shape, shp)
+    rng = np.random.default_rng(0)
+    mean, var = vn["obs_rms"]["mean"], vn["obs_rms"]["var"]
+    raw = rng.normal(mean, np.sqrt(var), (512, 101))
+    obs_n = osac.normalize_obs(raw, mean, var).astype(np.float32)
+    orc = osac.SacOracle(spec, params)
+    T = orc.tensors()
+    eps = rng.standard_normal((512, 5)).astype(np.float32)
+    a = osac.actor_fwd(spec, T, torch.from_numpy(obs_n), torch.from_numpy(eps))
+    c = osac.critic_fwd(spec, T, "model/values_fn", torch.from_numpy(obs_n), a["pi"], a["pi"])
+    t = osac.critic_fwd(spec, T, "target/values_fn", torch.from_numpy(obs_n))
+    alpha = float(np.exp(params["model/log_ent_coef:0"]))
+    minq = torch.minimum(c["qf1"], c["qf2"]).numpy()
+    v = c["v"].numpy()
+    corr = float(np.corrcoef(v, minq)[0, 1])
+    # reversed concat order must NOT satisfy the relation (discriminating check)
+    Tw = dict(T)
+    h = torch.from_numpy(obs_n)
+    qs = []
+    for q in ("qf1", "qf2"):
+        qin = torch.cat([a["pi"], h], 1)
+        qs.append(osac.dense(Tw, "model/values_fn/" + q, q,
+                             osac.mlp_fwd(spec, Tw, "model/values_fn/" + q, qin)).reshape(-1))
+    corr_rev = float(np.corrcoef(v, torch.minimum(*qs).numpy())[0, 1])
+    corr_tgt = float(np.corrcoef(v, t["v"].numpy())[0, 1])
+    pins["b5_sac_head_wiring"] = {"alpha": alpha, "corr_V_minQpi": corr, "corr_reversed_concat": corr_rev,
+                                  "corr_V_Vtarget": corr_tgt,
+                                  "mean_abs_V_minus_minQ": float(np.abs(v - minq).mean())}
+    print("B.5-1", pins["b5_sac_head_wiring"])
+    assert corr > 0.9 and corr_rev < 0.5 and corr_tgt > 0.99
+
+    # golden forward vectors on the 2 real observations (normalised with the shipped stats)
+    ro = osac.normalize_obs(real_obs, mean, var).astype(np.float32)
+    a2 = osac.actor_fwd(spec, T, torch.from_numpy(ro), torch.zeros(2, 5))
+    c2 = osac.critic_fwd(spec, T, "model/values_fn", torch.from_numpy(ro), a2["det"], a2["det"])
+    pins["sac_mlp_real_obs"] = {"mu": a2["mu"].numpy().tolist(), "log_std": a2["log_std"].numpy().tolist(),
+                                "det_action": a2["det"].numpy().tolist(), "v": c2["v"].numpy().tolist(),
+                                "qf1_det": c2["qf1"].numpy().tolist(), "qf2_det": c2["qf2"].numpy().tolist()}
+
+    # ---------------------------------------------------------------- observation statistics
+    vd = fx.load_vecnormalize_pkl(REF + "/trained_models/SAC_depth_1mbuffer/best_model/vecnormalize.pkl")
+    np.savez_compressed(DATA + "/obs_stats_depth.npz", mean=vd["obs_rms"]["mean"], var=vd["obs_rms"]["var"],
+                        count=vd["obs_rms"]["count"], ret_var=vd["ret_rms"]["var"])
+    vr = fx.load_vecnormalize_pkl(REF + "/trained_models/SAC_full_rgbd/vecnormalize.pkl")
+    np.savez_compressed(DATA + "/obs_stats_rgbd.npz", mean=vr["obs_rms"]["mean"], var=vr["obs_rms"]["var"],
+                        count=vr["obs_rms"]["count"], ret_var=vr["ret_rms"]["var"])
+    pins["obs_stats"] = {"depth_mean_range": [float(vd["obs_rms"]["mean"][..., 0].min()),
+                                              float(vd["obs_rms"]["mean"][..., 0].max())],
+                         "depth_pad00": [float(vd["obs_rms"]["mean"][0, 0, 1]), float(vd["obs_rms"]["var"][0, 0, 1])],
+                         "ret_var": float(vd["ret_rms"]["var"])}
+
+    # ---------------------------------------------------------------- real depth frames
+    frames = []
+    for p in sorted(glob.glob(REF + "/trained_models/**/vecnormalize.pkl", recursive=True)):
+        o = fx.load_vecnormalize_pkl(p)["old_obs"]
+        if o.ndim == 4:
+            frames.append(o[0, :, :, 0 if o.shape[-1] == 2 else 3].astype(np.float32))
+    frames = np.stack(frames)
+    np.savez_compressed(GOLD + "/depth_frames.npz", frames=frames)
+    print("real depth frames:", frames.shape, frames.min(), frames.max())
+
+    # ---------------------------------------------------------------- auto-encoder (B.5 check 2)
+    table = {}
+    for tag, p in (("root", REF + "/encoder_files/model.h5"),
+                   ("new_gripper_encoder", REF + "/encoder_files/new_gripper_encoder/model.h5"),
+                   ("original_encoder", REF + "/encoder_files/original_encoder/model.h5"),
+                   ("new_encoder", REF + "/encoder_files/new_encoder/model.h5")):
+        W = fx.load_keras_ae_h5(p)
+        x = frames[..., None]
+        rec = ae.decode(W, ae.encode(W, x))
+        mse_ok = float(np.mean((rec - x) ** 2))
+        # wrong conventions (symmetric k//2 padding) must be clearly worse
+        orig = ae.tf_same_pad
+        ae.tf_same_pad = lambda n, k, s: (k // 2, k // 2 - (1 if (n + 2 * (k // 2) - k) % s else 0)) \
+            if s > 1 else (k // 2, k // 2)
+        try:
+            rec_bad = ae.decode(W, ae.encode(W, x))
+        finally:
+            ae.tf_same_pad = orig
+        mse_bad = float(np.mean((rec_bad - x) ** 2))
+        table[tag] = {"mse_tf_same_nhwc": mse_ok, "mse_symmetric_pad": mse_bad}
+        print("B.5-2", tag, table[tag])
+        assert mse_ok < 0.5 * mse_bad and mse_ok < 0.01
+        if tag == "new_gripper_encoder":
+            enc = {k: v for k, v in W.items() if k.startswith("encoder/")}
+            np.savez_compressed(GOLD + "/ae_new_gripper_encoder.npz", **enc)
+            z = ae.encode(W, x)
+            np.savez_compressed(GOLD + "/ae_encodings.npz", z=z)
+            pins["ae_encoding_abs_mean"] = float(np.abs(z).mean())
+    pins["b5_autoencoder_mse"] = table
+
+    with open(GOLD + "/oracle_pins.json", "w") as f:
+        json.dump(pins, f, indent=1, sort_keys=True)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
