@@ -1,0 +1,449 @@
+// elem_kernels.h -- the HBM-/latency-bound pieces of the SAC update: replay gather + VecNormalize
+// normalisation, squashed-Gaussian sampling and its backward, loss/out-gradient kernel, split-slab
+// reduction, TF-style Adam fused with the Polyak target update, replay ingest, device RNG.
+//
+// Math follows SURVEY.md Appendix A (restating stable-baselines 2.10.1 SAC as wired by
+// /root/reference/manipulation_main/training/sb_helper.py:104-128).
+#pragma once
+#ifdef GRL_HOSTEMU
+#include "hostemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace grl {
+
+// ------------------------------------------------------------------------------------------------
+// device scalars shared by the kernels of one update (lives in the state arena)
+struct DevScalars {
+  float beta1_power, beta2_power;   // TF AdamOptimizer non-slot variables (start at beta1, beta2)
+  float adam_alpha;                 // lr * sqrt(1-b2p)/(1-b1p) of the current step
+  float pad0;
+  // metrics of the last update
+  float policy_loss, qf1_loss, qf2_loss, value_loss, ent_loss, ent_coef, entropy, mean_qf1, mean_v;
+  float pad1[3];
+  uint64_t rng_step;                // Philox counter (one per drawn minibatch)
+  int64_t replay_size;              // transitions currently stored
+};
+
+// ------------------------------------------------------------------------------------------------
+// replay gather + VecNormalize.normalize_obs / normalize_reward at sample time (A.1 step 3) +
+// observation_input /255 scaling (A.1 step 4).  float64 arithmetic as in the NumPy reference path,
+// rounded to float32 once, then the float32 division by 255 TF performs.
+struct GatherArgs {
+  const int64_t* idx;
+  int B, img_elems, n_direct, act_dim;
+  const float* rp_obs; const float* rp_next;       // [cap, img_elems]
+  const float* rp_dobs; const float* rp_dnext;     // [cap, n_direct]
+  const float* rp_act; const float* rp_rew; const float* rp_done;
+  const double* mean; const double* stdv;          // [img_elems] (std = sqrt(var + eps))
+  const double* dmean; const double* dstd;         // [n_direct]
+  const double* ret_std;                           // [1]
+  int normalize;
+  double clip_obs, clip_rew;
+  float scale_div;                                 // 255 for CNN policies, 1 for MLP
+  float* x_obs; float* x_obs2; float* x_next;      // destinations, row stride ldx
+  int ldx;
+  float* d_obs0; float* d_obs1; float* d_next;     // direct-feature destinations, row stride ldd
+  int ldd;
+  float* act_out; int ld_act;
+  float* rew_out; float* done_out;
+};
+
+__device__ __forceinline__ float norm_elem(float x, double mu, double sd, int normalize, double clip,
+                                           float scale_div) {
+  float y = x;
+  if (normalize) {
+    double z = ((double)x - mu) / sd;
+    z = z < -clip ? -clip : (z > clip ? clip : z);
+    y = (float)z;
+  }
+  return scale_div != 1.f ? y / scale_div : y;
+}
+
+__global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
+  const int b = blockIdx.y;
+  const int which = blockIdx.z;   // 0: obs, 1: next_obs
+  const int64_t src = a.idx[b];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < a.img_elems) {
+    const float* rp = which ? a.rp_next : a.rp_obs;
+    const float x = rp[src * a.img_elems + e];
+    const float y = norm_elem(x, a.normalize ? a.mean[e] : 0.0, a.normalize ? a.stdv[e] : 1.0,
+                              a.normalize, a.clip_obs, a.scale_div);
+    if (which) {
+      a.x_next[(long)b * a.ldx + e] = y;
+    } else {
+      a.x_obs[(long)b * a.ldx + e] = y;
+      if (a.x_obs2) a.x_obs2[(long)b * a.ldx + e] = y;
+    }
+  }
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (t < a.n_direct) {
+      const float* rp = which ? a.rp_dnext : a.rp_dobs;
+      const float x = rp[src * a.n_direct + t];
+      const float y = norm_elem(x, a.normalize ? a.dmean[t] : 0.0, a.normalize ? a.dstd[t] : 1.0,
+                                a.normalize, a.clip_obs, a.scale_div);
+      if (which) {
+        a.d_next[(long)b * a.ldd + t] = y;
+      } else {
+        a.d_obs0[(long)b * a.ldd + t] = y;
+        a.d_obs1[(long)b * a.ldd + t] = y;
+      }
+    }
+    if (which == 0) {
+      if (t < a.act_dim) a.act_out[(long)b * a.ld_act + t] = a.rp_act[src * a.act_dim + t];
+      if (t == 64) {
+        float r = a.rp_rew[src];
+        if (a.normalize) {
+          double z = (double)r / a.ret_std[0];
+          z = z < -a.clip_rew ? -a.clip_rew : (z > a.clip_rew ? a.clip_rew : z);
+          r = (float)z;
+        }
+        a.rew_out[b] = r;
+      }
+      if (t == 65) a.done_out[b] = a.rp_done[src];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// replay ingest: env-layout observation [n, HW, Cobs] (or [n, D]) -> image block [HW*Cimg] + direct
+struct IngestArgs {
+  const float* obs; const float* next_obs; const float* act; const float* rew; const float* done;
+  int n, hw, c_obs, c_img, n_direct, act_dim, vec_dim;   // vec_dim > 0: MLP vector observation
+  int64_t pos, cap;
+  float* rp_obs; float* rp_next; float* rp_dobs; float* rp_dnext; float* rp_act; float* rp_rew;
+  float* rp_done;
+};
+
+__global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
+  const int k = blockIdx.y;
+  const int which = blockIdx.z;
+  const int64_t dst = (a.pos + k) % a.cap;
+  const float* src = (which ? a.next_obs : a.obs);
+  float* img = which ? a.rp_next : a.rp_obs;
+  float* dir = which ? a.rp_dnext : a.rp_dobs;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (a.vec_dim > 0) {
+    if (e < a.vec_dim) img[dst * a.vec_dim + e] = src[(long)k * a.vec_dim + e];
+  } else {
+    const int img_elems = a.hw * a.c_img;
+    if (e < img_elems) {
+      const int px = e / a.c_img, c = e - px * a.c_img;
+      img[dst * img_elems + e] = src[((long)k * a.hw + px) * a.c_obs + c];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < a.n_direct)   // flatten(x[..., -1])[:, :n]  (custom_obs_policy.py:28-30)
+      dir[dst * a.n_direct + threadIdx.x] =
+          src[((long)k * a.hw + threadIdx.x) * a.c_obs + (a.c_obs - 1)];
+  }
+  if (blockIdx.x == 0 && which == 0) {
+    if (threadIdx.x < a.act_dim) a.rp_act[dst * a.act_dim + threadIdx.x] = a.act[(long)k * a.act_dim + threadIdx.x];
+    if (threadIdx.x == 64) a.rp_rew[dst] = a.rew[k];
+    if (threadIdx.x == 65) a.rp_done[dst] = a.done[k];
+  }
+}
+
+// observation of grl_act: already VecNormalize-d by the env wrapper; only split + /255
+struct ActIngestArgs {
+  const float* obs; int n, hw, c_obs, c_img, n_direct, vec_dim;
+  float scale_div;
+  float* x; int ldx;
+  float* d; int ldd;
+};
+
+__global__ __launch_bounds__(256) void act_ingest_kernel(ActIngestArgs a) {
+  const int k = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (a.vec_dim > 0) {
+    if (e < a.vec_dim) a.x[(long)k * a.ldx + e] = a.obs[(long)k * a.vec_dim + e];
+    return;
+  }
+  const int img_elems = a.hw * a.c_img;
+  if (e < img_elems) {
+    const int px = e / a.c_img, c = e - px * a.c_img;
+    a.x[(long)k * a.ldx + e] = a.obs[((long)k * a.hw + px) * a.c_obs + c] / a.scale_div;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < a.n_direct)
+    a.d[(long)k * a.ldd + threadIdx.x] =
+        a.obs[((long)k * a.hw + threadIdx.x) * a.c_obs + (a.c_obs - 1)] / a.scale_div;
+}
+
+// ------------------------------------------------------------------------------------------------
+// squashed Gaussian policy head (A.3).  mu/ls_raw are the `dense` / `dense_1` outputs.
+#define GRL_EPS 1e-6f
+#define GRL_LOG_STD_MAX 2.0f
+#define GRL_LOG_STD_MIN (-20.0f)
+
+struct SampleArgs {
+  const float* mu; const float* ls_raw; const float* eps; int B, A;
+  float* pi;       // tanh(mu + std*eps)        [B,A]
+  float* det;      // tanh(mu)                  [B,A]
+  float* logp;     // [B]
+  float* entropy;  // [B]
+};
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  float logp = 0.f, ent = 0.f;
+  for (int j = 0; j < a.A; ++j) {
+    const float mu = a.mu[b * a.A + j];
+    const float ls = fminf(fmaxf(a.ls_raw[b * a.A + j], GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+    const float sd = expf(ls);
+    const float u = mu + a.eps[b * a.A + j] * sd;
+    const float z = (u - mu) / (sd + GRL_EPS);
+    logp += -0.5f * (z * z + 2.f * ls + 1.8378770664093453f);        // log(2*pi)
+    ent += ls + 1.4189385332046727f;                                   // 0.5*log(2*pi*e)
+    const float t = tanhf(u);
+    logp -= logf(1.f - t * t + GRL_EPS);
+    a.pi[b * a.A + j] = t;
+    if (a.det) a.det[b * a.A + j] = tanhf(mu);
+  }
+  a.logp[b] = logp;
+  a.entropy[b] = ent;
+}
+
+// backward of policy_loss = mean(ent_coef*logp - qf1_pi) through the squashing / sampling.
+struct SampleBwdArgs {
+  const float* mu; const float* ls_raw; const float* eps; const float* pi;
+  const float* da;             // dL/d a_pi from the qf1 head backward   [B,A] (row stride ld_da)
+  int ld_da;
+  const float* log_ent_coef;   // parameter scalar
+  int B, A;
+  float* dmu; float* dls;      // [B,A]
+};
+
+__global__ __launch_bounds__(256) void sample_bwd_kernel(SampleBwdArgs a) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const float alpha_over_b = expf(a.log_ent_coef[0]) / (float)a.B;
+  for (int j = 0; j < a.A; ++j) {
+    const float lr = a.ls_raw[b * a.A + j];
+    const float ls = fminf(fmaxf(lr, GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+    const float sd = expf(ls);
+    const float ep = a.eps[b * a.A + j];
+    const float t = a.pi[b * a.A + j];
+    const float omt = 1.f - t * t;
+    // d/du [ alpha/B * (-log(1 - t^2 + EPS)) + (dL/da) * t ]
+    const float du = a.da[(long)b * a.ld_da + j] * omt + alpha_over_b * (2.f * t * omt / (omt + GRL_EPS));
+    a.dmu[b * a.A + j] = du;                       // Gaussian term has no mu-gradient: u - mu = std*eps
+    // Gaussian log-likelihood term: -0.5*(z^2 + 2 ls + c), z = sd*eps/(sd+EPS)
+    const float den = sd + GRL_EPS;
+    const float z = sd * ep / den;
+    const float dz_dls = ep * sd * GRL_EPS / (den * den);
+    float dls = du * sd * ep + alpha_over_b * (-(z * dz_dls + 1.f));
+    if (lr < GRL_LOG_STD_MIN || lr > GRL_LOG_STD_MAX) dls = 0.f;     // clip_by_value gradient
+    a.dls[b * a.A + j] = dls;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses (A.4) and their gradients w.r.t. the critic / value outputs; Adam step size; metrics.
+struct LossArgs {
+  int B; float gamma, target_entropy, lr;
+  const float* rew; const float* done;
+  const float* v_tgt; const float* qf1; const float* qf2; const float* v;
+  const float* qf1_pi; const float* qf2_pi; const float* logp; const float* entropy;
+  const float* log_ent_coef;
+  float* d_qf1; float* d_qf2; float* d_v; float* d_qf1_pi;   // [B] each
+  float* g_log_ent_coef;                                      // gradient slot in the flat bucket
+  DevScalars* sc;
+};
+
+#ifdef GRL_HOSTEMU
+// TEST-ONLY sequential form (see hostemu.h)
+inline void sac_loss_kernel(LossArgs a) {
+  if (threadIdx.x != 0) return;
+  const float log_alpha = a.log_ent_coef[0];
+  const float alpha = expf(log_alpha);
+  const float invB = 1.f / (float)a.B;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < a.B; ++b) {
+    const float qb = a.rew[b] + (1.f - a.done[b]) * a.gamma * a.v_tgt[b];
+    const float e1 = a.qf1[b] - qb, e2 = a.qf2[b] - qb;
+    const float lp = a.logp[b];
+    const float vb = fminf(a.qf1_pi[b], a.qf2_pi[b]) - alpha * lp;
+    const float ev = a.v[b] - vb;
+    a.d_qf1[b] = e1 * invB; a.d_qf2[b] = e2 * invB; a.d_v[b] = ev * invB; a.d_qf1_pi[b] = -invB;
+    s[0] += 0.5f * e1 * e1; s[1] += 0.5f * e2 * e2; s[2] += 0.5f * ev * ev;
+    s[3] += alpha * lp - a.qf1_pi[b]; s[4] += lp + a.target_entropy; s[5] += a.entropy[b];
+    s[6] += a.qf1[b]; s[7] += a.v[b];
+  }
+  DevScalars* sc = a.sc;
+  sc->qf1_loss = s[0] * invB; sc->qf2_loss = s[1] * invB; sc->value_loss = s[2] * invB;
+  sc->policy_loss = s[3] * invB;
+  const float mean_lp_h = s[4] * invB;
+  sc->ent_loss = -log_alpha * mean_lp_h;
+  a.g_log_ent_coef[0] = -mean_lp_h;
+  sc->ent_coef = alpha; sc->entropy = s[5] * invB; sc->mean_qf1 = s[6] * invB; sc->mean_v = s[7] * invB;
+  sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+  sc->beta1_power *= 0.9f;
+  sc->beta2_power *= 0.999f;
+}
+#else
+__global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) {
+  __shared__ float red[8][256];
+  const int t = threadIdx.x;
+  const float log_alpha = a.log_ent_coef[0];
+  const float alpha = expf(log_alpha);
+  const float invB = 1.f / (float)a.B;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = t; b < a.B; b += 256) {
+    const float qb = a.rew[b] + (1.f - a.done[b]) * a.gamma * a.v_tgt[b];
+    const float e1 = a.qf1[b] - qb, e2 = a.qf2[b] - qb;
+    const float lp = a.logp[b];
+    const float vb = fminf(a.qf1_pi[b], a.qf2_pi[b]) - alpha * lp;
+    const float ev = a.v[b] - vb;
+    a.d_qf1[b] = e1 * invB;
+    a.d_qf2[b] = e2 * invB;
+    a.d_v[b] = ev * invB;
+    a.d_qf1_pi[b] = -invB;
+    s[0] += 0.5f * e1 * e1;
+    s[1] += 0.5f * e2 * e2;
+    s[2] += 0.5f * ev * ev;
+    s[3] += alpha * lp - a.qf1_pi[b];
+    s[4] += lp + a.target_entropy;
+    s[5] += a.entropy[b];
+    s[6] += a.qf1[b];
+    s[7] += a.v[b];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[k][t] = s[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off)
+      for (int k = 0; k < 8; ++k) red[k][t] += red[k][t + off];
+    __syncthreads();
+  }
+  if (t == 0) {
+    DevScalars* sc = a.sc;
+    sc->qf1_loss = red[0][0] * invB;
+    sc->qf2_loss = red[1][0] * invB;
+    sc->value_loss = red[2][0] * invB;
+    sc->policy_loss = red[3][0] * invB;
+    const float mean_lp_h = red[4][0] * invB;
+    sc->ent_loss = -log_alpha * mean_lp_h;
+    a.g_log_ent_coef[0] = -mean_lp_h;
+    sc->ent_coef = alpha;
+    sc->entropy = red[5][0] * invB;
+    sc->mean_qf1 = red[6][0] * invB;
+    sc->mean_v = red[7][0] * invB;
+    // TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power); powers advance after
+    sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+    sc->beta1_power *= 0.9f;
+    sc->beta2_power *= 0.999f;
+  }
+}
+
+#endif  // GRL_HOSTEMU
+
+// ------------------------------------------------------------------------------------------------
+// sum split slabs of weight gradients into the flat gradient bucket
+struct ReduceDesc {
+  float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs) {
+  const ReduceDesc d = descs[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < d.splits; ++k) s += d.src[(long)k * d.slab_stride + i];
+    d.dst[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TF-1.x Adam (A.5) over the flat trainable block, fused with the Polyak target update (A.4):
+// target <- (1-tau)*target + tau*source for the leading `n_polyak` floats of model/values_fn.
+struct AdamArgs {
+  float* params; const float* grads; float* m; float* v;
+  int64_t n_train;
+  const DevScalars* sc;
+  float grad_scale, tau;
+  int64_t src_ofs, n_polyak;   // source range [src_ofs, src_ofs+n_polyak) inside params
+  float* target;               // target block
+};
+
+__global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
+  const float alpha = a.sc->adam_alpha;
+  const float omb1 = 1.f - 0.9f, omb2 = 1.f - 0.999f;
+  const float omt = 1.f - a.tau;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_train;
+       i += (int64_t)gridDim.x * 256) {
+    const float g = a.grads[i] * a.grad_scale;
+    float m = a.m[i], v = a.v[i];
+    m = m + (g - m) * omb1;
+    v = v + (g * g - v) * omb2;
+    const float p = a.params[i] - (m * alpha) / (sqrtf(v) + 1e-8f);
+    a.m[i] = m;
+    a.v[i] = v;
+    a.params[i] = p;
+    const int64_t k = i - a.src_ofs;
+    if (k >= 0 && k < a.n_polyak) a.target[k] = omt * a.target[k] + a.tau * p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device RNG (Philox4x32-10): replay indices uniform in [0, size) and standard normals
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+struct RngArgs {
+  DevScalars* sc; uint64_t seed; int B, A;
+  int64_t* idx; float* eps;
+};
+
+__global__ __launch_bounds__(256) void rng_kernel(RngArgs a) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t step = a.sc->rng_step;
+  if (b < a.B) {
+    const int64_t size = a.sc->replay_size;
+    uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, 0u};
+    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const uint64_t u = ((uint64_t)c[0] << 32) | c[1];
+    a.idx[b] = size > 0 ? (int64_t)__umul64hi(u, (uint64_t)size) : 0;
+    for (int j0 = 0; j0 < a.A; j0 += 2) {
+      uint32_t d[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, (uint32_t)(1 + j0)};
+      philox4x32_10(d, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+      const float u1 = ((float)(d[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+      const float u2 = ((float)(d[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+      const float rad = sqrtf(-2.f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      a.eps[b * a.A + j0] = rad * cs;
+      if (j0 + 1 < a.A) a.eps[b * a.A + j0 + 1] = rad * sn;
+    }
+  }
+}
+
+__global__ void rng_tick_kernel(DevScalars* sc) { sc->rng_step += 1; }
+
+// final tanh of the act path: a = deterministic ? tanh(mu) : tanh(mu + exp(clip(ls)) * eps)
+__global__ __launch_bounds__(256) void act_out_kernel(const float* mu, const float* ls_raw,
+                                                     const float* eps, int n, int A,
+                                                     int deterministic, float* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * A) return;
+  float u = mu[i];
+  if (!deterministic) {
+    const float ls = fminf(fmaxf(ls_raw[i], GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+    u += expf(ls) * eps[i];
+  }
+  out[i] = tanhf(u);
+}
+
+}  // namespace grl

@@ -1,0 +1,1388 @@
+// engine.hip -- host side of libgrl.so: parameter layout, addressing tables, the launch plan of one
+// SAC update and the C ABI of include/grl.h.
+//
+// What is built here is the stable-baselines SAC update the reference drives through
+// manipulation_main/training/sb_helper.py:104-128 (policy / extractor selection :85-96, extractor
+// custom_obs_policy.py:15-43), restated in SURVEY.md Appendix A.  All device memory belongs to the
+// caller; this file only plans where things live inside the caller's arenas and enqueues kernels.
+#ifdef GRL_HOSTEMU
+#include "hostemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/grl.h"
+#include "elem_kernels.h"
+#include "igemm.h"
+
+namespace grl {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(GRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+static inline int64_t rup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+struct Var {
+  std::string name;
+  int64_t off, numel;
+  int ndim;
+  int64_t shape[4];
+  bool trainable;
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0;
+  void* take(size_t bytes, size_t align = 256) {
+    off = (size_t)rup((int64_t)off, (int64_t)align);
+    void* p = base + off;   // base == nullptr: dry run, the value is only an offset
+    off += bytes;
+    return p;
+  }
+  float* f32(int64_t n) { return (float*)take((size_t)n * 4); }
+};
+
+struct Upload {
+  void* dst;
+  std::vector<uint8_t> bytes;
+};
+
+struct ConvGeom {
+  int H, W, C, KH, KW, S, pad, OH, OW, Cout;
+  int K() const { return KH * KW * C; }
+};
+
+struct ConvFwdTabs {
+  int32_t* tab_i = nullptr;   // [M]
+  int32_t* tab_r = nullptr;   // [K+1] (extra entry for the bias row of the weight gradient)
+  uint64_t* vmask = nullptr;  // [M] when pad > 0
+  uint8_t* tap = nullptr;     // [K+1]
+  int M = 0;
+};
+
+struct ConvBwdClass {
+  int32_t *tab_i, *tab_r, *q_tab_r, *c_tab_i;
+  uint64_t* vmask;
+  uint8_t* tap;
+  int M, K;
+};
+
+struct Launch {
+  int variant;   // 0: P along r, Q along j   1: P along r, Q along r   2: P along i, Q along j
+  std::vector<IgemmProb> probs;
+  IgemmProb* d_probs = nullptr;
+  int4* d_tiles = nullptr;
+  int n_tiles = 0;
+};
+
+struct Op {
+  std::string tag;
+  std::function<void(hipStream_t)> run;
+  double flops = 0;   // algorithmic FLOPs of one launch
+  double bytes = 0;   // algorithmic HBM bytes of one launch
+};
+
+struct ProfAcc {
+  double ms = 0;
+  int64_t n = 0;
+  double flops = 0, bytes = 0;
+};
+
+struct ExtractorP {
+  int64_t w[3], b[3], fw, fb;
+};
+struct MlpP {
+  int in_dim = 0;
+  int64_t w[GRL_MAX_LAYERS], b[GRL_MAX_LAYERS];
+  int n_out = 0;
+  int64_t ow[2], ob[2];
+  int out_dim = 0;
+};
+struct HeadAct {
+  float* z[GRL_MAX_LAYERS];
+  float* out[2];
+};
+struct HeadGrad {
+  float* g[GRL_MAX_LAYERS];
+};
+
+}  // namespace grl
+
+using namespace grl;
+
+struct grl_ctx {
+  grl_config cfg;
+  hipStream_t stream = nullptr;
+  bool dry = false;
+
+  // derived
+  bool cnn = false;
+  int C_img = 0, hw = 0, img_elems = 0, F = 0, Fc = 0, ldf = 0, A = 0, L = 0, B = 0, NA = 0;
+  int hid[GRL_MAX_LAYERS];
+
+  // parameter layout
+  std::vector<Var> vars;
+  int64_t n_params = 0, n_train = 0, tgt_off = 0, vf_off = 0, n_polyak = 0, ent_off = 0;
+  ExtractorP ex[3];   // 0 pi, 1 values_fn, 2 target
+  MlpP m_pi, m_vf, m_qf1, m_qf2, m_tgt;
+
+  // arenas
+  Arena st, gr, wk, rp;
+  float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grads = nullptr;
+  DevScalars* sc = nullptr;
+  double *s_mean = nullptr, *s_std = nullptr, *s_dmean = nullptr, *s_dstd = nullptr, *s_ret = nullptr;
+  // replay
+  float *rp_obs, *rp_next, *rp_dobs, *rp_dnext, *rp_act, *rp_rew, *rp_done;
+  int64_t rp_pos = 0, rp_size = 0;
+  // staging for host replay_add / act / encode
+  float *stg_obs, *stg_next, *stg_act, *stg_rew, *stg_done;
+  int stg_n = 0;
+
+  // workspace (train)
+  int64_t* idx_buf;
+  float* eps_buf;
+  float *x_obs, *x_next;
+  float *a1[3], *a2[3], *a3[3], *feat[3];
+  float *act, *rew, *done;
+  HeadAct hPI, hVF, hQF1, hQF2, hTGT, hQF1PI, hQF2PI;
+  float *pi_a, *logp, *ent;
+  float *d_qf1, *d_qf2, *d_v, *d_qf1pi;
+  HeadGrad gPI, gVF, gQF1, gQF2, gQF1PI;
+  float *da_pi, *dmu, *dls;
+  float *dfeat[2], *g3[2], *g2[2], *g1[2];
+  // act path
+  float *ax, *aa1, *aa2, *aa3, *afeat, *a_eps, *a_out;
+  HeadAct ahPI;
+  // encoder path
+  float *enc_w[8];
+  bool enc_loaded = false;
+  float *ex_in, *ec1, *ec2, *ec3, *eout;
+
+  std::vector<Upload> uploads;
+  std::vector<Launch*> launches;
+  std::vector<ReduceDesc> reduces;
+  ReduceDesc* d_reduces = nullptr;
+
+  std::vector<Op> ops_rng, ops_grads, ops_apply, ops_act, ops_enc;
+  float grad_scale = 1.f;   // read by the apply op
+
+  // graphs
+  hipGraphExec_t graph_rng = nullptr, graph_explicit = nullptr;
+  bool use_graph = true;
+
+  // profiling
+  bool prof = false;
+  std::map<std::string, ProfAcc> prof_acc;
+  std::vector<hipEvent_t> ev;
+
+  std::map<std::string, std::pair<const float*, int64_t>> dbg;
+
+  ~grl_ctx() {
+    for (auto* l : launches) delete l;
+    for (auto e : ev) hipEventDestroy(e);
+    if (graph_rng) hipGraphExecDestroy(graph_rng);
+    if (graph_explicit) hipGraphExecDestroy(graph_explicit);
+  }
+
+  // ---------------------------------------------------------------- helpers
+  template <class T>
+  T* upload_vec(Arena& a, const std::vector<T>& v) {
+    T* d = (T*)a.take(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!dry && !v.empty()) {
+      Upload u;
+      u.dst = d;
+      u.bytes.resize(v.size() * sizeof(T));
+      memcpy(u.bytes.data(), v.data(), u.bytes.size());
+      uploads.push_back(std::move(u));
+    }
+    return d;
+  }
+
+  int64_t add_var(const std::string& name, std::initializer_list<int64_t> shape, bool trainable) {
+    Var v;
+    v.name = name;
+    v.ndim = (int)shape.size();
+    v.numel = 1;
+    int k = 0;
+    for (auto s : shape) {
+      v.shape[k++] = s;
+      v.numel *= s;
+    }
+    for (; k < 4; ++k) v.shape[k] = 1;
+    v.off = n_params;
+    v.trainable = trainable;
+    n_params += rup(v.numel, 4);   // keep every tensor 16-byte aligned
+    vars.push_back(v);
+    return v.off;
+  }
+
+  void add_extractor(const std::string& scope, ExtractorP& e, bool trainable) {
+    if (!cnn) return;
+    const bool aug = cfg.extractor == GRL_EXTRACTOR_AUGMENTED;
+    const char* n[4] = {aug ? "cnn1" : "c1", aug ? "cnn2" : "c2", aug ? "cnn3" : "c3",
+                        aug ? "cnn_fc1" : "fc1"};
+    const int64_t cs[3][4] = {{8, 8, C_img, 32}, {4, 4, 32, 64}, {3, 3, 64, 64}};
+    for (int l = 0; l < 3; ++l) {
+      e.w[l] = add_var(scope + "/" + n[l] + "/w:0", {cs[l][0], cs[l][1], cs[l][2], cs[l][3]}, trainable);
+      e.b[l] = add_var(scope + "/" + n[l] + "/b:0", {1, cs[l][3], 1, 1}, trainable);
+    }
+    e.fw = add_var(scope + "/" + n[3] + "/w:0", {1024, 512}, trainable);
+    e.fb = add_var(scope + "/" + n[3] + "/b:0", {512}, trainable);
+  }
+
+  void add_mlp(const std::string& scope, MlpP& m, int in_dim, std::vector<std::string> outs, int out_dim,
+               bool trainable) {
+    m.in_dim = in_dim;
+    int d = in_dim;
+    for (int l = 0; l < L; ++l) {
+      m.w[l] = add_var(scope + "/fc" + std::to_string(l) + "/kernel:0", {d, hid[l]}, trainable);
+      m.b[l] = add_var(scope + "/fc" + std::to_string(l) + "/bias:0", {hid[l]}, trainable);
+      d = hid[l];
+    }
+    m.n_out = (int)outs.size();
+    m.out_dim = out_dim;
+    for (int k = 0; k < m.n_out; ++k) {
+      m.ow[k] = add_var(scope + "/" + outs[k] + "/kernel:0", {d, out_dim}, trainable);
+      m.ob[k] = add_var(scope + "/" + outs[k] + "/bias:0", {out_dim}, trainable);
+    }
+  }
+
+  void build_layout() {   // TF creation order == order of the shipped zips
+    add_extractor("model/pi", ex[0], true);
+    add_mlp("model/pi", m_pi, F, {"dense", "dense_1"}, A, true);
+    vf_off = n_params;
+    add_extractor("model/values_fn", ex[1], true);
+    add_mlp("model/values_fn/vf", m_vf, F, {"vf"}, 1, true);
+    n_polyak = n_params - vf_off;   // extractor + vf: what target_update_op averages (A.4)
+    add_mlp("model/values_fn/qf1", m_qf1, F + A, {"qf1"}, 1, true);
+    add_mlp("model/values_fn/qf2", m_qf2, F + A, {"qf2"}, 1, true);
+    ent_off = add_var("model/log_ent_coef:0", {}, true);
+    n_train = n_params;
+    tgt_off = n_params;
+    add_extractor("target/values_fn", ex[2], false);
+    add_mlp("target/values_fn/vf", m_tgt, F, {"vf"}, 1, false);
+  }
+
+  // ---------------------------------------------------------------- conv tables
+  ConvFwdTabs conv_fwd_tabs(const ConvGeom& g, int Bn) {
+    ConvFwdTabs t;
+    t.M = Bn * g.OH * g.OW;
+    const int K = g.K();
+    std::vector<int32_t> ti(t.M), tr(K + 1, 0);
+    std::vector<uint64_t> vm(t.M, ~0ull);
+    std::vector<uint8_t> tp(K + 1, 0);
+    for (int b = 0; b < Bn; ++b)
+      for (int oh = 0; oh < g.OH; ++oh)
+        for (int ow = 0; ow < g.OW; ++ow) {
+          const int m = (b * g.OH + oh) * g.OW + ow;
+          const int ih0 = oh * g.S - g.pad, iw0 = ow * g.S - g.pad;
+          ti[m] = ((b * g.H + ih0) * g.W + iw0) * g.C;
+          uint64_t bits = 0;
+          for (int kh = 0; kh < g.KH; ++kh)
+            for (int kw = 0; kw < g.KW; ++kw)
+              if (ih0 + kh >= 0 && ih0 + kh < g.H && iw0 + kw >= 0 && iw0 + kw < g.W)
+                bits |= 1ull << (kh * g.KW + kw);
+          vm[m] = bits;
+        }
+    for (int kh = 0; kh < g.KH; ++kh)
+      for (int kw = 0; kw < g.KW; ++kw)
+        for (int c = 0; c < g.C; ++c) {
+          const int r = (kh * g.KW + kw) * g.C + c;
+          tr[r] = (kh * g.W + kw) * g.C + c;
+          tp[r] = (uint8_t)(kh * g.KW + kw);
+        }
+    t.tab_i = upload_vec(wk, ti);
+    t.tab_r = upload_vec(wk, tr);
+    bool need_mask = false;   // TF 'SAME' padding may be one-sided (lo = 0, hi = 1)
+    const uint64_t full = (g.KH * g.KW >= 64) ? ~0ull : ((1ull << (g.KH * g.KW)) - 1);
+    for (auto b : vm) need_mask = need_mask || (b != full);
+    if (need_mask) {
+      t.vmask = upload_vec(wk, vm);
+      t.tap = upload_vec(wk, tp);
+    }
+    return t;
+  }
+
+  // transposed gather of a strided conv, decomposed by input-position parity:
+  // dX[b, S*i'+ph, S*j'+pw, cin] = sum_{jj,ll,co} dY[b, i'-jj, j'-ll, co] * W[ph+S*jj, pw+S*ll, cin, co]
+  std::vector<ConvBwdClass> conv_bwd_tabs(const ConvGeom& g, int Bn) {
+    std::vector<ConvBwdClass> out;
+    const int IHc = (g.H + g.S - 1) / g.S, IWc = (g.W + g.S - 1) / g.S;
+    const int TJ = (g.KH + g.S - 1) / g.S, TL = (g.KW + g.S - 1) / g.S;
+    for (int ph = 0; ph < g.S; ++ph)
+      for (int pw = 0; pw < g.S; ++pw) {
+        ConvBwdClass c;
+        c.M = Bn * IHc * IWc;
+        c.K = TJ * TL * g.Cout;
+        std::vector<int32_t> ti(c.M), tr(c.K), qt(c.K), ct(c.M);
+        std::vector<uint64_t> vm(c.M);
+        std::vector<uint8_t> tp(c.K);
+        for (int b = 0; b < Bn; ++b)
+          for (int i = 0; i < IHc; ++i)
+            for (int j = 0; j < IWc; ++j) {
+              const int m = (b * IHc + i) * IWc + j;
+              ti[m] = ((b * g.OH + i) * g.OW + j) * g.Cout;
+              uint64_t bits = 0;
+              for (int jj = 0; jj < TJ; ++jj)
+                for (int ll = 0; ll < TL; ++ll) {
+                  const int oh = i - jj, ow = j - ll;
+                  const int kh = ph + g.S * jj, kw = pw + g.S * ll;
+                  if (oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW && kh < g.KH && kw < g.KW)
+                    bits |= 1ull << (jj * TL + ll);
+                }
+              vm[m] = bits;
+              const int ih = g.S * i + ph, iw = g.S * j + pw;
+              ct[m] = (ih < g.H && iw < g.W) ? ((b * g.H + ih) * g.W + iw) * g.C : -1;
+            }
+        for (int jj = 0; jj < TJ; ++jj)
+          for (int ll = 0; ll < TL; ++ll)
+            for (int co = 0; co < g.Cout; ++co) {
+              const int r = (jj * TL + ll) * g.Cout + co;
+              tr[r] = -(jj * g.OW + ll) * g.Cout + co;
+              tp[r] = (uint8_t)(jj * TL + ll);
+              const int kh = std::min(ph + g.S * jj, g.KH - 1), kw = std::min(pw + g.S * ll, g.KW - 1);
+              qt[r] = ((kh * g.KW + kw) * g.C) * g.Cout + co;
+            }
+        c.tab_i = upload_vec(wk, ti);
+        c.tab_r = upload_vec(wk, tr);
+        c.q_tab_r = upload_vec(wk, qt);
+        c.c_tab_i = upload_vec(wk, ct);
+        c.vmask = upload_vec(wk, vm);
+        c.tap = upload_vec(wk, tp);
+        out.push_back(c);
+      }
+    return out;
+  }
+
+  // ---------------------------------------------------------------- problem builders
+  static IgemmProb blank() {
+    IgemmProb p;
+    memset(&p, 0, sizeof(p));
+    p.p_ones_i = -1;
+    p.split = 1;
+    return p;
+  }
+  static void set_split(IgemmProb& p, int split_target) {
+    const int tiles_r = (p.K + 31) / 32;
+    int s = std::max(1, std::min(split_target, tiles_r));
+    const int per = (tiles_r + s - 1) / s;
+    p.k_chunk = per * 32;
+    p.split = (p.K + p.k_chunk - 1) / p.k_chunk;
+    p.slab_stride = (int64_t)p.M * p.N;
+  }
+  static void single_part(IgemmProb& p) { p.p_k0 = p.p_k1 = INT_MAX; }
+
+  static IgemmProb dense_fwd(const float* x0, int ld0, int K0, const float* x1, int ld1, int K1, int M,
+                             const float* w, int N, const float* bias, float* y, int ldy, int act) {
+    IgemmProb p = blank();
+    p.M = M; p.N = N; p.K = K0 + K1;
+    p.p_base[0] = x0; p.p_ld_i[0] = ld0; p.p_ld_r[0] = 1;
+    p.p_base[1] = x1; p.p_ld_i[1] = ld1; p.p_ld_r[1] = 1;
+    p.p_k0 = K1 > 0 ? K0 : INT_MAX; p.p_k1 = INT_MAX;
+    p.q_base[0] = w; p.q_ld_r[0] = N; p.q_ld_j[0] = 1;
+    p.q_base[1] = w + (int64_t)K0 * N; p.q_ld_r[1] = N; p.q_ld_j[1] = 1;
+    p.c = y; p.ldc = ldy; p.bias = bias; p.act = act;
+    set_split(p, 1);
+    return p;
+  }
+
+  struct BwdPart {
+    const float* g; int ldg; int Nl; const float* w;
+  };
+  // dx[m, col0 + j] = sum_parts sum_n g_p[m, n] * W_p[col0 + j, n]   (optionally masked by mask > 0)
+  static IgemmProb dense_bwd(const std::vector<BwdPart>& parts, int M, int col0, int ncols, float* dx,
+                             int lddx, const float* mask) {
+    IgemmProb p = blank();
+    p.M = M; p.N = ncols; p.K = 0;
+    int bounds[3] = {INT_MAX, INT_MAX, INT_MAX};
+    for (size_t k = 0; k < parts.size(); ++k) {
+      p.p_base[k] = parts[k].g; p.p_ld_i[k] = parts[k].ldg; p.p_ld_r[k] = 1;
+      p.q_base[k] = parts[k].w + (int64_t)col0 * parts[k].Nl; p.q_ld_r[k] = 1; p.q_ld_j[k] = parts[k].Nl;
+      p.K += parts[k].Nl;
+      bounds[k] = p.K;
+    }
+    p.p_k0 = parts.size() > 1 ? bounds[0] : INT_MAX;
+    p.p_k1 = parts.size() > 2 ? bounds[1] : INT_MAX;
+    p.c = dx; p.ldc = lddx; p.relu_mask = mask;
+    set_split(p, 1);
+    return p;
+  }
+
+  // slab[(Kin + ones), N] = [x^T ; 1^T] * g     (weight + bias gradient of a dense layer)
+  static IgemmProb dense_wgrad(const float* x, int ldx, int Kin, bool ones, const float* g, int ldg, int N,
+                               int rows, float* slab, int split_target) {
+    IgemmProb p = blank();
+    p.M = Kin + (ones ? 1 : 0); p.N = N; p.K = rows;
+    p.p_base[0] = x; p.p_ld_i[0] = 1; p.p_ld_r[0] = ldx; single_part(p);
+    p.p_ones_i = ones ? Kin : -1;
+    p.q_base[0] = g; p.q_ld_r[0] = ldg; p.q_ld_j[0] = 1;
+    p.c = slab; p.ldc = N;
+    set_split(p, split_target);
+    return p;
+  }
+
+  static IgemmProb conv_fwd(const float* x, const ConvFwdTabs& t, const ConvGeom& g, const float* w,
+                            const float* bias, float* y, int act, float alpha) {
+    IgemmProb p = blank();
+    p.M = t.M; p.N = g.Cout; p.K = g.K();
+    p.p_base[0] = x; p.p_tab_i = t.tab_i; p.p_tab_r = t.tab_r; p.p_vmask_i = t.vmask; p.p_tap_r = t.tap;
+    single_part(p);
+    p.q_base[0] = w; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
+    p.c = y; p.ldc = g.Cout; p.bias = bias; p.act = act; p.act_alpha = alpha;
+    set_split(p, 1);
+    return p;
+  }
+
+  static IgemmProb conv_bwd(const float* gy, const ConvBwdClass& c, const ConvGeom& g, const float* w,
+                            float* dx, const float* mask) {
+    IgemmProb p = blank();
+    p.M = c.M; p.N = g.C; p.K = c.K;
+    p.p_base[0] = gy; p.p_tab_i = c.tab_i; p.p_tab_r = c.tab_r; p.p_vmask_i = c.vmask; p.p_tap_r = c.tap;
+    single_part(p);
+    p.q_base[0] = w; p.q_tab_r = c.q_tab_r; p.q_ld_j[0] = g.Cout;
+    p.c = dx; p.c_tab_i = c.c_tab_i; p.relu_mask = mask;
+    set_split(p, 1);
+    return p;
+  }
+
+  static IgemmProb conv_wgrad(const float* x, const ConvFwdTabs& t, const ConvGeom& g, const float* gy,
+                              float* slab, int split_target) {
+    IgemmProb p = blank();
+    p.M = g.K() + 1; p.N = g.Cout; p.K = t.M;
+    p.p_base[0] = x; p.p_tab_i = t.tab_r; p.p_tab_r = t.tab_i; single_part(p);
+    p.p_ones_i = g.K();
+    p.q_base[0] = gy; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
+    p.c = slab; p.ldc = g.Cout;
+    set_split(p, split_target);
+    return p;
+  }
+
+  // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op
+  void add_launch(std::vector<Op>& ops, const std::string& tag, int variant, std::vector<IgemmProb> probs) {
+    if (probs.empty()) return;
+    Launch* l = new Launch();
+    l->variant = variant;
+    l->probs = std::move(probs);
+    std::vector<int4> tiles;
+    std::vector<int> order(l->probs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return std::min(l->probs[a].K, l->probs[a].k_chunk) > std::min(l->probs[b].K, l->probs[b].k_chunk);
+    });
+    double flops = 0;
+    for (int pi : order) {
+      const IgemmProb& p = l->probs[pi];
+      flops += 2.0 * p.M * p.N * p.K;
+      for (int s = 0; s < p.split; ++s)
+        for (int ti = 0; ti < (p.M + 63) / 64; ++ti)
+          for (int tj = 0; tj < (p.N + 63) / 64; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
+    }
+    l->n_tiles = (int)tiles.size();
+    l->d_probs = upload_vec(wk, l->probs);
+    l->d_tiles = upload_vec(wk, tiles);
+    launches.push_back(l);
+    Op op;
+    op.tag = tag;
+    op.flops = flops;
+    op.run = [l](hipStream_t s) {
+      dim3 grid(l->n_tiles), block(256);
+      if (l->variant == 0)
+        hipLaunchKernelGGL((igemm_kernel<true, true>), grid, block, 0, s, l->d_probs, l->d_tiles);
+      else if (l->variant == 1)
+        hipLaunchKernelGGL((igemm_kernel<true, false>), grid, block, 0, s, l->d_probs, l->d_tiles);
+      else
+        hipLaunchKernelGGL((igemm_kernel<false, true>), grid, block, 0, s, l->d_probs, l->d_tiles);
+    };
+    ops.push_back(std::move(op));
+  }
+
+  // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
+  void add_wgrad(std::vector<IgemmProb>& probs, IgemmProb p, int64_t w_off, int64_t w_rows_off, int rows,
+                 int64_t b_off) {
+    probs.push_back(p);
+    ReduceDesc r;
+    r.src = p.c; r.splits = p.split; r.slab_stride = p.slab_stride;
+    r.dst = grads + w_off + w_rows_off * p.N; r.n = rows * p.N;
+    reduces.push_back(r);
+    if (b_off >= 0) {
+      ReduceDesc rb = r;
+      rb.src = p.c + (int64_t)rows * p.N; rb.dst = grads + b_off; rb.n = p.N;
+      reduces.push_back(rb);
+    }
+  }
+
+  void alloc_head(HeadAct& h, int rows, int n_out, int out_dim) {
+    for (int l = 0; l < L; ++l) h.z[l] = wk.f32((int64_t)rows * hid[l]);
+    for (int k = 0; k < n_out; ++k) h.out[k] = wk.f32((int64_t)rows * out_dim);
+  }
+  void alloc_hgrad(HeadGrad& g, int rows) {
+    for (int l = 0; l < L; ++l) g.g[l] = wk.f32((int64_t)rows * hid[l]);
+  }
+
+  // forward problems of one MLP head (layer l or the output layer)
+  IgemmProb head_layer(const MlpP& m, const float* P, const HeadAct& h, int l, const float* x0, int ld0,
+                       int K0, const float* x1, int ld1, int K1, int rows) {
+    if (l == 0)
+      return dense_fwd(x0, ld0, K0, x1, ld1, K1, rows, P + m.w[0], hid[0], P + m.b[0], h.z[0], hid[0], ACT_RELU);
+    return dense_fwd(h.z[l - 1], hid[l - 1], hid[l - 1], nullptr, 0, 0, rows, P + m.w[l], hid[l], P + m.b[l],
+                     h.z[l], hid[l], ACT_RELU);
+  }
+  IgemmProb head_out(const MlpP& m, const float* P, const HeadAct& h, int k, int rows) {
+    return dense_fwd(h.z[L - 1], hid[L - 1], hid[L - 1], nullptr, 0, 0, rows, P + m.ow[k], m.out_dim,
+                     P + m.ob[k], h.out[k], m.out_dim, ACT_NONE);
+  }
+
+  int plan();          // lays everything out in the arenas and builds the launch plans
+  int run_ops(std::vector<Op>& ops);
+  int capture(std::vector<std::vector<Op>*> seq, hipGraphExec_t* out);
+};
+
+static ConvGeom cnn_geom(int l, int C_img) {
+  ConvGeom g;
+  if (l == 0) g = {64, 64, C_img, 8, 8, 4, 0, 15, 15, 32};
+  else if (l == 1) g = {15, 15, 32, 4, 4, 2, 0, 6, 6, 64};
+  else g = {6, 6, 64, 3, 3, 1, 0, 4, 4, 64};
+  return g;
+}
+
+// --------------------------------------------------------------------------------------------------
+int grl_ctx::plan() {
+  const grl_config& c = cfg;
+  cnn = c.extractor != GRL_EXTRACTOR_MLP;
+  A = c.act_dim; L = c.n_layers; B = c.batch_size; NA = std::max(1, c.act_batch);
+  for (int l = 0; l < L; ++l) hid[l] = c.layers[l];
+  hw = c.img_hw;
+  if (cnn) {
+    const int nd = c.extractor == GRL_EXTRACTOR_AUGMENTED ? c.n_direct : 0;
+    C_img = c.obs_channels - (nd > 0 ? 1 : 0);
+    img_elems = hw * hw * C_img;
+    F = 512 + nd; Fc = 512;
+  } else {
+    C_img = 0; img_elems = c.obs_dim; F = c.obs_dim; Fc = 0;
+  }
+  const int nd = cnn ? F - 512 : 0;
+  ldf = (int)rup(F, 4);
+  build_layout();
+
+  // ---------------- state arena
+  params = st.f32(n_params);
+  adam_m = st.f32(n_train);
+  adam_v = st.f32(n_train);
+  sc = (DevScalars*)st.take(sizeof(DevScalars));
+  s_mean = (double*)st.take((size_t)img_elems * 8);
+  s_std = (double*)st.take((size_t)img_elems * 8);
+  s_dmean = (double*)st.take((size_t)std::max(nd, 1) * 8);
+  s_dstd = (double*)st.take((size_t)std::max(nd, 1) * 8);
+  s_ret = (double*)st.take(8);
+  grads = gr.f32(n_train);
+
+  // ---------------- replay arena
+  const int64_t cap = c.replay_capacity;
+  rp_obs = rp.f32(cap * img_elems);
+  rp_next = rp.f32(cap * img_elems);
+  rp_dobs = rp.f32(cap * std::max(nd, 1));
+  rp_dnext = rp.f32(cap * std::max(nd, 1));
+  rp_act = rp.f32(cap * A);
+  rp_rew = rp.f32(cap);
+  rp_done = rp.f32(cap);
+
+  // ---------------- staging (host-facing calls)
+  const int64_t obs_elems = cnn ? (int64_t)hw * hw * c.obs_channels : c.obs_dim;
+  stg_n = std::max(NA, 64);
+  stg_obs = wk.f32(stg_n * obs_elems);
+  stg_next = wk.f32(stg_n * obs_elems);
+  stg_act = wk.f32((int64_t)stg_n * A);
+  stg_rew = wk.f32(stg_n);
+  stg_done = wk.f32(stg_n);
+
+  // ---------------- training workspace
+  idx_buf = (int64_t*)wk.take((size_t)B * 8);
+  eps_buf = wk.f32((int64_t)B * A);
+  for (int n = 0; n < 3; ++n) feat[n] = wk.f32((int64_t)B * ldf);
+  if (cnn) {
+    x_obs = wk.f32((int64_t)B * img_elems);
+    x_next = wk.f32((int64_t)B * img_elems);
+    for (int n = 0; n < 3; ++n) {
+      a1[n] = wk.f32((int64_t)B * 225 * 32);
+      a2[n] = wk.f32((int64_t)B * 36 * 64);
+      a3[n] = wk.f32((int64_t)B * 16 * 64);
+    }
+  }
+  act = wk.f32((int64_t)B * A); rew = wk.f32(B); done = wk.f32(B);
+  alloc_head(hPI, B, 2, A); alloc_head(hVF, B, 1, 1); alloc_head(hQF1, B, 1, 1); alloc_head(hQF2, B, 1, 1);
+  alloc_head(hTGT, B, 1, 1); alloc_head(hQF1PI, B, 1, 1); alloc_head(hQF2PI, B, 1, 1);
+  pi_a = wk.f32((int64_t)B * A); logp = wk.f32(B); ent = wk.f32(B);
+  d_qf1 = wk.f32(B); d_qf2 = wk.f32(B); d_v = wk.f32(B); d_qf1pi = wk.f32(B);
+  alloc_hgrad(gPI, B); alloc_hgrad(gVF, B); alloc_hgrad(gQF1, B); alloc_hgrad(gQF2, B); alloc_hgrad(gQF1PI, B);
+  da_pi = wk.f32((int64_t)B * A); dmu = wk.f32((int64_t)B * A); dls = wk.f32((int64_t)B * A);
+  if (cnn)
+    for (int n = 0; n < 2; ++n) {
+      dfeat[n] = wk.f32((int64_t)B * ldf);
+      g3[n] = wk.f32((int64_t)B * 16 * 64);
+      g2[n] = wk.f32((int64_t)B * 36 * 64);
+      g1[n] = wk.f32((int64_t)B * 225 * 32);
+    }
+
+  const float* P = params;
+  const float* T = params;   // target block uses absolute offsets too
+
+  // =============================================================== RNG ops
+  {
+    Op op; op.tag = "rng";
+    RngArgs ra{sc, c.seed, B, A, idx_buf, eps_buf};
+    op.run = [ra](hipStream_t s) {
+      hipLaunchKernelGGL(rng_kernel, dim3((ra.B + 255) / 256), dim3(256), 0, s, ra);
+      hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, s, ra.sc);
+    };
+    ops_rng.push_back(op);
+  }
+
+  // =============================================================== forward
+  {
+    GatherArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.idx = idx_buf; ga.B = B; ga.img_elems = img_elems; ga.n_direct = nd; ga.act_dim = A;
+    ga.rp_obs = rp_obs; ga.rp_next = rp_next; ga.rp_dobs = rp_dobs; ga.rp_dnext = rp_dnext;
+    ga.rp_act = rp_act; ga.rp_rew = rp_rew; ga.rp_done = rp_done;
+    ga.mean = s_mean; ga.stdv = s_std; ga.dmean = s_dmean; ga.dstd = s_dstd; ga.ret_std = s_ret;
+    ga.normalize = c.normalize; ga.clip_obs = c.clip_obs; ga.clip_rew = c.clip_reward;
+    ga.scale_div = cnn ? 255.f : 1.f;
+    if (cnn) {
+      ga.x_obs = x_obs; ga.x_obs2 = nullptr; ga.x_next = x_next; ga.ldx = img_elems;
+      ga.d_obs0 = feat[0] + 512; ga.d_obs1 = feat[1] + 512; ga.d_next = feat[2] + 512; ga.ldd = ldf;
+    } else {
+      ga.x_obs = feat[0]; ga.x_obs2 = feat[1]; ga.x_next = feat[2]; ga.ldx = ldf;
+      ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;   // n_direct == 0: never written
+    }
+    ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
+    Op op; op.tag = "gather_norm";
+    op.bytes = 2.0 * B * ((double)img_elems * 8 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
+    op.run = [ga](hipStream_t s) {
+      hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
+    };
+    ops_grads.push_back(op);
+  }
+
+  ConvGeom cg[3];
+  ConvFwdTabs ft[3];
+  if (cnn) {
+    for (int l = 0; l < 3; ++l) { cg[l] = cnn_geom(l, C_img); ft[l] = conv_fwd_tabs(cg[l], B); }
+    const float* xin[3] = {x_obs, x_obs, x_next};
+    const char* tags[3] = {"conv1_fwd", "conv2_fwd", "conv3_fwd"};
+    for (int l = 0; l < 3; ++l) {
+      std::vector<IgemmProb> pr;
+      for (int n = 0; n < 3; ++n) {
+        const float* in = l == 0 ? xin[n] : (l == 1 ? a1[n] : a2[n]);
+        float* out = l == 0 ? a1[n] : (l == 1 ? a2[n] : a3[n]);
+        pr.push_back(conv_fwd(in, ft[l], cg[l], P + ex[n].w[l], P + ex[n].b[l], out, ACT_RELU, 0.f));
+      }
+      add_launch(ops_grads, tags[l], 0, pr);
+    }
+    std::vector<IgemmProb> pr;
+    for (int n = 0; n < 3; ++n)
+      pr.push_back(dense_fwd(a3[n], 1024, 1024, nullptr, 0, 0, B, P + ex[n].fw, 512, P + ex[n].fb, feat[n], ldf,
+                             ACT_RELU));
+    add_launch(ops_grads, "fc_fwd", 0, pr);
+  }
+  (void)T;
+
+  // heads forward: pi, vf, qf1, qf2 (data action), target vf
+  for (int l = 0; l < L; ++l) {
+    std::vector<IgemmProb> pr;
+    pr.push_back(head_layer(m_pi, P, hPI, l, feat[0], ldf, F, nullptr, 0, 0, B));
+    pr.push_back(head_layer(m_vf, P, hVF, l, feat[1], ldf, F, nullptr, 0, 0, B));
+    pr.push_back(head_layer(m_qf1, P, hQF1, l, feat[1], ldf, F, act, A, A, B));
+    pr.push_back(head_layer(m_qf2, P, hQF2, l, feat[1], ldf, F, act, A, A, B));
+    pr.push_back(head_layer(m_tgt, P, hTGT, l, feat[2], ldf, F, nullptr, 0, 0, B));
+    add_launch(ops_grads, "heads_fwd", 0, pr);
+  }
+  {
+    std::vector<IgemmProb> pr;
+    pr.push_back(head_out(m_pi, P, hPI, 0, B));
+    pr.push_back(head_out(m_pi, P, hPI, 1, B));
+    pr.push_back(head_out(m_vf, P, hVF, 0, B));
+    pr.push_back(head_out(m_qf1, P, hQF1, 0, B));
+    pr.push_back(head_out(m_qf2, P, hQF2, 0, B));
+    pr.push_back(head_out(m_tgt, P, hTGT, 0, B));
+    add_launch(ops_grads, "heads_fwd", 0, pr);
+  }
+  {
+    SampleArgs sa{hPI.out[0], hPI.out[1], eps_buf, B, A, pi_a, nullptr, logp, ent};
+    Op op; op.tag = "sample";
+    op.run = [sa](hipStream_t s) {
+      hipLaunchKernelGGL(sample_kernel, dim3((sa.B + 255) / 256), dim3(256), 0, s, sa);
+    };
+    ops_grads.push_back(op);
+  }
+  for (int l = 0; l < L; ++l) {
+    std::vector<IgemmProb> pr;
+    pr.push_back(head_layer(m_qf1, P, hQF1PI, l, feat[1], ldf, F, pi_a, A, A, B));
+    pr.push_back(head_layer(m_qf2, P, hQF2PI, l, feat[1], ldf, F, pi_a, A, A, B));
+    add_launch(ops_grads, "heads_fwd", 0, pr);
+  }
+  {
+    std::vector<IgemmProb> pr;
+    pr.push_back(head_out(m_qf1, P, hQF1PI, 0, B));
+    pr.push_back(head_out(m_qf2, P, hQF2PI, 0, B));
+    add_launch(ops_grads, "heads_fwd", 0, pr);
+  }
+  {
+    LossArgs la;
+    la.B = B; la.gamma = c.gamma; la.target_entropy = c.target_entropy; la.lr = c.lr;
+    la.rew = rew; la.done = done; la.v_tgt = hTGT.out[0]; la.qf1 = hQF1.out[0]; la.qf2 = hQF2.out[0];
+    la.v = hVF.out[0]; la.qf1_pi = hQF1PI.out[0]; la.qf2_pi = hQF2PI.out[0]; la.logp = logp; la.entropy = ent;
+    la.log_ent_coef = params + ent_off;
+    la.d_qf1 = d_qf1; la.d_qf2 = d_qf2; la.d_v = d_v; la.d_qf1_pi = d_qf1pi;
+    la.g_log_ent_coef = grads + ent_off; la.sc = sc;
+    Op op; op.tag = "sac_loss";
+    op.run = [la](hipStream_t s) { hipLaunchKernelGGL(sac_loss_kernel, dim3(1), dim3(256), 0, s, la); };
+    ops_grads.push_back(op);
+  }
+
+  // =============================================================== backward through the heads
+  // g[l] = gradient w.r.t. the pre-activation of layer l (ReLU mask already applied)
+  {
+    std::vector<IgemmProb> pr;   // output layer -> g[L-1]
+    pr.push_back(dense_bwd({{d_v, 1, 1, P + m_vf.ow[0]}}, B, 0, hid[L - 1], gVF.g[L - 1], hid[L - 1], hVF.z[L - 1]));
+    pr.push_back(dense_bwd({{d_qf1, 1, 1, P + m_qf1.ow[0]}}, B, 0, hid[L - 1], gQF1.g[L - 1], hid[L - 1], hQF1.z[L - 1]));
+    pr.push_back(dense_bwd({{d_qf2, 1, 1, P + m_qf2.ow[0]}}, B, 0, hid[L - 1], gQF2.g[L - 1], hid[L - 1], hQF2.z[L - 1]));
+    pr.push_back(dense_bwd({{d_qf1pi, 1, 1, P + m_qf1.ow[0]}}, B, 0, hid[L - 1], gQF1PI.g[L - 1], hid[L - 1], hQF1PI.z[L - 1]));
+    add_launch(ops_grads, "heads_bwd", 1, pr);
+  }
+  for (int l = L - 1; l >= 1; --l) {
+    std::vector<IgemmProb> pr;
+    pr.push_back(dense_bwd({{gVF.g[l], hid[l], hid[l], P + m_vf.w[l]}}, B, 0, hid[l - 1], gVF.g[l - 1], hid[l - 1], hVF.z[l - 1]));
+    pr.push_back(dense_bwd({{gQF1.g[l], hid[l], hid[l], P + m_qf1.w[l]}}, B, 0, hid[l - 1], gQF1.g[l - 1], hid[l - 1], hQF1.z[l - 1]));
+    pr.push_back(dense_bwd({{gQF2.g[l], hid[l], hid[l], P + m_qf2.w[l]}}, B, 0, hid[l - 1], gQF2.g[l - 1], hid[l - 1], hQF2.z[l - 1]));
+    pr.push_back(dense_bwd({{gQF1PI.g[l], hid[l], hid[l], P + m_qf1.w[l]}}, B, 0, hid[l - 1], gQF1PI.g[l - 1], hid[l - 1], hQF1PI.z[l - 1]));
+    add_launch(ops_grads, "heads_bwd", 1, pr);
+  }
+  {
+    std::vector<IgemmProb> pr;   // first layer: d a_pi (policy path) and d feat (critic CNN path)
+    pr.push_back(dense_bwd({{gQF1PI.g[0], hid[0], hid[0], P + m_qf1.w[0]}}, B, F, A, da_pi, A, nullptr));
+    if (cnn)
+      pr.push_back(dense_bwd({{gVF.g[0], hid[0], hid[0], P + m_vf.w[0]},
+                              {gQF1.g[0], hid[0], hid[0], P + m_qf1.w[0]},
+                              {gQF2.g[0], hid[0], hid[0], P + m_qf2.w[0]}},
+                             B, 0, Fc, dfeat[1], ldf, feat[1]));
+    add_launch(ops_grads, "heads_bwd", 1, pr);
+  }
+  {
+    SampleBwdArgs sb{hPI.out[0], hPI.out[1], eps_buf, pi_a, da_pi, A, params + ent_off, B, A, dmu, dls};
+    Op op; op.tag = "sample_bwd";
+    op.run = [sb](hipStream_t s) {
+      hipLaunchKernelGGL(sample_bwd_kernel, dim3((sb.B + 255) / 256), dim3(256), 0, s, sb);
+    };
+    ops_grads.push_back(op);
+  }
+  {
+    std::vector<IgemmProb> pr;
+    pr.push_back(dense_bwd({{dmu, A, A, P + m_pi.ow[0]}, {dls, A, A, P + m_pi.ow[1]}}, B, 0, hid[L - 1],
+                           gPI.g[L - 1], hid[L - 1], hPI.z[L - 1]));
+    add_launch(ops_grads, "heads_bwd", 1, pr);
+  }
+  for (int l = L - 1; l >= 1; --l) {
+    std::vector<IgemmProb> pr;
+    pr.push_back(dense_bwd({{gPI.g[l], hid[l], hid[l], P + m_pi.w[l]}}, B, 0, hid[l - 1], gPI.g[l - 1], hid[l - 1], hPI.z[l - 1]));
+    add_launch(ops_grads, "heads_bwd", 1, pr);
+  }
+  if (cnn) {
+    std::vector<IgemmProb> pr;
+    pr.push_back(dense_bwd({{gPI.g[0], hid[0], hid[0], P + m_pi.w[0]}}, B, 0, Fc, dfeat[0], ldf, feat[0]));
+    add_launch(ops_grads, "heads_bwd", 1, pr);
+  }
+
+  // =============================================================== backward through the two CNNs
+  std::vector<IgemmProb> wg;   // every weight gradient, one launch at the end
+  if (cnn) {
+    std::vector<ConvBwdClass> bc3 = conv_bwd_tabs(cg[2], B), bc2 = conv_bwd_tabs(cg[1], B);
+    {
+      std::vector<IgemmProb> pr;
+      for (int n = 0; n < 2; ++n)
+        pr.push_back(dense_bwd({{dfeat[n], ldf, 512, P + ex[n].fw}}, B, 0, 1024, g3[n], 1024, a3[n]));
+      add_launch(ops_grads, "fc_bwd", 1, pr);
+    }
+    {
+      std::vector<IgemmProb> pr;
+      for (int n = 0; n < 2; ++n)
+        for (auto& cl : bc3) pr.push_back(conv_bwd(g3[n], cl, cg[2], P + ex[n].w[2], g2[n], a2[n]));
+      add_launch(ops_grads, "conv3_bwd", 1, pr);
+    }
+    {
+      std::vector<IgemmProb> pr;
+      for (int n = 0; n < 2; ++n)
+        for (auto& cl : bc2) pr.push_back(conv_bwd(g2[n], cl, cg[1], P + ex[n].w[1], g1[n], a1[n]));
+      add_launch(ops_grads, "conv2_bwd", 1, pr);
+    }
+    // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
+    for (int n = 0; n < 2; ++n) {
+      const float* xin = x_obs;
+      {
+        IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, 96);
+        p.c = wk.f32(p.slab_stride * p.split);
+        add_wgrad(wg, p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
+      }
+      {
+        IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, 16);
+        p.c = wk.f32(p.slab_stride * p.split);
+        add_wgrad(wg, p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
+      }
+      {
+        IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, 8);
+        p.c = wk.f32(p.slab_stride * p.split);
+        add_wgrad(wg, p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
+      }
+      {
+        IgemmProb p = dense_wgrad(a3[n], 1024, 1024, true, dfeat[n], ldf, 512, B, nullptr, 1);
+        p.c = wk.f32(p.slab_stride * p.split);
+        add_wgrad(wg, p, ex[n].fw, 0, 1024, ex[n].fb);
+      }
+    }
+  }
+  // head weight gradients
+  auto head_wgrads = [&](const MlpP& m, const HeadAct& h, const HeadGrad& g, const float* x0, int ld0, int K0,
+                         const float* x1, int ld1, int K1, std::vector<const float*> douts) {
+    for (int l = 0; l < L; ++l) {
+      if (l == 0) {
+        if (K1 > 0) {
+          IgemmProb p0 = dense_wgrad(x0, ld0, K0, false, g.g[0], hid[0], hid[0], B, nullptr, 1);
+          p0.c = wk.f32(p0.slab_stride * p0.split);
+          add_wgrad(wg, p0, m.w[0], 0, K0, -1);
+          IgemmProb p1 = dense_wgrad(x1, ld1, K1, true, g.g[0], hid[0], hid[0], B, nullptr, 1);
+          p1.c = wk.f32(p1.slab_stride * p1.split);
+          add_wgrad(wg, p1, m.w[0], K0, K1, m.b[0]);
+        } else {
+          IgemmProb p0 = dense_wgrad(x0, ld0, K0, true, g.g[0], hid[0], hid[0], B, nullptr, 1);
+          p0.c = wk.f32(p0.slab_stride * p0.split);
+          add_wgrad(wg, p0, m.w[0], 0, K0, m.b[0]);
+        }
+      } else {
+        IgemmProb p = dense_wgrad(h.z[l - 1], hid[l - 1], hid[l - 1], true, g.g[l], hid[l], hid[l], B, nullptr, 1);
+        p.c = wk.f32(p.slab_stride * p.split);
+        add_wgrad(wg, p, m.w[l], 0, hid[l - 1], m.b[l]);
+      }
+    }
+    for (int k = 0; k < m.n_out; ++k) {
+      IgemmProb p = dense_wgrad(h.z[L - 1], hid[L - 1], hid[L - 1], true, douts[k], m.out_dim, m.out_dim, B, nullptr, 1);
+      p.c = wk.f32(p.slab_stride * p.split);
+      add_wgrad(wg, p, m.ow[k], 0, hid[L - 1], m.ob[k]);
+    }
+  };
+  head_wgrads(m_pi, hPI, gPI, feat[0], ldf, F, nullptr, 0, 0, {dmu, dls});
+  head_wgrads(m_vf, hVF, gVF, feat[1], ldf, F, nullptr, 0, 0, {d_v});
+  head_wgrads(m_qf1, hQF1, gQF1, feat[1], ldf, F, act, A, A, {d_qf1});
+  head_wgrads(m_qf2, hQF2, gQF2, feat[1], ldf, F, act, A, A, {d_qf2});
+  add_launch(ops_grads, "wgrad", 2, wg);
+  {
+    d_reduces = upload_vec(wk, reduces);
+    const int nred = (int)reduces.size();
+    int maxn = 1;
+    for (auto& r : reduces) maxn = std::max(maxn, r.n);
+    const int gx = std::min(64, (maxn + 255) / 256);
+    ReduceDesc* dr = d_reduces;
+    Op op; op.tag = "reduce_slabs";
+    op.run = [dr, nred, gx](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, nred), dim3(256), 0, s, dr);
+    };
+    ops_grads.push_back(op);
+  }
+
+  // =============================================================== apply
+  {
+    Op op; op.tag = "adam_polyak";
+    op.bytes = (double)n_train * 4 * 7 + (double)n_polyak * 4 * 2;
+    grl_ctx* self = this;
+    op.run = [self](hipStream_t s) {
+      AdamArgs aa;
+      aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = self->cfg.tau;
+      aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
+      const int blocks = (int)std::min<int64_t>(2048, (self->n_train + 255) / 256);
+      hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, s, aa);
+    };
+    ops_apply.push_back(op);
+  }
+
+  // =============================================================== act path (batch NA, pi net only)
+  {
+    ax = cnn ? wk.f32((int64_t)NA * img_elems) : nullptr;
+    afeat = wk.f32((int64_t)NA * ldf);
+    a_eps = wk.f32((int64_t)NA * A);
+    a_out = wk.f32((int64_t)NA * A);
+    alloc_head(ahPI, NA, 2, A);
+    ActIngestArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.obs = stg_obs; ia.n = NA; ia.hw = hw * hw; ia.c_obs = c.obs_channels; ia.c_img = C_img; ia.n_direct = nd;
+    ia.vec_dim = cnn ? 0 : c.obs_dim; ia.scale_div = cnn ? 255.f : 1.f;
+    ia.x = cnn ? ax : afeat; ia.ldx = cnn ? img_elems : ldf; ia.d = afeat + 512; ia.ldd = ldf;
+    {
+      Op op; op.tag = "act_ingest";
+      const int elems = cnn ? img_elems : c.obs_dim;
+      op.run = [ia, elems](hipStream_t s) {
+        hipLaunchKernelGGL(act_ingest_kernel, dim3((elems + 255) / 256, ia.n), dim3(256), 0, s, ia);
+      };
+      ops_act.push_back(op);
+    }
+    if (cnn) {
+      aa1 = wk.f32((int64_t)NA * 225 * 32); aa2 = wk.f32((int64_t)NA * 36 * 64); aa3 = wk.f32((int64_t)NA * 16 * 64);
+      float* io[4] = {ax, aa1, aa2, aa3};
+      for (int l = 0; l < 3; ++l) {
+        ConvFwdTabs t = conv_fwd_tabs(cg[l], NA);
+        add_launch(ops_act, "act_conv", 0,
+                   {conv_fwd(io[l], t, cg[l], P + ex[0].w[l], P + ex[0].b[l], io[l + 1], ACT_RELU, 0.f)});
+      }
+      add_launch(ops_act, "act_fc", 0,
+                 {dense_fwd(aa3, 1024, 1024, nullptr, 0, 0, NA, P + ex[0].fw, 512, P + ex[0].fb, afeat, ldf, ACT_RELU)});
+    }
+    for (int l = 0; l < L; ++l)
+      add_launch(ops_act, "act_head", 0, {head_layer(m_pi, P, ahPI, l, afeat, ldf, F, nullptr, 0, 0, NA)});
+    add_launch(ops_act, "act_head", 0, {head_out(m_pi, P, ahPI, 0, NA), head_out(m_pi, P, ahPI, 1, NA)});
+  }
+
+  // =============================================================== Keras auto-encoder (A.9), batch NA
+  {
+    const ConvGeom eg[3] = {{64, 64, 1, 7, 7, 2, 2, 32, 32, 32}, {32, 32, 32, 5, 5, 2, 1, 16, 16, 32},
+                            {16, 16, 32, 3, 3, 2, 0, 8, 8, 32}};
+    const int64_t wn[8] = {7 * 7 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 32, 32, 2048 * 100, 100};
+    for (int k = 0; k < 8; ++k) enc_w[k] = wk.f32(wn[k]);
+    ex_in = wk.f32((int64_t)NA * 4096);
+    ec1 = wk.f32((int64_t)NA * 32 * 32 * 32); ec2 = wk.f32((int64_t)NA * 16 * 16 * 32);
+    ec3 = wk.f32((int64_t)NA * 8 * 8 * 32); eout = wk.f32((int64_t)NA * 100);
+    float* io[4] = {ex_in, ec1, ec2, ec3};
+    for (int l = 0; l < 3; ++l) {
+      ConvFwdTabs t = conv_fwd_tabs(eg[l], NA);
+      add_launch(ops_enc, "enc_conv", 0,
+                 {conv_fwd(io[l], t, eg[l], enc_w[2 * l], enc_w[2 * l + 1], io[l + 1], ACT_LEAKY, 0.1f)});
+    }
+    IgemmProb p = dense_fwd(ec3, 2048, 2048, nullptr, 0, 0, NA, enc_w[6], 100, enc_w[7], eout, 100, ACT_LEAKY);
+    p.act_alpha = 0.1f;
+    add_launch(ops_enc, "enc_dense", 0, {p});
+  }
+
+  // debug taps
+  dbg["feat_pi"] = {feat[0], (int64_t)B * ldf};
+  dbg["feat_vf"] = {feat[1], (int64_t)B * ldf};
+  dbg["feat_tgt"] = {feat[2], (int64_t)B * ldf};
+  if (cnn) {
+    dbg["x_obs"] = {x_obs, (int64_t)B * img_elems};
+    dbg["x_next"] = {x_next, (int64_t)B * img_elems};
+    dbg["a1_pi"] = {a1[0], (int64_t)B * 225 * 32};
+    dbg["a2_pi"] = {a2[0], (int64_t)B * 36 * 64};
+    dbg["a3_pi"] = {a3[0], (int64_t)B * 1024};
+    dbg["g1_vf"] = {g1[1], (int64_t)B * 225 * 32};
+    dbg["g2_vf"] = {g2[1], (int64_t)B * 36 * 64};
+    dbg["g3_vf"] = {g3[1], (int64_t)B * 1024};
+    dbg["dfeat_pi"] = {dfeat[0], (int64_t)B * ldf};
+    dbg["dfeat_vf"] = {dfeat[1], (int64_t)B * ldf};
+  }
+  dbg["mu"] = {hPI.out[0], (int64_t)B * A};
+  dbg["log_std"] = {hPI.out[1], (int64_t)B * A};
+  dbg["pi"] = {pi_a, (int64_t)B * A};
+  dbg["logp"] = {logp, B};
+  dbg["qf1"] = {hQF1.out[0], B}; dbg["qf2"] = {hQF2.out[0], B};
+  dbg["v"] = {hVF.out[0], B}; dbg["v_tgt"] = {hTGT.out[0], B};
+  dbg["qf1_pi"] = {hQF1PI.out[0], B}; dbg["qf2_pi"] = {hQF2PI.out[0], B};
+  dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
+  dbg["dmu"] = {dmu, (int64_t)B * A}; dbg["dls"] = {dls, (int64_t)B * A}; dbg["da_pi"] = {da_pi, (int64_t)B * A};
+  dbg["grads"] = {grads, n_train};
+  return GRL_OK;
+}
+
+int grl_ctx::run_ops(std::vector<Op>& ops) {
+  if (!prof) {
+    for (auto& op : ops) op.run(stream);
+    return GRL_OK;
+  }
+  while (ev.size() < 2 * ops.size()) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    ev.push_back(e);
+  }
+  for (size_t i = 0; i < ops.size(); ++i) {
+    HIPCHK(hipEventRecord(ev[2 * i], stream));
+    ops[i].run(stream);
+    HIPCHK(hipEventRecord(ev[2 * i + 1], stream));
+  }
+  HIPCHK(hipStreamSynchronize(stream));
+  for (size_t i = 0; i < ops.size(); ++i) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    ProfAcc& a = prof_acc[ops[i].tag];
+    a.ms += ms; a.n += 1; a.flops += ops[i].flops; a.bytes += ops[i].bytes;
+  }
+  return GRL_OK;
+}
+
+int grl_ctx::capture(std::vector<std::vector<Op>*> seq, hipGraphExec_t* out) {
+  hipGraph_t g;
+  HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  for (auto* ops : seq)
+    for (auto& op : *ops) op.run(stream);
+  HIPCHK(hipStreamEndCapture(stream, &g));
+  HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+  HIPCHK(hipGraphDestroy(g));
+  return GRL_OK;
+}
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+static int check_cfg(const grl_config* c) {
+  if (!c) return fail(GRL_ERR_INVALID, "null config");
+  if (c->extractor < 0 || c->extractor > 2) return fail(GRL_ERR_INVALID, "extractor must be 0..2");
+  if (c->n_layers < 1 || c->n_layers > GRL_MAX_LAYERS) return fail(GRL_ERR_INVALID, "n_layers out of range");
+  for (int l = 0; l < c->n_layers; ++l)
+    if (c->layers[l] < 1 || c->layers[l] > 4096) return fail(GRL_ERR_INVALID, "layer width out of range");
+  if (c->batch_size < 1 || c->batch_size > 65536) return fail(GRL_ERR_INVALID, "batch_size out of range");
+  if (c->act_dim < 1 || c->act_dim > 64) return fail(GRL_ERR_INVALID, "act_dim out of range");
+  if (c->replay_capacity < 1) return fail(GRL_ERR_INVALID, "replay_capacity must be >= 1");
+  if (c->extractor == GRL_EXTRACTOR_MLP) {
+    if (c->obs_dim < 1) return fail(GRL_ERR_INVALID, "obs_dim must be >= 1 for the MLP extractor");
+  } else {
+    if (c->img_hw != 64) return fail(GRL_ERR_INVALID, "only 64x64 images (camera_info.yaml) are supported");
+    if (c->obs_channels < 1 || c->obs_channels > 8) return fail(GRL_ERR_INVALID, "obs_channels out of range");
+    if (c->extractor == GRL_EXTRACTOR_AUGMENTED && (c->n_direct < 0 || c->n_direct > 64))
+      return fail(GRL_ERR_INVALID, "n_direct out of range");
+    if (c->extractor == GRL_EXTRACTOR_AUGMENTED && c->n_direct > 0 && c->obs_channels < 2)
+      return fail(GRL_ERR_INVALID, "augmented extractor needs >= 2 observation channels");
+  }
+  return GRL_OK;
+}
+
+extern "C" {
+
+const char* grl_last_error(void) { return g_err.c_str(); }
+int grl_version(void) { return 1; }
+
+int grl_query_sizes(const grl_config* cfg, grl_sizes* out) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!out) return fail(GRL_ERR_INVALID, "null out");
+  grl_ctx ctx;
+  ctx.cfg = *cfg;
+  ctx.dry = true;
+  if (int e = ctx.plan()) return e;
+  out->state_bytes = ctx.st.off + 256;
+  out->grads_bytes = ctx.gr.off + 256;
+  out->work_bytes = ctx.wk.off + 256;
+  out->replay_bytes = ctx.rp.off + 256;
+  out->n_params = ctx.n_params;
+  out->n_trainable = ctx.n_train;
+  return GRL_OK;
+}
+
+int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!bufs || !out || !bufs->state || !bufs->grads || !bufs->work || !bufs->replay)
+    return fail(GRL_ERR_INVALID, "null buffers");
+  grl_ctx* h = new grl_ctx();
+  h->cfg = *cfg;
+  h->st.base = (char*)bufs->state; h->gr.base = (char*)bufs->grads;
+  h->wk.base = (char*)bufs->work; h->rp.base = (char*)bufs->replay;
+  if (int e = h->plan()) { delete h; return e; }
+  const char* ng = getenv("GRL_NO_GRAPH");
+  h->use_graph = !(ng && ng[0] == '1');
+  for (auto& u : h->uploads) {
+    hipError_t e = hipMemcpy(u.dst, u.bytes.data(), u.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
+  }
+  h->uploads.clear();
+  // state: zero Adam moments, scalars; stats = identity
+  hipMemset(h->adam_m, 0, (size_t)h->n_train * 4);
+  hipMemset(h->adam_v, 0, (size_t)h->n_train * 4);
+  hipMemset(h->grads, 0, (size_t)h->n_train * 4);
+  DevScalars s0;
+  memset(&s0, 0, sizeof(s0));
+  s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
+  hipError_t e = hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("scalar init: ") + hipGetErrorString(e)); }
+  *out = h;
+  return GRL_OK;
+}
+
+int grl_destroy(grl_handle h) {
+  if (!h) return GRL_OK;
+  hipStreamSynchronize(h->stream);
+  delete h;
+  return GRL_OK;
+}
+
+int grl_set_stream(grl_handle h, void* s) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if ((hipStream_t)s != h->stream) {   // graphs are tied to the capture stream only for capture; re-capture
+    if (h->graph_rng) { hipGraphExecDestroy(h->graph_rng); h->graph_rng = nullptr; }
+    if (h->graph_explicit) { hipGraphExecDestroy(h->graph_explicit); h->graph_explicit = nullptr; }
+  }
+  h->stream = (hipStream_t)s;
+  return GRL_OK;
+}
+
+int grl_param_count(grl_handle h) { return h ? (int)h->vars.size() : fail(GRL_ERR_INVALID, "null handle"); }
+
+int grl_param_info(grl_handle h, int i, char* name, int cap, int64_t* off, int64_t* numel, int32_t* ndim,
+                   int64_t shape[4], int32_t* trainable) {
+  if (!h || i < 0 || i >= (int)h->vars.size()) return fail(GRL_ERR_INVALID, "bad parameter index");
+  const Var& v = h->vars[i];
+  if (name && cap > 0) { strncpy(name, v.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (off) *off = v.off;
+  if (numel) *numel = v.numel;
+  if (ndim) *ndim = v.ndim;
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = v.shape[k];
+  if (trainable) *trainable = v.trainable ? 1 : 0;
+  return GRL_OK;
+}
+
+int grl_reset_optimizer(grl_handle h) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  HIPCHK(hipMemsetAsync(h->adam_m, 0, (size_t)h->n_train * 4, h->stream));
+  HIPCHK(hipMemsetAsync(h->adam_v, 0, (size_t)h->n_train * 4, h->stream));
+  DevScalars s0;
+  HIPCHK(hipMemcpy(&s0, h->sc, sizeof(s0), hipMemcpyDeviceToHost));
+  s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
+  HIPCHK(hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice));
+  return GRL_OK;
+}
+
+int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, double ret_var) {
+  if (!h || !mean || !var) return fail(GRL_ERR_INVALID, "null argument");
+  const grl_config& c = h->cfg;
+  const double eps = c.norm_eps;
+  const int nd = h->cnn ? h->F - 512 : 0;
+  std::vector<double> m(h->img_elems), s(h->img_elems), dm(std::max(nd, 1)), ds(std::max(nd, 1));
+  if (h->cnn) {
+    const int co = c.obs_channels, ci = h->C_img;
+    for (int px = 0; px < h->hw * h->hw; ++px)
+      for (int ch = 0; ch < ci; ++ch) {
+        m[px * ci + ch] = mean[px * co + ch];
+        s[px * ci + ch] = std::sqrt(var[px * co + ch] + eps);
+      }
+    for (int k = 0; k < nd; ++k) {
+      dm[k] = mean[k * co + (co - 1)];
+      ds[k] = std::sqrt(var[k * co + (co - 1)] + eps);
+    }
+  } else {
+    for (int k = 0; k < h->img_elems; ++k) { m[k] = mean[k]; s[k] = std::sqrt(var[k] + eps); }
+  }
+  const double rs = std::sqrt(ret_var + eps);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->s_mean, m.data(), m.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->s_std, s.data(), s.size() * 8, hipMemcpyHostToDevice));
+  if (nd > 0) {
+    HIPCHK(hipMemcpy(h->s_dmean, dm.data(), nd * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->s_dstd, ds.data(), nd * 8, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpy(h->s_ret, &rs, 8, hipMemcpyHostToDevice));
+  return GRL_OK;
+}
+
+static int replay_add_dev(grl_handle h, const float* obs, const float* act, const float* rew, const float* nxt,
+                          const float* done, int n) {
+  const grl_config& c = h->cfg;
+  IngestArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.obs = obs; ia.next_obs = nxt; ia.act = act; ia.rew = rew; ia.done = done;
+  ia.n = n; ia.hw = h->hw * h->hw; ia.c_obs = c.obs_channels; ia.c_img = h->C_img;
+  ia.n_direct = h->cnn ? h->F - 512 : 0; ia.act_dim = h->A; ia.vec_dim = h->cnn ? 0 : c.obs_dim;
+  ia.pos = h->rp_pos; ia.cap = c.replay_capacity;
+  ia.rp_obs = h->rp_obs; ia.rp_next = h->rp_next; ia.rp_dobs = h->rp_dobs; ia.rp_dnext = h->rp_dnext;
+  ia.rp_act = h->rp_act; ia.rp_rew = h->rp_rew; ia.rp_done = h->rp_done;
+  const int elems = h->cnn ? h->img_elems : c.obs_dim;
+  hipLaunchKernelGGL(ingest_kernel, dim3((elems + 255) / 256, n, 2), dim3(256), 0, h->stream, ia);
+  h->rp_pos = (h->rp_pos + n) % c.replay_capacity;
+  h->rp_size = std::min<int64_t>(c.replay_capacity, h->rp_size + n);
+  HIPCHK(hipMemcpyAsync(&h->sc->replay_size, &h->rp_size, 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_replay_add_device(grl_handle h, const float* obs, const float* act, const float* rew,
+                          const float* next_obs, const float* done, int n) {
+  if (!h || !obs || !act || !rew || !next_obs || !done || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (n > h->cfg.replay_capacity) return fail(GRL_ERR_INVALID, "n exceeds replay capacity");
+  return replay_add_dev(h, obs, act, rew, next_obs, done, n);
+}
+
+int grl_replay_add(grl_handle h, const float* obs, const float* act, const float* rew, const float* next_obs,
+                   const float* done, int n) {
+  if (!h || !obs || !act || !rew || !next_obs || !done || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  const int64_t oe = h->cnn ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
+  for (int k0 = 0; k0 < n; k0 += h->stg_n) {
+    const int m = std::min(h->stg_n, n - k0);
+    HIPCHK(hipMemcpyAsync(h->stg_obs, obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_next, next_obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_act, act + (int64_t)k0 * h->A, (size_t)m * h->A * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_rew, rew + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_done, done + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    if (int e = replay_add_dev(h, h->stg_obs, h->stg_act, h->stg_rew, h->stg_next, h->stg_done, m)) return e;
+    HIPCHK(hipStreamSynchronize(h->stream));   // staging buffers are reused by the next chunk
+  }
+  return GRL_OK;
+}
+
+int64_t grl_replay_size(grl_handle h) { return h ? h->rp_size : -1; }
+
+static int stage_noise(grl_handle h, const int64_t* idx, const float* eps, int step) {
+  HIPCHK(hipMemcpyAsync(h->idx_buf, idx + (int64_t)step * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->eps_buf, eps + (int64_t)step * h->B * h->A, (size_t)h->B * h->A * 4,
+                        hipMemcpyDeviceToDevice, h->stream));
+  return GRL_OK;
+}
+
+int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  if (idx) { if (int e = stage_noise(h, idx, eps, 0)) return e; }
+  else { if (int e = h->run_ops(h->ops_rng)) return e; }
+  if (int e = h->run_ops(h->ops_grads)) return e;
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_apply_grads(grl_handle h, float grad_scale) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  h->grad_scale = grad_scale;
+  if (int e = h->run_ops(h->ops_apply)) return e;
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps) {
+  if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  h->grad_scale = 1.f;
+  const bool graph = h->use_graph && !h->prof && h->stream != nullptr;   // the null stream cannot be captured
+  if (graph) {
+    if (idx && !h->graph_explicit) { if (int e = h->capture({&h->ops_grads, &h->ops_apply}, &h->graph_explicit)) return e; }
+    if (!idx && !h->graph_rng) { if (int e = h->capture({&h->ops_rng, &h->ops_grads, &h->ops_apply}, &h->graph_rng)) return e; }
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    if (idx) { if (int e = stage_noise(h, idx, eps, s)) return e; }
+    if (graph) {
+      HIPCHK(hipGraphLaunch(idx ? h->graph_explicit : h->graph_rng, h->stream));
+    } else {
+      if (!idx) { if (int e = h->run_ops(h->ops_rng)) return e; }
+      if (int e = h->run_ops(h->ops_grads)) return e;
+      if (int e = h->run_ops(h->ops_apply)) return e;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_get_metrics(grl_handle h, grl_metrics* out) {
+  if (!h || !out) return fail(GRL_ERR_INVALID, "null argument");
+  DevScalars s;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(&s, h->sc, sizeof(s), hipMemcpyDeviceToHost));
+  out->policy_loss = s.policy_loss; out->qf1_loss = s.qf1_loss; out->qf2_loss = s.qf2_loss;
+  out->value_loss = s.value_loss; out->ent_coef_loss = s.ent_loss; out->ent_coef = s.ent_coef;
+  out->entropy = s.entropy; out->mean_qf1 = s.mean_qf1; out->mean_v = s.mean_v;
+  return GRL_OK;
+}
+
+int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps, float* out) {
+  if (!h || !obs || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
+  if (!deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
+  const int64_t oe = h->cnn ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
+  HIPCHK(hipMemcpyAsync(h->stg_obs, obs, (size_t)n * oe * 4, hipMemcpyHostToDevice, h->stream));
+  if (!deterministic)
+    HIPCHK(hipMemcpyAsync(h->a_eps, eps, (size_t)n * h->A * 4, hipMemcpyHostToDevice, h->stream));
+  if (int e = h->run_ops(h->ops_act)) return e;
+  hipLaunchKernelGGL(act_out_kernel, dim3((n * h->A + 255) / 256), dim3(256), 0, h->stream, h->ahPI.out[0],
+                     h->ahPI.out[1], h->a_eps, n, h->A, deterministic, h->a_out);
+  HIPCHK(hipMemcpyAsync(out, h->a_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_encoder_load(grl_handle h, const float* const* w, const int64_t* numels, int n_arrays) {
+  if (!h || !w || !numels || n_arrays != 8) return fail(GRL_ERR_INVALID, "expected 8 weight arrays");
+  const int64_t wn[8] = {7 * 7 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 32, 32, 2048 * 100, 100};
+  for (int k = 0; k < 8; ++k)
+    if (numels[k] != wn[k]) return fail(GRL_ERR_INVALID, "encoder weight " + std::to_string(k) + " has the wrong size");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 8; ++k) HIPCHK(hipMemcpy(h->enc_w[k], w[k], (size_t)wn[k] * 4, hipMemcpyHostToDevice));
+  h->enc_loaded = true;
+  return GRL_OK;
+}
+
+int grl_encode(grl_handle h, const float* depth, int n, float* out) {
+  if (!h || !depth || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->enc_loaded) return fail(GRL_ERR_STATE, "grl_encoder_load has not been called");
+  if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
+  HIPCHK(hipMemcpyAsync(h->ex_in, depth, (size_t)n * 4096 * 4, hipMemcpyHostToDevice, h->stream));
+  if (int e = h->run_ops(h->ops_enc)) return e;
+  HIPCHK(hipMemcpyAsync(out, h->eout, (size_t)n * 100 * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int64_t grl_debug_fetch(grl_handle h, const char* name, float* out, int64_t cap) {
+  if (!h || !name || !out) return fail(GRL_ERR_INVALID, "null argument");
+  auto it = h->dbg.find(name);
+  if (it == h->dbg.end()) return fail(GRL_ERR_INVALID, std::string("unknown tensor ") + name);
+  const int64_t n = std::min(cap, it->second.second);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(GRL_ERR_HIP, "sync failed");
+  hipError_t e = hipMemcpy(out, it->second.first, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(GRL_ERR_HIP, hipGetErrorString(e));
+  return n;
+}
+
+int grl_profile_enable(grl_handle h, int on) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  h->prof = on != 0;
+  if (on) h->prof_acc.clear();
+  return GRL_OK;
+}
+
+int grl_profile_query(grl_handle h, const char* name, double* avg_ms, int64_t* launches) {
+  if (!h || !name) return fail(GRL_ERR_INVALID, "null argument");
+  auto it = h->prof_acc.find(name);
+  if (it == h->prof_acc.end()) return fail(GRL_ERR_INVALID, std::string("no profile for ") + name);
+  if (avg_ms) *avg_ms = it->second.n ? it->second.ms / it->second.n : 0.0;
+  if (launches) *launches = it->second.n;
+  return GRL_OK;
+}
+
+/* list profiled tags: writes "tag:avg_ms:launches:flops_per_launch:bytes_per_launch\n" lines */
+int grl_profile_dump(grl_handle h, char* buf, int cap) {
+  if (!h || !buf || cap < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  std::string s;
+  for (auto& kv : h->prof_acc) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s:%.6f:%lld:%.0f:%.0f\n", kv.first.c_str(),
+             kv.second.n ? kv.second.ms / kv.second.n : 0.0, (long long)kv.second.n,
+             kv.second.n ? kv.second.flops / kv.second.n : 0.0, kv.second.n ? kv.second.bytes / kv.second.n : 0.0);
+    s += line;
+  }
+  strncpy(buf, s.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return GRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""ctypes binding of libgrl.so (include/grl.h).  No torch / numpy dependency here."""
+import ctypes as C
+import os
+
+GRL_MAX_LAYERS = 4
+EXTRACTOR_MLP, EXTRACTOR_AUGMENTED, EXTRACTOR_NATURE = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libgrl.so")
+
+
+class GrlConfig(C.Structure):
+    _fields_ = [
+        ("extractor", C.c_int32), ("img_hw", C.c_int32), ("obs_channels", C.c_int32),
+        ("n_direct", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+        ("n_layers", C.c_int32), ("layers", C.c_int32 * GRL_MAX_LAYERS),
+        ("batch_size", C.c_int32), ("act_batch", C.c_int32), ("replay_capacity", C.c_int64),
+        ("normalize", C.c_int32), ("gamma", C.c_float), ("lr", C.c_float), ("tau", C.c_float),
+        ("clip_obs", C.c_float), ("clip_reward", C.c_float), ("norm_eps", C.c_float),
+        ("target_entropy", C.c_float), ("seed", C.c_uint64),
+    ]
+
+
+class GrlSizes(C.Structure):
+    _fields_ = [("state_bytes", C.c_size_t), ("grads_bytes", C.c_size_t), ("work_bytes", C.c_size_t),
+                ("replay_bytes", C.c_size_t), ("n_params", C.c_int64), ("n_trainable", C.c_int64)]
+
+
+class GrlBuffers(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("grads", C.c_void_p), ("work", C.c_void_p), ("replay", C.c_void_p)]
+
+
+class GrlMetrics(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("policy_loss", "qf1_loss", "qf2_loss", "value_loss", "ent_coef_loss",
+                                          "ent_coef", "entropy", "mean_qf1", "mean_v")]
+
+
+EXPORTS = [
+    "grl_last_error", "grl_version", "grl_query_sizes", "grl_create", "grl_destroy", "grl_set_stream",
+    "grl_param_count", "grl_param_info", "grl_reset_optimizer", "grl_set_obs_stats", "grl_replay_add",
+    "grl_replay_add_device", "grl_replay_size", "grl_train_step", "grl_compute_grads", "grl_apply_grads",
+    "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
+    "grl_profile_enable", "grl_profile_query", "grl_profile_dump",
+]
+
+
+class GrlError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libgrl.so and declare prototypes.  Raises loudly when the library is missing."""
+    path = path or os.environ.get("GRL_LIBRARY") or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise GrlError("libgrl.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, i32, i64, f32p, dp = C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p
+    lib.grl_last_error.restype = C.c_char_p
+    lib.grl_version.restype = i32
+    lib.grl_query_sizes.argtypes = [C.POINTER(GrlConfig), C.POINTER(GrlSizes)]
+    lib.grl_create.argtypes = [C.POINTER(GrlConfig), C.POINTER(GrlBuffers), C.POINTER(vp)]
+    lib.grl_destroy.argtypes = [vp]
+    lib.grl_set_stream.argtypes = [vp, vp]
+    lib.grl_param_count.argtypes = [vp]
+    lib.grl_param_info.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64),
+                                   C.POINTER(C.c_int32), C.POINTER(i64 * 4), C.POINTER(C.c_int32)]
+    lib.grl_reset_optimizer.argtypes = [vp]
+    lib.grl_set_obs_stats.argtypes = [vp, dp, dp, C.c_double]
+    lib.grl_replay_add.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, i32]
+    lib.grl_replay_add_device.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, i32]
+    lib.grl_replay_size.argtypes = [vp]
+    lib.grl_replay_size.restype = i64
+    lib.grl_train_step.argtypes = [vp, i32, vp, vp]
+    lib.grl_compute_grads.argtypes = [vp, vp, vp]
+    lib.grl_apply_grads.argtypes = [vp, C.c_float]
+    lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]
+    lib.grl_act.argtypes = [vp, f32p, i32, i32, f32p, f32p]
+    lib.grl_encoder_load.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), i32]
+    lib.grl_encode.argtypes = [vp, f32p, i32, f32p]
+    lib.grl_debug_fetch.argtypes = [vp, C.c_char_p, f32p, i64]
+    lib.grl_debug_fetch.restype = i64
+    lib.grl_profile_enable.argtypes = [vp, i32]
+    lib.grl_profile_query.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.grl_profile_dump.argtypes = [vp, C.c_char_p, i32]
+    return lib
+
+
+def check(lib, rc):
+    if rc < 0:
+        raise GrlError("libgrl: %s (code %d)" % (lib.grl_last_error().decode(), rc))
+    return rc
+
+
+def make_config(extractor, obs_channels=2, n_direct=1, obs_dim=0, act_dim=5, layers=(64, 64), batch_size=64,
+                act_batch=1, replay_capacity=50000, normalize=True, gamma=0.99, lr=3e-4, tau=0.005,
+                clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, target_entropy=None, seed=0, img_hw=64):
+    cfg = GrlConfig()
+    cfg.extractor = {"mlp": 0, "augmented": 1, "nature": 2}.get(extractor, extractor)
+    cfg.img_hw, cfg.obs_channels, cfg.n_direct, cfg.obs_dim, cfg.act_dim = img_hw, obs_channels, n_direct, obs_dim, act_dim
+    if len(layers) > GRL_MAX_LAYERS:
+        raise GrlError("at most %d hidden layers are supported" % GRL_MAX_LAYERS)
+    cfg.n_layers = len(layers)
+    for i, h in enumerate(layers):
+        cfg.layers[i] = int(h)
+    cfg.batch_size, cfg.act_batch, cfg.replay_capacity = batch_size, act_batch, replay_capacity
+    cfg.normalize = 1 if normalize else 0
+    cfg.gamma, cfg.lr, cfg.tau = gamma, lr, tau
+    cfg.clip_obs, cfg.clip_reward, cfg.norm_eps = clip_obs, clip_reward, norm_eps
+    cfg.target_entropy = -float(act_dim) if target_entropy is None else target_entropy
+    cfg.seed = seed
+    return cfg
+
+
+def param_table(lib, handle):
+    """[(name, offset_floats, numel, shape, trainable)] in TF creation order."""
+    out = []
+    for i in range(check(lib, lib.grl_param_count(handle))):
+        name = C.create_string_buffer(256)
+        off, numel, ndim, tr = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        shape = (C.c_int64 * 4)()
+        check(lib, lib.grl_param_info(handle, i, name, 256, C.byref(off), C.byref(numel), C.byref(ndim),
+                                      C.byref(shape), C.byref(tr)))
+        out.append((name.value.decode(), off.value, numel.value, tuple(shape[k] for k in range(ndim.value)),
+                    bool(tr.value)))
+    return out

@@ -1,0 +1,247 @@
+"""SacEngine -- thin Python owner of the device arenas + handle of libgrl.so.
+
+The arithmetic of the SAC update (replay gather/normalise, CNN + MLP forward/backward, losses, Adam,
+Polyak) runs in the HIP kernels behind the C ABI of include/grl.h; PyTorch-ROCm only provides the
+device memory (four flat tensors), the stream and -- for data parallelism -- the RCCL all-reduce of
+the flat gradient tensor.  There is no CPU fallback: constructing an engine without a HIP device or
+without the built library raises.
+
+Reference call sites this object stands behind: sb.SAC(...) construction and .learn()'s per-step
+update at /root/reference/manipulation_main/training/sb_helper.py:104-128,175-177.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _capi
+from ._capi import GrlError, check
+
+
+class TorchCudaBackend:
+    """Device memory = PyTorch-ROCm tensors; work is enqueued on a dedicated HIP stream."""
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        if not torch.cuda.is_available():
+            raise GrlError("no HIP device visible to PyTorch: the grasp_rl engine runs only on an AMD GPU "
+                           "(MI355X / gfx950); there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def alloc_f32(self, nbytes):
+        t = self.torch.zeros((nbytes + 3) // 4, dtype=self.torch.float32, device=self.device)
+        self.torch.cuda.synchronize(self.device)
+        return t
+
+    def ptr(self, t):
+        return t.data_ptr()
+
+    def stream_ptr(self):
+        return self.stream.cuda_stream
+
+    def to_device(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return t
+
+    def to_host(self, t):
+        self.stream.synchronize()
+        return t.detach().cpu().numpy()
+
+    def write(self, view, arr):
+        with self.torch.cuda.stream(self.stream):
+            view.copy_(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).reshape(view.shape),
+                       non_blocking=False)
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
+class SacEngine:
+    def __init__(self, cfg, backend=None, lib_path=None, device="cuda:0"):
+        self.lib = _capi.load_library(lib_path)
+        self.be = backend if backend is not None else TorchCudaBackend(device)
+        self.cfg = cfg
+        sizes = _capi.GrlSizes()
+        check(self.lib, self.lib.grl_query_sizes(C.byref(cfg), C.byref(sizes)))
+        self.sizes = sizes
+        self.state = self.be.alloc_f32(sizes.state_bytes)
+        self.grads = self.be.alloc_f32(sizes.grads_bytes)
+        self.work = self.be.alloc_f32(sizes.work_bytes)
+        self.replay = self.be.alloc_f32(sizes.replay_bytes)
+        bufs = _capi.GrlBuffers(self.be.ptr(self.state), self.be.ptr(self.grads), self.be.ptr(self.work),
+                                self.be.ptr(self.replay))
+        h = C.c_void_p()
+        check(self.lib, self.lib.grl_create(C.byref(cfg), C.byref(bufs), C.byref(h)))
+        self.h = h
+        check(self.lib, self.lib.grl_set_stream(self.h, C.c_void_p(self.be.stream_ptr())))
+        self.table = _capi.param_table(self.lib, self.h)
+        self.n_trainable = sizes.n_trainable
+        self.B, self.A = cfg.batch_size, cfg.act_dim
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.grl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def _view(self, off, numel, shape):
+        return self.state[off:off + numel].reshape(shape if len(shape) else ())
+
+    def param_names(self, trainable_only=False):
+        return [n for n, _, _, _, tr in self.table if tr or not trainable_only]
+
+    def get_parameters(self):
+        """OrderedDict TF-name -> float32 ndarray (SB ``get_parameters``, sb_helper.py:114)."""
+        self.be.synchronize()
+        out = OrderedDict()
+        flat = self.be.to_host(self.state[: self.sizes.n_params])
+        for name, off, numel, shape, _ in self.table:
+            out[name] = flat[off:off + numel].reshape(shape).copy()
+        return out
+
+    def set_parameters(self, params, exact_match=True):
+        """SB ``load_parameters(params, exact_match)`` (sb_helper.py:115,198,225)."""
+        known = {n for n, *_ in self.table}
+        if exact_match and set(params.keys()) != known:
+            raise GrlError("parameter names do not match: missing %s, unexpected %s" %
+                           (sorted(known - set(params)), sorted(set(params) - known)))
+        for name, off, numel, shape, _ in self.table:
+            if name not in params:
+                continue
+            arr = np.asarray(params[name], dtype=np.float32)
+            if int(arr.size) != numel:
+                raise GrlError("%s: expected %d values, got shape %s" % (name, numel, arr.shape))
+            self.be.write(self._view(off, numel, shape), arr.reshape(shape))
+        self.be.synchronize()
+
+    def reset_optimizer(self):
+        check(self.lib, self.lib.grl_reset_optimizer(self.h))
+
+    def grad_tensor(self):
+        """Flat fp32 gradient bucket (the tensor a data-parallel wrapper all-reduces)."""
+        return self.grads[: self.n_trainable]
+
+    def get_gradients(self):
+        flat = self.be.to_host(self.grads[: self.n_trainable])
+        out = OrderedDict()
+        for name, off, numel, shape, tr in self.table:
+            if tr:
+                out[name] = flat[off:off + numel].reshape(shape).copy()
+        return out
+
+    # ------------------------------------------------------------------ data
+    def set_obs_stats(self, mean, var, ret_var):
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        var = np.ascontiguousarray(var, dtype=np.float64)
+        check(self.lib, self.lib.grl_set_obs_stats(self.h, mean.ctypes.data, var.ctypes.data, float(ret_var)))
+
+    def replay_add(self, obs, act, rew, next_obs, done):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (obs, act, rew, next_obs, done)]
+        n = arrs[2].reshape(-1).shape[0]
+        check(self.lib, self.lib.grl_replay_add(self.h, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                                                arrs[3].ctypes.data, arrs[4].ctypes.data, n))
+
+    def replay_add_device(self, obs, act, rew, next_obs, done):
+        """Same with float32 device tensors (already visible to the engine stream)."""
+        n = int(rew.numel())
+        p = self.be.ptr
+        check(self.lib, self.lib.grl_replay_add_device(self.h, p(obs), p(act), p(rew), p(next_obs), p(done), n))
+
+    def replay_size(self):
+        return int(self.lib.grl_replay_size(self.h))
+
+    # ------------------------------------------------------------------ update
+    def _noise(self, idx, eps, n_steps):
+        if idx is None and eps is None:
+            return None, None, (None, None)
+        idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(n_steps, self.B)
+        eps = np.ascontiguousarray(eps, dtype=np.float32).reshape(n_steps, self.B, self.A)
+        if idx.min() < 0 or idx.max() >= self.replay_size():
+            raise GrlError("replay index out of range")
+        di, de = self.be.to_device(idx), self.be.to_device(eps)
+        return C.c_void_p(self.be.ptr(di)), C.c_void_p(self.be.ptr(de)), (di, de)
+
+    def train(self, n_steps=1, idx=None, eps=None):
+        """n_steps SAC updates; idx/eps (host arrays) make the minibatch and policy noise explicit."""
+        pi, pe, keep = self._noise(idx, eps, n_steps)
+        check(self.lib, self.lib.grl_train_step(self.h, n_steps, pi, pe))
+        self._keep = [keep]   # keep the staged tensors alive until the stream has consumed them
+
+    def train_device(self, n_steps, idx_dev=None, eps_dev=None):
+        """Same with idx/eps already resident on the device (or None for the device RNG)."""
+        pi = C.c_void_p(self.be.ptr(idx_dev)) if idx_dev is not None else None
+        pe = C.c_void_p(self.be.ptr(eps_dev)) if eps_dev is not None else None
+        check(self.lib, self.lib.grl_train_step(self.h, n_steps, pi, pe))
+
+    def compute_grads(self, idx=None, eps=None):
+        pi, pe, keep = self._noise(idx, eps, 1)
+        check(self.lib, self.lib.grl_compute_grads(self.h, pi, pe))
+        self._keep = [keep]
+
+    def apply_grads(self, grad_scale=1.0):
+        check(self.lib, self.lib.grl_apply_grads(self.h, float(grad_scale)))
+
+    def metrics(self):
+        m = _capi.GrlMetrics()
+        check(self.lib, self.lib.grl_get_metrics(self.h, C.byref(m)))
+        return {n: getattr(m, n) for n, _ in m._fields_}
+
+    def synchronize(self):
+        self.be.synchronize()
+
+    # ------------------------------------------------------------------ inference
+    def act(self, obs, deterministic=True, eps=None):
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        n = obs.shape[0]
+        out = np.empty((n, self.A), np.float32)
+        pe = None
+        if not deterministic:
+            eps = np.ascontiguousarray(eps, dtype=np.float32).reshape(n, self.A)
+            pe = eps.ctypes.data
+        check(self.lib, self.lib.grl_act(self.h, obs.ctypes.data, n, 1 if deterministic else 0, pe, out.ctypes.data))
+        return out
+
+    def load_encoder(self, weights):
+        """weights: Keras order conv2d_1..3 kernel/bias, dense_1 kernel/bias (encoders.py:90-108)."""
+        arrs = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        ptrs = (C.c_void_p * 8)(*[a.ctypes.data for a in arrs])
+        nums = (C.c_int64 * 8)(*[a.size for a in arrs])
+        check(self.lib, self.lib.grl_encoder_load(self.h, ptrs, nums, 8))
+
+    def encode(self, depth):
+        depth = np.ascontiguousarray(depth, dtype=np.float32).reshape(-1, 64, 64, 1)
+        n = depth.shape[0]
+        out = np.empty((n, 100), np.float32)
+        check(self.lib, self.lib.grl_encode(self.h, depth.ctypes.data, n, out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ debugging / profiling
+    def fetch(self, name, shape=None):
+        cap = 1 << 24
+        buf = np.empty(cap, np.float32) if shape is None else np.empty(int(np.prod(shape)), np.float32)
+        n = check(self.lib, self.lib.grl_debug_fetch(self.h, name.encode(), buf.ctypes.data, buf.size))
+        out = buf[:n].copy()
+        return out.reshape(shape) if shape is not None else out
+
+    def profile(self, on):
+        check(self.lib, self.lib.grl_profile_enable(self.h, 1 if on else 0))
+
+    def profile_dump(self):
+        buf = C.create_string_buffer(1 << 14)
+        check(self.lib, self.lib.grl_profile_dump(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            tag, ms, n, fl, by = line.split(":")
+            out[tag] = {"avg_ms": float(ms), "launches": int(n), "flops": float(fl), "bytes": float(by)}
+        return out

@@ -1,0 +1,161 @@
+/*
+ * grl.h -- C ABI of libgrl.so, the MI355X (gfx950) implementation of the SAC / DQN / BDQ
+ * update hot path of BarisYazici/deep-rl-grasping.
+ *
+ * The reference has no FFI of its own: its hot path is the stable-baselines model object it
+ * drives from Python.  Each entry point below names the reference call it stands behind
+ * (paths relative to /root/reference):
+ *
+ *   grl_create / grl_destroy      sb.SAC(policy, env, policy_kwargs=..., gamma=..., buffer_size=...,
+ *                                 batch_size=..., learning_rate=...)
+ *                                 manipulation_main/training/sb_helper.py:104-112,120-128
+ *   grl_param_count/info          model.get_parameters() / load_parameters()  sb_helper.py:114-115
+ *   grl_replay_add                SAC.learn -> replay_buffer.add(obs, action, reward, new_obs, done)
+ *                                 (stable-baselines learn loop entered at sb_helper.py:175-177)
+ *   grl_set_obs_stats             VecNormalize(env, norm_obs=True, norm_reward=True, clip_obs=10.)
+ *                                 statistics read at replay-sample time   sb_helper.py:117-119
+ *   grl_train_step                SAC._train_step + target_update_op, once per env step
+ *                                 (train_freq=1, gradient_steps=1)         sb_helper.py:175-177
+ *   grl_compute_grads/apply_grads the same step split around the data-parallel gradient all-reduce
+ *   grl_act                       model.predict(obs, deterministic)        manipulation_main/utils.py:71,
+ *                                 training/base_callbacks.py:84-88
+ *   grl_encode                    SimpleAutoEncoder.encode(imgs)           gripperEnv/encoders.py:59-61,
+ *                                 call site gripperEnv/sensor.py:220-222
+ *
+ * Conventions
+ *   - plain C types only; device memory is passed as raw pointers.  All device memory is OWNED BY
+ *     THE CALLER (PyTorch-ROCm tensors in the Python host); the library allocates no device memory.
+ *     Sizes of the arenas the caller must provide come from grl_query_sizes().
+ *   - every call enqueues its work on the HIP stream given by grl_set_stream() (default: the null
+ *     stream) and returns without synchronising, except the calls documented as "host" which copy
+ *     results to host memory and synchronise that stream.
+ *   - return value 0 = OK, negative = error; grl_last_error() returns a thread-local message.
+ *   - one handle per GPU / process; a handle is not re-entrant.
+ */
+#ifndef GRL_H_
+#define GRL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRL_OK 0
+#define GRL_ERR_INVALID (-1)
+#define GRL_ERR_HIP (-2)
+#define GRL_ERR_STATE (-3)
+
+#define GRL_MAX_LAYERS 4
+
+/* feature extractor selected by sb_helper.py:85-96 */
+#define GRL_EXTRACTOR_MLP 0        /* sacMlp on vector observations (auto-encoder features)      */
+#define GRL_EXTRACTOR_AUGMENTED 1  /* sacCnn + custom_obs_policy.create_augmented_nature_cnn(n)  */
+#define GRL_EXTRACTOR_NATURE 2     /* sacCnn with the default nature_cnn over all channels       */
+
+typedef struct grl_config {
+  int32_t extractor;      /* GRL_EXTRACTOR_*                                                    */
+  int32_t img_hw;         /* 64 (config/camera_info.yaml:1-2)                                   */
+  int32_t obs_channels;   /* channels of the env observation: 2 depth, 5 RGB-D (robot.py:223-228) */
+  int32_t n_direct;       /* direct features carried in the last channel (augmented only)       */
+  int32_t obs_dim;        /* vector observation size (MLP extractor only)                       */
+  int32_t act_dim;        /* 5 full / 3 simplified (actuator.py:60-73)                           */
+  int32_t n_layers;       /* len(config[algo]['layers'])                                        */
+  int32_t layers[GRL_MAX_LAYERS];
+  int32_t batch_size;     /* per-GPU minibatch                                                  */
+  int32_t act_batch;      /* max observations per grl_act call (vectorised envs)                */
+  int64_t replay_capacity;
+  int32_t normalize;      /* config['normalize'] -> VecNormalize at sample time                 */
+  float gamma, lr, tau;
+  float clip_obs, clip_reward, norm_eps;
+  float target_entropy;   /* -act_dim for ent_coef='auto'                                       */
+  uint64_t seed;          /* device RNG (replay indices, policy noise) when none are supplied   */
+} grl_config;
+
+/* byte sizes of the four caller-provided device arenas */
+typedef struct grl_sizes {
+  size_t state_bytes;   /* parameters (incl. target net), Adam moments, scalars                 */
+  size_t grads_bytes;   /* flat fp32 gradient bucket (the data-parallel all-reduce payload)     */
+  size_t work_bytes;    /* activations, gradient workspaces, descriptor tables                  */
+  size_t replay_bytes;  /* replay ring: obs, next_obs, action, reward, done                     */
+  int64_t n_params;     /* floats in the parameter block (trainable + target, incl. padding)    */
+  int64_t n_trainable;  /* floats covered by the gradient bucket                                */
+} grl_sizes;
+
+typedef struct grl_buffers {
+  void* state;
+  void* grads;
+  void* work;
+  void* replay;
+} grl_buffers;
+
+/* losses / diagnostics of one update, as logged by SB (logs.csv columns) */
+typedef struct grl_metrics {
+  float policy_loss, qf1_loss, qf2_loss, value_loss, ent_coef_loss, ent_coef, entropy;
+  float mean_qf1, mean_v;
+} grl_metrics;
+
+typedef struct grl_ctx* grl_handle;
+
+const char* grl_last_error(void);
+int grl_version(void);
+
+int grl_query_sizes(const grl_config* cfg, grl_sizes* out);
+int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out);
+int grl_destroy(grl_handle h);
+int grl_set_stream(grl_handle h, void* hip_stream);
+
+/* parameter layout: TF variable names (with ":0") in TF creation order, as in the SB zips */
+int grl_param_count(grl_handle h);
+int grl_param_info(grl_handle h, int index, char* name, int name_cap, int64_t* offset_floats,
+                   int64_t* numel, int32_t* ndim, int64_t shape[4], int32_t* trainable);
+/* re-initialise Adam moments / beta powers (after load_parameters) */
+int grl_reset_optimizer(grl_handle h);
+
+/* VecNormalize statistics (host float64, HWC layout of the observation space or [obs_dim]);
+   obs_var/ret_var are variances, epsilon is added inside.  Copied before returning. */
+int grl_set_obs_stats(grl_handle h, const double* obs_mean, const double* obs_var, double ret_var);
+
+/* append n raw (un-normalised) transitions; host pointers, obs in env layout [n,H,W,C] or [n,D] */
+int grl_replay_add(grl_handle h, const float* obs, const float* act, const float* rew,
+                   const float* next_obs, const float* done, int n);
+/* same, device pointers already on the stream */
+int grl_replay_add_device(grl_handle h, const float* obs, const float* act, const float* rew,
+                          const float* next_obs, const float* done, int n);
+int64_t grl_replay_size(grl_handle h);
+
+/* n_steps SAC updates.  idx [n_steps*batch] int64 replay indices and eps [n_steps*batch*act_dim]
+   standard-normal noise are DEVICE pointers; pass NULL to draw them on the device (Philox). */
+int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
+/* split form for data parallelism: grads -> (caller all-reduces the grads arena) -> apply */
+int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps);
+int grl_apply_grads(grl_handle h, float grad_scale);
+/* host: metrics of the most recent update (synchronises the stream) */
+int grl_get_metrics(grl_handle h, grl_metrics* out);
+
+/* host: actor forward for n <= act_batch already-normalised observations (env layout, host ptr);
+   eps_or_null: [n,act_dim] noise for stochastic actions (host).  Synchronises the stream. */
+int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps_or_null,
+            float* out_actions);
+
+/* Keras depth auto-encoder (encoder half).  weights: 8 host arrays in Keras order
+   conv2d_1..3 kernel(HWIO)/bias, dense_1 kernel [2048,100]/bias; copied into the work arena. */
+int grl_encoder_load(grl_handle h, const float* const* weights, const int64_t* numels, int n_arrays);
+/* host: depth [n,64,64,1] float32 -> out [n,100]; n <= act_batch.  Synchronises the stream. */
+int grl_encode(grl_handle h, const float* depth, int n, float* out_feat);
+
+/* debugging / parity: copy a named internal activation of the last update to the host.
+   Names: "x_obs","x_next","feat_pi","feat_vf","feat_tgt","mu","log_std","pi","logp","qf1","qf2",
+   "v","v_tgt","qf1_pi","qf2_pi","rew","done".  Returns the number of floats written or <0. */
+int64_t grl_debug_fetch(grl_handle h, const char* name, float* out, int64_t cap);
+
+/* wall-clock free kernel timing: enables hipEvent timing of tagged kernels in later steps */
+int grl_profile_enable(grl_handle h, int on);
+/* host: average ms per launch of the kernel tagged `name` since enable; "" lists tags into name_out */
+int grl_profile_query(grl_handle h, const char* name, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRL_H_ */

@@ -1,0 +1,46 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "deep-rl-grasping_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def hostemu_lib():
+    """TEST-ONLY g++ build of engine.hip with the HIP runtime stubbed (csrc/hostemu.h): validates the
+    host-side launch plan against the oracle without a GPU.  Never used by the product."""
+    out = os.path.join(ROOT, "tests", "_build", "libgrl_hostemu.so")
+    src = os.path.join(PKG, "csrc", "engine.hip")
+    deps = [os.path.join(PKG, "csrc", f) for f in ("engine.hip", "igemm.h", "elem_kernels.h", "hostemu.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DGRL_HOSTEMU", "-x", "c++", src,
+                               "-o", out])
+    return out
