@@ -188,7 +188,8 @@ struct grl_ctx {
   float grad_scale = 1.f;   // read by the apply op
 
   // graphs
-  hipGraphExec_t graph_rng = nullptr, graph_explicit = nullptr;
+  std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences, keyed by what they contain
+  float apply_graph_scale = 0.f;
   bool use_graph = true;
 
   // profiling
@@ -201,8 +202,29 @@ struct grl_ctx {
   ~grl_ctx() {
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
-    if (graph_rng) hipGraphExecDestroy(graph_rng);
-    if (graph_explicit) hipGraphExecDestroy(graph_explicit);
+    drop_graphs();
+  }
+  void drop_graphs() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear();
+  }
+  bool graphs_on() const { return use_graph && !prof && stream != nullptr; }   // the null stream cannot be captured
+  // run a sequence of op lists either eagerly or as a cached hipGraph
+  int run_seq(const std::string& key, std::vector<std::vector<Op>*> seq) {
+    if (!graphs_on()) {
+      for (auto* ops : seq)
+        if (int e = run_ops(*ops)) return e;
+      return GRL_OK;
+    }
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+      hipGraphExec_t g = nullptr;
+      if (int e = capture(seq, &g)) return e;
+      it = graphs.emplace(key, g).first;
+    }
+    hipError_t e_ = hipGraphLaunch(it->second, stream);
+    if (e_ != hipSuccess) return fail(GRL_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(e_));
+    return GRL_OK;
   }
 
   // ---------------------------------------------------------------- helpers
@@ -1129,10 +1151,7 @@ int grl_destroy(grl_handle h) {
 
 int grl_set_stream(grl_handle h, void* s) {
   if (!h) return fail(GRL_ERR_INVALID, "null handle");
-  if ((hipStream_t)s != h->stream) {   // graphs are tied to the capture stream only for capture; re-capture
-    if (h->graph_rng) { hipGraphExecDestroy(h->graph_rng); h->graph_rng = nullptr; }
-    if (h->graph_explicit) { hipGraphExecDestroy(h->graph_explicit); h->graph_explicit = nullptr; }
-  }
+  if ((hipStream_t)s != h->stream) h->drop_graphs();
   h->stream = (hipStream_t)s;
   return GRL_OK;
 }
@@ -1252,17 +1271,25 @@ int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps) {
   if (!h) return fail(GRL_ERR_INVALID, "null handle");
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
-  if (idx) { if (int e = stage_noise(h, idx, eps, 0)) return e; }
-  else { if (int e = h->run_ops(h->ops_rng)) return e; }
-  if (int e = h->run_ops(h->ops_grads)) return e;
+  if (idx) {
+    if (int e = stage_noise(h, idx, eps, 0)) return e;
+    if (int e = h->run_seq("grads_explicit", {&h->ops_grads})) return e;
+  } else {
+    if (int e = h->run_seq("grads_rng", {&h->ops_rng, &h->ops_grads})) return e;
+  }
   HIPCHK(hipGetLastError());
   return GRL_OK;
 }
 
 int grl_apply_grads(grl_handle h, float grad_scale) {
   if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (grad_scale != h->apply_graph_scale) {   // the scale is baked into the captured kernel arguments
+    auto it = h->graphs.find("apply");
+    if (it != h->graphs.end()) { (void)hipGraphExecDestroy(it->second); h->graphs.erase(it); }
+    h->apply_graph_scale = grad_scale;
+  }
   h->grad_scale = grad_scale;
-  if (int e = h->run_ops(h->ops_apply)) return e;
+  if (int e = h->run_seq("apply", {&h->ops_apply})) return e;
   HIPCHK(hipGetLastError());
   return GRL_OK;
 }
@@ -1272,19 +1299,12 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
-  const bool graph = h->use_graph && !h->prof && h->stream != nullptr;   // the null stream cannot be captured
-  if (graph) {
-    if (idx && !h->graph_explicit) { if (int e = h->capture({&h->ops_grads, &h->ops_apply}, &h->graph_explicit)) return e; }
-    if (!idx && !h->graph_rng) { if (int e = h->capture({&h->ops_rng, &h->ops_grads, &h->ops_apply}, &h->graph_rng)) return e; }
-  }
   for (int s = 0; s < n_steps; ++s) {
-    if (idx) { if (int e = stage_noise(h, idx, eps, s)) return e; }
-    if (graph) {
-      HIPCHK(hipGraphLaunch(idx ? h->graph_explicit : h->graph_rng, h->stream));
+    if (idx) {
+      if (int e = stage_noise(h, idx, eps, s)) return e;
+      if (int e = h->run_seq("full_explicit", {&h->ops_grads, &h->ops_apply})) return e;
     } else {
-      if (!idx) { if (int e = h->run_ops(h->ops_rng)) return e; }
-      if (int e = h->run_ops(h->ops_grads)) return e;
-      if (int e = h->run_ops(h->ops_apply)) return e;
+      if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
     }
   }
   HIPCHK(hipGetLastError());

@@ -1,0 +1,48 @@
+"""Data-parallel SAC update: one process per GPU, per-GPU minibatch fixed, replay sharded by rank
+(each rank samples its own shard), parameters / Adam state / target net replicated.
+
+The only exchange of the path is one all-reduce(sum) of the flat fp32 gradient bucket per update
+(1 342 990 floats = 5.4 MB for depth SAC) issued on the engine's HIP stream through
+``torch.distributed`` (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests), followed by the
+Adam/Polyak kernel with grad_scale = 1/world.  All three SAC losses are batch means, so the mean of
+per-shard gradients equals the gradient of the global batch.
+"""
+import torch
+import torch.distributed as dist
+
+
+def allreduce_mean_scale(world):
+    return 1.0 / float(world)
+
+
+def allreduce_flat_(flat, group=None):
+    """Sum-all-reduce of a flat gradient tensor, in place (one bucket, one collective)."""
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+class DataParallelSac:
+    def __init__(self, engine, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.scale = allreduce_mean_scale(self.world)
+        self.bucket = engine.grad_tensor()
+
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank `src`'s parameters (state arena prefix)."""
+        p = self.eng.state[: self.eng.sizes.n_params]
+        with torch.cuda.stream(self.eng.be.stream):
+            dist.broadcast(p, src=src, group=self.group)
+
+    def train(self, n_steps=1, idx=None, eps=None):
+        for s in range(n_steps):
+            if idx is None:
+                self.eng.compute_grads()
+            else:
+                self.eng.compute_grads(idx[s:s + 1], eps[s:s + 1])
+            with torch.cuda.stream(self.eng.be.stream):
+                allreduce_flat_(self.bucket, self.group)
+            self.eng.apply_grads(self.scale)

@@ -1,0 +1,175 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI of libgrl.so, against the CPU
+oracle on identical seeded minibatches (tolerances: tests/parity_util.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import parity_util as pu
+from grasp_rl import _capi, synthetic
+from grasp_rl.engine import SacEngine
+from oracle import sac as osac
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    "depth_augmented": dict(extractor="augmented", kind="depth", B=6, n_replay=24),
+    "depth_augmented_b64": dict(extractor="augmented", kind="depth", B=64, n_replay=200),
+    "rgbd_augmented": dict(extractor="augmented", kind="rgbd", B=5, n_replay=12),
+    "depth_nature": dict(extractor="nature", kind="depth", B=7, n_replay=16, act_dim=3),
+    "mlp_features": dict(extractor="mlp", B=64, n_replay=256),
+    "mlp_wide_3layer": dict(extractor="mlp", B=33, n_replay=64, layers=(128, 128, 32), obs_dim=37),
+    "depth_no_normalize": dict(extractor="augmented", kind="depth", B=4, n_replay=16, normalize=False),
+    "batch_1": dict(extractor="augmented", kind="depth", B=1, n_replay=3),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_update_matches_oracle(name):
+    case = pu.make_case(n_steps=2, **CASES[name])
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(1, case["idx"][1:2], case["eps"][1:2])
+    pu.compare_params(eng, orc, case["spec"].lr, 2)
+    eng.close()
+
+
+def test_headline_config_b256():
+    """BASELINE config 2: depth 64x64x2, batch 256, layers [64,64], A=5 -- three updates."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=600, n_steps=3)
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(2, case["idx"][1:3], case["eps"][1:3])
+    pu.compare_params(eng, orc, case["spec"].lr, 3)
+    m = eng.metrics()
+    assert abs(m["policy_loss"] - float(ref[2]["policy_loss"])) <= 2e-3 * abs(float(ref[2]["policy_loss"])) + 1e-4
+    eng.close()
+
+
+def test_graph_replay_equals_eager(monkeypatch):
+    case = pu.make_case(extractor="augmented", kind="depth", B=16, n_replay=64, n_steps=4)
+    engs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GRL_NO_GRAPH", flag)
+        eng = pu.engine_setup(case)
+        eng.train(4, case["idx"], case["eps"])
+        engs.append(eng.get_parameters())
+        eng.close()
+    for n in engs[0]:
+        assert np.array_equal(engs[0][n], engs[1][n]), n
+
+
+def test_split_api_equals_fused_and_is_deterministic():
+    case = pu.make_case(extractor="augmented", kind="depth", B=16, n_replay=64, n_steps=3)
+    outs = []
+    for mode in ("fused", "split", "fused"):
+        eng = pu.engine_setup(case)
+        if mode == "fused":
+            eng.train(3, case["idx"], case["eps"])
+        else:
+            for s in range(3):
+                eng.compute_grads(case["idx"][s:s + 1], case["eps"][s:s + 1])
+                eng.apply_grads(1.0)
+        outs.append(eng.get_parameters())
+        eng.close()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+        assert np.array_equal(outs[0][n], outs[2][n]), n
+
+
+def test_device_rng_mode_trains():
+    case = pu.make_case(extractor="augmented", kind="depth", B=32, n_replay=100)
+    eng = pu.engine_setup(case)
+    p0 = eng.get_parameters()
+    eng.train(5)
+    m = eng.metrics()
+    assert all(np.isfinite(v) for v in m.values()), m
+    p1 = eng.get_parameters()
+    assert not np.array_equal(p0["model/pi/cnn1/w:0"], p1["model/pi/cnn1/w:0"])
+    # same seed -> same trajectory
+    eng2 = pu.engine_setup(case)
+    eng2.train(5)
+    p2 = eng2.get_parameters()
+    for n in p1:
+        assert np.array_equal(p1[n], p2[n]), n
+    eng.close(); eng2.close()
+
+
+def test_replay_ring_wraps():
+    case = pu.make_case(extractor="mlp", B=8, n_replay=10, n_steps=1)
+    eng = pu.engine_setup(case)
+    tr = case["tr"]
+    assert eng.replay_size() == 10
+    eng.replay_add(tr["obs"][:4] + 1.0, tr["act"][:4], tr["rew"][:4], tr["next_obs"][:4], tr["done"][:4])
+    assert eng.replay_size() == 10
+    # slots 0..3 were overwritten: sampling index 0 must now see obs+1
+    idx = np.zeros((1, 8), np.int64)
+    eng.train(1, idx, case["eps"][:1])
+    st = case["stats"]
+    want = osac.normalize_obs(tr["obs"][:1] + 1.0, st["mean"], st["var"]).astype(np.float32)
+    got = eng.fetch("feat_pi", (8, 104))[:1, :101]
+    assert np.array_equal(got, want)
+    eng.close()
+
+
+def test_act_matches_oracle():
+    case = pu.make_case(extractor="augmented", kind="depth", B=2, n_replay=4)
+    eng = pu.engine_setup(case)
+    orc = osac.SacOracle(case["spec"], case["params"])
+    st = case["stats"]
+    obs = osac.normalize_obs(case["tr"]["obs"][:3], st["mean"], st["var"]).astype(np.float32)
+    eps = np.random.default_rng(3).standard_normal((3, 5)).astype(np.float32)
+    pu.close(eng.act(obs, True), orc.act(obs, True), what="deterministic action")
+    pu.close(eng.act(obs, False, eps), orc.act(obs, False, eps), what="stochastic action")
+    eng.close()
+
+
+def test_shipped_sac_mlp_weights_on_real_observations():
+    """Golden vectors: the reference's trained SAC-MLP parameters on the two real 101-d observations
+    preserved in its vecnormalize.pkl (tests/golden/oracle_pins.json, made by scripts/make_golden.py)."""
+    pins = json.load(open(os.path.join(GOLD, "oracle_pins.json")))
+    z = np.load(os.path.join(GOLD, "sac_mlp_best_model.npz"))
+    vn = np.load(os.path.join(GOLD, "vecnorm_encoder.npz"))
+    cfg = _capi.make_config("mlp", obs_dim=101, act_dim=5, layers=(64, 64), batch_size=2, replay_capacity=4,
+                            act_batch=2)
+    eng = SacEngine(cfg)
+    eng.set_parameters({k: z[k] for k in z.files})
+    obs = osac.normalize_obs(vn["real_obs"], vn["mean"], vn["var"]).astype(np.float32)
+    a = eng.act(obs, True)
+    pu.close(a, np.asarray(pins["sac_mlp_real_obs"]["det_action"], np.float32), what="golden action")
+    eng.close()
+
+
+def test_autoencoder_features_match_golden():
+    """encoder_files/new_gripper_encoder weights on the six real depth frames."""
+    W = np.load(os.path.join(GOLD, "ae_new_gripper_encoder.npz"))
+    frames = np.load(os.path.join(GOLD, "depth_frames.npz"))["frames"]
+    want = np.load(os.path.join(GOLD, "ae_encodings.npz"))["z"]
+    cfg = _capi.make_config("mlp", obs_dim=101, act_dim=5, batch_size=2, replay_capacity=4, act_batch=6)
+    eng = SacEngine(cfg)
+    order = ["encoder/conv2d_1/kernel", "encoder/conv2d_1/bias", "encoder/conv2d_2/kernel", "encoder/conv2d_2/bias",
+             "encoder/conv2d_3/kernel", "encoder/conv2d_3/bias", "encoder/dense_1/kernel", "encoder/dense_1/bias"]
+    eng.load_encoder([W[k] for k in order])
+    got = eng.encode(frames[..., None])
+    pu.close(got, want, atol=2e-5, rtol=2e-4, what="auto-encoder features")
+    # a single frame through the batch path gives the same row
+    pu.close(eng.encode(frames[2:3, ..., None]), want[2:3], atol=2e-5, rtol=2e-4, what="single frame")
+    eng.close()
+
+
+def test_error_paths():
+    cfg = _capi.make_config("mlp", obs_dim=11, act_dim=3, batch_size=4, replay_capacity=8)
+    eng = SacEngine(cfg)
+    with pytest.raises(_capi.GrlError):
+        eng.train(1)                      # empty replay
+    with pytest.raises(_capi.GrlError):
+        eng.encode(np.zeros((1, 64, 64, 1), np.float32))   # encoder not loaded
+    with pytest.raises(_capi.GrlError):
+        eng.set_parameters({"nope": np.zeros(3)})
+    eng.close()
