@@ -75,7 +75,7 @@ def cpu_baseline(seconds=15.0):
     st = synthetic.load_obs_stats("depth")
     tr = synthetic.make_transitions(1024, "depth", ACT_DIM, 0, st)
     idx, eps = synthetic.make_noise(400, BATCH, ACT_DIM, 1024, 1)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # the small convs stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(cores)
     stats = {"mean": st["mean"], "var": st["var"], "ret_var": st["ret_var"]}
 

@@ -90,6 +90,7 @@ struct ConvBwdClass {
 
 struct Launch {
   int variant;   // 0: P along r, Q along j   1: P along r, Q along r   2: P along i, Q along j
+  int pm = 0, qm = 0, np = 1;   // addressing modes / part count (igemm.h), uniform over a launch
   std::vector<IgemmProb> probs;
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
@@ -524,17 +525,41 @@ struct grl_ctx {
     l->d_probs = upload_vec(wk, l->probs);
     l->d_tiles = upload_vec(wk, tiles);
     launches.push_back(l);
+    // addressing modes are compile-time in the kernel: derive them and insist they are uniform
+    auto pm_of = [](const IgemmProb& p) { return p.p_tab_i ? (p.p_vmask_i ? PM_TABLE_MASK : PM_TABLE) : PM_AFFINE; };
+    auto qm_of = [](const IgemmProb& p) { return p.q_tab_r ? QM_TABLE : QM_AFFINE; };
+    l->pm = pm_of(l->probs[0]);
+    l->qm = qm_of(l->probs[0]);
+    for (auto& p : l->probs)
+      if (pm_of(p) != l->pm || qm_of(p) != l->qm || ((p.p_tab_i != nullptr) != (p.p_tab_r != nullptr))) {
+        fprintf(stderr, "grl: launch '%s' mixes addressing modes\n", tag.c_str());
+        abort();
+      }
+    for (auto& p : l->probs)
+      if (p.p_k0 < p.K) l->np = 3;
     Op op;
     op.tag = tag;
     op.flops = flops;
-    op.run = [l](hipStream_t s) {
+    op.run = [l, tag](hipStream_t s) {
       dim3 grid(l->n_tiles), block(256);
-      if (l->variant == 0)
-        hipLaunchKernelGGL((igemm_kernel<true, true>), grid, block, 0, s, l->d_probs, l->d_tiles);
-      else if (l->variant == 1)
-        hipLaunchKernelGGL((igemm_kernel<true, false>), grid, block, 0, s, l->d_probs, l->d_tiles);
-      else
-        hipLaunchKernelGGL((igemm_kernel<false, true>), grid, block, 0, s, l->d_probs, l->d_tiles);
+      const int key = l->np * 1000 + l->pm * 100 + l->qm * 10 + l->variant;
+#define GRL_IGEMM(PMv, QMv, PR, QJ, NPv) \
+  hipLaunchKernelGGL((igemm_kernel<PMv, QMv, PR, QJ, NPv>), grid, block, 0, s, l->d_probs, l->d_tiles)
+      switch (key) {
+        case 1000: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, true, 1); break;        // dense forward
+        case 3000: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, true, 3); break;        //   ... concatenated input
+        case 1100: GRL_IGEMM(PM_TABLE, QM_AFFINE, true, true, 1); break;         // VALID conv forward
+        case 1200: GRL_IGEMM(PM_TABLE_MASK, QM_AFFINE, true, true, 1); break;    // padded conv forward
+        case 1001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 1); break;       // dense backward-data
+        case 3001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 3); break;       //   ... summed over heads
+        case 1211: GRL_IGEMM(PM_TABLE_MASK, QM_TABLE, true, false, 1); break;    // conv backward-data
+        case 1002: GRL_IGEMM(PM_AFFINE, QM_AFFINE, false, true, 1); break;       // dense weight gradient
+        case 1102: GRL_IGEMM(PM_TABLE, QM_AFFINE, false, true, 1); break;        // conv weight gradient
+        default:
+          fprintf(stderr, "grl: no igemm instantiation for launch '%s' (key %d)\n", tag.c_str(), key);
+          abort();
+      }
+#undef GRL_IGEMM
     };
     ops.push_back(std::move(op));
   }
@@ -836,7 +861,7 @@ int grl_ctx::plan() {
   }
 
   // =============================================================== backward through the two CNNs
-  std::vector<IgemmProb> wg;   // every weight gradient, one launch at the end
+  std::vector<IgemmProb> wg, wgc;   // weight gradients: dense layers / conv layers, launched at the end
   if (cnn) {
     std::vector<ConvBwdClass> bc3 = conv_bwd_tabs(cg[2], B), bc2 = conv_bwd_tabs(cg[1], B);
     {
@@ -863,17 +888,17 @@ int grl_ctx::plan() {
       {
         IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, 96);
         p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wg, p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
+        add_wgrad(wgc, p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
       }
       {
         IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, 16);
         p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wg, p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
+        add_wgrad(wgc, p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
       }
       {
         IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, 8);
         p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wg, p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
+        add_wgrad(wgc, p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
       }
       {
         IgemmProb p = dense_wgrad(a3[n], 1024, 1024, true, dfeat[n], ldf, 512, B, nullptr, 1);
@@ -915,7 +940,8 @@ int grl_ctx::plan() {
   head_wgrads(m_vf, hVF, gVF, feat[1], ldf, F, nullptr, 0, 0, {d_v});
   head_wgrads(m_qf1, hQF1, gQF1, feat[1], ldf, F, act, A, A, {d_qf1});
   head_wgrads(m_qf2, hQF2, gQF2, feat[1], ldf, F, act, A, A, {d_qf2});
-  add_launch(ops_grads, "wgrad", 2, wg);
+  add_launch(ops_grads, "wgrad_conv", 2, wgc);
+  add_launch(ops_grads, "wgrad_dense", 2, wg);
   {
     d_reduces = upload_vec(wk, reduces);
     const int nred = (int)reduces.size();

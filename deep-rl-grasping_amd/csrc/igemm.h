@@ -59,13 +59,35 @@ struct IgemmProb {
   int32_t accumulate;     // += existing c
 };
 
+// Addressing modes are compile-time so the staging code has no branch around any load: every
+// load of a slab is issued back to back (masked lanes read offset 0 and select 0 afterwards) and the
+// compiler needs a single wait per slab.
+#ifndef GRL_HOSTEMU
+// Pointers fetched from a descriptor in memory are generic ("flat") to the compiler; flat loads also
+// count on lgkmcnt, so every LDS wait in the MFMA loop would drain the prefetched slab.  Typing them
+// as global (address space 1) yields global_load / global_store.
+#define GRL_GLOBAL __attribute__((address_space(1)))
+typedef const GRL_GLOBAL float* gcf32;
+typedef GRL_GLOBAL float* gf32;
+typedef const GRL_GLOBAL int32_t* gci32;
+typedef const GRL_GLOBAL uint64_t* gcu64;
+typedef const GRL_GLOBAL uint8_t* gcu8;
+#endif
+enum { PM_AFFINE = 0, PM_TABLE = 1, PM_TABLE_MASK = 2 };
+enum { QM_AFFINE = 0, QM_TABLE = 1 };
+
 #ifdef GRL_HOSTEMU
 // TEST-ONLY reference of the descriptor semantics (see hostemu.h); one call computes one tile.
-template <bool P_CONTIG_R, bool Q_CONTIG_J>
+template <int PM, int QM, bool P_CONTIG_R, bool Q_CONTIG_J, int NP>
 void igemm_kernel(const IgemmProb* probs, const int4* tiles) {
   if (threadIdx.x != 0) return;
   const int4 tl = tiles[blockIdx.x];
   const IgemmProb& pb = probs[tl.x];
+  // the launch-time mode must agree with what the descriptor carries
+  if ((PM != PM_AFFINE) != (pb.p_tab_i != nullptr && pb.p_tab_r != nullptr)) abort();
+  if ((PM == PM_TABLE_MASK) != (pb.p_vmask_i != nullptr)) abort();
+  if ((QM == QM_TABLE) != (pb.q_tab_r != nullptr)) abort();
+  if (NP == 1 && pb.p_k0 < pb.K) abort();   // single-part instantiation given a multi-part problem
   const int r_begin = tl.y * pb.k_chunk, r_end = std::min(pb.K, r_begin + pb.k_chunk);
   float* cbase = pb.c + (long)tl.y * pb.slab_stride;
   for (int i = tl.z * 64; i < std::min(pb.M, tl.z * 64 + 64); ++i)
@@ -101,7 +123,7 @@ void igemm_kernel(const IgemmProb* probs, const int4* tiles) {
     }
 }
 #else
-template <bool P_CONTIG_R, bool Q_CONTIG_J>
+template <int PM, int QM, bool P_CONTIG_R, bool Q_CONTIG_J, int NP>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict__ probs,
                                                    const int4* __restrict__ tiles) {
   constexpr int BI = 64, BJ = 64, BR = 32, LDP = BI + 1, LDQ = BJ + 1;
@@ -111,54 +133,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
 
   // flat tile list: {problem, split, i-tile, j-tile}; heavy problems first (built on the host)
   const int4 tl = tiles[blockIdx.x];
-  const int2 zm = make_int2(tl.x, tl.y);
-  const IgemmProb* __restrict__ pb = probs + zm.x;
+  const IgemmProb* __restrict__ pb = probs + tl.x;
   const int M = pb->M, N = pb->N, K = pb->K;
   const int i0 = tl.z * BI, j0 = tl.w * BJ;
-
-  const int r_begin = zm.y * pb->k_chunk;
+  const int r_begin = tl.y * pb->k_chunk;
   const int r_end = min(K, r_begin + pb->k_chunk);
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wi = wave >> 1, wj = wave & 1;
 
-  // ---- uniform operand descriptors
-  const float* pB0 = pb->p_base[0];
-  const float* pB1 = pb->p_base[1];
-  const float* pB2 = pb->p_base[2];
+  // ---- uniform operand descriptors (NP == 1: single-part problems, no per-element part selects)
+  const gcf32 pB0 = (gcf32)pb->p_base[0];
+  const gcf32 pB1 = (gcf32)pb->p_base[1];
+  const gcf32 pB2 = (gcf32)pb->p_base[2];
   const int pLi0 = pb->p_ld_i[0], pLi1 = pb->p_ld_i[1], pLi2 = pb->p_ld_i[2];
   const int pLr0 = pb->p_ld_r[0], pLr1 = pb->p_ld_r[1], pLr2 = pb->p_ld_r[2];
-  const int pk0 = pb->p_k0, pk1 = pb->p_k1;
-  const int32_t* pTi = pb->p_tab_i;
-  const int32_t* pTr = pb->p_tab_r;
-  const uint64_t* pVm = pb->p_vmask_i;
-  const uint8_t* pTap = pb->p_tap_r;
+  const int pk0 = NP == 1 ? 0x7fffffff : pb->p_k0, pk1 = NP == 1 ? 0x7fffffff : pb->p_k1;
+  const gci32 pTi = (gci32)pb->p_tab_i;
+  const gci32 pTr = (gci32)pb->p_tab_r;
+  const gcu64 pVm = (gcu64)pb->p_vmask_i;
+  const gcu8 pTap = (gcu8)pb->p_tap_r;
   const int ones_i = pb->p_ones_i;
-  const float* qB0 = pb->q_base[0];
-  const float* qB1 = pb->q_base[1];
-  const float* qB2 = pb->q_base[2];
+  const gcf32 qB0 = (gcf32)pb->q_base[0];
+  const gcf32 qB1 = (gcf32)pb->q_base[1];
+  const gcf32 qB2 = (gcf32)pb->q_base[2];
   const int qLr0 = pb->q_ld_r[0], qLr1 = pb->q_ld_r[1], qLr2 = pb->q_ld_r[2];
   const int qLj0 = pb->q_ld_j[0], qLj1 = pb->q_ld_j[1], qLj2 = pb->q_ld_j[2];
-  const int32_t* qTr = pb->q_tab_r;
+  const gci32 qTr = (gci32)pb->q_tab_r;
 
-  // ---- per-thread staging coordinates (8 P elements + 8 Q elements per 32-deep slab)
-  // P: lanes run along r (P_CONTIG_R) or along i.
-  const int p_rl = P_CONTIG_R ? (t & 31) : (t >> 6);   // + 4e when !P_CONTIG_R
-  const int p_il = P_CONTIG_R ? (t >> 5) : (t & 63);   // + 8e when  P_CONTIG_R
-  // Q: lanes run along j (Q_CONTIG_J) or along r.
+  // ---- per-thread staging coordinates: 8 P + 8 Q elements per 32-deep slab.
+  // P: lanes run along r (P_CONTIG_R: one r, rows p_il + 8e) or along i (one row, r = p_rl + 4e).
+  const int p_rl = P_CONTIG_R ? (t & 31) : (t >> 6);
+  const int p_il = P_CONTIG_R ? (t >> 5) : (t & 63);
+  // Q: lanes run along j (Q_CONTIG_J: one column, r = q_rl + 4e) or along r (one r, cols q_jl + 8e).
   const int q_rl = Q_CONTIG_J ? (t >> 6) : (t & 31);
   const int q_jl = Q_CONTIG_J ? (t & 63) : (t >> 5);
+  constexpr int PROWS = P_CONTIG_R ? 8 : 1;
 
-  // rows of P this thread stages are the same for every slab: hoist their row terms
-  int p_rowtab[8];
-  uint64_t p_vm[8];
+  // row terms of the rows this thread stages (fixed for the whole reduction)
+  int p_row[PROWS];
+  uint64_t p_vm[PROWS];
+  bool p_iok[PROWS];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int i = i0 + p_il + (P_CONTIG_R ? 8 * e : 0);
-    p_rowtab[e] = (pTi && i < M) ? pTi[i] : 0;
-    p_vm[e] = (pVm && i < M) ? pVm[i] : ~0ull;
-    if (!P_CONTIG_R) break;   // one row per thread
+  for (int e = 0; e < PROWS; ++e) {
+    const int i = i0 + p_il + 8 * e;
+    p_iok[e] = (i < M) && (i != ones_i);
+    const int ic = i < M ? i : i0;
+    p_row[e] = PM != PM_AFFINE ? pTi[ic] : i;
+    p_vm[e] = PM == PM_TABLE_MASK ? pVm[ic] : ~0ull;
   }
 
   typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -166,58 +189,125 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0.f;
 
-  for (int r0 = r_begin; r0 < r_end; r0 += BR) {
-    float pv[8], qv[8];
-    // ---------------- stage P
+  // The loads of slab k+1 are issued before the MFMAs of slab k and only waited for at the next LDS
+  // write, so L2/HBM latency hides behind the matrix pipe.  The loop is rotated (first trip only
+  // loads) so the staging code exists once.
+  // Loaded values are kept RAW in registers; validity masks are applied only when the slab is
+  // written to LDS on the next trip, so nothing touches a load result before the MFMAs are issued.
+  float pv[8], qv[8];
+  unsigned p_okm = 0, p_onem = 0, q_okm = 0;
+  for (int rr0 = r_begin - BR; rr0 < r_end; rr0 += BR) {
+    if (rr0 >= r_begin) {
+      __syncthreads();   // previous slab fully consumed
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int rl = p_rl + (P_CONTIG_R ? 0 : 4 * e);
-      const int il = p_il + (P_CONTIG_R ? 8 * e : 0);
-      const int r = r0 + rl, i = i0 + il;
-      const int part = (r >= pk0) + (r >= pk1);
-      const float* base = part == 0 ? pB0 : (part == 1 ? pB1 : pB2);
-      const int ldi = part == 0 ? pLi0 : (part == 1 ? pLi1 : pLi2);
-      const int ldr = part == 0 ? pLr0 : (part == 1 ? pLr1 : pLr2);
-      const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
-      bool ok = (r < r_end) && (i < M);
-      const int rc = ok ? r : r_begin;   // keep table reads in range
-      const int colterm = pTr ? pTr[rc] : (rc - rstart) * ldr;
-      const int rowterm = pTi ? p_rowtab[P_CONTIG_R ? e : 0] : i * ldi;
-      if (pVm) ok = ok && ((p_vm[P_CONTIG_R ? e : 0] >> pTap[rc]) & 1ull);
-      float v = 0.f;
-      if (ok && i != ones_i) v = base[(long)rowterm + colterm];
-      if (i == ones_i && r < r_end) v = 1.f;
-      pv[e] = v;
+      for (int e = 0; e < 8; ++e) {
+        const int prl = p_rl + (P_CONTIG_R ? 0 : 4 * e);
+        const int pil = p_il + (P_CONTIG_R ? 8 * e : 0);
+        const float pvv = ((p_okm >> e) & 1u) ? pv[e] : 0.f;
+        Ps[prl * LDP + pil] = ((p_onem >> e) & 1u) ? 1.f : pvv;
+        const int qrl = q_rl + (Q_CONTIG_J ? 4 * e : 0);
+        const int qjl = q_jl + (Q_CONTIG_J ? 0 : 8 * e);
+        Qs[qrl * LDQ + qjl] = ((q_okm >> e) & 1u) ? qv[e] : 0.f;
+      }
+      __syncthreads();
     }
-    // ---------------- stage Q
+    if (rr0 + BR < r_end) {
+      const int r0 = rr0 + BR;
+      p_okm = 0; p_onem = 0; q_okm = 0;
+      // ================= P
+      if (P_CONTIG_R) {
+        const int r = r0 + p_rl;
+        const bool rok = r < r_end;
+        const int rc = rok ? r : r_begin;
+        const int part = NP == 1 ? 0 : (r >= pk0) + (r >= pk1);
+        const gcf32 base = PM != PM_AFFINE ? pB0 : (part == 0 ? pB0 : (part == 1 ? pB1 : pB2));
+        const int ldi = part == 0 ? pLi0 : (part == 1 ? pLi1 : pLi2);
+        const int ldr = part == 0 ? pLr0 : (part == 1 ? pLr1 : pLr2);
+        const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
+        const int colterm = PM != PM_AFFINE ? pTr[rc] : (rc - rstart) * ldr;
+        const int tap = PM == PM_TABLE_MASK ? (int)pTap[rc] : 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int rl = q_rl + (Q_CONTIG_J ? 4 * e : 0);
-      const int jl = q_jl + (Q_CONTIG_J ? 0 : 8 * e);
-      const int r = r0 + rl, j = j0 + jl;
-      const int part = (r >= pk0) + (r >= pk1);
-      const float* base = part == 0 ? qB0 : (part == 1 ? qB1 : qB2);
-      const int ldr = part == 0 ? qLr0 : (part == 1 ? qLr1 : qLr2);
-      const int ldj = part == 0 ? qLj0 : (part == 1 ? qLj1 : qLj2);
-      const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
-      const bool ok = (r < r_end) && (j < N);
-      const int rc = ok ? r : r_begin;
-      const int rowterm = qTr ? qTr[rc] : (rc - rstart) * ldr;
-      float v = 0.f;
-      if (ok) v = base[(long)rowterm + (long)j * ldj];
-      qv[e] = v;
-    }
-    __syncthreads();   // previous slab fully consumed
+        for (int e = 0; e < 8; ++e) {
+          bool ok = rok && p_iok[e];
+          if (PM == PM_TABLE_MASK) ok = ok && ((p_vm[e] >> tap) & 1ull);
+          const long rowterm = PM != PM_AFFINE ? (long)p_row[e] : (long)p_row[e] * ldi;
+          pv[e] = base[ok ? rowterm + colterm : 0l];
+          p_okm |= ok ? (1u << e) : 0u;
+          p_onem |= (i0 + p_il + 8 * e == ones_i && rok) ? (1u << e) : 0u;
+        }
+      } else {
+        int colterm[8];
+        gcf32 base[8];
+        int ldi[8];
+        bool rok[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int prl = p_rl + (P_CONTIG_R ? 0 : 4 * e);
-      const int pil = p_il + (P_CONTIG_R ? 8 * e : 0);
-      Ps[prl * LDP + pil] = pv[e];
-      const int qrl = q_rl + (Q_CONTIG_J ? 4 * e : 0);
-      const int qjl = q_jl + (Q_CONTIG_J ? 0 : 8 * e);
-      Qs[qrl * LDQ + qjl] = qv[e];
+        for (int e = 0; e < 8; ++e) {   // table phase: every lookup issued before any data load
+          const int r = r0 + p_rl + 4 * e;
+          rok[e] = r < r_end;
+          const int rc = rok[e] ? r : r_begin;
+          const int part = NP == 1 ? 0 : (r >= pk0) + (r >= pk1);
+          base[e] = PM != PM_AFFINE ? pB0 : (part == 0 ? pB0 : (part == 1 ? pB1 : pB2));
+          ldi[e] = part == 0 ? pLi0 : (part == 1 ? pLi1 : pLi2);
+          const int ldr = part == 0 ? pLr0 : (part == 1 ? pLr1 : pLr2);
+          const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
+          colterm[e] = PM != PM_AFFINE ? pTr[rc] : (rc - rstart) * ldr;
+          if (PM == PM_TABLE_MASK) rok[e] = rok[e] && ((p_vm[0] >> pTap[rc]) & 1ull);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = rok[e] && p_iok[0];
+          const long rowterm = PM != PM_AFFINE ? (long)p_row[0] : (long)p_row[0] * ldi[e];
+          pv[e] = base[e][ok ? rowterm + colterm[e] : 0l];
+          p_okm |= ok ? (1u << e) : 0u;
+          p_onem |= (i0 + p_il == ones_i && (r0 + p_rl + 4 * e) < r_end) ? (1u << e) : 0u;
+        }
+      }
+      // ================= Q
+      if (Q_CONTIG_J) {
+        const int j = j0 + q_jl;
+        const bool jok = j < N;
+        int rowterm[8];
+        gcf32 base[8];
+        int ldj[8];
+        bool rok[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = r0 + q_rl + 4 * e;
+          rok[e] = r < r_end;
+          const int rc = rok[e] ? r : r_begin;
+          const int part = NP == 1 ? 0 : (r >= pk0) + (r >= pk1);
+          base[e] = part == 0 ? qB0 : (part == 1 ? qB1 : qB2);
+          const int ldr = part == 0 ? qLr0 : (part == 1 ? qLr1 : qLr2);
+          ldj[e] = part == 0 ? qLj0 : (part == 1 ? qLj1 : qLj2);
+          const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
+          rowterm[e] = QM == QM_TABLE ? qTr[rc] : (rc - rstart) * ldr;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = rok[e] && jok;
+          qv[e] = base[e][ok ? (long)rowterm[e] + (long)j * ldj[e] : 0l];
+          q_okm |= ok ? (1u << e) : 0u;
+        }
+      } else {
+        const int r = r0 + q_rl;
+        const bool rok = r < r_end;
+        const int rc = rok ? r : r_begin;
+        const int part = NP == 1 ? 0 : (r >= pk0) + (r >= pk1);
+        const gcf32 base = part == 0 ? qB0 : (part == 1 ? qB1 : qB2);
+        const int ldr = part == 0 ? qLr0 : (part == 1 ? qLr1 : qLr2);
+        const int ldj = part == 0 ? qLj0 : (part == 1 ? qLj1 : qLj2);
+        const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
+        const int rowterm = QM == QM_TABLE ? qTr[rc] : (rc - rstart) * ldr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = j0 + q_jl + 8 * e;
+          const bool ok = rok && (j < N);
+          qv[e] = base[ok ? (long)rowterm + (long)j * ldj : 0l];
+          q_okm |= ok ? (1u << e) : 0u;
+        }
+      }
     }
-    __syncthreads();
+    if (rr0 < r_begin) continue;
     // ---------------- 16 x v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]
     const float* pa = Ps + (lane >> 5) * LDP + wi * 32 + (lane & 31);
     const float* qa = Qs + (lane >> 5) * LDQ + wj * 32 + (lane & 31);
@@ -230,11 +320,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
   }
 
   // ---------------- epilogue: D[row][col], col = lane&31, row = (x&3) + 8*(x>>2) + 4*(lane>>5)
-  float* cbase = pb->c + (long)zm.y * pb->slab_stride;
+  const gf32 cbase = (gf32)(pb->c + (long)tl.y * pb->slab_stride);
   const int ldc = pb->ldc;
-  const int32_t* cT = pb->c_tab_i;
-  const float* bias = pb->bias;
-  const float* rmask = pb->relu_mask;
+  const gci32 cT = (gci32)pb->c_tab_i;
+  const gcf32 bias = (gcf32)pb->bias;
+  const gcf32 rmask = (gcf32)pb->relu_mask;
   const int act = pb->act;
   const float alpha = pb->act_alpha;
   const int accumulate = pb->accumulate;

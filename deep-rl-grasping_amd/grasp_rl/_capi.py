@@ -54,6 +54,10 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise GrlError("libgrl.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    try:   # PyTorch-ROCm bundles its own HIP runtime: load it first so that libgrl.so binds to the
+        import torch  # noqa: F401  same libamdhip64 (two runtimes in one process do not see the GPU)
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, i32, i64, f32p, dp = C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p
     lib.grl_last_error.restype = C.c_char_p

@@ -107,8 +107,10 @@ def compare_first_step(eng, case, d0):
     F = spec.feat_dim
     for name, key in (("feat_pi", "h_pi"), ("feat_vf", "h_c"), ("feat_tgt", "h_tgt")):
         close(eng.fetch(name, (B, ldf))[:, :F], d0[key], what=name)
-    for name in ("mu", "log_std", "pi"):
+    for name in ("mu", "pi"):
         close(eng.fetch(name, (B, A)), d0[name], what=name)
+    # the engine keeps the raw `dense_1` output; the oracle reports it after clip_by_value(-20, 2)
+    close(np.clip(eng.fetch("log_std", (B, A)), osac.LOG_STD_MIN, osac.LOG_STD_MAX), d0["log_std"], what="log_std")
     for name in ("logp", "qf1", "qf2", "v", "v_tgt", "qf1_pi", "qf2_pi"):
         close(eng.fetch(name, (B,)), d0[name], atol=2e-5, rtol=2e-4, what=name)
     m = eng.metrics()
