@@ -346,11 +346,25 @@ struct ReduceDesc {
   float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
 };
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs) {
-  const ReduceDesc d = descs[blockIdx.y];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+// flat work list: block b sums 256 consecutive outputs of descriptor tiles[b].x starting at tiles[b].y
+// (slab loads are independent: unrolled so several are in flight; the add order stays k = 0, 1, ...)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
+                                                          const int2* __restrict__ tiles) {
+  const int2 tl = tiles[blockIdx.x];
+  const ReduceDesc d = descs[tl.x];
+  const int i = tl.y + threadIdx.x;
+  if (i < d.n) {
+    const float* __restrict__ src = d.src + i;
     float s = 0.f;
-    for (int k = 0; k < d.splits; ++k) s += d.src[(long)k * d.slab_stride + i];
+    int k = 0;
+    for (; k + 8 <= d.splits; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * d.slab_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
     d.dst[i] = s;
   }
 }

@@ -944,14 +944,15 @@ int grl_ctx::plan() {
   add_launch(ops_grads, "wgrad_dense", 2, wg);
   {
     d_reduces = upload_vec(wk, reduces);
-    const int nred = (int)reduces.size();
-    int maxn = 1;
-    for (auto& r : reduces) maxn = std::max(maxn, r.n);
-    const int gx = std::min(64, (maxn + 255) / 256);
+    std::vector<int2> rt;
+    for (size_t k = 0; k < reduces.size(); ++k)
+      for (int st0 = 0; st0 < reduces[k].n; st0 += 256) rt.push_back(make_int2((int)k, st0));
+    int2* d_rt = upload_vec(wk, rt);
+    const int ntiles = (int)rt.size();
     ReduceDesc* dr = d_reduces;
     Op op; op.tag = "reduce_slabs";
-    op.run = [dr, nred, gx](hipStream_t s) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, nred), dim3(256), 0, s, dr);
+    op.run = [dr, d_rt, ntiles](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt);
     };
     ops_grads.push_back(op);
   }

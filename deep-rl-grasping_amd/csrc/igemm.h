@@ -196,6 +196,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
   // written to LDS on the next trip, so nothing touches a load result before the MFMAs are issued.
   float pv[8], qv[8];
   unsigned p_okm = 0, p_onem = 0, q_okm = 0;
+  // table entries are fetched one slab ahead so their latency is never exposed
+  constexpr int PCOLS = P_CONTIG_R ? 1 : 8;
+  constexpr int QROWS = Q_CONTIG_J ? 8 : 1;
+  int pcol_nx[PCOLS], ptap_nx = 0, qrow_nx[QROWS];
+#pragma unroll
+  for (int e = 0; e < PCOLS; ++e) {
+    const int r = r_begin + p_rl + 4 * e;
+    pcol_nx[e] = PM != PM_AFFINE ? pTr[r < r_end ? r : r_begin] : 0;
+    if (PM == PM_TABLE_MASK && P_CONTIG_R) ptap_nx = pTap[r < r_end ? r : r_begin];
+  }
+#pragma unroll
+  for (int e = 0; e < QROWS; ++e) {
+    const int r = r_begin + q_rl + 4 * e;
+    qrow_nx[e] = QM == QM_TABLE ? qTr[r < r_end ? r : r_begin] : 0;
+  }
   for (int rr0 = r_begin - BR; rr0 < r_end; rr0 += BR) {
     if (rr0 >= r_begin) {
       __syncthreads();   // previous slab fully consumed
@@ -224,8 +239,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
         const int ldi = part == 0 ? pLi0 : (part == 1 ? pLi1 : pLi2);
         const int ldr = part == 0 ? pLr0 : (part == 1 ? pLr1 : pLr2);
         const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
-        const int colterm = PM != PM_AFFINE ? pTr[rc] : (rc - rstart) * ldr;
-        const int tap = PM == PM_TABLE_MASK ? (int)pTap[rc] : 0;
+        const int colterm = PM != PM_AFFINE ? pcol_nx[0] : (rc - rstart) * ldr;
+        const int tap = PM == PM_TABLE_MASK ? ptap_nx : 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           bool ok = rok && p_iok[e];
@@ -234,6 +249,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
           pv[e] = base[ok ? rowterm + colterm : 0l];
           p_okm |= ok ? (1u << e) : 0u;
           p_onem |= (i0 + p_il + 8 * e == ones_i && rok) ? (1u << e) : 0u;
+        }
+        if (PM != PM_AFFINE) {   // next slab's table entries (issued behind the data loads)
+          const int rn = r + BR, rnc = rn < r_end ? rn : r_begin;
+          pcol_nx[0] = pTr[rnc];
+          if (PM == PM_TABLE_MASK) ptap_nx = pTap[rnc];
         }
       } else {
         int colterm[8];
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
           ldi[e] = part == 0 ? pLi0 : (part == 1 ? pLi1 : pLi2);
           const int ldr = part == 0 ? pLr0 : (part == 1 ? pLr1 : pLr2);
           const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
-          colterm[e] = PM != PM_AFFINE ? pTr[rc] : (rc - rstart) * ldr;
+          colterm[e] = PM != PM_AFFINE ? pcol_nx[P_CONTIG_R ? 0 : e] : (rc - rstart) * ldr;
           if (PM == PM_TABLE_MASK) rok[e] = rok[e] && ((p_vm[0] >> pTap[rc]) & 1ull);
         }
 #pragma unroll
@@ -260,6 +280,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
           pv[e] = base[e][ok ? rowterm + colterm[e] : 0l];
           p_okm |= ok ? (1u << e) : 0u;
           p_onem |= (i0 + p_il == ones_i && (r0 + p_rl + 4 * e) < r_end) ? (1u << e) : 0u;
+        }
+        if (PM != PM_AFFINE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int rn = r0 + BR + p_rl + 4 * e;
+            pcol_nx[P_CONTIG_R ? 0 : e] = pTr[rn < r_end ? rn : r_begin];
+          }
         }
       }
       // ================= Q
@@ -280,13 +307,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
           const int ldr = part == 0 ? qLr0 : (part == 1 ? qLr1 : qLr2);
           ldj[e] = part == 0 ? qLj0 : (part == 1 ? qLj1 : qLj2);
           const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
-          rowterm[e] = QM == QM_TABLE ? qTr[rc] : (rc - rstart) * ldr;
+          rowterm[e] = QM == QM_TABLE ? qrow_nx[Q_CONTIG_J ? e : 0] : (rc - rstart) * ldr;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const bool ok = rok[e] && jok;
           qv[e] = base[e][ok ? (long)rowterm[e] + (long)j * ldj[e] : 0l];
           q_okm |= ok ? (1u << e) : 0u;
+        }
+        if (QM == QM_TABLE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int rn = r0 + BR + q_rl + 4 * e;
+            qrow_nx[Q_CONTIG_J ? e : 0] = qTr[rn < r_end ? rn : r_begin];
+          }
         }
       } else {
         const int r = r0 + q_rl;
@@ -297,13 +331,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
         const int ldr = part == 0 ? qLr0 : (part == 1 ? qLr1 : qLr2);
         const int ldj = part == 0 ? qLj0 : (part == 1 ? qLj1 : qLj2);
         const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
-        const int rowterm = QM == QM_TABLE ? qTr[rc] : (rc - rstart) * ldr;
+        const int rowterm = QM == QM_TABLE ? qrow_nx[0] : (rc - rstart) * ldr;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int j = j0 + q_jl + 8 * e;
           const bool ok = rok && (j < N);
           qv[e] = base[ok ? (long)rowterm + (long)j * ldj : 0l];
           q_okm |= ok ? (1u << e) : 0u;
+        }
+        if (QM == QM_TABLE) {
+          const int rn = r + BR;
+          qrow_nx[0] = qTr[rn < r_end ? rn : r_begin];
         }
       }
     }

@@ -59,6 +59,12 @@ class TorchCudaBackend:
     def synchronize(self):
         self.stream.synchronize()
 
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def as_torch(self, t):
+        return t
+
 
 class SacEngine:
     def __init__(self, cfg, backend=None, lib_path=None, device="cuda:0"):

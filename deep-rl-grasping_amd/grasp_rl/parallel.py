@@ -29,12 +29,12 @@ class DataParallelSac:
         self.group = group
         self.world = dist.get_world_size(group)
         self.scale = allreduce_mean_scale(self.world)
-        self.bucket = engine.grad_tensor()
+        self.bucket = engine.be.as_torch(engine.grad_tensor())
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s parameters (state arena prefix)."""
-        p = self.eng.state[: self.eng.sizes.n_params]
-        with torch.cuda.stream(self.eng.be.stream):
+        p = self.eng.be.as_torch(self.eng.state[: self.eng.sizes.n_params])
+        with self.eng.be.stream_context():
             dist.broadcast(p, src=src, group=self.group)
 
     def train(self, n_steps=1, idx=None, eps=None):
@@ -43,6 +43,6 @@ class DataParallelSac:
                 self.eng.compute_grads()
             else:
                 self.eng.compute_grads(idx[s:s + 1], eps[s:s + 1])
-            with torch.cuda.stream(self.eng.be.stream):
+            with self.eng.be.stream_context():
                 allreduce_flat_(self.bucket, self.group)
             self.eng.apply_grads(self.scale)

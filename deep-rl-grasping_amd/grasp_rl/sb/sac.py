@@ -1,0 +1,332 @@
+"""``SAC`` with the stable-baselines 2.10 constructor / learn / predict / save / load surface that
+/root/reference/manipulation_main/training/sb_helper.py:104-128,175-177,228-247,
+train_stable_baselines.py:96-104, base_callbacks.py:78-117,139-149 and utils.py:65-76 exercise.
+The update itself (replay sampling + normalisation, CNN/MLP forward-backward, losses, Adam, Polyak)
+runs in the HIP engine (grasp_rl.engine.SacEngine -> libgrl.so); this file is the host loop that
+stable-baselines' ``SAC.learn`` implements: act -> env.step -> callbacks -> store
+raw transition -> every ``train_freq`` steps ``gradient_steps`` updates.
+
+Differences to stable-baselines, all opt-in: vectorised envs with ``num_envs > 1`` are accepted
+(stable-baselines 2 asserts a single env); ``ent_coef`` must be 'auto' / 'auto_<init>' and
+``target_update_interval`` 1 (what the reference uses: zip JSON).
+"""
+import time
+from collections import deque
+
+import numpy as np
+
+from .. import _capi
+from ..engine import SacEngine
+from ..init import init_parameters
+from . import logger
+from . import policies as pol
+from . import save_util
+from . import spaces as sp
+from .callbacks import as_callback
+from .vec_env import DummyVecEnv, VecEnv, unwrap_vec_normalize
+
+_POLICY_NAMES = {"MlpPolicy": pol.SacMlpPolicy, "CnnPolicy": pol.SacCnnPolicy, "LnMlpPolicy": pol.SacLnMlpPolicy,
+                 "LnCnnPolicy": pol.SacLnCnnPolicy}
+
+
+class SAC:
+    # tests substitute the g++ emulation build here; the product default needs a HIP device
+    _engine_factory = staticmethod(lambda cfg, device: SacEngine(cfg, device=device))
+
+    def __init__(self, policy, env, gamma=0.99, learning_rate=3e-4, buffer_size=50000, learning_starts=100,
+                 train_freq=1, batch_size=64, tau=0.005, ent_coef="auto", target_update_interval=1,
+                 gradient_steps=1, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
+                 tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False,
+                 seed=None, n_cpu_tf_sess=None, device="cuda:0"):
+        if isinstance(policy, str):
+            if policy not in _POLICY_NAMES:
+                raise ValueError("unknown policy %r" % policy)
+            policy = _POLICY_NAMES[policy]
+        self.policy = policy
+        self.policy_kwargs = {} if policy_kwargs is None else dict(policy_kwargs)
+        self.gamma, self.learning_rate = gamma, learning_rate
+        self.buffer_size, self.learning_starts = int(buffer_size), learning_starts
+        self.train_freq, self.batch_size, self.tau = train_freq, int(batch_size), tau
+        self.ent_coef, self.target_update_interval = ent_coef, target_update_interval
+        self.gradient_steps, self.target_entropy = gradient_steps, target_entropy
+        self.action_noise, self.random_exploration = action_noise, random_exploration
+        self.verbose, self.tensorboard_log = verbose, tensorboard_log
+        self.full_tensorboard_log, self.seed, self.n_cpu_tf_sess = full_tensorboard_log, seed, n_cpu_tf_sess
+        self.device = device
+        self.num_timesteps = 0
+        self.n_updates = 0
+        self.env = None
+        self.observation_space = self.action_space = None
+        self.n_envs = 1
+        self._vectorize_action = True
+        self._vec_normalize_env = None
+        self.engine = None
+        self.episode_reward = None
+        self._rng = np.random.default_rng(seed)
+        if env is not None:
+            self.set_env(env)
+        if _init_setup_model and self.observation_space is not None:
+            self.setup_model()
+
+    # ------------------------------------------------------------------ environment
+    def set_env(self, env):
+        if env is not None and not isinstance(env, VecEnv) and not hasattr(env, "num_envs"):
+            env = DummyVecEnv([lambda: env])
+        if env is not None:
+            if self.observation_space is not None and tuple(env.observation_space.shape) != tuple(self.observation_space.shape):
+                raise ValueError("observation space of the new env does not match the model")
+            self.observation_space, self.action_space = env.observation_space, env.action_space
+            self.n_envs = env.num_envs
+            self._vec_normalize_env = unwrap_vec_normalize(env)
+            if self.engine is not None and self.n_envs > self.engine.cfg.act_batch:
+                raise ValueError("env has more sub-environments than the model was built for")
+        self.env = env
+
+    def get_env(self):
+        return self.env
+
+    def get_vec_normalize_env(self):
+        return self._vec_normalize_env
+
+    # ------------------------------------------------------------------ model
+    def _learning_rate_value(self):
+        lr = self.learning_rate
+        return float(lr(1.0)) if callable(lr) else float(lr)
+
+    def setup_model(self):
+        if not sp.is_box(self.action_space):
+            raise ValueError("SAC needs a continuous (Box) action space")
+        if getattr(self.policy, "layer_norm", False) or self.policy_kwargs.get("layer_norm", False):
+            raise NotImplementedError("layer_norm policies are not implemented in the HIP engine")
+        if self.target_update_interval != 1:
+            raise NotImplementedError("target_update_interval must be 1 (Polyak update fused into the Adam kernel)")
+        ent = self.ent_coef
+        if not (isinstance(ent, str) and ent.startswith("auto")):
+            raise NotImplementedError("only ent_coef='auto' / 'auto_<init>' is implemented")
+        self._ent_init = float(ent.split("_")[1]) if "_" in ent else 1.0
+        extractor, n_direct = pol.extractor_from_kwargs(self.policy, self.policy_kwargs)
+        layers = tuple(self.policy_kwargs.get("layers", (64, 64)))
+        obs_shape = tuple(self.observation_space.shape)
+        act_dim = int(np.prod(self.action_space.shape))
+        if self.target_entropy == "auto":
+            self.target_entropy = -np.prod(self.action_space.shape).astype(np.float32)
+        kw = dict(act_dim=act_dim, layers=layers, batch_size=self.batch_size, act_batch=max(1, self.n_envs),
+                  replay_capacity=self.buffer_size, normalize=self._vec_normalize_env is not None
+                  and (self._vec_normalize_env.norm_obs or self._vec_normalize_env.norm_reward),
+                  gamma=self.gamma, lr=self._learning_rate_value(), tau=self.tau,
+                  target_entropy=float(self.target_entropy), seed=0 if self.seed is None else int(self.seed))
+        if self._vec_normalize_env is not None:
+            vn = self._vec_normalize_env
+            kw.update(clip_obs=vn.clip_obs, clip_reward=vn.clip_reward, norm_eps=vn.epsilon)
+        if extractor == "mlp":
+            if len(obs_shape) != 1:
+                raise ValueError("MlpPolicy expects vector observations, got shape %s" % (obs_shape,))
+            cfg = _capi.make_config("mlp", obs_dim=obs_shape[0], **kw)
+        else:
+            if len(obs_shape) != 3 or obs_shape[0] != 64 or obs_shape[1] != 64:
+                raise ValueError("CnnPolicy expects 64x64xC image observations, got %s" % (obs_shape,))
+            if not sp.has_finite_bounds(self.observation_space) or np.any(self.observation_space.low != 0) \
+                    or np.any(self.observation_space.high != 255):
+                raise NotImplementedError("image observation spaces other than Box(0, 255) are not implemented")
+            cfg = _capi.make_config(extractor, obs_channels=obs_shape[2], n_direct=n_direct, **kw)
+        self._extractor = extractor
+        self.engine = self._engine_factory(cfg, self.device)
+        params = init_parameters(self.engine.table, seed=0 if self.seed is None else int(self.seed))
+        params["model/log_ent_coef:0"] = np.float32(np.log(self._ent_init)).reshape(())
+        self.engine.set_parameters(params)
+        vn = self._vec_normalize_env
+        if vn is not None and vn.norm_obs != vn.norm_reward:
+            raise NotImplementedError("training with norm_obs != norm_reward is not implemented "
+                                      "(the reference trains with both on: sb_helper.py:117-119)")
+
+    def _sync_norm_stats(self):
+        """VecNormalize statistics are updated on the env side every step and read at sample time
+        with their *current* values: push them to the device before updating."""
+        vn = self._vec_normalize_env
+        if vn is None or not self.engine.cfg.normalize:
+            return
+        self.engine.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))
+
+    # ------------------------------------------------------------------ acting
+    def _act(self, obs, deterministic):
+        obs = np.asarray(obs, np.float32)
+        n = obs.shape[0]
+        out = np.empty((n, int(np.prod(self.action_space.shape))), np.float32)
+        cap = self.engine.cfg.act_batch
+        for k0 in range(0, n, cap):
+            chunk = obs[k0:k0 + cap]
+            eps = None if deterministic else self._rng.standard_normal((chunk.shape[0], out.shape[1])).astype(np.float32)
+            out[k0:k0 + cap] = self.engine.act(chunk, deterministic, eps)
+        return out
+
+    def _unscale(self, a):
+        low, high = np.asarray(self.action_space.low, np.float32), np.asarray(self.action_space.high, np.float32)
+        return low + 0.5 * (a + 1.0) * (high - low)
+
+    def _scale(self, a):
+        low, high = np.asarray(self.action_space.low, np.float32), np.asarray(self.action_space.high, np.float32)
+        return 2.0 * (a - low) / (high - low) - 1.0
+
+    def predict(self, observation, state=None, mask=None, deterministic=True):
+        observation = np.asarray(observation)
+        single = observation.shape == tuple(self.observation_space.shape)
+        obs = observation.reshape((-1,) + tuple(self.observation_space.shape))
+        act = self._unscale(self._act(obs, deterministic)).reshape((-1,) + tuple(self.action_space.shape))
+        act = np.clip(act, self.action_space.low, self.action_space.high)
+        return (act[0] if single else act), None
+
+    # ------------------------------------------------------------------ learn
+    def learn(self, total_timesteps, callback=None, log_interval=4, tb_log_name="SAC", reset_num_timesteps=True,
+              replay_wrapper=None):
+        if self.env is None:
+            raise ValueError("learn() needs an environment: pass env to the constructor / load() or call set_env")
+        total_timesteps = int(total_timesteps)
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        callback = as_callback(callback)
+        callback.init_callback(self)
+        eng, vn, N = self.engine, self._vec_normalize_env, self.n_envs
+        episode_rewards = [0.0]
+        episode_successes = []
+        ep_info_buf = deque(maxlen=100)
+        self.episode_reward = np.zeros((N,))
+        n_episodes = 0
+        infos_values = {}
+        start = time.time()
+        writer = None                                    # TensorBoard is not wired; callbacks see None
+        obs = self.env.reset()
+        obs_ = vn.get_original_obs() if vn is not None else obs
+        callback.on_training_start(locals(), globals())
+        callback.on_rollout_start()
+        step = 0
+        while self.num_timesteps < total_timesteps:
+            if self.num_timesteps < self.learning_starts or self._rng.random() < self.random_exploration:
+                unscaled_action = np.stack([np.asarray(self.action_space.sample(), np.float32) for _ in range(N)])
+                action = self._scale(unscaled_action)
+            else:
+                action = self._act(obs, deterministic=False)
+                if self.action_noise is not None:
+                    action = np.clip(action + self.action_noise(), -1, 1)
+                unscaled_action = self._unscale(action)
+            new_obs, reward, done, info = self.env.step(unscaled_action.reshape((N,) + tuple(self.action_space.shape)))
+            self.num_timesteps += N
+            callback.update_locals(locals())
+            if callback.on_step() is False:
+                break
+            if vn is not None:
+                new_obs_, reward_ = vn.get_original_obs(), vn.get_original_reward()
+            else:
+                new_obs_, reward_ = new_obs, reward
+            next_store = np.array(new_obs_, np.float32, copy=True)
+            for i in range(N):                            # an auto-reset env returns the first obs of the next
+                if done[i] and isinstance(info[i], dict) and "terminal_observation" in info[i]:   # episode
+                    next_store[i] = info[i]["terminal_observation"]
+            eng.replay_add(np.asarray(obs_, np.float32), action.reshape(N, -1), np.asarray(reward_, np.float32),
+                           next_store, np.asarray(done, np.float32))
+            obs, obs_ = new_obs, new_obs_
+            for i in range(N):
+                maybe = info[i].get("episode") if isinstance(info[i], dict) else None
+                if maybe is not None:
+                    ep_info_buf.append(maybe)
+                if isinstance(info[i], dict) and info[i].get("is_success") is not None and done[i]:
+                    episode_successes.append(float(info[i]["is_success"]))
+            self.episode_reward += np.asarray(reward_, np.float64).reshape(N)
+            step += 1
+            if step % self.train_freq == 0:
+                callback.on_rollout_end()
+                for _ in range(self.gradient_steps):
+                    if eng.replay_size() < self.batch_size or self.num_timesteps < self.learning_starts:
+                        break
+                    self.n_updates += 1
+                    self._sync_norm_stats()
+                    eng.train(1)
+                if self.n_updates > 0 and (step // self.train_freq) % 50 == 0:
+                    infos_values = eng.metrics()
+                callback.on_rollout_start()
+            episode_rewards[-1] += float(np.asarray(reward_).reshape(N)[0])
+            if done[0]:
+                if self.action_noise is not None:
+                    self.action_noise.reset()
+                episode_rewards.append(0.0)
+                n_episodes += 1
+                if self.verbose >= 1 and log_interval is not None and n_episodes % log_interval == 0:
+                    fps = int(self.num_timesteps / (time.time() - start + 1e-9))
+                    logger.logkv("episodes", n_episodes)
+                    logger.logkv("mean 100 episode reward", round(float(np.mean(episode_rewards[-101:-1])), 1))
+                    if ep_info_buf:
+                        logger.logkv("ep_rewmean", float(np.mean([e["r"] for e in ep_info_buf])))
+                        logger.logkv("eplenmean", float(np.mean([e["l"] for e in ep_info_buf])))
+                    logger.logkv("n_updates", self.n_updates)
+                    logger.logkv("current_lr", self._learning_rate_value())
+                    logger.logkv("fps", fps)
+                    logger.logkv("time_elapsed", int(time.time() - start))
+                    if episode_successes:
+                        logger.logkv("success rate", float(np.mean(episode_successes[-100:])))
+                    for k, v in (infos_values or eng.metrics()).items():
+                        logger.logkv(k, v)
+                    logger.logkv("total timesteps", self.num_timesteps)
+                    logger.dumpkvs()
+        callback.on_training_end()
+        return self
+
+    # ------------------------------------------------------------------ parameters / persistence
+    def get_parameter_list(self):
+        return self.engine.param_names()
+
+    def get_parameters(self):
+        return self.engine.get_parameters()
+
+    def load_parameters(self, load_path_or_dict, exact_match=True):
+        params = load_path_or_dict
+        if isinstance(params, str):
+            _, params = save_util.load_from_zip(params)
+        elif isinstance(params, (list, tuple)):
+            params = dict(zip(self.get_parameter_list(), params))
+        known = set(self.get_parameter_list())
+        unknown = [k for k in params if k not in known]
+        if unknown:
+            raise RuntimeError("load_parameters: unknown parameter(s) %s" % unknown[:5])
+        self.engine.set_parameters(params, exact_match=exact_match)
+
+    def _data(self):
+        return {
+            "learning_rate": self._learning_rate_value(), "buffer_size": self.buffer_size,
+            "learning_starts": self.learning_starts, "train_freq": self.train_freq, "batch_size": self.batch_size,
+            "tau": self.tau, "ent_coef": self.ent_coef if isinstance(self.ent_coef, str) else float(self.ent_coef),
+            "target_entropy": float(self.target_entropy), "gamma": self.gamma, "verbose": self.verbose,
+            "observation_space": self.observation_space, "action_space": self.action_space, "policy": self.policy,
+            "n_envs": self.n_envs, "n_cpu_tf_sess": self.n_cpu_tf_sess, "seed": self.seed,
+            "action_noise": self.action_noise, "random_exploration": self.random_exploration,
+            "_vectorize_action": self._vectorize_action, "policy_kwargs": self.policy_kwargs,
+        }
+
+    def save(self, save_path, cloudpickle=False):
+        return save_util.save_to_zip(save_path, self._data(), self.get_parameters())
+
+    @classmethod
+    def load(cls, load_path, env=None, custom_objects=None, **kwargs):
+        data, params = save_util.load_from_zip(load_path)
+        if "policy_kwargs" in kwargs and kwargs["policy_kwargs"] != data.get("policy_kwargs"):
+            raise ValueError("the specified policy kwargs do not equal the stored policy kwargs")
+        policy = data.get("policy")
+        if policy is None or not isinstance(policy, type):
+            policy = pol.SacCnnPolicy if any("/cnn" in n or "/c1/" in n for n in params) else pol.SacMlpPolicy
+        model = cls(policy=policy, env=None, _init_setup_model=False)
+        for k in ("gamma", "buffer_size", "learning_starts", "train_freq", "batch_size", "tau", "ent_coef", "verbose",
+                  "n_envs", "seed", "random_exploration", "policy_kwargs", "target_entropy"):
+            if k in data and data[k] is not None:
+                setattr(model, k, data[k])
+        if isinstance(data.get("learning_rate"), (int, float)):
+            model.learning_rate = float(data["learning_rate"])
+        model.policy_kwargs = dict(model.policy_kwargs or {})
+        model.target_entropy = float(np.asarray(model.target_entropy)) if model.target_entropy != "auto" else "auto"
+        for k, v in kwargs.items():
+            setattr(model, k, v)
+        model.observation_space, model.action_space = data.get("observation_space"), data.get("action_space")
+        if env is not None:
+            model.set_env(env)
+        if model.observation_space is None or model.action_space is None:
+            raise ValueError("the zip holds no readable spaces; pass env=")
+        model.setup_model()
+        model.load_parameters(params)
+        return model

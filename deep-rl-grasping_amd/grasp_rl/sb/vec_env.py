@@ -1,0 +1,262 @@
+"""Vectorised-environment wrappers with the stable-baselines call surface the reference uses:
+``DummyVecEnv([fn])`` (train_stable_baselines.py:52-54,65-67,86), ``VecNormalize(venv, training=,
+norm_obs=, norm_reward=, clip_obs=)`` + ``.save/.load`` (sb_helper.py:76-78,100-103,117-119,247;
+train_stable_baselines.py:88-91), ``sync_envs_normalization`` (base_callbacks.py:82), ``get_attr``
+(sb_helper.py:42-45), ``envs[0]`` (sb_helper.py:86), ``buf_infos`` (utils.py:76).
+
+VecNormalize arithmetic follows SURVEY.md A.1 (float64 statistics, clip, epsilon 1e-8, discounted
+return for the reward scale); its statistics are what the engine reads at replay-sample time.
+"""
+import copy
+import pickle
+
+import numpy as np
+
+from . import spaces as sp
+from .running_mean_std import RunningMeanStd
+
+
+class VecEnv:
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        pass
+
+    @property
+    def unwrapped(self):
+        return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
+
+
+class DummyVecEnv(VecEnv):
+    """Steps its environments sequentially in this process; resets an env automatically when its
+    episode ends (the terminal observation is kept in info['terminal_observation'])."""
+
+    def __init__(self, env_fns):
+        self.envs = [fn() for fn in env_fns]
+        env = self.envs[0]
+        super().__init__(len(self.envs), env.observation_space, env.action_space)
+        shape = tuple(self.observation_space.shape)
+        dtype = getattr(self.observation_space, "dtype", np.float32)
+        self.buf_obs = np.zeros((self.num_envs,) + shape, dtype=dtype)
+        self.buf_dones = np.zeros((self.num_envs,), dtype=bool)
+        self.buf_rews = np.zeros((self.num_envs,), dtype=np.float32)
+        self.buf_infos = [{} for _ in range(self.num_envs)]
+        self.actions = None
+
+    def step_async(self, actions):
+        self.actions = actions
+
+    def step_wait(self):
+        for i, env in enumerate(self.envs):
+            obs, self.buf_rews[i], self.buf_dones[i], self.buf_infos[i] = env.step(self.actions[i])
+            if self.buf_dones[i]:
+                self.buf_infos[i] = dict(self.buf_infos[i])
+                self.buf_infos[i]["terminal_observation"] = obs
+                obs = env.reset()
+            self.buf_obs[i] = obs
+        return self.buf_obs.copy(), self.buf_rews.copy(), self.buf_dones.copy(), list(self.buf_infos)
+
+    def reset(self):
+        for i, env in enumerate(self.envs):
+            self.buf_obs[i] = env.reset()
+        return self.buf_obs.copy()
+
+    def close(self):
+        for env in self.envs:
+            if hasattr(env, "close"):
+                env.close()
+
+    def render(self, *a, **k):
+        return self.envs[0].render(*a, **k)
+
+    def seed(self, seed=None):
+        return [env.seed(None if seed is None else seed + i) if hasattr(env, "seed") else None
+                for i, env in enumerate(self.envs)]
+
+    def _targets(self, indices):
+        if indices is None:
+            return self.envs
+        if isinstance(indices, int):
+            return [self.envs[indices]]
+        return [self.envs[i] for i in indices]
+
+    def get_attr(self, name, indices=None):
+        return [getattr(e, name) for e in self._targets(indices)]
+
+    def set_attr(self, name, value, indices=None):
+        for e in self._targets(indices):
+            setattr(e, name, value)
+
+    def env_method(self, name, *args, indices=None, **kwargs):
+        return [getattr(e, name)(*args, **kwargs) for e in self._targets(indices)]
+
+
+class VecEnvWrapper(VecEnv):
+    def __init__(self, venv, observation_space=None, action_space=None):
+        self.venv = venv
+        super().__init__(venv.num_envs, observation_space or venv.observation_space,
+                         action_space or venv.action_space)
+
+    def step_async(self, actions):
+        self.venv.step_async(actions)
+
+    def close(self):
+        return self.venv.close()
+
+    def render(self, *a, **k):
+        return self.venv.render(*a, **k)
+
+    def seed(self, seed=None):
+        return self.venv.seed(seed)
+
+    def get_attr(self, name, indices=None):
+        return self.venv.get_attr(name, indices)
+
+    def set_attr(self, name, value, indices=None):
+        return self.venv.set_attr(name, value, indices)
+
+    def env_method(self, name, *args, indices=None, **kwargs):
+        return self.venv.env_method(name, *args, indices=indices, **kwargs)
+
+    def __getattr__(self, name):            # e.g. .envs / .buf_infos of the wrapped DummyVecEnv
+        if name.startswith("__") or name == "venv":
+            raise AttributeError(name)
+        return getattr(self.venv, name)
+
+
+class VecNormalize(VecEnvWrapper):
+    def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
+                 gamma=0.99, epsilon=1e-8):
+        super().__init__(venv)
+        self.obs_rms = RunningMeanStd(shape=tuple(self.observation_space.shape))
+        self.ret_rms = RunningMeanStd(shape=())
+        self.clip_obs, self.clip_reward = clip_obs, clip_reward
+        self.ret = np.zeros(self.num_envs)
+        self.gamma, self.epsilon = gamma, epsilon
+        self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
+        self.old_obs = np.array([])
+        self.old_rews = np.array([])
+
+    # -- pickling: everything but the wrapped env (stable-baselines convention) ------------------
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("venv", "class_attributes", "ret"):
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.venv = None
+
+    def set_venv(self, venv):
+        if self.venv is not None:
+            raise ValueError("this VecNormalize already wraps an environment")
+        VecEnvWrapper.__init__(self, venv)
+        if tuple(self.obs_rms.mean.shape) != tuple(self.observation_space.shape):
+            raise ValueError("venv is incompatible with the saved statistics")
+        self.ret = np.zeros(self.num_envs)
+
+    # -- stepping ---------------------------------------------------------------------------------
+    def step_wait(self):
+        obs, rews, dones, infos = self.venv.step_wait()
+        self.old_obs, self.old_rews = obs, rews
+        if self.training:
+            self.obs_rms.update(obs)
+        obs = self.normalize_obs(obs)
+        if self.training:
+            self.ret = self.ret * self.gamma + rews
+            self.ret_rms.update(self.ret)
+        rews = self.normalize_reward(rews)
+        self.ret[dones] = 0
+        return obs, rews, dones, infos
+
+    def reset(self):
+        obs = self.venv.reset()
+        self.old_obs = obs
+        self.ret = np.zeros(self.num_envs)
+        if self.training:
+            self.obs_rms.update(obs)
+        return self.normalize_obs(obs)
+
+    def normalize_obs(self, obs):
+        if self.norm_obs:
+            obs = np.clip((obs - self.obs_rms.mean) / np.sqrt(self.obs_rms.var + self.epsilon),
+                          -self.clip_obs, self.clip_obs)
+        return obs
+
+    def normalize_reward(self, reward):
+        if self.norm_reward:
+            reward = np.clip(reward / np.sqrt(self.ret_rms.var + self.epsilon), -self.clip_reward, self.clip_reward)
+        return reward
+
+    def get_original_obs(self):
+        return self.old_obs.copy()
+
+    def get_original_reward(self):
+        return self.old_rews.copy()
+
+    # -- persistence --------------------------------------------------------------------------------
+    def save(self, path):
+        with open(path, "wb") as f:
+            pickle.dump(self, f)
+
+    @staticmethod
+    def load(load_path, venv):
+        """Reads both our own pickles and the ones the reference ships under trained_models/ (those name
+        ``stable_baselines...VecNormalize`` / ``RunningMeanStd`` / ``gym.spaces`` classes)."""
+        with open(load_path, "rb") as f:
+            obj = _CompatUnpickler(f).load()
+        if not isinstance(obj, VecNormalize):
+            raise TypeError("%s does not contain a VecNormalize object" % load_path)
+        for rms in (obj.obs_rms, obj.ret_rms):
+            rms.mean = np.asarray(rms.mean, np.float64)
+            rms.var = np.asarray(rms.var, np.float64)
+        obj.venv = None
+        obj.set_venv(venv)
+        return obj
+
+
+class _CompatUnpickler(pickle.Unpickler):
+    _MAP = {
+        ("VecNormalize",): lambda: VecNormalize,
+        ("RunningMeanStd",): lambda: RunningMeanStd,
+        ("Box",): lambda: sp.Box,
+        ("Discrete",): lambda: sp.Discrete,
+    }
+
+    def find_class(self, module, name):
+        if module.startswith("numpy"):
+            for m in (module, module.replace("numpy.core", "numpy._core"), module.replace("numpy._core", "numpy.core")):
+                try:
+                    return super().find_class(m, name)
+                except (ImportError, AttributeError):
+                    continue
+        if module.split(".")[0] in ("stable_baselines", "gym", "gymnasium", "grasp_rl"):
+            if (name,) in self._MAP:
+                return self._MAP[(name,)]()
+        return super().find_class(module, name)
+
+
+def unwrap_vec_normalize(env):
+    while isinstance(env, VecEnvWrapper):
+        if isinstance(env, VecNormalize):
+            return env
+        env = env.venv
+    return None
+
+
+def sync_envs_normalization(env, eval_env):
+    """Copy the running statistics of the training env's VecNormalize into the evaluation env's."""
+    a, b = env, eval_env
+    while isinstance(a, VecEnvWrapper) and isinstance(b, VecEnvWrapper):
+        if isinstance(a, VecNormalize) and isinstance(b, VecNormalize):
+            b.obs_rms = copy.deepcopy(a.obs_rms)
+            b.ret_rms = copy.deepcopy(a.ret_rms)
+        a, b = a.venv, b.venv

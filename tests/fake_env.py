@@ -1,0 +1,66 @@
+"""Stand-in for the reference's PyBullet 'gripper-env-v0' (manipulation_main/gripperEnv/robot.py): same
+observation / action spaces and the attributes sb_helper.py reads (``is_simplified``, ``depth_obs``,
+``full_obs``, ``history``, ``episode_rewards``, ``sr_mean``, ``curriculum``), synthetic dynamics."""
+import numpy as np
+
+from grasp_rl import synthetic
+from grasp_rl.sb.spaces import Box
+
+
+class _Curriculum:
+    _lambda = 0.0
+
+
+class FakeGraspEnv:
+    def __init__(self, kind="depth", episode_len=7, seed=0, vector_dim=None):
+        self._rng = np.random.default_rng(seed)
+        self.vector_dim = vector_dim
+        if vector_dim:
+            self.observation_space = Box(-1.0, 1.0, shape=(vector_dim,), dtype=np.float32)
+            self.depth_obs = self.full_obs = False
+        else:
+            self.stats = synthetic.load_obs_stats(kind)
+            C = self.stats["mean"].shape[-1]
+            self.observation_space = Box(0, 255, shape=(64, 64, C), dtype=np.float32)
+            self.depth_obs, self.full_obs = (kind == "depth"), (kind == "rgbd")
+        self.action_space = Box(-1.0, 1.0, shape=(5,), dtype=np.float32)
+        self.episode_len = episode_len
+        self.episode_step = 0
+        self.episode_rewards = 0.0
+        self.history = []
+        self.sr_mean = 0.0
+        self.curriculum = _Curriculum()
+        self.n_resets = 0
+
+    def is_simplified(self):
+        return False
+
+    def _obs(self):
+        if self.vector_dim:
+            return self._rng.uniform(-1, 1, self.vector_dim).astype(np.float32)
+        m, v = self.stats["mean"], self.stats["var"]
+        o = self._rng.normal(m, np.sqrt(v)).astype(np.float32)
+        o[..., -1] = 0.0
+        o[0, 0, -1] = self._rng.uniform(0, 1)
+        return o
+
+    def reset(self):
+        self.episode_step = 0
+        self.episode_rewards = 0.0
+        self.n_resets += 1
+        return self._obs()
+
+    def step(self, action):
+        assert np.asarray(action).shape == (5,)
+        self.episode_step += 1
+        r = float(-200.0 + 100.0 * np.tanh(np.sum(action)))
+        self.episode_rewards += r
+        done = self.episode_step >= self.episode_len
+        if done:
+            self.history.append(1)
+            self.sr_mean = 1.0
+        return self._obs(), r, done, {"is_success": done, "episode_step": self.episode_step,
+                                      "episode_rewards": self.episode_rewards, "status": 1}
+
+    def close(self):
+        pass

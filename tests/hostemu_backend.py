@@ -23,3 +23,11 @@ class NumpyHostBackend:
 
     def synchronize(self):
         pass
+
+    def stream_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def as_torch(self, a):
+        import torch
+        return torch.from_numpy(a)      # shares memory with the arena: collectives act in place

@@ -1,0 +1,73 @@
+"""Data-parallel path on CPU: 2 processes over gloo, each with its own engine (TEST-ONLY g++ emulation
+build) holding half of the minibatch, one all-reduce of the flat gradient bucket per update
+(grasp_rl.parallel.DataParallelSac).  Must equal one engine updating on the whole minibatch
+(every SAC loss is a batch mean, so the mean of shard gradients is the global gradient)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import parity_util as pu
+from grasp_rl import _capi
+from grasp_rl.parallel import DataParallelSac
+from hostemu_backend import NumpyHostBackend
+
+B, STEPS = 8, 2
+
+
+def _case():
+    return pu.make_case(extractor="augmented", kind="depth", B=B, n_replay=32, n_steps=STEPS)
+
+
+def _shard_cfg(cfg, batch):
+    c = _capi.GrlConfig.from_buffer_copy(cfg)
+    c.batch_size = batch
+    return c
+
+
+def _worker(rank, world, port, lib, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    case = _case()
+    case["cfg"] = _shard_cfg(case["cfg"], B // world)
+    eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=lib)
+    dp = DataParallelSac(eng)
+    if rank != 0:                                  # replicas must start identical: perturb, then broadcast
+        P = eng.get_parameters()
+        P["model/pi/fc0/bias:0"] = P["model/pi/fc0/bias:0"] + 1.0
+        eng.set_parameters(P)
+    dp.broadcast_parameters(src=0)
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+    P = eng.get_parameters()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_single_engine(hostemu_lib, tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, hostemu_lib, str(tmp_path)), nprocs=2, join=True)
+    case = _case()
+    single = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    single.train(STEPS, case["idx"], case["eps"])
+    ref = single.get_parameters()
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    lr = case["spec"].lr
+    for k, v in ref.items():
+        a, b = r0[k.replace("/", "|")], r1[k.replace("/", "|")]
+        assert np.array_equal(a, b), "replicas diverged: " + k
+        d = np.abs(a.astype(np.float64) - v)
+        assert d.max() <= 0.3 * lr * STEPS + 1e-7 and d.mean() <= 0.02 * lr * STEPS + 1e-9, (k, d.max(), d.mean())
+
+
+def test_scale_and_bucket_helpers():
+    from grasp_rl.parallel import allreduce_mean_scale
+    assert allreduce_mean_scale(8) == 0.125

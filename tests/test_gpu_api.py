@@ -1,0 +1,36 @@
+"""The reference's SAC call sequence (tests/test_sb_api_host.py) on the real engine / MI355X."""
+import pytest
+
+import test_sb_api_host as host
+from fake_env import FakeGraspEnv
+from stable_baselines.sac.policies import CnnPolicy as sacCnn
+from stable_baselines.sac.policies import MlpPolicy as sacMlp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sac_cnn_reference_sequence_gpu(tmp_path):
+    kwargs = {"layers": [64, 64], "cnn_extractor": host.create_augmented_nature_cnn(1)}
+    m = host.run_reference_sequence(tmp_path, sacCnn, lambda s: FakeGraspEnv("depth", seed=s), kwargs, batch_size=16,
+                                    total=40)
+    assert m.engine.cfg.extractor == 1
+
+
+def test_sac_mlp_reference_sequence_gpu(tmp_path):
+    kwargs = {"layers": [64, 64], "layer_norm": False}
+    host.run_reference_sequence(tmp_path, sacMlp, lambda s: FakeGraspEnv(seed=s, vector_dim=101), kwargs,
+                                batch_size=16, total=40)
+
+
+def test_vectorised_envs_gpu():
+    """N sub-environments feeding one engine (north_star: vectorised envs fan out across host cores)."""
+    import numpy as np
+    import stable_baselines as sb
+    from stable_baselines.common.vec_env import DummyVecEnv, VecNormalize
+    env = VecNormalize(DummyVecEnv([(lambda s=s: FakeGraspEnv("depth", seed=s)) for s in range(4)]))
+    kwargs = {"layers": [64, 64], "cnn_extractor": host.create_augmented_nature_cnn(1)}
+    model = sb.SAC(sacCnn, env, policy_kwargs=kwargs, buffer_size=256, batch_size=32, learning_starts=16)
+    model.learn(total_timesteps=64)
+    assert model.num_timesteps == 64 and model.engine.replay_size() == 64 and model.n_updates > 0
+    a, _ = model.predict(env.reset(), deterministic=True)
+    assert a.shape == (4, 5) and np.all(np.isfinite(a))

@@ -1,0 +1,173 @@
+"""API-conformance test: replays the call sequence of the reference's SAC branch
+(/root/reference/manipulation_main/training/sb_helper.py:68-128,175-181,228-247 and
+train_stable_baselines.py:75-109 `run`) through the ``stable_baselines`` alias package with a fake
+environment.  On CPU the engine behind the model is the TEST-ONLY g++ emulation build (host logic
+only); tests/test_gpu_api.py runs the same sequence on the MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import stable_baselines as sb
+from fake_env import FakeGraspEnv
+from grasp_rl.engine import SacEngine
+from grasp_rl.sb.sac import SAC
+from hostemu_backend import NumpyHostBackend
+from stable_baselines.bench import Monitor
+from stable_baselines.common.callbacks import BaseCallback, EvalCallback
+from stable_baselines.common.vec_env import DummyVecEnv, VecNormalize
+from stable_baselines.sac.policies import CnnPolicy as sacCnn
+from stable_baselines.sac.policies import MlpPolicy as sacMlp
+
+
+def create_augmented_nature_cnn(num_direct_features):
+    """Same shape as the reference's factory (custom_obs_policy.py:6-44): a closure named
+    ``augmented_nature_cnn`` over ``num_direct_features`` -- recognised, never called."""
+    def augmented_nature_cnn(scaled_images, **kwargs):
+        raise AssertionError("the TF extractor must not be called")
+    assert num_direct_features >= 0
+    return augmented_nature_cnn if num_direct_features is None else _bind(augmented_nature_cnn, num_direct_features)
+
+
+def _bind(fn, n):
+    def augmented_nature_cnn(scaled_images, **kwargs):
+        return fn(scaled_images, n=n, **kwargs)
+    return augmented_nature_cnn
+
+
+class CountingCallback(BaseCallback):
+    def __init__(self):
+        super().__init__()
+        self.steps, self.rollouts, self.started, self.ended = 0, 0, 0, 0
+
+    def _on_training_start(self):
+        self.started += 1
+        assert "writer" in self.locals and self.model is not None and self.training_env is not None
+
+    def _on_rollout_start(self):
+        self.rollouts += 1
+
+    def _on_step(self):
+        self.steps += 1
+        assert self.training_env.get_attr("curriculum")[0]._lambda == 0.0     # sb_helper.py:42-45
+        return True
+
+    def _on_training_end(self):
+        self.ended += 1
+
+
+class SaveVecNormalizeCallback(BaseCallback):        # base_callbacks.py:119-149
+    def __init__(self, path):
+        super().__init__()
+        self.path = path
+
+    def _on_step(self):
+        vn = self.model.get_vec_normalize_env()
+        assert vn is not None
+        vn.save(self.path)
+        return True
+
+
+@pytest.fixture
+def emulated_engine(hostemu_lib, monkeypatch):
+    monkeypatch.setattr(SAC, "_engine_factory",
+                        staticmethod(lambda cfg, device: SacEngine(cfg, backend=NumpyHostBackend(), lib_path=hostemu_lib)))
+
+
+def run_reference_sequence(tmp_path, policy, make_env, policy_kwargs, batch_size=4, total=24):
+    model_dir = str(tmp_path)
+    env = DummyVecEnv([lambda: Monitor(make_env(0), os.path.join(model_dir, "log_file"))])
+    test_env = DummyVecEnv([lambda: make_env(1)])
+    test_env = VecNormalize(test_env, norm_obs=True, norm_reward=False, clip_obs=10.)
+    save_vn = SaveVecNormalizeCallback(os.path.join(model_dir, "best_model_vecnormalize.pkl"))
+    eval_cb = EvalCallback(test_env, best_model_save_path=os.path.join(model_dir, "best_model"),
+                           log_path=os.path.join(model_dir, "best_model", "logs"), eval_freq=10, n_eval_episodes=2,
+                           callback_on_new_best=save_vn, deterministic=True, render=False)
+    assert env.envs[0].depth_obs in (True, False) and not env.envs[0].is_simplified()      # sb_helper.py:86
+    env = VecNormalize(env, norm_obs=True, norm_reward=True, clip_obs=10.)
+    model = sb.SAC(policy, env, policy_kwargs=policy_kwargs, verbose=2, gamma=0.99, buffer_size=64,
+                   batch_size=batch_size, learning_rate=3e-4, tensorboard_log=None, learning_starts=8)
+    counter = CountingCallback()
+    p0 = model.get_parameters()
+    model.learn(total_timesteps=int(str(total)), callback=[counter, eval_cb])
+    assert counter.started == 1 and counter.ended == 1 and counter.steps == total and counter.rollouts >= total
+    assert model.num_timesteps == total and model.n_updates == total - 8 + 1
+    p1 = model.get_parameters()
+    assert any(not np.array_equal(p0[k], p1[k]) for k in p0 if not k.startswith("target"))
+    assert os.path.exists(os.path.join(model_dir, "best_model", "best_model.zip"))
+    assert os.path.exists(os.path.join(model_dir, "best_model", "logs", "evaluations.npz"))
+    assert os.path.exists(os.path.join(model_dir, "best_model_vecnormalize.pkl"))
+    ev = np.load(os.path.join(model_dir, "best_model", "logs", "evaluations.npz"))
+    assert ev["results"].shape[1] == 2 and list(ev["timesteps"]) == [10, 20]
+    # SBPolicy.save (sb_helper.py:228-247)
+    path = os.path.join(model_dir, "SAC_model")
+    model.save(path)
+    model.get_vec_normalize_env().save(os.path.join(model_dir, "vecnormalize.pkl"))
+    with open(os.path.join(model_dir, "log_file.monitor.csv")) as f:
+        lines = f.read().splitlines()
+    assert lines[0].startswith("#{") and lines[1] == "r,l,t" and len(lines) >= 4
+    # `run` (train_stable_baselines.py:75-109)
+    task = DummyVecEnv([lambda: make_env(2)])
+    task = VecNormalize(task, training=False, norm_obs=False, norm_reward=False, clip_obs=10.)
+    task = VecNormalize.load(os.path.join(model_dir, "vecnormalize.pkl"), task)
+    assert task.norm_obs and task.norm_reward and task.obs_rms.count > 20
+    agent = sb.SAC.load(path)
+    obs = task.reset()
+    action = agent.predict(obs, deterministic=True)               # utils.py:71
+    assert action[0].shape == (1, 5) and np.all(np.abs(action[0]) <= 1)
+    assert np.allclose(action[0], model.predict(obs, deterministic=True)[0], atol=1e-6)
+    obs, reward, done, _ = task.step(action[0])
+    assert "episode_step" in task.buf_infos[0]                    # utils.py:76
+    # --load_dir transfer (sb_helper.py:97-115)
+    model2 = sb.SAC(policy, env, policy_kwargs=policy_kwargs, buffer_size=64, batch_size=batch_size)
+    model2.load_parameters(sb.SAC.load(path, env).get_parameters(), exact_match=False)
+    for k, v in model2.get_parameters().items():
+        assert np.array_equal(v, p1[k]), k
+    return model
+
+
+def test_sac_cnn_reference_sequence(tmp_path, emulated_engine):
+    kwargs = {"layers": [64, 64], "cnn_extractor": create_augmented_nature_cnn(1)}
+    m = run_reference_sequence(tmp_path, sacCnn, lambda s: FakeGraspEnv("depth", seed=s), kwargs)
+    assert m.engine.cfg.extractor == 1 and m.engine.cfg.n_direct == 1 and m.engine.cfg.normalize == 1
+
+
+def test_sac_mlp_reference_sequence(tmp_path, emulated_engine):
+    kwargs = {"layers": [64, 64], "layer_norm": False}
+    m = run_reference_sequence(tmp_path, sacMlp, lambda s: FakeGraspEnv(seed=s, vector_dim=101), kwargs, batch_size=8)
+    assert m.engine.cfg.extractor == 0 and m.engine.cfg.obs_dim == 101
+
+
+def test_loads_reference_shipped_artifacts(emulated_engine):
+    """The zip / pickle the reference ships (extracted to tests/golden by scripts/make_golden.py) in
+    stable-baselines' own container format."""
+    import io, json, zipfile
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gold, "sac_mlp_best_model.npz"))
+    from grasp_rl.sb import save_util
+    from grasp_rl.sb.spaces import Box
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        data = {"gamma": 0.99, "batch_size": 64, "buffer_size": 1000, "policy_kwargs": {"layers": [64, 64], "layer_norm": False},
+                "observation_space": Box(-1, 1, shape=(101,)), "action_space": Box(-1, 1, shape=(5,)), "policy": sacMlp,
+                "ent_coef": "auto", "n_envs": 1}
+        path = save_util.save_to_zip(os.path.join(d, "m"), data, {k: z[k] for k in z.files})
+        model = sb.SAC.load(path)
+        P = model.get_parameters()
+        for k in z.files:
+            assert np.array_equal(P[k], z[k]), k
+        pins = json.load(open(os.path.join(gold, "oracle_pins.json")))
+        vn = np.load(os.path.join(gold, "vecnorm_encoder.npz"))
+        obs = np.clip((vn["real_obs"] - vn["mean"]) / np.sqrt(vn["var"] + 1e-8), -10, 10).astype(np.float32)
+        a, _ = model.predict(obs, deterministic=True)
+        assert np.allclose(a, np.asarray(pins["sac_mlp_real_obs"]["det_action"]), atol=2e-5)
+
+
+def test_unsupported_paths_fail_loudly(emulated_engine):
+    env = DummyVecEnv([lambda: FakeGraspEnv(vector_dim=11)])
+    with pytest.raises(NotImplementedError):
+        sb.SAC(sacMlp, env, ent_coef=0.1)
+    with pytest.raises(NotImplementedError):
+        sb.SAC(sacMlp, env, policy_kwargs={"layer_norm": True})
+    with pytest.raises(NotImplementedError):
+        sb.TRPO(None, env)
