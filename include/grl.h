@@ -154,6 +154,8 @@ int64_t grl_debug_fetch(grl_handle h, const char* name, float* out, int64_t cap)
 int grl_profile_enable(grl_handle h, int on);
 /* host: average ms per launch of the kernel tagged `name` since enable; "" lists tags into name_out */
 int grl_profile_query(grl_handle h, const char* name, double* avg_ms, int64_t* launches);
+/* host: one "tag:avg_ms:launches:flops_per_launch:bytes_per_launch" line per profiled tag */
+int grl_profile_dump(grl_handle h, char* buf, int cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,116 @@
+"""The oracle against the golden vectors extracted from the reference's shipped artefacts
+(scripts/make_golden.py) and against closed-form known answers."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import autoencoder as ae
+from oracle import sac as osac
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PINS = json.load(open(os.path.join(GOLD, "oracle_pins.json")))
+
+
+def _mlp_oracle():
+    z = np.load(os.path.join(GOLD, "sac_mlp_best_model.npz"))
+    spec = osac.SacSpec(extractor="mlp", obs_dim=101, act_dim=5, layers=[64, 64])
+    return spec, osac.SacOracle(spec, {k: z[k] for k in z.files}), z
+
+
+def test_parameter_names_match_shipped_zip():
+    spec, _, z = _mlp_oracle()
+    assert list(osac.param_shapes(spec).keys()) == PINS["sac_mlp_zip"]["param_names"] == list(z.files)
+
+
+def test_b5_pins_recorded_by_make_golden():
+    b = PINS["b5_sac_head_wiring"]
+    assert b["corr_V_minQpi"] > 0.95 and b["corr_reversed_concat"] < 0.5 and b["corr_V_Vtarget"] > 0.999
+    for tag, row in PINS["b5_autoencoder_mse"].items():
+        assert row["mse_tf_same_nhwc"] < 0.01 < row["mse_symmetric_pad"], tag
+
+
+def test_sac_mlp_forward_on_real_observations():
+    spec, orc, _ = _mlp_oracle()
+    vn = np.load(os.path.join(GOLD, "vecnorm_encoder.npz"))
+    obs = osac.normalize_obs(vn["real_obs"], vn["mean"], vn["var"]).astype(np.float32)
+    T = orc.tensors()
+    a = osac.actor_fwd(spec, T, torch.from_numpy(obs), torch.zeros(2, 5))
+    c = osac.critic_fwd(spec, T, "model/values_fn", torch.from_numpy(obs), a["det"], a["det"])
+    g = PINS["sac_mlp_real_obs"]
+    assert np.allclose(a["mu"].numpy(), g["mu"], atol=1e-5)
+    assert np.allclose(a["log_std"].numpy(), g["log_std"], atol=1e-5)
+    assert np.allclose(c["v"].numpy(), g["v"], atol=1e-4)
+    assert np.allclose(c["qf1"].numpy(), g["qf1_det"], atol=1e-4)
+    # head roles (B.5): `dense` saturates tanh, `dense_1` is a plausible log-std
+    assert np.abs(np.asarray(g["mu"])).max() > 1.5 and -1.5 < np.asarray(g["log_std"]).min() and np.asarray(g["log_std"]).max() < 0
+
+
+def test_autoencoder_encodings_match_golden():
+    W = np.load(os.path.join(GOLD, "ae_new_gripper_encoder.npz"))
+    frames = np.load(os.path.join(GOLD, "depth_frames.npz"))["frames"]
+    want = np.load(os.path.join(GOLD, "ae_encodings.npz"))["z"]
+    got = ae.encode({k: W[k] for k in W.files}, frames[..., None])
+    assert got.shape == (6, 100) and np.allclose(got, want, atol=1e-6)
+
+
+def test_tf_same_padding_is_asymmetric():
+    assert ae.tf_same_pad(64, 7, 2) == (2, 3) and ae.tf_same_pad(32, 5, 2) == (1, 2) and ae.tf_same_pad(16, 3, 2) == (0, 1)
+    assert ae.tf_same_pad(8, 3, 1) == (1, 1)
+
+
+def test_tf_adam_known_answer():
+    """First TF-Adam step with g != 0 moves by lr*g/(|g| + eps*sqrt(1-b2)^-1...) ~ lr (A.5)."""
+    P = {"w": np.array([1.0, -2.0, 0.5], np.float32)}
+    st = osac.adam_init(P, ["w"])
+    g = np.array([0.3, -1e-3, 0.0], np.float32)
+    osac.adam_apply(P, {"w": g}, st, lr=1e-2)
+    alpha = np.float32(1e-2) * np.sqrt(np.float32(1 - 0.999)) / np.float32(1 - 0.9)
+    m, v = 0.1 * g, 0.001 * g * g
+    want = np.array([1.0, -2.0, 0.5], np.float32) - alpha * m / (np.sqrt(v) + 1e-8)
+    assert np.allclose(P["w"], want, rtol=1e-6) and P["w"][2] == 0.5
+    assert np.isclose(st["beta1_power"], 0.81) and np.isclose(st["beta2_power"], 0.998001)
+
+
+def test_running_mean_std_equals_batch_statistics():
+    rng = np.random.default_rng(0)
+    x = rng.normal(3.0, 2.0, (500, 4))
+    mean, var, cnt = np.zeros(4), np.ones(4), 1e-4
+    for chunk in np.split(x, 10):
+        mean, var, cnt = osac.rms_update(mean, var, cnt, chunk)
+    assert np.allclose(mean, x.mean(0), atol=1e-5) and np.allclose(var, x.var(0), atol=1e-4)
+
+
+def test_normalisation_clips_and_uses_current_statistics():
+    z = osac.normalize_obs(np.array([100.0, -100.0, 1.0]), np.zeros(3), np.ones(3))
+    assert list(z) == [10.0, -10.0, 1.0 / np.sqrt(1 + 1e-8)]
+    assert osac.normalize_reward(np.array([1e9]), 4.0)[0] == 10.0
+
+
+def test_losses_and_update_order_on_tiny_case():
+    """policy loss uses qf1_pi (not the min), v_backup uses the min; all three gradient sets come from
+    one forward pass at the pre-update parameters (A.4)."""
+    spec = osac.SacSpec(extractor="mlp", obs_dim=6, act_dim=2, layers=[8])
+    orc = osac.SacOracle(spec, seed=3)
+    rng = np.random.default_rng(1)
+    batch = {"obs": torch.from_numpy(rng.normal(size=(5, 6)).astype(np.float32)),
+             "next_obs": torch.from_numpy(rng.normal(size=(5, 6)).astype(np.float32)),
+             "act": torch.from_numpy(rng.uniform(-1, 1, (5, 2)).astype(np.float32)),
+             "rew": torch.from_numpy(rng.normal(size=5).astype(np.float32)),
+             "done": torch.from_numpy(np.array([0, 1, 0, 0, 1], np.float32))}
+    eps = rng.standard_normal((5, 2)).astype(np.float32)
+    out, G = orc.grads(batch, eps)
+    alpha = float(out["ent_coef"])
+    lp = out["logp"].detach().numpy()
+    assert np.isclose(float(out["policy_loss"]), np.mean(alpha * lp - out["qf1_pi"].detach().numpy()), atol=1e-6)
+    vb = np.minimum(out["qf1_pi"].detach().numpy(), out["qf2_pi"].detach().numpy()) - alpha * lp
+    assert np.allclose(out["v_backup"].numpy(), vb, atol=1e-6)
+    qb = batch["rew"].numpy() + (1 - batch["done"].numpy()) * spec.gamma * out["v_tgt"].detach().numpy()
+    assert np.allclose(out["q_backup"].numpy(), qb, atol=1e-6)
+    assert np.isclose(G["model/log_ent_coef:0"], -np.mean(lp + spec.target_entropy), atol=1e-6)
+    before = {k: v.copy() for k, v in orc.P.items()}
+    orc.step(batch, eps)
+    tau = spec.tau
+    for t, s in osac.polyak_pairs(spec):               # target uses the POST-update source
+        assert np.allclose(orc.P[t], (1 - tau) * before[t] + tau * orc.P[s], atol=1e-7)
