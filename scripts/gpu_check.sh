@@ -9,7 +9,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> $LOG 2>&1
 echo "smoke rc=$?" >> $LOG
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
 echo "== pytest" >> $LOG
-timeout 1200 python -m pytest tests -m gpu -q ${PYTEST_ARGS:--x} --timeout 600 >> $LOG 2>&1
+timeout 1200 python -m pytest tests -m gpu -q ${PYTEST_ARGS--x} --timeout 600 >> $LOG 2>&1
 echo "pytest rc=$?" >> $LOG
 fi
 echo "== bench" >> $LOG

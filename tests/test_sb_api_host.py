@@ -91,7 +91,7 @@ def run_reference_sequence(tmp_path, policy, make_env, policy_kwargs, batch_size
     p0 = model.get_parameters()
     model.learn(total_timesteps=int(str(total)), callback=[counter, eval_cb])
     assert counter.started == 1 and counter.ended == 1 and counter.steps == total and counter.rollouts >= total
-    assert model.num_timesteps == total and model.n_updates == total - 8 + 1
+    assert model.num_timesteps == total and model.n_updates == total - max(8, batch_size) + 1   # can_sample + learning_starts
     p1 = model.get_parameters()
     assert any(not np.array_equal(p0[k], p1[k]) for k in p0 if not k.startswith("target"))
     assert os.path.exists(os.path.join(model_dir, "best_model", "best_model.zip"))
