@@ -341,6 +341,154 @@ __global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) {
 #endif  // GRL_HOSTEMU
 
 // ------------------------------------------------------------------------------------------------
+// DQN / BDQ: dueling aggregation per branch, double-Q target averaged over branches,
+// Huber (DQN) or squared (BDQ) TD loss with importance weights, gradients w.r.t. the advantage /
+// value outputs of the online net, TD errors and priorities for prioritised replay.
+struct QLossArgs {
+  int B, D, n;               // rows, branches, bins per branch
+  float gamma, lr;
+  int huber, double_q;
+  const float* adv0; const float* v0;     // online(s)      [B, D*n], [B]
+  const float* adv1;                      // online(s')     (argmax; v and mean do not change it)
+  const float* adv2; const float* v2;     // target(s')
+  const float* act;                       // [B, D] bin indices stored as floats
+  const float* rew; const float* done; const float* weights;   // [B]
+  float* d_adv0; float* d_v0;             // gradients [B, D*n], [B]
+  float* td; float* priority;             // [B, D], [B]
+  DevScalars* sc;
+};
+
+__device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3) {
+  const int D = a.D, n = a.n;
+  const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
+  float qbest = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float* sel = (a.double_q ? a.adv1 : a.adv2) + ((long)b * D + d) * n;
+    const float* tg = a.adv2 + ((long)b * D + d) * n;
+    int best = 0;
+    float bv = sel[0], mean2 = 0.f;
+    for (int k = 0; k < n; ++k) {
+      if (sel[k] > bv) { bv = sel[k]; best = k; }
+      mean2 += tg[k];
+    }
+    qbest += a.v2[b] + tg[best] - mean2 * invn;
+  }
+  qbest *= invD;
+  const float y = a.rew[b] + a.gamma * (1.f - a.done[b]) * qbest;
+  const float w = a.weights[b];
+  float dv = 0.f, prio = 0.f, lossb = 0.f, qs = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float* ad = a.adv0 + ((long)b * D + d) * n;
+    float mean0 = 0.f;
+    for (int k = 0; k < n; ++k) mean0 += ad[k];
+    mean0 *= invn;
+    const int ai = (int)a.act[b * D + d];
+    const float q_sel = a.v0[b] + ad[ai] - mean0;
+    const float tdv = q_sel - y;
+    a.td[b * D + d] = tdv;
+    prio += fabsf(tdv);
+    qs += q_sel;
+    float err, dfd;
+    if (a.huber) {
+      const float at = fabsf(tdv);
+      err = at < 1.f ? 0.5f * tdv * tdv : at - 0.5f;
+      dfd = fminf(fmaxf(tdv, -1.f), 1.f);
+    } else {
+      err = tdv * tdv;
+      dfd = 2.f * tdv;
+    }
+    lossb += err;
+    const float g = w * invB * invD * dfd;
+    dv += g;
+    float* ga = a.d_adv0 + ((long)b * D + d) * n;
+    for (int k = 0; k < n; ++k) ga[k] = g * ((k == ai ? 1.f : 0.f) - invn);
+  }
+  a.d_v0[b] = dv;
+  a.priority[b] = prio;
+  s3[0] += w * lossb * invD;
+  s3[1] += qs * invD;
+  s3[2] += prio * invD;
+}
+
+__device__ __forceinline__ void q_loss_finish(const QLossArgs& a, float loss, float qm, float tdm) {
+  DevScalars* sc = a.sc;
+  const float invB = 1.f / (float)a.B;
+  sc->policy_loss = loss * invB;     // reported as the TD loss
+  sc->mean_qf1 = qm * invB;
+  sc->value_loss = tdm * invB;       // mean |td|
+  sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+  sc->beta1_power *= 0.9f;
+  sc->beta2_power *= 0.999f;
+}
+
+#ifdef GRL_HOSTEMU
+inline void q_loss_kernel(QLossArgs a) {
+  if (threadIdx.x != 0) return;
+  float s3[3] = {0, 0, 0};
+  for (int b = 0; b < a.B; ++b) q_loss_row(a, b, s3);
+  q_loss_finish(a, s3[0], s3[1], s3[2]);
+}
+#else
+__global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
+  __shared__ float red[3][256];
+  const int t = threadIdx.x;
+  float s3[3] = {0, 0, 0};
+  for (int b = t; b < a.B; b += 256) q_loss_row(a, b, s3);
+  for (int k = 0; k < 3; ++k) red[k][t] = s3[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off)
+      for (int k = 0; k < 3; ++k) red[k][t] += red[k][t + off];
+    __syncthreads();
+  }
+  if (t == 0) q_loss_finish(a, red[0][0], red[1][0], red[2][0]);
+}
+#endif
+
+// tf.clip_by_norm per variable: g <- g * clip / max(||g||, clip); one workgroup per variable
+struct VarSeg { int64_t off; int64_t n; };
+
+#ifdef GRL_HOSTEMU
+inline void clip_by_norm_kernel(float* grads, const VarSeg* segs, float clip) {
+  if (threadIdx.x != 0) return;
+  const VarSeg sg = segs[blockIdx.x];
+  float ss = 0.f;
+  for (int64_t i = 0; i < sg.n; ++i) ss += grads[sg.off + i] * grads[sg.off + i];
+  const float sc = clip / fmaxf(sqrtf(ss), clip);
+  for (int64_t i = 0; i < sg.n; ++i) grads[sg.off + i] *= sc;
+}
+#else
+__global__ __launch_bounds__(256) void clip_by_norm_kernel(float* grads, const VarSeg* segs, float clip) {
+  __shared__ float red[256];
+  const VarSeg sg = segs[blockIdx.x];
+  const int t = threadIdx.x;
+  float ss = 0.f;
+  for (int64_t i = t; i < sg.n; i += 256) { const float g = grads[sg.off + i]; ss += g * g; }
+  red[t] = ss;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) red[t] += red[t + off];
+    __syncthreads();
+  }
+  const float sc = clip / fmaxf(sqrtf(red[0]), clip);
+  for (int64_t i = t; i < sg.n; i += 256) grads[sg.off + i] *= sc;
+}
+#endif
+
+// Q-values of the act path: q[b, d, k] = v[b] + adv[b, d, k] - mean_k adv[b, d, :]
+__global__ __launch_bounds__(256) void dueling_kernel(const float* adv, const float* v, int rows, int D, int n,
+                                                     float* q) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * D) return;
+  const int b = i / D;
+  const float* a = adv + (long)i * n;
+  float m = 0.f;
+  for (int k = 0; k < n; ++k) m += a[k];
+  m /= (float)n;
+  for (int k = 0; k < n; ++k) q[(long)i * n + k] = v[b] + a[k] - m;
+}
+
+// ------------------------------------------------------------------------------------------------
 // sum split slabs of weight gradients into the flat gradient bucket
 struct ReduceDesc {
   float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
@@ -445,6 +593,11 @@ __global__ __launch_bounds__(256) void rng_kernel(RngArgs a) {
 }
 
 __global__ void rng_tick_kernel(DevScalars* sc) { sc->rng_step += 1; }
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
 
 // final tanh of the act path: a = deterministic ? tanh(mu) : tanh(mu + exp(clip(ls)) * eps)
 __global__ __launch_bounds__(256) void act_out_kernel(const float* mu, const float* ls_raw,

@@ -601,6 +601,12 @@ struct grl_ctx {
   }
 
   int plan();          // lays everything out in the arenas and builds the launch plans
+  int plan_sac();
+  int plan_q();        // DQN / BDQ (MLP towers, dueling, double-Q)
+  // Q-learning state
+  int qD = 0, qN = 0;
+  float *q_td = nullptr, *q_prio = nullptr, *q_aout = nullptr;
+  int64_t q_online_off = 0, q_online_n = 0;
   int run_ops(std::vector<Op>& ops);
   int capture(std::vector<std::vector<Op>*> seq, hipGraphExec_t* out);
 };
@@ -614,7 +620,9 @@ static ConvGeom cnn_geom(int l, int C_img) {
 }
 
 // --------------------------------------------------------------------------------------------------
-int grl_ctx::plan() {
+int grl_ctx::plan() { return cfg.algo == GRL_ALGO_SAC ? plan_sac() : plan_q(); }
+
+int grl_ctx::plan_sac() {
   const grl_config& c = cfg;
   cnn = c.extractor != GRL_EXTRACTOR_MLP;
   A = c.act_dim; L = c.n_layers; B = c.batch_size; NA = std::max(1, c.act_batch);
@@ -1058,6 +1066,347 @@ int grl_ctx::plan() {
   return GRL_OK;
 }
 
+// --------------------------------------------------------------------------------------------------
+// DQN (sb_helper.py:159-165) and BDQ (sb_helper.py:210-224): MLP towers on vector observations.
+// One structure covers both: optional shared trunk -> D advantage branches + a state
+// value tower, dueling aggregation per branch, double-Q target averaged over branches.
+namespace {
+struct QNetP {
+  std::vector<int64_t> cw, cb;                    // trunk
+  std::vector<std::vector<int64_t>> bw, bb;       // [branch][hidden..., out]
+  std::vector<int64_t> vw, vb;                    // value tower [hidden..., out]
+};
+struct QNetAct {
+  std::vector<float*> zc;
+  std::vector<std::vector<float*>> zb;
+  float* adv = nullptr;
+  std::vector<float*> zv;
+  float* v = nullptr;
+};
+}  // namespace
+
+int grl_ctx::plan_q() {
+  const grl_config& c = cfg;
+  cnn = false;
+  const int D = c.q_branches, nb = c.q_bins, Lc = c.q_n_common, Lb = c.q_n_branch, Lv = c.q_n_value;
+  qD = D; qN = nb;
+  A = D; L = 0; B = c.batch_size; NA = std::max(1, c.act_batch);
+  img_elems = c.obs_dim; F = c.obs_dim; Fc = 0; ldf = (int)rup(F, 4); C_img = 0; hw = c.img_hw;
+  const std::string scope = c.algo == GRL_ALGO_DQN ? "deepq" : "bdq";
+  auto fcname = [](int k) { return k == 0 ? std::string("fully_connected") : "fully_connected_" + std::to_string(k); };
+
+  // ---------------- layout (TF creation order of the shipped zips)
+  add_var(scope + "/eps:0", {}, false);   // exploration epsilon: stored with the model, never trained
+  auto add_net = [&](const std::string& pre, QNetP& P, bool tr) {
+    int d = c.obs_dim;
+    for (int k = 0; k < Lc; ++k) {
+      P.cw.push_back(add_var(pre + "/common_net/" + fcname(k) + "/weights:0", {d, c.q_common[k]}, tr));
+      P.cb.push_back(add_var(pre + "/common_net/" + fcname(k) + "/biases:0", {c.q_common[k]}, tr));
+      d = c.q_common[k];
+    }
+    int k = 0;
+    P.bw.resize(D); P.bb.resize(D);
+    for (int br = 0; br < D; ++br) {
+      int dd = d;
+      for (int l = 0; l < Lb; ++l, ++k) {
+        P.bw[br].push_back(add_var(pre + "/action_value/" + fcname(k) + "/weights:0", {dd, c.q_branch[l]}, tr));
+        P.bb[br].push_back(add_var(pre + "/action_value/" + fcname(k) + "/biases:0", {c.q_branch[l]}, tr));
+        dd = c.q_branch[l];
+      }
+      P.bw[br].push_back(add_var(pre + "/action_value/" + fcname(k) + "/weights:0", {dd, nb}, tr));
+      P.bb[br].push_back(add_var(pre + "/action_value/" + fcname(k) + "/biases:0", {nb}, tr));
+      ++k;
+    }
+    int dd = d;
+    for (int l = 0; l < Lv; ++l) {
+      P.vw.push_back(add_var(pre + "/state_value/" + fcname(l) + "/weights:0", {dd, c.q_value[l]}, tr));
+      P.vb.push_back(add_var(pre + "/state_value/" + fcname(l) + "/biases:0", {c.q_value[l]}, tr));
+      dd = c.q_value[l];
+    }
+    P.vw.push_back(add_var(pre + "/state_value/" + fcname(Lv) + "/weights:0", {dd, 1}, tr));
+    P.vb.push_back(add_var(pre + "/state_value/" + fcname(Lv) + "/biases:0", {1}, tr));
+  };
+  QNetP Pon, Ptg;
+  q_online_off = n_params;
+  add_net(scope + "/model", Pon, true);
+  q_online_n = n_params - q_online_off;
+  n_train = n_params;       // eps sits inside the bucket with a permanently zero gradient
+  tgt_off = n_params;
+  add_net(scope + "/target_q_func/model", Ptg, false);
+  vf_off = 0; n_polyak = 0; ent_off = 0;
+
+  // ---------------- arenas
+  params = st.f32(n_params);
+  adam_m = st.f32(n_train);
+  adam_v = st.f32(n_train);
+  sc = (DevScalars*)st.take(sizeof(DevScalars));
+  s_mean = (double*)st.take((size_t)img_elems * 8);
+  s_std = (double*)st.take((size_t)img_elems * 8);
+  s_dmean = (double*)st.take(8); s_dstd = (double*)st.take(8);
+  s_ret = (double*)st.take(8);
+  grads = gr.f32(n_train);
+  const int64_t cap = c.replay_capacity;
+  rp_obs = rp.f32(cap * img_elems); rp_next = rp.f32(cap * img_elems);
+  rp_dobs = rp.f32(cap); rp_dnext = rp.f32(cap);
+  rp_act = rp.f32(cap * A); rp_rew = rp.f32(cap); rp_done = rp.f32(cap);
+  stg_n = std::max(NA, 64);
+  stg_obs = wk.f32((int64_t)stg_n * c.obs_dim); stg_next = wk.f32((int64_t)stg_n * c.obs_dim);
+  stg_act = wk.f32((int64_t)stg_n * A); stg_rew = wk.f32(stg_n); stg_done = wk.f32(stg_n);
+  idx_buf = (int64_t*)wk.take((size_t)B * 8);
+  eps_buf = wk.f32(std::max(B, B * A));      // importance weights [B]
+  for (int n = 0; n < 3; ++n) feat[n] = wk.f32((int64_t)B * ldf);
+  act = wk.f32((int64_t)B * A); rew = wk.f32(B); done = wk.f32(B);
+
+  auto alloc_net = [&](QNetAct& a, int rows) {
+    for (int k = 0; k < Lc; ++k) a.zc.push_back(wk.f32((int64_t)rows * c.q_common[k]));
+    a.zb.resize(D);
+    for (int br = 0; br < D; ++br)
+      for (int l = 0; l < Lb; ++l) a.zb[br].push_back(wk.f32((int64_t)rows * c.q_branch[l]));
+    a.adv = wk.f32((int64_t)rows * D * nb);
+    for (int l = 0; l < Lv; ++l) a.zv.push_back(wk.f32((int64_t)rows * c.q_value[l]));
+    a.v = wk.f32(rows);
+  };
+  QNetAct net[3], gact, aact;           // online(s), online(s'), target(s'); gradients; act path
+  for (int n = 0; n < 3; ++n) alloc_net(net[n], B);
+  alloc_net(gact, B);                   // same shapes: gradient w.r.t. each pre-activation
+  q_td = wk.f32((int64_t)B * D); q_prio = wk.f32(B);
+  const float* P = params;
+  const int hdim = Lc > 0 ? c.q_common[Lc - 1] : c.obs_dim;
+
+  // forward stages of one net
+  auto fwd_stages = [&](const QNetP& W, const QNetAct& a, const float* x, int ldx, int rows,
+                        std::vector<std::vector<IgemmProb>>& st_common, std::vector<std::vector<IgemmProb>>& st_hidden,
+                        std::vector<IgemmProb>& st_out) {
+    const float* in = x; int ldin = ldx, kin = c.obs_dim;
+    st_common.resize(Lc);
+    for (int k = 0; k < Lc; ++k) {
+      st_common[k].push_back(dense_fwd(in, ldin, kin, nullptr, 0, 0, rows, P + W.cw[k], c.q_common[k], P + W.cb[k],
+                                       a.zc[k], c.q_common[k], ACT_RELU));
+      in = a.zc[k]; ldin = kin = c.q_common[k];
+    }
+    const float* h = in; const int ldh = ldin;
+    st_hidden.resize(std::max(Lb, Lv));
+    for (int br = 0; br < D; ++br) {
+      const float* z = h; int ldz = ldh, kz = hdim;
+      for (int l = 0; l < Lb; ++l) {
+        st_hidden[l].push_back(dense_fwd(z, ldz, kz, nullptr, 0, 0, rows, P + W.bw[br][l], c.q_branch[l],
+                                         P + W.bb[br][l], a.zb[br][l], c.q_branch[l], ACT_RELU));
+        z = a.zb[br][l]; ldz = kz = c.q_branch[l];
+      }
+      st_out.push_back(dense_fwd(z, ldz, kz, nullptr, 0, 0, rows, P + W.bw[br][Lb], nb, P + W.bb[br][Lb],
+                                 a.adv + br * nb, D * nb, ACT_NONE));
+    }
+    const float* z = h; int ldz = ldh, kz = hdim;
+    for (int l = 0; l < Lv; ++l) {
+      st_hidden[l].push_back(dense_fwd(z, ldz, kz, nullptr, 0, 0, rows, P + W.vw[l], c.q_value[l], P + W.vb[l],
+                                       a.zv[l], c.q_value[l], ACT_RELU));
+      z = a.zv[l]; ldz = kz = c.q_value[l];
+    }
+    st_out.push_back(dense_fwd(z, ldz, kz, nullptr, 0, 0, rows, P + W.vw[Lv], 1, P + W.vb[Lv], a.v, 1, ACT_NONE));
+  };
+
+  // =============================================================== RNG (uniform indices; weights = 1)
+  {
+    Op op; op.tag = "rng";
+    RngArgs ra{sc, c.seed, B, 1, idx_buf, eps_buf};
+    float* wbuf = eps_buf; const int Bq = B;
+    op.run = [ra, wbuf, Bq](hipStream_t s) {
+      hipLaunchKernelGGL(rng_kernel, dim3((ra.B + 255) / 256), dim3(256), 0, s, ra);
+      hipLaunchKernelGGL(fill_kernel, dim3((Bq + 255) / 256), dim3(256), 0, s, wbuf, 1.0f, Bq);
+      hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, s, ra.sc);
+    };
+    ops_rng.push_back(op);
+  }
+  // =============================================================== forward
+  {
+    GatherArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.idx = idx_buf; ga.B = B; ga.img_elems = img_elems; ga.n_direct = 0; ga.act_dim = A;
+    ga.rp_obs = rp_obs; ga.rp_next = rp_next; ga.rp_dobs = rp_dobs; ga.rp_dnext = rp_dnext;
+    ga.rp_act = rp_act; ga.rp_rew = rp_rew; ga.rp_done = rp_done;
+    ga.mean = s_mean; ga.stdv = s_std; ga.dmean = s_dmean; ga.dstd = s_dstd; ga.ret_std = s_ret;
+    ga.normalize = c.normalize; ga.clip_obs = c.clip_obs; ga.clip_rew = c.clip_reward; ga.scale_div = 1.f;
+    ga.x_obs = feat[0]; ga.x_obs2 = nullptr; ga.x_next = feat[2]; ga.ldx = ldf;
+    ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;
+    ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
+    Op op; op.tag = "gather_norm";
+    op.run = [ga](hipStream_t s) {
+      hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
+    };
+    ops_grads.push_back(op);
+  }
+  {
+    std::vector<std::vector<IgemmProb>> sc_[3], sh_[3];
+    std::vector<IgemmProb> so_[3];
+    fwd_stages(Pon, net[0], feat[0], ldf, B, sc_[0], sh_[0], so_[0]);
+    fwd_stages(Pon, net[1], feat[2], ldf, B, sc_[1], sh_[1], so_[1]);
+    fwd_stages(Ptg, net[2], feat[2], ldf, B, sc_[2], sh_[2], so_[2]);
+    auto merged = [&](std::vector<IgemmProb> a, const std::vector<IgemmProb>& b, const std::vector<IgemmProb>& d) {
+      a.insert(a.end(), b.begin(), b.end()); a.insert(a.end(), d.begin(), d.end()); return a;
+    };
+    for (int k = 0; k < Lc; ++k) add_launch(ops_grads, "q_fwd", 0, merged(sc_[0][k], sc_[1][k], sc_[2][k]));
+    for (size_t l = 0; l < sh_[0].size(); ++l) add_launch(ops_grads, "q_fwd", 0, merged(sh_[0][l], sh_[1][l], sh_[2][l]));
+    add_launch(ops_grads, "q_fwd", 0, merged(so_[0], so_[1], so_[2]));
+  }
+  {
+    QLossArgs qa;
+    qa.B = B; qa.D = D; qa.n = nb; qa.gamma = c.gamma; qa.lr = c.lr; qa.huber = c.q_huber; qa.double_q = c.q_double;
+    qa.adv0 = net[0].adv; qa.v0 = net[0].v; qa.adv1 = net[1].adv; qa.adv2 = net[2].adv; qa.v2 = net[2].v;
+    qa.act = act; qa.rew = rew; qa.done = done; qa.weights = eps_buf;
+    qa.d_adv0 = gact.adv; qa.d_v0 = gact.v; qa.td = q_td; qa.priority = q_prio; qa.sc = sc;
+    Op op; op.tag = "q_loss";
+    op.run = [qa](hipStream_t s) { hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, qa); };
+    ops_grads.push_back(op);
+  }
+  // =============================================================== backward (online net on s)
+  {
+    const QNetAct& a = net[0];
+    std::vector<IgemmProb> pr;      // output layers -> last hidden
+    for (int br = 0; br < D; ++br)
+      pr.push_back(dense_bwd({{gact.adv + br * nb, D * nb, nb, P + Pon.bw[br][Lb]}}, B, 0, c.q_branch[Lb - 1],
+                             gact.zb[br][Lb - 1], c.q_branch[Lb - 1], a.zb[br][Lb - 1]));
+    pr.push_back(dense_bwd({{gact.v, 1, 1, P + Pon.vw[Lv]}}, B, 0, c.q_value[Lv - 1], gact.zv[Lv - 1], c.q_value[Lv - 1],
+                           a.zv[Lv - 1]));
+    add_launch(ops_grads, "q_bwd", 1, pr);
+    for (int l = std::max(Lb, Lv) - 1; l >= 1; --l) {
+      std::vector<IgemmProb> p2;
+      if (l < Lb)
+        for (int br = 0; br < D; ++br)
+          p2.push_back(dense_bwd({{gact.zb[br][l], c.q_branch[l], c.q_branch[l], P + Pon.bw[br][l]}}, B, 0,
+                                 c.q_branch[l - 1], gact.zb[br][l - 1], c.q_branch[l - 1], a.zb[br][l - 1]));
+      if (l < Lv)
+        p2.push_back(dense_bwd({{gact.zv[l], c.q_value[l], c.q_value[l], P + Pon.vw[l]}}, B, 0, c.q_value[l - 1],
+                               gact.zv[l - 1], c.q_value[l - 1], a.zv[l - 1]));
+      add_launch(ops_grads, "q_bwd", 1, p2);
+    }
+    if (Lc > 0) {   // into the shared trunk: sum over the D+1 towers in chunks of three reduction parts
+      std::vector<BwdPart> towers;
+      for (int br = 0; br < D; ++br) towers.push_back({gact.zb[br][0], c.q_branch[0], c.q_branch[0], P + Pon.bw[br][0]});
+      towers.push_back({gact.zv[0], c.q_value[0], c.q_value[0], P + Pon.vw[0]});
+      for (size_t t0 = 0; t0 < towers.size(); t0 += 3) {
+        std::vector<BwdPart> chunk(towers.begin() + t0, towers.begin() + std::min(towers.size(), t0 + 3));
+        const bool last = t0 + 3 >= towers.size();
+        IgemmProb p = dense_bwd(chunk, B, 0, hdim, gact.zc[Lc - 1], hdim, last ? a.zc[Lc - 1] : nullptr);
+        p.accumulate = t0 > 0 ? 1 : 0;
+        p.out_scale = c.q_trunk_scale;
+        add_launch(ops_grads, "q_bwd", 1, {p});
+      }
+      for (int k = Lc - 1; k >= 1; --k)
+        add_launch(ops_grads, "q_bwd", 1,
+                   {dense_bwd({{gact.zc[k], c.q_common[k], c.q_common[k], P + Pon.cw[k]}}, B, 0, c.q_common[k - 1],
+                              gact.zc[k - 1], c.q_common[k - 1], a.zc[k - 1])});
+    }
+    // weight gradients
+    std::vector<IgemmProb> wg;
+    auto wgrad = [&](const float* x, int ldx, int kin, const float* g, int ldg, int n, int64_t woff, int64_t boff) {
+      IgemmProb p = dense_wgrad(x, ldx, kin, true, g, ldg, n, B, nullptr, 1);
+      p.c = wk.f32(p.slab_stride * p.split);
+      add_wgrad(wg, p, woff, 0, kin, boff);
+    };
+    const float* in = feat[0]; int ldin = ldf, kin = c.obs_dim;
+    for (int k = 0; k < Lc; ++k) {
+      wgrad(in, ldin, kin, gact.zc[k], c.q_common[k], c.q_common[k], Pon.cw[k], Pon.cb[k]);
+      in = a.zc[k]; ldin = kin = c.q_common[k];
+    }
+    for (int br = 0; br < D; ++br) {
+      const float* z = in; int ldz = ldin, kz = kin;
+      for (int l = 0; l < Lb; ++l) {
+        wgrad(z, ldz, kz, gact.zb[br][l], c.q_branch[l], c.q_branch[l], Pon.bw[br][l], Pon.bb[br][l]);
+        z = a.zb[br][l]; ldz = kz = c.q_branch[l];
+      }
+      wgrad(z, ldz, kz, gact.adv + br * nb, D * nb, nb, Pon.bw[br][Lb], Pon.bb[br][Lb]);
+    }
+    const float* z = in; int ldz = ldin, kz = kin;
+    for (int l = 0; l < Lv; ++l) {
+      wgrad(z, ldz, kz, gact.zv[l], c.q_value[l], c.q_value[l], Pon.vw[l], Pon.vb[l]);
+      z = a.zv[l]; ldz = kz = c.q_value[l];
+    }
+    wgrad(z, ldz, kz, gact.v, 1, 1, Pon.vw[Lv], Pon.vb[Lv]);
+    add_launch(ops_grads, "q_wgrad", 2, wg);
+  }
+  {
+    d_reduces = upload_vec(wk, reduces);
+    std::vector<int2> rt;
+    for (size_t k = 0; k < reduces.size(); ++k)
+      for (int st0 = 0; st0 < reduces[k].n; st0 += 256) rt.push_back(make_int2((int)k, st0));
+    int2* d_rt = upload_vec(wk, rt);
+    const int ntiles = (int)rt.size();
+    ReduceDesc* dr = d_reduces;
+    Op op; op.tag = "reduce_slabs";
+    op.run = [dr, d_rt, ntiles](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt);
+    };
+    ops_grads.push_back(op);
+  }
+  if (c.q_grad_clip > 0.f) {   // per-variable tf.clip_by_norm, after the data-parallel all-reduce point
+    std::vector<VarSeg> segs;
+    for (auto& v : vars)
+      if (v.trainable) segs.push_back({v.off, v.numel});
+    VarSeg* d_segs = upload_vec(wk, segs);
+    const int nseg = (int)segs.size();
+    float* g = grads; const float clip = c.q_grad_clip;
+    Op op; op.tag = "clip_by_norm";
+    op.run = [g, d_segs, nseg, clip](hipStream_t s) {
+      hipLaunchKernelGGL(clip_by_norm_kernel, dim3(nseg), dim3(256), 0, s, g, d_segs, clip);
+    };
+    ops_apply.push_back(op);
+  }
+  {
+    Op op; op.tag = "adam";
+    grl_ctx* self = this;
+    op.run = [self](hipStream_t s) {
+      AdamArgs aa;
+      aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f;
+      aa.src_ofs = 0; aa.n_polyak = 0; aa.target = self->params + self->tgt_off;
+      const int blocks = (int)std::min<int64_t>(2048, (self->n_train + 255) / 256);
+      hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, s, aa);
+    };
+    ops_apply.push_back(op);
+  }
+  // =============================================================== act path: Q-values of n observations
+  {
+    afeat = wk.f32((int64_t)NA * ldf);
+    q_aout = wk.f32((int64_t)NA * D * nb);
+    a_eps = wk.f32(NA); a_out = q_aout;
+    alloc_net(aact, NA);
+    ActIngestArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.obs = stg_obs; ia.n = NA; ia.vec_dim = c.obs_dim; ia.scale_div = 1.f; ia.x = afeat; ia.ldx = ldf; ia.d = afeat; ia.ldd = ldf;
+    Op op; op.tag = "act_ingest";
+    const int elems = c.obs_dim;
+    op.run = [ia, elems](hipStream_t s) {
+      hipLaunchKernelGGL(act_ingest_kernel, dim3((elems + 255) / 256, ia.n), dim3(256), 0, s, ia);
+    };
+    ops_act.push_back(op);
+    std::vector<std::vector<IgemmProb>> sc1, sh1;
+    std::vector<IgemmProb> so1;
+    fwd_stages(Pon, aact, afeat, ldf, NA, sc1, sh1, so1);
+    for (auto& v : sc1) add_launch(ops_act, "act_q", 0, v);
+    for (auto& v : sh1) add_launch(ops_act, "act_q", 0, v);
+    add_launch(ops_act, "act_q", 0, so1);
+    const float* adv = aact.adv; const float* vv = aact.v; float* qo = q_aout; const int rows = NA, Dq = D, nq = nb;
+    Op op2; op2.tag = "dueling";
+    op2.run = [adv, vv, qo, rows, Dq, nq](hipStream_t s) {
+      hipLaunchKernelGGL(dueling_kernel, dim3((rows * Dq + 255) / 256), dim3(256), 0, s, adv, vv, rows, Dq, nq, qo);
+    };
+    ops_act.push_back(op2);
+  }
+  for (int k = 0; k < 8; ++k) enc_w[k] = nullptr;
+  dbg["feat_pi"] = {feat[0], (int64_t)B * ldf};
+  dbg["feat_tgt"] = {feat[2], (int64_t)B * ldf};
+  dbg["adv"] = {net[0].adv, (int64_t)B * D * nb};
+  dbg["v"] = {net[0].v, B};
+  dbg["adv_next"] = {net[1].adv, (int64_t)B * D * nb};
+  dbg["adv_tgt"] = {net[2].adv, (int64_t)B * D * nb};
+  dbg["v_tgt"] = {net[2].v, B};
+  dbg["td"] = {q_td, (int64_t)B * D};
+  dbg["priority"] = {q_prio, B};
+  dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
+  dbg["grads"] = {grads, n_train};
+  return GRL_OK;
+}
+
 int grl_ctx::run_ops(std::vector<Op>& ops) {
   if (!prof) {
     for (auto& op : ops) op.run(stream);
@@ -1106,6 +1455,16 @@ static int check_cfg(const grl_config* c) {
   if (c->batch_size < 1 || c->batch_size > 65536) return fail(GRL_ERR_INVALID, "batch_size out of range");
   if (c->act_dim < 1 || c->act_dim > 64) return fail(GRL_ERR_INVALID, "act_dim out of range");
   if (c->replay_capacity < 1) return fail(GRL_ERR_INVALID, "replay_capacity must be >= 1");
+  if (c->algo < 0 || c->algo > 2) return fail(GRL_ERR_INVALID, "algo must be 0..2");
+  if (c->algo != GRL_ALGO_SAC) {
+    if (c->extractor != GRL_EXTRACTOR_MLP) return fail(GRL_ERR_INVALID, "DQN/BDQ run on vector observations (MLP extractor)");
+    if (c->q_branches < 1 || c->q_branches > 16 || c->q_branches != c->act_dim)
+      return fail(GRL_ERR_INVALID, "q_branches must be 1..16 and equal act_dim");
+    if (c->q_bins < 2 || c->q_bins > 1024) return fail(GRL_ERR_INVALID, "q_bins out of range");
+    if (c->q_n_common < 0 || c->q_n_common > GRL_MAX_LAYERS || c->q_n_branch < 1 || c->q_n_branch > GRL_MAX_LAYERS ||
+        c->q_n_value < 1 || c->q_n_value > GRL_MAX_LAYERS)
+      return fail(GRL_ERR_INVALID, "tower depths out of range (branch and value towers need >= 1 hidden layer)");
+  }
   if (c->extractor == GRL_EXTRACTOR_MLP) {
     if (c->obs_dim < 1) return fail(GRL_ERR_INVALID, "obs_dim must be >= 1 for the MLP extractor");
   } else {
@@ -1289,8 +1648,8 @@ int64_t grl_replay_size(grl_handle h) { return h ? h->rp_size : -1; }
 
 static int stage_noise(grl_handle h, const int64_t* idx, const float* eps, int step) {
   HIPCHK(hipMemcpyAsync(h->idx_buf, idx + (int64_t)step * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->eps_buf, eps + (int64_t)step * h->B * h->A, (size_t)h->B * h->A * 4,
-                        hipMemcpyDeviceToDevice, h->stream));
+  const int64_t per = h->cfg.algo == GRL_ALGO_SAC ? (int64_t)h->B * h->A : (int64_t)h->B;   // Q: importance weights
+  HIPCHK(hipMemcpyAsync(h->eps_buf, eps + (int64_t)step * per, (size_t)per * 4, hipMemcpyDeviceToDevice, h->stream));
   return GRL_OK;
 }
 
@@ -1352,6 +1711,14 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
 int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps, float* out) {
   if (!h || !obs || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
+  if (h->cfg.algo != GRL_ALGO_SAC) {   // Q-values [n, D*bins]
+    HIPCHK(hipMemcpyAsync(h->stg_obs, obs, (size_t)n * h->cfg.obs_dim * 4, hipMemcpyHostToDevice, h->stream));
+    if (int e = h->run_ops(h->ops_act)) return e;
+    HIPCHK(hipMemcpyAsync(out, h->q_aout, (size_t)n * h->qD * h->qN * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
   if (!deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
   const int64_t oe = h->cnn ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
   HIPCHK(hipMemcpyAsync(h->stg_obs, obs, (size_t)n * oe * 4, hipMemcpyHostToDevice, h->stream));
@@ -1366,8 +1733,17 @@ int grl_act(grl_handle h, const float* obs, int n, int deterministic, const floa
   return GRL_OK;
 }
 
+int grl_q_update_target(grl_handle h) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (h->cfg.algo == GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "SAC has no hard target update");
+  HIPCHK(hipMemcpyAsync(h->params + h->tgt_off, h->params + h->q_online_off, (size_t)h->q_online_n * 4,
+                        hipMemcpyDeviceToDevice, h->stream));
+  return GRL_OK;
+}
+
 int grl_encoder_load(grl_handle h, const float* const* w, const int64_t* numels, int n_arrays) {
   if (!h || !w || !numels || n_arrays != 8) return fail(GRL_ERR_INVALID, "expected 8 weight arrays");
+  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "the auto-encoder path is attached to SAC handles");
   const int64_t wn[8] = {7 * 7 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 32, 32, 2048 * 100, 100};
   for (int k = 0; k < 8; ++k)
     if (numels[k] != wn[k]) return fail(GRL_ERR_INVALID, "encoder weight " + std::to_string(k) + " has the wrong size");

@@ -57,6 +57,7 @@ struct IgemmProb {
   int32_t act;
   float act_alpha;
   int32_t accumulate;     // += existing c
+  float out_scale;        // accumulator scale before bias / accumulate (0 means 1)
 };
 
 // Addressing modes are compile-time so the staging code has no branch around any load: every
@@ -114,7 +115,7 @@ void igemm_kernel(const IgemmProb* probs, const int4* tiles) {
         if (pb.c_tab_i[i] < 0) continue;
         off = (long)pb.c_tab_i[i] + j;
       } else off = (long)i * pb.ldc + j;
-      float v = acc + (pb.bias ? pb.bias[j] : 0.f);
+      float v = acc * (pb.out_scale != 0.f ? pb.out_scale : 1.f) + (pb.bias ? pb.bias[j] : 0.f);
       if (pb.accumulate) v += cbase[off];
       if (pb.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (pb.act == ACT_LEAKY) v = v > 0.f ? v : pb.act_alpha * v;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
   const int act = pb->act;
   const float alpha = pb->act_alpha;
   const int accumulate = pb->accumulate;
+  const float oscale = pb->out_scale != 0.f ? pb->out_scale : 1.f;
   const int j = j0 + wj * 32 + (lane & 31);
   if (j < N) {
     const float bj = bias ? bias[j] : 0.f;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
       } else {
         off = (long)i * ldc + j;
       }
-      float v = acc[x] + bj;
+      float v = acc[x] * oscale + bj;
       if (accumulate) v += cbase[off];
       if (act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;

@@ -18,6 +18,11 @@ class GrlConfig(C.Structure):
         ("normalize", C.c_int32), ("gamma", C.c_float), ("lr", C.c_float), ("tau", C.c_float),
         ("clip_obs", C.c_float), ("clip_reward", C.c_float), ("norm_eps", C.c_float),
         ("target_entropy", C.c_float), ("seed", C.c_uint64),
+        ("algo", C.c_int32), ("q_branches", C.c_int32), ("q_bins", C.c_int32),
+        ("q_n_common", C.c_int32), ("q_common", C.c_int32 * GRL_MAX_LAYERS),
+        ("q_n_branch", C.c_int32), ("q_branch", C.c_int32 * GRL_MAX_LAYERS),
+        ("q_n_value", C.c_int32), ("q_value", C.c_int32 * GRL_MAX_LAYERS),
+        ("q_huber", C.c_int32), ("q_double", C.c_int32), ("q_grad_clip", C.c_float), ("q_trunk_scale", C.c_float),
     ]
 
 
@@ -40,7 +45,7 @@ EXPORTS = [
     "grl_param_count", "grl_param_info", "grl_reset_optimizer", "grl_set_obs_stats", "grl_replay_add",
     "grl_replay_add_device", "grl_replay_size", "grl_train_step", "grl_compute_grads", "grl_apply_grads",
     "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
-    "grl_profile_enable", "grl_profile_query", "grl_profile_dump",
+    "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target",
 ]
 
 
@@ -78,6 +83,7 @@ def load_library(path=None):
     lib.grl_train_step.argtypes = [vp, i32, vp, vp]
     lib.grl_compute_grads.argtypes = [vp, vp, vp]
     lib.grl_apply_grads.argtypes = [vp, C.c_float]
+    lib.grl_q_update_target.argtypes = [vp]
     lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]
     lib.grl_act.argtypes = [vp, f32p, i32, i32, f32p, f32p]
     lib.grl_encoder_load.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), i32]
@@ -128,3 +134,26 @@ def param_table(lib, handle):
         out.append((name.value.decode(), off.value, numel.value, tuple(shape[k] for k in range(ndim.value)),
                     bool(tr.value)))
     return out
+
+
+def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(64, 64), value_hidden=(64, 64),
+                  batch_size=32, act_batch=1, replay_capacity=50000, normalize=False, gamma=0.99, lr=5e-4,
+                  double_q=True, grad_clip=10.0, clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, seed=0):
+    """DQN (algo='dqn': separate dueling towers) / BDQ (algo='bdq': shared trunk + branches)."""
+    cfg = make_config("mlp", obs_dim=obs_dim, act_dim=n_branches, layers=(1,), batch_size=batch_size,
+                      act_batch=act_batch, replay_capacity=replay_capacity, normalize=normalize, gamma=gamma, lr=lr,
+                      clip_obs=clip_obs, clip_reward=clip_reward, norm_eps=norm_eps, seed=seed)
+    cfg.algo = {"dqn": 1, "bdq": 2}[algo]
+    cfg.q_branches, cfg.q_bins = n_branches, n_bins
+    for name, vals in (("common", common), ("branch", branch_hidden), ("value", value_hidden)):
+        if len(vals) > GRL_MAX_LAYERS:
+            raise GrlError("at most %d layers per tower" % GRL_MAX_LAYERS)
+        setattr(cfg, "q_n_" + name, len(vals))
+        arr = getattr(cfg, "q_" + name)
+        for i, h in enumerate(vals):
+            arr[i] = int(h)
+    cfg.q_huber = 1 if algo == "dqn" else 0
+    cfg.q_double = 1 if double_q else 0
+    cfg.q_grad_clip = grad_clip
+    cfg.q_trunk_scale = 1.0 / (n_branches + 1) if (algo == "bdq" and len(common) > 0) else 1.0
+    return cfg

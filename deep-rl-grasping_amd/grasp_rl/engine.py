@@ -251,3 +251,44 @@ class SacEngine:
             tag, ms, n, fl, by = line.split(":")
             out[tag] = {"avg_ms": float(ms), "launches": int(n), "flops": float(fl), "bytes": float(by)}
         return out
+
+
+class QEngine(SacEngine):
+    """DQN / BDQ handle (``_capi.make_q_config``): same arenas and calls; the explicit-noise slot of
+    ``train`` / ``compute_grads`` carries prioritised-replay importance weights [n_steps, B] and
+    ``act`` returns dueling Q-values [n, branches, bins]."""
+
+    def __init__(self, cfg, backend=None, lib_path=None, device="cuda:0"):
+        super().__init__(cfg, backend=backend, lib_path=lib_path, device=device)
+        self.D, self.bins = cfg.q_branches, cfg.q_bins
+
+    def _noise(self, idx, weights, n_steps):
+        if idx is None and weights is None:
+            return None, None, (None, None)
+        idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(n_steps, self.B)
+        if weights is None:
+            weights = np.ones((n_steps, self.B), np.float32)
+        weights = np.ascontiguousarray(weights, dtype=np.float32).reshape(n_steps, self.B)
+        if idx.min() < 0 or idx.max() >= self.replay_size():
+            raise GrlError("replay index out of range")
+        di, dw = self.be.to_device(idx), self.be.to_device(weights)
+        return C.c_void_p(self.be.ptr(di)), C.c_void_p(self.be.ptr(dw)), (di, dw)
+
+    def q_values(self, obs):
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        n = obs.shape[0]
+        out = np.empty((n, self.D * self.bins), np.float32)
+        check(self.lib, self.lib.grl_act(self.h, obs.ctypes.data, n, 1, None, out.ctypes.data))
+        return out.reshape(n, self.D, self.bins)
+
+    def act(self, obs, deterministic=True, eps=None):
+        return self.q_values(obs).argmax(axis=2)
+
+    def update_target(self):
+        check(self.lib, self.lib.grl_q_update_target(self.h))
+
+    def td_errors(self):
+        return self.fetch("td", (self.B, self.D))
+
+    def priorities(self):
+        return self.fetch("priority", (self.B,))

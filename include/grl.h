@@ -54,6 +54,10 @@ extern "C" {
 #define GRL_EXTRACTOR_AUGMENTED 1  /* sacCnn + custom_obs_policy.create_augmented_nature_cnn(n)  */
 #define GRL_EXTRACTOR_NATURE 2     /* sacCnn with the default nature_cnn over all channels       */
 
+#define GRL_ALGO_SAC 0   /* sb.SAC  sb_helper.py:104-128 */
+#define GRL_ALGO_DQN 1   /* sb.DQN  sb_helper.py:159-165 */
+#define GRL_ALGO_BDQ 2   /* sb.BDQ  sb_helper.py:210-224 */
+
 typedef struct grl_config {
   int32_t extractor;      /* GRL_EXTRACTOR_*                                                    */
   int32_t img_hw;         /* 64 (config/camera_info.yaml:1-2)                                   */
@@ -71,6 +75,18 @@ typedef struct grl_config {
   float clip_obs, clip_reward, norm_eps;
   float target_entropy;   /* -act_dim for ent_coef='auto'                                       */
   uint64_t seed;          /* device RNG (replay indices, policy noise) when none are supplied   */
+  /* ---- DQN / BDQ (algo != GRL_ALGO_SAC): vector observations, extractor must be GRL_EXTRACTOR_MLP,
+     act_dim = q_branches (the replay stores one bin index per action dimension)              */
+  int32_t algo;           /* GRL_ALGO_*                                                         */
+  int32_t q_branches;     /* 1 for DQN; action dimensions for BDQ                               */
+  int32_t q_bins;         /* discrete actions (DQN) / num_actions_pad per dimension (BDQ)       */
+  int32_t q_n_common;  int32_t q_common[GRL_MAX_LAYERS];   /* BDQ layers[0] (shared trunk)     */
+  int32_t q_n_branch;  int32_t q_branch[GRL_MAX_LAYERS];   /* hidden layers of each branch     */
+  int32_t q_n_value;   int32_t q_value[GRL_MAX_LAYERS];    /* hidden layers of the value tower */
+  int32_t q_huber;        /* 1: Huber loss (DQN), 0: squared TD (BDQ)                           */
+  int32_t q_double;       /* double-Q action selection                                          */
+  float q_grad_clip;      /* per-variable clip_by_norm (10 in stable-baselines), 0 = off        */
+  float q_trunk_scale;    /* gradient scale entering the shared trunk (BDQ: 1/(D+1))            */
 } grl_config;
 
 /* byte sizes of the four caller-provided device arenas */
@@ -125,9 +141,13 @@ int grl_replay_add_device(grl_handle h, const float* obs, const float* act, cons
                           const float* next_obs, const float* done, int n);
 int64_t grl_replay_size(grl_handle h);
 
-/* n_steps SAC updates.  idx [n_steps*batch] int64 replay indices and eps [n_steps*batch*act_dim]
-   standard-normal noise are DEVICE pointers; pass NULL to draw them on the device (Philox). */
+/* n_steps updates.  idx [n_steps*batch] int64 replay indices and eps [n_steps*batch*act_dim]
+   standard-normal noise are DEVICE pointers; pass NULL to draw them on the device (Philox).
+   DQN / BDQ handles: `eps` carries the prioritised-replay importance weights [n_steps*batch]
+   (NULL with idx == NULL: uniform sampling on the device, weights 1). */
 int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
+/* DQN / BDQ: hard copy of the online network into the target network (target_network_update_freq) */
+int grl_q_update_target(grl_handle h);
 /* split form for data parallelism: grads -> (caller all-reduces the grads arena) -> apply */
 int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps);
 int grl_apply_grads(grl_handle h, float grad_scale);
@@ -135,7 +155,8 @@ int grl_apply_grads(grl_handle h, float grad_scale);
 int grl_get_metrics(grl_handle h, grl_metrics* out);
 
 /* host: actor forward for n <= act_batch already-normalised observations (env layout, host ptr);
-   eps_or_null: [n,act_dim] noise for stochastic actions (host).  Synchronises the stream. */
+   eps_or_null: [n,act_dim] noise for stochastic actions (host).  Synchronises the stream.
+   DQN / BDQ handles: out receives the dueling Q-values [n, q_branches*q_bins]. */
 int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps_or_null,
             float* out_actions);
 

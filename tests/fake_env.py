@@ -4,7 +4,7 @@ observation / action spaces and the attributes sb_helper.py reads (``is_simplifi
 import numpy as np
 
 from grasp_rl import synthetic
-from grasp_rl.sb.spaces import Box
+from grasp_rl.sb.spaces import Box, Discrete
 
 
 class _Curriculum:
@@ -12,7 +12,7 @@ class _Curriculum:
 
 
 class FakeGraspEnv:
-    def __init__(self, kind="depth", episode_len=7, seed=0, vector_dim=None):
+    def __init__(self, kind="depth", episode_len=7, seed=0, vector_dim=None, discrete_actions=None, act_dim=5):
         self._rng = np.random.default_rng(seed)
         self.vector_dim = vector_dim
         if vector_dim:
@@ -23,7 +23,8 @@ class FakeGraspEnv:
             C = self.stats["mean"].shape[-1]
             self.observation_space = Box(0, 255, shape=(64, 64, C), dtype=np.float32)
             self.depth_obs, self.full_obs = (kind == "depth"), (kind == "rgbd")
-        self.action_space = Box(-1.0, 1.0, shape=(5,), dtype=np.float32)
+        self.action_space = Discrete(discrete_actions) if discrete_actions else Box(-1.0, 1.0, shape=(act_dim,), dtype=np.float32)
+        self.act_dim = act_dim
         self.episode_len = episode_len
         self.episode_step = 0
         self.episode_rewards = 0.0
@@ -51,7 +52,11 @@ class FakeGraspEnv:
         return self._obs()
 
     def step(self, action):
-        assert np.asarray(action).shape == (5,)
+        if hasattr(self.action_space, "n"):
+            assert 0 <= int(action) < self.action_space.n
+            action = np.array([float(action)])
+        else:
+            assert np.asarray(action).shape == (self.act_dim,) and np.all(np.abs(action) <= 1 + 1e-6)
         self.episode_step += 1
         r = float(-200.0 + 100.0 * np.tanh(np.sum(action)))
         self.episode_rewards += r

@@ -1,0 +1,101 @@
+"""DQN / BDQ engine-vs-oracle comparison shared by the CPU plan test and the GPU parity test."""
+import numpy as np
+import torch
+
+import parity_util as pu
+from grasp_rl import _capi
+from grasp_rl.engine import QEngine
+from oracle import dqn as od
+
+CASES = {
+    "dqn": dict(algo="dqn", obs_dim=20, D=1, bins=6, common=(), branch=(16, 16), value=(16, 16), B=8),
+    "dqn_reference_shape": dict(algo="dqn", obs_dim=100, D=1, bins=12, common=(), branch=(64, 64), value=(64, 64), B=32),
+    "bdq": dict(algo="bdq", obs_dim=20, D=3, bins=5, common=(16, 16), branch=(8,), value=(8,), B=8),
+    "bdq_5_branches": dict(algo="bdq", obs_dim=24, D=5, bins=7, common=(32, 16), branch=(8,), value=(12,), B=9),
+    "bdq_reference_shape": dict(algo="bdq", obs_dim=100, D=3, bins=33, common=(64, 64), branch=(32,), value=(32,), B=64),
+}
+
+
+def make_q_case(algo, obs_dim, D, bins, common, branch, value, B, n_replay=40, n_steps=3, seed=0, lr=1e-3,
+                normalize=False):
+    rng = np.random.default_rng(seed)
+    spec = od.QSpec(algo=algo, obs_dim=obs_dim, n_branches=D, n_bins=bins, common=list(common),
+                    branch_hidden=list(branch), value_hidden=list(value), gamma=0.97, lr=lr)
+    cfg = _capi.make_q_config(algo, obs_dim, D, bins, common, branch, value, batch_size=B, act_batch=4,
+                              replay_capacity=n_replay, gamma=0.97, lr=lr, normalize=normalize)
+    mean, var = rng.uniform(0.2, 0.8, obs_dim), rng.uniform(0.05, 0.2, obs_dim)
+    tr = {"obs": rng.normal(mean, np.sqrt(var), (n_replay, obs_dim)).astype(np.float32),
+          "next_obs": rng.normal(mean, np.sqrt(var), (n_replay, obs_dim)).astype(np.float32),
+          "act": rng.integers(0, bins, (n_replay, D)).astype(np.float32),
+          "rew": rng.normal(0, 2.0, n_replay).astype(np.float32),
+          "done": (rng.random(n_replay) < 0.2).astype(np.float32)}
+    idx = rng.integers(0, n_replay, (n_steps, B), dtype=np.int64)
+    weights = rng.uniform(0.3, 1.0, (n_steps, B)).astype(np.float32)
+    return dict(spec=spec, cfg=cfg, tr=tr, idx=idx, weights=weights, params=od.init_params(spec, seed), B=B,
+                n_steps=n_steps, stats={"mean": mean, "var": var, "ret_var": 9.0}, normalize=normalize)
+
+
+def q_engine_setup(case, backend=None, lib_path=None):
+    eng = QEngine(case["cfg"], backend=backend, lib_path=lib_path)
+    eng.set_parameters(case["params"])
+    st = case["stats"]
+    eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
+    tr = case["tr"]
+    eng.replay_add(tr["obs"], tr["act"], tr["rew"], tr["next_obs"], tr["done"])
+    return eng
+
+
+def _batch(case, s):
+    from oracle import sac as osac
+    tr, ii = case["tr"], case["idx"][s]
+    obs, nxt, rew = tr["obs"][ii], tr["next_obs"][ii], tr["rew"][ii]
+    if case["normalize"]:
+        st = case["stats"]
+        obs = osac.normalize_obs(obs, st["mean"], st["var"])
+        nxt = osac.normalize_obs(nxt, st["mean"], st["var"])
+        rew = osac.normalize_reward(rew, st["ret_var"])
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    return {"obs": f(obs), "next_obs": f(nxt), "act": f(tr["act"][ii]), "rew": f(rew), "done": f(tr["done"][ii])}
+
+
+def run_and_compare(case, backend=None, lib_path=None):
+    spec = case["spec"]
+    orc = od.QOracle(spec, case["params"])
+    eng = q_engine_setup(case, backend, lib_path)
+    B, D = case["B"], spec.n_branches
+    # act path
+    obs4 = case["tr"]["obs"][:3]
+    pu.close(eng.q_values(obs4), orc.q_values(obs4), atol=2e-5, rtol=2e-4, what="Q-values (act path)")
+    for s in range(case["n_steps"]):
+        ref = orc.step(_batch(case, s), case["weights"][s])
+        eng.compute_grads(case["idx"][s:s + 1], case["weights"][s:s + 1])
+        pu.close(eng.td_errors(), ref["td"], atol=3e-5, rtol=2e-4, what="td step %d" % s)
+        pu.close(eng.priorities(), ref["priority"], atol=1e-4, rtol=2e-4, what="priority")
+        if s == 0:
+            G = eng.get_gradients()
+            for n, g in ref["grads"].items():
+                pu.close_rel_max(G[n], g, what="grad " + n)
+            assert abs(eng.metrics()["policy_loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"]) + 1e-6
+        eng.apply_grads(1.0)
+        if s == 1:
+            eng.update_target()
+            orc.update_target()
+    pu.compare_params(eng, orc, spec.lr, case["n_steps"])
+    P = eng.get_parameters()
+    sc = spec.scope
+    for n in P:                                             # hard copy happened after step 1 only
+        if "/target_q_func/" in n:
+            assert not np.array_equal(P[n], P[n.replace("/target_q_func", "")]) or P[n].size <= 1, n
+    assert P[sc + "/eps:0"] == case["params"][sc + "/eps:0"]
+    # fused call == split calls
+    eng2 = q_engine_setup(case, backend, lib_path)
+    eng2.train(2, case["idx"][:2], case["weights"][:2])
+    eng3 = q_engine_setup(case, backend, lib_path)
+    for s in range(2):
+        eng3.compute_grads(case["idx"][s:s + 1], case["weights"][s:s + 1])
+        eng3.apply_grads(1.0)
+    Pa, Pb = eng2.get_parameters(), eng3.get_parameters()
+    for n in Pa:
+        assert np.array_equal(Pa[n], Pb[n]), n
+    for e in (eng, eng2, eng3):
+        e.close()

@@ -34,3 +34,19 @@ def test_vectorised_envs_gpu():
     assert model.num_timesteps == 64 and model.engine.replay_size() == 64 and model.n_updates > 0
     a, _ = model.predict(env.reset(), deterministic=True)
     assert a.shape == (4, 5) and np.all(np.isfinite(a))
+
+
+def test_dqn_and_bdq_reference_sequences_gpu(tmp_path):
+    import os
+    import stable_baselines as sb
+    os.makedirs(str(tmp_path / "a")), os.makedirs(str(tmp_path / "b"))
+    host.run_q_sequence(tmp_path / "a",
+                        lambda env: sb.DQN(host.DQNMlpPolicy, env, verbose=2, gamma=0.99, batch_size=16,
+                                           prioritized_replay=True, learning_starts=20,
+                                           target_network_update_freq=10, buffer_size=128),
+                        lambda s: FakeGraspEnv(seed=s, vector_dim=100, discrete_actions=12), n_steps=60)
+    host.run_q_sequence(tmp_path / "b",
+                        lambda env: sb.BDQ(host.MlpActPolicy, env, policy_kwargs={"layers": [[64, 64], [32], [32]]},
+                                           batch_size=16, buffer_size=128, num_actions_pad=33, learning_starts=20,
+                                           target_network_update_freq=10, prioritized_replay=False),
+                        lambda s: FakeGraspEnv(seed=s, vector_dim=100, act_dim=3), n_steps=60)

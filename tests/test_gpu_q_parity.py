@@ -1,0 +1,28 @@
+"""DQN / BDQ update on the MI355X (through the C ABI) against the oracle (oracle/dqn.py)."""
+import pytest
+
+import q_parity_util as qu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(qu.CASES))
+def test_q_update_matches_oracle(name):
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+
+
+def test_q_update_with_vecnormalize():
+    qu.run_and_compare(qu.make_q_case(normalize=True, **qu.CASES["bdq"]))
+
+
+def test_q_device_rng_mode_trains():
+    import numpy as np
+    case = qu.make_q_case(**qu.CASES["bdq_reference_shape"])
+    eng = qu.q_engine_setup(case)
+    p0 = eng.get_parameters()
+    eng.train(5)
+    p1 = eng.get_parameters()
+    assert np.isfinite(eng.metrics()["policy_loss"])
+    assert not np.array_equal(p0["bdq/model/common_net/fully_connected/weights:0"],
+                              p1["bdq/model/common_net/fully_connected/weights:0"])
+    eng.close()

@@ -1,0 +1,31 @@
+"""DQN / BDQ launch plan (tables, descriptors, loss / clip / Adam bookkeeping) against the oracle on CPU
+through the TEST-ONLY g++ emulation build (see tests/test_hostemu_plan.py)."""
+import pytest
+
+import q_parity_util as qu
+from hostemu_backend import NumpyHostBackend
+from oracle import dqn as od
+
+
+@pytest.mark.parametrize("name", ["dqn", "bdq", "bdq_5_branches"])
+def test_q_plan_matches_oracle(hostemu_lib, name):
+    case = qu.make_q_case(**qu.CASES[name])
+    qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+
+
+def test_q_plan_with_vecnormalize(hostemu_lib):
+    case = qu.make_q_case(normalize=True, **qu.CASES["bdq"])
+    qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+
+
+def test_layout_matches_shipped_zip_names(hostemu_lib):
+    """Engine variable names / order / shapes == TF names of trained_models/{DQN_4pads,BDQ_*}/*.zip."""
+    for spec, kw in ((od.QSpec(algo="dqn", obs_dim=100, n_bins=12), qu.CASES["dqn_reference_shape"]),
+                     (od.bdq_spec(100, 3, 33, [[64, 64], [32], [32]]), qu.CASES["bdq_reference_shape"])):
+        case = qu.make_q_case(**kw)
+        eng = qu.QEngine(case["cfg"], backend=NumpyHostBackend(), lib_path=hostemu_lib)
+        ref = od.param_shapes(spec)
+        assert [t[0] for t in eng.table] == list(ref.keys())
+        for name, _, _, shape, _ in eng.table:
+            assert tuple(shape) == tuple(ref[name]), name
+        eng.close()

@@ -171,3 +171,79 @@ def test_unsupported_paths_fail_loudly(emulated_engine):
         sb.SAC(sacMlp, env, policy_kwargs={"layer_norm": True})
     with pytest.raises(NotImplementedError):
         sb.TRPO(None, env)
+
+
+# ---------------------------------------------------------------------------------------------- DQN / BDQ
+from grasp_rl.engine import QEngine                                     # noqa: E402
+from grasp_rl.sb.dqn import BDQ, DQN, SumTree                           # noqa: E402
+from stable_baselines.bdq.policies import MlpActPolicy                  # noqa: E402
+from stable_baselines.deepq.policies import MlpPolicy as DQNMlpPolicy  # noqa: E402
+
+
+@pytest.fixture
+def emulated_q_engine(hostemu_lib, monkeypatch):
+    f = staticmethod(lambda cfg, device: QEngine(cfg, backend=NumpyHostBackend(), lib_path=hostemu_lib))
+    monkeypatch.setattr(DQN, "_engine_factory", f)
+    monkeypatch.setattr(BDQ, "_engine_factory", f)
+
+
+def run_q_sequence(tmp_path, make_model, make_env, n_steps=40):
+    env = DummyVecEnv([lambda: Monitor(make_env(0), os.path.join(str(tmp_path), "log_file"))])
+    model = make_model(env)
+    counter = CountingCallback()
+    p0 = model.get_parameters()
+    model.learn(total_timesteps=n_steps, callback=[counter])
+    assert counter.steps == n_steps and model.num_timesteps == n_steps
+    assert model.n_updates == n_steps - max(model.learning_starts, model.batch_size - 1)
+    p1 = model.get_parameters()
+    changed = [k for k in p0 if "target_q_func" not in k and "eps" not in k and not np.array_equal(p0[k], p1[k])]
+    assert len(changed) > 4
+    eps_name = [k for k in p1 if k.endswith("eps:0")][0]
+    assert abs(float(p1[eps_name]) - model.exploration_final_eps) < 1e-6           # schedule finished
+    tgt = [k for k in p1 if "target_q_func" in k and k.endswith("weights:0")][0]
+    assert not np.array_equal(p0[tgt], p1[tgt])                                      # hard update happened
+    path = os.path.join(str(tmp_path), "q_model")
+    model.save(path)
+    agent = type(model).load(path)
+    task = DummyVecEnv([lambda: make_env(1)])
+    obs = task.reset()
+    action = agent.predict(obs, deterministic=True)
+    assert np.array_equal(np.asarray(action[0]), np.asarray(model.predict(obs, deterministic=True)[0]))
+    task.step(action[0])
+    # sb_helper.py:186-198 / 205-225: transfer only the non-'action_value' layers whose name contains '2'
+    usable = {k: v for k, v in agent.get_parameters().items() if "action_value" not in k and "2" in k}
+    fresh = make_model(env)
+    fresh.load_parameters(usable, exact_match=False)
+    for k, v in usable.items():
+        assert np.array_equal(fresh.get_parameters()[k], v)
+    return model
+
+
+def test_dqn_reference_sequence(tmp_path, emulated_q_engine):
+    make_env = lambda s: FakeGraspEnv(seed=s, vector_dim=20, discrete_actions=12)
+    mk = lambda env: sb.DQN(DQNMlpPolicy, env, verbose=2, gamma=0.99, batch_size=8, prioritized_replay=True,
+                            tensorboard_log=None, learning_starts=10, target_network_update_freq=10, buffer_size=64)
+    m = run_q_sequence(tmp_path, mk, make_env)
+    assert m.engine.cfg.algo == 1 and m.engine.cfg.q_huber == 1 and m.engine.cfg.q_bins == 12
+    assert [n for n in m.get_parameter_list()][:2] == ["deepq/eps:0", "deepq/model/action_value/fully_connected/weights:0"]
+
+
+def test_bdq_reference_sequence(tmp_path, emulated_q_engine):
+    make_env = lambda s: FakeGraspEnv(seed=s, vector_dim=20, act_dim=3)
+    mk = lambda env: sb.BDQ(MlpActPolicy, env, verbose=2, policy_kwargs={"layers": [[16, 16], [8], [8]]}, gamma=0.99,
+                            batch_size=8, buffer_size=64, epsilon_greedy=True, exploration_fraction=0.3,
+                            exploration_final_eps=0.1, num_actions_pad=5, learning_starts=10,
+                            target_network_update_freq=10, prioritized_replay=False, tensorboard_log=None)
+    m = run_q_sequence(tmp_path, mk, make_env)
+    assert m.engine.cfg.algo == 2 and m.engine.cfg.q_branches == 3 and abs(m.engine.cfg.q_trunk_scale - 0.25) < 1e-7
+    a, _ = m.predict(np.zeros(20, np.float32))
+    assert a.shape == (3,) and set(np.round((a + 1) * 2, 5)) <= {0.0, 1.0, 2.0, 3.0, 4.0}     # bin centres
+
+
+def test_sum_tree_proportional_sampling():
+    t = SumTree(6)
+    t.set(np.arange(6), [1, 2, 3, 4, 0, 10])
+    assert t.total() == 20 and t.min[1] == 0
+    assert t.find_prefix(0.5) == 0 and t.find_prefix(1.5) == 1 and t.find_prefix(9.99) == 3 and t.find_prefix(10.0) == 5
+    t.set(4, 5.0)
+    assert t.total() == 25 and t.find_prefix(10.5) == 4
