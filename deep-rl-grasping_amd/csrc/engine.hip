@@ -25,6 +25,7 @@
 #include "../../include/grl.h"
 #include "elem_kernels.h"
 #include "igemm.h"
+#include "igemm2.h"
 
 namespace grl {
 
@@ -79,6 +80,7 @@ struct ConvFwdTabs {
   uint64_t* vmask = nullptr;  // [M] when pad > 0
   uint8_t* tap = nullptr;     // [K+1]
   int M = 0;
+  bool vec4 = false;          // 16-byte runs along the kernel index, 16-byte aligned pixel offsets
 };
 
 struct ConvBwdClass {
@@ -86,11 +88,15 @@ struct ConvBwdClass {
   uint64_t* vmask;
   uint8_t* tap;
   int M, K;
+  bool vec4_p, vec4_q;
 };
 
 struct Launch {
   int variant;   // 0: P along r, Q along j   1: P along r, Q along r   2: P along i, Q along j
   int pm = 0, qm = 0, np = 1;   // addressing modes / part count (igemm.h), uniform over a launch
+  bool v2 = false;              // igemm2_kernel (vectorised staging) instead of igemm_kernel
+  int cfg = 0;                  // igemm2 workgroup shape
+  int flags = 0;                // igemm2 instantiation flags (I2F_*)
   std::vector<IgemmProb> probs;
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
@@ -308,6 +314,33 @@ struct grl_ctx {
   }
 
   // ---------------------------------------------------------------- conv tables
+  // igemm2 fetches 4 consecutive table-addressed elements with one 16-byte load: that needs the
+  // offsets of a quad to be consecutive and the first one (plus every row term) a multiple of 4
+  template <class T>
+  static bool runs4(const std::vector<T>& v, size_t n, bool aligned) {
+    if (n % 4) return false;
+    for (size_t q = 0; q < n; q += 4) {
+      if (aligned && (((long)v[q]) & 3)) return false;
+      for (int e = 1; e < 4; ++e)
+        if ((long)v[q + e] != (long)v[q] + e) return false;
+    }
+    return true;
+  }
+  template <class T>
+  static bool const4(const std::vector<T>& v, size_t n) {
+    if (n % 4) return false;
+    for (size_t q = 0; q < n; q += 4)
+      for (int e = 1; e < 4; ++e)
+        if (v[q + e] != v[q]) return false;
+    return true;
+  }
+  template <class T>
+  static bool all_mod4(const std::vector<T>& v) {
+    for (auto x : v)
+      if (((long)x) & 3) return false;
+    return true;
+  }
+
   ConvFwdTabs conv_fwd_tabs(const ConvGeom& g, int Bn) {
     ConvFwdTabs t;
     t.M = Bn * g.OH * g.OW;
@@ -337,12 +370,15 @@ struct grl_ctx {
         }
     t.tab_i = upload_vec(wk, ti);
     t.tab_r = upload_vec(wk, tr);
+    t.vec4 = all_mod4(ti) && runs4(tr, (size_t)K, true);
+    const bool taps4 = const4(tp, (size_t)K);   // a masked quad must share one tap
     bool need_mask = false;   // TF 'SAME' padding may be one-sided (lo = 0, hi = 1)
     const uint64_t full = (g.KH * g.KW >= 64) ? ~0ull : ((1ull << (g.KH * g.KW)) - 1);
     for (auto b : vm) need_mask = need_mask || (b != full);
     if (need_mask) {
       t.vmask = upload_vec(wk, vm);
       t.tap = upload_vec(wk, tp);
+      t.vec4 = t.vec4 && taps4;
     }
     return t;
   }
@@ -387,6 +423,8 @@ struct grl_ctx {
               const int kh = std::min(ph + g.S * jj, g.KH - 1), kw = std::min(pw + g.S * ll, g.KW - 1);
               qt[r] = ((kh * g.KW + kw) * g.C) * g.Cout + co;
             }
+        c.vec4_p = all_mod4(ti) && runs4(tr, tr.size(), true) && const4(tp, tp.size());
+        c.vec4_q = runs4(qt, qt.size(), true) && (g.Cout % 4 == 0);
         c.tab_i = upload_vec(wk, ti);
         c.tab_r = upload_vec(wk, tr);
         c.q_tab_r = upload_vec(wk, qt);
@@ -473,6 +511,7 @@ struct grl_ctx {
     single_part(p);
     p.q_base[0] = w; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
     p.c = y; p.ldc = g.Cout; p.bias = bias; p.act = act; p.act_alpha = alpha;
+    p.vflags = t.vec4 ? VF_P_TABS : 0;
     set_split(p, 1);
     return p;
   }
@@ -485,6 +524,7 @@ struct grl_ctx {
     single_part(p);
     p.q_base[0] = w; p.q_tab_r = c.q_tab_r; p.q_ld_j[0] = g.Cout;
     p.c = dx; p.c_tab_i = c.c_tab_i; p.relu_mask = mask;
+    p.vflags = (c.vec4_p ? VF_P_TABS : 0) | (c.vec4_q ? VF_Q_TAB : 0);
     set_split(p, 1);
     return p;
   }
@@ -497,8 +537,54 @@ struct grl_ctx {
     p.p_ones_i = g.K();
     p.q_base[0] = gy; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
     p.c = slab; p.ldc = g.Cout;
+    p.vflags = t.vec4 ? VF_P_TABS : 0;
     set_split(p, split_target);
     return p;
+  }
+
+  // ---------------------------------------------------------------- igemm2 eligibility / shape choice
+  static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+  static bool v2_prob_ok(const IgemmProb& p, int variant) {
+    if (p.p_k0 < p.K) return false;                       // multi-part operands stay on igemm_kernel
+    if (!al16(p.p_base[0]) || !al16(p.q_base[0])) return false;
+    const bool ptab = p.p_tab_i != nullptr, qtab = p.q_tab_r != nullptr;
+    const int Meff = p.p_ones_i >= 0 ? p.M - 1 : p.M;
+    if (p.p_ones_i >= 0 && (p.p_ones_i != p.M - 1 || variant != 2)) return false;
+    if (variant == 2) {                                   // P along i
+      if (Meff % 4) return false;
+      if (ptab) { if (!(p.vflags & VF_P_TABS) || p.p_vmask_i) return false; }
+      else if (p.p_ld_i[0] != 1 || (p.p_ld_r[0] % 4)) return false;
+    } else {                                              // P along r
+      if (ptab) { if (!(p.vflags & VF_P_TABS) || (p.K % 4)) return false; }
+      else if (p.p_ld_r[0] != 1 || (p.p_ld_i[0] % 4) || p.p_ld_i[0] < rup(p.K, 4)) return false;
+    }
+    if (variant == 1) {                                   // Q along r
+      if (p.K % 4) return false;
+      if (qtab) { if (!(p.vflags & VF_Q_TAB) || (p.q_ld_j[0] % 4)) return false; }
+      else if (p.q_ld_r[0] != 1 || (p.q_ld_j[0] % 4)) return false;
+    } else {                                              // Q along j
+      if (qtab) return false;
+      if (p.q_ld_j[0] != 1 || (p.q_ld_r[0] % 4) || (p.N % 4)) return false;
+    }
+    return true;
+  }
+  // workgroup shape of a v2 launch: narrow outputs -> 128x32; few 64x64 tiles with long reductions
+  // -> 32x64 with the reduction split over the waves; otherwise 64x64
+  static int v2_pick_cfg(const std::vector<IgemmProb>& probs, int variant, const std::string& tag) {
+    const std::string key = "GRL_I2CFG_" + tag;
+    if (const char* e = getenv(key.c_str())) return atoi(e);
+    int maxN = 0;
+    long tiles64 = 0;
+    bool ones = false, longk = true;
+    for (auto& p : probs) {
+      maxN = std::max(maxN, p.N);
+      tiles64 += (long)p.split * ((p.M + 63) / 64) * ((p.N + 63) / 64);
+      ones = ones || p.p_ones_i >= 0;
+      longk = longk && std::min(p.K, p.k_chunk) >= 256;
+    }
+    if (maxN <= 32) return 1;
+    if (!ones && variant != 2 && tiles64 < 200 && longk) return 2;
+    return 0;
   }
 
   // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op
@@ -507,25 +593,7 @@ struct grl_ctx {
     Launch* l = new Launch();
     l->variant = variant;
     l->probs = std::move(probs);
-    std::vector<int4> tiles;
-    std::vector<int> order(l->probs.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return std::min(l->probs[a].K, l->probs[a].k_chunk) > std::min(l->probs[b].K, l->probs[b].k_chunk);
-    });
-    double flops = 0;
-    for (int pi : order) {
-      const IgemmProb& p = l->probs[pi];
-      flops += 2.0 * p.M * p.N * p.K;
-      for (int s = 0; s < p.split; ++s)
-        for (int ti = 0; ti < (p.M + 63) / 64; ++ti)
-          for (int tj = 0; tj < (p.N + 63) / 64; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
-    }
-    l->n_tiles = (int)tiles.size();
-    l->d_probs = upload_vec(wk, l->probs);
-    l->d_tiles = upload_vec(wk, tiles);
-    launches.push_back(l);
-    // addressing modes are compile-time in the kernel: derive them and insist they are uniform
+    // addressing modes are compile-time in the kernels: derive them and insist they are uniform
     auto pm_of = [](const IgemmProb& p) { return p.p_tab_i ? (p.p_vmask_i ? PM_TABLE_MASK : PM_TABLE) : PM_AFFINE; };
     auto qm_of = [](const IgemmProb& p) { return p.q_tab_r ? QM_TABLE : QM_AFFINE; };
     l->pm = pm_of(l->probs[0]);
@@ -537,11 +605,82 @@ struct grl_ctx {
       }
     for (auto& p : l->probs)
       if (p.p_k0 < p.K) l->np = 3;
+    const char* nv2 = getenv("GRL_NO_V2");
+    l->v2 = !(nv2 && nv2[0] == '1');
+    for (auto& p : l->probs) l->v2 = l->v2 && v2_prob_ok(p, variant);
+    // ones rows / K tails select a kernel instantiation: they must be uniform over the launch
+    {
+      bool any_ones = false, all_ones = true, ktail = false;
+      for (auto& p : l->probs) {
+        any_ones = any_ones || p.p_ones_i >= 0;
+        all_ones = all_ones && p.p_ones_i >= 0;
+        ktail = ktail || (p.K % 4) != 0;
+      }
+      if (any_ones != all_ones) l->v2 = false;
+      if (ktail && !(variant == 0 && l->pm == PM_AFFINE && l->qm == QM_AFFINE)) l->v2 = false;
+      l->flags = (any_ones ? I2F_ONES : 0) | (ktail ? I2F_KTAIL : 0);
+    }
+    l->cfg = l->v2 ? v2_pick_cfg(l->probs, variant, tag) : 0;
+    if (getenv("GRL_PLAN_DUMP"))
+      fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu\n", tag.c_str(), variant,
+              l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size());
+    const int BMt = l->v2 ? i2_bm(l->cfg) : 64, BNt = l->v2 ? i2_bn(l->cfg) : 64;
+
+    std::vector<int4> tiles;
+    std::vector<int> order(l->probs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return std::min(l->probs[a].K, l->probs[a].k_chunk) > std::min(l->probs[b].K, l->probs[b].k_chunk);
+    });
+    double flops = 0;
+    for (int pi : order) {
+      const IgemmProb& p = l->probs[pi];
+      flops += 2.0 * p.M * p.N * p.K;
+      const int Mt = (l->v2 && p.p_ones_i >= 0) ? p.M - 1 : p.M;   // v2: the ones row rides on row tile 0
+      for (int s = 0; s < p.split; ++s)
+        for (int ti = 0; ti < (Mt + BMt - 1) / BMt; ++ti)
+          for (int tj = 0; tj < (p.N + BNt - 1) / BNt; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
+    }
+    l->n_tiles = (int)tiles.size();
+    l->d_probs = upload_vec(wk, l->probs);
+    l->d_tiles = upload_vec(wk, tiles);
+    launches.push_back(l);
     Op op;
     op.tag = tag;
     op.flops = flops;
     op.run = [l, tag](hipStream_t s) {
       dim3 grid(l->n_tiles), block(256);
+      if (l->v2) {
+        const int key = l->variant * 10000 + l->pm * 1000 + l->qm * 100 + l->cfg * 10 + l->flags;
+#define GRL_I2(PLv, QLv, PMv, QMv, CF, FL) \
+  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, 0, s, l->d_probs, l->d_tiles)
+#define GRL_I2_CFGS(base, PLv, QLv, PMv, QMv, FL)                           \
+  case base + 0 + FL: GRL_I2(PLv, QLv, PMv, QMv, 0, FL); break;              \
+  case base + 10 + FL: GRL_I2(PLv, QLv, PMv, QMv, 1, FL); break;             \
+  case base + 20 + FL: GRL_I2(PLv, QLv, PMv, QMv, 2, FL); break;
+        switch (key) {
+          GRL_I2_CFGS(0, I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0)            // dense forward
+          GRL_I2_CFGS(0, I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, I2F_KTAIL)    //   ... K % 4 != 0
+          GRL_I2_CFGS(1000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0)          // VALID conv forward
+          GRL_I2_CFGS(2000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE_MASK, QM_AFFINE, 0)     // padded conv forward
+          GRL_I2_CFGS(10000, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0)        // dense backward-data
+          GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data
+          case 20000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, 0); break;         // dense weight gradient
+          case 20001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, I2F_ONES); break;  //   ... with bias row
+          case 20010: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 1, 0); break;
+          case 20011: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 1, I2F_ONES); break;
+          case 21000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, 0); break;          // conv weight gradient
+          case 21001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES); break;
+          case 21010: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 1, 0); break;
+          case 21011: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 1, I2F_ONES); break;
+          default:
+            fprintf(stderr, "grl: no igemm2 instantiation for launch '%s' (key %d)\n", tag.c_str(), key);
+            abort();
+        }
+#undef GRL_I2_CFGS
+#undef GRL_I2
+        return;
+      }
       const int key = l->np * 1000 + l->pm * 100 + l->qm * 10 + l->variant;
 #define GRL_IGEMM(PMv, QMv, PR, QJ, NPv) \
   hipLaunchKernelGGL((igemm_kernel<PMv, QMv, PR, QJ, NPv>), grid, block, 0, s, l->d_probs, l->d_tiles)

@@ -58,7 +58,11 @@ struct IgemmProb {
   float act_alpha;
   int32_t accumulate;     // += existing c
   float out_scale;        // accumulator scale before bias / accumulate (0 means 1)
+  // ---- host-side planning hints (never read on the device): addressing tables checked for 16-byte
+  // runs -- bit 0: P tables, bit 1: Q table (igemm2.h eligibility)
+  uint32_t vflags;
 };
+enum { VF_P_TABS = 1u, VF_Q_TAB = 2u };
 
 // Addressing modes are compile-time so the staging code has no branch around any load: every
 // load of a slab is issued back to back (masked lanes read offset 0 and select 0 afterwards) and the

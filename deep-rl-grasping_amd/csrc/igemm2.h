@@ -1,0 +1,477 @@
+// igemm2.h -- second-generation implicit GEMM on the gfx950 f32 matrix cores: the same descriptor
+// (IgemmProb, igemm.h) and the same arithmetic (v_mfma_f32_32x32x2_f32, exact fp32) as igemm_kernel,
+// but built for problems whose operands can be fetched 16 bytes at a time:
+//
+//   * every global access of the staging loop is a dwordx4 load (4 floats along whichever index the
+//     tensor is contiguous in), so a 32-deep slab costs 2-12 loads per thread instead of 16 scalar
+//     gathers with 16 address computations;
+//   * operands that are contiguous along the reduction index are kept K-contiguous in LDS
+//     ([row][32*WK + 4]); a lane then owns 16 consecutive k of its row (lanes 0-31: k 0..15, lanes
+//     32-63: k 16..31 of the slab) and fetches them with four conflict-free ds_read_b128 -- the
+//     k-pairing of the sixteen 32x32x2 MFMAs of a slab is {m, 16+m}, which both operands follow;
+//     operands contiguous along the output index stay k-major ([k][cols + 4], ds_read_b32);
+//   * LDS is double buffered: one barrier per slab, global loads of slab s+1 are in flight while
+//     the MFMAs of slab s run;
+//   * three workgroup shapes (CFG): 64x64 (2x2 waves), 128x32 (4x1 waves, narrow-N convolutions)
+//     and 32x64 with the four waves splitting the reduction (small-M dense layers: fills the chip
+//     without a global split-K pass; partial accumulators are summed through LDS in wave order);
+//   * the bias-gradient "ones row" of a weight-gradient problem is not an extra, nearly empty row
+//     tile any more: the workgroups of row tile 0 sum the staged dY slab column-wise (VALU, from
+//     LDS) while the matrix pipe works, and write the row the descriptor asks for.
+//
+// Eligibility (16-byte alignment, 4-runs in the addressing tables, single-part operands) is decided
+// on the host per launch (engine.hip: v2_plan); everything else keeps running on igemm_kernel.
+#pragma once
+#include "igemm.h"
+
+namespace grl {
+
+enum { I2_P_ALONG_R = 0, I2_P_ALONG_I = 1 };
+enum { I2_Q_ALONG_R = 0, I2_Q_ALONG_J = 1 };
+enum { I2F_ONES = 1, I2F_KTAIL = 2 };
+
+template <int CFG> struct I2Cfg;
+template <> struct I2Cfg<0> { static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, WK = 1, FM = 1, FN = 1; };
+template <> struct I2Cfg<1> { static constexpr int BM = 128, BN = 32, WM = 4, WN = 1, WK = 1, FM = 1, FN = 1; };
+template <> struct I2Cfg<2> { static constexpr int BM = 32, BN = 64, WM = 1, WN = 1, WK = 4, FM = 1, FN = 2; };
+
+static inline int i2_bm(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 128 : 32); }
+static inline int i2_bn(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 32 : 64); }
+
+#ifdef GRL_HOSTEMU
+// TEST-ONLY reference of the v2 tile semantics (see hostemu.h): tile = BM x BN of CFG; the ones row
+// (p_ones_i == M-1) is produced by row tile 0 and excluded from the row tiling.
+template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
+void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
+  if (threadIdx.x != 0) return;
+  if (((FLAGS & 1) != 0) != (probs[tiles[blockIdx.x].x].p_ones_i >= 0)) abort();
+  const int BM = i2_bm(CFG), BN = i2_bn(CFG);
+  const int4 tl = tiles[blockIdx.x];
+  const IgemmProb& pb = probs[tl.x];
+  if ((PM != PM_AFFINE) != (pb.p_tab_i != nullptr && pb.p_tab_r != nullptr)) abort();
+  if ((PM == PM_TABLE_MASK) != (pb.p_vmask_i != nullptr)) abort();
+  if ((QM == QM_TABLE) != (pb.q_tab_r != nullptr)) abort();
+  if (pb.p_k0 < pb.K) abort();
+  if (pb.p_ones_i >= 0 && pb.p_ones_i != pb.M - 1) abort();
+  const int Meff = pb.p_ones_i >= 0 ? pb.M - 1 : pb.M;
+  const int r_begin = tl.y * pb.k_chunk, r_end = std::min(pb.K, r_begin + pb.k_chunk);
+  float* cbase = pb.c + (long)tl.y * pb.slab_stride;
+  auto row = [&](int i) {
+    for (int j = tl.w * BN; j < std::min(pb.N, tl.w * BN + BN); ++j) {
+      float acc = 0.f;
+      for (int r = r_begin; r < r_end; ++r) {
+        float pv = 0.f;
+        bool ok = true;
+        if (pb.p_vmask_i && i != pb.p_ones_i) ok = (pb.p_vmask_i[i] >> pb.p_tap_r[r]) & 1ull;
+        if (i == pb.p_ones_i) pv = 1.f;
+        else if (ok) {
+          const long rowterm = pb.p_tab_i ? pb.p_tab_i[i] : (long)i * pb.p_ld_i[0];
+          const long colterm = pb.p_tab_r ? pb.p_tab_r[r] : (long)r * pb.p_ld_r[0];
+          pv = pb.p_base[0][rowterm + colterm];
+        }
+        const long qrow = pb.q_tab_r ? pb.q_tab_r[r] : (long)r * pb.q_ld_r[0];
+        acc = fmaf(pv, pb.q_base[0][qrow + (long)j * pb.q_ld_j[0]], acc);
+      }
+      long off;
+      if (pb.c_tab_i) {
+        if (pb.c_tab_i[i] < 0) continue;
+        off = (long)pb.c_tab_i[i] + j;
+      } else off = (long)i * pb.ldc + j;
+      float v = acc * (pb.out_scale != 0.f ? pb.out_scale : 1.f) + (pb.bias ? pb.bias[j] : 0.f);
+      if (pb.accumulate) v += cbase[off];
+      if (pb.act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (pb.act == ACT_LEAKY) v = v > 0.f ? v : pb.act_alpha * v;
+      if (pb.relu_mask) v = pb.relu_mask[off] > 0.f ? v : 0.f;
+      cbase[off] = v;
+    }
+  };
+  for (int i = tl.z * BM; i < std::min(Meff, tl.z * BM + BM); ++i) row(i);
+  if (pb.p_ones_i >= 0 && tl.z == 0) row(pb.p_ones_i);
+}
+#else
+
+#ifndef I2_ABLATE
+#define I2_ABLATE 0   // development only (scripts/igemm_bench.hip): 1 no global loads, 2 no LDS stores, 4 no barrier
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define I2_OOB ((int)0x80000000)   // byte offset beyond num_records: the buffer load returns zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t i2_rsrc(const float* p) {
+  // descriptor inputs made provably wave-uniform (no waterfall loop around the buffer loads)
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 i2_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
+// FLAGS: I2F_ONES  -- the problems carry a bias-gradient ones row (p_ones_i == M-1), Q along j, WK == 1
+//        I2F_KTAIL -- K % 4 != 0 (affine operands along r): elements past r_end are zeroed one by one
+template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
+__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
+                                                    const int4* __restrict__ tiles) {
+  using C = I2Cfg<CFG>;
+  constexpr int BM = C::BM, BN = C::BN, WK = C::WK, FM = C::FM, FN = C::FN, WN = C::WN, WM = C::WM;
+  constexpr bool ONES = (FLAGS & I2F_ONES) != 0, KTAIL = (FLAGS & I2F_KTAIL) != 0;
+  constexpr int BKT = 32 * WK;                 // reduction depth staged per barrier
+  constexpr int LDPK = BKT + 4, LDPM = BM + 4; // row strides of the two P layouts
+  constexpr int LDQK = BKT + 4, LDQN = BN + 4;
+  constexpr int PSZ = PL == I2_P_ALONG_R ? BM * LDPK : BKT * LDPM;
+  constexpr int QSZ = QL == I2_Q_ALONG_R ? BN * LDQK : BKT * LDQN;
+  constexpr int BUF = PSZ + QSZ;
+  constexpr int RED = WK > 1 ? WK * BM * (BN + 1) : 0;
+  constexpr int LDSF = 2 * BUF > RED ? 2 * BUF : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+
+  const int4 tl = tiles[blockIdx.x];
+  const IgemmProb* __restrict__ pb = probs + tl.x;
+  const int N = pb->N, K = pb->K;
+  const int ones_i = pb->p_ones_i;
+  const int M = ONES ? pb->M - 1 : pb->M;   // rows tiled; the ones row is handled by row tile 0
+  const int i0 = tl.z * BM, j0 = tl.w * BN;
+  const int r_begin = tl.y * pb->k_chunk;
+  const int r_end = min(K, r_begin + pb->k_chunk);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wk = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;
+
+  const __amdgpu_buffer_rsrc_t rsP = i2_rsrc(pb->p_base[0]);
+  const __amdgpu_buffer_rsrc_t rsQ = i2_rsrc(pb->q_base[0]);
+  const gci32 pTi = (gci32)pb->p_tab_i;
+  const gci32 pTr = (gci32)pb->p_tab_r;
+  const gcu64 pVm = (gcu64)pb->p_vmask_i;
+  const gcu8 pTap = (gcu8)pb->p_tap_r;
+  const gci32 qTr = (gci32)pb->q_tab_r;
+  const int pLi = pb->p_ld_i[0], pLr = pb->p_ld_r[0];
+  const int qLr = pb->q_ld_r[0], qLj = pb->q_ld_j[0];
+
+  // ------------------------------------------------------------------ staging coordinates
+  // operand along r: a thread owns k-quad *_q of rows/cols *_l + e*STEP.
+  // operand along i/j: it owns row/col-quad *_q of the k's *_l + e*STEP.
+  constexpr int PNQ = PL == I2_P_ALONG_R ? BKT / 4 : BM / 4;
+  constexpr int PSTEP = 256 / PNQ;
+  constexpr int NVP = (PL == I2_P_ALONG_R ? BM : BKT) / PSTEP;
+  const int p_q = t % PNQ, p_l = t / PNQ;
+  constexpr int NFP = PL == I2_P_ALONG_R ? NVP : 1;
+  int p_fix[NFP];            // element offset of the fixed (row) term, or I2_OOB/4-safe sentinel via p_fok
+  bool p_fok[NFP];
+  uint64_t p_vm[NFP];
+  if (PL == I2_P_ALONG_R) {
+#pragma unroll
+    for (int e = 0; e < NVP; ++e) {
+      const int i = i0 + p_l + e * PSTEP;
+      p_fok[e] = i < M;
+      const int ic = p_fok[e] ? i : i0;
+      p_fix[e] = PM != PM_AFFINE ? pTi[ic] : ic * pLi;
+      p_vm[e] = PM == PM_TABLE_MASK ? pVm[ic] : ~0ull;
+    }
+  } else {
+    const int i = i0 + 4 * p_q;
+    p_fok[0] = i < M;
+    const int ic = p_fok[0] ? i : i0;
+    p_fix[0] = PM != PM_AFFINE ? pTi[ic] : ic;
+    p_vm[0] = ~0ull;
+  }
+  constexpr int QNQ = QL == I2_Q_ALONG_R ? BKT / 4 : BN / 4;
+  constexpr int QSTEP = 256 / QNQ;
+  constexpr int NVQ = (QL == I2_Q_ALONG_R ? BN : BKT) / QSTEP;
+  const int q_q = t % QNQ, q_l = t / QNQ;
+  constexpr int NFQ = QL == I2_Q_ALONG_R ? NVQ : 1;
+  int q_fix[NFQ];
+  bool q_fok[NFQ];
+  if (QL == I2_Q_ALONG_R) {
+#pragma unroll
+    for (int e = 0; e < NVQ; ++e) {
+      const int j = j0 + q_l + e * QSTEP;
+      q_fok[e] = j < N;
+      q_fix[e] = (q_fok[e] ? j : j0) * qLj;
+    }
+  } else {
+    const int j = j0 + 4 * q_q;
+    q_fok[0] = j < N;
+    q_fix[0] = q_fok[0] ? j : j0;
+  }
+
+  // table entries are fetched two slabs ahead of the MFMAs that use the data
+  constexpr int NTP = PL == I2_P_ALONG_R ? 1 : NVP;
+  constexpr int NTQ = QL == I2_Q_ALONG_R ? 1 : NVQ;
+  int ptab_nx[NTP], ptap_nx = 0, qtab_nx[NTQ];
+  auto fetch_tabs = [&](int r0) {
+    if (PM != PM_AFFINE) {
+#pragma unroll
+      for (int e = 0; e < NTP; ++e) {
+        const int r = PL == I2_P_ALONG_R ? r0 + 4 * p_q : r0 + p_l + e * PSTEP;
+        const int rc = r < r_end ? r : r_begin;
+        ptab_nx[e] = pTr[rc];
+        if (PM == PM_TABLE_MASK && PL == I2_P_ALONG_R) ptap_nx = pTap[rc];
+      }
+    }
+    if (QM == QM_TABLE) {
+#pragma unroll
+      for (int e = 0; e < NTQ; ++e) {
+        const int r = QL == I2_Q_ALONG_R ? r0 + 4 * q_q : r0 + q_l + e * QSTEP;
+        qtab_nx[e] = qTr[r < r_end ? r : r_begin];
+      }
+    }
+  };
+
+  f32x4 pv[NVP], qv[NVQ];
+  unsigned p_kb = 0xfu, q_kb = 0xfu;   // KTAIL: validity of the 4 elements of an along-r vector
+
+  // one vector of slab r0 (compile-time e): offset select + buffer load, nothing else
+  auto load_p = [&](int r0, int e) {
+    if (I2_ABLATE & 1) { pv[e] = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
+    if (PL == I2_P_ALONG_R) {
+      const int r = r0 + 4 * p_q;
+      bool ok = r < r_end && p_fok[e];
+      if (PM == PM_TABLE_MASK) ok = ok && ((p_vm[e] >> ptap_nx) & 1ull);
+      const int colterm = PM != PM_AFFINE ? ptab_nx[0] : r;
+      pv[e] = i2_ld(rsP, ok ? (p_fix[e] + colterm) * 4 : I2_OOB);
+      if (KTAIL && e == 0) p_kb = r + 4 <= r_end ? 0xfu : (0xfu >> min(4, max(0, r + 4 - r_end)));
+    } else {
+      const int r = r0 + p_l + e * PSTEP;
+      const bool ok = r < r_end && p_fok[0];
+      const int colterm = PM != PM_AFFINE ? ptab_nx[e] : r * pLr;
+      pv[e] = i2_ld(rsP, ok ? (p_fix[0] + colterm) * 4 : I2_OOB);
+    }
+  };
+  auto load_q = [&](int r0, int e) {
+    if (I2_ABLATE & 1) { qv[e] = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
+    if (QL == I2_Q_ALONG_R) {
+      const int r = r0 + 4 * q_q;
+      const bool ok = r < r_end && q_fok[e];
+      const int rowterm = QM == QM_TABLE ? qtab_nx[0] : r;
+      qv[e] = i2_ld(rsQ, ok ? (rowterm + q_fix[e]) * 4 : I2_OOB);
+      if (KTAIL && e == 0) q_kb = r + 4 <= r_end ? 0xfu : (0xfu >> min(4, max(0, r + 4 - r_end)));
+    } else {
+      const int r = r0 + q_l + e * QSTEP;
+      const bool ok = r < r_end && q_fok[0];
+      const int rowterm = QM == QM_TABLE ? qtab_nx[e] : r * qLr;
+      qv[e] = i2_ld(rsQ, ok ? (rowterm + q_fix[0]) * 4 : I2_OOB);
+    }
+  };
+  auto ktail_fix = [&](f32x4 v, unsigned m) {
+    v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
+    v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+    return v;
+  };
+  // LDS position of reduction index k inside its 32-deep block: lane half h, MFMA step m consume
+  // position 16h + m, and that position holds k = 2m + h -- the k-order of a slab (pairs (0,1), (2,3),
+  // ...) is then the one igemm_kernel uses, so both kernels produce bit-identical sums.
+  auto kpos = [](int k) { return (k & ~31) | ((k & 1) << 4) | ((k & 31) >> 1); };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto put_kquad = [&](float* rowp, int q, f32x4 v) {   // logical k = 4q..4q+3 of a K-contiguous row
+    float* d = rowp + (q >> 3) * 32 + 2 * (q & 7);
+    *(f32x2*)d = f32x2{v.x, v.z};
+    *(f32x2*)(d + 16) = f32x2{v.y, v.w};
+  };
+  auto store_p = [&](float* buf, int e) {
+    if (I2_ABLATE & 2) { asm volatile("" ::"v"(pv[e].x)); return; }
+    if (PL == I2_P_ALONG_R) {
+      put_kquad(buf + (p_l + e * PSTEP) * LDPK, p_q, KTAIL ? ktail_fix(pv[e], p_kb) : pv[e]);
+    } else {
+      *(f32x4*)(buf + kpos(p_l + e * PSTEP) * LDPM + 4 * p_q) = pv[e];
+    }
+  };
+  auto store_q = [&](float* buf, int e) {
+    if (I2_ABLATE & 2) { asm volatile("" ::"v"(qv[e].x)); return; }
+    float* Qs = buf + PSZ;
+    if (QL == I2_Q_ALONG_R) {
+      put_kquad(Qs + (q_l + e * QSTEP) * LDQK, q_q, KTAIL ? ktail_fix(qv[e], q_kb) : qv[e]);
+    } else {
+      *(f32x4*)(Qs + kpos(q_l + e * QSTEP) * LDQN + 4 * q_q) = qv[e];
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
+
+  const bool do_ones = ONES && tl.z == 0;   // bias-gradient row: column sums of the staged Q slabs
+  float csum = 0.f;
+
+  // ---------------------------------------------------------------- pipeline
+  // registers hold slab s+1 while the MFMAs of slab s run from LDS buffer s&1; inside that MFMA chain
+  // the registers are written to buffer (s+1)&1 and immediately refilled with the loads of slab s+2.
+  // Every piece of staging work sits in the shadow of one MFMA of the (dependent, in-order) chain;
+  // per slab only the fragment reads after the barrier are exposed.
+  const int nslab = (r_end - r_begin + BKT - 1) / BKT;
+  fetch_tabs(r_begin);
+#pragma unroll
+  for (int e = 0; e < NVP; ++e) load_p(r_begin, e);
+#pragma unroll
+  for (int e = 0; e < NVQ; ++e) load_q(r_begin, e);
+  fetch_tabs(r_begin + BKT);
+#pragma unroll
+  for (int e = 0; e < NVP; ++e) store_p(lds, e);
+#pragma unroll
+  for (int e = 0; e < NVQ; ++e) store_q(lds, e);
+#pragma unroll
+  for (int e = 0; e < NVP; ++e) load_p(r_begin + BKT, e);
+#pragma unroll
+  for (int e = 0; e < NVQ; ++e) load_q(r_begin + BKT, e);
+  fetch_tabs(r_begin + 2 * BKT);
+  __syncthreads();
+
+  constexpr int NMF = 16 * FM * FN;            // MFMAs of one slab per wave
+  constexpr int NST = NVP + NVQ;               // staged vectors per thread and slab
+  static_assert(2 * NST + 1 <= NMF - 3 - (ONES ? 1 : 0), "staging work must fit into the MFMA gaps of a slab");
+  for (int s = 0; s < nslab; ++s) {
+    float* cur = lds + (s & 1) * BUF;
+    float* nxt = lds + ((s + 1) & 1) * BUF;
+    const int r2 = r_begin + (s + 2) * BKT;
+    // ---------------- fragments: LDS -> registers in four chunks of 4 k-steps.  Only chunk 0 is
+    // read before the chain starts (all four waves leave the barrier together, so whatever is read
+    // here queues on the LDS four deep); chunk c+1 is requested in the first gap of chunk c.
+    const float* Ps = cur;
+    const float* Qs = cur + PSZ;
+    float av[FM][16], bv[FN][16];
+    auto read_chunk = [&](int c) {
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        const int row = (wm * FM + a) * 32 + li;
+        if (PL == I2_P_ALONG_R) {
+          const f32x4 v = *(const f32x4*)(Ps + row * LDPK + wk * 32 + 16 * lh + 4 * c);
+          av[a][4 * c] = v.x; av[a][4 * c + 1] = v.y; av[a][4 * c + 2] = v.z; av[a][4 * c + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int m = 4 * c; m < 4 * c + 4; ++m) av[a][m] = Ps[(wk * 32 + 16 * lh + m) * LDPM + row];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < FN; ++b) {
+        const int col = (wn * FN + b) * 32 + li;
+        if (QL == I2_Q_ALONG_R) {
+          const f32x4 v = *(const f32x4*)(Qs + col * LDQK + wk * 32 + 16 * lh + 4 * c);
+          bv[b][4 * c] = v.x; bv[b][4 * c + 1] = v.y; bv[b][4 * c + 2] = v.z; bv[b][4 * c + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int m = 4 * c; m < 4 * c + 4; ++m) bv[b][m] = Qs[(wk * 32 + 16 * lh + m) * LDQN + col];
+        }
+      }
+    };
+    read_chunk(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- MFMA chain with one piece of other work per gap
+    constexpr int GPC = 4 * FM * FN;            // gaps per chunk
+    int piece = 0;                              // compile-time after unrolling
+#pragma unroll
+    for (int g = 0; g < NMF; ++g) {
+      const int m = g / (FM * FN), a = (g / FN) % FM, b = g % FN;
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][m], bv[b][m], acc[a][b], 0, 0, 0);
+      if (g % GPC == 0 && g / GPC < 3) {
+        read_chunk(g / GPC + 1);
+      } else if (ONES && g == 1) {
+        if (do_ones) {
+          const int col = t & (BN - 1), rq = t / BN;          // 256/BN row groups
+          constexpr int RPG = 32 / (256 / BN);
+#pragma unroll
+          for (int u = 0; u < RPG; ++u) csum += Qs[(rq * RPG + u) * LDQN + col];
+        }
+      } else {
+        if (piece < NVP) store_p(nxt, piece);
+        else if (piece < NST) store_q(nxt, piece - NVP);
+        else if (piece < NST + NVP) load_p(r2, piece - NST);
+        else if (piece < 2 * NST) load_q(r2, piece - NST - NVP);
+        else if (piece == 2 * NST) fetch_tabs(r2 + BKT);
+        ++piece;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(I2_ABLATE & 4)) __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const gf32 cbase = (gf32)(pb->c + (long)tl.y * pb->slab_stride);
+  const int ldc = pb->ldc;
+  const gci32 cT = (gci32)pb->c_tab_i;
+  const gcf32 bias = (gcf32)pb->bias;
+  const gcf32 rmask = (gcf32)pb->relu_mask;
+  const int act = pb->act;
+  const float alpha = pb->act_alpha;
+  const int accumulate = pb->accumulate;
+  const float oscale = pb->out_scale != 0.f ? pb->out_scale : 1.f;
+  auto emit = [&](int i, int j, float a, float bj) {
+    long off;
+    if (cT) {
+      const int o = cT[i];
+      if (o < 0) return;
+      off = (long)o + j;
+    } else {
+      off = (long)i * ldc + j;
+    }
+    float v = a * oscale + bj;
+    if (accumulate) v += cbase[off];
+    if (act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+    if (rmask) v = rmask[off] > 0.f ? v : 0.f;
+    cbase[off] = v;
+  };
+
+  if (WK == 1) {
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+      const int j = j0 + (wn * FN + b) * 32 + li;
+      if (j >= N) continue;
+      const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int i = i0 + (wm * FM + a) * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
+          if (i < M) emit(i, j, acc[a][b][x], bj);
+        }
+    }
+    if (ONES && do_ones) {
+      // all slabs are consumed (trailing barrier of the loop): reuse the staging LDS
+      lds[t] = csum;
+      __syncthreads();
+      if (t < BN) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 256 / BN; ++g) s += lds[g * BN + t];
+        const int j = j0 + t;
+        if (j < N) emit(ones_i, j, s, 0.f);
+      }
+    }
+  } else {
+    // the four waves hold partial sums over disjoint k ranges: add them in wave order through LDS
+    float* red = lds;
+    constexpr int LDR = BN + 1;
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int rl = (wm * FM + a) * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
+          const int cl = (wn * FN + b) * 32 + li;
+          red[(wk * BM + rl) * LDR + cl] = acc[a][b][x];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < BM * BN / 256; ++e) {
+      const int o = t + 256 * e;
+      const int rl = o / BN, cl = o % BN;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WK; ++w) s += red[(w * BM + rl) * LDR + cl];
+      const int i = i0 + rl, j = j0 + cl;
+      if (i < M && j < N) emit(i, j, s, bias ? bias[j] : 0.f);
+    }
+  }
+}
+
+#endif  // GRL_HOSTEMU
+
+}  // namespace grl
