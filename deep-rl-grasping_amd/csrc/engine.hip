@@ -26,6 +26,7 @@
 #include "elem_kernels.h"
 #include "igemm.h"
 #include "igemm2.h"
+#include "heads_kernels.h"
 
 namespace grl {
 
@@ -132,6 +133,7 @@ struct HeadAct {
 };
 struct HeadGrad {
   float* g[GRL_MAX_LAYERS];
+  int ld0 = 0;   // row stride of g[0] (fused heads: the critics' g[0] are column blocks of one buffer)
 };
 
 }  // namespace grl
@@ -178,6 +180,9 @@ struct grl_ctx {
   HeadGrad gPI, gVF, gQF1, gQF2, gQF1PI;
   float *da_pi, *dmu, *dls;
   float *dfeat[2], *g3[2], *g2[2], *g1[2];
+  bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
+  float *u_l0[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // layer-0 feature partials: pi, vf, qf1, qf2, target
+  float* g0cat = nullptr;            // [B, 3*H0]: layer-0 gradients of vf | qf1 | qf2
   // act path
   float *ax, *aa1, *aa2, *aa3, *afeat, *a_eps, *a_out;
   HeadAct ahPI;
@@ -187,6 +192,7 @@ struct grl_ctx {
   float *ex_in, *ec1, *ec2, *ec3, *eout;
 
   std::vector<Upload> uploads;
+  std::vector<std::pair<void*, size_t>> zero_once;   // regions cleared once at creation
   std::vector<Launch*> launches;
   std::vector<ReduceDesc> reduces;
   ReduceDesc* d_reduces = nullptr;
@@ -491,12 +497,16 @@ struct grl_ctx {
   }
 
   // slab[(Kin + ones), N] = [x^T ; 1^T] * g     (weight + bias gradient of a dense layer)
+  // Kin_pad >= Kin: x columns [Kin, Kin_pad) exist (row padding of the buffer, kept zero) and are carried
+  // along so that the row count is a multiple of 4 (igemm2 fetches 4 rows of x^T per load); their
+  // slab rows are never reduced into the gradient bucket.
   static IgemmProb dense_wgrad(const float* x, int ldx, int Kin, bool ones, const float* g, int ldg, int N,
-                               int rows, float* slab, int split_target) {
+                               int rows, float* slab, int split_target, int Kin_pad = 0) {
     IgemmProb p = blank();
-    p.M = Kin + (ones ? 1 : 0); p.N = N; p.K = rows;
+    const int Kp = std::max(Kin, Kin_pad);
+    p.M = Kp + (ones ? 1 : 0); p.N = N; p.K = rows;
     p.p_base[0] = x; p.p_ld_i[0] = 1; p.p_ld_r[0] = ldx; single_part(p);
-    p.p_ones_i = ones ? Kin : -1;
+    p.p_ones_i = ones ? Kp : -1;
     p.q_base[0] = g; p.q_ld_r[0] = ldg; p.q_ld_j[0] = 1;
     p.c = slab; p.ldc = N;
     set_split(p, split_target);
@@ -665,6 +675,7 @@ struct grl_ctx {
           GRL_I2_CFGS(2000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE_MASK, QM_AFFINE, 0)     // padded conv forward
           GRL_I2_CFGS(10000, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0)        // dense backward-data
           GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data
+          GRL_I2_CFGS(10100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 0)         // dense backward-data over several kernels
           case 20000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, 0); break;         // dense weight gradient
           case 20001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, I2F_ONES); break;  //   ... with bias row
           case 20010: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 1, 0); break;
@@ -692,6 +703,7 @@ struct grl_ctx {
         case 1001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 1); break;       // dense backward-data
         case 3001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 3); break;       //   ... summed over heads
         case 1211: GRL_IGEMM(PM_TABLE_MASK, QM_TABLE, true, false, 1); break;    // conv backward-data
+        case 1011: GRL_IGEMM(PM_AFFINE, QM_TABLE, true, false, 1); break;        // dense backward-data over several kernels
         case 1002: GRL_IGEMM(PM_AFFINE, QM_AFFINE, false, true, 1); break;       // dense weight gradient
         case 1102: GRL_IGEMM(PM_TABLE, QM_AFFINE, false, true, 1); break;        // conv weight gradient
         default:
@@ -711,9 +723,9 @@ struct grl_ctx {
     r.src = p.c; r.splits = p.split; r.slab_stride = p.slab_stride;
     r.dst = grads + w_off + w_rows_off * p.N; r.n = rows * p.N;
     reduces.push_back(r);
-    if (b_off >= 0) {
+    if (b_off >= 0) {   // the bias gradient is the ones row of the slab
       ReduceDesc rb = r;
-      rb.src = p.c + (int64_t)rows * p.N; rb.dst = grads + b_off; rb.n = p.N;
+      rb.src = p.c + (int64_t)p.p_ones_i * p.N; rb.dst = grads + b_off; rb.n = p.N;
       reduces.push_back(rb);
     }
   }
@@ -722,8 +734,9 @@ struct grl_ctx {
     for (int l = 0; l < L; ++l) h.z[l] = wk.f32((int64_t)rows * hid[l]);
     for (int k = 0; k < n_out; ++k) h.out[k] = wk.f32((int64_t)rows * out_dim);
   }
-  void alloc_hgrad(HeadGrad& g, int rows) {
-    for (int l = 0; l < L; ++l) g.g[l] = wk.f32((int64_t)rows * hid[l]);
+  void alloc_hgrad(HeadGrad& g, int rows, float* g0 = nullptr, int ld0 = 0) {
+    for (int l = 0; l < L; ++l) g.g[l] = (l == 0 && g0) ? g0 : wk.f32((int64_t)rows * hid[l]);
+    g.ld0 = g0 ? ld0 : hid[0];
   }
 
   // forward problems of one MLP head (layer l or the output layer)
@@ -813,7 +826,10 @@ int grl_ctx::plan_sac() {
   // ---------------- training workspace
   idx_buf = (int64_t*)wk.take((size_t)B * 8);
   eps_buf = wk.f32((int64_t)B * A);
-  for (int n = 0; n < 3; ++n) feat[n] = wk.f32((int64_t)B * ldf);
+  for (int n = 0; n < 3; ++n) {
+    feat[n] = wk.f32((int64_t)B * ldf);
+    zero_once.push_back({feat[n], (size_t)B * ldf * 4});   // row padding [F, ldf) is read by 16-byte loads
+  }
   if (cnn) {
     x_obs = wk.f32((int64_t)B * img_elems);
     x_next = wk.f32((int64_t)B * img_elems);
@@ -828,7 +844,22 @@ int grl_ctx::plan_sac() {
   alloc_head(hTGT, B, 1, 1); alloc_head(hQF1PI, B, 1, 1); alloc_head(hQF2PI, B, 1, 1);
   pi_a = wk.f32((int64_t)B * A); logp = wk.f32(B); ent = wk.f32(B);
   d_qf1 = wk.f32(B); d_qf2 = wk.f32(B); d_v = wk.f32(B); d_qf1pi = wk.f32(B);
-  alloc_hgrad(gPI, B); alloc_hgrad(gVF, B); alloc_hgrad(gQF1, B); alloc_hgrad(gQF2, B); alloc_hgrad(gQF1PI, B);
+  {
+    const char* nf = getenv("GRL_NO_FUSED_HEADS");
+    fused_heads = !(nf && nf[0] == '1') && A <= HT_MAXA && (hid[0] % 4) == 0;
+    for (int l = 0; l < L; ++l) fused_heads = fused_heads && hid[l] <= HT_MAXW;
+  }
+  if (fused_heads) {
+    for (int k = 0; k < 5; ++k) u_l0[k] = wk.f32((int64_t)B * hid[0]);
+    g0cat = wk.f32((int64_t)B * 3 * hid[0]);
+    alloc_hgrad(gPI, B);
+    alloc_hgrad(gVF, B, g0cat, 3 * hid[0]);
+    alloc_hgrad(gQF1, B, g0cat + hid[0], 3 * hid[0]);
+    alloc_hgrad(gQF2, B, g0cat + 2 * hid[0], 3 * hid[0]);
+    alloc_hgrad(gQF1PI, B);
+  } else {
+    alloc_hgrad(gPI, B); alloc_hgrad(gVF, B); alloc_hgrad(gQF1, B); alloc_hgrad(gQF2, B); alloc_hgrad(gQF1PI, B);
+  }
   da_pi = wk.f32((int64_t)B * A); dmu = wk.f32((int64_t)B * A); dls = wk.f32((int64_t)B * A);
   if (cnn)
     for (int n = 0; n < 2; ++n) {
@@ -901,45 +932,89 @@ int grl_ctx::plan_sac() {
   }
   (void)T;
 
-  // heads forward: pi, vf, qf1, qf2 (data action), target vf
-  for (int l = 0; l < L; ++l) {
+  // description of one head for the row-local kernels (heads_kernels.h)
+  auto mk_head = [&](const MlpP& m, const HeadAct& h, const HeadGrad* g, const float* u, const float* xa, int ld_xa,
+                     int n_xa) {
+    HtHead H;
+    memset(&H, 0, sizeof(H));
+    H.u = u; H.ldu = hid[0];
+    H.xa = xa; H.ld_xa = ld_xa; H.n_xa = n_xa;
+    H.w0a = P + m.w[0] + (int64_t)F * hid[0];
+    H.b0 = P + m.b[0]; H.z0 = h.z[0]; H.H0 = hid[0]; H.L = L;
+    for (int l = 0; l < L; ++l) H.hid[l] = hid[l];
+    for (int l = 1; l < L; ++l) { H.w[l] = P + m.w[l]; H.b[l] = P + m.b[l]; H.z[l] = h.z[l]; }
+    if (g) {
+      H.g0 = g->g[0]; H.ldg0 = g->ld0;
+      for (int l = 1; l < L; ++l) H.g[l] = g->g[l];
+    }
+    H.n_out = m.n_out; H.out_dim = m.out_dim;
+    for (int k = 0; k < m.n_out; ++k) { H.ow[k] = P + m.ow[k]; H.ob[k] = P + m.ob[k]; H.out[k] = h.out[k]; }
+    return H;
+  };
+  if (fused_heads) {
+    // layer 0, feature part only (no bias, no activation): u = feat . W0[0:F]
+    const MlpP* ms[5] = {&m_pi, &m_vf, &m_qf1, &m_qf2, &m_tgt};
+    const float* fin[5] = {feat[0], feat[1], feat[1], feat[1], feat[2]};
     std::vector<IgemmProb> pr;
-    pr.push_back(head_layer(m_pi, P, hPI, l, feat[0], ldf, F, nullptr, 0, 0, B));
-    pr.push_back(head_layer(m_vf, P, hVF, l, feat[1], ldf, F, nullptr, 0, 0, B));
-    pr.push_back(head_layer(m_qf1, P, hQF1, l, feat[1], ldf, F, act, A, A, B));
-    pr.push_back(head_layer(m_qf2, P, hQF2, l, feat[1], ldf, F, act, A, A, B));
-    pr.push_back(head_layer(m_tgt, P, hTGT, l, feat[2], ldf, F, nullptr, 0, 0, B));
-    add_launch(ops_grads, "heads_fwd", 0, pr);
-  }
-  {
-    std::vector<IgemmProb> pr;
-    pr.push_back(head_out(m_pi, P, hPI, 0, B));
-    pr.push_back(head_out(m_pi, P, hPI, 1, B));
-    pr.push_back(head_out(m_vf, P, hVF, 0, B));
-    pr.push_back(head_out(m_qf1, P, hQF1, 0, B));
-    pr.push_back(head_out(m_qf2, P, hQF2, 0, B));
-    pr.push_back(head_out(m_tgt, P, hTGT, 0, B));
-    add_launch(ops_grads, "heads_fwd", 0, pr);
-  }
-  {
-    SampleArgs sa{hPI.out[0], hPI.out[1], eps_buf, B, A, pi_a, nullptr, logp, ent};
-    Op op; op.tag = "sample";
-    op.run = [sa](hipStream_t s) {
-      hipLaunchKernelGGL(sample_kernel, dim3((sa.B + 255) / 256), dim3(256), 0, s, sa);
+    for (int k = 0; k < 5; ++k)
+      pr.push_back(dense_fwd(fin[k], ldf, F, nullptr, 0, 0, B, P + ms[k]->w[0], hid[0], nullptr, u_l0[k], hid[0], ACT_NONE));
+    add_launch(ops_grads, "heads_l0", 0, pr);
+    HeadsFwdArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.h[0] = mk_head(m_pi, hPI, nullptr, u_l0[0], nullptr, 0, 0);
+    fa.h[1] = mk_head(m_vf, hVF, nullptr, u_l0[1], nullptr, 0, 0);
+    fa.h[2] = mk_head(m_qf1, hQF1, nullptr, u_l0[2], act, A, A);
+    fa.h[3] = mk_head(m_qf2, hQF2, nullptr, u_l0[3], act, A, A);
+    fa.h[4] = mk_head(m_tgt, hTGT, nullptr, u_l0[4], nullptr, 0, 0);
+    fa.h[5] = mk_head(m_qf1, hQF1PI, nullptr, u_l0[2], pi_a, A, A);
+    fa.h[6] = mk_head(m_qf2, hQF2PI, nullptr, u_l0[3], pi_a, A, A);
+    fa.B = B; fa.A = A; fa.eps = eps_buf; fa.pi_a = pi_a; fa.logp = logp; fa.ent = ent;
+    Op op; op.tag = "heads_fwd";
+    op.run = [fa](hipStream_t s) {
+      hipLaunchKernelGGL(heads_fwd_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 5), dim3(256), 0, s, fa);
     };
     ops_grads.push_back(op);
-  }
-  for (int l = 0; l < L; ++l) {
-    std::vector<IgemmProb> pr;
-    pr.push_back(head_layer(m_qf1, P, hQF1PI, l, feat[1], ldf, F, pi_a, A, A, B));
-    pr.push_back(head_layer(m_qf2, P, hQF2PI, l, feat[1], ldf, F, pi_a, A, A, B));
-    add_launch(ops_grads, "heads_fwd", 0, pr);
-  }
-  {
-    std::vector<IgemmProb> pr;
-    pr.push_back(head_out(m_qf1, P, hQF1PI, 0, B));
-    pr.push_back(head_out(m_qf2, P, hQF2PI, 0, B));
-    add_launch(ops_grads, "heads_fwd", 0, pr);
+  } else {
+    // heads forward: pi, vf, qf1, qf2 (data action), target vf
+    for (int l = 0; l < L; ++l) {
+      std::vector<IgemmProb> pr;
+      pr.push_back(head_layer(m_pi, P, hPI, l, feat[0], ldf, F, nullptr, 0, 0, B));
+      pr.push_back(head_layer(m_vf, P, hVF, l, feat[1], ldf, F, nullptr, 0, 0, B));
+      pr.push_back(head_layer(m_qf1, P, hQF1, l, feat[1], ldf, F, act, A, A, B));
+      pr.push_back(head_layer(m_qf2, P, hQF2, l, feat[1], ldf, F, act, A, A, B));
+      pr.push_back(head_layer(m_tgt, P, hTGT, l, feat[2], ldf, F, nullptr, 0, 0, B));
+      add_launch(ops_grads, "heads_fwd", 0, pr);
+    }
+    {
+      std::vector<IgemmProb> pr;
+      pr.push_back(head_out(m_pi, P, hPI, 0, B));
+      pr.push_back(head_out(m_pi, P, hPI, 1, B));
+      pr.push_back(head_out(m_vf, P, hVF, 0, B));
+      pr.push_back(head_out(m_qf1, P, hQF1, 0, B));
+      pr.push_back(head_out(m_qf2, P, hQF2, 0, B));
+      pr.push_back(head_out(m_tgt, P, hTGT, 0, B));
+      add_launch(ops_grads, "heads_fwd", 0, pr);
+    }
+    {
+      SampleArgs sa{hPI.out[0], hPI.out[1], eps_buf, B, A, pi_a, nullptr, logp, ent};
+      Op op; op.tag = "sample";
+      op.run = [sa](hipStream_t s) {
+        hipLaunchKernelGGL(sample_kernel, dim3((sa.B + 255) / 256), dim3(256), 0, s, sa);
+      };
+      ops_grads.push_back(op);
+    }
+    for (int l = 0; l < L; ++l) {
+      std::vector<IgemmProb> pr;
+      pr.push_back(head_layer(m_qf1, P, hQF1PI, l, feat[1], ldf, F, pi_a, A, A, B));
+      pr.push_back(head_layer(m_qf2, P, hQF2PI, l, feat[1], ldf, F, pi_a, A, A, B));
+      add_launch(ops_grads, "heads_fwd", 0, pr);
+    }
+    {
+      std::vector<IgemmProb> pr;
+      pr.push_back(head_out(m_qf1, P, hQF1PI, 0, B));
+      pr.push_back(head_out(m_qf2, P, hQF2PI, 0, B));
+      add_launch(ops_grads, "heads_fwd", 0, pr);
+    }
   }
   {
     LossArgs la;
@@ -956,57 +1031,100 @@ int grl_ctx::plan_sac() {
 
   // =============================================================== backward through the heads
   // g[l] = gradient w.r.t. the pre-activation of layer l (ReLU mask already applied)
-  {
-    std::vector<IgemmProb> pr;   // output layer -> g[L-1]
-    pr.push_back(dense_bwd({{d_v, 1, 1, P + m_vf.ow[0]}}, B, 0, hid[L - 1], gVF.g[L - 1], hid[L - 1], hVF.z[L - 1]));
-    pr.push_back(dense_bwd({{d_qf1, 1, 1, P + m_qf1.ow[0]}}, B, 0, hid[L - 1], gQF1.g[L - 1], hid[L - 1], hQF1.z[L - 1]));
-    pr.push_back(dense_bwd({{d_qf2, 1, 1, P + m_qf2.ow[0]}}, B, 0, hid[L - 1], gQF2.g[L - 1], hid[L - 1], hQF2.z[L - 1]));
-    pr.push_back(dense_bwd({{d_qf1pi, 1, 1, P + m_qf1.ow[0]}}, B, 0, hid[L - 1], gQF1PI.g[L - 1], hid[L - 1], hQF1PI.z[L - 1]));
-    add_launch(ops_grads, "heads_bwd", 1, pr);
-  }
-  for (int l = L - 1; l >= 1; --l) {
-    std::vector<IgemmProb> pr;
-    pr.push_back(dense_bwd({{gVF.g[l], hid[l], hid[l], P + m_vf.w[l]}}, B, 0, hid[l - 1], gVF.g[l - 1], hid[l - 1], hVF.z[l - 1]));
-    pr.push_back(dense_bwd({{gQF1.g[l], hid[l], hid[l], P + m_qf1.w[l]}}, B, 0, hid[l - 1], gQF1.g[l - 1], hid[l - 1], hQF1.z[l - 1]));
-    pr.push_back(dense_bwd({{gQF2.g[l], hid[l], hid[l], P + m_qf2.w[l]}}, B, 0, hid[l - 1], gQF2.g[l - 1], hid[l - 1], hQF2.z[l - 1]));
-    pr.push_back(dense_bwd({{gQF1PI.g[l], hid[l], hid[l], P + m_qf1.w[l]}}, B, 0, hid[l - 1], gQF1PI.g[l - 1], hid[l - 1], hQF1PI.z[l - 1]));
-    add_launch(ops_grads, "heads_bwd", 1, pr);
-  }
-  {
-    std::vector<IgemmProb> pr;   // first layer: d a_pi (policy path) and d feat (critic CNN path)
-    pr.push_back(dense_bwd({{gQF1PI.g[0], hid[0], hid[0], P + m_qf1.w[0]}}, B, F, A, da_pi, A, nullptr));
-    if (cnn)
-      pr.push_back(dense_bwd({{gVF.g[0], hid[0], hid[0], P + m_vf.w[0]},
-                              {gQF1.g[0], hid[0], hid[0], P + m_qf1.w[0]},
-                              {gQF2.g[0], hid[0], hid[0], P + m_qf2.w[0]}},
-                             B, 0, Fc, dfeat[1], ldf, feat[1]));
-    add_launch(ops_grads, "heads_bwd", 1, pr);
-  }
-  {
-    SampleBwdArgs sb{hPI.out[0], hPI.out[1], eps_buf, pi_a, da_pi, A, params + ent_off, B, A, dmu, dls};
-    Op op; op.tag = "sample_bwd";
-    op.run = [sb](hipStream_t s) {
-      hipLaunchKernelGGL(sample_bwd_kernel, dim3((sb.B + 255) / 256), dim3(256), 0, s, sb);
+  if (fused_heads) {
+    HeadsBwdArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.h[0] = mk_head(m_pi, hPI, &gPI, u_l0[0], nullptr, 0, 0);
+    ba.h[1] = mk_head(m_vf, hVF, &gVF, u_l0[1], nullptr, 0, 0);
+    ba.h[2] = mk_head(m_qf1, hQF1, &gQF1, u_l0[2], act, A, A);
+    ba.h[3] = mk_head(m_qf2, hQF2, &gQF2, u_l0[3], act, A, A);
+    ba.h[4] = mk_head(m_qf1, hQF1PI, &gQF1PI, u_l0[2], pi_a, A, A);
+    ba.h[1].dout[0] = d_v; ba.h[2].dout[0] = d_qf1; ba.h[3].dout[0] = d_qf2; ba.h[4].dout[0] = d_qf1pi;
+    ba.B = B; ba.A = A; ba.mu = hPI.out[0]; ba.ls_raw = hPI.out[1]; ba.eps = eps_buf; ba.pi_a = pi_a;
+    ba.log_ent_coef = params + ent_off; ba.da_pi = da_pi; ba.dmu = dmu; ba.dls = dls;
+    Op op; op.tag = "heads_bwd";
+    op.run = [ba](hipStream_t s) {
+      hipLaunchKernelGGL(heads_bwd_kernel, dim3((ba.B + HT_RB - 1) / HT_RB, 4), dim3(256), 0, s, ba);
     };
     ops_grads.push_back(op);
-  }
-  {
-    std::vector<IgemmProb> pr;
-    pr.push_back(dense_bwd({{dmu, A, A, P + m_pi.ow[0]}, {dls, A, A, P + m_pi.ow[1]}}, B, 0, hid[L - 1],
-                           gPI.g[L - 1], hid[L - 1], hPI.z[L - 1]));
-    add_launch(ops_grads, "heads_bwd", 1, pr);
-  }
-  for (int l = L - 1; l >= 1; --l) {
-    std::vector<IgemmProb> pr;
-    pr.push_back(dense_bwd({{gPI.g[l], hid[l], hid[l], P + m_pi.w[l]}}, B, 0, hid[l - 1], gPI.g[l - 1], hid[l - 1], hPI.z[l - 1]));
-    add_launch(ops_grads, "heads_bwd", 1, pr);
-  }
-  if (cnn) {
-    std::vector<IgemmProb> pr;
-    pr.push_back(dense_bwd({{gPI.g[0], hid[0], hid[0], P + m_pi.w[0]}}, B, 0, Fc, dfeat[0], ldf, feat[0]));
-    add_launch(ops_grads, "heads_bwd", 1, pr);
-  }
+    if (cnn) {
+      // d feat = g0 . W0[0:Fc]^T, masked by feat > 0.  Critic net: the three layer-0 gradients sit side
+      // by side in g0cat and the three kernels are reached through a table (K = 3*H0 in one pass).
+      const int H0 = hid[0];
+      std::vector<int32_t> qt3(3 * H0), qt1(H0);
+      const int64_t offs[3] = {m_vf.w[0], m_qf1.w[0], m_qf2.w[0]};
+      for (int k = 0; k < 3; ++k)
+        for (int n = 0; n < H0; ++n) qt3[k * H0 + n] = (int32_t)(offs[k] - offs[0]) + n;
+      for (int n = 0; n < H0; ++n) qt1[n] = n;
+      auto tab_bwd = [&](const float* g, int ldg, int K, const float* wbase, const int32_t* dtab, float* dx,
+                         const float* mask) {
+        IgemmProb p = blank();
+        p.M = B; p.N = Fc; p.K = K;
+        p.p_base[0] = g; p.p_ld_i[0] = ldg; p.p_ld_r[0] = 1; single_part(p);
+        p.q_base[0] = wbase; p.q_tab_r = dtab; p.q_ld_j[0] = H0;
+        p.c = dx; p.ldc = ldf; p.relu_mask = mask;
+        p.vflags = VF_Q_TAB;
+        set_split(p, 1);
+        return p;
+      };
+      std::vector<IgemmProb> pr;
+      pr.push_back(tab_bwd(g0cat, 3 * H0, 3 * H0, P + m_vf.w[0], upload_vec(wk, qt3), dfeat[1], feat[1]));
+      pr.push_back(tab_bwd(gPI.g[0], H0, H0, P + m_pi.w[0], upload_vec(wk, qt1), dfeat[0], feat[0]));
+      add_launch(ops_grads, "heads_dfeat", 1, pr);
+    }
+  } else {
+    {
+      std::vector<IgemmProb> pr;   // output layer -> g[L-1]
+      pr.push_back(dense_bwd({{d_v, 1, 1, P + m_vf.ow[0]}}, B, 0, hid[L - 1], gVF.g[L - 1], hid[L - 1], hVF.z[L - 1]));
+      pr.push_back(dense_bwd({{d_qf1, 1, 1, P + m_qf1.ow[0]}}, B, 0, hid[L - 1], gQF1.g[L - 1], hid[L - 1], hQF1.z[L - 1]));
+      pr.push_back(dense_bwd({{d_qf2, 1, 1, P + m_qf2.ow[0]}}, B, 0, hid[L - 1], gQF2.g[L - 1], hid[L - 1], hQF2.z[L - 1]));
+      pr.push_back(dense_bwd({{d_qf1pi, 1, 1, P + m_qf1.ow[0]}}, B, 0, hid[L - 1], gQF1PI.g[L - 1], hid[L - 1], hQF1PI.z[L - 1]));
+      add_launch(ops_grads, "heads_bwd", 1, pr);
+    }
+    for (int l = L - 1; l >= 1; --l) {
+      std::vector<IgemmProb> pr;
+      pr.push_back(dense_bwd({{gVF.g[l], hid[l], hid[l], P + m_vf.w[l]}}, B, 0, hid[l - 1], gVF.g[l - 1], hid[l - 1], hVF.z[l - 1]));
+      pr.push_back(dense_bwd({{gQF1.g[l], hid[l], hid[l], P + m_qf1.w[l]}}, B, 0, hid[l - 1], gQF1.g[l - 1], hid[l - 1], hQF1.z[l - 1]));
+      pr.push_back(dense_bwd({{gQF2.g[l], hid[l], hid[l], P + m_qf2.w[l]}}, B, 0, hid[l - 1], gQF2.g[l - 1], hid[l - 1], hQF2.z[l - 1]));
+      pr.push_back(dense_bwd({{gQF1PI.g[l], hid[l], hid[l], P + m_qf1.w[l]}}, B, 0, hid[l - 1], gQF1PI.g[l - 1], hid[l - 1], hQF1PI.z[l - 1]));
+      add_launch(ops_grads, "heads_bwd", 1, pr);
+    }
+    {
+      std::vector<IgemmProb> pr;   // first layer: d a_pi (policy path) and d feat (critic CNN path)
+      pr.push_back(dense_bwd({{gQF1PI.g[0], hid[0], hid[0], P + m_qf1.w[0]}}, B, F, A, da_pi, A, nullptr));
+      if (cnn)
+        pr.push_back(dense_bwd({{gVF.g[0], hid[0], hid[0], P + m_vf.w[0]},
+                                {gQF1.g[0], hid[0], hid[0], P + m_qf1.w[0]},
+                                {gQF2.g[0], hid[0], hid[0], P + m_qf2.w[0]}},
+                               B, 0, Fc, dfeat[1], ldf, feat[1]));
+      add_launch(ops_grads, "heads_bwd", 1, pr);
+    }
+    {
+      SampleBwdArgs sb{hPI.out[0], hPI.out[1], eps_buf, pi_a, da_pi, A, params + ent_off, B, A, dmu, dls};
+      Op op; op.tag = "sample_bwd";
+      op.run = [sb](hipStream_t s) {
+        hipLaunchKernelGGL(sample_bwd_kernel, dim3((sb.B + 255) / 256), dim3(256), 0, s, sb);
+      };
+      ops_grads.push_back(op);
+    }
+    {
+      std::vector<IgemmProb> pr;
+      pr.push_back(dense_bwd({{dmu, A, A, P + m_pi.ow[0]}, {dls, A, A, P + m_pi.ow[1]}}, B, 0, hid[L - 1],
+                             gPI.g[L - 1], hid[L - 1], hPI.z[L - 1]));
+      add_launch(ops_grads, "heads_bwd", 1, pr);
+    }
+    for (int l = L - 1; l >= 1; --l) {
+      std::vector<IgemmProb> pr;
+      pr.push_back(dense_bwd({{gPI.g[l], hid[l], hid[l], P + m_pi.w[l]}}, B, 0, hid[l - 1], gPI.g[l - 1], hid[l - 1], hPI.z[l - 1]));
+      add_launch(ops_grads, "heads_bwd", 1, pr);
+    }
+    if (cnn) {
+      std::vector<IgemmProb> pr;
+      pr.push_back(dense_bwd({{gPI.g[0], hid[0], hid[0], P + m_pi.w[0]}}, B, 0, Fc, dfeat[0], ldf, feat[0]));
+      add_launch(ops_grads, "heads_bwd", 1, pr);
+    }
 
+  }
   // =============================================================== backward through the two CNNs
   std::vector<IgemmProb> wg, wgc;   // weight gradients: dense layers / conv layers, launched at the end
   if (cnn) {
@@ -1057,17 +1175,18 @@ int grl_ctx::plan_sac() {
   // head weight gradients
   auto head_wgrads = [&](const MlpP& m, const HeadAct& h, const HeadGrad& g, const float* x0, int ld0, int K0,
                          const float* x1, int ld1, int K1, std::vector<const float*> douts) {
+    const int K0p = ld0 >= (int)rup(K0, 4) ? (int)rup(K0, 4) : K0;   // feat rows are padded to ldf (zeros)
     for (int l = 0; l < L; ++l) {
       if (l == 0) {
         if (K1 > 0) {
-          IgemmProb p0 = dense_wgrad(x0, ld0, K0, false, g.g[0], hid[0], hid[0], B, nullptr, 1);
+          IgemmProb p0 = dense_wgrad(x0, ld0, K0, false, g.g[0], g.ld0, hid[0], B, nullptr, 1, K0p);
           p0.c = wk.f32(p0.slab_stride * p0.split);
           add_wgrad(wg, p0, m.w[0], 0, K0, -1);
-          IgemmProb p1 = dense_wgrad(x1, ld1, K1, true, g.g[0], hid[0], hid[0], B, nullptr, 1);
+          IgemmProb p1 = dense_wgrad(x1, ld1, K1, true, g.g[0], g.ld0, hid[0], B, nullptr, 1);
           p1.c = wk.f32(p1.slab_stride * p1.split);
           add_wgrad(wg, p1, m.w[0], K0, K1, m.b[0]);
         } else {
-          IgemmProb p0 = dense_wgrad(x0, ld0, K0, true, g.g[0], hid[0], hid[0], B, nullptr, 1);
+          IgemmProb p0 = dense_wgrad(x0, ld0, K0, true, g.g[0], g.ld0, hid[0], B, nullptr, 1, K0p);
           p0.c = wk.f32(p0.slab_stride * p0.split);
           add_wgrad(wg, p0, m.w[0], 0, K0, m.b[0]);
         }
@@ -1088,7 +1207,19 @@ int grl_ctx::plan_sac() {
   head_wgrads(m_qf1, hQF1, gQF1, feat[1], ldf, F, act, A, A, {d_qf1});
   head_wgrads(m_qf2, hQF2, gQF2, feat[1], ldf, F, act, A, A, {d_qf2});
   add_launch(ops_grads, "wgrad_conv", 2, wgc);
-  add_launch(ops_grads, "wgrad_dense", 2, wg);
+  {
+    // the vectorised kernel needs uniform launches: with / without bias row; whatever it cannot take
+    // (4-misaligned inputs such as the [B, A] action block, 1..A-wide output layers) goes to igemm_kernel
+    std::vector<IgemmProb> wg_ones, wg_plain, wg_rest;
+    for (auto& p : wg) {
+      if (!v2_prob_ok(p, 2) || (p.K % 4)) wg_rest.push_back(p);
+      else if (p.p_ones_i >= 0) wg_ones.push_back(p);
+      else wg_plain.push_back(p);
+    }
+    add_launch(ops_grads, "wgrad_dense", 2, wg_ones);
+    add_launch(ops_grads, "wgrad_dense", 2, wg_plain);
+    add_launch(ops_grads, "wgrad_small", 2, wg_rest);
+  }
   {
     d_reduces = upload_vec(wk, reduces);
     std::vector<int2> rt;
@@ -1654,6 +1785,7 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
     if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
   }
   h->uploads.clear();
+  for (auto& z : h->zero_once) hipMemset(z.first, 0, z.second);
   // state: zero Adam moments, scalars; stats = identity
   hipMemset(h->adam_m, 0, (size_t)h->n_train * 4);
   hipMemset(h->adam_v, 0, (size_t)h->n_train * 4);

@@ -1,0 +1,501 @@
+// heads_kernels.h -- row-local kernels for the actor / critic MLP heads of the SAC update.
+//
+// The heads (stable-baselines sac/policies.py FeedForwardPolicy.make_actor / make_critics as wired by
+// /root/reference/manipulation_main/training/sb_helper.py:87-96) are tiny: after the
+// first layer (K = 513 features, done by the implicit GEMM as a bias-free partial pre-activation `u`)
+// every remaining layer is a 64x64-ish product per batch row.  Launching them as GEMMs costs ~20 us of
+// latency per layer; here one workgroup owns 16 batch rows and walks a whole chain of heads with the
+// activations kept transposed in LDS:
+//
+//   forward  chain 0: pi head -> squashed-Gaussian sample -> qf1(s, pi) -> qf2(s, pi)
+//            chains 1..4: vf, qf1(s, a), qf2(s, a), target vf
+//   backward chain 0: qf1(s, pi) backward -> d a_pi -> sample backward -> pi head backward
+//            chains 1..3: vf, qf1, qf2 (gradients w.r.t. every pre-activation; the layer-0 ones feed the
+//            feature-gradient GEMM and the weight-gradient GEMMs)
+//
+// Arithmetic order per output element is the k-sequential fmaf chain the MFMA kernels produce
+// (partial sum, then the remaining inputs in order, bias last), so moving a head between this path
+// and the GEMM path does not change its bits.
+#pragma once
+#include "elem_kernels.h"
+#include "../../include/grl.h"
+
+namespace grl {
+
+enum { HT_RB = 16, HT_MAXW = 128, HT_MAXA = 64 };
+
+struct HtHead {
+  // layer 0: z0 = relu(u + xa . w0a + b0)
+  const float* u; int ldu;                 // [B, ldu] feature part of the pre-activation (no bias)
+  const float* xa; int ld_xa; int n_xa;    // second input part (the action), n_xa == 0: none
+  const float* w0a;                        // [n_xa, H0]: rows of the layer-0 kernel after the feature rows
+  const float* b0;
+  float* z0;                               // [B, H0]
+  float* g0; int ldg0;                     // backward: gradient w.r.t. the layer-0 pre-activation
+  int H0, L;
+  // layers 1 .. L-1 (index l): z_l = relu(z_{l-1} . w[l] + b[l]),  w[l] is [hid[l-1], hid[l]]
+  const float* w[GRL_MAX_LAYERS]; const float* b[GRL_MAX_LAYERS];
+  float* z[GRL_MAX_LAYERS]; float* g[GRL_MAX_LAYERS];
+  int hid[GRL_MAX_LAYERS];                 // hid[0] == H0
+  // output layers (1 for vf / qf, 2 for pi: mu and log_std), each [hid[L-1], out_dim]
+  int n_out, out_dim;
+  const float* ow[2]; const float* ob[2]; float* out[2];
+  const float* dout[2];                    // backward: gradient w.r.t. the outputs [B, out_dim]
+  float* da; int ld_da;                    // backward: gradient w.r.t. xa (nullptr: not needed)
+};
+
+struct HeadsFwdArgs {
+  HtHead h[7];            // 0 pi, 1 vf, 2 qf1(a), 3 qf2(a), 4 target vf, 5 qf1(pi), 6 qf2(pi)
+  int B, A;
+  const float* eps;       // [B, A]
+  float* pi_a; float* logp; float* ent;
+};
+
+struct HeadsBwdArgs {
+  HtHead h[5];            // 0 pi, 1 vf, 2 qf1(a), 3 qf2(a), 4 qf1(pi)
+  int B, A;
+  const float* mu; const float* ls_raw; const float* eps; const float* pi_a;
+  const float* log_ent_coef;
+  float* da_pi;           // [B, A] (debug tap / split API)
+  float* dmu; float* dls; // [B, A]
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-element pieces of the squashed-Gaussian sample and its backward (same arithmetic as
+// sample_kernel / sample_bwd_kernel in elem_kernels.h)
+__device__ __forceinline__ float ht_sample_elem(float m, float ls_raw, float ep, float& logp, float& ent) {
+  const float ls = fminf(fmaxf(ls_raw, GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+  const float sd = expf(ls);
+  const float u = m + ep * sd;
+  const float z = (u - m) / (sd + GRL_EPS);
+  logp += -0.5f * (z * z + 2.f * ls + 1.8378770664093453f);
+  ent += ls + 1.4189385332046727f;
+  const float t = tanhf(u);
+  logp -= logf(1.f - t * t + GRL_EPS);
+  return t;
+}
+__device__ __forceinline__ void ht_sample_bwd_elem(float lr, float ep, float t, float da, float alpha_over_b,
+                                                   float& dmu, float& dls) {
+  const float ls = fminf(fmaxf(lr, GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+  const float sd = expf(ls);
+  const float omt = 1.f - t * t;
+  const float du = da * omt + alpha_over_b * (2.f * t * omt / (omt + GRL_EPS));
+  dmu = du;
+  const float den = sd + GRL_EPS;
+  const float z = sd * ep / den;
+  const float dz_dls = ep * sd * GRL_EPS / (den * den);
+  float d = du * sd * ep + alpha_over_b * (-(z * dz_dls + 1.f));
+  if (lr < GRL_LOG_STD_MIN || lr > GRL_LOG_STD_MAX) d = 0.f;
+  dls = d;
+}
+
+// per-row forms (hostemu reference)
+__device__ __forceinline__ void ht_sample_row(const float* mu, const float* ls_raw, const float* eps, int A,
+                                              float* pi, float* logp_out, float* ent_out) {
+  float logp = 0.f, ent = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float m = mu[j];
+    const float ls = fminf(fmaxf(ls_raw[j], GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+    const float sd = expf(ls);
+    const float u = m + eps[j] * sd;
+    const float z = (u - m) / (sd + GRL_EPS);
+    logp += -0.5f * (z * z + 2.f * ls + 1.8378770664093453f);
+    ent += ls + 1.4189385332046727f;
+    const float t = tanhf(u);
+    logp -= logf(1.f - t * t + GRL_EPS);
+    pi[j] = t;
+  }
+  *logp_out = logp;
+  *ent_out = ent;
+}
+
+__device__ __forceinline__ void ht_sample_bwd_row(const float* ls_raw, const float* eps, const float* pi,
+                                                  const float* da, int A, float alpha_over_b, float* dmu,
+                                                  float* dls) {
+  for (int j = 0; j < A; ++j) {
+    const float lr = ls_raw[j];
+    const float ls = fminf(fmaxf(lr, GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+    const float sd = expf(ls);
+    const float ep = eps[j];
+    const float t = pi[j];
+    const float omt = 1.f - t * t;
+    const float du = da[j] * omt + alpha_over_b * (2.f * t * omt / (omt + GRL_EPS));
+    dmu[j] = du;
+    const float den = sd + GRL_EPS;
+    const float z = sd * ep / den;
+    const float dz_dls = ep * sd * GRL_EPS / (den * den);
+    float d = du * sd * ep + alpha_over_b * (-(z * dz_dls + 1.f));
+    if (lr < GRL_LOG_STD_MIN || lr > GRL_LOG_STD_MAX) d = 0.f;
+    dls[j] = d;
+  }
+}
+
+#ifdef GRL_HOSTEMU
+// ------------------------------------------------------------------------------------------------
+// TEST-ONLY sequential forms (see hostemu.h): same arithmetic order, one "thread" does a block.
+inline void ht_ref_fwd_head(const HtHead& h, int row, const float* xa_row) {
+  float zin[HT_MAXW], zout[HT_MAXW];
+  for (int n = 0; n < h.H0; ++n) {
+    float acc = h.u[(long)row * h.ldu + n];
+    for (int a = 0; a < h.n_xa; ++a) acc = fmaf(xa_row[a], h.w0a[a * h.H0 + n], acc);
+    acc += h.b0[n];
+    zin[n] = fmaxf(acc, 0.f);
+    h.z0[(long)row * h.H0 + n] = zin[n];
+  }
+  for (int l = 1; l < h.L; ++l) {
+    for (int n = 0; n < h.hid[l]; ++n) {
+      float acc = 0.f;
+      for (int k = 0; k < h.hid[l - 1]; ++k) acc = fmaf(zin[k], h.w[l][k * h.hid[l] + n], acc);
+      zout[n] = fmaxf(acc + h.b[l][n], 0.f);
+      h.z[l][(long)row * h.hid[l] + n] = zout[n];
+    }
+    for (int n = 0; n < h.hid[l]; ++n) zin[n] = zout[n];
+  }
+  const int HL = h.hid[h.L - 1];
+  for (int k = 0; k < h.n_out; ++k)
+    for (int o = 0; o < h.out_dim; ++o) {
+      float acc = 0.f;
+      for (int n = 0; n < HL; ++n) acc = fmaf(zin[n], h.ow[k][n * h.out_dim + o], acc);
+      h.out[k][(long)row * h.out_dim + o] = acc + h.ob[k][o];
+    }
+}
+
+inline void heads_fwd_kernel(HeadsFwdArgs a) {
+  if (threadIdx.x != 0) return;
+  const int chain = blockIdx.y;
+  for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row) {
+    if (chain == 0) {
+      ht_ref_fwd_head(a.h[0], row, nullptr);
+      ht_sample_row(a.h[0].out[0] + (long)row * a.A, a.h[0].out[1] + (long)row * a.A, a.eps + (long)row * a.A, a.A,
+                    a.pi_a + (long)row * a.A, a.logp + row, a.ent + row);
+      ht_ref_fwd_head(a.h[5], row, a.pi_a + (long)row * a.A);
+      ht_ref_fwd_head(a.h[6], row, a.pi_a + (long)row * a.A);
+    } else {
+      const HtHead& h = a.h[chain];
+      ht_ref_fwd_head(h, row, h.n_xa ? h.xa + (long)row * h.ld_xa : nullptr);
+    }
+  }
+}
+
+// dvals: n_out * out_dim output gradients of this row
+inline void ht_ref_bwd_head(const HtHead& h, int row, const float* dvals, float* da_row) {
+  float gin[HT_MAXW], gout[HT_MAXW];
+  const int HL = h.hid[h.L - 1];
+  const float* zl = h.L == 1 ? h.z0 : h.z[h.L - 1];
+  for (int n = 0; n < HL; ++n) {
+    float acc = 0.f;
+    for (int k = 0; k < h.n_out; ++k)
+      for (int o = 0; o < h.out_dim; ++o) acc = fmaf(dvals[k * h.out_dim + o], h.ow[k][n * h.out_dim + o], acc);
+    gin[n] = zl[(long)row * HL + n] > 0.f ? acc : 0.f;
+  }
+  for (int l = h.L - 1; l >= 1; --l) {
+    for (int n = 0; n < h.hid[l]; ++n) h.g[l][(long)row * h.hid[l] + n] = gin[n];
+    const float* zp = l == 1 ? h.z0 : h.z[l - 1];
+    for (int m = 0; m < h.hid[l - 1]; ++m) {
+      float acc = 0.f;
+      for (int n = 0; n < h.hid[l]; ++n) acc = fmaf(gin[n], h.w[l][m * h.hid[l] + n], acc);
+      gout[m] = zp[(long)row * h.hid[l - 1] + m] > 0.f ? acc : 0.f;
+    }
+    for (int m = 0; m < h.hid[l - 1]; ++m) gin[m] = gout[m];
+  }
+  for (int n = 0; n < h.H0; ++n) h.g0[(long)row * h.ldg0 + n] = gin[n];
+  if (da_row)
+    for (int a = 0; a < h.n_xa; ++a) {
+      float acc = 0.f;
+      for (int n = 0; n < h.H0; ++n) acc = fmaf(gin[n], h.w0a[a * h.H0 + n], acc);
+      da_row[a] = acc;
+    }
+}
+
+inline void heads_bwd_kernel(HeadsBwdArgs a) {
+  if (threadIdx.x != 0) return;
+  const int chain = blockIdx.y;
+  const float alpha_over_b = expf(a.log_ent_coef[0]) / (float)a.B;
+  for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row) {
+    float dv[2 * HT_MAXA];
+    if (chain == 0) {
+      const HtHead& q = a.h[4];
+      dv[0] = q.dout[0][row];
+      ht_ref_bwd_head(q, row, dv, a.da_pi + (long)row * a.A);
+      ht_sample_bwd_row(a.ls_raw + (long)row * a.A, a.eps + (long)row * a.A, a.pi_a + (long)row * a.A,
+                        a.da_pi + (long)row * a.A, a.A, alpha_over_b, a.dmu + (long)row * a.A, a.dls + (long)row * a.A);
+      for (int j = 0; j < a.A; ++j) { dv[j] = a.dmu[(long)row * a.A + j]; dv[a.A + j] = a.dls[(long)row * a.A + j]; }
+      ht_ref_bwd_head(a.h[0], row, dv, nullptr);
+    } else {
+      const HtHead& h = a.h[chain];
+      for (int k = 0; k < h.n_out; ++k)
+        for (int o = 0; o < h.out_dim; ++o) dv[k * h.out_dim + o] = h.dout[k][(long)row * h.out_dim + o];
+      ht_ref_bwd_head(h, row, dv, nullptr);
+    }
+  }
+}
+
+#else  // ------------------------------------------------------------------------------------ device
+
+typedef float ht_f4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(16))) HtLds {
+  float zT[2][HT_MAXW][HT_RB];      // activations / gradients of the current and the next layer, [col][row]
+  float xaT[HT_MAXA][HT_RB];        // second input part (action) of the rows, [a][row]
+  float oT[2 * HT_MAXA][HT_RB];     // outputs (forward: mu | log_std) / output gradients (backward), [k*out_dim + o][row]
+};
+
+// forward of one head for the 16 rows of this workgroup; xaT must hold the head's action part
+__device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, HtLds& s, bool keep_out) {
+  const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
+  // ---- layer 0
+  for (int c0 = 0; c0 < h.H0; c0 += 64) {
+    const int n = c0 + cl;
+    if (n < h.H0) {
+      float acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * rg + i;
+        acc[i] = row < B ? h.u[(long)row * h.ldu + n] : 0.f;
+      }
+      for (int a = 0; a < h.n_xa; ++a) {
+        const float w = h.w0a[a * h.H0 + n];
+        const ht_f4 x = *(const ht_f4*)&s.xaT[a][4 * rg];
+        acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
+        acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
+      }
+      const float bn = h.b0[n];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * rg + i;
+        const float v = fmaxf(acc[i] + bn, 0.f);
+        s.zT[0][n][4 * rg + i] = v;
+        if (row < B) h.z0[(long)row * h.H0 + n] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- hidden layers
+  for (int l = 1; l < h.L; ++l) {
+    const int Hin = h.hid[l - 1], Hout = h.hid[l];
+    float(*src)[HT_RB] = s.zT[(l - 1) & 1];
+    float(*dst)[HT_RB] = s.zT[l & 1];
+    for (int c0 = 0; c0 < Hout; c0 += 64) {
+      const int n = c0 + cl;
+      if (n < Hout) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = h.w[l] + n;
+#pragma unroll 8
+        for (int k = 0; k < Hin; ++k) {
+          const float w = wp[(long)k * Hout];
+          const ht_f4 x = *(const ht_f4*)&src[k][4 * rg];
+          acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
+          acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
+        }
+        const float bn = h.b[l][n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * rg + i;
+          const float v = fmaxf(acc[i] + bn, 0.f);
+          dst[n][4 * rg + i] = v;
+          if (row < B) h.z[l][(long)row * Hout + n] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- output layers (out_dim <= 64)
+  {
+    const int HL = h.hid[h.L - 1];
+    float(*src)[HT_RB] = s.zT[(h.L - 1) & 1];
+    for (int k = 0; k < h.n_out; ++k) {
+      if (cl < h.out_dim) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = h.ow[k] + cl;
+#pragma unroll 8
+        for (int n = 0; n < HL; ++n) {
+          const float w = wp[(long)n * h.out_dim];
+          const ht_f4 x = *(const ht_f4*)&src[n][4 * rg];
+          acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
+          acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
+        }
+        const float bo = h.ob[k][cl];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * rg + i;
+          const float v = acc[i] + bo;
+          if (keep_out) s.oT[k * h.out_dim + cl][4 * rg + i] = v;
+          if (row < B) h.out[k][(long)row * h.out_dim + cl] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void ht_load_xa(const HtHead& h, int row0, int B, HtLds& s) {
+  const int t = threadIdx.x;
+  for (int e = t; e < h.n_xa * HT_RB; e += 256) {
+    const int r = e / h.n_xa, a = e - r * h.n_xa;
+    const int row = row0 + r;
+    s.xaT[a][r] = row < B ? h.xa[(long)row * h.ld_xa + a] : 0.f;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsFwdArgs a) {
+  __shared__ HtLds s;
+  const int row0 = blockIdx.x * HT_RB, chain = blockIdx.y, t = threadIdx.x;
+  if (chain != 0) {
+    const HtHead& h = a.h[chain];
+    if (h.n_xa) ht_load_xa(h, row0, a.B, s);
+    ht_fwd_head(h, row0, a.B, s, false);
+    return;
+  }
+  // chain 0: pi head -> sample -> qf1(s, pi), qf2(s, pi)
+  ht_fwd_head(a.h[0], row0, a.B, s, true);
+  if (t < HT_RB) {
+    const int row = row0 + t;
+    float lp = 0.f, en = 0.f;
+    for (int j = 0; j < a.A; ++j) {
+      const float ep = row < a.B ? a.eps[(long)row * a.A + j] : 0.f;
+      const float pj = ht_sample_elem(s.oT[j][t], s.oT[a.A + j][t], ep, lp, en);
+      s.xaT[j][t] = pj;
+      if (row < a.B) a.pi_a[(long)row * a.A + j] = pj;
+    }
+    if (row < a.B) { a.logp[row] = lp; a.ent[row] = en; }
+  }
+  __syncthreads();
+  ht_fwd_head(a.h[5], row0, a.B, s, false);
+  ht_fwd_head(a.h[6], row0, a.B, s, false);
+}
+
+// backward of one head for the 16 rows of this workgroup.  oT must hold the output gradients
+// [k*out_dim + o][row].  Writes every g[l]; optionally d xa (to global and to xaT).
+__device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, HtLds& s, float* da, int ld_da) {
+  const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
+  const int L = h.L;
+  // ---- output layers -> g_{L-1}
+  {
+    const int HL = h.hid[L - 1];
+    const float* zl = L == 1 ? h.z0 : h.z[L - 1];
+    float* gl = L == 1 ? nullptr : h.g[L - 1];
+    for (int c0 = 0; c0 < HL; c0 += 64) {
+      const int n = c0 + cl;
+      if (n < HL) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < h.n_out; ++k) {
+          const float* wp = h.ow[k] + (long)n * h.out_dim;
+          for (int o = 0; o < h.out_dim; ++o) {
+            const float w = wp[o];
+            const ht_f4 d = *(const ht_f4*)&s.oT[k * h.out_dim + o][4 * rg];
+            acc[0] = fmaf(d.x, w, acc[0]); acc[1] = fmaf(d.y, w, acc[1]);
+            acc[2] = fmaf(d.z, w, acc[2]); acc[3] = fmaf(d.w, w, acc[3]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * rg + i;
+          float v = 0.f;
+          if (row < B) {
+            v = zl[(long)row * HL + n] > 0.f ? acc[i] : 0.f;
+            if (gl) gl[(long)row * HL + n] = v;
+            else h.g0[(long)row * h.ldg0 + n] = v;
+          }
+          s.zT[(L - 1) & 1][n][4 * rg + i] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- hidden layers: g_{l-1} = mask * (g_l . W_l^T)
+  for (int l = L - 1; l >= 1; --l) {
+    const int Hout = h.hid[l], Hin = h.hid[l - 1];
+    float(*src)[HT_RB] = s.zT[l & 1];
+    float(*dst)[HT_RB] = s.zT[(l - 1) & 1];
+    const float* zp = l == 1 ? h.z0 : h.z[l - 1];
+    for (int c0 = 0; c0 < Hin; c0 += 64) {
+      const int m = c0 + cl;
+      if (m < Hin) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = h.w[l] + (long)m * Hout;
+#pragma unroll 8
+        for (int n = 0; n < Hout; ++n) {
+          const float w = wp[n];
+          const ht_f4 g = *(const ht_f4*)&src[n][4 * rg];
+          acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
+          acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * rg + i;
+          float v = 0.f;
+          if (row < B) {
+            v = zp[(long)row * Hin + m] > 0.f ? acc[i] : 0.f;
+            if (l == 1) h.g0[(long)row * h.ldg0 + m] = v;
+            else h.g[l - 1][(long)row * Hin + m] = v;
+          }
+          dst[m][4 * rg + i] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- d xa = g_0 . w0a^T
+  if (da) {
+    if (cl < h.n_xa) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* wp = h.w0a + (long)cl * h.H0;
+      for (int n = 0; n < h.H0; ++n) {
+        const float w = wp[n];
+        const ht_f4 g = *(const ht_f4*)&s.zT[0][n][4 * rg];
+        acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
+        acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * rg + i;
+        s.xaT[cl][4 * rg + i] = acc[i];
+        if (row < B) da[(long)row * ld_da + cl] = acc[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs a) {
+  __shared__ HtLds s;
+  const int row0 = blockIdx.x * HT_RB, chain = blockIdx.y, t = threadIdx.x;
+  if (chain != 0) {
+    const HtHead& h = a.h[chain];
+    for (int e = t; e < h.n_out * h.out_dim * HT_RB; e += 256) {
+      const int r = e % HT_RB, ko = e / HT_RB;
+      const int k = ko / h.out_dim, o = ko - k * h.out_dim;
+      const int row = row0 + r;
+      s.oT[ko][r] = row < a.B ? h.dout[k][(long)row * h.out_dim + o] : 0.f;
+    }
+    __syncthreads();
+    ht_bwd_head(h, row0, a.B, s, nullptr, 0);
+    return;
+  }
+  // chain 0: qf1(s, pi) backward -> d a_pi -> sample backward -> pi head backward
+  const HtHead& q = a.h[4];
+  if (t < HT_RB) s.oT[0][t] = (row0 + t) < a.B ? q.dout[0][row0 + t] : 0.f;
+  __syncthreads();
+  ht_bwd_head(q, row0, a.B, s, a.da_pi, a.A);
+  if (t < HT_RB) {
+    const int row = row0 + t;
+    const float alpha_over_b = expf(a.log_ent_coef[0]) / (float)a.B;
+    const int rc = row < a.B ? row : 0;
+    for (int j = 0; j < a.A; ++j) {
+      float m, d;
+      ht_sample_bwd_elem(a.ls_raw[(long)rc * a.A + j], a.eps[(long)rc * a.A + j], a.pi_a[(long)rc * a.A + j],
+                         s.xaT[j][t], alpha_over_b, m, d);
+      if (row >= a.B) { m = 0.f; d = 0.f; }
+      s.oT[j][t] = m;
+      s.oT[a.A + j][t] = d;
+      if (row < a.B) { a.dmu[(long)row * a.A + j] = m; a.dls[(long)row * a.A + j] = d; }
+    }
+  }
+  __syncthreads();
+  ht_bwd_head(a.h[0], row0, a.B, s, nullptr, 0);
+}
+
+#endif  // GRL_HOSTEMU
+
+}  // namespace grl
