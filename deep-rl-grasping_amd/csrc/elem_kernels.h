@@ -19,13 +19,29 @@ namespace grl {
 struct DevScalars {
   float beta1_power, beta2_power;   // TF AdamOptimizer non-slot variables (start at beta1, beta2)
   float adam_alpha;                 // lr * sqrt(1-b2p)/(1-b1p) of the current step
-  float pad0;
+  uint32_t rng_used;                // set by a gather that drew from the device RNG; the loss reduction then advances rng_step
   // metrics of the last update
   float policy_loss, qf1_loss, qf2_loss, value_loss, ent_loss, ent_coef, entropy, mean_qf1, mean_v;
   float pad1[3];
   uint64_t rng_step;                // Philox counter (one per drawn minibatch)
   int64_t replay_size;              // transitions currently stored
 };
+
+// ------------------------------------------------------------------------------------------------
+// device RNG (Philox4x32-10): replay indices uniform in [0, size) and standard normals
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // replay gather + VecNormalize.normalize_obs / normalize_reward at sample time (A.1 step 3) +
@@ -48,7 +64,13 @@ struct GatherArgs {
   float* d_obs0; float* d_obs1; float* d_next;     // direct-feature destinations, row stride ldd
   int ldd;
   float* act_out; int ld_act;
+  float* act_out2; int ld_act2;                    // optional second copy (row-padded for 16-byte loads)
   float* rew_out; float* done_out;
+  // device-RNG mode (use_rng): the replay index of row b and its A standard normals are drawn here
+  // (Philox4x32-10 keyed by seed, counter = (rng_step, b, stream)); the last workgroup to finish
+  // advances rng_step.  Explicit mode reads idx (and the caller has staged eps).
+  int use_rng; DevScalars* sc; uint64_t seed;
+  int64_t* idx_w; float* eps_w; int n_eps;
 };
 
 __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int normalize, double clip,
@@ -65,7 +87,18 @@ __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int no
 __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   const int b = blockIdx.y;
   const int which = blockIdx.z;   // 0: obs, 1: next_obs
-  const int64_t src = a.idx[b];
+  int64_t src;
+  uint64_t step = 0;
+  if (a.use_rng) {
+    step = a.sc->rng_step;
+    const int64_t size = a.sc->replay_size;
+    uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, 0u};
+    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const uint64_t u = ((uint64_t)c[0] << 32) | c[1];
+    src = size > 0 ? (int64_t)__umul64hi(u, (uint64_t)size) : 0;
+  } else {
+    src = a.idx[b];
+  }
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < a.img_elems) {
     const float* rp = which ? a.rp_next : a.rp_obs;
@@ -94,7 +127,11 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
       }
     }
     if (which == 0) {
-      if (t < a.act_dim) a.act_out[(long)b * a.ld_act + t] = a.rp_act[src * a.act_dim + t];
+      if (t < a.act_dim) {
+        const float av = a.rp_act[src * a.act_dim + t];
+        a.act_out[(long)b * a.ld_act + t] = av;
+        if (a.act_out2) a.act_out2[(long)b * a.ld_act2 + t] = av;
+      }
       if (t == 64) {
         float r = a.rp_rew[src];
         if (a.normalize) {
@@ -105,8 +142,26 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
         a.rew_out[b] = r;
       }
       if (t == 65) a.done_out[b] = a.rp_done[src];
+      if (a.use_rng) {
+        if (t == 66) a.idx_w[b] = src;
+        if (t >= 128 && 2 * (t - 128) < a.n_eps) {   // Box-Muller pairs, as rng_kernel
+          const int j0 = 2 * (t - 128);
+          uint32_t d[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, (uint32_t)(1 + j0)};
+          philox4x32_10(d, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+          const float u1 = ((float)(d[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+          const float u2 = ((float)(d[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+          const float rad = sqrtf(-2.f * logf(u1));
+          float sn, cs;
+          sincosf(6.283185307179586f * u2, &sn, &cs);
+          a.eps_w[b * a.n_eps + j0] = rad * cs;
+          if (j0 + 1 < a.n_eps) a.eps_w[b * a.n_eps + j0 + 1] = rad * sn;
+        }
+      }
     }
   }
+  // rng_step itself is advanced by the (single-workgroup) loss reduction later in the update: a counter
+  // bumped by the last of these 8192 workgroups would serialise 8192 same-address atomics (~100 us)
+  if (a.use_rng && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.sc->rng_used = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -248,14 +303,16 @@ struct LossArgs {
   const float* v_tgt; const float* qf1; const float* qf2; const float* v;
   const float* qf1_pi; const float* qf2_pi; const float* logp; const float* entropy;
   const float* log_ent_coef;
-  float* d_qf1; float* d_qf2; float* d_v; float* d_qf1_pi;   // [B] each
+  float* d_qf1; float* d_qf2; float* d_v; float* d_qf1_pi;   // [B] each, element stride ld_d
+  int ld_d;
   float* g_log_ent_coef;                                      // gradient slot in the flat bucket
   DevScalars* sc;
+  int write_d;   // 0: the output gradients are produced row-locally by heads_bwd_kernel; only the reductions run here
 };
 
 #ifdef GRL_HOSTEMU
 // TEST-ONLY sequential form (see hostemu.h)
-inline void sac_loss_kernel(LossArgs a) {
+inline void sac_loss_body(const LossArgs& a) {
   if (threadIdx.x != 0) return;
   const float log_alpha = a.log_ent_coef[0];
   const float alpha = expf(log_alpha);
@@ -267,7 +324,7 @@ inline void sac_loss_kernel(LossArgs a) {
     const float lp = a.logp[b];
     const float vb = fminf(a.qf1_pi[b], a.qf2_pi[b]) - alpha * lp;
     const float ev = a.v[b] - vb;
-    a.d_qf1[b] = e1 * invB; a.d_qf2[b] = e2 * invB; a.d_v[b] = ev * invB; a.d_qf1_pi[b] = -invB;
+    if (a.write_d) { a.d_qf1[b * a.ld_d] = e1 * invB; a.d_qf2[b * a.ld_d] = e2 * invB; a.d_v[b * a.ld_d] = ev * invB; a.d_qf1_pi[b * a.ld_d] = -invB; }
     s[0] += 0.5f * e1 * e1; s[1] += 0.5f * e2 * e2; s[2] += 0.5f * ev * ev;
     s[3] += alpha * lp - a.qf1_pi[b]; s[4] += lp + a.target_entropy; s[5] += a.entropy[b];
     s[6] += a.qf1[b]; s[7] += a.v[b];
@@ -282,9 +339,11 @@ inline void sac_loss_kernel(LossArgs a) {
   sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
   sc->beta1_power *= 0.9f;
   sc->beta2_power *= 0.999f;
+  if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }
 }
+inline void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }
 #else
-__global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) {
+__device__ __forceinline__ void sac_loss_body(const LossArgs& a) {
   __shared__ float red[8][256];
   const int t = threadIdx.x;
   const float log_alpha = a.log_ent_coef[0];
@@ -297,10 +356,12 @@ __global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) {
     const float lp = a.logp[b];
     const float vb = fminf(a.qf1_pi[b], a.qf2_pi[b]) - alpha * lp;
     const float ev = a.v[b] - vb;
-    a.d_qf1[b] = e1 * invB;
-    a.d_qf2[b] = e2 * invB;
-    a.d_v[b] = ev * invB;
-    a.d_qf1_pi[b] = -invB;
+    if (a.write_d) {
+      a.d_qf1[b * a.ld_d] = e1 * invB;
+      a.d_qf2[b * a.ld_d] = e2 * invB;
+      a.d_v[b * a.ld_d] = ev * invB;
+      a.d_qf1_pi[b * a.ld_d] = -invB;
+    }
     s[0] += 0.5f * e1 * e1;
     s[1] += 0.5f * e2 * e2;
     s[2] += 0.5f * ev * ev;
@@ -335,8 +396,10 @@ __global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) {
     sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
     sc->beta1_power *= 0.9f;
     sc->beta2_power *= 0.999f;
+    if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch came from the device RNG
   }
 }
+__global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }
 
 #endif  // GRL_HOSTEMU
 
@@ -496,8 +559,15 @@ struct ReduceDesc {
 
 // flat work list: block b sums 256 consecutive outputs of descriptor tiles[b].x starting at tiles[b].y
 // (slab loads are independent: unrolled so several are in flight; the add order stays k = 0, 1, ...)
+// ... and, as workgroup n_tiles when has_loss is set, the batch reductions of the SAC losses (metrics,
+// entropy-coefficient gradient, Adam step size): they are needed by the apply kernel only.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
-                                                          const int2* __restrict__ tiles) {
+                                                          const int2* __restrict__ tiles, int n_tiles,
+                                                          LossArgs la, int has_loss) {
+  if ((int)blockIdx.x >= n_tiles) {
+    if (has_loss) sac_loss_body(la);
+    return;
+  }
   const int2 tl = tiles[blockIdx.x];
   const ReduceDesc d = descs[tl.x];
   const int i = tl.y + threadIdx.x;
@@ -545,22 +615,6 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
     a.params[i] = p;
     const int64_t k = i - a.src_ofs;
     if (k >= 0 && k < a.n_polyak) a.target[k] = omt * a.target[k] + a.tau * p;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// device RNG (Philox4x32-10): replay indices uniform in [0, size) and standard normals
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
 }
 

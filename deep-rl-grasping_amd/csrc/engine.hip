@@ -106,6 +106,11 @@ struct Launch {
 
 struct Op {
   std::string tag;
+  // graph capture places an op on the main lane (0) or the side lane (1).  `fork`: a side-lane op first
+  // waits for everything enqueued on the main lane so far; `join`: a main-lane op first waits for the
+  // side lane.  Eager execution (profiling, GRL_NO_GRAPH) runs the list in order on one stream.
+  int lane = 0;
+  bool fork = false, join = false;
   std::function<void(hipStream_t)> run;
   double flops = 0;   // algorithmic FLOPs of one launch
   double bytes = 0;   // algorithmic HBM bytes of one launch
@@ -180,6 +185,8 @@ struct grl_ctx {
   HeadGrad gPI, gVF, gQF1, gQF2, gQF1PI;
   float *da_pi, *dmu, *dls;
   float *dfeat[2], *g3[2], *g2[2], *g1[2];
+  float* act_p = nullptr;            // [B, Ap] row-padded copy of the minibatch actions (Ap = rup(A, 4))
+  int Ap = 0, ld_d = 1, ld_dm = 0;   // strides of the packed output-gradient buffers (fused heads)
   bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
   float *u_l0[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // layer-0 feature partials: pi, vf, qf1, qf2, target
   float* g0cat = nullptr;            // [B, 3*H0]: layer-0 gradients of vf | qf1 | qf2
@@ -197,11 +204,16 @@ struct grl_ctx {
   std::vector<ReduceDesc> reduces;
   ReduceDesc* d_reduces = nullptr;
 
-  std::vector<Op> ops_rng, ops_grads, ops_apply, ops_act, ops_enc;
+  std::vector<Op> ops_rng, ops_gather, ops_grads, ops_apply, ops_act, ops_enc, wgrad_ops;   // ops_rng: gather with device RNG; ops_gather: gather of explicit indices
+  bool use_lanes = false;
+  LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
+  bool loss_in_reduce = false;
   float grad_scale = 1.f;   // read by the apply op
 
   // graphs
   std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences, keyed by what they contain
+  hipStream_t side = nullptr;                     // second capture lane (independent weight-gradient launches)
+  std::vector<hipEvent_t> lane_ev;
   float apply_graph_scale = 0.f;
   bool use_graph = true;
 
@@ -215,6 +227,8 @@ struct grl_ctx {
   ~grl_ctx() {
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
+    for (auto e : lane_ev) hipEventDestroy(e);
+    if (side) hipStreamDestroy(side);
     drop_graphs();
   }
   void drop_graphs() {
@@ -574,7 +588,8 @@ struct grl_ctx {
       else if (p.q_ld_r[0] != 1 || (p.q_ld_j[0] % 4)) return false;
     } else {                                              // Q along j
       if (qtab) return false;
-      if (p.q_ld_j[0] != 1 || (p.q_ld_r[0] % 4) || (p.N % 4)) return false;
+      // a quad straddling N reads row padding (never stored): the row stride must cover it
+      if (p.q_ld_j[0] != 1 || (p.q_ld_r[0] % 4) || p.q_ld_r[0] < rup(p.N, 4)) return false;
     }
     return true;
   }
@@ -843,11 +858,24 @@ int grl_ctx::plan_sac() {
   alloc_head(hPI, B, 2, A); alloc_head(hVF, B, 1, 1); alloc_head(hQF1, B, 1, 1); alloc_head(hQF2, B, 1, 1);
   alloc_head(hTGT, B, 1, 1); alloc_head(hQF1PI, B, 1, 1); alloc_head(hQF2PI, B, 1, 1);
   pi_a = wk.f32((int64_t)B * A); logp = wk.f32(B); ent = wk.f32(B);
-  d_qf1 = wk.f32(B); d_qf2 = wk.f32(B); d_v = wk.f32(B); d_qf1pi = wk.f32(B);
   {
     const char* nf = getenv("GRL_NO_FUSED_HEADS");
     fused_heads = !(nf && nf[0] == '1') && A <= HT_MAXA && (hid[0] % 4) == 0;
     for (int l = 0; l < L; ++l) fused_heads = fused_heads && hid[l] <= HT_MAXW;
+  }
+  Ap = (int)rup(A, 4);
+  if (fused_heads) {
+    // output gradients packed / row-padded so that the weight-gradient GEMM can fetch them 16 bytes at a time
+    float** dd[4] = {&d_v, &d_qf1, &d_qf2, &d_qf1pi};
+    for (auto* q : dd) {
+      *q = wk.f32((int64_t)B * 4);
+      zero_once.push_back({*q, (size_t)B * 16});
+    }
+    ld_d = 4;
+    act_p = wk.f32((int64_t)B * Ap);
+    zero_once.push_back({act_p, (size_t)B * Ap * 4});
+  } else {
+    d_qf1 = wk.f32(B); d_qf2 = wk.f32(B); d_v = wk.f32(B); d_qf1pi = wk.f32(B); ld_d = 1;
   }
   if (fused_heads) {
     for (int k = 0; k < 5; ++k) u_l0[k] = wk.f32((int64_t)B * hid[0]);
@@ -860,7 +888,12 @@ int grl_ctx::plan_sac() {
   } else {
     alloc_hgrad(gPI, B); alloc_hgrad(gVF, B); alloc_hgrad(gQF1, B); alloc_hgrad(gQF2, B); alloc_hgrad(gQF1PI, B);
   }
-  da_pi = wk.f32((int64_t)B * A); dmu = wk.f32((int64_t)B * A); dls = wk.f32((int64_t)B * A);
+  ld_dm = fused_heads ? Ap : A;
+  da_pi = wk.f32((int64_t)B * A); dmu = wk.f32((int64_t)B * ld_dm); dls = wk.f32((int64_t)B * ld_dm);
+  if (fused_heads) {
+    zero_once.push_back({dmu, (size_t)B * ld_dm * 4});
+    zero_once.push_back({dls, (size_t)B * ld_dm * 4});
+  }
   if (cnn)
     for (int n = 0; n < 2; ++n) {
       dfeat[n] = wk.f32((int64_t)B * ldf);
@@ -872,18 +905,7 @@ int grl_ctx::plan_sac() {
   const float* P = params;
   const float* T = params;   // target block uses absolute offsets too
 
-  // =============================================================== RNG ops
-  {
-    Op op; op.tag = "rng";
-    RngArgs ra{sc, c.seed, B, A, idx_buf, eps_buf};
-    op.run = [ra](hipStream_t s) {
-      hipLaunchKernelGGL(rng_kernel, dim3((ra.B + 255) / 256), dim3(256), 0, s, ra);
-      hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, s, ra.sc);
-    };
-    ops_rng.push_back(op);
-  }
-
-  // =============================================================== forward
+  // =============================================================== minibatch: replay gather (+ device RNG)
   {
     GatherArgs ga;
     memset(&ga, 0, sizeof(ga));
@@ -901,12 +923,17 @@ int grl_ctx::plan_sac() {
       ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;   // n_direct == 0: never written
     }
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
-    Op op; op.tag = "gather_norm";
-    op.bytes = 2.0 * B * ((double)img_elems * 8 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
-    op.run = [ga](hipStream_t s) {
-      hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
-    };
-    ops_grads.push_back(op);
+    ga.act_out2 = act_p; ga.ld_act2 = Ap;
+    ga.sc = sc; ga.seed = c.seed; ga.idx_w = idx_buf; ga.eps_w = eps_buf; ga.n_eps = A;
+    for (int mode = 0; mode < 2; ++mode) {
+      ga.use_rng = mode;
+      Op op; op.tag = "gather_norm";
+      op.bytes = 2.0 * B * ((double)img_elems * 8 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
+      op.run = [ga](hipStream_t s) {
+        hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
+      };
+      (mode ? ops_rng : ops_gather).push_back(op);
+    }
   }
 
   ConvGeom cg[3];
@@ -1022,11 +1049,15 @@ int grl_ctx::plan_sac() {
     la.rew = rew; la.done = done; la.v_tgt = hTGT.out[0]; la.qf1 = hQF1.out[0]; la.qf2 = hQF2.out[0];
     la.v = hVF.out[0]; la.qf1_pi = hQF1PI.out[0]; la.qf2_pi = hQF2PI.out[0]; la.logp = logp; la.entropy = ent;
     la.log_ent_coef = params + ent_off;
-    la.d_qf1 = d_qf1; la.d_qf2 = d_qf2; la.d_v = d_v; la.d_qf1_pi = d_qf1pi;
+    la.d_qf1 = d_qf1; la.d_qf2 = d_qf2; la.d_v = d_v; la.d_qf1_pi = d_qf1pi; la.ld_d = ld_d;
     la.g_log_ent_coef = grads + ent_off; la.sc = sc;
-    Op op; op.tag = "sac_loss";
-    op.run = [la](hipStream_t s) { hipLaunchKernelGGL(sac_loss_kernel, dim3(1), dim3(256), 0, s, la); };
-    ops_grads.push_back(op);
+    la.write_d = fused_heads ? 0 : 1;
+    loss_args = la;
+    if (!fused_heads) {   // fused heads: output gradients are formed in heads_bwd_kernel, reductions ride on reduce_slabs
+      Op op; op.tag = "sac_loss";
+      op.run = [la](hipStream_t s) { hipLaunchKernelGGL(sac_loss_kernel, dim3(1), dim3(256), 0, s, la); };
+      ops_grads.push_back(op);
+    }
   }
 
   // =============================================================== backward through the heads
@@ -1040,6 +1071,11 @@ int grl_ctx::plan_sac() {
     ba.h[3] = mk_head(m_qf2, hQF2, &gQF2, u_l0[3], act, A, A);
     ba.h[4] = mk_head(m_qf1, hQF1PI, &gQF1PI, u_l0[2], pi_a, A, A);
     ba.h[1].dout[0] = d_v; ba.h[2].dout[0] = d_qf1; ba.h[3].dout[0] = d_qf2; ba.h[4].dout[0] = d_qf1pi;
+    for (int k = 1; k < 5; ++k) ba.h[k].ld_dout = ld_d;
+    ba.ld_dm = ld_dm;
+    ba.rew = rew; ba.done = done; ba.v_tgt = hTGT.out[0]; ba.qf1 = hQF1.out[0]; ba.qf2 = hQF2.out[0]; ba.v = hVF.out[0];
+    ba.qf1_pi = hQF1PI.out[0]; ba.qf2_pi = hQF2PI.out[0]; ba.logp = logp; ba.gamma = c.gamma;
+    ba.d_out[1] = d_v; ba.d_out[2] = d_qf1; ba.d_out[3] = d_qf2; ba.d_out[4] = d_qf1pi; ba.ld_d = ld_d;
     ba.B = B; ba.A = A; ba.mu = hPI.out[0]; ba.ls_raw = hPI.out[1]; ba.eps = eps_buf; ba.pi_a = pi_a;
     ba.log_ent_coef = params + ent_off; ba.da_pi = da_pi; ba.dmu = dmu; ba.dls = dls;
     Op op; op.tag = "heads_bwd";
@@ -1126,7 +1162,7 @@ int grl_ctx::plan_sac() {
 
   }
   // =============================================================== backward through the two CNNs
-  std::vector<IgemmProb> wg, wgc;   // weight gradients: dense layers / conv layers, launched at the end
+  std::vector<IgemmProb> wg, wgc[3];   // weight gradients: dense layers / conv layers 1..3
   if (cnn) {
     std::vector<ConvBwdClass> bc3 = conv_bwd_tabs(cg[2], B), bc2 = conv_bwd_tabs(cg[1], B);
     {
@@ -1153,17 +1189,17 @@ int grl_ctx::plan_sac() {
       {
         IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, 96);
         p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wgc, p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
+        add_wgrad(wgc[0], p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
       }
       {
         IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, 16);
         p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wgc, p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
+        add_wgrad(wgc[1], p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
       }
       {
         IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, 8);
         p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wgc, p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
+        add_wgrad(wgc[2], p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
       }
       {
         IgemmProb p = dense_wgrad(a3[n], 1024, 1024, true, dfeat[n], ldf, 512, B, nullptr, 1);
@@ -1172,17 +1208,20 @@ int grl_ctx::plan_sac() {
       }
     }
   }
-  // head weight gradients
+  // head weight gradients.  Fused-heads layout: every operand is row-padded to a multiple of 4 floats, and
+  // problems without a bias still carry the ones row (its slab row is simply not reduced), so that all
+  // dense weight gradients form ONE uniform launch of the vectorised kernel.
   auto head_wgrads = [&](const MlpP& m, const HeadAct& h, const HeadGrad& g, const float* x0, int ld0, int K0,
-                         const float* x1, int ld1, int K1, std::vector<const float*> douts) {
+                         const float* x1, int ld1, int K1, std::vector<const float*> douts, int ld_dout) {
     const int K0p = ld0 >= (int)rup(K0, 4) ? (int)rup(K0, 4) : K0;   // feat rows are padded to ldf (zeros)
+    const int K1p = (K1 > 0 && ld1 >= (int)rup(K1, 4)) ? (int)rup(K1, 4) : K1;
     for (int l = 0; l < L; ++l) {
       if (l == 0) {
         if (K1 > 0) {
-          IgemmProb p0 = dense_wgrad(x0, ld0, K0, false, g.g[0], g.ld0, hid[0], B, nullptr, 1, K0p);
+          IgemmProb p0 = dense_wgrad(x0, ld0, K0, fused_heads, g.g[0], g.ld0, hid[0], B, nullptr, 1, K0p);
           p0.c = wk.f32(p0.slab_stride * p0.split);
           add_wgrad(wg, p0, m.w[0], 0, K0, -1);
-          IgemmProb p1 = dense_wgrad(x1, ld1, K1, true, g.g[0], g.ld0, hid[0], B, nullptr, 1);
+          IgemmProb p1 = dense_wgrad(x1, ld1, K1, true, g.g[0], g.ld0, hid[0], B, nullptr, 1, K1p);
           p1.c = wk.f32(p1.slab_stride * p1.split);
           add_wgrad(wg, p1, m.w[0], K0, K1, m.b[0]);
         } else {
@@ -1197,28 +1236,66 @@ int grl_ctx::plan_sac() {
       }
     }
     for (int k = 0; k < m.n_out; ++k) {
-      IgemmProb p = dense_wgrad(h.z[L - 1], hid[L - 1], hid[L - 1], true, douts[k], m.out_dim, m.out_dim, B, nullptr, 1);
+      IgemmProb p = dense_wgrad(h.z[L - 1], hid[L - 1], hid[L - 1], true, douts[k], ld_dout, m.out_dim, B, nullptr, 1);
       p.c = wk.f32(p.slab_stride * p.split);
       add_wgrad(wg, p, m.ow[k], 0, hid[L - 1], m.ob[k]);
     }
   };
-  head_wgrads(m_pi, hPI, gPI, feat[0], ldf, F, nullptr, 0, 0, {dmu, dls});
-  head_wgrads(m_vf, hVF, gVF, feat[1], ldf, F, nullptr, 0, 0, {d_v});
-  head_wgrads(m_qf1, hQF1, gQF1, feat[1], ldf, F, act, A, A, {d_qf1});
-  head_wgrads(m_qf2, hQF2, gQF2, feat[1], ldf, F, act, A, A, {d_qf2});
-  add_launch(ops_grads, "wgrad_conv", 2, wgc);
+  const float* act_w = fused_heads ? act_p : act;
+  const int ld_act_w = fused_heads ? Ap : A;
+  head_wgrads(m_pi, hPI, gPI, feat[0], ldf, F, nullptr, 0, 0, {dmu, dls}, ld_dm);
+  head_wgrads(m_vf, hVF, gVF, feat[1], ldf, F, nullptr, 0, 0, {d_v}, ld_d);
+  head_wgrads(m_qf1, hQF1, gQF1, feat[1], ldf, F, act_w, ld_act_w, A, {d_qf1}, ld_d);
+  head_wgrads(m_qf2, hQF2, gQF2, feat[1], ldf, F, act_w, ld_act_w, A, {d_qf2}, ld_d);
   {
     // the vectorised kernel needs uniform launches: with / without bias row; whatever it cannot take
-    // (4-misaligned inputs such as the [B, A] action block, 1..A-wide output layers) goes to igemm_kernel
+    // goes to igemm_kernel.  (Fused heads: everything lands in the first group.)
     std::vector<IgemmProb> wg_ones, wg_plain, wg_rest;
     for (auto& p : wg) {
       if (!v2_prob_ok(p, 2) || (p.K % 4)) wg_rest.push_back(p);
       else if (p.p_ones_i >= 0) wg_ones.push_back(p);
       else wg_plain.push_back(p);
     }
-    add_launch(ops_grads, "wgrad_dense", 2, wg_ones);
-    add_launch(ops_grads, "wgrad_dense", 2, wg_plain);
-    add_launch(ops_grads, "wgrad_small", 2, wg_rest);
+    const char* le = getenv("GRL_LANES");
+    use_lanes = le && le[0] == '1';   // ROCm's graph scheduler serialises most forked kernels: off by default
+    wgrad_ops.clear();
+    add_launch(wgrad_ops, "wgrad_dense", 2, wg_ones);
+    add_launch(wgrad_ops, "wgrad_dense", 2, wg_plain);
+    add_launch(wgrad_ops, "wgrad_small", 2, wg_rest);
+    if (use_lanes) {
+      add_launch(wgrad_ops, "wgrad_conv3", 2, wgc[2]);
+      add_launch(wgrad_ops, "wgrad_conv2", 2, wgc[1]);
+      add_launch(wgrad_ops, "wgrad_conv1", 2, wgc[0]);
+    } else {
+      std::vector<IgemmProb> all;
+      for (int l = 2; l >= 0; --l) all.insert(all.end(), wgc[l].begin(), wgc[l].end());
+      add_launch(wgrad_ops, "wgrad_conv", 2, all);
+    }
+  }
+  // ---- schedule: weight gradients ride on the side lane next to the backward-data chain.  In list
+  // (= eager) order every op still follows its producers.
+  {
+    std::vector<Op> sched;
+    auto take = [&](const char* tag, bool side_lane) {
+      for (auto& o : wgrad_ops)
+        if (o.tag == tag) {
+          Op c = o;
+          if (side_lane && use_lanes) { c.lane = 1; c.fork = true; }
+          sched.push_back(c);
+        }
+    };
+    int dense_after = -1;   // the dense weight gradients need every head gradient and (CNN) d feat
+    for (size_t k = 0; k < ops_grads.size(); ++k)
+      if (ops_grads[k].tag == "heads_dfeat" || ops_grads[k].tag == "heads_bwd") dense_after = (int)k;
+    for (size_t k = 0; k < ops_grads.size(); ++k) {
+      const Op& o = ops_grads[k];
+      sched.push_back(o);
+      if ((int)k == dense_after) { take("wgrad_dense", cnn); take("wgrad_small", cnn); }
+      if (o.tag == "fc_bwd") take("wgrad_conv3", true);
+      else if (o.tag == "conv3_bwd") take("wgrad_conv2", true);
+      else if (o.tag == "conv2_bwd") { take("wgrad_conv1", false); take("wgrad_conv", false); }
+    }
+    ops_grads.swap(sched);
   }
   {
     d_reduces = upload_vec(wk, reduces);
@@ -1229,8 +1306,11 @@ int grl_ctx::plan_sac() {
     const int ntiles = (int)rt.size();
     ReduceDesc* dr = d_reduces;
     Op op; op.tag = "reduce_slabs";
-    op.run = [dr, d_rt, ntiles](hipStream_t s) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt);
+    op.join = true;
+    const LossArgs la = loss_args;
+    const int has_loss = fused_heads ? 1 : 0;
+    op.run = [dr, d_rt, ntiles, la, has_loss](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss);
     };
     ops_grads.push_back(op);
   }
@@ -1603,8 +1683,10 @@ int grl_ctx::plan_q() {
     const int ntiles = (int)rt.size();
     ReduceDesc* dr = d_reduces;
     Op op; op.tag = "reduce_slabs";
-    op.run = [dr, d_rt, ntiles](hipStream_t s) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt);
+    LossArgs none;
+    memset(&none, 0, sizeof(none));
+    op.run = [dr, d_rt, ntiles, none](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0);
     };
     ops_grads.push_back(op);
   }
@@ -1704,9 +1786,48 @@ int grl_ctx::run_ops(std::vector<Op>& ops) {
 
 int grl_ctx::capture(std::vector<std::vector<Op>*> seq, hipGraphExec_t* out) {
   hipGraph_t g;
+  if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  size_t nev = 0;
+  auto next_event = [&](hipEvent_t* e) -> hipError_t {
+    if (nev == lane_ev.size()) {
+      hipEvent_t x;
+      hipError_t r = hipEventCreateWithFlags(&x, hipEventDisableTiming);
+      if (r != hipSuccess) return r;
+      lane_ev.push_back(x);
+    }
+    *e = lane_ev[nev++];
+    return hipSuccess;
+  };
   HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  bool side_open = false;   // the side lane carries work that has not been joined yet
   for (auto* ops : seq)
-    for (auto& op : *ops) op.run(stream);
+    for (auto& op : *ops) {
+      if (op.lane == 1) {
+        if (op.fork) {
+          hipEvent_t e;
+          HIPCHK(next_event(&e));
+          HIPCHK(hipEventRecord(e, stream));
+          HIPCHK(hipStreamWaitEvent(side, e, 0));
+        }
+        op.run(side);
+        side_open = true;
+      } else {
+        if (op.join && side_open) {
+          hipEvent_t e;
+          HIPCHK(next_event(&e));
+          HIPCHK(hipEventRecord(e, side));
+          HIPCHK(hipStreamWaitEvent(stream, e, 0));
+          side_open = false;
+        }
+        op.run(stream);
+      }
+    }
+  if (side_open) {   // every forked lane must be joined before the capture ends
+    hipEvent_t e;
+    HIPCHK(next_event(&e));
+    HIPCHK(hipEventRecord(e, side));
+    HIPCHK(hipStreamWaitEvent(stream, e, 0));
+  }
   HIPCHK(hipStreamEndCapture(stream, &g));
   HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
   HIPCHK(hipGraphDestroy(g));
@@ -1930,7 +2051,7 @@ int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps) {
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   if (idx) {
     if (int e = stage_noise(h, idx, eps, 0)) return e;
-    if (int e = h->run_seq("grads_explicit", {&h->ops_grads})) return e;
+    if (int e = h->run_seq("grads_explicit", {&h->ops_gather, &h->ops_grads})) return e;
   } else {
     if (int e = h->run_seq("grads_rng", {&h->ops_rng, &h->ops_grads})) return e;
   }
@@ -1959,7 +2080,7 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   for (int s = 0; s < n_steps; ++s) {
     if (idx) {
       if (int e = stage_noise(h, idx, eps, s)) return e;
-      if (int e = h->run_seq("full_explicit", {&h->ops_grads, &h->ops_apply})) return e;
+      if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
     } else {
       if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
     }

@@ -40,7 +40,7 @@ struct HtHead {
   // output layers (1 for vf / qf, 2 for pi: mu and log_std), each [hid[L-1], out_dim]
   int n_out, out_dim;
   const float* ow[2]; const float* ob[2]; float* out[2];
-  const float* dout[2];                    // backward: gradient w.r.t. the outputs [B, out_dim]
+  const float* dout[2]; int ld_dout;       // backward: gradient w.r.t. the outputs [B, out_dim], row stride ld_dout
   float* da; int ld_da;                    // backward: gradient w.r.t. xa (nullptr: not needed)
 };
 
@@ -57,8 +57,27 @@ struct HeadsBwdArgs {
   const float* mu; const float* ls_raw; const float* eps; const float* pi_a;
   const float* log_ent_coef;
   float* da_pi;           // [B, A] (debug tap / split API)
-  float* dmu; float* dls; // [B, A]
+  float* dmu; float* dls; // [B, A], row stride ld_dm
+  int ld_dm;
+  // loss inputs: the output gradients of the critics are row-local (A.4), so they are formed here
+  //   d qf_i = (qf_i - (r + (1-d) gamma V_tgt)) / B,  d V = (V - (min(qf1_pi, qf2_pi) - alpha logp)) / B,  d qf1_pi = -1/B
+  const float* rew; const float* done; const float* v_tgt; const float* qf1; const float* qf2; const float* v;
+  const float* qf1_pi; const float* qf2_pi; const float* logp;
+  float gamma;
+  float* d_out[5];        // [B] (stride ld_d) per chain head index: 1 d_v, 2 d_qf1, 3 d_qf2, 4 d_qf1_pi
+  int ld_d;
 };
+
+__device__ __forceinline__ float ht_dout(const HeadsBwdArgs& a, int head, int row, float alpha) {
+  const float invB = 1.f / (float)a.B;
+  if (head == 4) return -invB;
+  if (head == 1) {
+    const float vb = fminf(a.qf1_pi[row], a.qf2_pi[row]) - alpha * a.logp[row];
+    return (a.v[row] - vb) * invB;
+  }
+  const float qb = a.rew[row] + (1.f - a.done[row]) * a.gamma * a.v_tgt[row];
+  return ((head == 2 ? a.qf1[row] : a.qf2[row]) - qb) * invB;
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-element pieces of the squashed-Gaussian sample and its backward (same arithmetic as
@@ -215,16 +234,17 @@ inline void heads_bwd_kernel(HeadsBwdArgs a) {
     float dv[2 * HT_MAXA];
     if (chain == 0) {
       const HtHead& q = a.h[4];
-      dv[0] = q.dout[0][row];
+      dv[0] = ht_dout(a, 4, row, expf(a.log_ent_coef[0]));
+      a.d_out[4][(long)row * a.ld_d] = dv[0];
       ht_ref_bwd_head(q, row, dv, a.da_pi + (long)row * a.A);
       ht_sample_bwd_row(a.ls_raw + (long)row * a.A, a.eps + (long)row * a.A, a.pi_a + (long)row * a.A,
-                        a.da_pi + (long)row * a.A, a.A, alpha_over_b, a.dmu + (long)row * a.A, a.dls + (long)row * a.A);
-      for (int j = 0; j < a.A; ++j) { dv[j] = a.dmu[(long)row * a.A + j]; dv[a.A + j] = a.dls[(long)row * a.A + j]; }
+                        a.da_pi + (long)row * a.A, a.A, alpha_over_b, a.dmu + (long)row * a.ld_dm, a.dls + (long)row * a.ld_dm);
+      for (int j = 0; j < a.A; ++j) { dv[j] = a.dmu[(long)row * a.ld_dm + j]; dv[a.A + j] = a.dls[(long)row * a.ld_dm + j]; }
       ht_ref_bwd_head(a.h[0], row, dv, nullptr);
     } else {
       const HtHead& h = a.h[chain];
-      for (int k = 0; k < h.n_out; ++k)
-        for (int o = 0; o < h.out_dim; ++o) dv[k * h.out_dim + o] = h.dout[k][(long)row * h.out_dim + o];
+      dv[0] = ht_dout(a, chain, row, expf(a.log_ent_coef[0]));
+      a.d_out[chain][(long)row * a.ld_d] = dv[0];
       ht_ref_bwd_head(h, row, dv, nullptr);
     }
   }
@@ -234,11 +254,42 @@ inline void heads_bwd_kernel(HeadsBwdArgs a) {
 
 typedef float ht_f4 __attribute__((ext_vector_type(4)));
 
+enum { HT_LDW = HT_MAXW + 1 };   // odd row stride: column reads (forward) and row reads (backward) are both conflict-free
 struct __attribute__((aligned(16))) HtLds {
+  float W[HT_MAXW * HT_LDW + 128]; // the layer kernel(s), staged once per (head, layer); two [128, 64+1] output kernels fit
   float zT[2][HT_MAXW][HT_RB];      // activations / gradients of the current and the next layer, [col][row]
   float xaT[HT_MAXA][HT_RB];        // second input part (action) of the rows, [a][row]
   float oT[2 * HT_MAXA][HT_RB];     // outputs (forward: mu | log_std) / output gradients (backward), [k*out_dim + o][row]
 };
+
+// kernel [Hin, Hout] (row-major) -> LDS W[k * (Hout+1) + n]; all loads are issued before the first write
+__device__ __forceinline__ void ht_stage_w_at(const float* w, int Hin, int Hout, float* W) {
+  const int t = threadIdx.x;
+  const int ld = Hout + 1;
+  __syncthreads();   // the previous stage may still be reading W
+  if ((Hout & 3) == 0) {
+    const int nq = Hin * Hout / 4;            // <= 4096 quads -> <= 16 per thread
+    ht_f4 r[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (t + 256 * e < nq) r[e] = *(const ht_f4*)(w + 4 * (t + 256 * e));
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (t + 256 * e < nq) {
+        const int idx = 4 * (t + 256 * e);
+        const int k = idx / Hout, n = idx - k * Hout;
+        float* d = W + k * ld + n;
+        d[0] = r[e].x; d[1] = r[e].y; d[2] = r[e].z; d[3] = r[e].w;
+      }
+  } else {
+    for (int idx = t; idx < Hin * Hout; idx += 256) {
+      const int k = idx / Hout, n = idx - k * Hout;
+      W[k * ld + n] = w[idx];
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void ht_stage_w(const float* w, int Hin, int Hout, HtLds& s) { ht_stage_w_at(w, Hin, Hout, s.W); }
 
 // forward of one head for the 16 rows of this workgroup; xaT must hold the head's action part
 __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, HtLds& s, bool keep_out) {
@@ -275,14 +326,15 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
     const int Hin = h.hid[l - 1], Hout = h.hid[l];
     float(*src)[HT_RB] = s.zT[(l - 1) & 1];
     float(*dst)[HT_RB] = s.zT[l & 1];
+    ht_stage_w(h.w[l], Hin, Hout, s);
     for (int c0 = 0; c0 < Hout; c0 += 64) {
       const int n = c0 + cl;
       if (n < Hout) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = h.w[l] + n;
+        const float* wp = s.W + n;
 #pragma unroll 8
         for (int k = 0; k < Hin; ++k) {
-          const float w = wp[(long)k * Hout];
+          const float w = wp[k * (Hout + 1)];
           const ht_f4 x = *(const ht_f4*)&src[k][4 * rg];
           acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
           acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
@@ -304,12 +356,13 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
     const int HL = h.hid[h.L - 1];
     float(*src)[HT_RB] = s.zT[(h.L - 1) & 1];
     for (int k = 0; k < h.n_out; ++k) {
+      ht_stage_w(h.ow[k], HL, h.out_dim, s);
       if (cl < h.out_dim) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = h.ow[k] + cl;
+        const float* wp = s.W + cl;
 #pragma unroll 8
         for (int n = 0; n < HL; ++n) {
-          const float w = wp[(long)n * h.out_dim];
+          const float w = wp[n * (h.out_dim + 1)];
           const ht_f4 x = *(const ht_f4*)&src[n][4 * rg];
           acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
           acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
@@ -375,12 +428,13 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
     const int HL = h.hid[L - 1];
     const float* zl = L == 1 ? h.z0 : h.z[L - 1];
     float* gl = L == 1 ? nullptr : h.g[L - 1];
+    for (int k = 0; k < h.n_out; ++k) ht_stage_w_at(h.ow[k], HL, h.out_dim, s.W + k * HL * (h.out_dim + 1));
     for (int c0 = 0; c0 < HL; c0 += 64) {
       const int n = c0 + cl;
       if (n < HL) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < h.n_out; ++k) {
-          const float* wp = h.ow[k] + (long)n * h.out_dim;
+          const float* wp = s.W + k * HL * (h.out_dim + 1) + n * (h.out_dim + 1);
           for (int o = 0; o < h.out_dim; ++o) {
             const float w = wp[o];
             const ht_f4 d = *(const ht_f4*)&s.oT[k * h.out_dim + o][4 * rg];
@@ -409,11 +463,12 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
     float(*src)[HT_RB] = s.zT[l & 1];
     float(*dst)[HT_RB] = s.zT[(l - 1) & 1];
     const float* zp = l == 1 ? h.z0 : h.z[l - 1];
+    ht_stage_w(h.w[l], Hin, Hout, s);
     for (int c0 = 0; c0 < Hin; c0 += 64) {
       const int m = c0 + cl;
       if (m < Hin) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = h.w[l] + (long)m * Hout;
+        const float* wp = s.W + m * (Hout + 1);
 #pragma unroll 8
         for (int n = 0; n < Hout; ++n) {
           const float w = wp[n];
@@ -438,9 +493,10 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
   }
   // ---- d xa = g_0 . w0a^T
   if (da) {
+    ht_stage_w(h.w0a, h.n_xa, h.H0, s);
     if (cl < h.n_xa) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* wp = h.w0a + (long)cl * h.H0;
+      const float* wp = s.W + cl * (h.H0 + 1);
       for (int n = 0; n < h.H0; ++n) {
         const float w = wp[n];
         const ht_f4 g = *(const ht_f4*)&s.zT[0][n][4 * rg];
@@ -463,11 +519,14 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs a) {
   const int row0 = blockIdx.x * HT_RB, chain = blockIdx.y, t = threadIdx.x;
   if (chain != 0) {
     const HtHead& h = a.h[chain];
-    for (int e = t; e < h.n_out * h.out_dim * HT_RB; e += 256) {
-      const int r = e % HT_RB, ko = e / HT_RB;
-      const int k = ko / h.out_dim, o = ko - k * h.out_dim;
-      const int row = row0 + r;
-      s.oT[ko][r] = row < a.B ? h.dout[k][(long)row * h.out_dim + o] : 0.f;
+    if (t < HT_RB) {
+      const int row = row0 + t;
+      float d = 0.f;
+      if (row < a.B) {
+        d = ht_dout(a, chain, row, expf(a.log_ent_coef[0]));
+        a.d_out[chain][(long)row * a.ld_d] = d;
+      }
+      s.oT[0][t] = d;
     }
     __syncthreads();
     ht_bwd_head(h, row0, a.B, s, nullptr, 0);
@@ -475,7 +534,15 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs a) {
   }
   // chain 0: qf1(s, pi) backward -> d a_pi -> sample backward -> pi head backward
   const HtHead& q = a.h[4];
-  if (t < HT_RB) s.oT[0][t] = (row0 + t) < a.B ? q.dout[0][row0 + t] : 0.f;
+  if (t < HT_RB) {
+    const int row = row0 + t;
+    float d = 0.f;
+    if (row < a.B) {
+      d = ht_dout(a, 4, row, 0.f);
+      a.d_out[4][(long)row * a.ld_d] = d;
+    }
+    s.oT[0][t] = d;
+  }
   __syncthreads();
   ht_bwd_head(q, row0, a.B, s, a.da_pi, a.A);
   if (t < HT_RB) {
@@ -489,7 +556,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs a) {
       if (row >= a.B) { m = 0.f; d = 0.f; }
       s.oT[j][t] = m;
       s.oT[a.A + j][t] = d;
-      if (row < a.B) { a.dmu[(long)row * a.A + j] = m; a.dls[(long)row * a.A + j] = d; }
+      if (row < a.B) { a.dmu[(long)row * a.ld_dm + j] = m; a.dls[(long)row * a.ld_dm + j] = d; }
     }
   }
   __syncthreads();

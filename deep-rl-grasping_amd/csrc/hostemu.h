@@ -55,6 +55,11 @@ static inline hipError_t hipEventCreate(hipEvent_t*) { return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t*, int) { return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t*, int) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return 0; }
 static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return 1; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, int) { return 1; }

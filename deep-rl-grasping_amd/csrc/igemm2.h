@@ -418,6 +418,40 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     cbase[off] = v;
   };
 
+  // The 16 results of a lane go to 16 different rows.  Output offsets (scatter table), ReLU masks and
+  // accumulate operands are fetched for all of them before the first store: the stores may alias the
+  // loads as far as the compiler knows, so interleaving them would serialise 16 dependent round trips.
+  auto emit16 = [&](const int (&iv)[16], int j, const float (&val)[16], float bj) {
+    long off[16];
+    bool ok[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      ok[x] = iv[x] < M;
+      const int ic = ok[x] ? iv[x] : 0;
+      if (cT) {
+        const int o = cT[ic];
+        ok[x] = ok[x] && o >= 0;
+        off[x] = (long)(o >= 0 ? o : 0) + j;
+      } else {
+        off[x] = (long)ic * ldc + j;
+      }
+    }
+    float mk[16], prev[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      mk[x] = (rmask && ok[x]) ? rmask[off[x]] : 1.f;
+      prev[x] = (accumulate && ok[x]) ? cbase[off[x]] : 0.f;
+    }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      float v = val[x] * oscale + bj + prev[x];
+      if (act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+      v = mk[x] > 0.f ? v : 0.f;
+      if (ok[x]) cbase[off[x]] = v;
+    }
+  };
+
   if (WK == 1) {
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
@@ -425,12 +459,16 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       if (j >= N) continue;
       const float bj = bias ? bias[j] : 0.f;
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+      for (int a = 0; a < FM; ++a) {
+        int iv[16];
+        float val[16];
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
-          const int i = i0 + (wm * FM + a) * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
-          if (i < M) emit(i, j, acc[a][b][x], bj);
+          iv[x] = i0 + (wm * FM + a) * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
+          val[x] = acc[a][b][x];
         }
+        emit16(iv, j, val, bj);
+      }
     }
     if (ONES && do_ones) {
       // all slabs are consumed (trailing barrier of the loop): reuse the staging LDS
@@ -459,15 +497,26 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
           red[(wk * BM + rl) * LDR + cl] = acc[a][b][x];
         }
     __syncthreads();
+    static_assert(BM * BN / 256 <= 16, "reduction epilogue handles up to 16 outputs per thread");
+    {
+      // thread t owns column cl = t % BN of rows rl = t / BN + e * (256 / BN)
+      const int cl = t % BN, j = j0 + cl;
+      int iv[16];
+      float val[16];
 #pragma unroll
-    for (int e = 0; e < BM * BN / 256; ++e) {
-      const int o = t + 256 * e;
-      const int rl = o / BN, cl = o % BN;
-      float s = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        iv[e] = M;   // inactive
+        val[e] = 0.f;
+        if (e < BM * BN / 256) {
+          const int rl = t / BN + e * (256 / BN);
+          float sacc = 0.f;
 #pragma unroll
-      for (int w = 0; w < WK; ++w) s += red[(w * BM + rl) * LDR + cl];
-      const int i = i0 + rl, j = j0 + cl;
-      if (i < M && j < N) emit(i, j, s, bias ? bias[j] : 0.f);
+          for (int w = 0; w < WK; ++w) sacc += red[(w * BM + rl) * LDR + cl];
+          iv[e] = i0 + rl;
+          val[e] = sacc;
+        }
+      }
+      if (j < N) emit16(iv, j, val, bias ? bias[j] : 0.f);
     }
   }
 }
