@@ -593,8 +593,8 @@ struct grl_ctx {
     }
     return true;
   }
-  // workgroup shape of a v2 launch: narrow outputs -> 128x32; few 64x64 tiles with long reductions
-  // -> 32x64 with the reduction split over the waves; otherwise 64x64
+  // workgroup shape of a v2 launch: narrow outputs -> 128x32; few 64x64 tiles -> 32x64 with the reduction
+  // split over wave pairs; otherwise 64x64 (shape 2, a 4-way split, stays selectable by GRL_I2CFG_<tag>)
   static int v2_pick_cfg(const std::vector<IgemmProb>& probs, int variant, const std::string& tag) {
     const std::string key = "GRL_I2CFG_" + tag;
     if (const char* e = getenv(key.c_str())) return atoi(e);
@@ -608,7 +608,10 @@ struct grl_ctx {
       longk = longk && std::min(p.K, p.k_chunk) >= 256;
     }
     if (maxN <= 32) return 1;
-    if (!ones && variant != 2 && tiles64 < 200 && longk) return 2;
+    // measured on MI355X (scripts/cfg_sweep.sh): below ~1.5 64x64 tiles per CU the 32x64 shape with a
+    // 2-way reduction split wins (twice the workgroups, 48 KB of LDS so that three share a CU)
+    (void)longk;
+    if (!ones && variant != 2 && tiles64 < 400) return 3;
     return 0;
   }
 
@@ -682,7 +685,8 @@ struct grl_ctx {
 #define GRL_I2_CFGS(base, PLv, QLv, PMv, QMv, FL)                           \
   case base + 0 + FL: GRL_I2(PLv, QLv, PMv, QMv, 0, FL); break;              \
   case base + 10 + FL: GRL_I2(PLv, QLv, PMv, QMv, 1, FL); break;             \
-  case base + 20 + FL: GRL_I2(PLv, QLv, PMv, QMv, 2, FL); break;
+  case base + 20 + FL: GRL_I2(PLv, QLv, PMv, QMv, 2, FL); break;             \
+  case base + 30 + FL: GRL_I2(PLv, QLv, PMv, QMv, 3, FL); break;
         switch (key) {
           GRL_I2_CFGS(0, I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0)            // dense forward
           GRL_I2_CFGS(0, I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, I2F_KTAIL)    //   ... K % 4 != 0

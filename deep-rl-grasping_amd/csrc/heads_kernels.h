@@ -273,23 +273,58 @@ __device__ __forceinline__ void ht_stage_w_at(const float* w, int Hin, int Hout,
 #pragma unroll
     for (int e = 0; e < 16; ++e)
       if (t + 256 * e < nq) r[e] = *(const ht_f4*)(w + 4 * (t + 256 * e));
+    // element 4*(t + 256 e) -> (row k, column c): one division per thread, then incremental
+    int k = (4 * t) / Hout, c = 4 * t - k * Hout;
+    const int dk = 1024 / Hout, dc = 1024 - dk * Hout;
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int e = 0; e < 16; ++e) {
       if (t + 256 * e < nq) {
-        const int idx = 4 * (t + 256 * e);
-        const int k = idx / Hout, n = idx - k * Hout;
-        float* d = W + k * ld + n;
+        float* d = W + k * ld + c;
         d[0] = r[e].x; d[1] = r[e].y; d[2] = r[e].z; d[3] = r[e].w;
       }
+      k += dk; c += dc;
+      if (c >= Hout) { c -= Hout; ++k; }
+    }
   } else {
+    int k = t / Hout, c = t - k * Hout;
+    const int dk = 256 / Hout, dc = 256 - dk * Hout;
     for (int idx = t; idx < Hin * Hout; idx += 256) {
-      const int k = idx / Hout, n = idx - k * Hout;
-      W[k * ld + n] = w[idx];
+      W[k * ld + c] = w[idx];
+      k += dk; c += dc;
+      if (c >= Hout) { c -= Hout; ++k; }
     }
   }
   __syncthreads();
 }
 __device__ __forceinline__ void ht_stage_w(const float* w, int Hin, int Hout, HtLds& s) { ht_stage_w_at(w, Hin, Hout, s.W); }
+
+// acc[r] += sum_k x[k][r] * w[k * wstride]  (k ascending: the fmaf chain order of the GEMM path).
+// x points at zT[..][0][4*rg]: 4 consecutive rows of column k are one 16-byte LDS read (row stride HT_RB).
+// Operands of 8 k-steps are fetched before the first fma: otherwise every step exposes the LDS latency.
+__device__ __forceinline__ void ht_dot(float (&acc)[4], const float* w, int wstride, const float* x, int K) {
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float wv[8];
+    ht_f4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      wv[u] = w[(k + u) * wstride];
+      xv[u] = *(const ht_f4*)(x + (k + u) * HT_RB);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0] = fmaf(xv[u].x, wv[u], acc[0]); acc[1] = fmaf(xv[u].y, wv[u], acc[1]);
+      acc[2] = fmaf(xv[u].z, wv[u], acc[2]); acc[3] = fmaf(xv[u].w, wv[u], acc[3]);
+    }
+  }
+  for (; k < K; ++k) {
+    const float wv = w[k * wstride];
+    const ht_f4 xv = *(const ht_f4*)(x + k * HT_RB);
+    acc[0] = fmaf(xv.x, wv, acc[0]); acc[1] = fmaf(xv.y, wv, acc[1]);
+    acc[2] = fmaf(xv.z, wv, acc[2]); acc[3] = fmaf(xv.w, wv, acc[3]);
+  }
+}
 
 // forward of one head for the 16 rows of this workgroup; xaT must hold the head's action part
 __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, HtLds& s, bool keep_out) {
@@ -331,14 +366,7 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
       const int n = c0 + cl;
       if (n < Hout) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = s.W + n;
-#pragma unroll 8
-        for (int k = 0; k < Hin; ++k) {
-          const float w = wp[k * (Hout + 1)];
-          const ht_f4 x = *(const ht_f4*)&src[k][4 * rg];
-          acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
-          acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
-        }
+        ht_dot(acc, s.W + n, Hout + 1, &src[0][4 * rg], Hin);
         const float bn = h.b[l][n];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -359,14 +387,7 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
       ht_stage_w(h.ow[k], HL, h.out_dim, s);
       if (cl < h.out_dim) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = s.W + cl;
-#pragma unroll 8
-        for (int n = 0; n < HL; ++n) {
-          const float w = wp[n * (h.out_dim + 1)];
-          const ht_f4 x = *(const ht_f4*)&src[n][4 * rg];
-          acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
-          acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
-        }
+        ht_dot(acc, s.W + cl, h.out_dim + 1, &src[0][4 * rg], HL);
         const float bo = h.ob[k][cl];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -383,11 +404,8 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
 
 __device__ __forceinline__ void ht_load_xa(const HtHead& h, int row0, int B, HtLds& s) {
   const int t = threadIdx.x;
-  for (int e = t; e < h.n_xa * HT_RB; e += 256) {
-    const int r = e / h.n_xa, a = e - r * h.n_xa;
-    const int row = row0 + r;
-    s.xaT[a][r] = row < B ? h.xa[(long)row * h.ld_xa + a] : 0.f;
-  }
+  const int r = t & (HT_RB - 1), row = row0 + r;
+  for (int a = t / HT_RB; a < h.n_xa; a += 256 / HT_RB) s.xaT[a][r] = row < B ? h.xa[(long)row * h.ld_xa + a] : 0.f;
   __syncthreads();
 }
 
@@ -468,14 +486,7 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
       const int m = c0 + cl;
       if (m < Hin) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* wp = s.W + m * (Hout + 1);
-#pragma unroll 8
-        for (int n = 0; n < Hout; ++n) {
-          const float w = wp[n];
-          const ht_f4 g = *(const ht_f4*)&src[n][4 * rg];
-          acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
-          acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
-        }
+        ht_dot(acc, s.W + m * (Hout + 1), 1, &src[0][4 * rg], Hout);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + 4 * rg + i;
@@ -496,13 +507,7 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
     ht_stage_w(h.w0a, h.n_xa, h.H0, s);
     if (cl < h.n_xa) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* wp = s.W + cl * (h.H0 + 1);
-      for (int n = 0; n < h.H0; ++n) {
-        const float w = wp[n];
-        const ht_f4 g = *(const ht_f4*)&s.zT[0][n][4 * rg];
-        acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
-        acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
-      }
+      ht_dot(acc, s.W + cl * (h.H0 + 1), 1, &s.zT[0][0][4 * rg], h.H0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * rg + i;

@@ -12,8 +12,9 @@
 //     operands contiguous along the output index stay k-major ([k][cols + 4], ds_read_b32);
 //   * LDS is double buffered: one barrier per slab, global loads of slab s+1 are in flight while
 //     the MFMAs of slab s run;
-//   * three workgroup shapes (CFG): 64x64 (2x2 waves), 128x32 (4x1 waves, narrow-N convolutions)
-//     and 32x64 with the four waves splitting the reduction (small-M dense layers: fills the chip
+//   * workgroup shapes (CFG): 64x64 (2x2 waves), 128x32 (4x1 waves, narrow-N convolutions), 32x64 with
+//     the reduction split 2 ways (1x2 waves x 2, 48 KB of LDS: three per CU) and 32x64 with the four
+//     waves splitting the reduction (small-M dense layers: fills the chip
 //     without a global split-K pass; partial accumulators are summed through LDS in wave order);
 //   * the bias-gradient "ones row" of a weight-gradient problem is not an extra, nearly empty row
 //     tile any more: the workgroups of row tile 0 sum the staged dY slab column-wise (VALU, from
@@ -34,8 +35,9 @@ template <int CFG> struct I2Cfg;
 template <> struct I2Cfg<0> { static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, WK = 1, FM = 1, FN = 1; };
 template <> struct I2Cfg<1> { static constexpr int BM = 128, BN = 32, WM = 4, WN = 1, WK = 1, FM = 1, FN = 1; };
 template <> struct I2Cfg<2> { static constexpr int BM = 32, BN = 64, WM = 1, WN = 1, WK = 4, FM = 1, FN = 2; };
+template <> struct I2Cfg<3> { static constexpr int BM = 32, BN = 64, WM = 1, WN = 2, WK = 2, FM = 1, FN = 1; };
 
-static inline int i2_bm(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 128 : 32); }
+static inline int i2_bm(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 128 : 32); }   // cfg 2, 3: 32
 static inline int i2_bn(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 32 : 64); }
 
 #ifdef GRL_HOSTEMU
