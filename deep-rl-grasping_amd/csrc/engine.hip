@@ -548,7 +548,7 @@ struct grl_ctx {
     single_part(p);
     p.q_base[0] = w; p.q_tab_r = c.q_tab_r; p.q_ld_j[0] = g.Cout;
     p.c = dx; p.c_tab_i = c.c_tab_i; p.relu_mask = mask;
-    p.vflags = (c.vec4_p ? VF_P_TABS : 0) | (c.vec4_q ? VF_Q_TAB : 0);
+    p.vflags = (c.vec4_p ? VF_P_TABS : 0) | (c.vec4_q ? VF_Q_TAB : 0) | ((g.C % 4 == 0) ? VF_CT4 : 0);
     set_split(p, 1);
     return p;
   }
@@ -649,6 +649,11 @@ struct grl_ctx {
       l->flags = (any_ones ? I2F_ONES : 0) | (ktail ? I2F_KTAIL : 0);
     }
     l->cfg = l->v2 ? v2_pick_cfg(l->probs, variant, tag) : 0;
+    if (l->v2)   // outputs that can leave as 16-byte stores (igemm2 wide epilogue)
+      for (auto& p : l->probs)
+        if (al16(p.c) && (p.ldc % 4) == 0 && (p.N % 4) == 0 && (p.slab_stride % 4) == 0 &&
+            (!p.c_tab_i || (p.vflags & VF_CT4)) && (!p.relu_mask || al16(p.relu_mask)) && (!p.bias || al16(p.bias)))
+          p.vflags |= VF_C_VEC;
     if (getenv("GRL_PLAN_DUMP"))
       fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu\n", tag.c_str(), variant,
               l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size());

@@ -58,11 +58,13 @@ struct IgemmProb {
   float act_alpha;
   int32_t accumulate;     // += existing c
   float out_scale;        // accumulator scale before bias / accumulate (0 means 1)
-  // ---- host-side planning hints (never read on the device): addressing tables checked for 16-byte
-  // runs -- bit 0: P tables, bit 1: Q table (igemm2.h eligibility)
+  // ---- planning hints: addressing tables checked for 16-byte runs -- bit 0: P tables, bit 1: Q table
+  // (igemm2.h eligibility, host only); bit 2: outputs (and ReLU mask / accumulate operands) can be moved
+  // 16 bytes at a time: base, row offsets and N are multiples of 4 floats (igemm2 epilogue)
   uint32_t vflags;
+  void* dbg_t;            // I2_TIMING builds (scripts/igemm_bench.hip): s_memtime stamps of three workgroups
 };
-enum { VF_P_TABS = 1u, VF_Q_TAB = 2u };
+enum { VF_P_TABS = 1u, VF_Q_TAB = 2u, VF_C_VEC = 4u, VF_CT4 = 8u };   // VF_CT4 (host): scatter-table offsets are multiples of 4   // VF_C_VEC is also read by the igemm2 epilogue
 
 // Addressing modes are compile-time so the staging code has no branch around any load: every
 // load of a slab is issued back to back (masked lanes read offset 0 and select 0 afterwards) and the

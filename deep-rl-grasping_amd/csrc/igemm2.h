@@ -125,10 +125,17 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   constexpr int PSZ = PL == I2_P_ALONG_R ? BM * LDPK : BKT * LDPM;
   constexpr int QSZ = QL == I2_Q_ALONG_R ? BN * LDQK : BKT * LDQN;
   constexpr int BUF = PSZ + QSZ;
-  constexpr int RED = WK > 1 ? WK * BM * (BN + 1) : 0;
+  constexpr int RED = WK > 1 ? WK * BM * (BN + 4) : BM * (BN + 4);   // k-split partials / output tile of the wide epilogue
   constexpr int LDSF = 2 * BUF > RED ? 2 * BUF : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
+#ifdef I2_TIMING
+#define I2_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) { \
+    unsigned long long* d_ = (unsigned long long*)probs[0].dbg_t; if (d_) d_[(blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 16 : 8)) + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define I2_STAMP(k) do { } while (0)
+#endif
+  I2_STAMP(0);
   const int4 tl = tiles[blockIdx.x];
   const IgemmProb* __restrict__ pb = probs + tl.x;
   const int N = pb->N, K = pb->K;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   unsigned p_kb = 0xfu, q_kb = 0xfu;   // KTAIL: validity of the 4 elements of an along-r vector
 
   // one vector of slab r0 (compile-time e): offset select + buffer load, nothing else
-  auto load_p = [&](int r0, int e) {
+  auto load_p = [&](int r0, int e, f32x4 (&pv)[NVP], unsigned& p_kb) {
     if (I2_ABLATE & 1) { pv[e] = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
     if (PL == I2_P_ALONG_R) {
       const int r = r0 + 4 * p_q;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       pv[e] = i2_ld(rsP, ok ? (p_fix[0] + colterm) * 4 : I2_OOB);
     }
   };
-  auto load_q = [&](int r0, int e) {
+  auto load_q = [&](int r0, int e, f32x4 (&qv)[NVQ], unsigned& q_kb) {
     if (I2_ABLATE & 1) { qv[e] = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
     if (QL == I2_Q_ALONG_R) {
       const int r = r0 + 4 * q_q;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     *(f32x2*)d = f32x2{v.x, v.z};
     *(f32x2*)(d + 16) = f32x2{v.y, v.w};
   };
-  auto store_p = [&](float* buf, int e) {
+  auto store_p = [&](float* buf, int e, const f32x4 (&pv)[NVP], unsigned p_kb) {
     if (I2_ABLATE & 2) { asm volatile("" ::"v"(pv[e].x)); return; }
     if (PL == I2_P_ALONG_R) {
       put_kquad(buf + (p_l + e * PSTEP) * LDPK, p_q, KTAIL ? ktail_fix(pv[e], p_kb) : pv[e]);
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       *(f32x4*)(buf + kpos(p_l + e * PSTEP) * LDPM + 4 * p_q) = pv[e];
     }
   };
-  auto store_q = [&](float* buf, int e) {
+  auto store_q = [&](float* buf, int e, const f32x4 (&qv)[NVQ], unsigned q_kb) {
     if (I2_ABLATE & 2) { asm volatile("" ::"v"(qv[e].x)); return; }
     float* Qs = buf + PSZ;
     if (QL == I2_Q_ALONG_R) {
@@ -308,23 +315,31 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   // Every piece of staging work sits in the shadow of one MFMA of the (dependent, in-order) chain;
   // per slab only the fragment reads after the barrier are exposed.
   const int nslab = (r_end - r_begin + BKT - 1) / BKT;
-  fetch_tabs(r_begin);
+  I2_STAMP(1);
+  // prologue: slab 0 goes through its own registers so that slab 1 can be requested before slab 0 has
+  // landed (one memory round trip less before the first MFMA)
+  {
+    f32x4 pv0[NVP], qv0[NVQ];
+    unsigned p_kb0 = 0xfu, q_kb0 = 0xfu;
+    fetch_tabs(r_begin);
 #pragma unroll
-  for (int e = 0; e < NVP; ++e) load_p(r_begin, e);
+    for (int e = 0; e < NVP; ++e) load_p(r_begin, e, pv0, p_kb0);
 #pragma unroll
-  for (int e = 0; e < NVQ; ++e) load_q(r_begin, e);
-  fetch_tabs(r_begin + BKT);
+    for (int e = 0; e < NVQ; ++e) load_q(r_begin, e, qv0, q_kb0);
+    fetch_tabs(r_begin + BKT);
 #pragma unroll
-  for (int e = 0; e < NVP; ++e) store_p(lds, e);
+    for (int e = 0; e < NVP; ++e) load_p(r_begin + BKT, e, pv, p_kb);
 #pragma unroll
-  for (int e = 0; e < NVQ; ++e) store_q(lds, e);
+    for (int e = 0; e < NVQ; ++e) load_q(r_begin + BKT, e, qv, q_kb);
+    fetch_tabs(r_begin + 2 * BKT);
 #pragma unroll
-  for (int e = 0; e < NVP; ++e) load_p(r_begin + BKT, e);
+    for (int e = 0; e < NVP; ++e) store_p(lds, e, pv0, p_kb0);
 #pragma unroll
-  for (int e = 0; e < NVQ; ++e) load_q(r_begin + BKT, e);
-  fetch_tabs(r_begin + 2 * BKT);
+    for (int e = 0; e < NVQ; ++e) store_q(lds, e, qv0, q_kb0);
+  }
   __syncthreads();
 
+  I2_STAMP(2);
   constexpr int NMF = 16 * FM * FN;            // MFMAs of one slab per wave
   constexpr int NST = NVP + NVQ;               // staged vectors per thread and slab
   static_assert(2 * NST + 1 <= NMF - 3 - (ONES ? 1 : 0), "staging work must fit into the MFMA gaps of a slab");
@@ -381,10 +396,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
           for (int u = 0; u < RPG; ++u) csum += Qs[(rq * RPG + u) * LDQN + col];
         }
       } else {
-        if (piece < NVP) store_p(nxt, piece);
-        else if (piece < NST) store_q(nxt, piece - NVP);
-        else if (piece < NST + NVP) load_p(r2, piece - NST);
-        else if (piece < 2 * NST) load_q(r2, piece - NST - NVP);
+        if (piece < NVP) store_p(nxt, piece, pv, p_kb);
+        else if (piece < NST) store_q(nxt, piece - NVP, qv, q_kb);
+        else if (piece < NST + NVP) load_p(r2, piece - NST, pv, p_kb);
+        else if (piece < 2 * NST) load_q(r2, piece - NST - NVP, qv, q_kb);
         else if (piece == 2 * NST) fetch_tabs(r2 + BKT);
         ++piece;
       }
@@ -393,6 +408,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     if (!(I2_ABLATE & 4)) __syncthreads();
   }
 
+  I2_STAMP(3);
   // ------------------------------------------------------------------ epilogue
   const gf32 cbase = (gf32)(pb->c + (long)tl.y * pb->slab_stride);
   const int ldc = pb->ldc;
@@ -454,7 +470,74 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     }
   };
 
+  // Row-per-lane dword stores drain at ~7 B/clk/CU (store-issue bound): a 64x64 tile then spends
+  // longer in its epilogue than in three slabs of MFMAs.  When the output allows 16-byte accesses
+  // (VF_C_VEC) the tile goes through LDS once and leaves as dwordx4 stores, 4 columns per lane.
+  const bool cvec = (pb->vflags & VF_C_VEC) != 0;
+  constexpr int LDC_S = BN + 4;
+  auto wide_out = [&](float* tile) {   // tile[BM][LDC_S] holds acc (already summed over the k split)
+    constexpr int NC4 = BN / 4, RSTEP = 256 / NC4, NQ = BM / RSTEP;
+    const int c4 = t % NC4, rl0 = t / NC4;
+    const int j = j0 + 4 * c4;
+    if (j >= N) return;
+    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bj = *(const GRL_GLOBAL f32x4*)(bias + j);
+    long off[NQ];
+    bool ok[NQ];
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int i = i0 + rl0 + e * RSTEP;
+      ok[e] = i < M;
+      const int ic = ok[e] ? i : 0;
+      if (cT) {
+        const int o = cT[ic];
+        ok[e] = ok[e] && o >= 0;
+        off[e] = (long)(o >= 0 ? o : 0) + j;
+      } else {
+        off[e] = (long)ic * ldc + j;
+      }
+    }
+    f32x4 mk[NQ], prev[NQ];
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      mk[e] = f32x4{1.f, 1.f, 1.f, 1.f};
+      prev[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rmask && ok[e]) mk[e] = *(const GRL_GLOBAL f32x4*)(rmask + off[e]);
+      if (accumulate && ok[e]) prev[e] = *(const GRL_GLOBAL f32x4*)(cbase + off[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      f32x4 v = *(const f32x4*)(tile + (rl0 + e * RSTEP) * LDC_S + 4 * c4);
+      v = v * oscale + bj + prev[e];
+      if (act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      else if (act == ACT_LEAKY) {
+        v.x = v.x > 0.f ? v.x : alpha * v.x; v.y = v.y > 0.f ? v.y : alpha * v.y;
+        v.z = v.z > 0.f ? v.z : alpha * v.z; v.w = v.w > 0.f ? v.w : alpha * v.w;
+      }
+      v.x = mk[e].x > 0.f ? v.x : 0.f; v.y = mk[e].y > 0.f ? v.y : 0.f;
+      v.z = mk[e].z > 0.f ? v.z : 0.f; v.w = mk[e].w > 0.f ? v.w : 0.f;
+      if (ok[e]) *(GRL_GLOBAL f32x4*)(cbase + off[e]) = v;
+    }
+  };
+
   if (WK == 1) {
+    if (cvec) {
+      // all slabs are consumed (trailing barrier of the loop): the staging LDS is free
+      float* tile = lds;
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int x = 0; x < 16; ++x) {
+            const int rl = (wm * FM + a) * 32 + (x & 3) + 8 * (x >> 2) + 4 * lh;
+            const int cl = (wn * FN + b) * 32 + li;
+            tile[rl * LDC_S + cl] = acc[a][b][x];
+          }
+      __syncthreads();
+      wide_out(tile);
+      if (ONES && do_ones) __syncthreads();   // the column sums below reuse lds[0..255]
+    } else {
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
       const int j = j0 + (wn * FN + b) * 32 + li;
@@ -472,8 +555,8 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
         emit16(iv, j, val, bj);
       }
     }
+    }
     if (ONES && do_ones) {
-      // all slabs are consumed (trailing barrier of the loop): reuse the staging LDS
       lds[t] = csum;
       __syncthreads();
       if (t < BN) {
@@ -485,9 +568,9 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       }
     }
   } else {
-    // the four waves hold partial sums over disjoint k ranges: add them in wave order through LDS
+    // the waves hold partial sums over disjoint k ranges: add them in wave order through LDS
     float* red = lds;
-    constexpr int LDR = BN + 1;
+    constexpr int LDR = BN + 4;
 #pragma unroll
     for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -499,8 +582,21 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
           red[(wk * BM + rl) * LDR + cl] = acc[a][b][x];
         }
     __syncthreads();
-    static_assert(BM * BN / 256 <= 16, "reduction epilogue handles up to 16 outputs per thread");
-    {
+    if (cvec) {
+      // sum the partials in place (each thread owns the quads it will store), then the wide path
+      constexpr int NC4 = BN / 4, RSTEP = 256 / NC4, NQ = BM / RSTEP;
+      const int c4 = t % NC4, rl0 = t / NC4;
+#pragma unroll
+      for (int e = 0; e < NQ; ++e) {
+        const int rl = rl0 + e * RSTEP;
+        f32x4 sacc = *(const f32x4*)(red + rl * LDR + 4 * c4);
+#pragma unroll
+        for (int w = 1; w < WK; ++w) sacc += *(const f32x4*)(red + (w * BM + rl) * LDR + 4 * c4);
+        *(f32x4*)(red + rl * LDR + 4 * c4) = sacc;
+      }
+      wide_out(red);
+    } else {
+      static_assert(BM * BN / 256 <= 16, "reduction epilogue handles up to 16 outputs per thread");
       // thread t owns column cl = t % BN of rows rl = t / BN + e * (256 / BN)
       const int cl = t % BN, j = j0 + cl;
       int iv[16];
@@ -521,6 +617,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       if (j < N) emit16(iv, j, val, bias ? bias[j] : 0.f);
     }
   }
+  I2_STAMP(4);
 }
 
 #endif  // GRL_HOSTEMU

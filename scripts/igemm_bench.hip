@@ -114,7 +114,8 @@ int main(int argc, char** argv) {
       if (sh.variant == 0) { p.p_ld_i[0] = sh.K; p.p_ld_r[0] = 1; p.q_ld_r[0] = sh.N; p.q_ld_j[0] = 1; }
       if (sh.variant == 1) { p.p_ld_i[0] = sh.K; p.p_ld_r[0] = 1; p.q_ld_r[0] = 1; p.q_ld_j[0] = sh.K; }
       if (sh.variant == 2) { p.p_ld_i[0] = 1; p.p_ld_r[0] = sh.M; p.q_ld_r[0] = sh.N; p.q_ld_j[0] = 1; }
-      p.c = dc; p.ldc = sh.N;
+      p.c = dc; p.ldc = sh.N; p.vflags = (getenv("NO_CVEC") ? 0 : VF_C_VEC);
+      { void* z; CK(hipMalloc(&z, 64 * 8)); CK(hipMemset(z, 0, 64 * 8)); p.dbg_t = z; }
       const int tiles_r = (sh.K + 31) / 32;
       const int per = (tiles_r + sh.split - 1) / sh.split;
       p.k_chunk = per * 32; p.split = (sh.K + p.k_chunk - 1) / p.k_chunk; p.slab_stride = (int64_t)sh.M * sh.N;
@@ -163,6 +164,16 @@ int main(int argc, char** argv) {
       else if (!ref.empty()) for (size_t i = 0; i < out.size(); ++i) maxd = std::max(maxd, (double)fabsf(out[i] - ref[i]));
       printf("%s M=%d N=%d K=%d x%d split=%d  %s cfg=%d tiles=%zu: %.2f us  %.1f TFLOP/s  maxdiff_vs_v1=%.2e\n", sh.name, sh.M,
              sh.N, sh.K, sh.nprob, sh.split, cfg < 0 ? "v1" : "v2", cfg, tiles.size(), ms * 1e3, flops / ms / 1e9, maxd);
+#ifdef I2_TIMING
+      if (cfg >= 0) {
+        unsigned long long st[24];
+        CK(hipMemcpy(st, probs[0].dbg_t, sizeof(st), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 3; ++w)
+          printf("    wg %-5s start+%6lld | descr %6lld  prologue %6lld  loop %6lld  epilogue %6lld  (cycles)\n", w == 0 ? "first" : (w == 1 ? "mid" : "last"),
+                 (long long)(st[8 * w] - st[0]), (long long)(st[8 * w + 1] - st[8 * w]), (long long)(st[8 * w + 2] - st[8 * w + 1]),
+                 (long long)(st[8 * w + 3] - st[8 * w + 2]), (long long)(st[8 * w + 4] - st[8 * w + 3]));
+      }
+#endif
       CK(hipFree(dt));
     }
   }
