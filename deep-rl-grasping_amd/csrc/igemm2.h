@@ -230,8 +230,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     }
   };
 
-  f32x4 pv[NVP], qv[NVQ];
-  unsigned p_kb = 0xfu, q_kb = 0xfu;   // KTAIL: validity of the 4 elements of an along-r vector
+  // two register sets: while slab s runs from LDS, slab s+1 (one set) is written to the other LDS buffer
+  // and slab s+2 (other set) is still in flight -- loads have two slabs of MFMAs to land
+  f32x4 pv[NVP], qv[NVQ], pvB[NVP], qvB[NVQ];
+  unsigned p_kb = 0xfu, q_kb = 0xfu, p_kbB = 0xfu, q_kbB = 0xfu;   // KTAIL: validity of the 4 elements of an along-r vector
 
   // one vector of slab r0 (compile-time e): offset select + buffer load, nothing else
   auto load_p = [&](int r0, int e, f32x4 (&pv)[NVP], unsigned& p_kb) {
@@ -333,6 +335,11 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     for (int e = 0; e < NVQ; ++e) load_q(r_begin + BKT, e, qv, q_kb);
     fetch_tabs(r_begin + 2 * BKT);
 #pragma unroll
+    for (int e = 0; e < NVP; ++e) load_p(r_begin + 2 * BKT, e, pvB, p_kbB);
+#pragma unroll
+    for (int e = 0; e < NVQ; ++e) load_q(r_begin + 2 * BKT, e, qvB, q_kbB);
+    fetch_tabs(r_begin + 3 * BKT);
+#pragma unroll
     for (int e = 0; e < NVP; ++e) store_p(lds, e, pv0, p_kb0);
 #pragma unroll
     for (int e = 0; e < NVQ; ++e) store_q(lds, e, qv0, q_kb0);
@@ -343,10 +350,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   constexpr int NMF = 16 * FM * FN;            // MFMAs of one slab per wave
   constexpr int NST = NVP + NVQ;               // staged vectors per thread and slab
   static_assert(2 * NST + 1 <= NMF - 3 - (ONES ? 1 : 0), "staging work must fit into the MFMA gaps of a slab");
-  for (int s = 0; s < nslab; ++s) {
+  auto slab_body = [&](int s, f32x4 (&pv)[NVP], f32x4 (&qv)[NVQ], unsigned& p_kb, unsigned& q_kb) {
     float* cur = lds + (s & 1) * BUF;
     float* nxt = lds + ((s + 1) & 1) * BUF;
-    const int r2 = r_begin + (s + 2) * BKT;
+    const int r2 = r_begin + (s + 3) * BKT;   // the set written to LDS now (slab s+1) is refilled with slab s+3
     // ---------------- fragments: LDS -> registers in four chunks of 4 k-steps.  Only chunk 0 is
     // read before the chain starts (all four waves leave the barrier together, so whatever is read
     // here queues on the LDS four deep); chunk c+1 is requested in the first gap of chunk c.
@@ -406,6 +413,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!(I2_ABLATE & 4)) __syncthreads();
+  };
+  for (int s = 0; s < nslab; s += 2) {
+    slab_body(s, pv, qv, p_kb, q_kb);
+    if (s + 1 < nslab) slab_body(s + 1, pvB, qvB, p_kbB, q_kbB);
   }
 
   I2_STAMP(3);
