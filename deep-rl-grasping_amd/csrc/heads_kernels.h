@@ -298,6 +298,41 @@ __device__ __forceinline__ void ht_stage_w_at(const float* w, int Hin, int Hout,
 }
 __device__ __forceinline__ void ht_stage_w(const float* w, int Hin, int Hout, HtLds& s) { ht_stage_w_at(w, Hin, Hout, s.W); }
 
+// The kernel of the NEXT stage travels global -> registers while the current stage computes (kernels of up
+// to 4096 floats, i.e. 64x64; larger or odd-sized ones are copied at commit time without overlap).
+struct HtW { ht_f4 r[4]; };
+__device__ __forceinline__ bool ht_w_fast(int n) { return (n & 3) == 0 && n <= 4096; }
+__device__ __forceinline__ void ht_w_fetch(HtW& p, const float* w, int n) {
+  if (!ht_w_fast(n)) return;
+  const int t = threadIdx.x, nq = n >> 2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (256 * e < nq) p.r[e] = *(const ht_f4*)(w + 4 * min(t + 256 * e, nq - 1));
+}
+__device__ __forceinline__ void ht_w_commit(const HtW& p, const float* w, int Hin, int Hout, float* W) {
+  const int n = Hin * Hout;
+  if (!ht_w_fast(n)) { ht_stage_w_at(w, Hin, Hout, W); return; }
+  const int t = threadIdx.x, ld = Hout + 1, nq = n >> 2;
+  __syncthreads();   // the previous stage may still be reading W
+  int k = (4 * t) / Hout, c = 4 * t - k * Hout;
+  const int dk = 1024 / Hout, dc = 1024 - dk * Hout;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (t + 256 * e < nq) {
+      const float v[4] = {p.r[e].x, p.r[e].y, p.r[e].z, p.r[e].w};
+      int kk = k, cc = c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        W[kk * ld + cc] = v[i];
+        if (++cc == Hout) { cc = 0; ++kk; }
+      }
+    }
+    k += dk; c += dc;
+    if (c >= Hout) { c -= Hout; ++k; }
+  }
+  __syncthreads();
+}
+
 // acc[r] += sum_k x[k][r] * w[k * wstride]  (k ascending: the fmaf chain order of the GEMM path).
 // x points at zT[..][0][4*rg]: 4 consecutive rows of column k are one 16-byte LDS read (row stride HT_RB).
 // Operands of 8 k-steps are fetched before the first fma: otherwise every step exposes the LDS latency.
@@ -329,11 +364,17 @@ __device__ __forceinline__ void ht_dot(float (&acc)[4], const float* w, int wstr
 // forward of one head for the 16 rows of this workgroup; xaT must hold the head's action part
 __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, HtLds& s, bool keep_out) {
   const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
+  const int HL = h.hid[h.L - 1];
+  HtW pw;
+  // kernel of the first staged stage (hidden layer 1, or the first output layer)
+  if (h.L > 1) ht_w_fetch(pw, h.w[1], h.hid[0] * h.hid[1]);
+  else ht_w_fetch(pw, h.ow[0], HL * h.out_dim);
   // ---- layer 0
   for (int c0 = 0; c0 < h.H0; c0 += 64) {
     const int n = c0 + cl;
     if (n < h.H0) {
       float acc[4];
+      const float bn = h.b0[n];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * rg + i;
@@ -345,7 +386,6 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
         acc[0] = fmaf(x.x, w, acc[0]); acc[1] = fmaf(x.y, w, acc[1]);
         acc[2] = fmaf(x.z, w, acc[2]); acc[3] = fmaf(x.w, w, acc[3]);
       }
-      const float bn = h.b0[n];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * rg + i;
@@ -355,19 +395,20 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
       }
     }
   }
-  __syncthreads();
-  // ---- hidden layers
+  // ---- hidden layers (ht_w_commit's barriers also publish zT of the previous layer)
   for (int l = 1; l < h.L; ++l) {
     const int Hin = h.hid[l - 1], Hout = h.hid[l];
     float(*src)[HT_RB] = s.zT[(l - 1) & 1];
     float(*dst)[HT_RB] = s.zT[l & 1];
-    ht_stage_w(h.w[l], Hin, Hout, s);
+    ht_w_commit(pw, h.w[l], Hin, Hout, s.W);
+    if (l + 1 < h.L) ht_w_fetch(pw, h.w[l + 1], Hout * h.hid[l + 1]);
+    else ht_w_fetch(pw, h.ow[0], HL * h.out_dim);
     for (int c0 = 0; c0 < Hout; c0 += 64) {
       const int n = c0 + cl;
       if (n < Hout) {
+        const float bn = h.b[l][n];   // requested before the dot product, consumed after it
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         ht_dot(acc, s.W + n, Hout + 1, &src[0][4 * rg], Hin);
-        const float bn = h.b[l][n];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + 4 * rg + i;
@@ -377,18 +418,17 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
         }
       }
     }
-    __syncthreads();
   }
   // ---- output layers (out_dim <= 64)
   {
-    const int HL = h.hid[h.L - 1];
     float(*src)[HT_RB] = s.zT[(h.L - 1) & 1];
     for (int k = 0; k < h.n_out; ++k) {
-      ht_stage_w(h.ow[k], HL, h.out_dim, s);
+      ht_w_commit(pw, h.ow[k], HL, h.out_dim, s.W);
+      if (k + 1 < h.n_out) ht_w_fetch(pw, h.ow[k + 1], HL * h.out_dim);
       if (cl < h.out_dim) {
+        const float bo = h.ob[k][cl];
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         ht_dot(acc, s.W + cl, h.out_dim + 1, &src[0][4 * rg], HL);
-        const float bo = h.ob[k][cl];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + 4 * rg + i;
@@ -441,6 +481,9 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsFwdArgs a) {
 __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, HtLds& s, float* da, int ld_da) {
   const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
   const int L = h.L;
+  HtW pw;   // kernel of the stage after the output layers: last hidden layer, or the action rows (d xa)
+  if (L > 1) ht_w_fetch(pw, h.w[L - 1], h.hid[L - 2] * h.hid[L - 1]);
+  else if (da) ht_w_fetch(pw, h.w0a, h.n_xa * h.H0);
   // ---- output layers -> g_{L-1}
   {
     const int HL = h.hid[L - 1];
@@ -481,10 +524,18 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
     float(*src)[HT_RB] = s.zT[l & 1];
     float(*dst)[HT_RB] = s.zT[(l - 1) & 1];
     const float* zp = l == 1 ? h.z0 : h.z[l - 1];
-    ht_stage_w(h.w[l], Hin, Hout, s);
+    ht_w_commit(pw, h.w[l], Hin, Hout, s.W);
+    if (l > 1) ht_w_fetch(pw, h.w[l - 1], h.hid[l - 2] * Hin);
+    else if (da) ht_w_fetch(pw, h.w0a, h.n_xa * h.H0);
     for (int c0 = 0; c0 < Hin; c0 += 64) {
       const int m = c0 + cl;
       if (m < Hin) {
+        float zm[4];   // ReLU mask operands: requested before the dot product
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * rg + i;
+          zm[i] = row < B ? zp[(long)row * Hin + m] : 0.f;
+        }
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         ht_dot(acc, s.W + m * (Hout + 1), 1, &src[0][4 * rg], Hout);
 #pragma unroll
@@ -492,7 +543,7 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
           const int row = row0 + 4 * rg + i;
           float v = 0.f;
           if (row < B) {
-            v = zp[(long)row * Hin + m] > 0.f ? acc[i] : 0.f;
+            v = zm[i] > 0.f ? acc[i] : 0.f;
             if (l == 1) h.g0[(long)row * h.ldg0 + m] = v;
             else h.g[l - 1][(long)row * Hin + m] = v;
           }
@@ -504,7 +555,7 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
   }
   // ---- d xa = g_0 . w0a^T
   if (da) {
-    ht_stage_w(h.w0a, h.n_xa, h.H0, s);
+    ht_w_commit(pw, h.w0a, h.n_xa, h.H0, s.W);
     if (cl < h.n_xa) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       ht_dot(acc, s.W + cl * (h.H0 + 1), 1, &s.zT[0][0][4 * rg], h.H0);
