@@ -4,7 +4,8 @@
 layers [64,64], VecNormalize on).
 
 One step = draw a minibatch from the HBM-resident replay (device Philox) + normalise + 3 CNN
-forwards + heads + losses + backward through both trainable CNNs + 3 Adam applies + Polyak update.
+forwards + heads + losses + backward through both trainable CNNs + 3 Adam applies + Polyak update
+(17 kernel launches replayed as one hipGraph).
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, data parallel,
 per-GPU batch fixed at 256 (weak scaling), one RCCL all-reduce of the flat fp32 gradient bucket
 per step; `value` counts batch-256 gradient computations per second over the whole job
@@ -174,6 +175,11 @@ def main():
                 "avg_launch_ms": round(d["avg_ms"], 5), "flops_per_launch": d["flops"],
                 "measured": "separate eager pass, hipEvents on the engine stream, same workload",
                 "step_kernel_ms": {k: round(total[k] / max(1, min(args.steps, 50)), 5) for k in sorted(total)}}
+        # whole update: algorithmic FLOPs of every GEMM-shaped launch of one step over the graph-replay step time
+        step_flops = sum(v["flops"] * v["launches"] for v in prof.values()) / max(1, min(args.steps, 50))
+        roof["step_flops"] = step_flops
+        roof["step_achieved"] = round(step_flops / (dt / args.steps) / 1e12, 3)
+        roof["step_frac"] = round(roof["step_achieved"] / PEAK_F32_TFLOPS, 4)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

@@ -10,6 +10,7 @@ Differences to stable-baselines, all opt-in: vectorised envs with ``num_envs > 1
 (stable-baselines 2 asserts a single env); ``ent_coef`` must be 'auto' / 'auto_<init>' and
 ``target_update_interval`` 1 (what the reference uses: zip JSON).
 """
+import os
 import time
 from collections import deque
 
@@ -37,7 +38,7 @@ class SAC:
                  train_freq=1, batch_size=64, tau=0.005, ent_coef="auto", target_update_interval=1,
                  gradient_steps=1, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
                  tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False,
-                 seed=None, n_cpu_tf_sess=None, device="cuda:0"):
+                 seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None):
         if isinstance(policy, str):
             if policy not in _POLICY_NAMES:
                 raise ValueError("unknown policy %r" % policy)
@@ -53,6 +54,12 @@ class SAC:
         self.verbose, self.tensorboard_log = verbose, tensorboard_log
         self.full_tensorboard_log, self.seed, self.n_cpu_tf_sess = full_tensorboard_log, seed, n_cpu_tf_sess
         self.device = device
+        # Opt-in pipelining (not stable-baselines semantics): the gradient update of step t is launched while
+        # the (subprocess) environments compute step t, i.e. it samples a replay that does not yet hold
+        # transition t.  Off by default: the default loop is SB's strict step -> store -> update order.
+        if overlap_env_step is None:
+            overlap_env_step = os.environ.get("GRL_OVERLAP_ENV_STEP", "0") == "1"
+        self.overlap_env_step = bool(overlap_env_step)
         self.num_timesteps = 0
         self.n_updates = 0
         self.env = None
@@ -208,7 +215,20 @@ class SAC:
                 if self.action_noise is not None:
                     action = np.clip(action + self.action_noise(), -1, 1)
                 unscaled_action = self._unscale(action)
-            new_obs, reward, done, info = self.env.step(unscaled_action.reshape((N,) + tuple(self.action_space.shape)))
+            def run_updates():
+                callback.on_rollout_end()
+                for _ in range(self.gradient_steps):
+                    if eng.replay_size() < self.batch_size or self.num_timesteps < self.learning_starts:
+                        break
+                    self.n_updates += 1
+                    self._sync_norm_stats()
+                    eng.train(1)
+                callback.on_rollout_start()
+
+            self.env.step_async(unscaled_action.reshape((N,) + tuple(self.action_space.shape)))
+            if self.overlap_env_step and (step + 1) % self.train_freq == 0:
+                run_updates()          # GPU works while the simulator workers step
+            new_obs, reward, done, info = self.env.step_wait()
             self.num_timesteps += N
             callback.update_locals(locals())
             if callback.on_step() is False:
@@ -233,16 +253,10 @@ class SAC:
             self.episode_reward += np.asarray(reward_, np.float64).reshape(N)
             step += 1
             if step % self.train_freq == 0:
-                callback.on_rollout_end()
-                for _ in range(self.gradient_steps):
-                    if eng.replay_size() < self.batch_size or self.num_timesteps < self.learning_starts:
-                        break
-                    self.n_updates += 1
-                    self._sync_norm_stats()
-                    eng.train(1)
+                if not self.overlap_env_step:
+                    run_updates()
                 if self.n_updates > 0 and (step // self.train_freq) % 50 == 0:
                     infos_values = eng.metrics()
-                callback.on_rollout_start()
             episode_rewards[-1] += float(np.asarray(reward_).reshape(N)[0])
             if done[0]:
                 if self.action_noise is not None:

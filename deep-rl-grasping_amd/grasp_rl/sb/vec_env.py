@@ -98,6 +98,144 @@ class DummyVecEnv(VecEnv):
         return [getattr(e, name)(*args, **kwargs) for e in self._targets(indices)]
 
 
+def _subproc_worker(remote, parent_remote, env_fn_pickled):
+    """Worker loop of SubprocVecEnv: owns ONE environment, answers commands over a pipe."""
+    parent_remote.close()
+    env = pickle.loads(env_fn_pickled)()
+    try:
+        while True:
+            cmd, data = remote.recv()
+            if cmd == "step":
+                obs, rew, done, info = env.step(data)
+                if done:
+                    info = dict(info)
+                    info["terminal_observation"] = obs
+                    obs = env.reset()
+                remote.send((obs, rew, done, info))
+            elif cmd == "reset":
+                remote.send(env.reset())
+            elif cmd == "seed":
+                remote.send(env.seed(data) if hasattr(env, "seed") else None)
+            elif cmd == "spaces":
+                remote.send((env.observation_space, env.action_space))
+            elif cmd == "get_attr":
+                remote.send(getattr(env, data))
+            elif cmd == "set_attr":
+                setattr(env, data[0], data[1])
+                remote.send(None)
+            elif cmd == "env_method":
+                remote.send(getattr(env, data[0])(*data[1], **data[2]))
+            elif cmd == "render":
+                remote.send(env.render(*data[0], **data[1]) if hasattr(env, "render") else None)
+            elif cmd == "close":
+                if hasattr(env, "close"):
+                    env.close()
+                remote.close()
+                break
+            else:
+                raise NotImplementedError(cmd)
+    except (EOFError, KeyboardInterrupt):
+        pass
+
+
+class SubprocVecEnv(VecEnv):
+    """One worker PROCESS per environment (PyBullet steps are CPU-bound and hold the GIL): the fan-out
+    of BASELINE configs 2 and 5 -- N simulators on N host cores feeding one engine.  Same protocol as
+    stable-baselines' SubprocVecEnv: ``step_async`` posts the actions, ``step_wait`` collects
+    ``(obs, rew, done, info)``; an env resets itself when its episode ends and reports the last
+    observation in ``info['terminal_observation']``.  ``start_method``: 'forkserver' / 'spawn' keep the
+    workers free of this process's HIP context ('fork' after HIP initialisation is unsafe)."""
+
+    def __init__(self, env_fns, start_method=None):
+        import multiprocessing as mp
+        if start_method is None:
+            start_method = "forkserver" if "forkserver" in mp.get_all_start_methods() else "spawn"
+        ctx = mp.get_context(start_method)
+        self.waiting = False
+        self.closed = False
+        self.remotes, self.work_remotes = zip(*[ctx.Pipe() for _ in env_fns])
+        self.processes = []
+        try:
+            import cloudpickle as _pk
+        except ImportError:      # plain pickle: env_fns must be importable callables
+            _pk = pickle
+        for work_remote, remote, fn in zip(self.work_remotes, self.remotes, env_fns):
+            proc = ctx.Process(target=_subproc_worker, args=(work_remote, remote, _pk.dumps(fn)), daemon=True)
+            proc.start()
+            self.processes.append(proc)
+            work_remote.close()
+        self.remotes[0].send(("spaces", None))
+        obs_space, act_space = self.remotes[0].recv()
+        super().__init__(len(env_fns), obs_space, act_space)
+        self.buf_infos = [{} for _ in range(self.num_envs)]
+
+    def step_async(self, actions):
+        for remote, action in zip(self.remotes, actions):
+            remote.send(("step", action))
+        self.waiting = True
+
+    def step_wait(self):
+        results = [remote.recv() for remote in self.remotes]
+        self.waiting = False
+        obs, rews, dones, infos = zip(*results)
+        self.buf_infos = list(infos)
+        return (np.stack(obs).astype(getattr(self.observation_space, "dtype", np.float32)),
+                np.asarray(rews, dtype=np.float32), np.asarray(dones, dtype=bool), list(infos))
+
+    def reset(self):
+        for remote in self.remotes:
+            remote.send(("reset", None))
+        obs = [remote.recv() for remote in self.remotes]
+        return np.stack(obs).astype(getattr(self.observation_space, "dtype", np.float32))
+
+    def seed(self, seed=None):
+        for i, remote in enumerate(self.remotes):
+            remote.send(("seed", None if seed is None else seed + i))
+        return [remote.recv() for remote in self.remotes]
+
+    def close(self):
+        if self.closed:
+            return
+        if self.waiting:
+            for remote in self.remotes:
+                remote.recv()
+        for remote in self.remotes:
+            remote.send(("close", None))
+        for proc in self.processes:
+            proc.join()
+        self.closed = True
+
+    def render(self, *a, **k):
+        self.remotes[0].send(("render", (a, k)))
+        return self.remotes[0].recv()
+
+    def _targets(self, indices):
+        if indices is None:
+            return list(self.remotes)
+        if isinstance(indices, int):
+            return [self.remotes[indices]]
+        return [self.remotes[i] for i in indices]
+
+    def get_attr(self, name, indices=None):
+        rs = self._targets(indices)
+        for r in rs:
+            r.send(("get_attr", name))
+        return [r.recv() for r in rs]
+
+    def set_attr(self, name, value, indices=None):
+        rs = self._targets(indices)
+        for r in rs:
+            r.send(("set_attr", (name, value)))
+        for r in rs:
+            r.recv()
+
+    def env_method(self, name, *args, indices=None, **kwargs):
+        rs = self._targets(indices)
+        for r in rs:
+            r.send(("env_method", (name, args, kwargs)))
+        return [r.recv() for r in rs]
+
+
 class VecEnvWrapper(VecEnv):
     def __init__(self, venv, observation_space=None, action_space=None):
         self.venv = venv

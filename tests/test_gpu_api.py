@@ -50,3 +50,23 @@ def test_dqn_and_bdq_reference_sequences_gpu(tmp_path):
                                            batch_size=16, buffer_size=128, num_actions_pad=33, learning_starts=20,
                                            target_network_update_freq=10, prioritized_replay=False),
                         lambda s: FakeGraspEnv(seed=s, vector_dim=100, act_dim=3), n_steps=60)
+
+
+def test_subproc_envs_overlap_gpu():
+    """Simulator worker processes step while the GPU runs the update (opt-in overlap_env_step)."""
+    import functools
+    import numpy as np
+    import stable_baselines as sb
+    from stable_baselines.common.vec_env import SubprocVecEnv, VecNormalize
+    venv = SubprocVecEnv([functools.partial(FakeGraspEnv, "depth", 7, s) for s in range(4)])
+    try:
+        env = VecNormalize(venv)
+        kwargs = {"layers": [64, 64], "cnn_extractor": host.create_augmented_nature_cnn(1)}
+        model = sb.SAC(sacCnn, env, policy_kwargs=kwargs, buffer_size=256, batch_size=32, learning_starts=16,
+                       overlap_env_step=True)
+        model.learn(total_timesteps=96)
+        assert model.num_timesteps == 96 and model.engine.replay_size() == 96 and model.n_updates > 0
+        a, _ = model.predict(env.reset(), deterministic=True)
+        assert a.shape == (4, 5) and np.all(np.isfinite(a))
+    finally:
+        venv.close()

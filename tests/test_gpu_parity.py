@@ -38,6 +38,20 @@ def test_update_matches_oracle(name):
     eng.close()
 
 
+@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_V2", "GRL_LANES"])
+def test_fallback_paths_match_oracle(monkeypatch, var):
+    """The per-layer GEMM heads, the scalar-gather igemm_kernel and the two-lane capture stay correct."""
+    monkeypatch.setenv(var, "1")
+    case = pu.make_case(n_steps=2, extractor="augmented", kind="depth", B=16, n_replay=48)
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(1, case["idx"][1:2], case["eps"][1:2])
+    pu.compare_params(eng, orc, case["spec"].lr, 2)
+    eng.close()
+
+
 def test_headline_config_b256():
     """BASELINE config 2: depth 64x64x2, batch 256, layers [64,64], A=5 -- three updates."""
     case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=600, n_steps=3)

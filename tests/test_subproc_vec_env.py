@@ -1,0 +1,49 @@
+"""SubprocVecEnv (BASELINE configs 2 / 5: N simulators on N host cores feeding one engine): same
+observations, rewards, dones and auto-reset behaviour as DummyVecEnv on identically seeded envs."""
+import functools
+
+import numpy as np
+
+from fake_env import FakeGraspEnv
+from stable_baselines.common.vec_env import DummyVecEnv, SubprocVecEnv, VecNormalize
+
+
+def _make(seed):
+    return FakeGraspEnv(seed=seed, vector_dim=12, act_dim=3, episode_len=5)
+
+
+def test_subproc_matches_dummy_and_supports_the_reference_calls():
+    fns = [functools.partial(_make, s) for s in range(3)]
+    ref = DummyVecEnv(fns)
+    sub = SubprocVecEnv(fns)
+    try:
+        assert sub.num_envs == 3 and sub.observation_space.shape == (12,)
+        o_ref, o_sub = ref.reset(), sub.reset()
+        assert np.array_equal(o_ref, o_sub)
+        rng = np.random.default_rng(0)
+        saw_done = False
+        for _ in range(12):
+            a = rng.uniform(-1, 1, (3, 3)).astype(np.float32)
+            r1, r2 = ref.step(a), sub.step(a)
+            for x, y in zip(r1[:3], r2[:3]):
+                assert np.array_equal(x, y)
+            for i1, i2 in zip(r1[3], r2[3]):
+                assert ("terminal_observation" in i1) == ("terminal_observation" in i2)
+                if "terminal_observation" in i1:
+                    saw_done = True
+                    assert np.array_equal(i1["terminal_observation"], i2["terminal_observation"])
+        assert saw_done
+        # attribute / method access used by sb_helper.py:42-45 and the callbacks
+        assert sub.get_attr("episode_len") == [5, 5, 5]
+        sub.set_attr("episode_len", 9, indices=1)
+        assert sub.get_attr("episode_len") == [5, 9, 5]
+        assert sub.env_method("is_simplified") == [False, False, False]
+        # VecNormalize wraps it like any VecEnv
+        vn = VecNormalize(sub, norm_obs=True, norm_reward=True, clip_obs=10.)
+        o = vn.reset()
+        assert o.shape == (3, 12) and np.all(np.isfinite(o))
+        o, r, d, info = vn.step(rng.uniform(-1, 1, (3, 3)).astype(np.float32))
+        assert o.shape == (3, 12) and r.shape == (3,) and len(info) == 3
+    finally:
+        sub.close()
+        ref.close()
