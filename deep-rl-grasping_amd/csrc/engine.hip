@@ -1007,7 +1007,7 @@ int grl_ctx::plan_sac() {
     fa.B = B; fa.A = A; fa.eps = eps_buf; fa.pi_a = pi_a; fa.logp = logp; fa.ent = ent;
     Op op; op.tag = "heads_fwd";
     op.run = [fa](hipStream_t s) {
-      hipLaunchKernelGGL(heads_fwd_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 5), dim3(256), 0, s, fa);
+      hipLaunchKernelGGL(heads_fwd_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 6), dim3(256), 0, s, fa);
     };
     ops_grads.push_back(op);
   } else {
@@ -1193,20 +1193,22 @@ int grl_ctx::plan_sac() {
       add_launch(ops_grads, "conv2_bwd", 1, pr);
     }
     // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
+    int wsplit[3] = {96, 16, 8};   // reduction splits of conv1..3 (GRL_WG_SPLIT=a,b,c overrides: tuning aid)
+    if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
     for (int n = 0; n < 2; ++n) {
       const float* xin = x_obs;
       {
-        IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, 96);
+        IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, wsplit[0]);
         p.c = wk.f32(p.slab_stride * p.split);
         add_wgrad(wgc[0], p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
       }
       {
-        IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, 16);
+        IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, wsplit[1]);
         p.c = wk.f32(p.slab_stride * p.split);
         add_wgrad(wgc[1], p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
       }
       {
-        IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, 8);
+        IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, wsplit[2]);
         p.c = wk.f32(p.slab_stride * p.split);
         add_wgrad(wgc[2], p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
       }

@@ -7,7 +7,8 @@
 // latency per layer; here one workgroup owns 16 batch rows and walks a whole chain of heads with the
 // activations kept transposed in LDS:
 //
-//   forward  chain 0: pi head -> squashed-Gaussian sample -> qf1(s, pi) -> qf2(s, pi)
+//   forward  chain 0: pi head -> squashed-Gaussian sample -> qf1(s, pi)   (chain 5: the same with qf2(s, pi);
+//            the pi head is cheap to recompute and the critical path loses a whole head)
 //            chains 1..4: vf, qf1(s, a), qf2(s, a), target vf
 //   backward chain 0: qf1(s, pi) backward -> d a_pi -> sample backward -> pi head backward
 //            chains 1..3: vf, qf1, qf2 (gradients w.r.t. every pre-activation; the layer-0 ones feed the
@@ -183,12 +184,11 @@ inline void heads_fwd_kernel(HeadsFwdArgs a) {
   if (threadIdx.x != 0) return;
   const int chain = blockIdx.y;
   for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row) {
-    if (chain == 0) {
+    if (chain == 0 || chain == 5) {   // both recompute the pi head; chain 0 owns its outputs
       ht_ref_fwd_head(a.h[0], row, nullptr);
       ht_sample_row(a.h[0].out[0] + (long)row * a.A, a.h[0].out[1] + (long)row * a.A, a.eps + (long)row * a.A, a.A,
                     a.pi_a + (long)row * a.A, a.logp + row, a.ent + row);
-      ht_ref_fwd_head(a.h[5], row, a.pi_a + (long)row * a.A);
-      ht_ref_fwd_head(a.h[6], row, a.pi_a + (long)row * a.A);
+      ht_ref_fwd_head(a.h[chain == 0 ? 5 : 6], row, a.pi_a + (long)row * a.A);
     } else {
       const HtHead& h = a.h[chain];
       ht_ref_fwd_head(h, row, h.n_xa ? h.xa + (long)row * h.ld_xa : nullptr);
@@ -361,20 +361,33 @@ __device__ __forceinline__ void ht_dot(float (&acc)[4], const float* w, int wstr
   }
 }
 
-// forward of one head for the 16 rows of this workgroup; xaT must hold the head's action part
-__device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, HtLds& s, bool keep_out) {
+// sum over the 64 lanes of a wave, fixed butterfly order (deterministic)
+__device__ __forceinline__ float ht_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// forward of one head for the 16 rows of this workgroup; xaT must hold the head's action part.
+// `store`: write activations / outputs to global (false for the duplicate pi head of chain 5).
+// A single 1-wide output layer (vf / qf heads) is folded into the last hidden stage: each lane holds
+// z[4 rows][its column], multiplies by ow[column] and the wave (= one row group) adds the 64 lanes.
+__device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, HtLds& s, bool keep_out, bool store = true) {
   const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
   const int HL = h.hid[h.L - 1];
+  const bool fuse_out = h.n_out == 1 && h.out_dim == 1;
+  float opart[4] = {0.f, 0.f, 0.f, 0.f};   // fused output layer: per-lane partial of sum_n z[r][n] * ow[n]
   HtW pw;
   // kernel of the first staged stage (hidden layer 1, or the first output layer)
   if (h.L > 1) ht_w_fetch(pw, h.w[1], h.hid[0] * h.hid[1]);
-  else ht_w_fetch(pw, h.ow[0], HL * h.out_dim);
+  else if (!fuse_out) ht_w_fetch(pw, h.ow[0], HL * h.out_dim);
   // ---- layer 0
   for (int c0 = 0; c0 < h.H0; c0 += 64) {
     const int n = c0 + cl;
     if (n < h.H0) {
       float acc[4];
       const float bn = h.b0[n];
+      const float own = (fuse_out && h.L == 1) ? h.ow[0][n] : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * rg + i;
@@ -391,7 +404,8 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
         const int row = row0 + 4 * rg + i;
         const float v = fmaxf(acc[i] + bn, 0.f);
         s.zT[0][n][4 * rg + i] = v;
-        if (row < B) h.z0[(long)row * h.H0 + n] = v;
+        if (row < B && store) h.z0[(long)row * h.H0 + n] = v;
+        opart[i] = fmaf(v, own, opart[i]);
       }
     }
   }
@@ -402,11 +416,12 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
     float(*dst)[HT_RB] = s.zT[l & 1];
     ht_w_commit(pw, h.w[l], Hin, Hout, s.W);
     if (l + 1 < h.L) ht_w_fetch(pw, h.w[l + 1], Hout * h.hid[l + 1]);
-    else ht_w_fetch(pw, h.ow[0], HL * h.out_dim);
+    else if (!fuse_out) ht_w_fetch(pw, h.ow[0], HL * h.out_dim);
     for (int c0 = 0; c0 < Hout; c0 += 64) {
       const int n = c0 + cl;
       if (n < Hout) {
         const float bn = h.b[l][n];   // requested before the dot product, consumed after it
+        const float own = (fuse_out && l + 1 == h.L) ? h.ow[0][n] : 0.f;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         ht_dot(acc, s.W + n, Hout + 1, &src[0][4 * rg], Hin);
 #pragma unroll
@@ -414,13 +429,22 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
           const int row = row0 + 4 * rg + i;
           const float v = fmaxf(acc[i] + bn, 0.f);
           dst[n][4 * rg + i] = v;
-          if (row < B) h.z[l][(long)row * Hout + n] = v;
+          if (row < B && store) h.z[l][(long)row * Hout + n] = v;
+          opart[i] = fmaf(v, own, opart[i]);
         }
       }
     }
   }
   // ---- output layers (out_dim <= 64)
-  {
+  if (fuse_out) {
+    const float ob = h.ob[0][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float q = ht_wave_sum(opart[i]) + ob;
+      const int row = row0 + 4 * rg + i;
+      if (cl == 0 && row < B && store) h.out[0][row] = q;
+    }
+  } else {
     float(*src)[HT_RB] = s.zT[(h.L - 1) & 1];
     for (int k = 0; k < h.n_out; ++k) {
       ht_w_commit(pw, h.ow[k], HL, h.out_dim, s.W);
@@ -434,7 +458,7 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
           const int row = row0 + 4 * rg + i;
           const float v = acc[i] + bo;
           if (keep_out) s.oT[k * h.out_dim + cl][4 * rg + i] = v;
-          if (row < B) h.out[k][(long)row * h.out_dim + cl] = v;
+          if (row < B && store) h.out[k][(long)row * h.out_dim + cl] = v;
         }
       }
     }
@@ -452,14 +476,16 @@ __device__ __forceinline__ void ht_load_xa(const HtHead& h, int row0, int B, HtL
 __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsFwdArgs a) {
   __shared__ HtLds s;
   const int row0 = blockIdx.x * HT_RB, chain = blockIdx.y, t = threadIdx.x;
-  if (chain != 0) {
+  if (chain >= 1 && chain <= 4) {
     const HtHead& h = a.h[chain];
     if (h.n_xa) ht_load_xa(h, row0, a.B, s);
     ht_fwd_head(h, row0, a.B, s, false);
     return;
   }
-  // chain 0: pi head -> sample -> qf1(s, pi), qf2(s, pi)
-  ht_fwd_head(a.h[0], row0, a.B, s, true);
+  // chains 0 and 5: pi head -> sample -> qf1(s, pi) resp. qf2(s, pi).  Both compute the (cheap) pi head;
+  // chain 0 owns its global outputs.
+  const bool own = chain == 0;
+  ht_fwd_head(a.h[0], row0, a.B, s, true, own);
   if (t < HT_RB) {
     const int row = row0 + t;
     float lp = 0.f, en = 0.f;
@@ -467,13 +493,13 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsFwdArgs a) {
       const float ep = row < a.B ? a.eps[(long)row * a.A + j] : 0.f;
       const float pj = ht_sample_elem(s.oT[j][t], s.oT[a.A + j][t], ep, lp, en);
       s.xaT[j][t] = pj;
-      if (row < a.B) a.pi_a[(long)row * a.A + j] = pj;
+      if (row < a.B && own) a.pi_a[(long)row * a.A + j] = pj;
     }
-    if (row < a.B) { a.logp[row] = lp; a.ent[row] = en; }
+    if (row < a.B && own) { a.logp[row] = lp; a.ent[row] = en; }
   }
   __syncthreads();
-  ht_fwd_head(a.h[5], row0, a.B, s, false);
-  ht_fwd_head(a.h[6], row0, a.B, s, false);
+  if (own) ht_fwd_head(a.h[5], row0, a.B, s, false);
+  else ht_fwd_head(a.h[6], row0, a.B, s, false);
 }
 
 // backward of one head for the 16 rows of this workgroup.  oT must hold the output gradients
@@ -489,11 +515,18 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
     const int HL = h.hid[L - 1];
     const float* zl = L == 1 ? h.z0 : h.z[L - 1];
     float* gl = L == 1 ? nullptr : h.g[L - 1];
-    for (int k = 0; k < h.n_out; ++k) ht_stage_w_at(h.ow[k], HL, h.out_dim, s.W + k * HL * (h.out_dim + 1));
+    const bool one = h.n_out == 1 && h.out_dim == 1;   // vf / qf heads: a rank-1 product, straight from global
+    if (!one)
+      for (int k = 0; k < h.n_out; ++k) ht_stage_w_at(h.ow[k], HL, h.out_dim, s.W + k * HL * (h.out_dim + 1));
     for (int c0 = 0; c0 < HL; c0 += 64) {
       const int n = c0 + cl;
       if (n < HL) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (one) {
+          const float w = h.ow[0][n];
+          const ht_f4 d = *(const ht_f4*)&s.oT[0][4 * rg];
+          acc[0] = fmaf(d.x, w, 0.f); acc[1] = fmaf(d.y, w, 0.f); acc[2] = fmaf(d.z, w, 0.f); acc[3] = fmaf(d.w, w, 0.f);
+        } else
         for (int k = 0; k < h.n_out; ++k) {
           const float* wp = s.W + k * HL * (h.out_dim + 1) + n * (h.out_dim + 1);
           for (int o = 0; o < h.out_dim; ++o) {
