@@ -27,6 +27,7 @@
 #include "igemm.h"
 #include "igemm2.h"
 #include "heads_kernels.h"
+#include "per_kernels.h"
 
 namespace grl {
 
@@ -780,6 +781,11 @@ struct grl_ctx {
   int plan_sac();
   int plan_q();        // DQN / BDQ (MLP towers, dueling, double-Q)
   // Q-learning state
+  PerArgs per;                      // prioritised replay (cfg.q_per): device arrays + kernel arguments
+  bool per_on = false;
+  int per_blocks = 0;
+  float* per_u = nullptr;
+  std::vector<Op> ops_per_rng, ops_per_u, ops_per_update;
   int qD = 0, qN = 0;
   float *q_td = nullptr, *q_prio = nullptr, *q_aout = nullptr;
   int64_t q_online_off = 0, q_online_n = 0;
@@ -934,12 +940,16 @@ int grl_ctx::plan_sac() {
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
     ga.act_out2 = act_p; ga.ld_act2 = Ap;
     ga.sc = sc; ga.seed = c.seed; ga.idx_w = idx_buf; ga.eps_w = eps_buf; ga.n_eps = A;
+#ifndef GRL_HOSTEMU
+    ga.vec4 = (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
+#endif
+    const int per_block = ga.vec4 ? 1024 : 256;
     for (int mode = 0; mode < 2; ++mode) {
       ga.use_rng = mode;
       Op op; op.tag = "gather_norm";
       op.bytes = 2.0 * B * ((double)img_elems * 8 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
-      op.run = [ga](hipStream_t s) {
-        hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
+      op.run = [ga, per_block](hipStream_t s) {
+        hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + per_block - 1) / per_block, ga.B, 2), dim3(256), 0, s, ga);
       };
       (mode ? ops_rng : ops_gather).push_back(op);
     }
@@ -1566,6 +1576,45 @@ int grl_ctx::plan_q() {
     st_out.push_back(dense_fwd(z, ldz, kz, nullptr, 0, 0, rows, P + W.vw[Lv], 1, P + W.vb[Lv], a.v, 1, ACT_NONE));
   };
 
+  // =============================================================== prioritised replay (per_kernels.h)
+  per_on = c.q_per != 0;
+  if (per_on) {
+    memset(&per, 0, sizeof(per));
+    per_blocks = (int)((cap + PER_BLK - 1) / PER_BLK);
+    per.p = rp.f32(cap);
+    per.bsum = (double*)rp.take((size_t)per_blocks * 8);
+    per.bmin = rp.f32(per_blocks);
+    per.st = (PerState*)rp.take(sizeof(PerState));
+    per_u = wk.f32(B);
+    per.sc = sc; per.seed = c.seed; per.B = B; per.alpha = c.q_per_alpha; per.eps = c.q_per_eps;
+    per.idx_out = idx_buf; per.w_out = eps_buf; per.prio_in = nullptr;   // set below (q_prio)
+    for (int mode = 0; mode < 2; ++mode) {
+      PerArgs pa = per;
+      pa.u = mode ? per_u : nullptr;
+      const int nb = per_blocks;
+      grl_ctx* self = this;
+      Op op; op.tag = "per_sample";
+      op.run = [self, pa, nb, mode](hipStream_t s) {
+        PerArgs q = pa;
+        q.prio_in = self->q_prio;
+        hipLaunchKernelGGL(per_blocksum_kernel, dim3(nb), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb);
+        if (!mode) hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, s, q.sc);
+      };
+      (mode ? ops_per_u : ops_per_rng).push_back(op);
+    }
+    {
+      grl_ctx* self = this;
+      Op op; op.tag = "per_update";
+      op.run = [self](hipStream_t s) {
+        PerArgs q = self->per;
+        q.prio_in = self->q_prio;
+        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(64), 0, s, q, (const int64_t*)self->idx_buf);
+      };
+      ops_per_update.push_back(op);
+    }
+  }
+
   // =============================================================== RNG (uniform indices; weights = 1)
   {
     Op op; op.tag = "rng";
@@ -1764,6 +1813,9 @@ int grl_ctx::plan_q() {
   dbg["adv_tgt"] = {net[2].adv, (int64_t)B * D * nb};
   dbg["v_tgt"] = {net[2].v, B};
   dbg["td"] = {q_td, (int64_t)B * D};
+  dbg["idx_raw"] = {(const float*)idx_buf, (int64_t)2 * B};     // int64 viewed as float pairs
+  dbg["weights"] = {eps_buf, B};
+  if (per_on) dbg["per_p"] = {per.p, cap};
   dbg["priority"] = {q_prio, B};
   dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
   dbg["grads"] = {grads, n_train};
@@ -1927,6 +1979,14 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
   s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
   hipError_t e = hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("scalar init: ") + hipGetErrorString(e)); }
+  if (h->per_on) {
+    hipMemset(h->per.p, 0, (size_t)cfg->replay_capacity * 4);
+    PerState ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.max_priority = 1.f; ps.p_min = 1.f; ps.beta = 1.f;
+    e = hipMemcpy(h->per.st, &ps, sizeof(ps), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("per init: ") + hipGetErrorString(e)); }
+  }
   *out = h;
   return GRL_OK;
 }
@@ -2016,6 +2076,9 @@ static int replay_add_dev(grl_handle h, const float* obs, const float* act, cons
   ia.rp_act = h->rp_act; ia.rp_rew = h->rp_rew; ia.rp_done = h->rp_done;
   const int elems = h->cnn ? h->img_elems : c.obs_dim;
   hipLaunchKernelGGL(ingest_kernel, dim3((elems + 255) / 256, n, 2), dim3(256), 0, h->stream, ia);
+  if (h->per_on)   // new transitions enter with max_priority ** alpha
+    hipLaunchKernelGGL(per_add_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->per, h->rp_pos, n,
+                       (int64_t)c.replay_capacity);
   h->rp_pos = (h->rp_pos + n) % c.replay_capacity;
   h->rp_size = std::min<int64_t>(c.replay_capacity, h->rp_size + n);
   HIPCHK(hipMemcpyAsync(&h->sc->replay_size, &h->rp_size, 8, hipMemcpyHostToDevice, h->stream));
@@ -2094,6 +2157,24 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
       if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
     } else {
       if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u) {
+  if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->per_on) return fail(GRL_ERR_STATE, "prioritised replay is not enabled (grl_config.q_per)");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  h->grad_scale = 1.f;
+  HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 4, hipMemcpyHostToDevice, h->stream));
+  for (int s = 0; s < n_steps; ++s) {
+    if (u) {
+      HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 4, hipMemcpyDeviceToDevice, h->stream));
+      if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
+    } else {
+      if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
     }
   }
   HIPCHK(hipGetLastError());

@@ -23,6 +23,7 @@ class GrlConfig(C.Structure):
         ("q_n_branch", C.c_int32), ("q_branch", C.c_int32 * GRL_MAX_LAYERS),
         ("q_n_value", C.c_int32), ("q_value", C.c_int32 * GRL_MAX_LAYERS),
         ("q_huber", C.c_int32), ("q_double", C.c_int32), ("q_grad_clip", C.c_float), ("q_trunk_scale", C.c_float),
+        ("q_per", C.c_int32), ("q_per_alpha", C.c_float), ("q_per_eps", C.c_float),
     ]
 
 
@@ -45,7 +46,7 @@ EXPORTS = [
     "grl_param_count", "grl_param_info", "grl_reset_optimizer", "grl_set_obs_stats", "grl_replay_add",
     "grl_replay_add_device", "grl_replay_size", "grl_train_step", "grl_compute_grads", "grl_apply_grads",
     "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
-    "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target",
+    "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
 ]
 
 
@@ -84,6 +85,7 @@ def load_library(path=None):
     lib.grl_compute_grads.argtypes = [vp, vp, vp]
     lib.grl_apply_grads.argtypes = [vp, C.c_float]
     lib.grl_q_update_target.argtypes = [vp]
+    lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_float, vp]
     lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]
     lib.grl_act.argtypes = [vp, f32p, i32, i32, f32p, f32p]
     lib.grl_encoder_load.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), i32]
@@ -138,7 +140,8 @@ def param_table(lib, handle):
 
 def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(64, 64), value_hidden=(64, 64),
                   batch_size=32, act_batch=1, replay_capacity=50000, normalize=False, gamma=0.99, lr=5e-4,
-                  double_q=True, grad_clip=10.0, clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, seed=0):
+                  double_q=True, grad_clip=10.0, clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, seed=0,
+                  prioritized=False, per_alpha=0.6, per_eps=1e-6):
     """DQN (algo='dqn': separate dueling towers) / BDQ (algo='bdq': shared trunk + branches)."""
     cfg = make_config("mlp", obs_dim=obs_dim, act_dim=n_branches, layers=(1,), batch_size=batch_size,
                       act_batch=act_batch, replay_capacity=replay_capacity, normalize=normalize, gamma=gamma, lr=lr,
@@ -156,4 +159,5 @@ def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(6
     cfg.q_double = 1 if double_q else 0
     cfg.q_grad_clip = grad_clip
     cfg.q_trunk_scale = 1.0 / (n_branches + 1) if (algo == "bdq" and len(common) > 0) else 1.0
+    cfg.q_per, cfg.q_per_alpha, cfg.q_per_eps = (1 if prioritized else 0), per_alpha, per_eps
     return cfg

@@ -287,6 +287,29 @@ class QEngine(SacEngine):
     def update_target(self):
         check(self.lib, self.lib.grl_q_update_target(self.h))
 
+    # ---- prioritised replay on the device (cfg.q_per; csrc/per_kernels.h)
+    def train_per(self, n_steps=1, beta=1.0, u=None):
+        """n_steps updates on minibatches drawn proportionally to priority**alpha (stratified), with
+        importance weights (N p)^-beta / max; priorities are refreshed on the device afterwards.
+        u: optional host array [n_steps, B] of uniforms in [0, 1) (parity tests); None = device RNG."""
+        pu, keep = None, None
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float32).reshape(n_steps, self.B)
+            keep = self.be.to_device(u)
+            pu = C.c_void_p(self.be.ptr(keep))
+        check(self.lib, self.lib.grl_train_step_per(self.h, n_steps, float(beta), pu))
+        self._keep = [keep]
+
+    def sampled_indices(self):
+        return self.fetch("idx_raw", (2 * self.B,)).view(np.int64).copy()
+
+    def importance_weights(self):
+        return self.fetch("weights", (self.B,))
+
+    def stored_priorities(self):
+        """priority**alpha of every slot of the ring (zeros where nothing is stored)"""
+        return self.fetch("per_p", (int(self.cfg.replay_capacity),))
+
     def td_errors(self):
         return self.fetch("td", (self.B, self.D))
 

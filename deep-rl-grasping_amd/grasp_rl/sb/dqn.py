@@ -142,11 +142,15 @@ class _QModel:
         lr = float(self.learning_rate(1.0)) if callable(self.learning_rate) else float(self.learning_rate)
         cfg = _capi.make_q_config(self.algo, obs_shape[0], D, bins, common, branch, value, batch_size=self.batch_size,
                                   act_batch=1, replay_capacity=self.buffer_size, normalize=vn is not None, gamma=self.gamma,
-                                  lr=lr, double_q=self.double_q, seed=0 if self.seed is None else int(self.seed), **kw)
+                                  lr=lr, double_q=self.double_q, seed=0 if self.seed is None else int(self.seed),
+                                  prioritized=bool(self.prioritized_replay), per_alpha=self.prioritized_replay_alpha,
+                                  per_eps=self.prioritized_replay_eps, **kw)
         self.engine = self._engine_factory(cfg, self.device)
         self.D, self.bins = D, bins
         self._init_weights()
-        self._tree = SumTree(self.buffer_size) if self.prioritized_replay else None
+        # prioritised replay lives on the device (csrc/per_kernels.h): sampling, importance weights and the
+        # priority write-back never leave HBM.  (SumTree above is the host restatement kept for its unit test.)
+        self._tree = None
         self._max_priority = 1.0
 
     def _init_weights(self):
@@ -245,8 +249,6 @@ class _QModel:
             new_obs_, rew_ = (vn.get_original_obs(), vn.get_original_reward()) if vn is not None else (new_obs, rew)
             eng.replay_add(np.asarray(obs_, np.float32), bins.astype(np.float32).reshape(1, -1),
                            np.asarray(rew_, np.float32), np.asarray(new_obs_, np.float32), np.asarray(done, np.float32))
-            if self._tree is not None:
-                self._tree.set(ring_pos, self._max_priority ** self.prioritized_replay_alpha)
             ring_pos = (ring_pos + 1) % self.buffer_size
             obs, obs_ = new_obs, new_obs_
             episode_rewards[-1] += float(np.asarray(rew_).reshape(-1)[0])
@@ -257,15 +259,14 @@ class _QModel:
             can_sample = eng.replay_size() >= self.batch_size
             if can_sample and self.num_timesteps > self.learning_starts and self.num_timesteps % self.train_freq == 0:
                 callback.on_rollout_end()
-                idx, w = self._sample(beta_schedule.value(self.num_timesteps))
                 if vn is not None:
                     eng.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))
-                eng.train(1, idx[None], w[None])
+                if self.prioritized_replay:
+                    eng.train_per(1, beta_schedule.value(self.num_timesteps))
+                else:
+                    idx, w = self._sample(beta_schedule.value(self.num_timesteps))
+                    eng.train(1, idx[None], w[None])
                 self.n_updates += 1
-                if self._tree is not None:
-                    pr = eng.priorities().astype(np.float64) + self.prioritized_replay_eps
-                    self._tree.set(idx, pr ** self.prioritized_replay_alpha)
-                    self._max_priority = max(self._max_priority, float(pr.max()))
                 callback.on_rollout_start()
             if can_sample and self.num_timesteps > self.learning_starts and \
                     self.num_timesteps % self.target_network_update_freq == 0:

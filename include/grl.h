@@ -87,6 +87,11 @@ typedef struct grl_config {
   int32_t q_double;       /* double-Q action selection                                          */
   float q_grad_clip;      /* per-variable clip_by_norm (10 in stable-baselines), 0 = off        */
   float q_trunk_scale;    /* gradient scale entering the shared trunk (BDQ: 1/(D+1))            */
+  /* prioritised replay on the device (`prioritized_replay: True`, gripper_grasp.yaml:102;
+     stable-baselines PrioritizedReplayBuffer semantics, csrc/per_kernels.h)                       */
+  int32_t q_per;          /* 1: keep priorities in the replay arena, enable grl_train_step_per  */
+  float q_per_alpha;      /* prioritized_replay_alpha (0.6)                                      */
+  float q_per_eps;        /* prioritized_replay_eps (1e-6)                                       */
 } grl_config;
 
 /* byte sizes of the four caller-provided device arenas */
@@ -146,6 +151,10 @@ int64_t grl_replay_size(grl_handle h);
    DQN / BDQ handles: `eps` carries the prioritised-replay importance weights [n_steps*batch]
    (NULL with idx == NULL: uniform sampling on the device, weights 1). */
 int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
+/* DQN / BDQ with q_per: n_steps updates on minibatches drawn proportionally to priority**alpha
+   (stratified), importance weights (N p)^-beta / max, then priorities <- (|td| + eps)**alpha.
+   u_or_null: DEVICE pointer to [n_steps*batch] uniforms in [0,1) (parity tests); NULL = device Philox. */
+int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u_or_null);
 /* DQN / BDQ: hard copy of the online network into the target network (target_network_update_freq) */
 int grl_q_update_target(grl_handle h);
 /* split form for data parallelism: grads -> (caller all-reduces the grads arena) -> apply */

@@ -99,3 +99,55 @@ def run_and_compare(case, backend=None, lib_path=None):
         assert np.array_equal(Pa[n], Pb[n]), n
     for e in (eng, eng2, eng3):
         e.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# prioritised replay on the device (csrc/per_kernels.h) against oracle/per.py, draw for draw
+def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps=4, seed=3):
+    """Fill, then alternate (sample with explicit uniforms -> update -> priorities written back).  The chosen
+    index must own the stratified mass (interval check against float64 prefix sums of the SAME float32
+    priorities), the importance weights and the stored priorities must match the oracle."""
+    from oracle.per import PerOracle
+    rng = np.random.default_rng(seed)
+    c = dict(CASES["dqn"])
+    c["B"] = B
+    case = make_q_case(n_replay=n_store, n_steps=n_steps, **c)
+    case["cfg"].replay_capacity = cap
+    case["cfg"].q_per, case["cfg"].q_per_alpha, case["cfg"].q_per_eps = 1, 0.6, 1e-6
+    eng = q_engine_setup(case, backend=backend, lib_path=lib_path)
+    orc = PerOracle(cap, 0.6, 1e-6)
+    orc.add(n_store)
+    p0 = eng.stored_priorities()
+    assert np.array_equal(p0[:n_store], orc.p[:n_store]) and not p0[n_store:].any()
+    for s in range(n_steps):
+        beta = 0.4 + 0.15 * s
+        u = rng.random(B).astype(np.float32)
+        eng.train_per(1, beta, u[None])
+        idx = eng.sampled_indices()
+        w = eng.importance_weights()
+        ref_idx, ref_w, mass, prefix = orc.sample(u, beta)
+        # the device block scan may round a boundary differently: accept any index whose interval holds the mass
+        tol = 1e-9 * prefix[-1]
+        assert np.all((prefix[idx] <= mass + tol) & (mass < prefix[idx + 1] + tol)), (idx, ref_idx)
+        assert np.mean(idx == ref_idx) > 0.9
+        same = idx == ref_idx
+        assert np.allclose(w[same], ref_w[same], rtol=2e-5, atol=1e-7), (w, ref_w)
+        assert w.max() <= 1.0 + 1e-6 and w.min() > 0
+        prio = eng.priorities()                        # sum_d |td_d| of the minibatch just trained on
+        orc.update(idx, prio)
+        p = eng.stored_priorities()
+        assert np.allclose(p[:n_store], orc.p[:n_store], rtol=2e-6, atol=0), np.abs(p[:n_store] - orc.p[:n_store]).max()
+    # new transitions enter with the maximal priority seen so far, ring wrap included
+    tr = case["tr"]
+    k = cap - n_store + 7
+    eng.replay_add(tr["obs"][:k], tr["act"][:k], tr["rew"][:k], tr["next_obs"][:k], tr["done"][:k])
+    orc.add(k)
+    p = eng.stored_priorities()
+    assert np.allclose(p, orc.p, rtol=2e-6, atol=0)
+    # device RNG path: runs, indices in range, deterministic stratification (one draw per stratum)
+    eng.train_per(2, 1.0)
+    idx = eng.sampled_indices()
+    assert idx.min() >= 0 and idx.max() < cap
+    tot = p.astype(np.float64).sum()
+    eng.close()
+    return tot

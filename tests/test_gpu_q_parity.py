@@ -26,3 +26,9 @@ def test_q_device_rng_mode_trains():
     assert not np.array_equal(p0["bdq/model/common_net/fully_connected/weights:0"],
                               p1["bdq/model/common_net/fully_connected/weights:0"])
     eng.close()
+
+
+def test_prioritised_replay_gpu():
+    """Block-scan sampler, importance weights and priority write-back on the MI355X against oracle/per.py."""
+    qu.per_check()
+    qu.per_check(cap=5000, n_store=5000, B=64, n_steps=3, seed=11)

@@ -29,3 +29,9 @@ def test_layout_matches_shipped_zip_names(hostemu_lib):
         for name, _, _, shape, _ in eng.table:
             assert tuple(shape) == tuple(ref[name]), name
         eng.close()
+
+
+def test_prioritised_replay_plan(hostemu_lib):
+    """Sampler / priority write-back / add semantics of the device PER against oracle/per.py (CPU, host emulation)."""
+    from hostemu_backend import NumpyHostBackend
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib)
