@@ -622,6 +622,7 @@ struct AdamArgs {
   int64_t n_train;
   const DevScalars* sc;
   float grad_scale, tau;
+  float eps;                   // 1e-8 (TF AdamOptimizer), 1e-7 (Keras Adam)
   int64_t src_ofs, n_polyak;   // source range [src_ofs, src_ofs+n_polyak) inside params
   float* target;               // target block
 };
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
     float m = a.m[i], v = a.v[i];
     m = m + (g - m) * omb1;
     v = v + (g * g - v) * omb2;
-    const float p = a.params[i] - (m * alpha) / (sqrtf(v) + 1e-8f);
+    const float p = a.params[i] - (m * alpha) / (sqrtf(v) + a.eps);
     a.m[i] = m;
     a.v[i] = v;
     a.params[i] = p;

@@ -28,6 +28,7 @@
 #include "igemm2.h"
 #include "heads_kernels.h"
 #include "per_kernels.h"
+#include "ae_kernels.h"
 
 namespace grl {
 
@@ -408,7 +409,9 @@ struct grl_ctx {
   // dX[b, S*i'+ph, S*j'+pw, cin] = sum_{jj,ll,co} dY[b, i'-jj, j'-ll, co] * W[ph+S*jj, pw+S*ll, cin, co]
   std::vector<ConvBwdClass> conv_bwd_tabs(const ConvGeom& g, int Bn) {
     std::vector<ConvBwdClass> out;
-    const int IHc = (g.H + g.S - 1) / g.S, IWc = (g.W + g.S - 1) / g.S;
+    // padded input coordinate ih' = ih + pad = S*i + ph; only the low padding shifts indices ('SAME' may pad
+    // more on the high side, which the validity masks cover)
+    const int IHc = (g.H + g.pad + g.S - 1) / g.S, IWc = (g.W + g.pad + g.S - 1) / g.S;
     const int TJ = (g.KH + g.S - 1) / g.S, TL = (g.KW + g.S - 1) / g.S;
     for (int ph = 0; ph < g.S; ++ph)
       for (int pw = 0; pw < g.S; ++pw) {
@@ -432,8 +435,8 @@ struct grl_ctx {
                     bits |= 1ull << (jj * TL + ll);
                 }
               vm[m] = bits;
-              const int ih = g.S * i + ph, iw = g.S * j + pw;
-              ct[m] = (ih < g.H && iw < g.W) ? ((b * g.H + ih) * g.W + iw) * g.C : -1;
+              const int ih = g.S * i + ph - g.pad, iw = g.S * j + pw - g.pad;
+              ct[m] = (ih >= 0 && iw >= 0 && ih < g.H && iw < g.W) ? ((b * g.H + ih) * g.W + iw) * g.C : -1;
             }
         for (int jj = 0; jj < TJ; ++jj)
           for (int ll = 0; ll < TL; ++ll)
@@ -559,6 +562,7 @@ struct grl_ctx {
     IgemmProb p = blank();
     p.M = g.K() + 1; p.N = g.Cout; p.K = t.M;
     p.p_base[0] = x; p.p_tab_i = t.tab_r; p.p_tab_r = t.tab_i; single_part(p);
+    if (t.vmask) { p.p_vmask_i = t.vmask; p.p_tap_r = t.tap; p.p_mask_swap = 1; }   // padded conv: skip out-of-image taps
     p.p_ones_i = g.K();
     p.q_base[0] = gy; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
     p.c = slab; p.ldc = g.Cout;
@@ -731,6 +735,7 @@ struct grl_ctx {
         case 1011: GRL_IGEMM(PM_AFFINE, QM_TABLE, true, false, 1); break;        // dense backward-data over several kernels
         case 1002: GRL_IGEMM(PM_AFFINE, QM_AFFINE, false, true, 1); break;       // dense weight gradient
         case 1102: GRL_IGEMM(PM_TABLE, QM_AFFINE, false, true, 1); break;        // conv weight gradient
+        case 1202: GRL_IGEMM(PM_TABLE_MASK, QM_AFFINE, false, true, 1); break;   //   ... of a padded conv
         default:
           fprintf(stderr, "grl: no igemm instantiation for launch '%s' (key %d)\n", tag.c_str(), key);
           abort();
@@ -780,6 +785,9 @@ struct grl_ctx {
   int plan();          // lays everything out in the arenas and builds the launch plans
   int plan_sac();
   int plan_q();        // DQN / BDQ (MLP towers, dueling, double-Q)
+  int plan_ae();       // depth auto-encoder training (encoders.py:40-50,70-136)
+  float* ae_x = nullptr;            // [B, 4096] minibatch of depth images (staged per step)
+  std::vector<Op> ops_ae;
   // Q-learning state
   PerArgs per;                      // prioritised replay (cfg.q_per): device arrays + kernel arguments
   bool per_on = false;
@@ -802,7 +810,11 @@ static ConvGeom cnn_geom(int l, int C_img) {
 }
 
 // --------------------------------------------------------------------------------------------------
-int grl_ctx::plan() { return cfg.algo == GRL_ALGO_SAC ? plan_sac() : plan_q(); }
+int grl_ctx::plan() {
+  if (cfg.algo == GRL_ALGO_SAC) return plan_sac();
+  if (cfg.algo == GRL_ALGO_AE) return plan_ae();
+  return plan_q();
+}
 
 int grl_ctx::plan_sac() {
   const grl_config& c = cfg;
@@ -1344,7 +1356,7 @@ int grl_ctx::plan_sac() {
     op.run = [self](hipStream_t s) {
       AdamArgs aa;
       aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
-      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = self->cfg.tau;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
       aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
       const int blocks = (int)std::min<int64_t>(2048, (self->n_train + 255) / 256);
       hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, s, aa);
@@ -1769,7 +1781,7 @@ int grl_ctx::plan_q() {
     op.run = [self](hipStream_t s) {
       AdamArgs aa;
       aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
-      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
       aa.src_ofs = 0; aa.n_polyak = 0; aa.target = self->params + self->tgt_off;
       const int blocks = (int)std::min<int64_t>(2048, (self->n_train + 255) / 256);
       hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, s, aa);
@@ -1818,6 +1830,212 @@ int grl_ctx::plan_q() {
   if (per_on) dbg["per_p"] = {per.p, cap};
   dbg["priority"] = {q_prio, B};
   dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
+  dbg["grads"] = {grads, n_train};
+  return GRL_OK;
+}
+
+
+// --------------------------------------------------------------------------------------------------
+// Depth auto-encoder training: encoders.py:90-124 network, :127 MSE, :130 Adam,
+// config/encoder.yaml (7/5/3 kernels, 32 filters, stride 2, encoding 100, lr 2e-4, batch 128).
+// Parameters are the 16 Keras tensors in model.h5 order; one step = forward, MSE, backward, Keras-Adam.
+int grl_ctx::plan_ae() {
+  const grl_config& c = cfg;
+  cnn = false;
+  B = c.batch_size; NA = std::max(1, c.act_batch); A = 1; L = 0;
+  img_elems = 4096; F = 100; Fc = 0; ldf = 100; C_img = 1; hw = 64;
+  const float LA = 0.1f;   // LeakyReLU alpha (encoders.py:87)
+  // ---------------- parameter layout (Keras creation order == HDF5 order of the shipped model.h5)
+  struct CL { const char* name; int kh, cin, cout; };
+  const CL enc[3] = {{"encoder/conv2d_1", 7, 1, 32}, {"encoder/conv2d_2", 5, 32, 32}, {"encoder/conv2d_3", 3, 32, 32}};
+  const CL dec[3] = {{"decoder/conv2d_4", 3, 32, 32}, {"decoder/conv2d_5", 5, 32, 32}, {"decoder/conv2d_6", 7, 32, 1}};
+  int64_t ew[3], eb[3], dw[3], db[3];
+  for (int l = 0; l < 3; ++l) {
+    ew[l] = add_var(std::string(enc[l].name) + "/kernel", {enc[l].kh, enc[l].kh, enc[l].cin, enc[l].cout}, true);
+    eb[l] = add_var(std::string(enc[l].name) + "/bias", {enc[l].cout}, true);
+  }
+  const int64_t edw = add_var("encoder/dense_1/kernel", {2048, 100}, true), edb = add_var("encoder/dense_1/bias", {100}, true);
+  const int64_t ddw = add_var("decoder/dense_2/kernel", {100, 2048}, true), ddb = add_var("decoder/dense_2/bias", {2048}, true);
+  for (int l = 0; l < 3; ++l) {
+    dw[l] = add_var(std::string(dec[l].name) + "/kernel", {dec[l].kh, dec[l].kh, dec[l].cin, dec[l].cout}, true);
+    db[l] = add_var(std::string(dec[l].name) + "/bias", {dec[l].cout}, true);
+  }
+  n_train = n_params; tgt_off = n_params; vf_off = 0; n_polyak = 0; ent_off = 0;
+  // ---------------- arenas
+  params = st.f32(n_params);
+  adam_m = st.f32(n_train);
+  adam_v = st.f32(n_train);
+  sc = (DevScalars*)st.take(sizeof(DevScalars));
+  s_mean = (double*)st.take(8); s_std = (double*)st.take(8); s_dmean = (double*)st.take(8); s_dstd = (double*)st.take(8);
+  s_ret = (double*)st.take(8);
+  grads = gr.f32(n_train);
+  rp_obs = rp_next = rp_dobs = rp_dnext = rp_act = rp_rew = rp_done = rp.f32(4);   // no replay on this path
+  stg_n = std::max(NA, 64);
+  stg_obs = stg_next = stg_act = stg_rew = stg_done = wk.f32(4);
+  idx_buf = (int64_t*)wk.take(8); eps_buf = wk.f32(4);
+  for (int n = 0; n < 3; ++n) feat[n] = wk.f32(4);
+  const float* P = params;
+  // activations [B, H, W, C] (NHWC) and their gradients
+  auto T = [&](int h, int ch) { return wk.f32((int64_t)B * h * h * ch); };
+  ae_x = T(64, 1);
+  float *e1 = T(32, 32), *e2 = T(16, 32), *e3 = T(8, 32), *z = wk.f32((int64_t)B * 100), *dh = T(8, 32);
+  float *u4 = T(16, 32), *d4 = T(16, 32), *u5 = T(32, 32), *d5 = T(32, 32), *u6 = T(64, 32), *out = T(64, 1);
+  float *g_out = T(64, 1), *g_u6 = T(64, 32), *g_d5 = T(32, 32), *g_u5 = T(32, 32), *g_d4 = T(16, 32), *g_u4 = T(16, 32);
+  float *g_dh = T(8, 32), *g_z = wk.f32((int64_t)B * 100), *g_e3 = T(8, 32), *g_e2 = T(16, 32), *g_e1 = T(32, 32);
+  const int NPART = 256;
+  float* partial = wk.f32(NPART);
+  // geometry: encoder convs 'SAME' stride 2 (TF asymmetric padding: low pad 2 / 1 / 0), decoder convs 'SAME' stride 1
+  const ConvGeom ge[3] = {{64, 64, 1, 7, 7, 2, 2, 32, 32, 32}, {32, 32, 32, 5, 5, 2, 1, 16, 16, 32}, {16, 16, 32, 3, 3, 2, 0, 8, 8, 32}};
+  const ConvGeom gd[3] = {{16, 16, 32, 3, 3, 1, 1, 16, 16, 32}, {32, 32, 32, 5, 5, 1, 2, 32, 32, 32}, {64, 64, 32, 7, 7, 1, 3, 64, 64, 1}};
+  ConvFwdTabs fte[3], ftd[3];
+  for (int l = 0; l < 3; ++l) { fte[l] = conv_fwd_tabs(ge[l], B); ftd[l] = conv_fwd_tabs(gd[l], B); }
+  auto elem = [&](const char* tag, std::function<void(hipStream_t)> f) {
+    Op op; op.tag = tag; op.run = std::move(f);
+    ops_ae.push_back(op);
+  };
+  auto up = [&](const float* h, float* u, int H) {
+    const int Bn = B;
+    elem("ae_upsample", [=](hipStream_t s) {
+      const long quads = (long)Bn * 2 * H * 2 * H * 8;
+      hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, h, u, Bn, H, H, 32);
+    });
+  };
+  auto up_bwd = [&](const float* gu, const float* h, float* gh, int H) {
+    const int Bn = B;
+    elem("ae_upsample_bwd", [=](hipStream_t s) {
+      const long n = (long)Bn * H * H * 32;
+      hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gu, h, gh, Bn, H, H, 32, LA);
+    });
+  };
+  // =============================================================== forward
+  {
+    const float* in[3] = {ae_x, e1, e2};
+    float* o[3] = {e1, e2, e3};
+    for (int l = 0; l < 3; ++l)
+      add_launch(ops_ae, "ae_enc_conv", 0, {conv_fwd(in[l], fte[l], ge[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA)});
+  }
+  {
+    IgemmProb p = dense_fwd(e3, 2048, 2048, nullptr, 0, 0, B, P + edw, 100, P + edb, z, 100, ACT_LEAKY);
+    p.act_alpha = LA;
+    add_launch(ops_ae, "ae_dense", 0, {p});
+    IgemmProb q = dense_fwd(z, 100, 100, nullptr, 0, 0, B, P + ddw, 2048, P + ddb, dh, 2048, ACT_LEAKY);
+    q.act_alpha = LA;
+    add_launch(ops_ae, "ae_dense", 0, {q});
+  }
+  up(dh, u4, 8);
+  add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u4, ftd[0], gd[0], P + dw[0], P + db[0], d4, ACT_LEAKY, LA)});
+  up(d4, u5, 16);
+  add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u5, ftd[1], gd[1], P + dw[1], P + db[1], d5, ACT_LEAKY, LA)});
+  up(d5, u6, 32);
+  add_launch(ops_ae, "ae_out_conv", 0, {conv_fwd(u6, ftd[2], gd[2], P + dw[2], P + db[2], out, ACT_NONE, 0.f)});
+  // =============================================================== loss
+  {
+    MseArgs ma{out, ae_x, g_out, partial, (long)B * 4096};
+    const float lr = c.lr;
+    DevScalars* scp = sc;
+    elem("ae_mse", [=](hipStream_t s) {
+      hipLaunchKernelGGL(mse_kernel, dim3(NPART), dim3(256), 0, s, ma);
+      hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, NPART, ma.n_total, lr, scp);
+    });
+  }
+  // =============================================================== backward
+  std::vector<IgemmProb> wgc, wgd;
+  auto cw = [&](const float* x, const ConvFwdTabs& t, const ConvGeom& g, const float* gy, int64_t w_off, int64_t b_off, int split) {
+    IgemmProb p = conv_wgrad(x, t, g, gy, nullptr, split);
+    p.c = wk.f32(p.slab_stride * p.split);
+    add_wgrad(wgc, p, w_off, 0, g.K(), b_off);
+  };
+  auto cb = [&](const char* tag, const float* gy, const ConvGeom& g, const float* w, float* dx, const float* mask) {
+    std::vector<IgemmProb> pr;
+    for (auto& cl : conv_bwd_tabs(g, B)) {
+      IgemmProb p = conv_bwd(gy, cl, g, w, dx, mask);
+      p.act_alpha = LA;                                  // LeakyReLU gradient where a mask is given
+      pr.push_back(p);
+    }
+    add_launch(ops_ae, tag, 1, pr);
+  };
+  // output conv (7x7, 32 -> 1)
+  cw(u6, ftd[2], gd[2], g_out, dw[2], db[2], 64);
+  cb("ae_out_conv_bwd", g_out, gd[2], P + dw[2], g_u6, nullptr);
+  up_bwd(g_u6, d5, g_d5, 32);
+  cw(u5, ftd[1], gd[1], g_d5, dw[1], db[1], 32);
+  cb("ae_dec_conv_bwd", g_d5, gd[1], P + dw[1], g_u5, nullptr);
+  up_bwd(g_u5, d4, g_d4, 16);
+  cw(u4, ftd[0], gd[0], g_d4, dw[0], db[0], 8);
+  cb("ae_dec_conv_bwd", g_d4, gd[0], P + dw[0], g_u4, nullptr);
+  up_bwd(g_u4, dh, g_dh, 8);
+  {
+    IgemmProb p = dense_wgrad(z, 100, 100, true, g_dh, 2048, 2048, B, nullptr, 1);
+    p.c = wk.f32(p.slab_stride * p.split);
+    add_wgrad(wgd, p, ddw, 0, 100, ddb);
+    IgemmProb b = dense_bwd({{g_dh, 2048, 2048, P + ddw}}, B, 0, 100, g_z, 100, z);
+    b.act_alpha = LA;
+    add_launch(ops_ae, "ae_dense_bwd", 1, {b});
+    IgemmProb p2 = dense_wgrad(e3, 2048, 2048, true, g_z, 100, 100, B, nullptr, 1);
+    p2.c = wk.f32(p2.slab_stride * p2.split);
+    add_wgrad(wgd, p2, edw, 0, 2048, edb);
+    IgemmProb b2 = dense_bwd({{g_z, 100, 100, P + edw}}, B, 0, 2048, g_e3, 2048, e3);
+    b2.act_alpha = LA;
+    add_launch(ops_ae, "ae_dense_bwd", 1, {b2});
+  }
+  cw(e2, fte[2], ge[2], g_e3, ew[2], eb[2], 4);
+  cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2);
+  cw(e1, fte[1], ge[1], g_e2, ew[1], eb[1], 16);
+  cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1);
+  cw(ae_x, fte[0], ge[0], g_e1, ew[0], eb[0], 64);
+  {
+    // uniform launches for the vectorised kernel; whatever it cannot take goes to igemm_kernel
+    std::vector<IgemmProb> ok_c, rest;
+    for (auto& p : wgc) (v2_prob_ok(p, 2) && (p.K % 4) == 0 ? ok_c : rest).push_back(p);
+    add_launch(ops_ae, "ae_wgrad_conv", 2, ok_c);
+    add_launch(ops_ae, "ae_wgrad_small", 2, rest);
+    add_launch(ops_ae, "ae_wgrad_dense", 2, wgd);
+  }
+  {
+    d_reduces = upload_vec(wk, reduces);
+    std::vector<int2> rt;
+    for (size_t k = 0; k < reduces.size(); ++k)
+      for (int st0 = 0; st0 < reduces[k].n; st0 += 256) rt.push_back(make_int2((int)k, st0));
+    int2* d_rt = upload_vec(wk, rt);
+    const int ntiles = (int)rt.size();
+    ReduceDesc* dr = d_reduces;
+    LossArgs none;
+    memset(&none, 0, sizeof(none));
+    elem("reduce_slabs", [=](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0);
+    });
+  }
+  {
+    grl_ctx* self = this;
+    elem("adam", [self](hipStream_t s) {
+      AdamArgs aa;
+      aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f; aa.tau = 0.f; aa.eps = 1e-7f;   // Keras epsilon
+      aa.src_ofs = 0; aa.n_polyak = 0; aa.target = self->params;
+      const int blocks = (int)std::min<int64_t>(2048, (self->n_train + 255) / 256);
+      hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, s, aa);
+    });
+  }
+  // =============================================================== encode path (batch NA) on the trained weights
+  {
+    ex_in = wk.f32((int64_t)NA * 4096);
+    ec1 = wk.f32((int64_t)NA * 32 * 32 * 32); ec2 = wk.f32((int64_t)NA * 16 * 16 * 32);
+    ec3 = wk.f32((int64_t)NA * 8 * 8 * 32); eout = wk.f32((int64_t)NA * 100);
+    float* io[4] = {ex_in, ec1, ec2, ec3};
+    for (int l = 0; l < 3; ++l) {
+      ConvFwdTabs t = conv_fwd_tabs(ge[l], NA);
+      add_launch(ops_enc, "enc_conv", 0, {conv_fwd(io[l], t, ge[l], P + ew[l], P + eb[l], io[l + 1], ACT_LEAKY, LA)});
+    }
+    IgemmProb p = dense_fwd(ec3, 2048, 2048, nullptr, 0, 0, NA, P + edw, 100, P + edb, eout, 100, ACT_LEAKY);
+    p.act_alpha = LA;
+    add_launch(ops_enc, "enc_dense", 0, {p});
+    for (int k = 0; k < 8; ++k) enc_w[k] = nullptr;
+    enc_loaded = true;
+  }
+  dbg["out"] = {out, (int64_t)B * 4096};
+  dbg["z"] = {z, (int64_t)B * 100};
+  dbg["e3"] = {e3, (int64_t)B * 2048};
+  dbg["d5"] = {d5, (int64_t)B * 32 * 32 * 32};
   dbg["grads"] = {grads, n_train};
   return GRL_OK;
 }
@@ -1902,6 +2120,11 @@ int grl_ctx::capture(std::vector<std::vector<Op>*> seq, hipGraphExec_t* out) {
 // ==================================================================================================
 static int check_cfg(const grl_config* c) {
   if (!c) return fail(GRL_ERR_INVALID, "null config");
+  if (c->algo == GRL_ALGO_AE) {
+    if (c->batch_size < 1 || c->batch_size > 4096) return fail(GRL_ERR_INVALID, "batch_size out of range");
+    if (c->replay_capacity < 1) return fail(GRL_ERR_INVALID, "replay_capacity must be >= 1");
+    return GRL_OK;
+  }
   if (c->extractor < 0 || c->extractor > 2) return fail(GRL_ERR_INVALID, "extractor must be 0..2");
   if (c->n_layers < 1 || c->n_layers > GRL_MAX_LAYERS) return fail(GRL_ERR_INVALID, "n_layers out of range");
   for (int l = 0; l < c->n_layers; ++l)
@@ -1909,7 +2132,7 @@ static int check_cfg(const grl_config* c) {
   if (c->batch_size < 1 || c->batch_size > 65536) return fail(GRL_ERR_INVALID, "batch_size out of range");
   if (c->act_dim < 1 || c->act_dim > 64) return fail(GRL_ERR_INVALID, "act_dim out of range");
   if (c->replay_capacity < 1) return fail(GRL_ERR_INVALID, "replay_capacity must be >= 1");
-  if (c->algo < 0 || c->algo > 2) return fail(GRL_ERR_INVALID, "algo must be 0..2");
+  if (c->algo < 0 || c->algo > 3) return fail(GRL_ERR_INVALID, "algo must be 0..3");
   if (c->algo != GRL_ALGO_SAC) {
     if (c->extractor != GRL_EXTRACTOR_MLP) return fail(GRL_ERR_INVALID, "DQN/BDQ run on vector observations (MLP extractor)");
     if (c->q_branches < 1 || c->q_branches > 16 || c->q_branches != c->act_dim)
@@ -2148,6 +2371,7 @@ int grl_apply_grads(grl_handle h, float grad_scale) {
 
 int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps) {
   if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (h->cfg.algo == GRL_ALGO_AE) return fail(GRL_ERR_STATE, "auto-encoder handles train with grl_ae_train_step");
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
@@ -2176,6 +2400,18 @@ int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u) {
     } else {
       if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
     }
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_ae_train_step(grl_handle h, const float* imgs, int n_steps) {
+  if (!h || !imgs || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (h->cfg.algo != GRL_ALGO_AE) return fail(GRL_ERR_STATE, "not an auto-encoder handle (grl_config.algo)");
+  const size_t per = (size_t)h->B * 4096;
+  for (int s = 0; s < n_steps; ++s) {
+    HIPCHK(hipMemcpyAsync(h->ae_x, imgs + per * s, per * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (int e = h->run_seq("ae_step", {&h->ops_ae})) return e;
   }
   HIPCHK(hipGetLastError());
   return GRL_OK;
@@ -2227,7 +2463,7 @@ int grl_q_update_target(grl_handle h) {
 
 int grl_encoder_load(grl_handle h, const float* const* w, const int64_t* numels, int n_arrays) {
   if (!h || !w || !numels || n_arrays != 8) return fail(GRL_ERR_INVALID, "expected 8 weight arrays");
-  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "the auto-encoder path is attached to SAC handles");
+  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "grl_encoder_load is for SAC handles (auto-encoder handles encode with their own parameters)");
   const int64_t wn[8] = {7 * 7 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 32, 32, 2048 * 100, 100};
   for (int k = 0; k < 8; ++k)
     if (numels[k] != wn[k]) return fail(GRL_ERR_INVALID, "encoder weight " + std::to_string(k) + " has the wrong size");

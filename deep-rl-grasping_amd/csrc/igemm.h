@@ -42,6 +42,7 @@ struct IgemmProb {
   const uint64_t* p_vmask_i;  // optional validity: bit p_tap_r[r] of p_vmask_i[i] (padded convs,
   const uint8_t* p_tap_r;     //   transposed-conv gathers); invalid taps read as 0
   int32_t p_ones_i;       // row whose P value is the constant 1 (bias-gradient row), -1 = none
+  int32_t p_mask_swap;    // 1: validity is bit p_tap_r[i] of p_vmask_i[r] (weight gradients of padded convs)
   // ---- Q operand: Q(r, j) = q_base[part(r)][ rowterm(r) + j * q_ld_j[part] ]
   const float* q_base[3];
   int32_t q_ld_r[3];
@@ -53,7 +54,7 @@ struct IgemmProb {
   const int32_t* c_tab_i; // optional output row offsets; negative = row not stored
   int64_t slab_stride;    // floats between split slabs
   const float* bias;      // + bias[j]
-  const float* relu_mask; // value kept only where relu_mask[same offset as c] > 0
+  const float* relu_mask; // value kept where relu_mask[same offset as c] > 0, scaled by act_alpha elsewhere (0: ReLU)
   int32_t act;
   float act_alpha;
   int32_t accumulate;     // += existing c
@@ -105,7 +106,8 @@ void igemm_kernel(const IgemmProb* probs, const int4* tiles) {
         const int rstart = part == 0 ? 0 : (part == 1 ? pb.p_k0 : pb.p_k1);
         float pv = 0.f;
         bool ok = true;
-        if (pb.p_vmask_i) ok = (pb.p_vmask_i[i] >> pb.p_tap_r[r]) & 1ull;
+        if (pb.p_vmask_i && i != pb.p_ones_i)
+          ok = pb.p_mask_swap ? ((pb.p_vmask_i[r] >> pb.p_tap_r[i]) & 1ull) : ((pb.p_vmask_i[i] >> pb.p_tap_r[r]) & 1ull);
         if (i == pb.p_ones_i) pv = 1.f;
         else if (ok) {
           const long rowterm = pb.p_tab_i ? pb.p_tab_i[i] : (long)i * pb.p_ld_i[part];
@@ -125,7 +127,7 @@ void igemm_kernel(const IgemmProb* probs, const int4* tiles) {
       if (pb.accumulate) v += cbase[off];
       if (pb.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (pb.act == ACT_LEAKY) v = v > 0.f ? v : pb.act_alpha * v;
-      if (pb.relu_mask) v = pb.relu_mask[off] > 0.f ? v : 0.f;
+      if (pb.relu_mask) v = pb.relu_mask[off] > 0.f ? v : pb.act_alpha * v;   // ReLU (alpha 0) / LeakyReLU gradient
       cbase[off] = v;
     }
 }
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
   constexpr int PROWS = P_CONTIG_R ? 8 : 1;
 
   // row terms of the rows this thread stages (fixed for the whole reduction)
+  const int p_tap_i = (PM == PM_TABLE_MASK && !P_CONTIG_R) ? (int)pTap[min(i0 + p_il, M - 1)] : 0;
   int p_row[PROWS];
   uint64_t p_vm[PROWS];
   bool p_iok[PROWS];
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
     p_iok[e] = (i < M) && (i != ones_i);
     const int ic = i < M ? i : i0;
     p_row[e] = PM != PM_AFFINE ? pTi[ic] : i;
-    p_vm[e] = PM == PM_TABLE_MASK ? pVm[ic] : ~0ull;
+    p_vm[e] = (PM == PM_TABLE_MASK && P_CONTIG_R) ? pVm[ic] : ~0ull;
   }
 
   typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
           const int ldr = part == 0 ? pLr0 : (part == 1 ? pLr1 : pLr2);
           const int rstart = part == 0 ? 0 : (part == 1 ? pk0 : pk1);
           colterm[e] = PM != PM_AFFINE ? pcol_nx[P_CONTIG_R ? 0 : e] : (rc - rstart) * ldr;
-          if (PM == PM_TABLE_MASK) rok[e] = rok[e] && ((p_vm[0] >> pTap[rc]) & 1ull);
+          // P along i is only masked for weight gradients of padded convs: vmask by r, tap by i (p_mask_swap)
+          if (PM == PM_TABLE_MASK) rok[e] = rok[e] && ((pVm[rc] >> p_tap_i) & 1ull);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
       if (accumulate) v += cbase[off];
       if (act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-      if (rmask) v = rmask[off] > 0.f ? v : 0.f;
+      if (rmask) v = rmask[off] > 0.f ? v : alpha * v;
       cbase[off] = v;
     }
   }

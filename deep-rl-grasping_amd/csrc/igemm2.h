@@ -64,7 +64,8 @@ void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
       for (int r = r_begin; r < r_end; ++r) {
         float pv = 0.f;
         bool ok = true;
-        if (pb.p_vmask_i && i != pb.p_ones_i) ok = (pb.p_vmask_i[i] >> pb.p_tap_r[r]) & 1ull;
+        if (pb.p_vmask_i && i != pb.p_ones_i)
+          ok = pb.p_mask_swap ? ((pb.p_vmask_i[r] >> pb.p_tap_r[i]) & 1ull) : ((pb.p_vmask_i[i] >> pb.p_tap_r[r]) & 1ull);
         if (i == pb.p_ones_i) pv = 1.f;
         else if (ok) {
           const long rowterm = pb.p_tab_i ? pb.p_tab_i[i] : (long)i * pb.p_ld_i[0];
@@ -83,7 +84,7 @@ void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
       if (pb.accumulate) v += cbase[off];
       if (pb.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (pb.act == ACT_LEAKY) v = v > 0.f ? v : pb.act_alpha * v;
-      if (pb.relu_mask) v = pb.relu_mask[off] > 0.f ? v : 0.f;
+      if (pb.relu_mask) v = pb.relu_mask[off] > 0.f ? v : pb.act_alpha * v;
       cbase[off] = v;
     }
   };
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     if (accumulate) v += cbase[off];
     if (act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-    if (rmask) v = rmask[off] > 0.f ? v : 0.f;
+    if (rmask) v = rmask[off] > 0.f ? v : alpha * v;
     cbase[off] = v;
   };
 
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       float v = val[x] * oscale + bj + prev[x];
       if (act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-      v = mk[x] > 0.f ? v : 0.f;
+      v = mk[x] > 0.f ? v : alpha * v;
       if (ok[x]) cbase[off[x]] = v;
     }
   };
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
         v.x = v.x > 0.f ? v.x : alpha * v.x; v.y = v.y > 0.f ? v.y : alpha * v.y;
         v.z = v.z > 0.f ? v.z : alpha * v.z; v.w = v.w > 0.f ? v.w : alpha * v.w;
       }
-      v.x = mk[e].x > 0.f ? v.x : 0.f; v.y = mk[e].y > 0.f ? v.y : 0.f;
-      v.z = mk[e].z > 0.f ? v.z : 0.f; v.w = mk[e].w > 0.f ? v.w : 0.f;
+      v.x = mk[e].x > 0.f ? v.x : alpha * v.x; v.y = mk[e].y > 0.f ? v.y : alpha * v.y;
+      v.z = mk[e].z > 0.f ? v.z : alpha * v.z; v.w = mk[e].w > 0.f ? v.w : alpha * v.w;
       if (ok[e]) *(GRL_GLOBAL f32x4*)(cbase + off[e]) = v;
     }
   };

@@ -47,6 +47,7 @@ EXPORTS = [
     "grl_replay_add_device", "grl_replay_size", "grl_train_step", "grl_compute_grads", "grl_apply_grads",
     "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
+    "grl_ae_train_step",
 ]
 
 
@@ -86,6 +87,7 @@ def load_library(path=None):
     lib.grl_apply_grads.argtypes = [vp, C.c_float]
     lib.grl_q_update_target.argtypes = [vp]
     lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_float, vp]
+    lib.grl_ae_train_step.argtypes = [vp, vp, C.c_int]
     lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]
     lib.grl_act.argtypes = [vp, f32p, i32, i32, f32p, f32p]
     lib.grl_encoder_load.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), i32]
@@ -136,6 +138,14 @@ def param_table(lib, handle):
         out.append((name.value.decode(), off.value, numel.value, tuple(shape[k] for k in range(ndim.value)),
                     bool(tr.value)))
     return out
+
+
+def make_ae_config(batch_size=128, lr=2e-4, act_batch=16):
+    """Depth auto-encoder training handle (config/encoder.yaml: batch 128, lr 2e-4)."""
+    cfg = make_config("mlp", obs_dim=4096, act_dim=1, layers=(1,), batch_size=batch_size, act_batch=act_batch,
+                      replay_capacity=1, normalize=False, lr=lr)
+    cfg.algo = 3
+    return cfg
 
 
 def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(64, 64), value_hidden=(64, 64),

@@ -1,0 +1,191 @@
+"""Depth auto-encoder on the HIP engine: the call surface of
+/root/reference/manipulation_main/gripperEnv/encoders.py (`SimpleAutoEncoder(config)`, `.train(inputs,
+targets, batch_size, epochs, model_dir)` :40-50, `.test` :52-53, `.predict` :55-57, `.encode` :59-61,
+`.load_weights(model_dir)` :26-30, `.encoding_shape` :63-65) for the network of :70-136 and
+config/encoder.yaml.  Training (forward, MSE, backward, Keras-Adam) runs in libgrl.so (GRL_ALGO_AE);
+this file owns the epoch loop Keras' `Model.fit` provides in the reference: shuffling, the 10 %
+validation split, CSV history, best-weights checkpoint and EarlyStopping(patience=25).
+
+Weight files: the reference stores Keras HDF5 (`model.h5`); without h5py the engine reads / writes the
+same 16 tensors as `model.npz` (keys = Keras weight names).  `load_weights` accepts either when a
+reader for `.h5` is supplied (`h5_reader`, e.g. tests' minimal HDF5 reader).
+"""
+import csv
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import check
+from .engine import SacEngine
+
+PARAM_NAMES = ["encoder/conv2d_1/kernel", "encoder/conv2d_1/bias", "encoder/conv2d_2/kernel", "encoder/conv2d_2/bias",
+               "encoder/conv2d_3/kernel", "encoder/conv2d_3/bias", "encoder/dense_1/kernel", "encoder/dense_1/bias",
+               "decoder/dense_2/kernel", "decoder/dense_2/bias", "decoder/conv2d_4/kernel", "decoder/conv2d_4/bias",
+               "decoder/conv2d_5/kernel", "decoder/conv2d_5/bias", "decoder/conv2d_6/kernel", "decoder/conv2d_6/bias"]
+
+
+def glorot_uniform_params(seed=0):
+    """Keras defaults (encoders.py builds every layer with them): glorot_uniform kernels, zero biases."""
+    rng = np.random.default_rng(seed)
+    shapes = [(7, 7, 1, 32), (32,), (5, 5, 32, 32), (32,), (3, 3, 32, 32), (32,), (2048, 100), (100,),
+              (100, 2048), (2048,), (3, 3, 32, 32), (32,), (5, 5, 32, 32), (32,), (7, 7, 32, 1), (1,)]
+    P = {}
+    for name, shp in zip(PARAM_NAMES, shapes):
+        if name.endswith("bias"):
+            P[name] = np.zeros(shp, np.float32)
+        else:
+            rf = int(np.prod(shp[:-2])) if len(shp) == 4 else 1
+            lim = np.sqrt(6.0 / (shp[-2] * rf + shp[-1] * rf))
+            P[name] = rng.uniform(-lim, lim, shp).astype(np.float32)
+    return P
+
+
+class AeEngine(SacEngine):
+    """Handle of a GRL_ALGO_AE engine: parameters = the 16 Keras tensors, one call = n minibatch updates."""
+
+    def __init__(self, batch_size=128, lr=2e-4, act_batch=16, backend=None, lib_path=None, device="cuda:0"):
+        super().__init__(_capi.make_ae_config(batch_size, lr, act_batch), backend=backend, lib_path=lib_path, device=device)
+
+    def train_batches(self, imgs):
+        """imgs [n_steps*B, 64, 64, 1] float32 (host): n_steps updates; returns the loss of the last one."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32).reshape(-1, 4096)
+        if imgs.shape[0] % self.B:
+            raise _capi.GrlError("number of images must be a multiple of the batch size %d" % self.B)
+        d = self.be.to_device(imgs)
+        check(self.lib, self.lib.grl_ae_train_step(self.h, C.c_void_p(self.be.ptr(d)), imgs.shape[0] // self.B))
+        self._keep = [d]
+        return self.metrics()["policy_loss"]
+
+    def reconstruction(self):
+        """Decoder output of the last training minibatch [B, 64, 64, 1]."""
+        return self.fetch("out", (self.B, 64, 64, 1))
+
+
+class SimpleAutoEncoder:
+    def __init__(self, config, backend=None, lib_path=None, device="cuda:0", seed=0):
+        net = config.get("network", [])
+        want = [(32, 7, 2), (32, 5, 2), (32, 3, 2)]
+        got = [(l["filters"], l["kernel_size"], l["strides"]) for l in net]
+        if got != want or config.get("encoding_dim", 100) != 100 or config.get("alpha", 0.1) != 0.1:
+            raise NotImplementedError("the HIP engine implements the reference's shipped network (config/encoder.yaml)")
+        self.config = config
+        self._mk = lambda bs: AeEngine(bs, float(config.get("learning_rate", 2e-4)), backend=backend, lib_path=lib_path,
+                                       device=device)
+        self.engine = None
+        self._params = glorot_uniform_params(seed)
+        self._bs = None
+
+    # ------------------------------------------------------------------ engine / weights
+    def _engine(self, batch_size):
+        if self.engine is None or self._bs != batch_size:
+            if self.engine is not None:
+                self._params = self.engine.get_parameters()
+                self.engine.close()
+            self.engine = self._mk(batch_size)
+            self.engine.set_parameters(self._params)
+            self._bs = batch_size
+        return self.engine
+
+    def get_weights(self):
+        return self.engine.get_parameters() if self.engine is not None else dict(self._params)
+
+    def set_weights(self, params):
+        self._params = {k: np.asarray(params[k], np.float32) for k in PARAM_NAMES}
+        if self.engine is not None:
+            self.engine.set_parameters(self._params)
+
+    def load_weights(self, model_dir, h5_reader=None):
+        model_dir = os.path.expanduser(model_dir)
+        npz, h5 = os.path.join(model_dir, "model.npz"), os.path.join(model_dir, "model.h5")
+        if os.path.exists(npz):
+            with np.load(npz) as f:
+                self.set_weights({k: f[k] for k in PARAM_NAMES})
+        elif os.path.exists(h5) and h5_reader is not None:
+            self.set_weights(h5_reader(h5))
+        else:
+            raise FileNotFoundError("no model.npz in %s (and no h5_reader given for model.h5)" % model_dir)
+
+    def save_weights(self, model_dir):
+        os.makedirs(model_dir, exist_ok=True)
+        np.savez(os.path.join(model_dir, "model.npz"), **self.get_weights())
+
+    # ------------------------------------------------------------------ reference surface
+    def train(self, inputs, targets, batch_size, epochs, model_dir, validation_split=0.1, patience=25, seed=0):
+        """encoders.py:40-50: fit with 10 % validation (the LAST 10 % of the data, as Keras splits before
+        shuffling), per-epoch shuffle, history.csv, best-val checkpoint, EarlyStopping(patience=25)."""
+        if targets is not inputs and not np.array_equal(inputs, targets):
+            raise NotImplementedError("the auto-encoder is trained to reconstruct its input")
+        x = np.ascontiguousarray(inputs, np.float32).reshape(-1, 64, 64, 1)
+        n_val = int(x.shape[0] * validation_split)
+        xt, xv = x[: x.shape[0] - n_val], x[x.shape[0] - n_val:]
+        eng = self._engine(batch_size)
+        rng = np.random.default_rng(seed)
+        os.makedirs(model_dir, exist_ok=True)
+        hist = {"loss": [], "val_loss": []}
+        best, since = np.inf, 0
+        with open(os.path.join(model_dir, "history.csv"), "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["epoch", "loss", "val_loss"])
+            for ep in range(epochs):
+                order = rng.permutation(xt.shape[0])
+                n_full = (xt.shape[0] // batch_size) * batch_size      # the engine's batch is static: drop the remainder
+                losses = []
+                for k0 in range(0, n_full, batch_size):
+                    losses.append(eng.train_batches(xt[order[k0:k0 + batch_size]]))
+                loss = float(np.mean(losses)) if losses else float("nan")
+                val = self.test(xv, xv) if n_val else loss
+                hist["loss"].append(loss); hist["val_loss"].append(val)
+                wr.writerow([ep, loss, val]); f.flush()
+                if val < best:
+                    best, since = val, 0
+                    self.save_weights(model_dir)
+                else:
+                    since += 1
+                    if since > patience:
+                        break
+        return hist
+
+    def predict(self, imgs):
+        """Reconstructions [N,64,64,1].  Runs the training graph's forward half on padded minibatches with a
+        zero learning rate would still move Adam state, so prediction uses a dedicated evaluation pass:
+        encode on the device, decode through the oracle-free NumPy decoder of the same weights."""
+        return _decode_numpy(self.get_weights(), self.encode(imgs))
+
+    def test(self, inputs, targets):
+        out = self.predict(inputs)
+        return float(np.mean((out - np.asarray(targets, np.float32).reshape(out.shape)) ** 2))
+
+    def encode(self, imgs):
+        eng = self.engine if self.engine is not None else self._engine(self._bs or 128)
+        imgs = np.ascontiguousarray(imgs, np.float32).reshape(-1, 64, 64, 1)
+        nb = int(eng.cfg.act_batch)
+        return np.concatenate([eng.encode(imgs[k:k + nb]) for k in range(0, imgs.shape[0], nb)], axis=0)
+
+    @property
+    def encoding_shape(self):
+        return (100,)
+
+
+def _leaky(x, a=0.1):
+    return np.where(x > 0, x, a * x)
+
+
+def _conv_same_s1(x, w, b):
+    """NHWC 'same' stride-1 convolution (validation / predict only; the training path is the HIP engine)."""
+    k = w.shape[0]
+    lo = (k - 1) // 2
+    xp = np.pad(x, ((0, 0), (lo, k - 1 - lo), (lo, k - 1 - lo), (0, 0)))
+    n, H, W, _ = x.shape
+    win = np.lib.stride_tricks.sliding_window_view(xp, (k, k), axis=(1, 2))      # [n,H,W,C,k,k]
+    return np.einsum("nhwcij,ijco->nhwo", win, w, optimize=True) + b
+
+
+def _decode_numpy(P, z):
+    h = _leaky(z @ P["decoder/dense_2/kernel"] + P["decoder/dense_2/bias"]).reshape(-1, 8, 8, 32)
+    for i in (4, 5):
+        h = h.repeat(2, axis=1).repeat(2, axis=2)
+        h = _leaky(_conv_same_s1(h, P["decoder/conv2d_%d/kernel" % i], P["decoder/conv2d_%d/bias" % i]))
+    h = h.repeat(2, axis=1).repeat(2, axis=2)
+    return _conv_same_s1(h, P["decoder/conv2d_6/kernel"], P["decoder/conv2d_6/bias"]).astype(np.float32)

@@ -57,6 +57,7 @@ extern "C" {
 #define GRL_ALGO_SAC 0   /* sb.SAC  sb_helper.py:104-128 */
 #define GRL_ALGO_DQN 1   /* sb.DQN  sb_helper.py:159-165 */
 #define GRL_ALGO_BDQ 2   /* sb.BDQ  sb_helper.py:210-224 */
+#define GRL_ALGO_AE 3    /* depth auto-encoder training: gripperEnv/encoders.py:40-50,70-136, config/encoder.yaml */
 
 typedef struct grl_config {
   int32_t extractor;      /* GRL_EXTRACTOR_*                                                    */
@@ -168,6 +169,13 @@ int grl_get_metrics(grl_handle h, grl_metrics* out);
    DQN / BDQ handles: out receives the dueling Q-values [n, q_branches*q_bins]. */
 int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps_or_null,
             float* out_actions);
+
+/* GRL_ALGO_AE handles: n_steps minibatch updates of the depth auto-encoder (forward, mean-squared
+   reconstruction error, backward, Keras-Adam; encoders.py:40-50,127-136).  imgs: DEVICE pointer to
+   [n_steps*batch_size, 64, 64, 1] float32 depth images (train_encoder.py:19-27 preprocessing is the
+   caller's).  Parameters are the 16 Keras tensors of model.h5 (grl_param_info); grl_get_metrics reports
+   the reconstruction loss of the last minibatch in policy_loss; grl_encode works on the handle. */
+int grl_ae_train_step(grl_handle h, const float* imgs, int n_steps);
 
 /* Keras depth auto-encoder (encoder half).  weights: 8 host arrays in Keras order
    conv2d_1..3 kernel(HWIO)/bias, dense_1 kernel [2048,100]/bias; copied into the work arena. */
