@@ -9,9 +9,11 @@
 namespace grl {
 
 // UpSampling2D(size=2), nearest: u[n, 2i+a, 2j+b, c] = h[n, i, j, c].  One thread per 4 channels of an
-// output pixel (C % 4 == 0).
+// output pixel (C % 4 == 0).  The result is written into the interior of a buffer with a border of `lo`
+// pixels before and `hi` after each image row / column (kept zero), so that the 'same' convolution that
+// consumes it is a 'valid' one over the bordered image: no per-tap bounds masks in the GEMM kernels.
 __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ h, float* __restrict__ u, int N,
-                                                       int H, int W, int C) {
+                                                       int H, int W, int C, int lo, int hi) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x;          // quad index over [N, 2H, 2W, C/4]
   const int C4 = C / 4;
   const long total = (long)N * 2 * H * 2 * W * C4;
@@ -22,8 +24,22 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
   const int oh = (int)(r % (2 * H));
   const int n = (int)(r / (2 * H));
   const float* src = h + (((long)n * H + oh / 2) * W + ow / 2) * C + 4 * c4;
-  float* dst = u + q * 4;
+  const int Hp = 2 * H + lo + hi, Wp = 2 * W + lo + hi;
+  float* dst = u + (((long)n * Hp + oh + lo) * Wp + ow + lo) * C + 4 * c4;
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+}
+
+// copy [N, H, W, C] into the interior of a zero-bordered [N, H+lo+hi, W+lo+hi, C] buffer (same purpose)
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ x, float* __restrict__ xp, long total,
+                                                      int H, int W, int C, int lo, int hi) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;          // element index over [N, H, W, C]
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  long r = e / C;
+  const int w = (int)(r % W); r /= W;
+  const int hh = (int)(r % H);
+  const long n = r / H;
+  xp[((n * (H + lo + hi) + hh + lo) * (W + lo + hi) + w + lo) * C + c] = x[e];
 }
 
 // backward of UpSampling2D(2) fused with the LeakyReLU gradient of the layer that produced h:
@@ -51,47 +67,86 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
 // MSE: g_out = 2 (out - x) / n_total, partial sums of (out - x)^2 per workgroup (fixed tree order)
 struct MseArgs {
   const float* out; const float* x; float* g_out; float* partial; long n_total;
+  float* g_pad;      // optional copy of g_out with a zero border of 3 pixels: [N, 70, 70] (64x64 images)
+  float* partial_g;  // per-workgroup sums of g_out (bias gradient of the 1-channel output conv)
 };
+__device__ __forceinline__ long mse_pad_index(long i) {   // i over [N, 64, 64] -> [N, 70, 70] interior
+  const long n = i >> 12;
+  const int r = (int)(i & 4095);
+  return n * 4900 + ((r >> 6) + 3) * 70 + (r & 63) + 3;
+}
 #ifdef GRL_HOSTEMU
 inline void mse_kernel(MseArgs a) {
   if (threadIdx.x != 0) return;
   const long per = (a.n_total + gridDim.x - 1) / gridDim.x;
   const long i0 = (long)blockIdx.x * per, i1 = std::min(a.n_total, i0 + per);
-  float s = 0.f;
+  float s = 0.f, sg = 0.f;
   for (long i = i0; i < i1; ++i) {
     const float d = a.out[i] - a.x[i];
-    a.g_out[i] = 2.f * d / (float)a.n_total;
+    const float g = 2.f * d / (float)a.n_total;
+    a.g_out[i] = g;
+    if (a.g_pad) a.g_pad[mse_pad_index(i)] = g;
     s += d * d;
+    sg += g;
   }
   a.partial[blockIdx.x] = s;
+  a.partial_g[blockIdx.x] = sg;
 }
 #else
 __global__ __launch_bounds__(256) void mse_kernel(MseArgs a) {
-  __shared__ float red[256];
+  __shared__ float red[256], redg[256];
   const long per = (a.n_total + gridDim.x - 1) / gridDim.x;
   const long i0 = (long)blockIdx.x * per, i1 = min(a.n_total, i0 + per);
   const float inv = 2.f / (float)a.n_total;
-  float s = 0.f;
+  float s = 0.f, sg = 0.f;
   for (long i = i0 + threadIdx.x; i < i1; i += 256) {
     const float d = a.out[i] - a.x[i];
-    a.g_out[i] = d * inv;
+    const float g = d * inv;
+    a.g_out[i] = g;
+    if (a.g_pad) a.g_pad[mse_pad_index(i)] = g;
     s += d * d;
+    sg += g;
   }
-  red[threadIdx.x] = s;
+  red[threadIdx.x] = s; redg[threadIdx.x] = sg;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    if ((int)threadIdx.x < off) { red[threadIdx.x] += red[threadIdx.x + off]; redg[threadIdx.x] += redg[threadIdx.x + off]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) { a.partial[blockIdx.x] = red[0]; a.partial_g[blockIdx.x] = redg[0]; }
 }
 #endif
 
-// loss value + Keras-Adam step size lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); advances the beta powers
-__global__ void ae_finish_kernel(const float* partial, int n_partial, long n_total, float lr, DevScalars* sc) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Output convolution 7x7 'same', 32 -> 1 channel, restructured for the matrix cores: the GEMM
+// T[tap, p] = sum_c W[tap, c] u[p, c] (49 rows instead of N = 1; tap-major so that the reads below are
+// coalesced across the pixels of a wavefront and every T element is read exactly once) followed by
+//   out[n, oh, ow] = b + sum_{kh, kw} T[kh*7+kw, (n, oh+kh-3, ow+kw-3)]      (taps outside the image skipped)
+__global__ __launch_bounds__(256) void ae_tapsum_kernel(const float* __restrict__ T, long ldT, const float* __restrict__ bias,
+                                                       float* __restrict__ out, long n_pix) {
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_pix) return;
+  const long n = o >> 12;
+  const int oh = (int)((o >> 6) & 63), ow = (int)(o & 63);
   float s = 0.f;
-  for (int k = 0; k < n_partial; ++k) s += partial[k];
+  for (int kh = 0; kh < 7; ++kh) {
+    const int ih = oh + kh - 3;
+    if (ih < 0 || ih > 63) continue;
+    for (int kw = 0; kw < 7; ++kw) {
+      const int iw = ow + kw - 3;
+      if (iw < 0 || iw > 63) continue;
+      s += T[(long)(kh * 7 + kw) * ldT + (n << 12) + (ih << 6) + iw];
+    }
+  }
+  out[o] = s + bias[0];
+}
+
+// loss value + Keras-Adam step size lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); advances the beta powers
+__global__ void ae_finish_kernel(const float* partial, const float* partial_g, int n_partial, long n_total, float lr,
+                                 DevScalars* sc, float* g_out_bias) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f, sg = 0.f;
+  for (int k = 0; k < n_partial; ++k) { s += partial[k]; sg += partial_g[k]; }
+  if (g_out_bias) g_out_bias[0] = sg;             // d loss / d bias of the output convolution
   sc->policy_loss = s / (float)n_total;          // reported as the reconstruction loss
   sc->adam_alpha = lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
   sc->beta1_power *= 0.9f;

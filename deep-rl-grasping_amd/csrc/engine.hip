@@ -1879,7 +1879,19 @@ int grl_ctx::plan_ae() {
   auto T = [&](int h, int ch) { return wk.f32((int64_t)B * h * h * ch); };
   ae_x = T(64, 1);
   float *e1 = T(32, 32), *e2 = T(16, 32), *e3 = T(8, 32), *z = wk.f32((int64_t)B * 100), *dh = T(8, 32);
-  float *u4 = T(16, 32), *d4 = T(16, 32), *u5 = T(32, 32), *d5 = T(32, 32), *u6 = T(64, 32), *out = T(64, 1);
+  float *d4 = T(16, 32), *d5 = T(32, 32), *u6 = T(64, 32), *out = T(64, 1);
+  // inputs of the padded convolutions live in zero-bordered buffers (border written once): the 'same'
+  // convolution becomes a 'valid' one over the bordered image, so neither the forward GEMM nor the weight
+  // gradient needs per-tap bounds masks and both run on the vectorised kernel
+  auto TP = [&](int h, int lo, int hi, int ch) {
+    const int64_t n = (int64_t)B * (h + lo + hi) * (h + lo + hi) * ch;
+    float* b = wk.f32(n);
+    zero_once.push_back({b, (size_t)n * 4});
+    return b;
+  };
+  float *x_p = TP(64, 2, 3, 1), *e1_p = TP(32, 1, 2, 32), *e2_p = TP(16, 0, 1, 32);
+  float *u4 = TP(16, 1, 1, 32), *u5 = TP(32, 2, 2, 32);
+  float* g_pad = nullptr;
   float *g_out = T(64, 1), *g_u6 = T(64, 32), *g_d5 = T(32, 32), *g_u5 = T(32, 32), *g_d4 = T(16, 32), *g_u4 = T(16, 32);
   float *g_dh = T(8, 32), *g_z = wk.f32((int64_t)B * 100), *g_e3 = T(8, 32), *g_e2 = T(16, 32), *g_e1 = T(32, 32);
   const int NPART = 256;
@@ -1887,17 +1899,28 @@ int grl_ctx::plan_ae() {
   // geometry: encoder convs 'SAME' stride 2 (TF asymmetric padding: low pad 2 / 1 / 0), decoder convs 'SAME' stride 1
   const ConvGeom ge[3] = {{64, 64, 1, 7, 7, 2, 2, 32, 32, 32}, {32, 32, 32, 5, 5, 2, 1, 16, 16, 32}, {16, 16, 32, 3, 3, 2, 0, 8, 8, 32}};
   const ConvGeom gd[3] = {{16, 16, 32, 3, 3, 1, 1, 16, 16, 32}, {32, 32, 32, 5, 5, 1, 2, 32, 32, 32}, {64, 64, 32, 7, 7, 1, 3, 64, 64, 1}};
-  ConvFwdTabs fte[3], ftd[3];
-  for (int l = 0; l < 3; ++l) { fte[l] = conv_fwd_tabs(ge[l], B); ftd[l] = conv_fwd_tabs(gd[l], B); }
+  // the same convolutions as 'valid' ones over the bordered inputs (forward + weight gradient)
+  const ConvGeom gev[3] = {{69, 69, 1, 7, 7, 2, 0, 32, 32, 32}, {35, 35, 32, 5, 5, 2, 0, 16, 16, 32}, {17, 17, 32, 3, 3, 2, 0, 8, 8, 32}};
+  const ConvGeom gdv[2] = {{18, 18, 32, 3, 3, 1, 0, 16, 16, 32}, {36, 36, 32, 5, 5, 1, 0, 32, 32, 32}};
+  ConvFwdTabs fte[3], ftd[2];
+  for (int l = 0; l < 3; ++l) fte[l] = conv_fwd_tabs(gev[l], B);
+  for (int l = 0; l < 2; ++l) ftd[l] = conv_fwd_tabs(gdv[l], B);
   auto elem = [&](const char* tag, std::function<void(hipStream_t)> f) {
     Op op; op.tag = tag; op.run = std::move(f);
     ops_ae.push_back(op);
   };
-  auto up = [&](const float* h, float* u, int H) {
+  auto up = [&](const float* h, float* u, int H, int border) {
     const int Bn = B;
     elem("ae_upsample", [=](hipStream_t s) {
       const long quads = (long)Bn * 2 * H * 2 * H * 8;
-      hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, h, u, Bn, H, H, 32);
+      hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, h, u, Bn, H, H, 32,
+                         border, border);
+    });
+  };
+  auto padcp = [&](const float* x, float* xp, int H, int C, int lo, int hi) {
+    const long total = (long)B * H * H * C;
+    elem("ae_pad_copy", [=](hipStream_t s) {
+      hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, xp, total, H, H, C, lo, hi);
     });
   };
   auto up_bwd = [&](const float* gu, const float* h, float* gh, int H) {
@@ -1909,10 +1932,14 @@ int grl_ctx::plan_ae() {
   };
   // =============================================================== forward
   {
-    const float* in[3] = {ae_x, e1, e2};
+    const float* in[3] = {x_p, e1_p, e2_p};
     float* o[3] = {e1, e2, e3};
-    for (int l = 0; l < 3; ++l)
-      add_launch(ops_ae, "ae_enc_conv", 0, {conv_fwd(in[l], fte[l], ge[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA)});
+    padcp(ae_x, x_p, 64, 1, 2, 3);
+    for (int l = 0; l < 3; ++l) {
+      add_launch(ops_ae, "ae_enc_conv", 0, {conv_fwd(in[l], fte[l], gev[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA)});
+      if (l == 0) padcp(e1, e1_p, 32, 32, 1, 2);
+      if (l == 1) padcp(e2, e2_p, 16, 32, 0, 1);
+    }
   }
   {
     IgemmProb p = dense_fwd(e3, 2048, 2048, nullptr, 0, 0, B, P + edw, 100, P + edb, z, 100, ACT_LEAKY);
@@ -1922,20 +1949,36 @@ int grl_ctx::plan_ae() {
     q.act_alpha = LA;
     add_launch(ops_ae, "ae_dense", 0, {q});
   }
-  up(dh, u4, 8);
-  add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u4, ftd[0], gd[0], P + dw[0], P + db[0], d4, ACT_LEAKY, LA)});
-  up(d4, u5, 16);
-  add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u5, ftd[1], gd[1], P + dw[1], P + db[1], d5, ACT_LEAKY, LA)});
-  up(d5, u6, 32);
-  add_launch(ops_ae, "ae_out_conv", 0, {conv_fwd(u6, ftd[2], gd[2], P + dw[2], P + db[2], out, ACT_NONE, 0.f)});
+  up(dh, u4, 8, 1);
+  add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u4, ftd[0], gdv[0], P + dw[0], P + db[0], d4, ACT_LEAKY, LA)});
+  up(d4, u5, 16, 2);
+  add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u5, ftd[1], gdv[1], P + dw[1], P + db[1], d5, ACT_LEAKY, LA)});
+  up(d5, u6, 32, 0);
+  // output conv (7x7 'same', 32 -> 1): N = 1 wastes the matrix cores, so T[tap, p] = W[tap, :] . u6[p, :] as a
+  // GEMM with M = 49, then a 49-tap gather-sum (ae_kernels.h: ae_tapsum_kernel)
+  const long ldT = (long)B * 4096;
+  float* Tt = wk.f32(49 * ldT);
+  add_launch(ops_ae, "ae_out_conv", 1, {dense_bwd({{P + dw[2], 32, 32, u6}}, 49, 0, B * 4096, Tt, (int)ldT, nullptr)});
+  {
+    const long npix = (long)B * 4096;
+    const float* b6 = P + db[2];
+    elem("ae_out_tapsum", [=](hipStream_t s) {
+      hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix);
+    });
+  }
   // =============================================================== loss
   {
-    MseArgs ma{out, ae_x, g_out, partial, (long)B * 4096};
+    g_pad = wk.f32((int64_t)B * 4900);
+    zero_once.push_back({g_pad, (size_t)B * 4900 * 4});   // the 3-pixel border stays zero
+    float* partial_g = wk.f32(NPART);
+    MseArgs ma{out, ae_x, g_out, partial, (long)B * 4096, g_pad, partial_g};
     const float lr = c.lr;
     DevScalars* scp = sc;
+    float* gb6 = grads + db[2];
     elem("ae_mse", [=](hipStream_t s) {
       hipLaunchKernelGGL(mse_kernel, dim3(NPART), dim3(256), 0, s, ma);
-      hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, NPART, ma.n_total, lr, scp);
+      hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, (const float*)partial_g, NPART,
+                         ma.n_total, lr, scp, gb6);
     });
   }
   // =============================================================== backward
@@ -1954,14 +1997,33 @@ int grl_ctx::plan_ae() {
     }
     add_launch(ops_ae, tag, 1, pr);
   };
-  // output conv (7x7, 32 -> 1)
-  cw(u6, ftd[2], gd[2], g_out, dw[2], db[2], 64);
+  // output conv (7x7, 32 -> 1): dW[tap, c] = sum_p g[p - shift(tap)] u6[p, c] -- a GEMM with M = 49 taps, N = 32
+  // channels, K = pixels; g is read from its zero-bordered copy so that no tap needs a mask.  (Its bias
+  // gradient, sum g, comes from the MSE kernel.)
+  {
+    std::vector<int32_t> ti(49), tr((size_t)B * 4096);
+    for (int kh = 0; kh < 7; ++kh)
+      for (int kw = 0; kw < 7; ++kw) ti[kh * 7 + kw] = -((kh - 3) * 70 + (kw - 3));
+    for (int n = 0; n < B; ++n)
+      for (int oh = 0; oh < 64; ++oh)
+        for (int ow = 0; ow < 64; ++ow) tr[((size_t)n * 64 + oh) * 64 + ow] = n * 4900 + (oh + 3) * 70 + (ow + 3);
+    IgemmProb p = blank();
+    p.M = 49; p.N = 32; p.K = B * 4096;
+    p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
+    p.q_base[0] = u6; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
+    p.ldc = 32;
+    set_split(p, 256);
+    p.c = wk.f32(p.slab_stride * p.split);
+    std::vector<IgemmProb> one;
+    add_wgrad(one, p, dw[2], 0, 49, -1);
+    add_launch(ops_ae, "ae_out_wgrad", 0, one);
+  }
   cb("ae_out_conv_bwd", g_out, gd[2], P + dw[2], g_u6, nullptr);
   up_bwd(g_u6, d5, g_d5, 32);
-  cw(u5, ftd[1], gd[1], g_d5, dw[1], db[1], 32);
+  cw(u5, ftd[1], gdv[1], g_d5, dw[1], db[1], 32);
   cb("ae_dec_conv_bwd", g_d5, gd[1], P + dw[1], g_u5, nullptr);
   up_bwd(g_u5, d4, g_d4, 16);
-  cw(u4, ftd[0], gd[0], g_d4, dw[0], db[0], 8);
+  cw(u4, ftd[0], gdv[0], g_d4, dw[0], db[0], 8);
   cb("ae_dec_conv_bwd", g_d4, gd[0], P + dw[0], g_u4, nullptr);
   up_bwd(g_u4, dh, g_dh, 8);
   {
@@ -1978,11 +2040,11 @@ int grl_ctx::plan_ae() {
     b2.act_alpha = LA;
     add_launch(ops_ae, "ae_dense_bwd", 1, {b2});
   }
-  cw(e2, fte[2], ge[2], g_e3, ew[2], eb[2], 4);
+  cw(e2_p, fte[2], gev[2], g_e3, ew[2], eb[2], 4);
   cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2);
-  cw(e1, fte[1], ge[1], g_e2, ew[1], eb[1], 16);
+  cw(e1_p, fte[1], gev[1], g_e2, ew[1], eb[1], 16);
   cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1);
-  cw(ae_x, fte[0], ge[0], g_e1, ew[0], eb[0], 64);
+  cw(x_p, fte[0], gev[0], g_e1, ew[0], eb[0], 64);
   {
     // uniform launches for the vectorised kernel; whatever it cannot take goes to igemm_kernel
     std::vector<IgemmProb> ok_c, rest;
