@@ -7,6 +7,7 @@ The only exchange of the path is one all-reduce(sum) of the flat fp32 gradient b
 Adam/Polyak kernel with grad_scale = 1/world.  All three SAC losses are batch means, so the mean of
 per-shard gradients equals the gradient of the global batch.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -19,6 +20,30 @@ def allreduce_flat_(flat, group=None):
     """Sum-all-reduce of a flat gradient tensor, in place (one bucket, one collective)."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def gather_moments(mean, var, count, group=None):
+    """All-gather of one batch's (mean, var, count); returns them in rank order (float64 throughout)."""
+    mean, var = np.asarray(mean, np.float64), np.asarray(var, np.float64)
+    flat = np.concatenate([[float(count)], mean.ravel(), var.ravel()])
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"      # RCCL moves device buffers only
+    mine = torch.from_numpy(flat).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, mine, group=group)
+    n = mean.size
+    out = []
+    for p in parts:
+        a = p.cpu().numpy()
+        out.append((a[1:1 + n].reshape(mean.shape), a[1 + n:].reshape(var.shape), a[0]))
+    return out
+
+
+def share_running_stats(vec_normalize, group=None):
+    """Keep the VecNormalize statistics of all replicas identical: every ``update`` of
+    obs_rms / ret_rms merges the batch moments of all ranks, in rank order, into each replica."""
+    for rms in (vec_normalize.obs_rms, vec_normalize.ret_rms):
+        rms.gather = lambda m, v, c, _g=group: gather_moments(m, v, c, _g)
+    return vec_normalize
 
 
 class DataParallelSac:

@@ -68,6 +68,57 @@ def test_two_rank_update_equals_single_engine(hostemu_lib, tmp_path):
         assert d.max() <= 0.3 * lr * STEPS + 1e-7 and d.mean() <= 0.02 * lr * STEPS + 1e-9, (k, d.max(), d.mean())
 
 
+def _stats_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grasp_rl.parallel import share_running_stats
+    from grasp_rl.sb.running_mean_std import RunningMeanStd
+
+    class _VN:                                     # the two attributes share_running_stats touches
+        obs_rms, ret_rms = RunningMeanStd(shape=(4, 3)), RunningMeanStd(shape=())
+    vn = share_running_stats(_VN())
+    rng = np.random.default_rng(100 + rank)
+    for _ in range(3):
+        vn.obs_rms.update(rng.normal(rank, 1.0 + rank, (5 + rank, 4, 3)))
+        vn.ret_rms.update(rng.normal(size=5 + rank))
+    import pickle
+    assert "gather" not in pickle.loads(pickle.dumps(vn.obs_rms)).__dict__
+    np.savez(os.path.join(out_dir, "stats%d.npz" % rank), mean=vn.obs_rms.mean, var=vn.obs_rms.var,
+             count=vn.obs_rms.count, rmean=vn.ret_rms.mean, rvar=vn.ret_rms.var)
+    dist.destroy_process_group()
+
+
+def test_running_stats_are_merged_over_ranks(tmp_path):
+    """VecNormalize moments under data parallelism: replicas stay identical and equal the rank-ordered merge."""
+    from grasp_rl.sb.running_mean_std import RunningMeanStd
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_stats_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "stats0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "stats1.npz"))
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    ref, rref = RunningMeanStd(shape=(4, 3)), RunningMeanStd(shape=())
+    rngs = [np.random.default_rng(100), np.random.default_rng(101)]
+    for _ in range(3):
+        batches = [(rngs[r].normal(r, 1.0 + r, (5 + r, 4, 3)), rngs[r].normal(size=5 + r)) for r in range(2)]
+        for o, ret in batches:
+            ref.update(o)
+            rref.update(ret)
+    assert np.array_equal(ref.mean, r0["mean"]) and np.array_equal(ref.var, r0["var"]) and ref.count == float(r0["count"])
+    assert np.array_equal(rref.var, r0["rvar"])
+    # and the merge is the statistics of the union of all batches
+    rngs = [np.random.default_rng(100), np.random.default_rng(101)]
+    allobs = []
+    for _ in range(3):
+        for r in range(2):
+            allobs.append(rngs[r].normal(r, 1.0 + r, (5 + r, 4, 3)))
+            rngs[r].normal(size=5 + r)
+    allobs = np.concatenate(allobs)
+    assert np.allclose(r0["mean"], allobs.mean(0), atol=1e-4) and np.allclose(r0["var"], allobs.var(0), rtol=1e-3, atol=1e-4)
+
+
 def test_scale_and_bucket_helpers():
     from grasp_rl.parallel import allreduce_mean_scale
     assert allreduce_mean_scale(8) == 0.125
