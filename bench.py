@@ -95,6 +95,25 @@ def cpu_baseline(seconds=15.0):
                       % (n, BATCH, dt)}
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of launch `tag` from the newest committed PMC summary (separate rocprofv3 --pmc
+    passes of this same command, scripts/pmc_traffic.sh: FETCH_SIZE with the gfx950 correction + WRITE_SIZE);
+    counters cannot be collected from inside the timed process, so this is the recorded measurement or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_hbm_traffic*.csv")))
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get("launch_tag") == tag:
+                        mb = [v for k, v in row.items() if k and k.startswith("HBM_MB_per_launch")][0]
+                        return round(float(mb) * 1048576.0), "profiles/" + os.path.basename(f)
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +194,9 @@ def main():
                 "avg_launch_ms": round(d["avg_ms"], 5), "flops_per_launch": d["flops"],
                 "measured": "separate eager pass, hipEvents on the engine stream, same workload",
                 "step_kernel_ms": {k: round(total[k] / max(1, min(args.steps, 50)), 5) for k in sorted(total)}}
+        tr = pmc_traffic(dom)
+        if tr:
+            roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr[0], "bytes/launch", tr[1]
         # whole update: algorithmic FLOPs of every GEMM-shaped launch of one step over the graph-replay step time
         step_flops = sum(v["flops"] * v["launches"] for v in prof.values()) / max(1, min(args.steps, 50))
         roof["step_flops"] = step_flops

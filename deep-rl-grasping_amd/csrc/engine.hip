@@ -659,9 +659,6 @@ struct grl_ctx {
         if (al16(p.c) && (p.ldc % 4) == 0 && (p.N % 4) == 0 && (p.slab_stride % 4) == 0 &&
             (!p.c_tab_i || (p.vflags & VF_CT4)) && (!p.relu_mask || al16(p.relu_mask)) && (!p.bias || al16(p.bias)))
           p.vflags |= VF_C_VEC;
-    if (getenv("GRL_PLAN_DUMP"))
-      fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu\n", tag.c_str(), variant,
-              l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size());
     const int BMt = l->v2 ? i2_bm(l->cfg) : 64, BNt = l->v2 ? i2_bn(l->cfg) : 64;
 
     std::vector<int4> tiles;
@@ -680,6 +677,9 @@ struct grl_ctx {
           for (int tj = 0; tj < (p.N + BNt - 1) / BNt; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
     }
     l->n_tiles = (int)tiles.size();
+    if (getenv("GRL_PLAN_DUMP"))
+      fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu  tiles %d\n", tag.c_str(),
+              variant, l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size(), l->n_tiles);
     l->d_probs = upload_vec(wk, l->probs);
     l->d_tiles = upload_vec(wk, tiles);
     launches.push_back(l);
@@ -1292,6 +1292,23 @@ int grl_ctx::plan_sac() {
     const char* le = getenv("GRL_LANES");
     use_lanes = le && le[0] == '1';   // ROCm's graph scheduler serialises most forked kernels: off by default
     wgrad_ops.clear();
+    // One launch for all weight gradients: the dense problems (x^T read with affine addresses) are re-expressed
+    // with the table addressing of the convolution ones and appended to that launch -- one kernel boundary
+    // less, and their short reductions (K = B) fill the tail of the long convolution tiles.
+    std::vector<IgemmProb> wg_merged;
+    const char* nm = getenv("GRL_NO_WGRAD_MERGE");
+    if (cnn && !use_lanes && !(nm && nm[0] == '1') && wg_plain.empty() && !wgc[0].empty() && v2_prob_ok(wgc[0][0], 2)) {
+      for (auto p : wg_ones) {
+        std::vector<int32_t> ti(p.M), tr(p.K);
+        for (int i = 0; i < p.M; ++i) ti[i] = i * p.p_ld_i[0];
+        for (int r = 0; r < p.K; ++r) tr[r] = r * p.p_ld_r[0];
+        p.p_tab_i = upload_vec(wk, ti);
+        p.p_tab_r = upload_vec(wk, tr);
+        p.vflags |= VF_P_TABS;                    // v2_prob_ok held for the affine form: unit stride along i, ld_r % 4 == 0
+        wg_merged.push_back(p);
+      }
+      wg_ones.clear();
+    }
     add_launch(wgrad_ops, "wgrad_dense", 2, wg_ones);
     add_launch(wgrad_ops, "wgrad_dense", 2, wg_plain);
     add_launch(wgrad_ops, "wgrad_small", 2, wg_rest);
@@ -1302,6 +1319,7 @@ int grl_ctx::plan_sac() {
     } else {
       std::vector<IgemmProb> all;
       for (int l = 2; l >= 0; --l) all.insert(all.end(), wgc[l].begin(), wgc[l].end());
+      all.insert(all.end(), wg_merged.begin(), wg_merged.end());
       add_launch(wgrad_ops, "wgrad_conv", 2, all);
     }
   }
