@@ -72,6 +72,11 @@ struct GatherArgs {
   int use_rng; DevScalars* sc; uint64_t seed;
   int64_t* idx_w; float* eps_w; int n_eps;
   int vec4;   // img_elems, ldx multiples of 4 and 16-byte aligned rows: a thread moves 4 elements (grid.x = ceil(img_elems / 1024))
+  // adam_tick: this launch opens an update -- one thread fixes the Adam step size of the update from the
+  // beta powers and advances them (TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power)).
+  // Done here, a whole launch chain before the first consumer, so that the fused reduce + Adam launch
+  // can read it from any workgroup without ordering against the workgroup that produces the losses.
+  int adam_tick; float adam_lr;
 };
 
 __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int normalize, double clip,
@@ -188,7 +193,15 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   }
   // rng_step itself is advanced by the (single-workgroup) loss reduction later in the update: a counter
   // bumped by the last of these 8192 workgroups would serialise 8192 same-address atomics (~100 us)
-  if (a.use_rng && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.sc->rng_used = 1u;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    if (a.use_rng) a.sc->rng_used = 1u;
+    if (a.adam_tick) {
+      DevScalars* sc = a.sc;
+      sc->adam_alpha = a.adam_lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+      sc->beta1_power *= 0.9f;
+      sc->beta2_power *= 0.999f;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -322,6 +335,14 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(SampleBwdArgs a) {
   }
 }
 
+// one element of TF-1.x Adam (A.5; epsilon outside the bias correction, which lives in alpha)
+__device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v, float alpha, float eps) {
+  const float omb1 = 1.f - 0.9f, omb2 = 1.f - 0.999f;
+  m = m + (g - m) * omb1;
+  v = v + (g * g - v) * omb2;
+  p = p - (m * alpha) / (sqrtf(v) + eps);
+}
+
 // ------------------------------------------------------------------------------------------------
 // losses (A.4) and their gradients w.r.t. the critic / value outputs; Adam step size; metrics.
 struct LossArgs {
@@ -335,11 +356,15 @@ struct LossArgs {
   float* g_log_ent_coef;                                      // gradient slot in the flat bucket
   DevScalars* sc;
   int write_d;   // 0: the output gradients are produced row-locally by heads_bwd_kernel; only the reductions run here
+  int adam_ticked;   // the gather launch of this update already fixed adam_alpha / advanced the beta powers
+  // fused apply (reduce_slabs_kernel with fuse_adam): this workgroup also applies Adam to log_ent_coef, the
+  // one trainable scalar whose gradient is produced here
+  float* ent_param; float* ent_m; float* ent_v;
 };
 
 #ifdef GRL_HOSTEMU
 // TEST-ONLY sequential form (see hostemu.h)
-inline void sac_loss_body(const LossArgs& a) {
+inline void sac_loss_body(const LossArgs& a, int fuse_adam = 0) {
   if (threadIdx.x != 0) return;
   const float log_alpha = a.log_ent_coef[0];
   const float alpha = expf(log_alpha);
@@ -363,14 +388,17 @@ inline void sac_loss_body(const LossArgs& a) {
   sc->ent_loss = -log_alpha * mean_lp_h;
   a.g_log_ent_coef[0] = -mean_lp_h;
   sc->ent_coef = alpha; sc->entropy = s[5] * invB; sc->mean_qf1 = s[6] * invB; sc->mean_v = s[7] * invB;
-  sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
-  sc->beta1_power *= 0.9f;
-  sc->beta2_power *= 0.999f;
+  if (!a.adam_ticked) {
+    sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+    sc->beta1_power *= 0.9f;
+    sc->beta2_power *= 0.999f;
+  }
+  if (fuse_adam) adam_elem(-mean_lp_h, a.ent_param[0], a.ent_m[0], a.ent_v[0], sc->adam_alpha, 1e-8f);
   if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }
 }
 inline void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }
 #else
-__device__ __forceinline__ void sac_loss_body(const LossArgs& a) {
+__device__ __forceinline__ void sac_loss_body(const LossArgs& a, int fuse_adam = 0) {
   __shared__ float red[8][256];
   const int t = threadIdx.x;
   const float log_alpha = a.log_ent_coef[0];
@@ -420,9 +448,12 @@ __device__ __forceinline__ void sac_loss_body(const LossArgs& a) {
     sc->mean_qf1 = red[6][0] * invB;
     sc->mean_v = red[7][0] * invB;
     // TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power); powers advance after
-    sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
-    sc->beta1_power *= 0.9f;
-    sc->beta2_power *= 0.999f;
+    if (!a.adam_ticked) {
+      sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+      sc->beta1_power *= 0.9f;
+      sc->beta2_power *= 0.999f;
+    }
+    if (fuse_adam) adam_elem(a.g_log_ent_coef[0], a.ent_param[0], a.ent_m[0], a.ent_v[0], sc->adam_alpha, 1e-8f);
     if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch came from the device RNG
   }
 }
@@ -580,43 +611,6 @@ __global__ __launch_bounds__(256) void dueling_kernel(const float* adv, const fl
 
 // ------------------------------------------------------------------------------------------------
 // sum split slabs of weight gradients into the flat gradient bucket
-struct ReduceDesc {
-  float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
-};
-
-// flat work list: block b sums 256 consecutive outputs of descriptor tiles[b].x starting at tiles[b].y
-// (slab loads are independent: unrolled so several are in flight; the add order stays k = 0, 1, ...)
-// ... and, as workgroup n_tiles when has_loss is set, the batch reductions of the SAC losses (metrics,
-// entropy-coefficient gradient, Adam step size): they are needed by the apply kernel only.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
-                                                          const int2* __restrict__ tiles, int n_tiles,
-                                                          LossArgs la, int has_loss) {
-  if ((int)blockIdx.x >= n_tiles) {
-    if (has_loss) sac_loss_body(la);
-    return;
-  }
-  const int2 tl = tiles[blockIdx.x];
-  const ReduceDesc d = descs[tl.x];
-  const int i = tl.y + threadIdx.x;
-  if (i < d.n) {
-    const float* __restrict__ src = d.src + i;
-    float s = 0.f;
-    int k = 0;
-    for (; k + 8 <= d.splits; k += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * d.slab_stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
-    d.dst[i] = s;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// TF-1.x Adam (A.5) over the flat trainable block, fused with the Polyak target update (A.4):
-// target <- (1-tau)*target + tau*source for the leading `n_polyak` floats of model/values_fn.
 struct AdamArgs {
   float* params; const float* grads; float* m; float* v;
   int64_t n_train;
@@ -627,17 +621,62 @@ struct AdamArgs {
   float* target;               // target block
 };
 
+struct ReduceDesc {
+  float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
+};
+
+// flat work list: block b sums 256 consecutive outputs of descriptor tiles[b].x starting at tiles[b].y
+// (slab loads are independent: unrolled so several are in flight; the add order stays k = 0, 1, ...)
+// ... and, as workgroup n_tiles when has_loss is set, the batch reductions of the SAC losses (metrics,
+// entropy-coefficient gradient, Adam step size): they are needed by the apply kernel only.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
+                                                          const int2* __restrict__ tiles, int n_tiles,
+                                                          LossArgs la, int has_loss, AdamArgs aa, int fuse_adam) {
+  if ((int)blockIdx.x >= n_tiles) {
+    if (has_loss) sac_loss_body(la, fuse_adam);
+    return;
+  }
+  const int2 tl = tiles[blockIdx.x];
+  const ReduceDesc d = descs[tl.x];
+  const int i = tl.y + threadIdx.x;
+  if (i < d.n) {
+    // fused apply: the element's Adam state is requested before the slab sums (independent loads)
+    const int64_t e = fuse_adam ? (d.dst + i) - aa.grads : 0;
+    float p = 0.f, m = 0.f, v = 0.f, tg = 0.f;
+    const int64_t kp = e - aa.src_ofs;
+    const bool pol = fuse_adam && kp >= 0 && kp < aa.n_polyak;
+    if (fuse_adam) { p = aa.params[e]; m = aa.m[e]; v = aa.v[e]; if (pol) tg = aa.target[kp]; }
+    const float* __restrict__ src = d.src + i;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= d.splits; k += 8) {
+      float vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vv[u] = src[(long)(k + u) * d.slab_stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += vv[u];
+    }
+    for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
+    d.dst[i] = s;
+    if (fuse_adam) {   // the update every trainable tensor gets from adam_polyak_kernel, element by element
+      adam_elem(s * aa.grad_scale, p, m, v, aa.sc->adam_alpha, aa.eps);
+      aa.params[e] = p; aa.m[e] = m; aa.v[e] = v;
+      if (pol) aa.target[kp] = (1.f - aa.tau) * tg + aa.tau * p;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TF-1.x Adam (A.5) over the flat trainable block, fused with the Polyak target update (A.4):
+// target <- (1-tau)*target + tau*source for the leading `n_polyak` floats of model/values_fn.
 __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
   const float alpha = a.sc->adam_alpha;
-  const float omb1 = 1.f - 0.9f, omb2 = 1.f - 0.999f;
   const float omt = 1.f - a.tau;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_train;
        i += (int64_t)gridDim.x * 256) {
     const float g = a.grads[i] * a.grad_scale;
-    float m = a.m[i], v = a.v[i];
-    m = m + (g - m) * omb1;
-    v = v + (g * g - v) * omb2;
-    const float p = a.params[i] - (m * alpha) / (sqrtf(v) + a.eps);
+    float m = a.m[i], v = a.v[i], p = a.params[i];
+    adam_elem(g, p, m, v, alpha, a.eps);
     a.m[i] = m;
     a.v[i] = v;
     a.params[i] = p;

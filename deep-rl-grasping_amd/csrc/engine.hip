@@ -209,6 +209,7 @@ struct grl_ctx {
   std::vector<Op> ops_rng, ops_gather, ops_grads, ops_apply, ops_act, ops_enc, wgrad_ops;   // ops_rng: gather with device RNG; ops_gather: gather of explicit indices
   bool use_lanes = false;
   LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
+  std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
   bool loss_in_reduce = false;
   float grad_scale = 1.f;   // read by the apply op
 
@@ -952,6 +953,7 @@ int grl_ctx::plan_sac() {
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
     ga.act_out2 = act_p; ga.ld_act2 = Ap;
     ga.sc = sc; ga.seed = c.seed; ga.idx_w = idx_buf; ga.eps_w = eps_buf; ga.n_eps = A;
+    ga.adam_tick = fused_heads ? 1 : 0; ga.adam_lr = c.lr;   // otherwise sac_loss_kernel fixes the step size
 #ifndef GRL_HOSTEMU
     ga.vec4 = (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
 #endif
@@ -1083,6 +1085,8 @@ int grl_ctx::plan_sac() {
     la.d_qf1 = d_qf1; la.d_qf2 = d_qf2; la.d_v = d_v; la.d_qf1_pi = d_qf1pi; la.ld_d = ld_d;
     la.g_log_ent_coef = grads + ent_off; la.sc = sc;
     la.write_d = fused_heads ? 0 : 1;
+    la.adam_ticked = fused_heads ? 1 : 0;
+    la.ent_param = params + ent_off; la.ent_m = adam_m + ent_off; la.ent_v = adam_v + ent_off;
     loss_args = la;
     if (!fused_heads) {   // fused heads: output gradients are formed in heads_bwd_kernel, reductions ride on reduce_slabs
       Op op; op.tag = "sac_loss";
@@ -1360,10 +1364,29 @@ int grl_ctx::plan_sac() {
     op.join = true;
     const LossArgs la = loss_args;
     const int has_loss = fused_heads ? 1 : 0;
-    op.run = [dr, d_rt, ntiles, la, has_loss](hipStream_t s) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss);
+    AdamArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.params = params; aa.grads = grads; aa.m = adam_m; aa.v = adam_v; aa.n_train = n_train; aa.sc = sc;
+    aa.grad_scale = 1.f; aa.tau = c.tau; aa.eps = 1e-8f;
+    aa.src_ofs = vf_off; aa.n_polyak = n_polyak; aa.target = params + tgt_off;
+    op.run = [dr, d_rt, ntiles, la, has_loss, aa](hipStream_t s) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss, aa, 0);
     };
     ops_grads.push_back(op);
+    // Full updates (no gradient exchange in between): every trainable element is the sum of one slab
+    // column, so Adam + Polyak are applied where the sum is formed -- one launch and one pass over the
+    // gradient bucket less.  log_ent_coef, whose gradient comes from the loss workgroup, is applied there.
+    const char* nf = getenv("GRL_NO_FUSED_ADAM");
+    if (has_loss && !(nf && nf[0] == '1')) {
+      ops_grads_apply.assign(ops_grads.begin(), ops_grads.end() - 1);
+      Op fo; fo.tag = "reduce_adam";
+      fo.join = true;
+      fo.bytes = (double)n_train * 4 * 7 + (double)n_polyak * 4 * 2;
+      fo.run = [dr, d_rt, ntiles, la, has_loss, aa](hipStream_t s) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss, aa, 1);
+      };
+      ops_grads_apply.push_back(fo);
+    }
   }
 
   // =============================================================== apply
@@ -1776,7 +1799,7 @@ int grl_ctx::plan_q() {
     LossArgs none;
     memset(&none, 0, sizeof(none));
     op.run = [dr, d_rt, ntiles, none](hipStream_t s) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0, AdamArgs{}, 0);
     };
     ops_grads.push_back(op);
   }
@@ -2082,7 +2105,7 @@ int grl_ctx::plan_ae() {
     LossArgs none;
     memset(&none, 0, sizeof(none));
     elem("reduce_slabs", [=](hipStream_t s) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0, AdamArgs{}, 0);
     });
   }
   {
@@ -2458,9 +2481,13 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   for (int s = 0; s < n_steps; ++s) {
     if (idx) {
       if (int e = stage_noise(h, idx, eps, s)) return e;
-      if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
+      if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads_apply})) return e;
+      } else if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
     } else {
-      if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
+      if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads_apply})) return e;
+      } else if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
     }
   }
   HIPCHK(hipGetLastError());
