@@ -6,9 +6,10 @@ config/encoder.yaml.  Training (forward, MSE, backward, Keras-Adam) runs in libg
 this file owns the epoch loop Keras' `Model.fit` provides in the reference: shuffling, the 10 %
 validation split, CSV history, best-weights checkpoint and EarlyStopping(patience=25).
 
-Weight files: the reference stores Keras HDF5 (`model.h5`); without h5py the engine reads / writes the
-same 16 tensors as `model.npz` (keys = Keras weight names).  `load_weights` accepts either when a
-reader for `.h5` is supplied (`h5_reader`, e.g. tests' minimal HDF5 reader).
+Weight files: the reference stores Keras HDF5 (`model.h5`, written by `save_weights`, read back by
+`load_weights`, encoders.py:27-31).  `grasp_rl.keras_h5` reads and writes that format without h5py, so the
+encoders shipped under `encoder_files/` load directly and a model trained here is a `model.h5` the
+reference's Keras code accepts; `model.npz` (keys = Keras weight names) is written next to it.
 """
 import csv
 import ctypes as C
@@ -16,7 +17,7 @@ import os
 
 import numpy as np
 
-from . import _capi
+from . import _capi, keras_h5
 from ._capi import check
 from .engine import SacEngine
 
@@ -96,20 +97,31 @@ class SimpleAutoEncoder:
         if self.engine is not None:
             self.engine.set_parameters(self._params)
 
-    def load_weights(self, model_dir, h5_reader=None):
+    def load_weights(self, model_dir):
+        """encoders.py:26-30: weights from ``<model_dir>/model.h5`` (Keras HDF5); ``model.npz`` as a fallback."""
         model_dir = os.path.expanduser(model_dir)
         npz, h5 = os.path.join(model_dir, "model.npz"), os.path.join(model_dir, "model.h5")
-        if os.path.exists(npz):
+        if os.path.exists(h5):
+            w = keras_h5.read_keras_weights(h5)
+            missing = [k for k in PARAM_NAMES if k + ":0" not in w]
+            if missing:
+                raise KeyError("%s lacks the auto-encoder weights %s" % (h5, missing))
+            self.set_weights({k: w[k + ":0"] for k in PARAM_NAMES})
+        elif os.path.exists(npz):
             with np.load(npz) as f:
                 self.set_weights({k: f[k] for k in PARAM_NAMES})
-        elif os.path.exists(h5) and h5_reader is not None:
-            self.set_weights(h5_reader(h5))
         else:
-            raise FileNotFoundError("no model.npz in %s (and no h5_reader given for model.h5)" % model_dir)
+            raise FileNotFoundError("neither model.h5 nor model.npz in %s" % model_dir)
 
     def save_weights(self, model_dir):
+        """``model.h5`` in the layout Keras' ``save_weights`` gives this model (layers input_1 / encoder /
+        decoder, weight names ``conv2d_1/kernel:0`` ...) plus ``model.npz``."""
         os.makedirs(model_dir, exist_ok=True)
-        np.savez(os.path.join(model_dir, "model.npz"), **self.get_weights())
+        w = self.get_weights()
+        np.savez(os.path.join(model_dir, "model.npz"), **w)
+        keras_h5.write_keras_weights(os.path.join(model_dir, "model.h5"),
+                                     {k + ":0": np.asarray(w[k], np.float32) for k in PARAM_NAMES},
+                                     extra_layers=("input_1",))
 
     # ------------------------------------------------------------------ reference surface
     def train(self, inputs, targets, batch_size, epochs, model_dir, validation_split=0.1, patience=25, seed=0):

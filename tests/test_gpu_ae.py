@@ -27,8 +27,11 @@ def test_simple_autoencoder_train_surface(tmp_path):
     hist = model.train(x, x, batch_size=16, epochs=6, model_dir=str(tmp_path))
     assert len(hist["loss"]) == 6 and hist["loss"][-1] < hist["loss"][0] and np.isfinite(hist["val_loss"]).all()
     assert os.path.exists(tmp_path / "history.csv") and os.path.exists(tmp_path / "model.npz")
+    assert os.path.exists(tmp_path / "model.h5")                  # the file Keras' load_weights reads (encoders.py:27-31)
     z = model.encode(x[:5])
     assert z.shape == (5, 100) and model.encoding_shape == (100,)
+    os.remove(tmp_path / "model.npz")                             # reload through the HDF5 file alone
     m2 = SimpleAutoEncoder(cfg)
     m2.load_weights(str(tmp_path))
     assert abs(m2.test(x[:8], x[:8]) - min(hist["val_loss"])) < 0.05
+    assert m2.encode(x[:5]).shape == (5, 100)
