@@ -208,28 +208,35 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     q_fix[0] = q_fok[0] ? j : j0;
   }
 
-  // table entries are fetched two slabs ahead of the MFMAs that use the data
+  // Table entries (vector global loads: they share vmcnt with the data loads).  Each register set of
+  // staged data has its own table registers, fetched right after the set's data loads were issued and
+  // consumed two slabs later by the set's next refill: at that point the only younger memory operations
+  // are the other set's loads, so the wait in front of the consumer is the one the LDS stores of this set
+  // need anyway.  (One shared copy, fetched last and consumed next, made that wait vmcnt(0): every slab
+  // drained all loads in flight.)
   constexpr int NTP = PL == I2_P_ALONG_R ? 1 : NVP;
   constexpr int NTQ = QL == I2_Q_ALONG_R ? 1 : NVQ;
-  int ptab_nx[NTP], ptap_nx = 0, qtab_nx[NTQ];
-  auto fetch_tabs = [&](int r0) {
+  struct Tabs { int p[NTP]; int tap; int q[NTQ]; };
+  auto fetch_tabs = [&](int r0, Tabs& tb) {
     if (PM != PM_AFFINE) {
 #pragma unroll
       for (int e = 0; e < NTP; ++e) {
         const int r = PL == I2_P_ALONG_R ? r0 + 4 * p_q : r0 + p_l + e * PSTEP;
         const int rc = r < r_end ? r : r_begin;
-        ptab_nx[e] = pTr[rc];
-        if (PM == PM_TABLE_MASK && PL == I2_P_ALONG_R) ptap_nx = pTap[rc];
+        tb.p[e] = pTr[rc];
+        if (PM == PM_TABLE_MASK && PL == I2_P_ALONG_R) tb.tap = pTap[rc];
       }
     }
     if (QM == QM_TABLE) {
 #pragma unroll
       for (int e = 0; e < NTQ; ++e) {
         const int r = QL == I2_Q_ALONG_R ? r0 + 4 * q_q : r0 + q_l + e * QSTEP;
-        qtab_nx[e] = qTr[r < r_end ? r : r_begin];
+        tb.q[e] = qTr[r < r_end ? r : r_begin];
       }
     }
   };
+  Tabs tbA, tbB;
+  tbA.tap = tbB.tap = 0;
 
   // two register sets: while slab s runs from LDS, slab s+1 (one set) is written to the other LDS buffer
   // and slab s+2 (other set) is still in flight -- loads have two slabs of MFMAs to land
@@ -237,34 +244,34 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   unsigned p_kb = 0xfu, q_kb = 0xfu, p_kbB = 0xfu, q_kbB = 0xfu;   // KTAIL: validity of the 4 elements of an along-r vector
 
   // one vector of slab r0 (compile-time e): offset select + buffer load, nothing else
-  auto load_p = [&](int r0, int e, f32x4 (&pv)[NVP], unsigned& p_kb) {
+  auto load_p = [&](int r0, int e, f32x4 (&pv)[NVP], unsigned& p_kb, const Tabs& tb) {
     if (I2_ABLATE & 1) { pv[e] = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
     if (PL == I2_P_ALONG_R) {
       const int r = r0 + 4 * p_q;
       bool ok = r < r_end && p_fok[e];
-      if (PM == PM_TABLE_MASK) ok = ok && ((p_vm[e] >> ptap_nx) & 1ull);
-      const int colterm = PM != PM_AFFINE ? ptab_nx[0] : r;
+      if (PM == PM_TABLE_MASK) ok = ok && ((p_vm[e] >> tb.tap) & 1ull);
+      const int colterm = PM != PM_AFFINE ? tb.p[0] : r;
       pv[e] = i2_ld(rsP, ok ? (p_fix[e] + colterm) * 4 : I2_OOB);
       if (KTAIL && e == 0) p_kb = r + 4 <= r_end ? 0xfu : (0xfu >> min(4, max(0, r + 4 - r_end)));
     } else {
       const int r = r0 + p_l + e * PSTEP;
       const bool ok = r < r_end && p_fok[0];
-      const int colterm = PM != PM_AFFINE ? ptab_nx[e] : r * pLr;
+      const int colterm = PM != PM_AFFINE ? tb.p[e] : r * pLr;
       pv[e] = i2_ld(rsP, ok ? (p_fix[0] + colterm) * 4 : I2_OOB);
     }
   };
-  auto load_q = [&](int r0, int e, f32x4 (&qv)[NVQ], unsigned& q_kb) {
+  auto load_q = [&](int r0, int e, f32x4 (&qv)[NVQ], unsigned& q_kb, const Tabs& tb) {
     if (I2_ABLATE & 1) { qv[e] = f32x4{1.f, 2.f, 3.f, 4.f}; return; }
     if (QL == I2_Q_ALONG_R) {
       const int r = r0 + 4 * q_q;
       const bool ok = r < r_end && q_fok[e];
-      const int rowterm = QM == QM_TABLE ? qtab_nx[0] : r;
+      const int rowterm = QM == QM_TABLE ? tb.q[0] : r;
       qv[e] = i2_ld(rsQ, ok ? (rowterm + q_fix[e]) * 4 : I2_OOB);
       if (KTAIL && e == 0) q_kb = r + 4 <= r_end ? 0xfu : (0xfu >> min(4, max(0, r + 4 - r_end)));
     } else {
       const int r = r0 + q_l + e * QSTEP;
       const bool ok = r < r_end && q_fok[0];
-      const int rowterm = QM == QM_TABLE ? qtab_nx[e] : r * qLr;
+      const int rowterm = QM == QM_TABLE ? tb.q[e] : r * qLr;
       qv[e] = i2_ld(rsQ, ok ? (rowterm + q_fix[0]) * 4 : I2_OOB);
     }
   };
@@ -279,6 +286,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   auto kpos = [](int k) { return (k & ~31) | ((k & 1) << 4) | ((k & 31) >> 1); };
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto put_kquad = [&](float* rowp, int q, f32x4 v) {   // logical k = 4q..4q+3 of a K-contiguous row
+    // The (x, z) / (y, w) pairing needs register copies.  The empty asm pins them (and the wait for the
+    // load that produced v) to this point of the MFMA chain: left alone, the compiler hoists the copies to
+    // the loop back edge, where they wait for loads issued a few instructions earlier.
+    asm volatile("" : "+v"(v));
     float* d = rowp + (q >> 3) * 32 + 2 * (q & 7);
     *(f32x2*)d = f32x2{v.x, v.z};
     *(f32x2*)(d + 16) = f32x2{v.y, v.w};
@@ -324,22 +335,31 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   {
     f32x4 pv0[NVP], qv0[NVQ];
     unsigned p_kb0 = 0xfu, q_kb0 = 0xfu;
-    fetch_tabs(r_begin);
+    Tabs tb0;
+    tb0.tap = 0;
+    fetch_tabs(r_begin, tb0);
+    fetch_tabs(r_begin + BKT, tbA);
+    fetch_tabs(r_begin + 2 * BKT, tbB);
 #pragma unroll
-    for (int e = 0; e < NVP; ++e) load_p(r_begin, e, pv0, p_kb0);
+    for (int e = 0; e < NVP; ++e) load_p(r_begin, e, pv0, p_kb0, tb0);
 #pragma unroll
-    for (int e = 0; e < NVQ; ++e) load_q(r_begin, e, qv0, q_kb0);
-    fetch_tabs(r_begin + BKT);
+    for (int e = 0; e < NVQ; ++e) load_q(r_begin, e, qv0, q_kb0, tb0);
 #pragma unroll
-    for (int e = 0; e < NVP; ++e) load_p(r_begin + BKT, e, pv, p_kb);
+    for (int e = 0; e < NVP; ++e) load_p(r_begin + BKT, e, pv, p_kb, tbA);
 #pragma unroll
-    for (int e = 0; e < NVQ; ++e) load_q(r_begin + BKT, e, qv, q_kb);
-    fetch_tabs(r_begin + 2 * BKT);
+    for (int e = 0; e < NVQ; ++e) load_q(r_begin + BKT, e, qv, q_kb, tbA);
+    __builtin_amdgcn_sched_barrier(0);
+    // same issue order as in the loop (data A, tables A, data B, tables B): the compiler's static wait
+    // counts are the minimum over all paths into the loop head, the entry path included
+    fetch_tabs(r_begin + 3 * BKT, tbA);          // for the first refill of set A (slab 3)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < NVP; ++e) load_p(r_begin + 2 * BKT, e, pvB, p_kbB);
+    for (int e = 0; e < NVP; ++e) load_p(r_begin + 2 * BKT, e, pvB, p_kbB, tbB);
 #pragma unroll
-    for (int e = 0; e < NVQ; ++e) load_q(r_begin + 2 * BKT, e, qvB, q_kbB);
-    fetch_tabs(r_begin + 3 * BKT);
+    for (int e = 0; e < NVQ; ++e) load_q(r_begin + 2 * BKT, e, qvB, q_kbB, tbB);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_tabs(r_begin + 4 * BKT, tbB);          // for the first refill of set B (slab 4)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < NVP; ++e) store_p(lds, e, pv0, p_kb0);
 #pragma unroll
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   constexpr int NMF = 16 * FM * FN;            // MFMAs of one slab per wave
   constexpr int NST = NVP + NVQ;               // staged vectors per thread and slab
   static_assert(2 * NST + 1 <= NMF - 3 - (ONES ? 1 : 0), "staging work must fit into the MFMA gaps of a slab");
-  auto slab_body = [&](int s, f32x4 (&pv)[NVP], f32x4 (&qv)[NVQ], unsigned& p_kb, unsigned& q_kb) {
+  auto slab_body = [&](int s, f32x4 (&pv)[NVP], f32x4 (&qv)[NVQ], unsigned& p_kb, unsigned& q_kb, Tabs& tb) {
     float* cur = lds + (s & 1) * BUF;
     float* nxt = lds + ((s + 1) & 1) * BUF;
     const int r2 = r_begin + (s + 3) * BKT;   // the set written to LDS now (slab s+1) is refilled with slab s+3
@@ -406,19 +426,26 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
       } else {
         if (piece < NVP) store_p(nxt, piece, pv, p_kb);
         else if (piece < NST) store_q(nxt, piece - NVP, qv, q_kb);
-        else if (piece < NST + NVP) load_p(r2, piece - NST, pv, p_kb);
-        else if (piece < 2 * NST) load_q(r2, piece - NST - NVP, qv, q_kb);
-        else if (piece == 2 * NST) fetch_tabs(r2 + BKT);
+        else if (piece < NST + NVP) load_p(r2, piece - NST, pv, p_kb, tb);
+        else if (piece < 2 * NST) load_q(r2, piece - NST - NVP, qv, q_kb, tb);
+        else if (piece == 2 * NST) fetch_tabs(r2 + 2 * BKT, tb);   // this set's next refill (two slabs on)
         ++piece;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!(I2_ABLATE & 4)) __syncthreads();
   };
-  for (int s = 0; s < nslab; s += 2) {
-    slab_body(s, pv, qv, p_kb, q_kb);
-    if (s + 1 < nslab) slab_body(s + 1, pvB, qvB, p_kbB, q_kbB);
+  // The loop body is exactly two slabs and has ONE path back to its head.  (With an `if (s + 1 < nslab)`
+  // around the second slab the control-flow graph also contains "first half -> latch -> first half"; on
+  // that path the loads just issued into set A are the youngest, so the compiler's static s_waitcnt
+  // before the LDS stores of set A must cover it and becomes vmcnt(3..0): every iteration then waited
+  // for the loads of set B, issued less than one slab earlier, instead of only for its own.)
+  int s = 0;
+  for (; s + 1 < nslab; s += 2) {
+    slab_body(s, pv, qv, p_kb, q_kb, tbA);
+    slab_body(s + 1, pvB, qvB, p_kbB, q_kbB, tbB);
   }
+  if (s < nslab) slab_body(s, pv, qv, p_kb, q_kb, tbA);
 
   I2_STAMP(3);
   // ------------------------------------------------------------------ epilogue
