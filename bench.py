@@ -5,7 +5,7 @@ layers [64,64], VecNormalize on).
 
 One step = draw a minibatch from the HBM-resident replay (device Philox) + normalise + 3 CNN
 forwards + heads + losses + backward through both trainable CNNs + 3 Adam applies + Polyak update
-(17 kernel launches replayed as one hipGraph).
+(14 kernel launches replayed as one hipGraph).
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, data parallel,
 per-GPU batch fixed at 256 (weak scaling), one RCCL all-reduce of the flat fp32 gradient bucket
 per step; `value` counts batch-256 gradient computations per second over the whole job
