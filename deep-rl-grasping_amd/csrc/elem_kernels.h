@@ -477,6 +477,7 @@ struct QLossArgs {
   float* d_adv0; float* d_v0;             // gradients [B, D*n], [B]
   float* td; float* priority;             // [B, D], [B]
   DevScalars* sc;
+  float* row_part; unsigned* counter;     // [3 B] per-row partial sums, completion counter (zero between launches)
 };
 
 __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3) {
@@ -550,7 +551,8 @@ inline void q_loss_kernel(QLossArgs a) {
   q_loss_finish(a, s3[0], s3[1], s3[2]);
 }
 #else
-__global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
+// fallback for more than 64 bins per branch: one thread per row
+__global__ __launch_bounds__(256) void q_loss_rows_kernel(QLossArgs a) {
   __shared__ float red[3][256];
   const int t = threadIdx.x;
   float s3[3] = {0, 0, 0};
@@ -563,6 +565,99 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
     __syncthreads();
   }
   if (t == 0) q_loss_finish(a, red[0][0], red[1][0], red[2][0]);
+}
+
+// One wavefront per minibatch row, lane = bin (n <= 64): the bin loops of q_loss_row become wave reductions
+// (fixed butterfly order), the D branches stay a loop.  Row partial sums go to a.row_part; the last
+// workgroup to finish (device-scope counter) adds them in row order and runs q_loss_finish.
+__device__ __forceinline__ float q_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int D = a.D, n = a.n;
+  if (b < a.B) {
+    const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
+    const bool on = lane < n;
+    float qbest = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const long o = ((long)b * D + d) * n + lane;
+      float sv = on ? (a.double_q ? a.adv1 : a.adv2)[o] : -INFINITY;
+      const float tg = on ? a.adv2[o] : 0.f;
+      int si = lane;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {      // arg max, ties -> lowest bin (the sequential scan keeps the first maximum)
+        const float ov = __shfl_xor(sv, m, 64);
+        const int oi = __shfl_xor(si, m, 64);
+        if (ov > sv || (ov == sv && oi < si)) { sv = ov; si = oi; }
+      }
+      const float mean2 = q_wave_sum(tg);
+      qbest += a.v2[b] + __shfl(tg, si, 64) - mean2 * invn;
+    }
+    qbest *= invD;
+    const float y = a.rew[b] + a.gamma * (1.f - a.done[b]) * qbest;
+    const float w = a.weights[b];
+    float dv = 0.f, prio = 0.f, lossb = 0.f, qs = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const long o = ((long)b * D + d) * n + lane;
+      const float ad = on ? a.adv0[o] : 0.f;
+      const float mean0 = q_wave_sum(ad) * invn;
+      const int ai = (int)a.act[b * D + d];
+      const float q_sel = a.v0[b] + __shfl(ad, ai, 64) - mean0;
+      const float tdv = q_sel - y;
+      prio += fabsf(tdv);
+      qs += q_sel;
+      float err, dfd;
+      if (a.huber) {
+        const float at = fabsf(tdv);
+        err = at < 1.f ? 0.5f * tdv * tdv : at - 0.5f;
+        dfd = fminf(fmaxf(tdv, -1.f), 1.f);
+      } else {
+        err = tdv * tdv;
+        dfd = 2.f * tdv;
+      }
+      lossb += err;
+      const float g = w * invB * invD * dfd;
+      dv += g;
+      if (on) a.d_adv0[o] = g * ((lane == ai ? 1.f : 0.f) - invn);
+      if (lane == 0) a.td[b * D + d] = tdv;
+    }
+    if (lane == 0) {
+      a.d_v0[b] = dv;
+      a.priority[b] = prio;
+      a.row_part[3 * b] = w * lossb * invD;
+      a.row_part[3 * b + 1] = qs * invD;
+      a.row_part[3 * b + 2] = prio * invD;
+    }
+  }
+  // ---- last workgroup: batch sums in row order
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = atomicAdd(a.counter, 1u);
+    last = done == gridDim.x - 1;
+    if (last) *a.counter = 0u;                 // ready for the next launch (graph replay)
+  }
+  __syncthreads();
+  if (last) {                                   // fixed tree order: deterministic
+    __shared__ float red[3][256];
+    __threadfence();
+    const int t = threadIdx.x;
+    const volatile float* rp = a.row_part;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int r = t; r < a.B; r += 256) { s0 += rp[3 * r]; s1 += rp[3 * r + 1]; s2 += rp[3 * r + 2]; }
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off)
+        for (int k = 0; k < 3; ++k) red[k][t] += red[k][t + off];
+      __syncthreads();
+    }
+    if (t == 0) q_loss_finish(a, red[0][0], red[1][0], red[2][0]);
+  }
 }
 #endif
 

@@ -1662,7 +1662,7 @@ int grl_ctx::plan_q() {
       op.run = [self](hipStream_t s) {
         PerArgs q = self->per;
         q.prio_in = self->q_prio;
-        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(64), 0, s, q, (const int64_t*)self->idx_buf);
+        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(256), 0, s, q, (const int64_t*)self->idx_buf);
       };
       ops_per_update.push_back(op);
     }
@@ -1717,8 +1717,18 @@ int grl_ctx::plan_q() {
     qa.adv0 = net[0].adv; qa.v0 = net[0].v; qa.adv1 = net[1].adv; qa.adv2 = net[2].adv; qa.v2 = net[2].v;
     qa.act = act; qa.rew = rew; qa.done = done; qa.weights = eps_buf;
     qa.d_adv0 = gact.adv; qa.d_v0 = gact.v; qa.td = q_td; qa.priority = q_prio; qa.sc = sc;
+    qa.row_part = wk.f32(3 * (int64_t)B);
+    qa.counter = (unsigned*)wk.take(16);
+    zero_once.push_back({qa.counter, 16});
     Op op; op.tag = "q_loss";
-    op.run = [qa](hipStream_t s) { hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, qa); };
+    op.run = [qa](hipStream_t s) {
+#ifdef GRL_HOSTEMU
+      hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, qa);
+#else
+      if (qa.n <= 64) hipLaunchKernelGGL(q_loss_kernel, dim3((qa.B + 3) / 4), dim3(256), 0, s, qa);
+      else hipLaunchKernelGGL(q_loss_rows_kernel, dim3(1), dim3(256), 0, s, qa);
+#endif
+    };
     ops_grads.push_back(op);
   }
   // =============================================================== backward (online net on s)
@@ -2244,6 +2254,7 @@ static int check_cfg(const grl_config* c) {
     if (c->q_n_common < 0 || c->q_n_common > GRL_MAX_LAYERS || c->q_n_branch < 1 || c->q_n_branch > GRL_MAX_LAYERS ||
         c->q_n_value < 1 || c->q_n_value > GRL_MAX_LAYERS)
       return fail(GRL_ERR_INVALID, "tower depths out of range (branch and value towers need >= 1 hidden layer)");
+    if (c->q_per && c->batch_size > 1024) return fail(GRL_ERR_INVALID, "prioritised replay supports batch_size <= 1024");
   }
   if (c->extractor == GRL_EXTRACTOR_MLP) {
     if (c->obs_dim < 1) return fail(GRL_ERR_INVALID, "obs_dim must be >= 1 for the MLP extractor");

@@ -205,9 +205,11 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
 }
 #endif
 
-// priorities of the minibatch just trained on (sequential: a transition drawn twice keeps the later value,
-// as a Python loop over the batch would)
-__global__ void per_update_kernel(PerArgs a, const int64_t* idx) {
+// priorities of the minibatch just trained on.  A transition drawn twice keeps the value of its LAST
+// occurrence (what a Python loop over the batch leaves behind): every sample writes unless a later sample
+// names the same index.  One workgroup; B <= 1024.
+#ifdef GRL_HOSTEMU
+inline void per_update_kernel(PerArgs a, const int64_t* idx) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float mx = a.st->max_priority;
   for (int k = 0; k < a.B; ++k) {
@@ -217,5 +219,30 @@ __global__ void per_update_kernel(PerArgs a, const int64_t* idx) {
   }
   a.st->max_priority = mx;
 }
+#else
+__global__ __launch_bounds__(256) void per_update_kernel(PerArgs a, const int64_t* idx) {
+  __shared__ int64_t sidx[1024];
+  __shared__ float smax[256];
+  const int t = threadIdx.x;
+  for (int k = t; k < a.B; k += 256) sidx[k] = idx[k];
+  __syncthreads();
+  float mx = 0.f;
+  for (int k = t; k < a.B; k += 256) {
+    const float pr = a.prio_in[k] + a.eps;
+    mx = fmaxf(mx, pr);
+    const int64_t me = sidx[k];
+    bool later = false;
+    for (int j = k + 1; j < a.B; ++j) later = later || sidx[j] == me;
+    if (!later) a.p[me] = powf(pr, a.alpha);
+  }
+  smax[t] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) smax[t] = fmaxf(smax[t], smax[t + off]);
+    __syncthreads();
+  }
+  if (t == 0) a.st->max_priority = fmaxf(a.st->max_priority, smax[0]);
+}
+#endif
 
 }  // namespace grl
