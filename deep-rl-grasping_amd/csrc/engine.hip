@@ -29,6 +29,7 @@
 #include "heads_kernels.h"
 #include "per_kernels.h"
 #include "ae_kernels.h"
+#include "q_kernels.h"
 
 namespace grl {
 
@@ -1698,7 +1699,106 @@ int grl_ctx::plan_q() {
     };
     ops_grads.push_back(op);
   }
+  // ---- row-local chains (q_kernels.h) when every width fits the head primitives; else one GEMM launch per layer
+  bool fused_q = false;
   {
+    const char* nf = getenv("GRL_NO_FUSED_Q");
+    bool ok = !(nf && nf[0] == '1') && nb <= 64 && Lc + std::max(Lb, Lv) <= GRL_MAX_LAYERS;
+    for (int k = 0; k < Lc; ++k) ok = ok && c.q_common[k] <= HT_MAXW;
+    for (int l = 0; l < Lb; ++l) ok = ok && c.q_branch[l] <= HT_MAXW;
+    for (int l = 0; l < Lv; ++l) ok = ok && c.q_value[l] <= HT_MAXW;
+    if (Lc > 0) ok = ok && c.q_common[Lc - 1] <= HT_MAXA;
+    fused_q = ok;
+  }
+  QFusedArgs qf;
+  memset(&qf, 0, sizeof(qf));
+  if (fused_q) {
+    const QNetP* Wn[3] = {&Pon, &Pon, &Ptg};
+    const float* xin[3] = {feat[0], feat[2], feat[2]};
+    auto tower_w = [&](const QNetP& W, int tw, int l) { return P + (tw < D ? W.bw[tw][l] : W.vw[l]); };
+    auto tower_b = [&](const QNetP& W, int tw, int l) { return P + (tw < D ? W.bb[tw][l] : W.vb[l]); };
+    auto tower_hid = [&](int tw, int l) { return tw < D ? c.q_branch[l] : c.q_value[l]; };
+    auto tower_z = [&](const QNetAct& a, int tw, int l) { return tw < D ? a.zb[tw][l] : a.zv[l]; };
+    std::vector<HtHead> hf, hb;
+    std::vector<IgemmProb> l0;
+    for (int n = 0; n < 3; ++n) {
+      const QNetP& W = *Wn[n];
+      const QNetAct& a = net[n];
+      float* u_trunk = nullptr;
+      if (Lc > 0) {   // layer 0 of the trunk: one GEMM (K = obs_dim), no bias / activation (applied by the chain)
+        u_trunk = wk.f32((int64_t)B * c.q_common[0]);
+        l0.push_back(dense_fwd(xin[n], ldf, c.obs_dim, nullptr, 0, 0, B, P + W.cw[0], c.q_common[0], nullptr, u_trunk,
+                               c.q_common[0], ACT_NONE));
+      }
+      for (int tw = 0; tw <= D; ++tw) {
+        const int Lt = tw < D ? Lb : Lv;
+        HtHead h;
+        memset(&h, 0, sizeof(h));
+        int li = 0;
+        if (Lc > 0) {
+          h.u = u_trunk; h.ldu = c.q_common[0]; h.b0 = P + W.cb[0]; h.H0 = c.q_common[0];
+          h.z0 = tw == 0 ? a.zc[0] : nullptr;             // the trunk is recomputed per tower, stored once
+          h.hid[0] = c.q_common[0];
+          for (li = 1; li < Lc; ++li) {
+            h.w[li] = P + W.cw[li]; h.b[li] = P + W.cb[li]; h.hid[li] = c.q_common[li];
+            h.z[li] = tw == 0 ? a.zc[li] : nullptr;
+          }
+          for (int l = 0; l < Lt; ++l, ++li) {
+            h.w[li] = tower_w(W, tw, l); h.b[li] = tower_b(W, tw, l); h.hid[li] = tower_hid(tw, l); h.z[li] = tower_z(a, tw, l);
+          }
+        } else {      // no trunk: layer 0 of every tower from the GEMM launch
+          float* u = wk.f32((int64_t)B * tower_hid(tw, 0));
+          l0.push_back(dense_fwd(xin[n], ldf, c.obs_dim, nullptr, 0, 0, B, tower_w(W, tw, 0), tower_hid(tw, 0), nullptr, u,
+                                 tower_hid(tw, 0), ACT_NONE));
+          h.u = u; h.ldu = tower_hid(tw, 0); h.b0 = tower_b(W, tw, 0); h.H0 = tower_hid(tw, 0);
+          h.z0 = tower_z(a, tw, 0); h.hid[0] = h.H0;
+          for (li = 1; li < Lt; ++li) {
+            h.w[li] = tower_w(W, tw, li); h.b[li] = tower_b(W, tw, li); h.hid[li] = tower_hid(tw, li); h.z[li] = tower_z(a, tw, li);
+          }
+        }
+        h.L = li;
+        h.n_out = 1; h.out_dim = tw < D ? nb : 1;
+        h.ow[0] = tower_w(W, tw, Lt); h.ob[0] = tower_b(W, tw, Lt);
+        h.out[0] = tw < D ? a.adv + tw * nb : a.v;
+        h.ld_out = tw < D ? D * nb : 1;
+        hf.push_back(h);
+      }
+    }
+    // backward views of the online net on s
+    const QNetAct& a = net[0];
+    for (int tw = 0; tw <= D; ++tw) {
+      const int Lt = tw < D ? Lb : Lv;
+      HtHead h;
+      memset(&h, 0, sizeof(h));
+      h.H0 = tower_hid(tw, 0); h.L = Lt; h.hid[0] = h.H0;
+      h.z0 = tower_z(a, tw, 0); h.g0 = tower_z(gact, tw, 0); h.ldg0 = h.H0;
+      if (Lc > 0) { h.n_xa = c.q_common[Lc - 1]; h.w0a = tower_w(Pon, tw, 0); }
+      for (int l = 1; l < Lt; ++l) {
+        h.w[l] = tower_w(Pon, tw, l); h.hid[l] = tower_hid(tw, l); h.z[l] = tower_z(a, tw, l); h.g[l] = tower_z(gact, tw, l);
+      }
+      h.n_out = 1; h.out_dim = tw < D ? nb : 1; h.ow[0] = tower_w(Pon, tw, Lt);
+      hb.push_back(h);
+    }
+    qf.fwd = upload_vec(wk, hf);
+    qf.bwd_tw = upload_vec(wk, hb);
+    qf.B = B; qf.D = D; qf.nb = nb; qf.Ht = Lc > 0 ? c.q_common[Lc - 1] : 0;
+    qf.d_adv = gact.adv; qf.d_v = gact.v; qf.trunk_scale = c.q_trunk_scale;
+    if (Lc > 0) {
+      HtHead h;
+      memset(&h, 0, sizeof(h));
+      h.H0 = c.q_common[0]; h.L = Lc; h.z0 = a.zc[0]; h.g0 = gact.zc[0]; h.ldg0 = h.H0; h.hid[0] = h.H0;
+      for (int l = 1; l < Lc; ++l) { h.w[l] = P + Pon.cw[l]; h.hid[l] = c.q_common[l]; h.z[l] = a.zc[l]; h.g[l] = gact.zc[l]; }
+      qf.bwd_tr = upload_vec(wk, std::vector<HtHead>{h});
+      qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
+    }
+    add_launch(ops_grads, "q_l0", 0, l0);
+    Op op; op.tag = "q_fwd";
+    const QFusedArgs fa = qf;
+    op.run = [fa](hipStream_t s) {
+      hipLaunchKernelGGL(q_fwd_fused_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 3, fa.D + 1), dim3(256), 0, s, fa);
+    };
+    ops_grads.push_back(op);
+  } else {
     std::vector<std::vector<IgemmProb>> sc_[3], sh_[3];
     std::vector<IgemmProb> so_[3];
     fwd_stages(Pon, net[0], feat[0], ldf, B, sc_[0], sh_[0], so_[0]);
@@ -1734,40 +1834,50 @@ int grl_ctx::plan_q() {
   // =============================================================== backward (online net on s)
   {
     const QNetAct& a = net[0];
-    std::vector<IgemmProb> pr;      // output layers -> last hidden
-    for (int br = 0; br < D; ++br)
-      pr.push_back(dense_bwd({{gact.adv + br * nb, D * nb, nb, P + Pon.bw[br][Lb]}}, B, 0, c.q_branch[Lb - 1],
-                             gact.zb[br][Lb - 1], c.q_branch[Lb - 1], a.zb[br][Lb - 1]));
-    pr.push_back(dense_bwd({{gact.v, 1, 1, P + Pon.vw[Lv]}}, B, 0, c.q_value[Lv - 1], gact.zv[Lv - 1], c.q_value[Lv - 1],
-                           a.zv[Lv - 1]));
-    add_launch(ops_grads, "q_bwd", 1, pr);
-    for (int l = std::max(Lb, Lv) - 1; l >= 1; --l) {
-      std::vector<IgemmProb> p2;
-      if (l < Lb)
-        for (int br = 0; br < D; ++br)
-          p2.push_back(dense_bwd({{gact.zb[br][l], c.q_branch[l], c.q_branch[l], P + Pon.bw[br][l]}}, B, 0,
-                                 c.q_branch[l - 1], gact.zb[br][l - 1], c.q_branch[l - 1], a.zb[br][l - 1]));
-      if (l < Lv)
-        p2.push_back(dense_bwd({{gact.zv[l], c.q_value[l], c.q_value[l], P + Pon.vw[l]}}, B, 0, c.q_value[l - 1],
-                               gact.zv[l - 1], c.q_value[l - 1], a.zv[l - 1]));
-      add_launch(ops_grads, "q_bwd", 1, p2);
-    }
-    if (Lc > 0) {   // into the shared trunk: sum over the D+1 towers in chunks of three reduction parts
-      std::vector<BwdPart> towers;
-      for (int br = 0; br < D; ++br) towers.push_back({gact.zb[br][0], c.q_branch[0], c.q_branch[0], P + Pon.bw[br][0]});
-      towers.push_back({gact.zv[0], c.q_value[0], c.q_value[0], P + Pon.vw[0]});
-      for (size_t t0 = 0; t0 < towers.size(); t0 += 3) {
-        std::vector<BwdPart> chunk(towers.begin() + t0, towers.begin() + std::min(towers.size(), t0 + 3));
-        const bool last = t0 + 3 >= towers.size();
-        IgemmProb p = dense_bwd(chunk, B, 0, hdim, gact.zc[Lc - 1], hdim, last ? a.zc[Lc - 1] : nullptr);
-        p.accumulate = t0 > 0 ? 1 : 0;
-        p.out_scale = c.q_trunk_scale;
-        add_launch(ops_grads, "q_bwd", 1, {p});
+    if (fused_q) {
+      const QFusedArgs fa = qf;
+      Op op; op.tag = "q_bwd";
+      op.run = [fa](hipStream_t s) {
+        hipLaunchKernelGGL(q_bwd_towers_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, fa.D + 1), dim3(256), 0, s, fa);
+        if (fa.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, dim3((fa.B + HT_RB - 1) / HT_RB), dim3(256), 0, s, fa);
+      };
+      ops_grads.push_back(op);
+    } else {
+      std::vector<IgemmProb> pr;      // output layers -> last hidden
+      for (int br = 0; br < D; ++br)
+        pr.push_back(dense_bwd({{gact.adv + br * nb, D * nb, nb, P + Pon.bw[br][Lb]}}, B, 0, c.q_branch[Lb - 1],
+                               gact.zb[br][Lb - 1], c.q_branch[Lb - 1], a.zb[br][Lb - 1]));
+      pr.push_back(dense_bwd({{gact.v, 1, 1, P + Pon.vw[Lv]}}, B, 0, c.q_value[Lv - 1], gact.zv[Lv - 1], c.q_value[Lv - 1],
+                             a.zv[Lv - 1]));
+      add_launch(ops_grads, "q_bwd", 1, pr);
+      for (int l = std::max(Lb, Lv) - 1; l >= 1; --l) {
+        std::vector<IgemmProb> p2;
+        if (l < Lb)
+          for (int br = 0; br < D; ++br)
+            p2.push_back(dense_bwd({{gact.zb[br][l], c.q_branch[l], c.q_branch[l], P + Pon.bw[br][l]}}, B, 0,
+                                   c.q_branch[l - 1], gact.zb[br][l - 1], c.q_branch[l - 1], a.zb[br][l - 1]));
+        if (l < Lv)
+          p2.push_back(dense_bwd({{gact.zv[l], c.q_value[l], c.q_value[l], P + Pon.vw[l]}}, B, 0, c.q_value[l - 1],
+                                 gact.zv[l - 1], c.q_value[l - 1], a.zv[l - 1]));
+        add_launch(ops_grads, "q_bwd", 1, p2);
       }
-      for (int k = Lc - 1; k >= 1; --k)
-        add_launch(ops_grads, "q_bwd", 1,
-                   {dense_bwd({{gact.zc[k], c.q_common[k], c.q_common[k], P + Pon.cw[k]}}, B, 0, c.q_common[k - 1],
-                              gact.zc[k - 1], c.q_common[k - 1], a.zc[k - 1])});
+      if (Lc > 0) {   // into the shared trunk: sum over the D+1 towers in chunks of three reduction parts
+        std::vector<BwdPart> towers;
+        for (int br = 0; br < D; ++br) towers.push_back({gact.zb[br][0], c.q_branch[0], c.q_branch[0], P + Pon.bw[br][0]});
+        towers.push_back({gact.zv[0], c.q_value[0], c.q_value[0], P + Pon.vw[0]});
+        for (size_t t0 = 0; t0 < towers.size(); t0 += 3) {
+          std::vector<BwdPart> chunk(towers.begin() + t0, towers.begin() + std::min(towers.size(), t0 + 3));
+          const bool last = t0 + 3 >= towers.size();
+          IgemmProb p = dense_bwd(chunk, B, 0, hdim, gact.zc[Lc - 1], hdim, last ? a.zc[Lc - 1] : nullptr);
+          p.accumulate = t0 > 0 ? 1 : 0;
+          p.out_scale = c.q_trunk_scale;
+          add_launch(ops_grads, "q_bwd", 1, {p});
+        }
+        for (int k = Lc - 1; k >= 1; --k)
+          add_launch(ops_grads, "q_bwd", 1,
+                     {dense_bwd({{gact.zc[k], c.q_common[k], c.q_common[k], P + Pon.cw[k]}}, B, 0, c.q_common[k - 1],
+                                gact.zc[k - 1], c.q_common[k - 1], a.zc[k - 1])});
+      }
     }
     // weight gradients
     std::vector<IgemmProb> wg;

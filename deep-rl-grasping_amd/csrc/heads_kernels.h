@@ -41,6 +41,7 @@ struct HtHead {
   // output layers (1 for vf / qf, 2 for pi: mu and log_std), each [hid[L-1], out_dim]
   int n_out, out_dim;
   const float* ow[2]; const float* ob[2]; float* out[2];
+  int ld_out;                              // row stride of out[k] (0: out_dim); activations z0 / z[l] may be nullptr (not stored)
   const float* dout[2]; int ld_dout;       // backward: gradient w.r.t. the outputs [B, out_dim], row stride ld_dout
   float* da; int ld_da;                    // backward: gradient w.r.t. xa (nullptr: not needed)
 };
@@ -160,14 +161,14 @@ inline void ht_ref_fwd_head(const HtHead& h, int row, const float* xa_row) {
     for (int a = 0; a < h.n_xa; ++a) acc = fmaf(xa_row[a], h.w0a[a * h.H0 + n], acc);
     acc += h.b0[n];
     zin[n] = fmaxf(acc, 0.f);
-    h.z0[(long)row * h.H0 + n] = zin[n];
+    if (h.z0) h.z0[(long)row * h.H0 + n] = zin[n];
   }
   for (int l = 1; l < h.L; ++l) {
     for (int n = 0; n < h.hid[l]; ++n) {
       float acc = 0.f;
       for (int k = 0; k < h.hid[l - 1]; ++k) acc = fmaf(zin[k], h.w[l][k * h.hid[l] + n], acc);
       zout[n] = fmaxf(acc + h.b[l][n], 0.f);
-      h.z[l][(long)row * h.hid[l] + n] = zout[n];
+      if (h.z[l]) h.z[l][(long)row * h.hid[l] + n] = zout[n];
     }
     for (int n = 0; n < h.hid[l]; ++n) zin[n] = zout[n];
   }
@@ -176,7 +177,7 @@ inline void ht_ref_fwd_head(const HtHead& h, int row, const float* xa_row) {
     for (int o = 0; o < h.out_dim; ++o) {
       float acc = 0.f;
       for (int n = 0; n < HL; ++n) acc = fmaf(zin[n], h.ow[k][n * h.out_dim + o], acc);
-      h.out[k][(long)row * h.out_dim + o] = acc + h.ob[k][o];
+      h.out[k][(long)row * (h.ld_out ? h.ld_out : h.out_dim) + o] = acc + h.ob[k][o];
     }
 }
 
@@ -196,15 +197,18 @@ inline void heads_fwd_kernel(HeadsFwdArgs a) {
   }
 }
 
-// dvals: n_out * out_dim output gradients of this row
-inline void ht_ref_bwd_head(const HtHead& h, int row, const float* dvals, float* da_row) {
+// dvals: n_out * out_dim output gradients of this row; or dz_last != nullptr: the gradient w.r.t. the last
+// hidden activation is given directly (a trunk whose consumers were differentiated elsewhere)
+inline void ht_ref_bwd_head(const HtHead& h, int row, const float* dvals, float* da_row, const float* dz_last = nullptr) {
   float gin[HT_MAXW], gout[HT_MAXW];
   const int HL = h.hid[h.L - 1];
   const float* zl = h.L == 1 ? h.z0 : h.z[h.L - 1];
   for (int n = 0; n < HL; ++n) {
     float acc = 0.f;
-    for (int k = 0; k < h.n_out; ++k)
-      for (int o = 0; o < h.out_dim; ++o) acc = fmaf(dvals[k * h.out_dim + o], h.ow[k][n * h.out_dim + o], acc);
+    if (dz_last) acc = dz_last[n];
+    else
+      for (int k = 0; k < h.n_out; ++k)
+        for (int o = 0; o < h.out_dim; ++o) acc = fmaf(dvals[k * h.out_dim + o], h.ow[k][n * h.out_dim + o], acc);
     gin[n] = zl[(long)row * HL + n] > 0.f ? acc : 0.f;
   }
   for (int l = h.L - 1; l >= 1; --l) {
@@ -404,7 +408,7 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
         const int row = row0 + 4 * rg + i;
         const float v = fmaxf(acc[i] + bn, 0.f);
         s.zT[0][n][4 * rg + i] = v;
-        if (row < B && store) h.z0[(long)row * h.H0 + n] = v;
+        if (row < B && store && h.z0) h.z0[(long)row * h.H0 + n] = v;
         opart[i] = fmaf(v, own, opart[i]);
       }
     }
@@ -429,7 +433,7 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
           const int row = row0 + 4 * rg + i;
           const float v = fmaxf(acc[i] + bn, 0.f);
           dst[n][4 * rg + i] = v;
-          if (row < B && store) h.z[l][(long)row * Hout + n] = v;
+          if (row < B && store && h.z[l]) h.z[l][(long)row * Hout + n] = v;
           opart[i] = fmaf(v, own, opart[i]);
         }
       }
@@ -458,7 +462,7 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
           const int row = row0 + 4 * rg + i;
           const float v = acc[i] + bo;
           if (keep_out) s.oT[k * h.out_dim + cl][4 * rg + i] = v;
-          if (row < B && store) h.out[k][(long)row * h.out_dim + cl] = v;
+          if (row < B && store) h.out[k][(long)row * (h.ld_out ? h.ld_out : h.out_dim) + cl] = v;
         }
       }
     }
@@ -504,7 +508,12 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsFwdArgs a) {
 
 // backward of one head for the 16 rows of this workgroup.  oT must hold the output gradients
 // [k*out_dim + o][row].  Writes every g[l]; optionally d xa (to global and to xaT).
-__device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, HtLds& s, float* da, int ld_da) {
+// dz_parts != nullptr: instead of output layers, the gradient w.r.t. the last hidden ACTIVATION is given as
+// n_parts partial sums [n_parts][B, HL] (added in order, then scaled): a trunk whose consumers (towers) were
+// differentiated by other workgroups.
+__device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, HtLds& s, float* da, int ld_da,
+                                            const float* dz_parts = nullptr, int n_parts = 0, long part_stride = 0,
+                                            float dz_scale = 1.f) {
   const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
   const int L = h.L;
   HtW pw;   // kernel of the stage after the output layers: last hidden layer, or the action rows (d xa)
@@ -516,13 +525,22 @@ __device__ __forceinline__ void ht_bwd_head(const HtHead& h, int row0, int B, Ht
     const float* zl = L == 1 ? h.z0 : h.z[L - 1];
     float* gl = L == 1 ? nullptr : h.g[L - 1];
     const bool one = h.n_out == 1 && h.out_dim == 1;   // vf / qf heads: a rank-1 product, straight from global
-    if (!one)
+    if (!one && !dz_parts)
       for (int k = 0; k < h.n_out; ++k) ht_stage_w_at(h.ow[k], HL, h.out_dim, s.W + k * HL * (h.out_dim + 1));
     for (int c0 = 0; c0 < HL; c0 += 64) {
       const int n = c0 + cl;
       if (n < HL) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (one) {
+        if (dz_parts) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * rg + i;
+            float sum = 0.f;
+            if (row < B)
+              for (int p = 0; p < n_parts; ++p) sum += dz_parts[p * part_stride + (long)row * HL + n];
+            acc[i] = sum * dz_scale;
+          }
+        } else if (one) {
           const float w = h.ow[0][n];
           const ht_f4 d = *(const ht_f4*)&s.oT[0][4 * rg];
           acc[0] = fmaf(d.x, w, 0.f); acc[1] = fmaf(d.y, w, 0.f); acc[2] = fmaf(d.z, w, 0.f); acc[3] = fmaf(d.w, w, 0.f);

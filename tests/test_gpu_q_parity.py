@@ -11,6 +11,13 @@ def test_q_update_matches_oracle(name):
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 
+@pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
+def test_q_update_per_layer_gemm_fallback(name, monkeypatch):
+    """GRL_NO_FUSED_Q=1: the per-layer GEMM launches stay correct next to the row-local chains."""
+    monkeypatch.setenv("GRL_NO_FUSED_Q", "1")
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+
+
 def test_q_update_with_vecnormalize():
     qu.run_and_compare(qu.make_q_case(normalize=True, **qu.CASES["bdq"]))
 

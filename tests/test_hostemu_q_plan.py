@@ -13,6 +13,14 @@ def test_q_plan_matches_oracle(hostemu_lib, name):
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
 
 
+@pytest.mark.parametrize("name", ["dqn", "bdq_5_branches"])
+def test_q_plan_per_layer_gemm_fallback(hostemu_lib, name, monkeypatch):
+    """GRL_NO_FUSED_Q=1: one GEMM launch per layer instead of the row-local chains of q_kernels.h."""
+    monkeypatch.setenv("GRL_NO_FUSED_Q", "1")
+    case = qu.make_q_case(**qu.CASES[name])
+    qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+
+
 def test_q_plan_with_vecnormalize(hostemu_lib):
     case = qu.make_q_case(normalize=True, **qu.CASES["bdq"])
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
