@@ -541,6 +541,7 @@ __device__ __forceinline__ void q_loss_finish(const QLossArgs& a, float loss, fl
   sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
   sc->beta1_power *= 0.9f;
   sc->beta2_power *= 0.999f;
+  if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch was drawn by the device RNG
 }
 
 #ifdef GRL_HOSTEMU
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
 struct RngArgs {
   DevScalars* sc; uint64_t seed; int B, A;
   int64_t* idx; float* eps;
+  float* ones; int mark;     // optional: ones[b] = 1 (uniform importance weights); mark: set rng_used instead of a separate tick launch
 };
 
 __global__ __launch_bounds__(256) void rng_kernel(RngArgs a) {
@@ -805,7 +807,9 @@ __global__ __launch_bounds__(256) void rng_kernel(RngArgs a) {
       a.eps[b * a.A + j0] = rad * cs;
       if (j0 + 1 < a.A) a.eps[b * a.A + j0 + 1] = rad * sn;
     }
+    if (a.ones) a.ones[b] = 1.f;
   }
+  if (a.mark && b == 0) a.sc->rng_used = 1u;
 }
 
 __global__ void rng_tick_kernel(DevScalars* sc) { sc->rng_step += 1; }

@@ -1652,8 +1652,7 @@ int grl_ctx::plan_q() {
         PerArgs q = pa;
         q.prio_in = self->q_prio;
         hipLaunchKernelGGL(per_blocksum_kernel, dim3(nb), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb);
-        if (!mode) hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, s, q.sc);
+        hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb);   // RNG mode: marks rng_used, q_loss ticks
       };
       (mode ? ops_per_u : ops_per_rng).push_back(op);
     }
@@ -1672,12 +1671,9 @@ int grl_ctx::plan_q() {
   // =============================================================== RNG (uniform indices; weights = 1)
   {
     Op op; op.tag = "rng";
-    RngArgs ra{sc, c.seed, B, 1, idx_buf, eps_buf};
-    float* wbuf = eps_buf; const int Bq = B;
-    op.run = [ra, wbuf, Bq](hipStream_t s) {
+    RngArgs ra{sc, c.seed, B, 1, idx_buf, eps_buf, eps_buf, 1};   // weights = 1; the loss kernel advances rng_step
+    op.run = [ra](hipStream_t s) {
       hipLaunchKernelGGL(rng_kernel, dim3((ra.B + 255) / 256), dim3(256), 0, s, ra);
-      hipLaunchKernelGGL(fill_kernel, dim3((Bq + 255) / 256), dim3(256), 0, s, wbuf, 1.0f, Bq);
-      hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, s, ra.sc);
     };
     ops_rng.push_back(op);
   }

@@ -84,7 +84,7 @@ inline void per_sample_kernel(PerArgs a, int n_blocks) {
   a.idx_out[k] = i;
   const double ps = (double)a.p[i] / total, pm = (double)pmin / total;
   a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));
-  if (k == 0) { a.st->total = total; a.st->p_min = pmin; }
+  if (k == 0) { a.st->total = total; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }
 }
 #else
 __global__ __launch_bounds__(256) void per_blocksum_kernel(PerArgs a) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
     a.idx_out[k] = idx;
     const double ps = (double)a.p[idx] / total, pm = (double)pmin / total;
     a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));
-    if (k == 0) { a.st->total = total; a.st->p_min = pmin; }
+    if (k == 0) { a.st->total = total; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }   // q_loss_kernel advances rng_step
   }
 }
 #endif
