@@ -30,6 +30,7 @@
 #include "per_kernels.h"
 #include "ae_kernels.h"
 #include "q_kernels.h"
+#include "igemm_sk.h"
 
 namespace grl {
 
@@ -101,6 +102,7 @@ struct Launch {
   bool v2 = false;              // igemm2_kernel (vectorised staging) instead of igemm_kernel
   int cfg = 0;                  // igemm2 workgroup shape
   int flags = 0;                // igemm2 instantiation flags (I2F_*)
+  int sk = 0;                   // igemm_sk_kernel (streaming short-K forward): the reduction length, or 0
   std::vector<IgemmProb> probs;
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
@@ -661,6 +663,45 @@ struct grl_ctx {
         if (al16(p.c) && (p.ldc % 4) == 0 && (p.N % 4) == 0 && (p.slab_stride % 4) == 0 &&
             (!p.c_tab_i || (p.vflags & VF_CT4)) && (!p.relu_mask || al16(p.relu_mask)) && (!p.bias || al16(p.bias)))
           p.vflags |= VF_C_VEC;
+    // short reductions with a narrow output (first convolution of the extractors): streaming kernel, igemm_sk.h
+    {
+      const char* ns = getenv("GRL_NO_SK");
+      bool ok = l->v2 && variant == 0 && l->pm == PM_TABLE && l->qm == QM_AFFINE && l->flags == 0 && !(ns && ns[0] == '1');
+      for (auto& p : l->probs)
+        ok = ok && (p.K == 64 || p.K == 32) && p.K == l->probs[0].K && p.N <= 32 && (p.N % 4) == 0 && p.split == 1 &&
+             (p.vflags & VF_P_TABS) && (p.vflags & VF_C_VEC) && !p.c_tab_i && !p.relu_mask && !p.accumulate &&
+             p.q_ld_j[0] == 1 && (p.q_ld_r[0] % 4) == 0 && p.M >= 256;
+      l->sk = ok ? l->probs[0].K : 0;
+    }
+    if (l->sk) {
+      long total = 0;
+      for (auto& p : l->probs) total += (p.M + 127) / 128;
+      const int per = (int)std::max<long>(1, (total + 511) / 512);     // ~2 workgroups per CU, each streams `per` tiles
+      std::vector<int4> work;
+      double flops = 0;
+      for (size_t pi = 0; pi < l->probs.size(); ++pi) {
+        const IgemmProb& p = l->probs[pi];
+        flops += 2.0 * p.M * p.N * p.K;
+        const int nt = (p.M + 127) / 128;
+        for (int t0 = 0; t0 < nt; t0 += per) work.push_back(make_int4((int)pi, t0, std::min(per, nt - t0), 0));
+      }
+      l->n_tiles = (int)work.size();
+      l->d_probs = upload_vec(wk, l->probs);
+      l->d_tiles = upload_vec(wk, work);
+      launches.push_back(l);
+      if (getenv("GRL_PLAN_DUMP"))
+        fprintf(stderr, "grl plan: %-14s streaming short-K kernel K %d  probs %zu  workgroups %d x %d tiles\n", tag.c_str(), l->sk,
+                l->probs.size(), l->n_tiles, per);
+      Op op;
+      op.tag = tag;
+      op.flops = flops;
+      op.run = [l](hipStream_t s) {
+        if (l->sk == 64) hipLaunchKernelGGL((igemm_sk_kernel<64>), dim3(l->n_tiles), dim3(256), 0, s, l->d_probs, l->d_tiles);
+        else hipLaunchKernelGGL((igemm_sk_kernel<32>), dim3(l->n_tiles), dim3(256), 0, s, l->d_probs, l->d_tiles);
+      };
+      ops.push_back(op);
+      return;
+    }
     const int BMt = l->v2 ? i2_bm(l->cfg) : 64, BNt = l->v2 ? i2_bn(l->cfg) : 64;
 
     std::vector<int4> tiles;
