@@ -80,6 +80,23 @@ def test_graph_replay_equals_eager(monkeypatch):
         assert np.array_equal(engs[0][n], engs[1][n]), n
 
 
+@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM"])
+def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
+    """igemm_sk_kernel accumulates exactly like igemm2_kernel, and the launch-merging / Adam-fusion switches only
+    regroup work: parameters after three updates are bit-identical.  (igemm_kernel shares the k-order too, but
+    igemm2's workgroup shapes that split the reduction over waves add their partial sums in another order.)"""
+    case = pu.make_case(extractor="augmented", kind="depth", B=32, n_replay=96, n_steps=3)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv(var, flag)
+        eng = pu.engine_setup(case)
+        eng.train(3, case["idx"], case["eps"])
+        outs.append(eng.get_parameters())
+        eng.close()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+
+
 def test_split_api_equals_fused_and_is_deterministic():
     case = pu.make_case(extractor="augmented", kind="depth", B=16, n_replay=64, n_steps=3)
     outs = []
