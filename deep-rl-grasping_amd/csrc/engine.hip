@@ -690,8 +690,8 @@ struct grl_ctx {
       l->d_tiles = upload_vec(wk, work);
       launches.push_back(l);
       if (getenv("GRL_PLAN_DUMP"))
-        fprintf(stderr, "grl plan: %-14s streaming short-K kernel K %d  probs %zu  workgroups %d x %d tiles\n", tag.c_str(), l->sk,
-                l->probs.size(), l->n_tiles, per);
+        fprintf(stderr, "grl plan: %-14s streaming short-K kernel K %d  probs %zu  row tiles per workgroup %d  tiles %d\n",
+                tag.c_str(), l->sk, l->probs.size(), per, l->n_tiles);
       Op op;
       op.tag = tag;
       op.flops = flops;
