@@ -1,0 +1,66 @@
+"""Data-parallel update with REAL engines: two processes share the one MI355X of the test box, each owns an
+engine with half of the minibatch, and exchange the flat gradient bucket (a device tensor) over gloo --
+`grasp_rl.parallel.DataParallelSac`, i.e. bench.py's N > 1 path minus RCCL itself.  Must equal one engine
+updating on the whole minibatch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import parity_util as pu
+from grasp_rl import _capi
+
+pytestmark = pytest.mark.gpu
+B, STEPS = 16, 3
+
+
+def _case():
+    return pu.make_case(extractor="augmented", kind="depth", B=B, n_replay=48, n_steps=STEPS)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grasp_rl.parallel import DataParallelSac
+    case = _case()
+    cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+    cfg.batch_size = B // world
+    case["cfg"] = cfg
+    eng = pu.engine_setup(case)
+    dp = DataParallelSac(eng)
+    if rank != 0:                                  # replicas must start identical: perturb, then broadcast
+        P = eng.get_parameters()
+        P["model/pi/fc0/bias:0"] = P["model/pi/fc0/bias:0"] + 1.0
+        eng.set_parameters(P)
+    dp.broadcast_parameters(src=0)
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+    eng.synchronize()
+    P = eng.get_parameters()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_device_equal_single_engine(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    case = _case()
+    single = pu.engine_setup(case)
+    single.train(STEPS, case["idx"], case["eps"])
+    ref = single.get_parameters()
+    single.close()
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    lr = case["spec"].lr
+    for k, v in ref.items():
+        a, b = r0[k.replace("/", "|")], r1[k.replace("/", "|")]
+        assert np.array_equal(a, b), "replicas diverged: " + k
+        d = np.abs(a.astype(np.float64) - v)
+        assert d.max() <= 0.3 * lr * STEPS + 1e-7 and d.mean() <= 0.02 * lr * STEPS + 1e-9, (k, d.max(), d.mean())
