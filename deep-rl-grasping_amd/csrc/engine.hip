@@ -194,6 +194,7 @@ struct grl_ctx {
   int Ap = 0, ld_d = 1, ld_dm = 0;   // strides of the packed output-gradient buffers (fused heads)
   bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
   float *u_l0[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // layer-0 feature partials: pi, vf, qf1, qf2, target
+  int l0_split = 1;
   float* g0cat = nullptr;            // [B, 3*H0]: layer-0 gradients of vf | qf1 | qf2
   // act path
   float *ax, *aa1, *aa2, *aa3, *afeat, *a_eps, *a_out;
@@ -948,7 +949,15 @@ int grl_ctx::plan_sac() {
     d_qf1 = wk.f32(B); d_qf2 = wk.f32(B); d_v = wk.f32(B); d_qf1pi = wk.f32(B); ld_d = 1;
   }
   if (fused_heads) {
-    for (int k = 0; k < 5; ++k) u_l0[k] = wk.f32((int64_t)B * hid[0]);
+    {
+      const char* e = getenv("GRL_L0_SPLIT");
+      l0_split = e ? std::max(1, atoi(e)) : 3;       // reduction of the layer-0 GEMM (K = 513) cut into partial sums
+      IgemmProb probe = blank();
+      probe.M = B; probe.N = hid[0]; probe.K = F;
+      set_split(probe, l0_split);
+      l0_split = probe.split;
+    }
+    for (int k = 0; k < 5; ++k) u_l0[k] = wk.f32((int64_t)B * hid[0] * l0_split);
     g0cat = wk.f32((int64_t)B * 3 * hid[0]);
     alloc_hgrad(gPI, B);
     alloc_hgrad(gVF, B, g0cat, 3 * hid[0]);
@@ -1039,7 +1048,7 @@ int grl_ctx::plan_sac() {
                      int n_xa) {
     HtHead H;
     memset(&H, 0, sizeof(H));
-    H.u = u; H.ldu = hid[0];
+    H.u = u; H.ldu = hid[0]; H.u_split = l0_split; H.u_stride = (long)B * hid[0];
     H.xa = xa; H.ld_xa = ld_xa; H.n_xa = n_xa;
     H.w0a = P + m.w[0] + (int64_t)F * hid[0];
     H.b0 = P + m.b[0]; H.z0 = h.z[0]; H.H0 = hid[0]; H.L = L;
@@ -1058,8 +1067,11 @@ int grl_ctx::plan_sac() {
     const MlpP* ms[5] = {&m_pi, &m_vf, &m_qf1, &m_qf2, &m_tgt};
     const float* fin[5] = {feat[0], feat[1], feat[1], feat[1], feat[2]};
     std::vector<IgemmProb> pr;
-    for (int k = 0; k < 5; ++k)
-      pr.push_back(dense_fwd(fin[k], ldf, F, nullptr, 0, 0, B, P + ms[k]->w[0], hid[0], nullptr, u_l0[k], hid[0], ACT_NONE));
+    for (int k = 0; k < 5; ++k) {
+      IgemmProb p = dense_fwd(fin[k], ldf, F, nullptr, 0, 0, B, P + ms[k]->w[0], hid[0], nullptr, u_l0[k], hid[0], ACT_NONE);
+      set_split(p, l0_split);     // partial sums [split][B, H0]: the head chains add them (40 -> 120 workgroups)
+      pr.push_back(p);
+    }
     add_launch(ops_grads, "heads_l0", 0, pr);
     HeadsFwdArgs fa;
     memset(&fa, 0, sizeof(fa));

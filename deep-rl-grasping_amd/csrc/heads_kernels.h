@@ -27,7 +27,8 @@ enum { HT_RB = 16, HT_MAXW = 128, HT_MAXA = 64 };
 
 struct HtHead {
   // layer 0: z0 = relu(u + xa . w0a + b0)
-  const float* u; int ldu;                 // [B, ldu] feature part of the pre-activation (no bias)
+  const float* u; int ldu;                 // [B, ldu] feature part of the pre-activation (no bias) ...
+  int u_split; long u_stride;              // ... as u_split partial sums, u_stride floats apart (0 / 1: a single one), added in order
   const float* xa; int ld_xa; int n_xa;    // second input part (the action), n_xa == 0: none
   const float* w0a;                        // [n_xa, H0]: rows of the layer-0 kernel after the feature rows
   const float* b0;
@@ -158,6 +159,7 @@ inline void ht_ref_fwd_head(const HtHead& h, int row, const float* xa_row) {
   float zin[HT_MAXW], zout[HT_MAXW];
   for (int n = 0; n < h.H0; ++n) {
     float acc = h.u[(long)row * h.ldu + n];
+    for (int sp = 1; sp < h.u_split; ++sp) acc += h.u[sp * h.u_stride + (long)row * h.ldu + n];
     for (int a = 0; a < h.n_xa; ++a) acc = fmaf(xa_row[a], h.w0a[a * h.H0 + n], acc);
     acc += h.b0[n];
     zin[n] = fmaxf(acc, 0.f);
@@ -397,6 +399,12 @@ __device__ __forceinline__ void ht_fwd_head(const HtHead& h, int row0, int B, Ht
         const int row = row0 + 4 * rg + i;
         acc[i] = row < B ? h.u[(long)row * h.ldu + n] : 0.f;
       }
+      for (int sp = 1; sp < h.u_split; ++sp)     // split reduction of the layer-0 GEMM: partial sums, in order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * rg + i;
+          acc[i] += row < B ? h.u[sp * h.u_stride + (long)row * h.ldu + n] : 0.f;
+        }
       for (int a = 0; a < h.n_xa; ++a) {
         const float w = h.w0a[a * h.H0 + n];
         const ht_f4 x = *(const ht_f4*)&s.xaT[a][4 * rg];
