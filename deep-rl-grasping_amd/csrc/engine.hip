@@ -1273,7 +1273,7 @@ int grl_ctx::plan_sac() {
       add_launch(ops_grads, "conv2_bwd", 1, pr);
     }
     // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
-    int wsplit[3] = {96, 16, 8};   // reduction splits of conv1..3 (GRL_WG_SPLIT=a,b,c overrides: tuning aid)
+    int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3, tuned with the merged launch (GRL_WG_SPLIT=a,b,c overrides)
     if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
     for (int n = 0; n < 2; ++n) {
       const float* xin = x_obs;
