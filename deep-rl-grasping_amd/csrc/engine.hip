@@ -677,7 +677,9 @@ struct grl_ctx {
     if (l->sk) {
       long total = 0;
       for (auto& p : l->probs) total += (p.M + 127) / 128;
-      const int per = (int)std::max<long>(1, (total + 511) / 512);     // ~2 workgroups per CU, each streams `per` tiles
+      long slots = 512;                                                // ~2 workgroups per CU, each streams `per` tiles
+      if (const char* e = getenv("GRL_SK_WGS")) slots = std::max(1, atoi(e));   // tuning aid
+      const int per = (int)std::max<long>(1, (total + slots - 1) / slots);
       std::vector<int4> work;
       double flops = 0;
       for (size_t pi = 0; pi < l->probs.size(); ++pi) {
