@@ -101,7 +101,13 @@ def pmc_traffic(tag):
     counters cannot be collected from inside the timed process, so this is the recorded measurement or None."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_hbm_traffic*.csv")))
+    import re
+
+    def version(path):          # ..._v11.csv after ..._v9.csv
+        m = re.search(r"_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)) if m else -1, path)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_hbm_traffic*.csv")),
+                   key=version)
     for f in reversed(files):
         try:
             with open(f) as fh:
