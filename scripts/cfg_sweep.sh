@@ -1,11 +1,9 @@
 #!/bin/bash
-# development aid: per-launch workgroup-shape sweep (GRL_I2CFG_<tag>) using bench.py's eager per-op timings
-run() { env "$@" python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "
+# development aid: per-launch workgroup-shape sweep (GRL_I2CFG_<tag>) using the graph-replay throughput
+run() { env "$@" python bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-profile 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['roofline']['step_kernel_ms']
-print('%-34s value %7.1f  ' % (' '.join(sys.argv[1:]) or 'baseline', d['value']) + ' '.join('%s=%.1f' % (t, 1e3*k[t]) for t in sorted(k) if t in ('conv1_fwd','conv2_fwd','conv3_fwd','fc_fwd','heads_l0','heads_dfeat','fc_bwd','conv3_bwd','conv2_bwd','wgrad_dense','wgrad_conv')))
+d=json.loads(sys.stdin.readlines()[-1]); print('%-34s %7.1f' % (' '.join(sys.argv[1:]) or 'baseline', d['value']))
 " "$@"; }
 run
-for tag in conv2_fwd conv3_fwd fc_fwd heads_l0 heads_dfeat fc_bwd conv3_bwd; do
-  for c in 0 2 3; do run GRL_I2CFG_$tag=$c; done
-done
+for spec in conv2_fwd=3 conv2_fwd=1 conv3_fwd=0 fc_fwd=0 fc_bwd=0 conv3_bwd=0 conv2_bwd=0 conv2_bwd=3 heads_dfeat=0 wgrad_conv=1; do run GRL_I2CFG_$spec; done
+run
