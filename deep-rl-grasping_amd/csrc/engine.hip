@@ -210,7 +210,7 @@ struct grl_ctx {
   std::vector<ReduceDesc> reduces;
   ReduceDesc* d_reduces = nullptr;
 
-  std::vector<Op> ops_rng, ops_gather, ops_grads, ops_apply, ops_act, ops_enc, wgrad_ops;   // ops_rng: gather with device RNG; ops_gather: gather of explicit indices
+  std::vector<Op> ops_rng, ops_gather, ops_grads, ops_apply, ops_act, ops_act_det, ops_act_sto, ops_enc, wgrad_ops;   // ops_rng: gather with device RNG; ops_gather: gather of explicit indices
   bool use_lanes = false;
   LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
@@ -232,6 +232,8 @@ struct grl_ctx {
   std::map<std::string, std::pair<const float*, int64_t>> dbg;
 
   ~grl_ctx() {
+    if (pin_in) hipHostFree(pin_in);
+    if (pin_out) hipHostFree(pin_out);
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
     for (auto e : lane_ev) hipEventDestroy(e);
@@ -842,6 +844,10 @@ struct grl_ctx {
   std::vector<Op> ops_per_rng, ops_per_u, ops_per_update;
   int qD = 0, qN = 0;
   float *q_td = nullptr, *q_prio = nullptr, *q_aout = nullptr;
+  // pinned host staging of the per-env-step calls (grl_act / grl_encode): pageable copies cost more than the kernels
+  float *pin_in = nullptr, *pin_out = nullptr;
+  size_t pin_in_n = 0, pin_out_n = 0;
+  int act_rows = 0;   // rows the act-path output kernel covers (the launches are sized for act_batch: one static graph)
   int64_t q_online_off = 0, q_online_n = 0;
   int run_ops(std::vector<Op>& ops);
   int capture(std::vector<std::vector<Op>*> seq, hipGraphExec_t* out);
@@ -1495,6 +1501,16 @@ int grl_ctx::plan_sac() {
     for (int l = 0; l < L; ++l)
       add_launch(ops_act, "act_head", 0, {head_layer(m_pi, P, ahPI, l, afeat, ldf, F, nullptr, 0, 0, NA)});
     add_launch(ops_act, "act_head", 0, {head_out(m_pi, P, ahPI, 0, NA), head_out(m_pi, P, ahPI, 1, NA)});
+    // final tanh (+ sampling): two variants so that each is a static graph
+    for (int det = 0; det < 2; ++det) {
+      const float* mu = ahPI.out[0]; const float* ls = ahPI.out[1]; const float* ep = a_eps; float* ao = a_out;
+      const int rows = NA, Ad = A;
+      Op op; op.tag = "act_out";
+      op.run = [mu, ls, ep, ao, rows, Ad, det](hipStream_t s) {
+        hipLaunchKernelGGL(act_out_kernel, dim3((rows * Ad + 255) / 256), dim3(256), 0, s, mu, ls, ep, rows, Ad, det, ao);
+      };
+      (det ? ops_act_det : ops_act_sto).push_back(op);
+    }
   }
 
   // =============================================================== Keras auto-encoder (A.9), batch NA
@@ -2711,28 +2727,48 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
   return GRL_OK;
 }
 
+// host buffer -> pinned staging -> device (and back): hipMemcpyAsync from pageable memory is a synchronous
+// staged copy; through page-locked buffers the per-call overhead is a host memcpy plus a true async DMA
+static int pin_reserve(grl_handle h, size_t in_floats, size_t out_floats) {
+  if (in_floats > h->pin_in_n) {
+    if (h->pin_in) hipHostFree(h->pin_in);
+    h->pin_in = nullptr; h->pin_in_n = 0;
+    HIPCHK(hipHostMalloc((void**)&h->pin_in, in_floats * 4, 0));
+    h->pin_in_n = in_floats;
+  }
+  if (out_floats > h->pin_out_n) {
+    if (h->pin_out) hipHostFree(h->pin_out);
+    h->pin_out = nullptr; h->pin_out_n = 0;
+    HIPCHK(hipHostMalloc((void**)&h->pin_out, out_floats * 4, 0));
+    h->pin_out_n = out_floats;
+  }
+  return GRL_OK;
+}
+
 int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps, float* out) {
   if (!h || !obs || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
-  if (h->cfg.algo != GRL_ALGO_SAC) {   // Q-values [n, D*bins]
-    HIPCHK(hipMemcpyAsync(h->stg_obs, obs, (size_t)n * h->cfg.obs_dim * 4, hipMemcpyHostToDevice, h->stream));
-    if (int e = h->run_ops(h->ops_act)) return e;
-    HIPCHK(hipMemcpyAsync(out, h->q_aout, (size_t)n * h->qD * h->qN * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipGetLastError());
-    return GRL_OK;
+  const bool q = h->cfg.algo != GRL_ALGO_SAC;   // DQN / BDQ: Q-values [n, D*bins]
+  if (!q && !deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
+  const int64_t oe = (!q && h->cnn) ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
+  const size_t n_in = (size_t)n * oe, n_eps = (!q && !deterministic) ? (size_t)n * h->A : 0;
+  const size_t n_out = q ? (size_t)n * h->qD * h->qN : (size_t)n * h->A;
+  if (int e = pin_reserve(h, n_in + n_eps, n_out)) return e;
+  memcpy(h->pin_in, obs, n_in * 4);
+  if (n_eps) memcpy(h->pin_in + n_in, eps, n_eps * 4);
+  HIPCHK(hipMemcpyAsync(h->stg_obs, h->pin_in, n_in * 4, hipMemcpyHostToDevice, h->stream));
+  if (n_eps) HIPCHK(hipMemcpyAsync(h->a_eps, h->pin_in + n_in, n_eps * 4, hipMemcpyHostToDevice, h->stream));
+  if (q) {
+    if (int e = h->run_seq("act", {&h->ops_act})) return e;
+  } else {
+    // the launches cover act_batch rows whatever n is (rows beyond n hold stale observations: computed, not returned)
+    if (int e = h->run_seq(deterministic ? "act_det" : "act_sto", {&h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
+      return e;
   }
-  if (!deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
-  const int64_t oe = h->cnn ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
-  HIPCHK(hipMemcpyAsync(h->stg_obs, obs, (size_t)n * oe * 4, hipMemcpyHostToDevice, h->stream));
-  if (!deterministic)
-    HIPCHK(hipMemcpyAsync(h->a_eps, eps, (size_t)n * h->A * 4, hipMemcpyHostToDevice, h->stream));
-  if (int e = h->run_ops(h->ops_act)) return e;
-  hipLaunchKernelGGL(act_out_kernel, dim3((n * h->A + 255) / 256), dim3(256), 0, h->stream, h->ahPI.out[0],
-                     h->ahPI.out[1], h->a_eps, n, h->A, deterministic, h->a_out);
-  HIPCHK(hipMemcpyAsync(out, h->a_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->pin_out, q ? h->q_aout : h->a_out, n_out * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
+  memcpy(out, h->pin_out, n_out * 4);
   return GRL_OK;
 }
 
@@ -2760,11 +2796,14 @@ int grl_encode(grl_handle h, const float* depth, int n, float* out) {
   if (!h || !depth || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (!h->enc_loaded) return fail(GRL_ERR_STATE, "grl_encoder_load has not been called");
   if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
-  HIPCHK(hipMemcpyAsync(h->ex_in, depth, (size_t)n * 4096 * 4, hipMemcpyHostToDevice, h->stream));
-  if (int e = h->run_ops(h->ops_enc)) return e;
-  HIPCHK(hipMemcpyAsync(out, h->eout, (size_t)n * 100 * 4, hipMemcpyDeviceToHost, h->stream));
+  if (int e = pin_reserve(h, (size_t)n * 4096, (size_t)n * 100)) return e;
+  memcpy(h->pin_in, depth, (size_t)n * 4096 * 4);
+  HIPCHK(hipMemcpyAsync(h->ex_in, h->pin_in, (size_t)n * 4096 * 4, hipMemcpyHostToDevice, h->stream));
+  if (int e = h->run_seq("encode", {&h->ops_enc})) return e;
+  HIPCHK(hipMemcpyAsync(h->pin_out, h->eout, (size_t)n * 100 * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
+  memcpy(out, h->pin_out, (size_t)n * 100 * 4);
   return GRL_OK;
 }
 
