@@ -2611,10 +2611,30 @@ int grl_replay_add_device(grl_handle h, const float* obs, const float* act, cons
   return replay_add_dev(h, obs, act, rew, next_obs, done, n);
 }
 
+// host buffer -> pinned staging -> device (and back): hipMemcpyAsync from pageable memory is a synchronous
+// staged copy; through page-locked buffers the per-call overhead is a host memcpy plus a true async DMA
+static int pin_reserve(grl_handle h, size_t in_floats, size_t out_floats) {
+  if (in_floats > h->pin_in_n) {
+    if (h->pin_in) hipHostFree(h->pin_in);
+    h->pin_in = nullptr; h->pin_in_n = 0;
+    HIPCHK(hipHostMalloc((void**)&h->pin_in, in_floats * 4, 0));
+    h->pin_in_n = in_floats;
+  }
+  if (out_floats > h->pin_out_n) {
+    if (h->pin_out) hipHostFree(h->pin_out);
+    h->pin_out = nullptr; h->pin_out_n = 0;
+    HIPCHK(hipHostMalloc((void**)&h->pin_out, out_floats * 4, 0));
+    h->pin_out_n = out_floats;
+  }
+  return GRL_OK;
+}
+
 int grl_replay_add(grl_handle h, const float* obs, const float* act, const float* rew, const float* next_obs,
                    const float* done, int n) {
   if (!h || !obs || !act || !rew || !next_obs || !done || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
   const int64_t oe = h->cnn ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
+  // (pageable copies: for these sizes -- 64 KB per transition -- an extra host copy into pinned staging costs
+  // more than it saves: 77 -> 90 us for 16 transitions, 150 -> 214 us for 64; measured with scripts/act_bench.py)
   for (int k0 = 0; k0 < n; k0 += h->stg_n) {
     const int m = std::min(h->stg_n, n - k0);
     HIPCHK(hipMemcpyAsync(h->stg_obs, obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
@@ -2724,24 +2744,6 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
   out->policy_loss = s.policy_loss; out->qf1_loss = s.qf1_loss; out->qf2_loss = s.qf2_loss;
   out->value_loss = s.value_loss; out->ent_coef_loss = s.ent_loss; out->ent_coef = s.ent_coef;
   out->entropy = s.entropy; out->mean_qf1 = s.mean_qf1; out->mean_v = s.mean_v;
-  return GRL_OK;
-}
-
-// host buffer -> pinned staging -> device (and back): hipMemcpyAsync from pageable memory is a synchronous
-// staged copy; through page-locked buffers the per-call overhead is a host memcpy plus a true async DMA
-static int pin_reserve(grl_handle h, size_t in_floats, size_t out_floats) {
-  if (in_floats > h->pin_in_n) {
-    if (h->pin_in) hipHostFree(h->pin_in);
-    h->pin_in = nullptr; h->pin_in_n = 0;
-    HIPCHK(hipHostMalloc((void**)&h->pin_in, in_floats * 4, 0));
-    h->pin_in_n = in_floats;
-  }
-  if (out_floats > h->pin_out_n) {
-    if (h->pin_out) hipHostFree(h->pin_out);
-    h->pin_out = nullptr; h->pin_out_n = 0;
-    HIPCHK(hipHostMalloc((void**)&h->pin_out, out_floats * 4, 0));
-    h->pin_out_n = out_floats;
-  }
   return GRL_OK;
 }
 

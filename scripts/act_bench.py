@@ -24,6 +24,14 @@ for n in (1, 16, 64):
         eng.act(obs, True)
     dt = (time.perf_counter() - t0) / 200
     print("act   n=%2d: %.1f us per call (%.1f us per env)" % (n, 1e6 * dt, 1e6 * dt / n))
+    a = np.zeros((n, 5), np.float32); r = np.zeros(n, np.float32)
+    for _ in range(10):
+        eng.replay_add(obs, a, r, obs, r)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.replay_add(obs, a, r, obs, r)
+    dt = (time.perf_counter() - t0) / 200
+    print("replay_add n=%2d: %.1f us per call" % (n, 1e6 * dt))
     eng.close()
 W = np.load(os.path.join(ROOT, "tests", "golden", "ae_new_gripper_encoder.npz"))
 order = ["encoder/conv2d_1/kernel", "encoder/conv2d_1/bias", "encoder/conv2d_2/kernel", "encoder/conv2d_2/bias",
