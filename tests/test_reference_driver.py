@@ -1,0 +1,98 @@
+"""The reference's OWN training driver on top of this package.
+
+`/root/reference/manipulation_main/training/sb_helper.py` (class SBPolicy: policy selection :85-96, model
+construction :120-128, callbacks :70-84, `model.learn` :175-177, `save` :228-247) together with its
+`base_callbacks.py` and `custom_obs_policy.py` is imported from where it lies -- unmodified, nothing copied --
+with `stable_baselines` resolving to the alias package of this repository and two stub modules for what the
+container lacks (`tensorflow`: only attribute access at import time, the extractor closure is never called;
+`gym`: the `Env` name used in type annotations).  The engine behind the model is the TEST-ONLY g++ emulation
+build, the environment is tests/fake_env.py.  Skipped where /root/reference does not exist (the GPU box)."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+import stable_baselines as sb
+from fake_env import FakeGraspEnv
+from grasp_rl.engine import QEngine, SacEngine
+from grasp_rl.sb import spaces
+from grasp_rl.sb.dqn import DQN
+from grasp_rl.sb.sac import SAC
+from hostemu_backend import NumpyHostBackend
+from stable_baselines.bench import Monitor
+from stable_baselines.common.vec_env import DummyVecEnv, VecNormalize
+
+REF_TRAINING = "/root/reference/manipulation_main/training"
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF_TRAINING, "sb_helper.py")),
+                                reason="/root/reference is not present on this box")
+
+
+@pytest.fixture
+def reference_sb_helper(monkeypatch, hostemu_lib):
+    tf = types.ModuleType("tensorflow")
+    tf.nn = types.SimpleNamespace(relu=lambda x: x)
+    tf.contrib = types.SimpleNamespace()
+    tf.Summary = type("Summary", (), {"Value": staticmethod(lambda **k: k), "__init__": lambda self, **k: None})
+    gym = types.ModuleType("gym")
+    gym.Env = type("Env", (), {})
+    gym.spaces = spaces
+    monkeypatch.setitem(sys.modules, "tensorflow", tf)
+    monkeypatch.setitem(sys.modules, "gym", gym)
+    monkeypatch.syspath_prepend(REF_TRAINING)
+    for name in ("sb_helper", "base_callbacks", "custom_obs_policy"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    monkeypatch.setattr(SAC, "_engine_factory",
+                        staticmethod(lambda cfg, device: SacEngine(cfg, backend=NumpyHostBackend(), lib_path=hostemu_lib)))
+    monkeypatch.setattr(DQN, "_engine_factory",
+                        staticmethod(lambda cfg, device: QEngine(cfg, backend=NumpyHostBackend(), lib_path=hostemu_lib)))
+    mod = importlib.import_module("sb_helper")
+    assert os.path.realpath(mod.__file__).startswith("/root/reference/")
+    yield mod
+    for name in ("sb_helper", "base_callbacks", "custom_obs_policy"):
+        sys.modules.pop(name, None)
+
+
+def test_reference_sbpolicy_trains_saves_and_reloads(reference_sb_helper, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("models/run")
+    config = {"normalize": True, "discount_factor": 0.99,
+              "SAC": {"tensorboard_logs": None, "layers": [64, 64], "buffer_size": 256, "batch_size": 4,
+                      "step_size": 3e-4, "total_timesteps": 112}}
+    env = DummyVecEnv([lambda: Monitor(FakeGraspEnv("depth", seed=0), os.path.join("models/run", "log_file"))])
+    test_env = DummyVecEnv([lambda: FakeGraspEnv("depth", seed=1)])
+    driver = reference_sb_helper.SBPolicy(env, test_env, config, "models/run", algo="SAC")
+    driver.learn()                                            # the reference's code path end to end
+    assert os.path.isfile("models/run/run.zip") and os.path.isfile("models/run/vecnormalize.pkl")
+    assert os.path.isdir("models/run/best_model")             # EvalCallback._init_callback of base_callbacks.py
+    # what train_stable_baselines.py `run` does with the result (:86-109)
+    venv = VecNormalize.load("models/run/vecnormalize.pkl", DummyVecEnv([lambda: FakeGraspEnv("depth", seed=2)]))
+    venv.training = False
+    model = sb.SAC.load("models/run/run.zip")
+    assert model.engine.cfg.extractor == 1                    # custom_obs_policy.create_augmented_nature_cnn(1) was recognised
+    obs = venv.reset()
+    action, _ = model.predict(obs, deterministic=True)
+    assert action.shape == (1, 5) and np.all(np.isfinite(action)) and np.all(np.abs(action) <= 1)
+    P = model.get_parameters()
+    assert "model/pi/c1/w:0" in P or any(k.startswith("model/pi/") for k in P)
+    assert venv.obs_rms.count > 100                           # statistics gathered during the reference's learn()
+
+
+def test_reference_sbpolicy_dqn_branch(reference_sb_helper, tmp_path, monkeypatch):
+    """sb_helper.py:155-165: `sb.DQN(DQNMlpPolicy, env, verbose, gamma, batch_size, prioritized_replay, tensorboard_log)`
+    on the auto-encoder-feature observation (100-d) with 12 discrete actions, prioritised replay on."""
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("models/dqn")
+    config = {"normalize": False, "discount_factor": 0.99,
+              "DQN": {"tensorboard_logs": None, "batch_size": 8, "prioritized_replay": True, "total_timesteps": 1100}}
+    mk = lambda s: FakeGraspEnv(seed=s, vector_dim=100, discrete_actions=12)
+    env = DummyVecEnv([lambda: Monitor(mk(0), os.path.join("models/dqn", "log_file"))])
+    driver = reference_sb_helper.SBPolicy(env, DummyVecEnv([lambda: mk(1)]), config, "models/dqn", algo="DQN")
+    driver.learn()
+    assert os.path.isfile("models/dqn/dqn.zip")
+    model = sb.DQN.load("models/dqn/dqn.zip")
+    a, _ = model.predict(np.zeros((1, 100), np.float32), deterministic=True)
+    assert a.shape == (1,) and 0 <= int(a[0]) < 12
+    assert any("action_value" in k for k in model.get_parameters())       # the names sb_helper.load_params filters on (:190-193)
