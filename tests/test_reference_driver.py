@@ -96,3 +96,25 @@ def test_reference_sbpolicy_dqn_branch(reference_sb_helper, tmp_path, monkeypatc
     a, _ = model.predict(np.zeros((1, 100), np.float32), deterministic=True)
     assert a.shape == (1,) and 0 <= int(a[0]) < 12
     assert any("action_value" in k for k in model.get_parameters())       # the names sb_helper.load_params filters on (:190-193)
+
+
+def test_reference_run_agent_evaluation_loop(reference_sb_helper, tmp_path, monkeypatch):
+    """`manipulation_main/utils.py: run_agent` (:10-44, the loop behind `train_stable_baselines.py run`, :106-109):
+    `agent.predict(obs, deterministic=)`, `task.step(action[0])`, `task.buf_infos[0][...]`."""
+    import enum
+    import importlib.util
+    robot = types.ModuleType("manipulation_main.gripperEnv.robot")
+    robot.RobotEnv = type("RobotEnv", (), {"Status": enum.IntEnum("Status", {"RUNNING": 0, "SUCCESS": 1})})
+    for name, mod in (("manipulation_main", types.ModuleType("manipulation_main")),
+                      ("manipulation_main.gripperEnv", types.ModuleType("manipulation_main.gripperEnv")),
+                      ("manipulation_main.gripperEnv.robot", robot)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    spec = importlib.util.spec_from_file_location("reference_utils", "/root/reference/manipulation_main/utils.py")
+    utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(utils)
+    task = DummyVecEnv([lambda: FakeGraspEnv("depth", seed=3, episode_len=5)])
+    model = sb.SAC(reference_sb_helper.sacCnn, task, policy_kwargs={
+        "layers": [64, 64], "cnn_extractor": reference_sb_helper.custom_obs_policy.create_augmented_nature_cnn(1)},
+        buffer_size=16, batch_size=4)
+    rewards, steps, success, timings = utils.run_agent(task, model, n_episodes=3)
+    assert rewards.shape == (3,) and np.all(steps == 5) and np.all(success == 1) and np.all(np.isfinite(rewards))
