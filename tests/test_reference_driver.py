@@ -118,3 +118,71 @@ def test_reference_run_agent_evaluation_loop(reference_sb_helper, tmp_path, monk
         buffer_size=16, batch_size=4)
     rewards, steps, success, timings = utils.run_agent(task, model, n_episodes=3)
     assert rewards.shape == (3,) and np.all(steps == 5) and np.all(success == 1) and np.all(np.isfinite(rewards))
+
+
+def test_reference_train_script_train_then_run(reference_sb_helper, tmp_path, monkeypatch):
+    """`train_stable_baselines.py`: its `train(args)` (:26-75) and `run(args)` (:77-109) functions, imported from
+    the reference and called as its `__main__` would, on the reference's own `config/gripper_grasp.yaml`
+    (replay / batch size reduced for the CPU emulation; `gym.make('gripper-env-v0', ...)` returns the fake env)."""
+    import enum
+    import importlib.util
+    import yaml
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    robot = types.ModuleType("manipulation_main.gripperEnv.robot")
+    robot.RobotEnv = type("RobotEnv", (), {"Status": enum.IntEnum("Status", {"RUNNING": 0, "SUCCESS": 1})})
+    wrapper = types.ModuleType("manipulation_main.training.wrapper")
+    wrapper.TimeFeatureWrapper = lambda env: env
+    pkgs = {n: types.ModuleType(n) for n in ("manipulation_main", "manipulation_main.gripperEnv", "manipulation_main.training",
+                                             "manipulation_main.common")}
+    for m in pkgs.values():
+        m.__path__ = []
+    pkgs.update({"manipulation_main.gripperEnv.robot": robot, "manipulation_main.training.wrapper": wrapper})
+    for n, m in pkgs.items():
+        monkeypatch.setitem(sys.modules, n, m)
+    real_yaml_load = yaml.load                                  # the reference targets PyYAML < 6: `yaml.load(f)` without a Loader
+    monkeypatch.setattr(yaml, "load", lambda f, Loader=None: real_yaml_load(f, Loader=Loader or yaml.FullLoader))
+    io_utils = load("manipulation_main.common.io_utils", "/root/reference/manipulation_main/common/io_utils.py")
+    monkeypatch.setitem(sys.modules, "manipulation_main.common.io_utils", io_utils)
+    pkgs["manipulation_main.common"].io_utils = io_utils
+    utils = load("manipulation_main.utils", "/root/reference/manipulation_main/utils.py")
+    monkeypatch.setitem(sys.modules, "manipulation_main.utils", utils)
+    made = []
+
+    def make(name, config=None, **kw):
+        assert name == "gripper-env-v0" and config["robot"]["discrete"] is False
+        made.append(kw)
+        return FakeGraspEnv("depth", seed=len(made), episode_len=5)
+    sys.modules["gym"].make = make
+    monkeypatch.delitem(sys.modules, "train_stable_baselines", raising=False)
+    script = importlib.import_module("train_stable_baselines")
+    assert os.path.realpath(script.__file__).startswith("/root/reference/")
+
+    with open("/root/reference/config/gripper_grasp.yaml") as f:
+        cfg = yaml.safe_load(f)
+    assert cfg["SAC"]["buffer_size"] == 1000000 and cfg["normalize"] is True        # the reference's values ...
+    cfg["SAC"]["buffer_size"], cfg["SAC"]["batch_size"] = 256, 4                    # ... scaled for the emulated engine
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("trained")
+    with open("cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    args = types.SimpleNamespace(config="cfg.yaml", model_dir="trained/sac_test", algo="SAC", load_dir=None, timestep="112",
+                                 simple=False, shaped=False, visualize=False, timefeature=False)
+    script.train(args)
+    assert os.path.isfile("trained/sac_test/sac_test.zip") and os.path.isfile("trained/sac_test/vecnormalize.pkl")
+    assert os.path.isfile("trained/sac_test/config.yaml") and os.path.isfile("trained/sac_test/best_model/config.yaml")
+    calls = []
+    full_run_agent = utils.run_agent
+
+    def run_few(task, agent, stochastic=False):               # the script asks for 100 episodes; four are enough here
+        calls.append(1)
+        return full_run_agent(task, agent, stochastic, n_episodes=4)
+    monkeypatch.setattr(script, "run_agent", run_few)
+    script.run(types.SimpleNamespace(model="trained/sac_test/sac_test.zip", visualize=False, test=True, stochastic=False))
+    assert calls == [1] and len(made) == 3                    # train env, eval env, run env
+    sys.modules.pop("train_stable_baselines", None)
