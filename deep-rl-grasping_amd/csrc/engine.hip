@@ -835,6 +835,8 @@ struct grl_ctx {
   int plan_q();        // DQN / BDQ (MLP towers, dueling, double-Q)
   int plan_ae();       // depth auto-encoder training (encoders.py:40-50,70-136)
   float* ae_x = nullptr;            // [B, 4096] minibatch of depth images (staged per step)
+  float* ae_out = nullptr;          // [B, 4096] reconstruction of that minibatch
+  std::vector<Op> ops_ae_fwd;       // forward half of ops_ae (grl_ae_reconstruct)
   std::vector<Op> ops_ae;
   // Q-learning state
   PerArgs per;                      // prioritised replay (cfg.q_per): device arrays + kernel arguments
@@ -2194,6 +2196,8 @@ int grl_ctx::plan_ae() {
       hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix);
     });
   }
+  ae_out = out;
+  ops_ae_fwd = ops_ae;            // everything so far: the forward pass (Model.predict / evaluate)
   // =============================================================== loss
   {
     g_pad = wk.f32((int64_t)B * 4900);
@@ -2732,6 +2736,17 @@ int grl_ae_train_step(grl_handle h, const float* imgs, int n_steps) {
     HIPCHK(hipMemcpyAsync(h->ae_x, imgs + per * s, per * 4, hipMemcpyDeviceToDevice, h->stream));
     if (int e = h->run_seq("ae_step", {&h->ops_ae})) return e;
   }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_ae_reconstruct(grl_handle h, const float* imgs, float* out) {
+  if (!h || !imgs || !out) return fail(GRL_ERR_INVALID, "null argument");
+  if (h->cfg.algo != GRL_ALGO_AE) return fail(GRL_ERR_STATE, "not an auto-encoder handle (grl_config.algo)");
+  const size_t per = (size_t)h->B * 4096;
+  HIPCHK(hipMemcpyAsync(h->ae_x, imgs, per * 4, hipMemcpyDeviceToDevice, h->stream));
+  if (int e = h->run_seq("ae_fwd", {&h->ops_ae_fwd})) return e;
+  HIPCHK(hipMemcpyAsync(out, h->ae_out, per * 4, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipGetLastError());
   return GRL_OK;
 }

@@ -48,6 +48,7 @@ EXPORTS = [
     "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
     "grl_ae_train_step",
+    "grl_ae_reconstruct",
 ]
 
 
@@ -88,6 +89,7 @@ def load_library(path=None):
     lib.grl_q_update_target.argtypes = [vp]
     lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_float, vp]
     lib.grl_ae_train_step.argtypes = [vp, vp, C.c_int]
+    lib.grl_ae_reconstruct.argtypes = [vp, vp, vp]
     lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]
     lib.grl_act.argtypes = [vp, f32p, i32, i32, f32p, f32p]
     lib.grl_encoder_load.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), i32]

@@ -63,6 +63,22 @@ class AeEngine(SacEngine):
         """Decoder output of the last training minibatch [B, 64, 64, 1]."""
         return self.fetch("out", (self.B, 64, 64, 1))
 
+    def reconstruct(self, imgs):
+        """Forward pass only (Keras `Model.predict`): imgs [N, 64, 64, 1] -> reconstructions [N, 64, 64, 1].
+        The engine's batch is static: the last minibatch is padded with zeros."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32).reshape(-1, 4096)
+        n = imgs.shape[0]
+        out = np.empty((n, 4096), np.float32)
+        for k0 in range(0, n, self.B):
+            chunk = np.zeros((self.B, 4096), np.float32)
+            m = min(self.B, n - k0)
+            chunk[:m] = imgs[k0:k0 + m]
+            d_in = self.be.to_device(chunk)
+            d_out = self.be.to_device(np.empty((self.B, 4096), np.float32))
+            check(self.lib, self.lib.grl_ae_reconstruct(self.h, C.c_void_p(self.be.ptr(d_in)), C.c_void_p(self.be.ptr(d_out))))
+            out[k0:k0 + m] = self.be.to_host(d_out)[:m]
+        return out.reshape(n, 64, 64, 1)
+
 
 class SimpleAutoEncoder:
     def __init__(self, config, backend=None, lib_path=None, device="cuda:0", seed=0):
@@ -160,10 +176,9 @@ class SimpleAutoEncoder:
         return hist
 
     def predict(self, imgs):
-        """Reconstructions [N,64,64,1].  Runs the training graph's forward half on padded minibatches with a
-        zero learning rate would still move Adam state, so prediction uses a dedicated evaluation pass:
-        encode on the device, decode through the oracle-free NumPy decoder of the same weights."""
-        return _decode_numpy(self.get_weights(), self.encode(imgs))
+        """encoders.py:55-57: reconstructions [N, 64, 64, 1] -- the forward half of the training graph on the device."""
+        eng = self.engine if self.engine is not None else self._engine(self._bs or 128)
+        return eng.reconstruct(imgs)
 
     def test(self, inputs, targets):
         out = self.predict(inputs)
@@ -178,26 +193,3 @@ class SimpleAutoEncoder:
     @property
     def encoding_shape(self):
         return (100,)
-
-
-def _leaky(x, a=0.1):
-    return np.where(x > 0, x, a * x)
-
-
-def _conv_same_s1(x, w, b):
-    """NHWC 'same' stride-1 convolution (validation / predict only; the training path is the HIP engine)."""
-    k = w.shape[0]
-    lo = (k - 1) // 2
-    xp = np.pad(x, ((0, 0), (lo, k - 1 - lo), (lo, k - 1 - lo), (0, 0)))
-    n, H, W, _ = x.shape
-    win = np.lib.stride_tricks.sliding_window_view(xp, (k, k), axis=(1, 2))      # [n,H,W,C,k,k]
-    return np.einsum("nhwcij,ijco->nhwo", win, w, optimize=True) + b
-
-
-def _decode_numpy(P, z):
-    h = _leaky(z @ P["decoder/dense_2/kernel"] + P["decoder/dense_2/bias"]).reshape(-1, 8, 8, 32)
-    for i in (4, 5):
-        h = h.repeat(2, axis=1).repeat(2, axis=2)
-        h = _leaky(_conv_same_s1(h, P["decoder/conv2d_%d/kernel" % i], P["decoder/conv2d_%d/bias" % i]))
-    h = h.repeat(2, axis=1).repeat(2, axis=2)
-    return _conv_same_s1(h, P["decoder/conv2d_6/kernel"], P["decoder/conv2d_6/bias"]).astype(np.float32)

@@ -177,6 +177,11 @@ int grl_act(grl_handle h, const float* obs, int n, int deterministic, const floa
    the reconstruction loss of the last minibatch in policy_loss; grl_encode works on the handle. */
 int grl_ae_train_step(grl_handle h, const float* imgs, int n_steps);
 
+/* GRL_ALGO_AE handles: forward pass only (Keras Model.predict, encoders.py:52-57 `test` / `predict`): the
+   reconstruction of one minibatch.  imgs, out: DEVICE pointers to [batch_size, 64, 64, 1] float32.
+   Parameters and optimiser state are untouched. */
+int grl_ae_reconstruct(grl_handle h, const float* imgs, float* out);
+
 /* Keras depth auto-encoder (encoder half).  weights: 8 host arrays in Keras order
    conv2d_1..3 kernel(HWIO)/bias, dense_1 kernel [2048,100]/bias; copied into the work arena. */
 int grl_encoder_load(grl_handle h, const float* const* weights, const int64_t* numels, int n_arrays);

@@ -1,5 +1,6 @@
 """Auto-encoder training step: engine vs oracle/autoencoder.py (shared by the CPU plan test and the GPU test)."""
 import numpy as np
+import torch
 
 from grasp_rl.autoencoder import AeEngine, PARAM_NAMES
 from oracle import autoencoder as oae
@@ -39,4 +40,11 @@ def ae_check(backend=None, lib_path=None, B=4, n_steps=3, seed=0, lr=2e-4):
         assert d.mean() <= 0.02 * lr * n_steps + 1e-9, "param %s: mean |d| %.3e" % (n, d.mean())
     z = eng.encode(x[:3])
     assert np.allclose(z, oae.encode(Po, x[:3]), atol=2e-5, rtol=2e-4)
+    # forward-only pass (Model.predict): same numbers as the oracle's forward at the engine's parameters,
+    # for a batch that is not a multiple of the engine's, without touching parameters or optimiser state
+    rec = eng.reconstruct(x[:B + 1])
+    want = oae.AeOracle(Pe, lr=lr).forward(torch.from_numpy(x[:B + 1]))[0].detach().numpy()
+    assert rec.shape == (B + 1, 64, 64, 1) and np.allclose(rec, want, atol=2e-5, rtol=1e-4), np.abs(rec - want).max()
+    Pa = eng.get_parameters()
+    assert all(np.array_equal(Pa[n], Pe[n]) for n in PARAM_NAMES)
     eng.close()
