@@ -35,41 +35,6 @@ class LinearSchedule:
         return self.initial_p + frac * (self.final_p - self.initial_p)
 
 
-class SumTree:
-    """Proportional prioritisation (Schaul et al. 2016): array-backed binary sum / min trees."""
-
-    def __init__(self, capacity):
-        self.n = 1
-        while self.n < capacity:
-            self.n *= 2
-        self.sum = np.zeros(2 * self.n, np.float64)
-        self.min = np.full(2 * self.n, np.inf, np.float64)
-
-    def set(self, idx, value):
-        idx = np.atleast_1d(np.asarray(idx, np.int64))
-        value = np.broadcast_to(np.asarray(value, np.float64), idx.shape)
-        for i, v in zip(idx + self.n, value):
-            self.sum[i] = self.min[i] = v
-            i //= 2
-            while i >= 1:
-                self.sum[i] = self.sum[2 * i] + self.sum[2 * i + 1]
-                self.min[i] = min(self.min[2 * i], self.min[2 * i + 1])
-                i //= 2
-
-    def total(self):
-        return self.sum[1]
-
-    def find_prefix(self, mass):
-        i = 1
-        while i < self.n:
-            if self.sum[2 * i] > mass:
-                i = 2 * i
-            else:
-                mass -= self.sum[2 * i]
-                i = 2 * i + 1
-        return i - self.n
-
-
 class _QModel:
     """Shared host loop of DQN and BDQ."""
     _engine_factory = staticmethod(lambda cfg, device: QEngine(cfg, device=device))
@@ -149,8 +114,7 @@ class _QModel:
         self.D, self.bins = D, bins
         self._init_weights()
         # prioritised replay lives on the device (csrc/per_kernels.h): sampling, importance weights and the
-        # priority write-back never leave HBM.  (SumTree above is the host restatement kept for its unit test.)
-        self._tree = None
+        # priority write-back never leave HBM
         self._max_priority = 1.0
 
     def _init_weights(self):
@@ -195,21 +159,6 @@ class _QModel:
             acts.append(self._bins_to_env_action(b))
         acts = np.asarray(acts)
         return (acts[0] if single else acts), None
-
-    # ------------------------------------------------------------------ replay sampling
-    def _sample(self, beta):
-        n, B = self.engine.replay_size(), self.batch_size
-        if self._tree is None:
-            return self._rng.integers(0, n, B, dtype=np.int64), np.ones(B, np.float32)
-        total = self._tree.total()
-        seg = total / B
-        idx = np.array([self._tree.find_prefix(min(self._rng.uniform(seg * k, seg * (k + 1)), total * (1 - 1e-12)))
-                        for k in range(B)], np.int64)
-        idx = np.minimum(idx, n - 1)
-        p = self._tree.sum[idx + self._tree.n] / total
-        p_min = self._tree.min[1] / total
-        w = (p * n) ** (-beta) / ((p_min * n) ** (-beta))
-        return idx, w.astype(np.float32)
 
     # ------------------------------------------------------------------ learn
     def learn(self, total_timesteps, callback=None, log_interval=100, tb_log_name=None, reset_num_timesteps=True,
@@ -264,8 +213,7 @@ class _QModel:
                 if self.prioritized_replay:
                     eng.train_per(1, beta_schedule.value(self.num_timesteps))
                 else:
-                    idx, w = self._sample(beta_schedule.value(self.num_timesteps))
-                    eng.train(1, idx[None], w[None])
+                    eng.train(1)                   # uniform indices from the device RNG, importance weights 1
                 self.n_updates += 1
                 callback.on_rollout_start()
             if can_sample and self.num_timesteps > self.learning_starts and \

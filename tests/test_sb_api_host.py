@@ -175,7 +175,7 @@ def test_unsupported_paths_fail_loudly(emulated_engine):
 
 # ---------------------------------------------------------------------------------------------- DQN / BDQ
 from grasp_rl.engine import QEngine                                     # noqa: E402
-from grasp_rl.sb.dqn import BDQ, DQN, SumTree                           # noqa: E402
+from grasp_rl.sb.dqn import BDQ, DQN                                    # noqa: E402
 from stable_baselines.bdq.policies import MlpActPolicy                  # noqa: E402
 from stable_baselines.deepq.policies import MlpPolicy as DQNMlpPolicy  # noqa: E402
 
@@ -238,12 +238,3 @@ def test_bdq_reference_sequence(tmp_path, emulated_q_engine):
     assert m.engine.cfg.algo == 2 and m.engine.cfg.q_branches == 3 and abs(m.engine.cfg.q_trunk_scale - 0.25) < 1e-7
     a, _ = m.predict(np.zeros(20, np.float32))
     assert a.shape == (3,) and set(np.round((a + 1) * 2, 5)) <= {0.0, 1.0, 2.0, 3.0, 4.0}     # bin centres
-
-
-def test_sum_tree_proportional_sampling():
-    t = SumTree(6)
-    t.set(np.arange(6), [1, 2, 3, 4, 0, 10])
-    assert t.total() == 20 and t.min[1] == 0
-    assert t.find_prefix(0.5) == 0 and t.find_prefix(1.5) == 1 and t.find_prefix(9.99) == 3 and t.find_prefix(10.0) == 5
-    t.set(4, 5.0)
-    assert t.total() == 25 and t.find_prefix(10.5) == 4
