@@ -238,3 +238,26 @@ def test_bdq_reference_sequence(tmp_path, emulated_q_engine):
     assert m.engine.cfg.algo == 2 and m.engine.cfg.q_branches == 3 and abs(m.engine.cfg.q_trunk_scale - 0.25) < 1e-7
     a, _ = m.predict(np.zeros(20, np.float32))
     assert a.shape == (3,) and set(np.round((a + 1) * 2, 5)) <= {0.0, 1.0, 2.0, 3.0, 4.0}     # bin centres
+
+
+def test_monitor_logs_are_readable_by_results_plotter(tmp_path):
+    """scripts/plot.py:7,64,76 of the reference: `load_results(folder)` + `ts2xy(result, 'timesteps')` on the CSV
+    our Monitor writes, and on a log the reference ships (its fork adds columns)."""
+    from stable_baselines.results_plotter import load_results, ts2xy
+    env = Monitor(FakeGraspEnv(seed=0, vector_dim=10, episode_len=4), os.path.join(str(tmp_path), "log_file"))
+    for _ in range(3):
+        env.reset()
+        done = False
+        while not done:
+            _, _, done, _ = env.step(np.zeros(5, np.float32))
+    env.close()
+    df = load_results(str(tmp_path))
+    assert list(df.columns[:3]) == ["r", "l", "t"] and len(df) == 3 and np.all(df.l.values == 4)
+    x, y = ts2xy(df, "timesteps")
+    assert list(x) == [4, 8, 12] and len(y) == 3
+    shipped = "/root/reference/trained_models/SAC_depth_1mbuffer"
+    if os.path.isdir(shipped):
+        ref = load_results(shipped)
+        assert {"r", "l", "t", "s"} <= set(ref.columns) and len(ref) > 1000
+        xs, ys = ts2xy(ref, "timesteps", y_column="s")
+        assert np.all(np.diff(xs) > 0) and ys.min() >= 0.0 and ys.max() <= 1.0        # running success rate
