@@ -80,6 +80,27 @@ def test_reference_sbpolicy_trains_saves_and_reloads(reference_sb_helper, tmp_pa
     assert venv.obs_rms.count > 100                           # statistics gathered during the reference's learn()
 
 
+def test_reference_callbacks_fire_on_evaluation(reference_sb_helper, tmp_path, monkeypatch):
+    """base_callbacks.py of the reference: its EvalCallback (:16-117) with the SaveVecNormalizeCallback (:119-149) as
+    `callback_on_new_best` and the TrainingTimeCallback, with an evaluation period short enough to trigger:
+    sync_envs_normalization, evaluate_policy(return_episode_rewards=True), best-model zip, evaluations.npz."""
+    bc = sys.modules["base_callbacks"]
+    monkeypatch.chdir(tmp_path)
+    mk = lambda s: FakeGraspEnv(seed=s, vector_dim=101, episode_len=5)
+    env = VecNormalize(DummyVecEnv([lambda: mk(0)]), norm_obs=True, norm_reward=True, clip_obs=10.)
+    test_env = VecNormalize(DummyVecEnv([lambda: mk(1)]), norm_obs=True, norm_reward=False, clip_obs=10.)
+    save_vn = bc.SaveVecNormalizeCallback(save_freq=1, save_path="best")
+    evalcb = bc.EvalCallback(test_env, best_model_save_path="best", log_path="best/logs", eval_freq=30, n_eval_episodes=2,
+                             callback_on_new_best=save_vn, deterministic=True, render=False)
+    model = sb.SAC(reference_sb_helper.sacMlp, env, policy_kwargs={"layers": [64, 64], "layer_norm": False},
+                   buffer_size=128, batch_size=8, learning_starts=10)
+    model.learn(total_timesteps=70, callback=[evalcb, bc.TrainingTimeCallback()])
+    assert os.path.isfile("best/best_model.zip") and os.path.isfile("best/vecnormalize.pkl")
+    ev = np.load("best/logs/evaluations.npz")
+    assert list(ev["timesteps"]) == [30, 60] and ev["results"].shape == (2, 2) and np.all(ev["ep_lengths"] == 5)
+    assert test_env.obs_rms.count > 60                                    # statistics copied over by sync_envs_normalization
+
+
 def test_reference_sbpolicy_dqn_branch(reference_sb_helper, tmp_path, monkeypatch):
     """sb_helper.py:155-165: `sb.DQN(DQNMlpPolicy, env, verbose, gamma, batch_size, prioritized_replay, tensorboard_log)`
     on the auto-encoder-feature observation (100-d) with 12 discrete actions, prioritised replay on."""
