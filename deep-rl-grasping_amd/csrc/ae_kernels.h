@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void ae_tapsum_kernel(const float* __restrict_
   out[o] = s + bias[0];
 }
 
+// kernel of the 7x7 output convolution re-ordered for its backward-data GEMM: Wp[kh, j, c] = W[kh, 7 - j, c] for
+// j = 1..7 and 0 for j = 0 -- the taps of a kernel row in DESCENDING kw, padded to 8, so that the gradient pixels
+// a quad of taps needs are 4 ascending neighbours in the bordered gradient image (one 16-byte load)
+__global__ __launch_bounds__(256) void ae_out_kernel_flip(const float* __restrict__ W, float* __restrict__ Wp, int C) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 7 * 8 * C) return;
+  const int c = e % C, j = (e / C) % 8, kh = e / (8 * C);
+  Wp[e] = j == 0 ? 0.f : W[(kh * 7 + (7 - j)) * C + c];
+}
+
 // loss value + Keras-Adam step size lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); advances the beta powers
 __global__ void ae_finish_kernel(const float* partial, const float* partial_g, int n_partial, long n_total, float lr,
                                  DevScalars* sc, float* g_out_bias) {

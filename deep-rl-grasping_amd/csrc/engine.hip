@@ -2254,7 +2254,30 @@ int grl_ctx::plan_ae() {
     add_wgrad(one, p, dw[2], 0, 49, -1);
     add_launch(ops_ae, "ae_out_wgrad", 0, one);
   }
-  cb("ae_out_conv_bwd", g_out, gd[2], P + dw[2], g_u6, nullptr);
+  {
+    // backward-data of the output conv: g_u6[p, c] = sum_{kh,kw} g_pad[p - shift(kh,kw)] W[kh,kw,c], a GEMM with
+    // M = pixels, N = 32, K = 7 x 8 taps (each kernel row flipped and padded to 8: ae_kernels.h) on the
+    // vectorised kernel -- the taps of a quad are 4 neighbouring gradient pixels
+    float* Wp = wk.f32(56 * 32);
+    const float* W6 = P + dw[2];
+    elem("ae_out_kernel_flip", [=](hipStream_t s) {
+      hipLaunchKernelGGL(ae_out_kernel_flip, dim3((56 * 32 + 255) / 256), dim3(256), 0, s, W6, Wp, 32);
+    });
+    std::vector<int32_t> ti((size_t)B * 4096), tr(56);
+    for (int n = 0; n < B; ++n)
+      for (int ih = 0; ih < 64; ++ih)
+        for (int iw = 0; iw < 64; ++iw) ti[((size_t)n * 64 + ih) * 64 + iw] = n * 4900 + (ih + 6) * 70 + (iw + 6);
+    for (int kh = 0; kh < 7; ++kh)
+      for (int j = 0; j < 8; ++j) tr[kh * 8 + j] = -kh * 70 - 7 + j;
+    IgemmProb p = blank();
+    p.M = B * 4096; p.N = 32; p.K = 56;
+    p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
+    p.vflags |= VF_P_TABS;                       // 4-runs along the taps, dword-aligned offsets
+    p.q_base[0] = Wp; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
+    p.c = g_u6; p.ldc = 32;
+    set_split(p, 1);
+    add_launch(ops_ae, "ae_out_conv_bwd", 0, {p});
+  }
   up_bwd(g_u6, d5, g_d5, 32);
   cw(u5, ftd[1], gdv[1], g_d5, dw[1], db[1], 32);
   cb("ae_dec_conv_bwd", g_d5, gd[1], P + dw[1], g_u5, nullptr);
