@@ -2303,7 +2303,37 @@ int grl_ctx::plan_ae() {
   cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2);
   cw(e1_p, fte[1], gev[1], g_e2, ew[1], eb[1], 16);
   cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1);
-  cw(x_p, fte[0], gev[0], g_e1, ew[0], eb[0], 64);
+  {
+    // weight gradient of the 1-channel first convolution (7x7, stride 2): rows = taps, each kernel row padded to 8
+    // so that a quad of rows is 4 neighbouring pixels of the bordered image (16-byte loads at dword alignment);
+    // the padding rows (kw = 7) are computed and never reduced
+    std::vector<int32_t> ti(57), tr((size_t)B * 1024);
+    for (int kh = 0; kh < 7; ++kh)
+      for (int j = 0; j < 8; ++j) ti[kh * 8 + j] = kh * 69 + j;
+    ti[56] = 0;
+    for (int n = 0; n < B; ++n)
+      for (int oh = 0; oh < 32; ++oh)
+        for (int ow = 0; ow < 32; ++ow) tr[((size_t)n * 32 + oh) * 32 + ow] = n * 69 * 69 + 2 * oh * 69 + 2 * ow;
+    IgemmProb p = blank();
+    p.M = 57; p.N = 32; p.K = B * 1024;
+    p.p_base[0] = x_p; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
+    p.p_ones_i = 56;
+    p.vflags |= VF_P_TABS;
+    p.q_base[0] = g_e1; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
+    p.ldc = 32;
+    set_split(p, 64);
+    p.c = wk.f32(p.slab_stride * p.split);
+    wgc.push_back(p);
+    for (int kh = 0; kh < 7; ++kh) {
+      ReduceDesc r;
+      r.src = p.c + (int64_t)kh * 8 * 32; r.splits = p.split; r.slab_stride = p.slab_stride;
+      r.dst = grads + ew[0] + (int64_t)kh * 7 * 32; r.n = 7 * 32;
+      reduces.push_back(r);
+    }
+    ReduceDesc rb;
+    rb.src = p.c + (int64_t)56 * 32; rb.splits = p.split; rb.slab_stride = p.slab_stride; rb.dst = grads + eb[0]; rb.n = 32;
+    reduces.push_back(rb);
+  }
   {
     // uniform launches for the vectorised kernel; whatever it cannot take goes to igemm_kernel
     std::vector<IgemmProb> ok_c, rest;
