@@ -207,3 +207,62 @@ def test_reference_train_script_train_then_run(reference_sb_helper, tmp_path, mo
     script.run(types.SimpleNamespace(model="trained/sac_test/sac_test.zip", visualize=False, test=True, stochastic=False))
     assert calls == [1] and len(made) == 3                    # train env, eval env, run env
     sys.modules.pop("train_stable_baselines", None)
+
+
+def test_reference_train_encoder_script(hostemu_lib, tmp_path, monkeypatch):
+    """`manipulation_main/training/train_encoder.py`: its `train(args)` (:30-49) and `test(args)` (:52-64) on the
+    reference's `config/encoder.yaml` (epochs / batch size reduced, `data_path` pointing at a synthetic pickle of
+    the documented layout), with `manipulation_main.gripperEnv.encoders` resolving to `grasp_rl.autoencoder`."""
+    import functools
+    import importlib.util
+    import pickle
+    import yaml
+    from grasp_rl import autoencoder as gae
+
+    real_yaml_load = yaml.load
+    monkeypatch.setattr(yaml, "load", lambda f, Loader=None: real_yaml_load(f, Loader=Loader or yaml.FullLoader))
+    encoders = types.ModuleType("manipulation_main.gripperEnv.encoders")
+    encoders.SimpleAutoEncoder = functools.partial(gae.SimpleAutoEncoder, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    pkgs = {n: types.ModuleType(n) for n in ("manipulation_main", "manipulation_main.gripperEnv", "manipulation_main.common")}
+    for m in pkgs.values():
+        m.__path__ = []
+    pkgs["manipulation_main.gripperEnv"].encoders = encoders
+    for n, m in list(pkgs.items()) + [("manipulation_main.gripperEnv.encoders", encoders)]:
+        monkeypatch.setitem(sys.modules, n, m)
+    spec = importlib.util.spec_from_file_location("manipulation_main.common.io_utils",
+                                                  "/root/reference/manipulation_main/common/io_utils.py")
+    io_utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(io_utils)
+    monkeypatch.setitem(sys.modules, "manipulation_main.common.io_utils", io_utils)
+    pkgs["manipulation_main.common"].io_utils = io_utils
+    import matplotlib
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location("reference_train_encoder", os.path.join(REF_TRAINING, "train_encoder.py"))
+    script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(script)
+
+    rng = np.random.default_rng(0)
+
+    def split(n):
+        depth = np.zeros((n, 64, 64, 1), np.float32)
+        masks = np.zeros((n, 64, 64, 1), np.int32)                      # 0 = flat surface, max = gripper, others = objects
+        for i in range(n):
+            r0, c0 = rng.integers(5, 40, 2)
+            depth[i, r0:r0 + 18, c0:c0 + 16, 0] = rng.uniform(0.2, 0.5)
+            masks[i, r0:r0 + 18, c0:c0 + 16, 0] = 3
+            depth[i, :6, :6, 0] = 0.1
+            masks[i, :6, :6, 0] = 7
+        return {"depth": depth, "masks": masks, "rgb": np.zeros((n, 64, 64, 3), np.uint8)}
+    with open(tmp_path / "imgs.pkl", "wb") as f:
+        pickle.dump({"train": split(8), "test": split(4)}, f)
+    with open("/root/reference/config/encoder.yaml") as f:
+        cfg = yaml.safe_load(f)
+    assert cfg["batch_size"] == 128 and cfg["encoding_dim"] == 100
+    cfg.update(batch_size=4, epochs=2, data_path=str(tmp_path / "imgs.pkl"))
+    with open(tmp_path / "encoder.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    model_dir = str(tmp_path / "enc")
+    script.train(types.SimpleNamespace(config=str(tmp_path / "encoder.yaml"), model_dir=model_dir))
+    assert all(os.path.isfile(os.path.join(model_dir, n)) for n in ("config.yaml", "model.h5", "history.csv"))
+    loss = script.test(types.SimpleNamespace(model_dir=model_dir))
+    assert np.isfinite(loss) and 0.0 < loss < 0.1
