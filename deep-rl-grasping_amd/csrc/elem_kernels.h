@@ -22,10 +22,16 @@ struct DevScalars {
   uint32_t rng_used;                // set by a gather that drew from the device RNG; the loss reduction then advances rng_step
   // metrics of the last update
   float policy_loss, qf1_loss, qf2_loss, value_loss, ent_loss, ent_coef, entropy, mean_qf1, mean_v;
-  float pad1[3];
+  float lr;                         // learning rate of the current update (grl_set_learning_rate; starts at cfg.lr)
+  float pad1[2];
   uint64_t rng_step;                // Philox counter (one per drawn minibatch)
   int64_t replay_size;              // transitions currently stored
 };
+
+// one float written in stream order (grl_set_learning_rate: the step size read by captured graphs)
+__global__ void set_f32_kernel(float* p, float v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // device RNG (Philox4x32-10): replay indices uniform in [0, size) and standard normals
@@ -56,7 +62,8 @@ struct GatherArgs {
   const double* mean; const double* stdv;          // [img_elems] (std = sqrt(var + eps))
   const double* dmean; const double* dstd;         // [n_direct]
   const double* ret_std;                           // [1]
-  int normalize;
+  int normalize;                                   // observations (VecNormalize norm_obs)
+  int normalize_rew;                               // rewards (VecNormalize norm_reward)
   double clip_obs, clip_rew;
   float scale_div;                                 // 255 for CNN policies, 1 for MLP
   float* x_obs; float* x_obs2; float* x_next;      // destinations, row stride ldx
@@ -76,7 +83,7 @@ struct GatherArgs {
   // beta powers and advances them (TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power)).
   // Done here, a whole launch chain before the first consumer, so that the fused reduce + Adam launch
   // can read it from any workgroup without ordering against the workgroup that produces the losses.
-  int adam_tick; float adam_lr;
+  int adam_tick;
 };
 
 __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int normalize, double clip,
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
       }
       if (t == 64) {
         float r = a.rp_rew[src];
-        if (a.normalize) {
+        if (a.normalize_rew) {
           double z = (double)r / a.ret_std[0];
           z = z < -a.clip_rew ? -a.clip_rew : (z > a.clip_rew ? a.clip_rew : z);
           r = (float)z;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
     if (a.use_rng) a.sc->rng_used = 1u;
     if (a.adam_tick) {
       DevScalars* sc = a.sc;
-      sc->adam_alpha = a.adam_lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+      sc->adam_alpha = sc->lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
       sc->beta1_power *= 0.9f;
       sc->beta2_power *= 0.999f;
     }
@@ -389,7 +396,7 @@ inline void sac_loss_body(const LossArgs& a, int fuse_adam = 0) {
   a.g_log_ent_coef[0] = -mean_lp_h;
   sc->ent_coef = alpha; sc->entropy = s[5] * invB; sc->mean_qf1 = s[6] * invB; sc->mean_v = s[7] * invB;
   if (!a.adam_ticked) {
-    sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+    sc->adam_alpha = sc->lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
     sc->beta1_power *= 0.9f;
     sc->beta2_power *= 0.999f;
   }
@@ -449,7 +456,7 @@ __device__ __forceinline__ void sac_loss_body(const LossArgs& a, int fuse_adam =
     sc->mean_v = red[7][0] * invB;
     // TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power); powers advance after
     if (!a.adam_ticked) {
-      sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+      sc->adam_alpha = sc->lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
       sc->beta1_power *= 0.9f;
       sc->beta2_power *= 0.999f;
     }
@@ -538,7 +545,7 @@ __device__ __forceinline__ void q_loss_finish(const QLossArgs& a, float loss, fl
   sc->policy_loss = loss * invB;     // reported as the TD loss
   sc->mean_qf1 = qm * invB;
   sc->value_loss = tdm * invB;       // mean |td|
-  sc->adam_alpha = a.lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+  sc->adam_alpha = sc->lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
   sc->beta1_power *= 0.9f;
   sc->beta2_power *= 0.999f;
   if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch was drawn by the device RNG

@@ -1002,7 +1002,8 @@ int grl_ctx::plan_sac() {
     ga.rp_obs = rp_obs; ga.rp_next = rp_next; ga.rp_dobs = rp_dobs; ga.rp_dnext = rp_dnext;
     ga.rp_act = rp_act; ga.rp_rew = rp_rew; ga.rp_done = rp_done;
     ga.mean = s_mean; ga.stdv = s_std; ga.dmean = s_dmean; ga.dstd = s_dstd; ga.ret_std = s_ret;
-    ga.normalize = c.normalize; ga.clip_obs = c.clip_obs; ga.clip_rew = c.clip_reward;
+    ga.normalize = (c.normalize == 1 || c.normalize == 2); ga.normalize_rew = (c.normalize == 1 || c.normalize == 3);
+    ga.clip_obs = c.clip_obs; ga.clip_rew = c.clip_reward;
     ga.scale_div = cnn ? 255.f : 1.f;
     if (cnn) {
       ga.x_obs = x_obs; ga.x_obs2 = nullptr; ga.x_next = x_next; ga.ldx = img_elems;
@@ -1014,7 +1015,7 @@ int grl_ctx::plan_sac() {
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
     ga.act_out2 = act_p; ga.ld_act2 = Ap;
     ga.sc = sc; ga.seed = c.seed; ga.idx_w = idx_buf; ga.eps_w = eps_buf; ga.n_eps = A;
-    ga.adam_tick = fused_heads ? 1 : 0; ga.adam_lr = c.lr;   // otherwise sac_loss_kernel fixes the step size
+    ga.adam_tick = fused_heads ? 1 : 0;   // otherwise sac_loss_kernel fixes the step size
 #ifndef GRL_HOSTEMU
     ga.vec4 = (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
 #endif
@@ -1561,6 +1562,8 @@ int grl_ctx::plan_sac() {
   dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
   dbg["dmu"] = {dmu, (int64_t)B * A}; dbg["dls"] = {dls, (int64_t)B * A}; dbg["da_pi"] = {da_pi, (int64_t)B * A};
   dbg["grads"] = {grads, n_train};
+  dbg["adam_m"] = {adam_m, n_train};
+  dbg["adam_v"] = {adam_v, n_train};
   return GRL_OK;
 }
 
@@ -1758,7 +1761,8 @@ int grl_ctx::plan_q() {
     ga.rp_obs = rp_obs; ga.rp_next = rp_next; ga.rp_dobs = rp_dobs; ga.rp_dnext = rp_dnext;
     ga.rp_act = rp_act; ga.rp_rew = rp_rew; ga.rp_done = rp_done;
     ga.mean = s_mean; ga.stdv = s_std; ga.dmean = s_dmean; ga.dstd = s_dstd; ga.ret_std = s_ret;
-    ga.normalize = c.normalize; ga.clip_obs = c.clip_obs; ga.clip_rew = c.clip_reward; ga.scale_div = 1.f;
+    ga.normalize = (c.normalize == 1 || c.normalize == 2); ga.normalize_rew = (c.normalize == 1 || c.normalize == 3);
+    ga.clip_obs = c.clip_obs; ga.clip_rew = c.clip_reward; ga.scale_div = 1.f;
     ga.x_obs = feat[0]; ga.x_obs2 = nullptr; ga.x_next = feat[2]; ga.ldx = ldf;
     ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
@@ -2061,6 +2065,8 @@ int grl_ctx::plan_q() {
   dbg["priority"] = {q_prio, B};
   dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
   dbg["grads"] = {grads, n_train};
+  dbg["adam_m"] = {adam_m, n_train};
+  dbg["adam_v"] = {adam_v, n_train};
   return GRL_OK;
 }
 
@@ -2388,6 +2394,8 @@ int grl_ctx::plan_ae() {
   dbg["e3"] = {e3, (int64_t)B * 2048};
   dbg["d5"] = {d5, (int64_t)B * 32 * 32 * 32};
   dbg["grads"] = {grads, n_train};
+  dbg["adam_m"] = {adam_m, n_train};
+  dbg["adam_v"] = {adam_v, n_train};
   return GRL_OK;
 }
 
@@ -2552,6 +2560,7 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
   DevScalars s0;
   memset(&s0, 0, sizeof(s0));
   s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
+  s0.lr = cfg->lr;
   hipError_t e = hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("scalar init: ") + hipGetErrorString(e)); }
   if (h->per_on) {
@@ -2603,6 +2612,14 @@ int grl_reset_optimizer(grl_handle h) {
   HIPCHK(hipMemcpy(&s0, h->sc, sizeof(s0), hipMemcpyDeviceToHost));
   s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
   HIPCHK(hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice));
+  return GRL_OK;
+}
+
+int grl_set_learning_rate(grl_handle h, float lr) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (!(lr >= 0.f)) return fail(GRL_ERR_INVALID, "learning rate must be >= 0");
+  // the step size lives in device memory (the captured graphs read it), set in stream order
+  hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, h->stream, &h->sc->lr, lr);
   return GRL_OK;
 }
 
@@ -2884,6 +2901,17 @@ int64_t grl_debug_fetch(grl_handle h, const char* name, float* out, int64_t cap)
   const int64_t n = std::min(cap, it->second.second);
   if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(GRL_ERR_HIP, "sync failed");
   hipError_t e = hipMemcpy(out, it->second.first, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(GRL_ERR_HIP, hipGetErrorString(e));
+  return n;
+}
+
+int64_t grl_debug_store(grl_handle h, const char* name, const float* in, int64_t n) {
+  if (!h || !name || !in) return fail(GRL_ERR_INVALID, "null argument");
+  auto it = h->dbg.find(name);
+  if (it == h->dbg.end()) return fail(GRL_ERR_INVALID, std::string("unknown tensor ") + name);
+  if (n > it->second.second) return fail(GRL_ERR_INVALID, std::string("too many values for ") + name);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(GRL_ERR_HIP, "sync failed");
+  hipError_t e = hipMemcpy(const_cast<float*>(it->second.first), in, (size_t)n * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail(GRL_ERR_HIP, hipGetErrorString(e));
   return n;
 }

@@ -10,8 +10,7 @@
 // Instead of the sum / min segment trees of the reference implementation (pointer chasing, one update
 // at a time) the ring is cut into blocks of 1024 priorities: a block-sum pass (HBM-bound, 4 B/transition)
 // followed by one workgroup per sample that scans the <= 1024 block sums and then the one block that
-// contains its mass, both with LDS prefix scans.  Sums are float64 so that block boundaries do not
-// depend on the summation tree.
+// contains its mass, both as LDS segment trees in float64 with the reference's association order.
 #pragma once
 #include "elem_kernels.h"
 
@@ -48,24 +47,51 @@ __global__ __launch_bounds__(256) void per_add_kernel(PerArgs a, int64_t pos, in
   if (k < n) a.p[(pos + k) % cap] = powf(a.st->max_priority, a.alpha);
 }
 
+// The sums follow the association order of the reference's SumSegmentTree (stable_baselines/common/
+// segment_tree.py, v2.10.1): a binary tree over the next power of two >= capacity, node = left + right in
+// float64, and the sampler walks it from the root (left child if its sum exceeds the remaining mass, else
+// subtract it and go right).  A block of 1024 priorities is an aligned subtree of height 10, the block sums
+// are the leaves of the upper tree: both trees are rebuilt level by level in LDS and walked exactly like the
+// reference walks its array, so the drawn index is bit-identical to oracle/per.py on the same priorities.
 #ifdef GRL_HOSTEMU
+inline double per_tree_root(double* tr, int leaves) {   // tr[leaves + i] filled; builds tr[1 .. leaves)
+  for (int i = leaves - 1; i >= 1; --i) tr[i] = tr[2 * i] + tr[2 * i + 1];
+  return tr[1];
+}
+inline int per_tree_walk(const double* tr, int leaves, double& rem) {
+  int i = 1;
+  while (i < leaves) {
+    const double left = tr[2 * i];
+    if (left > rem) i = 2 * i;
+    else { rem -= left; i = 2 * i + 1; }
+  }
+  return i - leaves;
+}
 inline void per_blocksum_kernel(PerArgs a) {
   if (threadIdx.x != 0) return;
   const int64_t size = a.sc->replay_size;
   const int64_t i0 = (int64_t)blockIdx.x * PER_BLK;
-  double s = 0.0;
+  static thread_local double tr[2 * PER_BLK];
   float m = INFINITY;
-  for (int64_t i = i0; i < std::min(size, i0 + PER_BLK); ++i) { s += (double)a.p[i]; m = fminf(m, a.p[i]); }
-  a.bsum[blockIdx.x] = s;
+  for (int i = 0; i < PER_BLK; ++i) {
+    const bool in = i0 + i < size;
+    tr[PER_BLK + i] = in ? (double)a.p[i0 + i] : 0.0;
+    if (in) m = fminf(m, a.p[i0 + i]);
+  }
+  a.bsum[blockIdx.x] = per_tree_root(tr, PER_BLK);
   a.bmin[blockIdx.x] = m;
 }
 inline void per_sample_kernel(PerArgs a, int n_blocks) {
   if (threadIdx.x != 0) return;
   const int k = blockIdx.x;
   const int64_t size = a.sc->replay_size;
-  double total = 0.0;
+  static thread_local double tr[2 * PER_BLK];
   float pmin = INFINITY;
-  for (int j = 0; j < n_blocks; ++j) { total += a.bsum[j]; pmin = fminf(pmin, a.bmin[j]); }
+  for (int j = 0; j < PER_BLK; ++j) {
+    tr[PER_BLK + j] = j < n_blocks ? a.bsum[j] : 0.0;
+    if (j < n_blocks) pmin = fminf(pmin, a.bmin[j]);
+  }
+  const double total = per_tree_root(tr, PER_BLK);
   float u;
   if (a.u) u = a.u[k];
   else {
@@ -74,13 +100,12 @@ inline void per_sample_kernel(PerArgs a, int n_blocks) {
     philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     u = (float)(c[0] >> 8) * (1.f / 16777216.f);
   }
-  const double mass = ((double)u + (double)k) * total / (double)a.B;
-  double acc = 0.0;
-  int j = 0;
-  for (; j < n_blocks - 1; ++j) { if (acc + a.bsum[j] > mass) break; acc += a.bsum[j]; }
-  int64_t i = (int64_t)j * PER_BLK;
-  const int64_t iend = std::min(size, i + PER_BLK);
-  for (; i < iend - 1; ++i) { if (acc + (double)a.p[i] > mass) break; acc += (double)a.p[i]; }
+  double rem = ((double)u + (double)k) * total / (double)a.B;
+  const int j = per_tree_walk(tr, PER_BLK, rem);
+  const int64_t b0 = (int64_t)j * PER_BLK;
+  for (int i = 0; i < PER_BLK; ++i) tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? (double)a.p[b0 + i] : 0.0;
+  per_tree_root(tr, PER_BLK);
+  const int64_t i = std::min<int64_t>(b0 + per_tree_walk(tr, PER_BLK, rem), size - 1);
   a.idx_out[k] = i;
   const double ps = (double)a.p[i] / total, pm = (double)pmin / total;
   a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));
@@ -93,61 +118,61 @@ __global__ __launch_bounds__(256) void per_blocksum_kernel(PerArgs a) {
   const int t = threadIdx.x;
   const int64_t size = a.sc->replay_size;
   const int64_t i0 = (int64_t)blockIdx.x * PER_BLK + 4 * t;
-  double s = 0.0;
+  double v[4];
   float m = INFINITY;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (i0 + e < size) { const float v = a.p[i0 + e]; s += (double)v; m = fminf(m, v); }
-  ss[t] = s; sm[t] = m;
+  for (int e = 0; e < 4; ++e) {
+    v[e] = 0.0;
+    if (i0 + e < size) { const float x = a.p[i0 + e]; v[e] = (double)x; m = fminf(m, x); }
+  }
+  ss[t] = (v[0] + v[1]) + (v[2] + v[3]);    // the aligned 4-leaf subtree
+  sm[t] = m;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (t < off) { ss[t] += ss[t + off]; sm[t] = fminf(sm[t], sm[t + off]); }
+  for (int off = 1; off < 256; off <<= 1) {   // adjacent pairs: node = left + right, level by level
+    if ((t & (2 * off - 1)) == 0) { ss[t] = ss[t] + ss[t + off]; sm[t] = fminf(sm[t], sm[t + off]); }
     __syncthreads();
   }
   if (t == 0) { a.bsum[blockIdx.x] = ss[0]; a.bmin[blockIdx.x] = sm[0]; }
 }
 
-// scan of 1024 doubles held 4 per thread (v[0..3] are consecutive elements 4t..4t+3): v becomes the
-// inclusive prefix, ex the exclusive one -- ex of an element IS the inclusive value of its predecessor
-// (same bits), so the intervals [ex, v) tile [0, total) without gaps or overlaps
-__device__ __forceinline__ void per_scan1024(double (&v)[4], double (&ex)[4], double* lds, double& total) {
+// tr[1024 + i] holds leaf i (all 1024 written, barrier done by the caller): builds the internal nodes
+// tr[1 .. 1024) level by level; returns the root.  Ends with a barrier.
+__device__ __forceinline__ double per_tree_build(double* tr) {
   const int t = threadIdx.x;
-  v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
-  lds[t] = v[3];
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {   // Hillis-Steele over the 256 per-thread totals
-    const double x = t >= off ? lds[t - off] : 0.0;
-    __syncthreads();
-    lds[t] += x;
+  for (int n = PER_BLK / 2; n >= 1; n >>= 1) {
+    for (int i = n + t; i < 2 * n; i += 256) tr[i] = tr[2 * i] + tr[2 * i + 1];
     __syncthreads();
   }
-  const double before = t > 0 ? lds[t - 1] : 0.0;
-  total = lds[255];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] += before;
-  ex[0] = before; ex[1] = v[0]; ex[2] = v[1]; ex[3] = v[2];
-  __syncthreads();
+  return tr[1];
+}
+// the reference's find_prefixsum_idx over one 1024-leaf tree; every thread walks (LDS broadcasts)
+__device__ __forceinline__ int per_tree_walk(const double* tr, double& rem) {
+  int i = 1;
+#pragma unroll 1
+  for (int lvl = 0; lvl < 10; ++lvl) {
+    const double left = tr[2 * i];
+    if (left > rem) i = 2 * i;
+    else { rem -= left; i = 2 * i + 1; }
+  }
+  return i - PER_BLK;
 }
 
 __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks) {
-  __shared__ double lds[256];
+  __shared__ double tr[2 * PER_BLK];
   __shared__ float smin[256];
-  __shared__ int sh_j, sh_i;
-  __shared__ double sh_before;
   const int t = threadIdx.x, k = blockIdx.x;
   const int64_t size = a.sc->replay_size;
-  // ---- level 1: prefix over the block sums (n_blocks <= 1024)
-  double v[4];
+  // ---- upper tree: leaves = block sums (zero beyond n_blocks, like the unused leaves of the reference's tree)
   float m = INFINITY;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int j = 4 * t + e;
-    v[e] = j < n_blocks ? a.bsum[j] : 0.0;
+    tr[PER_BLK + j] = j < n_blocks ? a.bsum[j] : 0.0;
     if (j < n_blocks) m = fminf(m, a.bmin[j]);
   }
   smin[t] = m;
-  double total, vx[4];
-  per_scan1024(v, vx, lds, total);
+  __syncthreads();
+  const double total = per_tree_build(tr);
   for (int off = 128; off > 0; off >>= 1) {
     if (t < off) smin[t] = fminf(smin[t], smin[t + off]);
     __syncthreads();
@@ -161,42 +186,21 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
     philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     u = (float)(c[0] >> 8) * (1.f / 16777216.f);
   }
-  const double mass = ((double)u + (double)k) * total / (double)a.B;
-  if (t == 0) { sh_j = n_blocks - 1; sh_before = total; }   // overwritten: exactly one block interval holds the mass
-  __syncthreads();
-  // the first block whose inclusive prefix exceeds the mass: exactly one (thread, e) sees the crossing
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = 4 * t + e;
-    if (j < n_blocks && vx[e] <= mass && v[e] > mass) { sh_j = j; sh_before = vx[e]; }
-  }
-  __syncthreads();
-  const int j = sh_j;
-  const double before = sh_before;
-  // ---- level 2: prefix inside block j
+  double rem = ((double)u + (double)k) * total / (double)a.B;
+  const int j = per_tree_walk(tr, rem);
+  __syncthreads();                                   // everyone is done reading the upper tree
+  // ---- the subtree of block j
   const int64_t b0 = (int64_t)j * PER_BLK;
-  const int64_t nin = min((int64_t)PER_BLK, size - b0);
-  double w[4];
-  float pv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int i = 4 * t + e;
-    pv[e] = i < nin ? a.p[b0 + i] : 0.f;
-    w[e] = (double)pv[e];
-  }
-  double btotal, wx[4];
-  per_scan1024(w, wx, lds, btotal);
-  if (t == 0) sh_i = (int)nin - 1;
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = 4 * t + e;
-    // (a mass within rounding of the block's end finds no crossing and keeps the last element)
-    if (i < nin && before + wx[e] <= mass && before + w[e] > mass) sh_i = i;
+    tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? (double)a.p[b0 + i] : 0.0;
   }
   __syncthreads();
+  per_tree_build(tr);
+  const int i = per_tree_walk(tr, rem);
   if (t == 0) {
-    const int64_t idx = b0 + sh_i;
+    const int64_t idx = min(b0 + (int64_t)i, size - 1);   // a mass that rounds up to the total walks off the stored range
     a.idx_out[k] = idx;
     const double ps = (double)a.p[idx] / total, pm = (double)pmin / total;
     a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));

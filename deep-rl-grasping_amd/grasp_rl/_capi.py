@@ -48,7 +48,7 @@ EXPORTS = [
     "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
     "grl_ae_train_step",
-    "grl_ae_reconstruct",
+    "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate",
 ]
 
 
@@ -79,6 +79,7 @@ def load_library(path=None):
                                    C.POINTER(C.c_int32), C.POINTER(i64 * 4), C.POINTER(C.c_int32)]
     lib.grl_reset_optimizer.argtypes = [vp]
     lib.grl_set_obs_stats.argtypes = [vp, dp, dp, C.c_double]
+    lib.grl_set_learning_rate.argtypes = [vp, C.c_float]
     lib.grl_replay_add.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, i32]
     lib.grl_replay_add_device.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, i32]
     lib.grl_replay_size.argtypes = [vp]
@@ -96,6 +97,8 @@ def load_library(path=None):
     lib.grl_encode.argtypes = [vp, f32p, i32, f32p]
     lib.grl_debug_fetch.argtypes = [vp, C.c_char_p, f32p, i64]
     lib.grl_debug_fetch.restype = i64
+    lib.grl_debug_store.argtypes = [vp, C.c_char_p, f32p, i64]
+    lib.grl_debug_store.restype = i64
     lib.grl_profile_enable.argtypes = [vp, i32]
     lib.grl_profile_query.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.grl_profile_dump.argtypes = [vp, C.c_char_p, i32]
@@ -106,6 +109,21 @@ def check(lib, rc):
     if rc < 0:
         raise GrlError("libgrl: %s (code %d)" % (lib.grl_last_error().decode(), rc))
     return rc
+
+
+def norm_mode(normalize):
+    """grl_config.normalize: 0 off, 1 observations and rewards, 2 observations only, 3 rewards only.
+    Accepts a bool, one of those integers, "obs" / "reward", or an object with norm_obs / norm_reward
+    (a VecNormalize wrapper)."""
+    if hasattr(normalize, "norm_obs"):
+        return {(True, True): 1, (True, False): 2, (False, True): 3, (False, False): 0}[
+            (bool(normalize.norm_obs), bool(normalize.norm_reward))]
+    if normalize in ("obs", "reward"):
+        return {"obs": 2, "reward": 3}[normalize]
+    mode = int(normalize)
+    if mode not in (0, 1, 2, 3):
+        raise GrlError("normalize must be 0..3, a bool, 'obs' or 'reward'")
+    return mode
 
 
 def make_config(extractor, obs_channels=2, n_direct=1, obs_dim=0, act_dim=5, layers=(64, 64), batch_size=64,
@@ -120,7 +138,7 @@ def make_config(extractor, obs_channels=2, n_direct=1, obs_dim=0, act_dim=5, lay
     for i, h in enumerate(layers):
         cfg.layers[i] = int(h)
     cfg.batch_size, cfg.act_batch, cfg.replay_capacity = batch_size, act_batch, replay_capacity
-    cfg.normalize = 1 if normalize else 0
+    cfg.normalize = norm_mode(normalize)
     cfg.gamma, cfg.lr, cfg.tau = gamma, lr, tau
     cfg.clip_obs, cfg.clip_reward, cfg.norm_eps = clip_obs, clip_reward, norm_eps
     cfg.target_entropy = -float(act_dim) if target_entropy is None else target_entropy

@@ -148,6 +148,9 @@ class SimpleAutoEncoder:
         x = np.ascontiguousarray(inputs, np.float32).reshape(-1, 64, 64, 1)
         n_val = int(x.shape[0] * validation_split)
         xt, xv = x[: x.shape[0] - n_val], x[x.shape[0] - n_val:]
+        if xt.shape[0] < batch_size:
+            raise ValueError("%d training images after the validation split, fewer than one batch of %d: the device "
+                             "batch is static (Keras would train on the partial batch)" % (xt.shape[0], batch_size))
         eng = self._engine(batch_size)
         rng = np.random.default_rng(seed)
         os.makedirs(model_dir, exist_ok=True)
@@ -171,7 +174,7 @@ class SimpleAutoEncoder:
                     self.save_weights(model_dir)
                 else:
                     since += 1
-                    if since > patience:
+                    if since >= patience:          # Keras EarlyStopping: stop when `wait >= patience`
                         break
         return hist
 

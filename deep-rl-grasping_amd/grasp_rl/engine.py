@@ -43,8 +43,10 @@ class TorchCudaBackend:
         return self.stream.cuda_stream
 
     def to_device(self, arr):
-        t = self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
-        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        # allocated and filled ON the engine stream: the caching allocator then only hands the block to someone
+        # else after work queued on this stream (the kernels that read it) has been ordered before the reuse
+        with self.torch.cuda.stream(self.stream):
+            t = self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
         return t
 
     def to_host(self, t):
@@ -152,6 +154,9 @@ class SacEngine:
         var = np.ascontiguousarray(var, dtype=np.float64)
         check(self.lib, self.lib.grl_set_obs_stats(self.h, mean.ctypes.data, var.ctypes.data, float(ret_var)))
 
+    def set_learning_rate(self, lr):
+        check(self.lib, self.lib.grl_set_learning_rate(self.h, float(lr)))
+
     def replay_add(self, obs, act, rew, next_obs, done):
         arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (obs, act, rew, next_obs, done)]
         n = arrs[2].reshape(-1).shape[0]
@@ -239,6 +244,11 @@ class SacEngine:
         n = check(self.lib, self.lib.grl_debug_fetch(self.h, name.encode(), buf.ctypes.data, buf.size))
         out = buf[:n].copy()
         return out.reshape(shape) if shape is not None else out
+
+    def store(self, name, arr):
+        """Overwrite a named internal tensor (parity tests only; grl_debug_store)."""
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        check(self.lib, self.lib.grl_debug_store(self.h, name.encode(), arr.ctypes.data, arr.size))
 
     def profile(self, on):
         check(self.lib, self.lib.grl_profile_enable(self.h, 1 if on else 0))

@@ -106,7 +106,7 @@ class _QModel:
             kw = dict(clip_obs=vn.clip_obs, clip_reward=vn.clip_reward, norm_eps=vn.epsilon)
         lr = float(self.learning_rate(1.0)) if callable(self.learning_rate) else float(self.learning_rate)
         cfg = _capi.make_q_config(self.algo, obs_shape[0], D, bins, common, branch, value, batch_size=self.batch_size,
-                                  act_batch=1, replay_capacity=self.buffer_size, normalize=vn is not None, gamma=self.gamma,
+                                  act_batch=1, replay_capacity=self.buffer_size, normalize=0 if vn is None else _capi.norm_mode(vn), gamma=self.gamma,
                                   lr=lr, double_q=self.double_q, seed=0 if self.seed is None else int(self.seed),
                                   prioritized=bool(self.prioritized_replay), per_alpha=self.prioritized_replay_alpha,
                                   per_eps=self.prioritized_replay_eps, **kw)
@@ -176,7 +176,8 @@ class _QModel:
         beta_iters = self.prioritized_replay_beta_iters or total_timesteps
         beta_schedule = LinearSchedule(beta_iters, 1.0, self.prioritized_replay_beta0)
         episode_rewards, episode_successes = [0.0], []
-        writer = None
+        writer = logger.SummaryWriter(self.tensorboard_log, tb_log_name or type(self).__name__) \
+            if getattr(self, "tensorboard_log", None) else None
         obs = self.env.reset()
         obs_ = vn.get_original_obs() if vn is not None else obs
         ring_pos = eng.replay_size() % self.buffer_size
@@ -208,7 +209,7 @@ class _QModel:
             can_sample = eng.replay_size() >= self.batch_size
             if can_sample and self.num_timesteps > self.learning_starts and self.num_timesteps % self.train_freq == 0:
                 callback.on_rollout_end()
-                if vn is not None:
+                if vn is not None and eng.cfg.normalize:
                     eng.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))
                 if self.prioritized_replay:
                     eng.train_per(1, beta_schedule.value(self.num_timesteps))
@@ -231,6 +232,8 @@ class _QModel:
         P = {self._eps_name(): np.float32(self.exploration.value(self.num_timesteps)).reshape(())}
         eng.set_parameters(P, exact_match=False)        # stable-baselines stores the last epsilon with the model
         callback.on_training_end()
+        if writer is not None:
+            writer.close()
         return self
 
     # ------------------------------------------------------------------ persistence

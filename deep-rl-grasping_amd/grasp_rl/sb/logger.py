@@ -67,3 +67,55 @@ def info(*args):
 
 
 warn = error = debug = log = info
+
+
+class SummaryWriter:
+    """Stand-in for the ``tf.summary.FileWriter`` stable-baselines hands to callbacks as ``locals['writer']``
+    when ``tensorboard_log`` is set (the reference's TensorboardCallback calls
+    ``self.locals['writer'].add_summary(tf.Summary(value=[tf.Summary.Value(tag=, simple_value=)]), step)``,
+    /root/reference/manipulation_main/training/sb_helper.py:50-52; `tensorboard_logs` is set in
+    config/full_depth_obs.yaml:65 and simplified_object_picking.yaml:74).  TensorBoard event files are out of
+    scope: scalars that can be read off the summary object are appended to ``<logdir>/scalars.csv``
+    (step, tag, value); anything else is accepted and dropped."""
+
+    def __init__(self, log_dir, tb_log_name="run", new_tb_log=True):
+        n = 1
+        if os.path.isdir(log_dir):
+            runs = [d for d in os.listdir(log_dir) if d.startswith(tb_log_name + "_") and d.rsplit("_", 1)[1].isdigit()]
+            n = max([int(d.rsplit("_", 1)[1]) for d in runs], default=0) + (1 if new_tb_log or not runs else 0)
+        self.log_dir = os.path.join(log_dir, "%s_%d" % (tb_log_name, n))
+        os.makedirs(self.log_dir, exist_ok=True)
+        self._f = open(os.path.join(self.log_dir, "scalars.csv"), "at")
+        if self._f.tell() == 0:
+            self._f.write("step,tag,value\n")
+        self.n_summaries = 0
+
+    @staticmethod
+    def _scalars(summary):
+        vals = getattr(summary, "value", None)
+        if vals is None and isinstance(summary, dict):
+            vals = summary.get("value")
+        out = []
+        for v in vals or []:
+            tag = v.get("tag") if isinstance(v, dict) else getattr(v, "tag", None)
+            val = v.get("simple_value") if isinstance(v, dict) else getattr(v, "simple_value", None)
+            if tag is not None and val is not None:
+                out.append((str(tag), float(val)))
+        return out
+
+    def add_summary(self, summary, global_step=None):
+        self.n_summaries += 1
+        for tag, val in self._scalars(summary):
+            self._f.write("%s,%s,%.9g\n" % ("" if global_step is None else int(global_step), tag, val))
+
+    def add_run_metadata(self, *a, **k):
+        pass
+
+    add_graph = add_event = add_run_metadata
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        if not self._f.closed:
+            self._f.close()

@@ -118,8 +118,8 @@ class SAC:
         if self.target_entropy == "auto":
             self.target_entropy = -np.prod(self.action_space.shape).astype(np.float32)
         kw = dict(act_dim=act_dim, layers=layers, batch_size=self.batch_size, act_batch=max(1, self.n_envs),
-                  replay_capacity=self.buffer_size, normalize=self._vec_normalize_env is not None
-                  and (self._vec_normalize_env.norm_obs or self._vec_normalize_env.norm_reward),
+                  replay_capacity=self.buffer_size,
+                  normalize=0 if self._vec_normalize_env is None else _capi.norm_mode(self._vec_normalize_env),
                   gamma=self.gamma, lr=self._learning_rate_value(), tau=self.tau,
                   target_entropy=float(self.target_entropy), seed=0 if self.seed is None else int(self.seed))
         if self._vec_normalize_env is not None:
@@ -141,10 +141,6 @@ class SAC:
         params = init_parameters(self.engine.table, seed=0 if self.seed is None else int(self.seed))
         params["model/log_ent_coef:0"] = np.float32(np.log(self._ent_init)).reshape(())
         self.engine.set_parameters(params)
-        vn = self._vec_normalize_env
-        if vn is not None and vn.norm_obs != vn.norm_reward:
-            raise NotImplementedError("training with norm_obs != norm_reward is not implemented "
-                                      "(the reference trains with both on: sb_helper.py:117-119)")
 
     def _sync_norm_stats(self):
         """VecNormalize statistics are updated on the env side every step and read at sample time
@@ -200,7 +196,8 @@ class SAC:
         n_episodes = 0
         infos_values = {}
         start = time.time()
-        writer = None                                    # TensorBoard is not wired; callbacks see None
+        # stable-baselines hands callbacks a FileWriter when tensorboard_log is set, None otherwise
+        writer = logger.SummaryWriter(self.tensorboard_log, tb_log_name) if self.tensorboard_log else None
         obs = self.env.reset()
         obs_ = vn.get_original_obs() if vn is not None else obs
         callback.on_training_start(locals(), globals())
@@ -222,6 +219,9 @@ class SAC:
                         break
                     self.n_updates += 1
                     self._sync_norm_stats()
+                    if callable(self.learning_rate):    # SB: frac = 1 - step / total (step = index of this env step)
+                        done_steps = max(0, self.num_timesteps - N)
+                        eng.set_learning_rate(self.learning_rate(1.0 - done_steps / max(1, total_timesteps)))
                     eng.train(1)
                 callback.on_rollout_start()
 
@@ -281,6 +281,8 @@ class SAC:
                     logger.logkv("total timesteps", self.num_timesteps)
                     logger.dumpkvs()
         callback.on_training_end()
+        if writer is not None:
+            writer.close()
         return self
 
     # ------------------------------------------------------------------ parameters / persistence
@@ -323,8 +325,11 @@ class SAC:
         if "policy_kwargs" in kwargs and kwargs["policy_kwargs"] != data.get("policy_kwargs"):
             raise ValueError("the specified policy kwargs do not equal the stored policy kwargs")
         policy = data.get("policy")
+        inferred_policy, inferred_kwargs = pol.infer_sac_policy_kwargs(params)
         if policy is None or not isinstance(policy, type):
-            policy = pol.SacCnnPolicy if any("/cnn" in n or "/c1/" in n for n in params) else pol.SacMlpPolicy
+            policy = inferred_policy
+        if not isinstance(data.get("policy_kwargs"), dict):   # e.g. a cloudpickled extractor closure that was not unpickled
+            data["policy_kwargs"] = inferred_kwargs
         model = cls(policy=policy, env=None, _init_setup_model=False)
         for k in ("gamma", "buffer_size", "learning_starts", "train_freq", "batch_size", "tau", "ent_coef", "verbose",
                   "n_envs", "seed", "random_exploration", "policy_kwargs", "target_entropy"):

@@ -8,6 +8,7 @@ VecNormalize arithmetic follows SURVEY.md A.1 (float64 statistics, clip, epsilon
 return for the reward scale); its statistics are what the engine reads at replay-sample time.
 """
 import copy
+import os
 import pickle
 
 import numpy as np
@@ -362,12 +363,24 @@ class VecNormalize(VecEnvWrapper):
 
 
 class _CompatUnpickler(pickle.Unpickler):
+    """Unpickler for files that may come from elsewhere (``vecnormalize.pkl``, the ``:serialized:`` members of
+    a model zip).  Only what those files legitimately hold can be constructed: NumPy arrays / dtypes / random
+    states, plain containers, ``VecNormalize`` / ``RunningMeanStd`` / ``Box`` / ``Discrete`` (whatever package
+    path they were pickled under) and the policy *selector* classes.  Any other global -- in particular
+    arbitrary callables such as ``os.system`` or a cloudpickled function body -- raises ``UnpicklingError``;
+    the model loaders then rebuild the value from the readable copies stored next to it
+    (save_util.json_to_data) or from the parameter shapes.  ``GRL_TRUST_PICKLES=1`` lifts the restriction for
+    files you produced yourself."""
     _MAP = {
         ("VecNormalize",): lambda: VecNormalize,
         ("RunningMeanStd",): lambda: RunningMeanStd,
         ("Box",): lambda: sp.Box,
         ("Discrete",): lambda: sp.Discrete,
     }
+    _BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                 "complex", "slice", "range", "object"}
+    _OTHER = {("collections", "OrderedDict"), ("collections", "deque"), ("copyreg", "_reconstructor"),
+              ("copy_reg", "_reconstructor"), ("_codecs", "encode")}
 
     def find_class(self, module, name):
         if module.startswith("numpy"):
@@ -376,10 +389,24 @@ class _CompatUnpickler(pickle.Unpickler):
                     return super().find_class(m, name)
                 except (ImportError, AttributeError):
                     continue
-        if module.split(".")[0] in ("stable_baselines", "gym", "gymnasium", "grasp_rl"):
+        top = module.split(".")[0]
+        if top in ("stable_baselines", "gym", "gymnasium", "grasp_rl"):
             if (name,) in self._MAP:
                 return self._MAP[(name,)]()
-        return super().find_class(module, name)
+            if module.endswith("policies"):
+                from . import policies as pol
+                try:
+                    obj = super().find_class(module, name)
+                except (ImportError, AttributeError):
+                    obj = None
+                if isinstance(obj, type) and issubclass(obj, (pol.BasePolicy, pol.AugmentedNatureCnn)):
+                    return obj
+        if (module in ("builtins", "__builtin__") and name in self._BUILTINS) or (module, name) in self._OTHER:
+            return super().find_class("builtins" if module == "__builtin__" else module, name)
+        if os.environ.get("GRL_TRUST_PICKLES", "0") == "1":
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("global %s.%s is not on the allow-list of files this package reads "
+                                     "(set GRL_TRUST_PICKLES=1 for files you created yourself)" % (module, name))
 
 
 def unwrap_vec_normalize(env):

@@ -71,7 +71,9 @@ typedef struct grl_config {
   int32_t batch_size;     /* per-GPU minibatch                                                  */
   int32_t act_batch;      /* max observations per grl_act call (vectorised envs)                */
   int64_t replay_capacity;
-  int32_t normalize;      /* config['normalize'] -> VecNormalize at sample time                 */
+  int32_t normalize;      /* config['normalize'] -> VecNormalize at sample time: 0 off, 1 observations and
+                             rewards (sb_helper.py:117-119), 2 observations only (norm_reward=False),
+                             3 rewards only (norm_obs=False)                                     */
   float gamma, lr, tau;
   float clip_obs, clip_reward, norm_eps;
   float target_entropy;   /* -act_dim for ent_coef='auto'                                       */
@@ -135,6 +137,11 @@ int grl_param_info(grl_handle h, int index, char* name, int name_cap, int64_t* o
 /* re-initialise Adam moments / beta powers (after load_parameters) */
 int grl_reset_optimizer(grl_handle h);
 
+/* learning rate of the following updates (stable-baselines evaluates `learning_rate(progress)` before every
+   update when a schedule is given; a constant needs no call: updates start with cfg.lr).  Takes effect in
+   stream order; captured graphs stay valid (the value lives in device memory). */
+int grl_set_learning_rate(grl_handle h, float lr);
+
 /* VecNormalize statistics (host float64, HWC layout of the observation space or [obs_dim]);
    obs_var/ret_var are variances, epsilon is added inside.  Copied before returning. */
 int grl_set_obs_stats(grl_handle h, const double* obs_mean, const double* obs_var, double ret_var);
@@ -192,6 +199,10 @@ int grl_encode(grl_handle h, const float* depth, int n, float* out_feat);
    Names: "x_obs","x_next","feat_pi","feat_vf","feat_tgt","mu","log_std","pi","logp","qf1","qf2",
    "v","v_tgt","qf1_pi","qf2_pi","rew","done".  Returns the number of floats written or <0. */
 int64_t grl_debug_fetch(grl_handle h, const char* name, float* out, int64_t cap);
+/* debugging / parity: overwrite the first n floats of a named internal tensor from host memory (the parity
+   tests place arbitrary stored priorities "per_p" or optimiser moments "adam_m" / "adam_v" this way; no
+   reference call stands behind it).  Synchronises the stream.  Returns n or <0. */
+int64_t grl_debug_store(grl_handle h, const char* name, const float* in, int64_t n);
 
 /* wall-clock free kernel timing: enables hipEvent timing of tagged kernels in later steps */
 int grl_profile_enable(grl_handle h, int on);

@@ -172,13 +172,15 @@ def rms_update(mean, var, count, x):
     return new_mean, m2 / tot, tot
 
 
-def prepare_batch(spec, raw, stats):
+def prepare_batch(spec, raw, stats, norm_obs=True, norm_reward=True):
     """raw: dict obs[B,H,W,Cobs]|[B,D], act, rew, next_obs, done.  stats: obs mean/var, ret_var
-    (or None for ``normalize: False`` configs).  Returns float32 torch tensors as fed to TF."""
+    (or None for ``normalize: False`` configs); norm_obs / norm_reward are the VecNormalize flags of the same
+    names (both on in the reference, sb_helper.py:117-119).  Returns float32 torch tensors as fed to TF."""
     obs, nxt, rew = raw["obs"], raw["next_obs"], raw["rew"]
-    if stats is not None:
+    if stats is not None and norm_obs:
         obs = normalize_obs(obs, stats["mean"], stats["var"], spec.clip_obs, spec.norm_eps)
         nxt = normalize_obs(nxt, stats["mean"], stats["var"], spec.clip_obs, spec.norm_eps)
+    if stats is not None and norm_reward:
         rew = normalize_reward(rew, stats["ret_var"], spec.clip_reward, spec.norm_eps)
     obs = torch.from_numpy(np.asarray(obs, np.float32))
     nxt = torch.from_numpy(np.asarray(nxt, np.float32))

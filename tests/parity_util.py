@@ -55,7 +55,9 @@ def oracle_run(case):
     for s in range(case["n_steps"]):
         ii = case["idx"][s]
         raw = {k: tr[k][ii] for k in ("obs", "act", "rew", "next_obs", "done")}
-        batch = osac.prepare_batch(spec, raw, case["stats"] if case["normalize"] else None)
+        nm = case["normalize"]          # True / False / "obs" / "reward" (VecNormalize norm_obs / norm_reward)
+        batch = osac.prepare_batch(spec, raw, case["stats"] if nm else None, norm_obs=nm in (True, "obs"),
+                                   norm_reward=nm in (True, "reward"))
         d = orc.step(batch, case["eps"][s])
         d["batch"] = batch
         out.append(d)
@@ -123,13 +125,86 @@ def compare_first_step(eng, case, d0):
         close_rel_max(G[n], g, what="grad " + n)
 
 
+def adam_state(eng):
+    """(m, v) of the engine's optimiser as name -> ndarray (trainable variables)."""
+    fm, fv = eng.fetch("adam_m", (eng.n_trainable,)), eng.fetch("adam_v", (eng.n_trainable,))
+    m, v = OrderedDict(), OrderedDict()
+    for name, off, numel, shape, tr in eng.table:
+        if tr:
+            m[name] = fm[off:off + numel].reshape(shape).copy()
+            v[name] = fv[off:off + numel].reshape(shape).copy()
+    return m, v
+
+
+def check_apply_step(eng, t, lr, tau=None, polyak=None, apply=None, rel_step=1e-3):
+    """TIGHT check of the optimiser in isolation.  With gradients already in the engine's bucket
+    (after ``compute_grads``): read parameters, moments and gradients, run ``apply_grads`` (or `apply`), and
+    compare with the oracle's TF-Adam (oracle/sac.py: adam_apply) fed the SAME float32 inputs at step `t`
+    (1-based).  Identical inputs leave only float32 rounding inside the Adam expression, so every weight must
+    agree to 1e-3 of one Adam step (lr) plus 2 ulp of the weight, the moments to 1e-6 relative: an epsilon
+    placed inside the bias correction, a wrong beta power or a swapped moment is hundreds of times larger.
+    `polyak`: list of (target_name, source_name) updated with `tau` after the step (SAC target_update_op)."""
+    P0, G = eng.get_parameters(), eng.get_gradients()
+    m0, v0 = adam_state(eng)
+    f = np.float32
+    st = {"m": {n: m0[n].copy() for n in G}, "v": {n: v0[n].copy() for n in G},
+          "beta1_power": f(1), "beta2_power": f(1)}
+    for _ in range(t):                                     # float32 products, as TF keeps them
+        st["beta1_power"] = f(st["beta1_power"] * f(0.9))
+        st["beta2_power"] = f(st["beta2_power"] * f(0.999))
+    Pref = OrderedDict((n, P0[n].copy()) for n in P0)
+    osac.adam_apply(Pref, G, st, lr)
+    if polyak:
+        for tn, sn in polyak:
+            Pref[tn] = ((f(1) - f(tau)) * Pref[tn] + f(tau) * Pref[sn]).astype(np.float32)
+    (apply or (lambda: eng.apply_grads(1.0)))()
+    P1 = eng.get_parameters()
+    m1, v1 = adam_state(eng)
+    for n in Pref:
+        d = np.abs(P1[n].astype(np.float64) - Pref[n].astype(np.float64))
+        bound = rel_step * lr + 2.4e-7 * np.abs(Pref[n].astype(np.float64))
+        assert (d <= bound).all(), "Adam/Polyak %s: max |d| %.3e at step %d (lr %.1e)" % (n, d.max(), t, lr)
+    for n in G:
+        assert np.allclose(m1[n], st["m"][n], rtol=1e-6, atol=1e-12), "Adam m " + n
+        assert np.allclose(v1[n], st["v"][n], rtol=1e-6, atol=1e-20), "Adam v " + n
+    return P1
+
+
+def check_optimiser_steps(case, backend=None, lib_path=None, n=3):
+    """`check_apply_step` on n consecutive SAC updates of `case` (split path; the fused path is bit-identical to
+    it, tests/test_gpu_parity.py::test_split_api_equals_fused_and_is_deterministic)."""
+    spec = case["spec"]
+    eng = engine_setup(case, backend=backend, lib_path=lib_path)
+    pairs = osac.polyak_pairs(spec)
+    for s in range(n):
+        k = s % case["n_steps"]
+        eng.compute_grads(case["idx"][k:k + 1], case["eps"][k:k + 1])
+        check_apply_step(eng, s + 1, spec.lr, spec.tau, pairs)
+    eng.close()
+
+
+def compare_moments(eng, orc_opts):
+    """Adam moments after n updates against the oracle's (list of adam_init dicts): gradient-level tolerance
+    (1e-3 of the per-tensor max) -- m is a decayed sum of gradients, v of their squares."""
+    m, v = adam_state(eng)
+    for st in orc_opts:
+        for n in st["m"]:
+            close_rel_max(m[n], st["m"][n], what="Adam m " + n, floor=1e-20)
+            close_rel_max(v[n], st["v"][n], rel=2e-3, what="Adam v " + n, floor=1e-30)
+
+
 def compare_params(eng, orc, lr, n_steps):
     """Post-update weights.  Adam's first steps move every weight by ~lr*sign(g), so the comparison
     is made on the scale of the update, not of the weight: max |d| <= 0.3*lr*n_steps and
-    mean |d| <= 0.02*lr*n_steps per tensor (elements whose gradient is ~0 are sign-sensitive)."""
+    mean |d| <= 0.02*lr*n_steps per tensor (elements whose gradient is ~0 are sign-sensitive).
+    The optimiser itself is pinned tightly by `check_apply_step` (same inputs -> 1e-3 of a step) and
+    `compare_moments`; this end-to-end check only has to catch what those two cannot: a wrong hand-over between
+    the gradient bucket and the optimiser."""
     P = eng.get_parameters()
     for n, ref in orc.P.items():
         d = np.abs(np.asarray(P[n], np.float64) - np.asarray(ref, np.float64))
         assert P[n].shape == ref.shape, n
         assert d.max() <= 0.3 * lr * n_steps + 1e-7, "param %s: max |d| %.3e (lr %.1e)" % (n, d.max(), lr)
         assert d.mean() <= 0.02 * lr * n_steps + 1e-9, "param %s: mean |d| %.3e (lr %.1e)" % (n, d.mean(), lr)
+    if hasattr(orc, "opt"):
+        compare_moments(eng, orc.opt if isinstance(orc.opt, list) else [orc.opt])

@@ -13,6 +13,9 @@ CASES = {
     "bdq": dict(algo="bdq", obs_dim=20, D=3, bins=5, common=(16, 16), branch=(8,), value=(8,), B=8),
     "bdq_5_branches": dict(algo="bdq", obs_dim=24, D=5, bins=7, common=(32, 16), branch=(8,), value=(12,), B=9),
     "bdq_reference_shape": dict(algo="bdq", obs_dim=100, D=3, bins=33, common=(64, 64), branch=(32,), value=(32,), B=64),
+    # BASELINE configs[2] exactly: gripper_grasp.yaml:104-118 (layers [[64,64],[32],[32]], num_actions_pad 33,
+    # batch 64) on the 101-d auto-encoder observation (100 features + gripper width), 5 action dimensions
+    "bdq_baseline_config3": dict(algo="bdq", obs_dim=101, D=5, bins=33, common=(64, 64), branch=(32,), value=(32,), B=64, lr=1e-4),
 }
 
 
@@ -103,13 +106,13 @@ def run_and_compare(case, backend=None, lib_path=None):
 
 # ---------------------------------------------------------------------------------------------------
 # prioritised replay on the device (csrc/per_kernels.h) against oracle/per.py, draw for draw
-def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps=4, seed=3):
-    """Fill, then alternate (sample with explicit uniforms -> update -> priorities written back).  The chosen
-    index must own the stratified mass (interval check against float64 prefix sums of the SAME float32
-    priorities), the importance weights and the stored priorities must match the oracle."""
+def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps=4, seed=3, case_name="dqn"):
+    """Fill, then alternate (sample with explicit uniforms -> update -> priorities written back).  The drawn
+    indices must EQUAL the oracle's segment-tree walk over the same float32 priorities; the importance weights
+    and the stored priorities must match the oracle within float tolerances."""
     from oracle.per import PerOracle
     rng = np.random.default_rng(seed)
-    c = dict(CASES["dqn"])
+    c = dict(CASES[case_name])
     c["B"] = B
     case = make_q_case(n_replay=n_store, n_steps=n_steps, **c)
     case["cfg"].replay_capacity = cap
@@ -122,16 +125,19 @@ def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps
     for s in range(n_steps):
         beta = 0.4 + 0.15 * s
         u = rng.random(B).astype(np.float32)
+        # index work is bit-exact: hand the oracle the float32 priorities the device holds (its own powf results
+        # may differ from NumPy's in the last bit -- checked separately below with a tolerance) and require the
+        # segment-tree walk over them to name the SAME transitions
+        orc.p[:] = eng.stored_priorities()
         eng.train_per(1, beta, u[None])
         idx = eng.sampled_indices()
         w = eng.importance_weights()
         ref_idx, ref_w, mass, prefix = orc.sample(u, beta)
-        # the device block scan may round a boundary differently: accept any index whose interval holds the mass
+        assert np.array_equal(idx, ref_idx), (idx, ref_idx)
+        # (and the walk's answer owns the stratified mass of the sequential float64 prefix sums up to rounding)
         tol = 1e-9 * prefix[-1]
-        assert np.all((prefix[idx] <= mass + tol) & (mass < prefix[idx + 1] + tol)), (idx, ref_idx)
-        assert np.mean(idx == ref_idx) > 0.9
-        same = idx == ref_idx
-        assert np.allclose(w[same], ref_w[same], rtol=2e-5, atol=1e-7), (w, ref_w)
+        assert np.all((prefix[idx] <= mass + tol) & (mass < prefix[idx + 1] + tol))
+        assert np.allclose(w, ref_w, rtol=2e-5, atol=1e-7), (w, ref_w)
         assert w.max() <= 1.0 + 1e-6 and w.min() > 0
         prio = eng.priorities()                        # sum_d |td_d| of the minibatch just trained on
         orc.update(idx, prio)

@@ -107,6 +107,22 @@ def test_prioritised_sampler_over_one_million_priorities():
     assert np.array_equal(idx, want), (idx[:4], want[:4])
     w = eng.importance_weights()
     assert np.allclose(w, 1.0, atol=1e-6)
+    # arbitrary priorities over the whole ring: the drawn indices must EQUAL the oracle's segment-tree walk over
+    # the same one million float32 values (2^20-leaf tree, 1024 blocks of 1024), weights within float tolerance
+    from oracle.per import PerOracle
+    prng = np.random.default_rng(21)
+    pvals = (prng.gamma(0.7, 1.0, CAP).astype(np.float32) + np.float32(1e-6)) ** np.float32(0.6)
+    pvals[prng.integers(0, CAP, 1000)] *= np.float32(300.0)          # a few very heavy transitions
+    eng.store("per_p", pvals)
+    orc = PerOracle(CAP, 0.6, 1e-6)
+    orc.add(CAP)
+    for trial in range(3):
+        orc.p[:] = eng.stored_priorities()
+        uu = prng.random(64).astype(np.float32)
+        eng.train_per(1, beta=0.7, u=uu[None])
+        ref_idx, ref_w, _, _ = orc.sample(uu, 0.7)
+        assert np.array_equal(eng.sampled_indices(), ref_idx), trial
+        assert np.allclose(eng.importance_weights(), ref_w, rtol=2e-5, atol=1e-7)
     # after the write-back the trained transitions carry new priorities; sampling keeps working
     eng.train_per(20, beta=0.5)
     idx = eng.sampled_indices()

@@ -23,6 +23,8 @@ CASES = {
     "mlp_wide_3layer": dict(extractor="mlp", B=33, n_replay=64, layers=(128, 128, 32), obs_dim=37),
     "depth_no_normalize": dict(extractor="augmented", kind="depth", B=4, n_replay=16, normalize=False),
     "batch_1": dict(extractor="augmented", kind="depth", B=1, n_replay=3),
+    "depth_norm_obs_only": dict(extractor="augmented", kind="depth", B=8, n_replay=16, normalize="obs"),
+    "mlp_norm_reward_only": dict(extractor="mlp", B=16, n_replay=32, normalize="reward"),
 }
 
 
@@ -65,6 +67,41 @@ def test_headline_config_b256():
     m = eng.metrics()
     assert abs(m["policy_loss"] - float(ref[2]["policy_loss"])) <= 2e-3 * abs(float(ref[2]["policy_loss"])) + 1e-4
     eng.close()
+
+
+def test_rgbd_config_b256():
+    """BASELINE configs[3]: RGB-D observation 64x64x5 (4 image channels + the direct-feature channel), batch 256,
+    augmented extractor, layers [64,64], A=5 -- three updates (trained_models/SAC_full_rgbd/config.yaml:25-33,47-50)."""
+    case = pu.make_case(extractor="augmented", kind="rgbd", B=256, n_replay=400, n_steps=3)
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(2, case["idx"][1:3], case["eps"][1:3])
+    pu.compare_params(eng, orc, case["spec"].lr, 3)
+    eng.close()
+
+
+def test_cpu_reference_config_nature_b64():
+    """BASELINE configs[0]: simplified_object_picking.yaml with depth observations -> sacCnn with the default
+    nature_cnn over both channels, default layers [64,64], A=3, batch 64, no VecNormalize
+    (sb_helper.py:91-93; simplified_object_picking.yaml:67,80)."""
+    case = pu.make_case(extractor="nature", kind="depth", B=64, n_replay=200, act_dim=3, normalize=False, n_steps=3)
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(2, case["idx"][1:3], case["eps"][1:3])
+    pu.compare_params(eng, orc, case["spec"].lr, 3)
+    eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(extractor="augmented", kind="depth", B=256, n_replay=300),
+                                dict(extractor="mlp", B=64, n_replay=128)], ids=["depth_b256", "mlp_b64"])
+def test_optimiser_step_is_tf_adam_on_identical_inputs(kw):
+    """Adam / Polyak kernels in isolation: the device's own gradients, moments and weights are handed to the
+    oracle's TF-Adam; weights must agree to 1e-3 of ONE step, moments to 1e-6 (parity_util.check_apply_step)."""
+    pu.check_optimiser_steps(pu.make_case(n_steps=3, **kw), n=4)
 
 
 def test_graph_replay_equals_eager(monkeypatch):

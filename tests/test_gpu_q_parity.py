@@ -36,6 +36,9 @@ def test_q_device_rng_mode_trains():
 
 
 def test_prioritised_replay_gpu():
-    """Block-scan sampler, importance weights and priority write-back on the MI355X against oracle/per.py."""
+    """Segment-tree sampler (indices bit-exact), importance weights and priority write-back on the MI355X
+    against oracle/per.py; the last case is BASELINE configs[2] (BDQ 5 x 33 bins on 101-d observations, batch 64,
+    prioritised replay on -- gripper_grasp.yaml:102,104-118)."""
     qu.per_check()
     qu.per_check(cap=5000, n_store=5000, B=64, n_steps=3, seed=11)
+    qu.per_check(cap=20000, n_store=17000, B=64, n_steps=4, seed=5, case_name="bdq_baseline_config3")

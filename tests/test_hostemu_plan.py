@@ -21,6 +21,9 @@ CASES = {
     "mlp_features": dict(extractor="mlp", B=16, n_replay=64),
     "mlp_wide_3layer": dict(extractor="mlp", B=8, n_replay=32, layers=(128, 128, 32), obs_dim=37),
     "depth_no_normalize": dict(extractor="augmented", kind="depth", B=4, n_replay=16, normalize=False),
+    # VecNormalize(norm_obs=True, norm_reward=False) / (False, True): each flag honoured on its own
+    "depth_norm_obs_only": dict(extractor="augmented", kind="depth", B=4, n_replay=16, normalize="obs"),
+    "mlp_norm_reward_only": dict(extractor="mlp", B=8, n_replay=32, normalize="reward"),
 }
 
 
@@ -56,6 +59,14 @@ def test_plan_matches_oracle(hostemu_lib, name):
     for n in Pa:
         assert np.array_equal(Pa[n], Pb[n]), n
     eng.close(); eng2.close()
+
+
+@pytest.mark.parametrize("name", ["depth_augmented", "mlp_features"])
+def test_optimiser_step_is_tf_adam_on_identical_inputs(hostemu_lib, name):
+    """Adam / Polyak bookkeeping of the plan in isolation: same gradients, moments and weights into the oracle's
+    TF-Adam -> weights within 1e-3 of one step, moments 1e-6 relative (tests/parity_util.py: check_apply_step)."""
+    case = pu.make_case(n_steps=2, **CASES[name])
+    pu.check_optimiser_steps(case, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=3)
 
 
 def test_act_matches_oracle(hostemu_lib):

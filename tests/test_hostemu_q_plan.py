@@ -7,7 +7,7 @@ from hostemu_backend import NumpyHostBackend
 from oracle import dqn as od
 
 
-@pytest.mark.parametrize("name", ["dqn", "bdq", "bdq_5_branches"])
+@pytest.mark.parametrize("name", ["dqn", "bdq", "bdq_5_branches", "bdq_baseline_config3"])
 def test_q_plan_matches_oracle(hostemu_lib, name):
     case = qu.make_q_case(**qu.CASES[name])
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
@@ -43,3 +43,6 @@ def test_prioritised_replay_plan(hostemu_lib):
     """Sampler / priority write-back / add semantics of the device PER against oracle/per.py (CPU, host emulation)."""
     from hostemu_backend import NumpyHostBackend
     qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=4096, n_store=4096, B=32, n_steps=2, seed=9)
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=2500, n_store=2100, B=64, n_steps=2, seed=5,
+                 case_name="bdq_baseline_config3")

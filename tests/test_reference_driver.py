@@ -35,7 +35,7 @@ def reference_sb_helper(monkeypatch, hostemu_lib):
     tf = types.ModuleType("tensorflow")
     tf.nn = types.SimpleNamespace(relu=lambda x: x)
     tf.contrib = types.SimpleNamespace()
-    tf.Summary = type("Summary", (), {"Value": staticmethod(lambda **k: k), "__init__": lambda self, **k: None})
+    tf.Summary = type("Summary", (), {"Value": staticmethod(lambda **k: k), "__init__": lambda self, **k: self.__dict__.update(k)})
     gym = types.ModuleType("gym")
     gym.Env = type("Env", (), {})
     gym.spaces = spaces
@@ -78,6 +78,47 @@ def test_reference_sbpolicy_trains_saves_and_reloads(reference_sb_helper, tmp_pa
     P = model.get_parameters()
     assert "model/pi/c1/w:0" in P or any(k.startswith("model/pi/") for k in P)
     assert venv.obs_rms.count > 100                           # statistics gathered during the reference's learn()
+
+
+def test_reference_sbpolicy_load_dir_transfer_and_tensorboard(reference_sb_helper, tmp_path, monkeypatch):
+    """sb_helper.py:97-115, the `--load_dir` branch: `VecNormalize(env, training=True, norm_obs=False,
+    norm_reward=False)` -> `VecNormalize.load(<top folder>/vecnormalize.pkl, env)` -> `sb.SAC(...)` ->
+    `sb.SAC.load(load_dir, env)` -> `get_parameters()` -> `load_parameters(params, exact_match=False)`; with
+    `tensorboard_logs` set (config/full_depth_obs.yaml:65) so that the reference's TensorboardCallback reaches
+    `self.locals['writer'].add_summary(...)` (sb_helper.py:50-52)."""
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("models/first")
+    os.makedirs("models/second")
+    sac = {"tensorboard_logs": None, "layers": [64, 64], "buffer_size": 256, "batch_size": 4, "step_size": 3e-4,
+           "total_timesteps": 108}
+    mk = lambda d, s: DummyVecEnv([lambda: Monitor(FakeGraspEnv("depth", seed=s), os.path.join(d, "log_file"))])
+    first = reference_sb_helper.SBPolicy(mk("models/first", 0), DummyVecEnv([lambda: FakeGraspEnv("depth", seed=1)]),
+                                         {"normalize": True, "discount_factor": 0.99, "SAC": dict(sac)}, "models/first",
+                                         algo="SAC")
+    first.learn()
+    P_first = sb.SAC.load("models/first/first.zip").get_parameters()
+    cfg2 = {"normalize": True, "discount_factor": 0.99, "SAC": dict(sac, tensorboard_logs=True, total_timesteps=104)}
+    second = reference_sb_helper.SBPolicy(mk("models/second", 2), DummyVecEnv([lambda: FakeGraspEnv("depth", seed=3)]),
+                                          cfg2, "models/second", load_dir="models/first/first.zip", algo="SAC")
+    seen = {}
+    real_load_parameters = SAC.load_parameters
+
+    def spy(self, params, exact_match=True):
+        seen["exact_match"], seen["n"] = exact_match, len(params)
+        real_load_parameters(self, params, exact_match=exact_match)
+        seen["after"] = self.get_parameters()
+    monkeypatch.setattr(SAC, "load_parameters", spy)
+    second.learn()
+    assert seen["exact_match"] is False and seen["n"] == len(P_first)
+    for k, v in P_first.items():                               # the transferred weights are the trained ones ...
+        assert np.array_equal(seen["after"][k], v), k
+    vn = second.env                                            # ... and the statistics of run 1 carried over
+    assert isinstance(vn, VecNormalize) and vn.norm_obs and vn.norm_reward and isinstance(vn.venv, VecNormalize)
+    assert not vn.venv.norm_obs and not vn.venv.norm_reward
+    assert vn.obs_rms.count > 200                              # 108 steps of run 1 + 104 of run 2
+    assert os.path.isfile("models/second/second.zip") and os.path.isfile("models/second/vecnormalize.pkl")
+    rows = open("tensorboard_logs/models/second/SAC_1/scalars.csv").read().strip().splitlines()
+    assert rows[0] == "step,tag,value" and len(rows) > 50 and all(r.split(",")[1] == "success_rate" for r in rows[1:])
 
 
 def test_reference_callbacks_fire_on_evaluation(reference_sb_helper, tmp_path, monkeypatch):

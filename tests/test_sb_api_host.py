@@ -240,6 +240,82 @@ def test_bdq_reference_sequence(tmp_path, emulated_q_engine):
     assert a.shape == (3,) and set(np.round((a + 1) * 2, 5)) <= {0.0, 1.0, 2.0, 3.0, 4.0}     # bin centres
 
 
+def test_vecnormalize_flags_are_honoured_separately(emulated_engine, emulated_q_engine):
+    """VecNormalize(norm_obs=, norm_reward=) each reach the device gather on their own (stable-baselines honours
+    them separately at sample time): the engine's `normalize` mode is 1 both / 2 observations / 3 rewards / 0."""
+    for flags, mode in (((True, True), 1), ((True, False), 2), ((False, True), 3), ((False, False), 0)):
+        mk = lambda: VecNormalize(DummyVecEnv([lambda: FakeGraspEnv(seed=0, vector_dim=20, discrete_actions=6)]),
+                                  norm_obs=flags[0], norm_reward=flags[1])
+        m = sb.DQN(DQNMlpPolicy, mk(), batch_size=4, buffer_size=32, learning_starts=5)
+        assert m.engine.cfg.normalize == mode, (flags, m.engine.cfg.normalize)
+        m.learn(total_timesteps=12)
+        env = VecNormalize(DummyVecEnv([lambda: FakeGraspEnv(seed=0, vector_dim=20)]), norm_obs=flags[0], norm_reward=flags[1])
+        s = sb.SAC(sacMlp, env, batch_size=4, buffer_size=32, learning_starts=5)
+        assert s.engine.cfg.normalize == mode
+        s.learn(total_timesteps=12)
+        if mode in (2, 3):        # what the update saw: normalised observations xor normalised rewards
+            rew = s.engine.fetch("rew", (4,))
+            raw_scale = np.abs(rew).max() > 10.0 + 1e-6          # raw rewards of the fake env are ~ -200
+            assert raw_scale == (mode == 2)
+
+
+def test_learning_rate_schedule_is_evaluated_before_every_update(emulated_engine):
+    """A callable `learning_rate` is SB's schedule lr(progress_remaining): re-evaluated for each update (the step
+    size lives in device memory, grl_set_learning_rate), not frozen at construction."""
+    seen = []
+
+    def schedule(frac):
+        seen.append(frac)
+        return 3e-4 * frac
+    env = DummyVecEnv([lambda: FakeGraspEnv(seed=0, vector_dim=11)])
+    m = sb.SAC(sacMlp, env, batch_size=4, buffer_size=32, learning_starts=4, learning_rate=schedule)
+    seen.clear()
+    m.learn(total_timesteps=20)
+    assert len(seen) == m.n_updates > 10 and seen[0] > seen[-1] > 0.0
+    before = m.get_parameters()
+    m.learning_rate = lambda frac: 0.0            # a zero step size must freeze the weights (Adam moments still move)
+    m.learn(total_timesteps=8)
+    after = m.get_parameters()
+    assert all(np.array_equal(before[k], after[k]) for k in before if k.startswith("model/pi/"))
+
+
+def test_untrusted_pickles_cannot_name_arbitrary_callables(tmp_path, monkeypatch):
+    """vecnormalize.pkl / zip members come from elsewhere: only NumPy, plain containers and the mapped classes
+    may be constructed; a pickle that names os.system (or any other global) is refused."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            import os as _os
+            return (_os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    with open(tmp_path / "vecnormalize.pkl", "wb") as f:
+        pickle.dump(Evil(), f)
+    venv = DummyVecEnv([lambda: FakeGraspEnv(seed=0, vector_dim=11)])
+    with pytest.raises(pickle.UnpicklingError):
+        VecNormalize.load(str(tmp_path / "vecnormalize.pkl"), venv)
+    assert not (tmp_path / "pwned").exists()
+    from grasp_rl.sb import save_util
+    import base64, json
+    blob = json.dumps({"gamma": 0.9, "policy_kwargs": {":type:": "<class 'dict'>",
+                                                        ":serialized:": base64.b64encode(pickle.dumps(Evil())).decode()}})
+    data = save_util.json_to_data(blob)                       # refused -> rebuilt from readable attributes -> None
+    assert data["gamma"] == 0.9 and data["policy_kwargs"] is None and not (tmp_path / "pwned").exists()
+
+
+def test_extractor_is_inferred_when_the_closure_is_not_unpickled(tmp_path, emulated_engine):
+    """A zip saved with the reference's cloudpickled `cnn_extractor` closure loads without executing the pickle:
+    extractor / direct features / layers come from the parameter names and shapes."""
+    env = DummyVecEnv([lambda: FakeGraspEnv("depth", seed=0)])
+    kwargs = {"layers": [32, 48], "cnn_extractor": create_augmented_nature_cnn(1)}
+    m = sb.SAC(sacCnn, env, policy_kwargs=kwargs, buffer_size=16, batch_size=2)
+    m.save(str(tmp_path / "m"))
+    m2 = sb.SAC.load(str(tmp_path / "m"))
+    c = m2.engine.cfg
+    assert (c.extractor, c.n_direct, c.n_layers, c.layers[0], c.layers[1]) == (1, 1, 2, 32, 48)
+    m2.save(str(tmp_path / "m2"))                              # and the stand-in extractor object round-trips
+    assert sb.SAC.load(str(tmp_path / "m2")).engine.cfg.extractor == 1
+
+
 def test_monitor_logs_are_readable_by_results_plotter(tmp_path):
     """scripts/plot.py:7,64,76 of the reference: `load_results(folder)` + `ts2xy(result, 'timesteps')` on the CSV
     our Monitor writes, and on a log the reference ships (its fork adds columns)."""
