@@ -27,6 +27,7 @@
 #include "igemm.h"
 #include "igemm2.h"
 #include "heads_kernels.h"
+#include "heads_mfma.h"
 #include "per_kernels.h"
 #include "ae_kernels.h"
 #include "q_kernels.h"
@@ -193,6 +194,7 @@ struct grl_ctx {
   float* act_p = nullptr;            // [B, Ap] row-padded copy of the minibatch actions (Ap = rup(A, 4))
   int Ap = 0, ld_d = 1, ld_dm = 0;   // strides of the packed output-gradient buffers (fused heads)
   bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
+  bool heads_mfma = false;           // heads_mfma.h: forward + backward of all heads as ONE launch on 16x16x4 MFMAs
   float *u_l0[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // layer-0 feature partials: pi, vf, qf1, qf2, target
   int l0_split = 1;
   float* g0cat = nullptr;            // [B, 3*H0]: layer-0 gradients of vf | qf1 | qf2
@@ -1094,11 +1096,43 @@ int grl_ctx::plan_sac() {
     fa.h[5] = mk_head(m_qf1, hQF1PI, nullptr, u_l0[2], pi_a, A, A);
     fa.h[6] = mk_head(m_qf2, hQF2PI, nullptr, u_l0[3], pi_a, A, A);
     fa.B = B; fa.A = A; fa.eps = eps_buf; fa.pi_a = pi_a; fa.logp = logp; fa.ent = ent;
+    {
+      const char* nm = getenv("GRL_NO_HEADS_MFMA");
+      heads_mfma = !(nm && nm[0] == '1');
+    }
+    if (heads_mfma) {
+      // forward and backward of every head in one launch (heads_mfma.h); d_out / gradients as in the backward args below
+      HeadsFusedArgs ha;
+      memset(&ha, 0, sizeof(ha));
+      ha.h[0] = mk_head(m_pi, hPI, &gPI, u_l0[0], nullptr, 0, 0);
+      ha.h[1] = mk_head(m_vf, hVF, &gVF, u_l0[1], nullptr, 0, 0);
+      ha.h[2] = mk_head(m_qf1, hQF1, &gQF1, u_l0[2], act, A, A);
+      ha.h[3] = mk_head(m_qf2, hQF2, &gQF2, u_l0[3], act, A, A);
+      ha.h[4] = mk_head(m_tgt, hTGT, nullptr, u_l0[4], nullptr, 0, 0);
+      ha.h[5] = mk_head(m_qf1, hQF1PI, nullptr, u_l0[2], pi_a, A, A);
+      ha.h[6] = mk_head(m_qf2, hQF2PI, nullptr, u_l0[3], pi_a, A, A);
+      ha.B = B; ha.A = A; ha.eps = eps_buf; ha.pi_a = pi_a; ha.logp = logp; ha.ent = ent;
+      ha.log_ent_coef = params + ent_off; ha.da_pi = da_pi; ha.dmu = dmu; ha.dls = dls; ha.ld_dm = ld_dm;
+      ha.rew = rew; ha.done = done; ha.gamma = c.gamma;
+      ha.d_out[1] = d_v; ha.d_out[2] = d_qf1; ha.d_out[3] = d_qf2; ha.d_out[4] = d_qf1pi; ha.ld_d = ld_d;
+      int wide = 2 * A > 64 ? 1 : 0;
+      for (int l = 0; l < L; ++l) wide = wide || hid[l] > 64;
+      const HeadsFusedArgs* d_ha = upload_vec(wk, std::vector<HeadsFusedArgs>{ha});
+      const int nblk = (B + HT_RB - 1) / HT_RB;
+      Op op; op.tag = "heads";
+      op.run = [d_ha, nblk, wide](hipStream_t s) {
+        const dim3 grid(nblk, 4);
+        if (wide) hipLaunchKernelGGL((heads_fused_kernel<128>), grid, dim3(256), 0, s, d_ha);
+        else hipLaunchKernelGGL((heads_fused_kernel<64>), grid, dim3(256), 0, s, d_ha);
+      };
+      ops_grads.push_back(op);
+    } else {
     Op op; op.tag = "heads_fwd";
     op.run = [fa](hipStream_t s) {
       hipLaunchKernelGGL(heads_fwd_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 6), dim3(256), 0, s, fa);
     };
     ops_grads.push_back(op);
+    }
   } else {
     // heads forward: pi, vf, qf1, qf2 (data action), target vf
     for (int l = 0; l < L; ++l) {
@@ -1178,11 +1212,13 @@ int grl_ctx::plan_sac() {
     ba.d_out[1] = d_v; ba.d_out[2] = d_qf1; ba.d_out[3] = d_qf2; ba.d_out[4] = d_qf1pi; ba.ld_d = ld_d;
     ba.B = B; ba.A = A; ba.mu = hPI.out[0]; ba.ls_raw = hPI.out[1]; ba.eps = eps_buf; ba.pi_a = pi_a;
     ba.log_ent_coef = params + ent_off; ba.da_pi = da_pi; ba.dmu = dmu; ba.dls = dls;
+    if (!heads_mfma) {
     Op op; op.tag = "heads_bwd";
     op.run = [ba](hipStream_t s) {
       hipLaunchKernelGGL(heads_bwd_kernel, dim3((ba.B + HT_RB - 1) / HT_RB, 4), dim3(256), 0, s, ba);
     };
     ops_grads.push_back(op);
+    }
     if (cnn) {
       // d feat = g0 . W0[0:Fc]^T, masked by feat > 0.  Critic net: the three layer-0 gradients sit side
       // by side in g0cat and the three kernels are reached through a table (K = 3*H0 in one pass).
@@ -1406,7 +1442,7 @@ int grl_ctx::plan_sac() {
     };
     int dense_after = -1;   // the dense weight gradients need every head gradient and (CNN) d feat
     for (size_t k = 0; k < ops_grads.size(); ++k)
-      if (ops_grads[k].tag == "heads_dfeat" || ops_grads[k].tag == "heads_bwd") dense_after = (int)k;
+      if (ops_grads[k].tag == "heads_dfeat" || ops_grads[k].tag == "heads_bwd" || ops_grads[k].tag == "heads") dense_after = (int)k;
     for (size_t k = 0; k < ops_grads.size(); ++k) {
       const Op& o = ops_grads[k];
       sched.push_back(o);

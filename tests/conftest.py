@@ -38,7 +38,8 @@ def hostemu_lib():
     host-side launch plan against the oracle without a GPU.  Never used by the product."""
     out = os.path.join(ROOT, "tests", "_build", "libgrl_hostemu.so")
     src = os.path.join(PKG, "csrc", "engine.hip")
-    deps = [os.path.join(PKG, "csrc", f) for f in ("engine.hip", "igemm.h", "igemm2.h", "elem_kernels.h", "heads_kernels.h", "per_kernels.h", "ae_kernels.h", "q_kernels.h", "igemm_sk.h", "hostemu.h")]
+    csrc = os.path.join(PKG, "csrc")
+    deps = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DGRL_HOSTEMU", "-x", "c++", src,

@@ -40,9 +40,9 @@ def test_update_matches_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_V2", "GRL_LANES", "GRL_NO_FUSED_ADAM", "GRL_NO_WGRAD_MERGE", "GRL_NO_SK"])
+@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_HEADS_MFMA", "GRL_NO_V2", "GRL_LANES", "GRL_NO_FUSED_ADAM", "GRL_NO_WGRAD_MERGE", "GRL_NO_SK"])
 def test_fallback_paths_match_oracle(monkeypatch, var):
-    """The per-layer GEMM heads, the scalar-gather igemm_kernel, the two-lane capture, the separate Adam launch,
+    """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel, the two-lane capture, the separate Adam launch,
     the separate dense weight-gradient launch and conv1 on igemm2_kernel instead of the streaming kernel stay correct."""
     monkeypatch.setenv(var, "1")
     case = pu.make_case(n_steps=2, extractor="augmented", kind="depth", B=16, n_replay=48)

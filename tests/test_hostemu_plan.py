@@ -69,6 +69,19 @@ def test_optimiser_step_is_tf_adam_on_identical_inputs(hostemu_lib, name):
     pu.check_optimiser_steps(case, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=3)
 
 
+def test_two_launch_head_chains_still_match(hostemu_lib, monkeypatch):
+    """GRL_NO_HEADS_MFMA=1: the plan with heads_fwd + heads_bwd (heads_kernels.h) instead of the fused launch."""
+    monkeypatch.setenv("GRL_NO_HEADS_MFMA", "1")
+    case = pu.make_case(n_steps=2, **CASES["depth_augmented"])
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(1, case["idx"][1:2], case["eps"][1:2])
+    pu.compare_params(eng, orc, case["spec"].lr, 2)
+    eng.close()
+
+
 def test_act_matches_oracle(hostemu_lib):
     case = pu.make_case(extractor="augmented", kind="depth", B=2, n_replay=4)
     eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
