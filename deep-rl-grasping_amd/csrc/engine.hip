@@ -1098,7 +1098,8 @@ int grl_ctx::plan_sac() {
     fa.B = B; fa.A = A; fa.eps = eps_buf; fa.pi_a = pi_a; fa.logp = logp; fa.ent = ent;
     {
       const char* nm = getenv("GRL_NO_HEADS_MFMA");
-      heads_mfma = !(nm && nm[0] == '1');
+      heads_mfma = !(nm && nm[0] == '1') && 2 * A <= 64;      // heads_mfma.h: layer widths (and 2A) up to 64
+      for (int l = 0; l < L; ++l) heads_mfma = heads_mfma && hid[l] <= 64;
     }
     if (heads_mfma) {
       // forward and backward of every head in one launch (heads_mfma.h); d_out / gradients as in the backward args below
@@ -1115,15 +1116,18 @@ int grl_ctx::plan_sac() {
       ha.log_ent_coef = params + ent_off; ha.da_pi = da_pi; ha.dmu = dmu; ha.dls = dls; ha.ld_dm = ld_dm;
       ha.rew = rew; ha.done = done; ha.gamma = c.gamma;
       ha.d_out[1] = d_v; ha.d_out[2] = d_qf1; ha.d_out[3] = d_qf2; ha.d_out[4] = d_qf1pi; ha.ld_d = ld_d;
-      int wide = 2 * A > 64 ? 1 : 0;
-      for (int l = 0; l < L; ++l) wide = wide || hid[l] > 64;
+      if (const char* e = getenv("GRL_HEADS_STAMPS")) {
+        if (e[0] == '1') {
+          ha.stamps = (unsigned long long*)wk.take(4 * 32 * 8);
+          zero_once.push_back({ha.stamps, 4 * 32 * 8});
+          dbg["heads_stamps"] = {(const float*)ha.stamps, 4 * 32 * 2};
+        }
+      }
       const HeadsFusedArgs* d_ha = upload_vec(wk, std::vector<HeadsFusedArgs>{ha});
       const int nblk = (B + HT_RB - 1) / HT_RB;
       Op op; op.tag = "heads";
-      op.run = [d_ha, nblk, wide](hipStream_t s) {
-        const dim3 grid(nblk, 4);
-        if (wide) hipLaunchKernelGGL((heads_fused_kernel<128>), grid, dim3(256), 0, s, d_ha);
-        else hipLaunchKernelGGL((heads_fused_kernel<64>), grid, dim3(256), 0, s, d_ha);
+      op.run = [d_ha, nblk](hipStream_t s) {
+        hipLaunchKernelGGL((heads_fused_kernel<64>), dim3(nblk, 4), dim3(256), 0, s, d_ha);
       };
       ops_grads.push_back(op);
     } else {

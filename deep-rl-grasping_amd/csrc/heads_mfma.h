@@ -8,8 +8,9 @@
 // VALU chains (forward, then backward) that cost ~2.5 us per 64x64 layer stage; here
 //
 //   * a workgroup owns 16 batch rows -- the M of a 16x16x4 MFMA -- and a layer stage is 16 MFMAs per wave
-//     (4 waves = 4 column blocks of 16): weights go global -> registers (B operand, no LDS staging), the
-//     activations of the 16 rows sit in LDS row-major with a +4 pad (A operand: 16-byte reads, no conflicts);
+//     (4 waves = 4 column blocks of 16, layer widths up to 64; wider heads stay on heads_kernels.h): weights go
+//     global -> registers (B operand, no LDS staging), the activations of the 16 rows sit in LDS row-major with
+//     a +4 pad (A operand: 16-byte reads, no conflicts);
 //   * forward activations stay in REGISTERS in the MFMA result layout, which is exactly where the ReLU mask
 //     of the backward stage needs them;
 //   * every backward chain is made self-contained by recomputing the few forward heads it depends on
@@ -27,6 +28,7 @@
 // against the oracle with the same tolerances (tests/test_gpu_parity.py).
 #pragma once
 #include "heads_kernels.h"
+#include "igemm2.h"
 
 namespace grl {
 
@@ -42,6 +44,7 @@ struct HeadsFusedArgs {
   const float* rew; const float* done; float gamma;
   float* d_out[5];        // [B] (stride ld_d): 1 d_v, 2 d_qf1, 3 d_qf2, 4 d_qf1_pi
   int ld_d;
+  unsigned long long* stamps;   // development aid (GRL_HEADS_STAMPS=1): [4 types][32] wall-clock stamps of row block 0
 };
 
 #ifdef GRL_HOSTEMU
@@ -165,6 +168,20 @@ void heads_fused_kernel(const HeadsFusedArgs* ap) {
 #else  // ------------------------------------------------------------------------------------ device
 
 typedef float hm_f4 __attribute__((ext_vector_type(4)));
+// pointers read from the argument block are generic to the compiler: flat loads count on lgkmcnt too, so every LDS
+// wait would drain the prefetched weights.  Typed as global (address space 1) they become global_load / global_store.
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. it
+// would wait at every stage for the operands requested a head ahead
+#define HM_SYNC()                                                         \
+  do {                                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");       \
+    __builtin_amdgcn_s_barrier();                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");       \
+  } while (0)
+#define HM_G(p) ((gcf32)(p))
+#define HM_GW(p) ((gf32)(p))
+
+enum { HM_W = 64, HM_K4 = HM_W / 4, HM_LD = HM_W + 4 };
 
 // B operand of a stage: element (k, n) of a [K, N] matrix served from one or two weight tensors; zero outside.
 struct HmB {
@@ -173,50 +190,117 @@ struct HmB {
   int sk, sn;      // strides of k and n inside a part
   int split;       // first index served by p1 -- along n (on_k == 0) or along k (on_k == 1); >= extent: one part
   int on_k;
+  const float* bias0; const float* bias1;   // optional bias of the stage's outputs (split along n like p0 / p1)
 };
+// operands of every stage of one head, requested in one burst (static slots: 16 registers per stage)
+struct HmFw { float a0[HM_K4], hid[GRL_MAX_LAYERS][HM_K4], out[HM_K4]; float b0, bh[GRL_MAX_LAYERS], bo; };   // forward
+struct HmBw { float out[HM_K4], hid[GRL_MAX_LAYERS][HM_K4], da[HM_K4]; float ow; };                            // backward
 
-template <int W>
 struct HmLds {
-  float z[2][HT_RB][W + 4];       // activations / gradients entering the next stage, row-major
-  float o[HT_RB][W + 4];          // head outputs (mu | log_std), output gradients, feature of a rank-K product
-  float pi[HT_RB][HT_MAXA];       // sampled action of the rows
+  float z[2][HT_RB][HM_LD];       // activations / gradients entering the next stage, row-major (A operand)
+  float o[HT_RB][HM_LD];          // head outputs (mu | log_std) / output gradients (dmu | dls) (A operand)
+  float pi[HT_RB][HM_LD];         // action part of a head's input: sampled action or minibatch action (A operand)
   float ls[HT_RB][HT_MAXA];       // raw log_std
+  float mu[HT_RB][HT_MAXA];
   float da[HT_RB][HT_MAXA];       // d loss / d action
-  float sv[8][HT_RB];             // per-row scalars: 0 qf1_pi, 1 qf2_pi, 2 logp, 3 v / q, 4 v_tgt, 5 d
+  float eps[HT_RB][HT_MAXA];      // policy noise of the rows
+  float u[4][HT_RB][HM_LD];       // layer-0 feature partial sums of the chain's heads (added up), fetched as coalesced quads
+  float sv[10][HT_RB];            // per-row scalars: 0 qf1_pi, 1 qf2_pi, 2 logp, 3 entropy, 4 v_tgt, 5 d, 6 reward, 7 done, 8 v / q
+  float alpha;                    // exp(log_ent_coef)
+  float sink[256 * 4];            // landing zone of the cache-warming sweep (never read)
+  HeadsFusedArgs args;            // the argument block, copied once: field reads are LDS reads, not scalar-cache misses
 };
 
-// The argument block lives in device memory (descriptor upload of the plan): a by-value struct indexed with the
-// run-time chain type would be copied to scratch by the compiler.
+// Latency rules this kernel is built on (measured with the wall-clock stamps of GRL_HEADS_STAMPS=1, MI355X):
+// every dependent global access costs ~1.2 us here, an MFMA stage ~0.3 us.  So (1) the argument block is copied to
+// LDS in one coalesced read, (2) the per-row inputs and the layer-0 partial sums of every head of the chain are
+// requested in one burst of few, wide loads, (3) the register operands of ALL stages of a head are requested one
+// head ahead of their use -- but never more than ~60 vector loads in flight: the counter the waits are expressed
+// in has 6 bits, beyond it the wave stalls at issue and a wait for the oldest load drains younger ones too --
+// and (4) no global store is issued before the end of the chain: gfx950 counts stores and loads on the same
+// in-order counter, so a wait for a young load is also a wait for the acknowledgement of every older store.
 template <int W>
 __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* __restrict__ ap) {
-  constexpr int K4 = W / 4, NB = W / 64, LD = W + 4;
-  const HeadsFusedArgs& a = *ap;
-  __shared__ __attribute__((aligned(16))) HmLds<W> s;
+  static_assert(W == HM_W, "layer widths above 64 run on heads_kernels.h");
+  constexpr int K4 = HM_K4, LD = HM_LD;
+  __shared__ __attribute__((aligned(16))) HmLds s;
   const int t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4;
+  const int n = 16 * w + c;       // column owned by this lane in a stage output (result layout: rows 4q .. 4q+3)
+  // ---- round trip 1: the argument block (2.5 KB) in one coalesced read
+  {
+    typedef const GRL_GLOBAL uint32_t* gcu32;
+    constexpr int NW = (int)(sizeof(HeadsFusedArgs) / 4), NE = (NW + 255) / 256;
+    uint32_t tmp[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) tmp[e] = t + 256 * e < NW ? ((gcu32)ap)[t + 256 * e] : 0u;
+    // every A operand is read over the padded width: start from finite (zero) LDS (everything in front of `sink`)
+    for (int x = t; x < (int)(offsetof(HmLds, sink) / 4); x += 256) ((float*)&s)[x] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (t + 256 * e < NW) ((uint32_t*)&s.args)[t + 256 * e] = tmp[e];
+  }
+  HM_SYNC();
+  const HeadsFusedArgs& a = s.args;
   const int row0 = blockIdx.x * HT_RB, type = blockIdx.y, B = a.B, A = a.A;
   const float invB = 1.f / (float)B;
+  int stamp_k = 0;
+  auto stamp = [&]() {
+    if (a.stamps && blockIdx.x == 0 && t == 0 && stamp_k < 32) a.stamps[type * 32 + stamp_k] = wall_clock64();
+    ++stamp_k;
+  };
+  stamp();
 
   // ---------------------------------------------------------------- primitives
-  // column owned by this lane in column block b of a stage output (MFMA result layout: rows 4q .. 4q+3)
-  auto col_of = [&](int b) { return 16 * (w + 4 * b) + c; };
-  auto load_b = [&](float (&bw)[NB][K4], const HmB& d) {
+  // Branch-free operand fetch: buffer loads through a descriptor on the part's base; an element outside the logical
+  // matrix (or served by the other part) gets an out-of-range offset and comes back as zero.
+  auto ldw = [&](__amdgpu_buffer_rsrc_t rs, int off_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off_bytes, 0, 0));
+  };
+  // The kernel is bound by instruction issue (a wave64 VALU instruction occupies its SIMD for 4 cycles; ~2000
+  // address / predicate instructions were 3.6 us): the common shapes take paths with no per-element VALU work.
+  auto load_b = [&](float (&bw)[K4], const HmB& d) {
+    // one descriptor based on the lower of the two parts (both live in the parameter block): one load per element
+    const float* base = (d.p1 && d.p1 < d.p0) ? d.p1 : d.p0;
+    const __amdgpu_buffer_rsrc_t rs = i2_rsrc(base);
+    const int off0 = (int)(d.p0 - base), off1 = d.p1 ? (int)(d.p1 - base) : 0;
+    if (d.K >= HM_W && !d.on_k) {
+      // full-depth stage: every k of the padded width exists; the lane's part / validity is fixed -> one lane
+      // offset, the k step rides on the scalar offset (or on 16-byte loads when k is contiguous)
+      const bool first = n < d.split;
+      const int voff = n < d.N ? ((first ? off0 : off1) + K4 * q * d.sk + (first ? n : n - d.split) * d.sn) * 4 : I2_OOB;
+      if (d.sk == 1) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int n = col_of(b);
+        for (int j = 0; j < K4 / 4; ++j) {
+          const hm_f4 v = i2_ld(rs, voff + 16 * j);
+          bw[4 * j] = v.x; bw[4 * j + 1] = v.y; bw[4 * j + 2] = v.z; bw[4 * j + 3] = v.w;
+        }
+      } else {
+        const int stepb = d.sk * 4;
 #pragma unroll
-      for (int sI = 0; sI < K4; ++sI) {
+        for (int sI = 0; sI < K4; ++sI)
+          bw[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, sI * stepb, 0));
+      }
+      return;
+    }
+    const int steps = d.K < K4 ? d.K : K4;     // K <= 16 lives entirely in lane quarter 0: later steps are all zero
+#pragma unroll
+    for (int sI = 0; sI < K4; ++sI) {
+      bw[sI] = 0.f;
+      if (sI < steps) {
         const int k = K4 * q + sI;
-        const float* p = d.p0;
-        int kk = k, nn = n;
-        if (d.on_k) { if (k >= d.split) { p = d.p1; kk = k - d.split; } }
-        else { if (n >= d.split) { p = d.p1; nn = n - d.split; } }
         const bool ok = k < d.K && n < d.N;
-        bw[b][sI] = ok ? p[(long)kk * d.sk + (long)nn * d.sn] : 0.f;
+        const bool first = d.on_k ? k < d.split : n < d.split;
+        const int kk = (d.on_k && !first) ? k - d.split : k, nn = (!d.on_k && !first) ? n - d.split : n;
+        bw[sI] = ldw(rs, ok ? ((first ? off0 : off1) + kk * d.sk + nn * d.sn) * 4 : I2_OOB);
       }
     }
   };
-  // acc[b] += zin[16 rows][W] . bw   (A operand: lane (row c, quarter q) holds k = K4 q .. K4 q + K4 - 1)
-  auto mma = [&](hm_f4 (&acc)[NB], const float (*zin)[LD], const float (&bw)[NB][K4]) {
+  auto load_bias = [&](const float* b0, const float* b1, int split, int N) {   // split along n like the B operand
+    if (n >= N) return 0.f;
+    return n < split ? HM_G(b0)[n] : HM_G(b1)[n - split];
+  };
+  // acc += zin[16 rows][64] . bw   (A operand: lane (row c, quarter q) holds k = 16 q .. 16 q + 15)
+  auto mma = [&](hm_f4& acc, const float (*zin)[LD], const float (&bw)[K4]) {
     float av[K4];
 #pragma unroll
     for (int j = 0; j < K4 / 4; ++j) {
@@ -224,302 +308,374 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
       av[4 * j] = v.x; av[4 * j + 1] = v.y; av[4 * j + 2] = v.z; av[4 * j + 3] = v.w;
     }
 #pragma unroll
-    for (int sI = 0; sI < K4; ++sI)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sI], bw[b][sI], acc[b], 0, 0, 0);
+    for (int sI = 0; sI < K4; ++sI) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sI], bw[sI], acc, 0, 0, 0);
   };
-  auto zero_acc = [&](hm_f4 (&acc)[NB]) {
+
+  // ---- operand prefetch of a whole head
+  // (the head descriptors sit in LDS: every lambda first takes a local copy, so that the field reads are issued
+  //  together and waited for once -- read where they are used, each one is a ds_read + wait in a dependent chain)
+  auto prefetch_fwd = [&](const HtHead& h_, HmFw& f) {
+    const HtHead h = h_;
+    f.b0 = n < h.H0 ? HM_G(h.b0)[n] : 0.f;
+    if (h.n_xa > 0) load_b(f.a0, HmB{h.w0a, nullptr, h.n_xa, h.H0, h.H0, 1, INT_MAX, 0, nullptr, nullptr});
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = hm_f4{0.f, 0.f, 0.f, 0.f};
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly)
+      if (ly < h.L) {
+        load_b(f.hid[ly], HmB{h.w[ly], nullptr, h.hid[ly - 1], h.hid[ly], h.hid[ly], 1, INT_MAX, 0, nullptr, nullptr});
+        f.bh[ly] = n < h.hid[ly] ? HM_G(h.b[ly])[n] : 0.f;
+      }
+    const int NO = h.n_out * h.out_dim;
+    int HLf = h.hid[0];                       // width of the last hidden layer (static indices: no scratch copy)
+#pragma unroll
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HLf = (ly == h.L - 1) ? h.hid[ly] : HLf;
+    load_b(f.out, HmB{h.ow[0], h.n_out > 1 ? h.ow[1] : nullptr, HLf, NO, h.out_dim, 1,
+                      h.n_out > 1 ? h.out_dim : INT_MAX, 0, nullptr, nullptr});
+    f.bo = load_bias(h.ob[0], h.n_out > 1 ? h.ob[1] : h.ob[0], h.n_out > 1 ? h.out_dim : INT_MAX, NO);
+  };
+  auto prefetch_bwd = [&](const HtHead& h_, HmBw& g, bool rank1, bool want_da) {
+    const HtHead h = h_;
+    const int L = h.L;
+    int HL = h.hid[0];
+#pragma unroll
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HL = (ly == L - 1) ? h.hid[ly] : HL;
+    g.ow = 0.f;
+    if (rank1) g.ow = n < HL ? HM_G(h.ow[0])[n] : 0.f;
+    else   // element (k, n) = ow[k / out_dim][n * out_dim + k % out_dim]
+      load_b(g.out, HmB{h.ow[0], h.n_out > 1 ? h.ow[1] : nullptr, h.n_out * h.out_dim, HL, 1, h.out_dim,
+                        h.n_out > 1 ? h.out_dim : INT_MAX, 1, nullptr, nullptr});
+#pragma unroll
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly)
+      if (ly < L)   // g_{ly-1} = g_ly . W_ly^T: element (k, m) = w[ly][m * hid[ly] + k]
+        load_b(g.hid[ly], HmB{h.w[ly], nullptr, h.hid[ly], h.hid[ly - 1], 1, h.hid[ly], INT_MAX, 0, nullptr, nullptr});
+    if (want_da) load_b(g.da, HmB{h.w0a, nullptr, h.H0, h.n_xa, 1, h.H0, INT_MAX, 0, nullptr, nullptr});
   };
 
   int cur = 0;   // s.z[cur] holds the input of the next MFMA stage
 
-  // forward of one head.  zsv[l][b][i]: activations kept in the result layout (row 4q+i, column col_of(b)).
-  // xa: the action part comes from s.pi (use_pi) or from global h.xa.  Outputs land in s.o[row][k*out_dim+o].
-  auto fwd_head = [&](const HtHead& h, bool use_pi, bool store, float (&zsv)[GRL_MAX_LAYERS][NB][4]) {
-    float bw[NB][K4];
-    if (h.L > 1) load_b(bw, HmB{h.w[1], nullptr, h.hid[0], h.hid[1], h.hid[1], 1, INT_MAX, 0});
-    else load_b(bw, HmB{h.ow[0], h.n_out > 1 ? h.ow[1] : nullptr, h.hid[0], h.n_out * h.out_dim, h.out_dim, 1,
-                        h.n_out > 1 ? h.out_dim : INT_MAX, 0});
-    // ---- layer 0 (element-wise on the partial sums of the heads_l0 GEMM)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int n = col_of(b);
-      const bool nok = n < h.H0;
-      const float bn = nok ? h.b0[n] : 0.f;
+  // forward of one head.  zsv[l][i]: activations kept in the result layout (row 4q+i, column n).  u0: layer-0
+  // feature partial sums of the rows (already added up); the action part of the input is s.pi (an MFMA stage of its
+  // own: K = n_xa).  Outputs land in s.o[row][k*out_dim+o].  No global stores (flush at the end of the kernel).
+  auto fwd_head = [&](const HtHead& h_, const HmFw& f, const float (&u0)[4], float (&zsv)[GRL_MAX_LAYERS][4]) {
+    struct { int L, H0, n_xa, no, hid[GRL_MAX_LAYERS]; } h = {h_.L, h_.H0, h_.n_xa, h_.n_out * h_.out_dim, {h_.hid[0], h_.hid[1], h_.hid[2], h_.hid[3]}};
+    // ---- layer 0
+    {
+      hm_f4 acc = {u0[0], u0[1], u0[2], u0[3]};
+      if (h.n_xa > 0) mma(acc, s.pi, f.a0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = 4 * q + i, row = row0 + r;
-        float v = 0.f;
-        if (nok && row < B) {
-          float acc = h.u[(long)row * h.ldu + n];
-          for (int sp = 1; sp < h.u_split; ++sp) acc += h.u[sp * h.u_stride + (long)row * h.ldu + n];
-          for (int x = 0; x < h.n_xa; ++x)
-            acc = fmaf(use_pi ? s.pi[r][x] : h.xa[(long)row * h.ld_xa + x], h.w0a[x * h.H0 + n], acc);
-          v = fmaxf(acc + bn, 0.f);
-          if (store && h.z0) h.z0[(long)row * h.H0 + n] = v;
-        }
-        zsv[0][b][i] = v;
+        const int r = 4 * q + i;
+        const float v = (n < h.H0 && row0 + r < B) ? fmaxf(acc[i] + f.b0, 0.f) : 0.f;
+        zsv[0][i] = v;
         s.z[cur][r][n] = v;
       }
     }
-    __syncthreads();
+    HM_SYNC();
     // ---- hidden layers
 #pragma unroll
     for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) {
       if (ly < h.L) {
-        const int Hout = h.hid[ly];
-        hm_f4 acc[NB];
-        zero_acc(acc);
-        float bias[NB];
+        hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma(acc, s.z[cur], f.hid[ly]);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) bias[b] = col_of(b) < Hout ? h.b[ly][col_of(b)] : 0.f;
-        mma(acc, s.z[cur], bw);
-        if (ly + 1 < h.L) load_b(bw, HmB{h.w[ly + 1], nullptr, Hout, h.hid[ly + 1], h.hid[ly + 1], 1, INT_MAX, 0});
-        else load_b(bw, HmB{h.ow[0], h.n_out > 1 ? h.ow[1] : nullptr, Hout, h.n_out * h.out_dim, h.out_dim, 1,
-                            h.n_out > 1 ? h.out_dim : INT_MAX, 0});
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int n = col_of(b);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i, row = row0 + r;
-            const float v = (n < Hout && row < B) ? fmaxf(acc[b][i] + bias[b], 0.f) : 0.f;
-            zsv[ly][b][i] = v;
-            s.z[cur ^ 1][r][n] = v;
-            if (store && h.z[ly] && n < Hout && row < B) h.z[ly][(long)row * Hout + n] = v;
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          const float v = (n < h.hid[ly] && row0 + r < B) ? fmaxf(acc[i] + f.bh[ly], 0.f) : 0.f;
+          zsv[ly][i] = v;
+          s.z[cur ^ 1][r][n] = v;
         }
         cur ^= 1;
-        __syncthreads();
+        HM_SYNC();
       }
     }
     // ---- output layer(s): [mu | log_std] or one value
     {
-      const int NO = h.n_out * h.out_dim;
-      hm_f4 acc[NB];
-      zero_acc(acc);
-      float bias[NB];
+      hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
+      mma(acc, s.z[cur], f.out);
+      if (n < h.no) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int n = col_of(b);
-        bias[b] = n < NO ? (n < h.out_dim ? h.ob[0][n] : h.ob[1][n - h.out_dim]) : 0.f;
-      }
-      mma(acc, s.z[cur], bw);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int n = col_of(b);
-        if (n < NO) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i, row = row0 + r;
-            const float v = row < B ? acc[b][i] + bias[b] : 0.f;
-            s.o[r][n] = v;
-            if (store && row < B) {
-              const int k = n < h.out_dim ? 0 : 1, o = n - k * h.out_dim;
-              h.out[k][(long)row * (h.ld_out ? h.ld_out : h.out_dim) + o] = v;
-            }
-          }
-        }
+        for (int i = 0; i < 4; ++i) s.o[4 * q + i][n] = row0 + 4 * q + i < B ? acc[i] + f.bo : 0.f;
       }
     }
-    __syncthreads();
+    HM_SYNC();
   };
 
-  // backward of one head.  rank1: the head has one scalar output whose gradient per row is s.sv[5][row];
-  // otherwise the output gradients are s.o[row][k*out_dim + o] (zero beyond).  Writes g (heads with g pointers),
-  // and with want_da the gradient w.r.t. the action part into s.da (+ global da when given).
-  auto bwd_head = [&](const HtHead& h, const float (&zsv)[GRL_MAX_LAYERS][NB][4], bool rank1, bool want_da, float* da_glob,
-                      bool store_g) {
+  // backward of one head.  rank1: the head has one scalar output whose gradient per row is s.sv[5][row]; otherwise
+  // the output gradients are s.o[row][k*out_dim + o] (zero beyond).  gsv[l][i]: gradients w.r.t. the layer
+  // pre-activations in the result layout (stored at the end); with want_da the gradient w.r.t. the action -> s.da.
+  auto bwd_head = [&](const HtHead& h_, const HmBw& g, const float (&zsv)[GRL_MAX_LAYERS][4], float (&gsv)[GRL_MAX_LAYERS][4],
+                      bool rank1, bool want_da) {
+    struct { int L, n_xa, hid[GRL_MAX_LAYERS]; } h = {h_.L, h_.n_xa, {h_.hid[0], h_.hid[1], h_.hid[2], h_.hid[3]}};
     const int L = h.L;
-    const int HL = h.hid[L - 1];
-    float bw[NB][K4];
+    int HL = h.hid[0];
+#pragma unroll
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HL = (ly == L - 1) ? h.hid[ly] : HL;
     // ---- output layer(s) -> gradient of the last hidden pre-activation
     {
-      hm_f4 acc[NB];
-      zero_acc(acc);
+      hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
       if (rank1) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int n = col_of(b);
-          const float wn = n < HL ? h.ow[0][n] : 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[b][i] = s.sv[5][4 * q + i] * wn;
-        }
+        for (int i = 0; i < 4; ++i) acc[i] = s.sv[5][4 * q + i] * g.ow;
       } else {
-        // element (k, n) = ow[k / out_dim][n * out_dim + k % out_dim]
-        load_b(bw, HmB{h.ow[0], h.n_out > 1 ? h.ow[1] : nullptr, h.n_out * h.out_dim, HL, 1, h.out_dim,
-                       h.n_out > 1 ? h.out_dim : INT_MAX, 1});
-        mma(acc, s.o, bw);
+        mma(acc, s.o, g.out);
       }
-      if (L > 1) load_b(bw, HmB{h.w[L - 1], nullptr, HL, h.hid[L - 2], 1, HL, INT_MAX, 0});
-      else if (want_da) load_b(bw, HmB{h.w0a, nullptr, h.H0, h.n_xa, 1, h.H0, INT_MAX, 0});
-      float* gl = !store_g ? nullptr : (L == 1 ? h.g0 : h.g[L - 1]);
-      const int ldgl = L == 1 ? h.ldg0 : HL;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int n = col_of(b);
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * q + i;
+        float zl = 0.f;                         // activation of the last hidden layer (static register indices)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * q + i, row = row0 + r;
-          float zl = 0.f;                         // activation of the last hidden layer (static register indices)
+        for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) zl = (ly == L - 1) ? zsv[ly][i] : zl;
+        const float v = (n < HL && row0 + r < B && zl > 0.f) ? acc[i] : 0.f;
+        s.z[cur][r][n] = v;
 #pragma unroll
-          for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) zl = (ly == L - 1) ? zsv[ly][b][i] : zl;
-          const float v = (n < HL && row < B && zl > 0.f) ? acc[b][i] : 0.f;
-          s.z[cur][r][n] = v;
-          if (gl && n < HL && row < B) gl[(long)row * ldgl + n] = v;
-        }
+        for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) gsv[ly][i] = (ly == L - 1) ? v : gsv[ly][i];
       }
     }
-    __syncthreads();
+    HM_SYNC();
     // ---- hidden layers: g_{l-1} = mask * (g_l . W_l^T)
 #pragma unroll
     for (int ly = GRL_MAX_LAYERS - 1; ly >= 1; --ly) {
       if (ly < L) {
-        const int Hin = h.hid[ly - 1];
-        hm_f4 acc[NB];
-        zero_acc(acc);
-        mma(acc, s.z[cur], bw);
-        if (ly > 1) load_b(bw, HmB{h.w[ly - 1], nullptr, Hin, h.hid[ly - 2], 1, Hin, INT_MAX, 0});
-        else if (want_da) load_b(bw, HmB{h.w0a, nullptr, h.H0, h.n_xa, 1, h.H0, INT_MAX, 0});
+        hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma(acc, s.z[cur], g.hid[ly]);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int m = col_of(b);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i, row = row0 + r;
-            const float v = (m < Hin && row < B && zsv[ly - 1][b][i] > 0.f) ? acc[b][i] : 0.f;
-            s.z[cur ^ 1][r][m] = v;
-            if (store_g && m < Hin && row < B) {
-              if (ly == 1) h.g0[(long)row * h.ldg0 + m] = v;
-              else h.g[ly - 1][(long)row * Hin + m] = v;
-            }
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          const float v = (n < h.hid[ly - 1] && row0 + r < B && zsv[ly - 1][i] > 0.f) ? acc[i] : 0.f;
+          s.z[cur ^ 1][r][n] = v;
+          gsv[ly - 1][i] = v;
         }
         cur ^= 1;
-        __syncthreads();
+        HM_SYNC();
       }
     }
     // ---- d xa = g_0 . w0a^T
     if (want_da) {
-      hm_f4 acc[NB];
-      zero_acc(acc);
-      mma(acc, s.z[cur], bw);
+      hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
+      mma(acc, s.z[cur], g.da);
+      if (n < h.n_xa) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int x = col_of(b);
-        if (x < h.n_xa) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i, row = row0 + r;
-            s.da[r][x] = acc[b][i];
-            if (da_glob && row < B) da_glob[(long)row * h.n_xa + x] = acc[b][i];
-          }
-        }
+        for (int i = 0; i < 4; ++i) s.da[4 * q + i][n] = acc[i];
       }
-      __syncthreads();
+      HM_SYNC();
     }
   };
 
-  // squashed-Gaussian sample of the rows from s.o = [mu | log_std]; one lane per row (A is small)
-  auto sample = [&](bool store) {
-    if (t < HT_RB) {
-      const int row = row0 + t;
+  // squashed-Gaussian sample of the rows from s.o = [mu | log_std]: one lane per (row, action dimension), 32 lanes
+  // per row (2A <= 64), log-probability / entropy added up over a row's lanes by a fixed butterfly
+  auto sample = [&]() {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = 8 * pass + (t >> 5), j = t & 31;
       float lp = 0.f, en = 0.f;
-      for (int j = 0; j < A; ++j) {
-        const float ep = row < B ? a.eps[(long)row * A + j] : 0.f;
-        const float lr = s.o[t][A + j];
-        const float pj = ht_sample_elem(s.o[t][j], lr, ep, lp, en);
-        s.pi[t][j] = pj;
-        s.ls[t][j] = lr;
-        if (row < B && store) a.pi_a[(long)row * A + j] = pj;
+      if (j < A) {
+        const float m = s.o[r][j], lr = s.o[r][A + j];
+        s.pi[r][j] = ht_sample_elem(m, lr, s.eps[r][j], lp, en);
+        s.mu[r][j] = m;
+        s.ls[r][j] = lr;
       }
-      s.sv[2][t] = lp;
-      if (row < B && store) { a.logp[row] = lp; a.ent[row] = en; }
+#pragma unroll
+      for (int msk = 16; msk >= 1; msk >>= 1) { lp += __shfl_xor(lp, msk, 64); en += __shfl_xor(en, msk, 64); }
+      if (j == 0) { s.sv[2][r] = lp; s.sv[3][r] = en; }
     }
-    __syncthreads();
+    HM_SYNC();
   };
 
-  // every A operand is read over the padded width: start from finite (zero) LDS
-  for (int x = t; x < (int)(sizeof(s) / 4); x += 256) ((float*)&s)[x] = 0.f;
-  __syncthreads();
+  // ---- end-of-kernel stores of a head's activations / gradients (result layout -> row-major tensors)
+  auto store_z = [&](const HtHead& h_, const float (&zsv)[GRL_MAX_LAYERS][4]) {
+    const HtHead h = h_;
+#pragma unroll
+    for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) {
+      float* zp = ly == 0 ? h.z0 : h.z[ly];
+      if (ly < h.L && zp && n < h.hid[ly]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (row0 + 4 * q + i < B) HM_GW(zp)[(long)(row0 + 4 * q + i) * h.hid[ly] + n] = zsv[ly][i];
+      }
+    }
+  };
+  auto store_g = [&](const HtHead& h_, const float (&gsv)[GRL_MAX_LAYERS][4]) {
+    const HtHead h = h_;
+#pragma unroll
+    for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) {
+      float* gp = ly == 0 ? h.g0 : h.g[ly];
+      const int ldg = ly == 0 ? h.ldg0 : h.hid[ly];
+      if (ly < h.L && gp && n < h.hid[ly]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (row0 + 4 * q + i < B) HM_GW(gp)[(long)(row0 + 4 * q + i) * ldg + n] = gsv[ly][i];
+      }
+    }
+  };
+  auto store_rows = [&](float* dst, int ld, const float* src_row0) {   // one scalar per row, lanes 0..15
+    if (t < HT_RB && row0 + t < B) HM_GW(dst)[(long)(row0 + t) * ld] = src_row0[t];
+  };
 
-  float zsA[GRL_MAX_LAYERS][NB][4], zsB[GRL_MAX_LAYERS][NB][4];
-  if (type <= 1) {
-    const bool own = type == 0;
-    fwd_head(a.h[0], false, own, zsA);          // pi: s.o = [mu | log_std]
-    sample(own);
-    fwd_head(a.h[5], true, false, zsB);         // qf1(s, pi): s.o[r][0]
-    if (t < HT_RB) {
-      s.sv[0][t] = s.o[t][0];
-      if (own && row0 + t < B) a.h[5].out[0][row0 + t] = s.o[t][0];
+  // ---------------------------------------------------------------- round trip 2, one burst
+  // layer-0 partial sums of a head: the 16 x 64 tile of each split as ONE 16-byte load per thread (row t / 16,
+  // columns 4 (t % 16) ..), added in split order
+  auto issue_u = [&](const HtHead& h_, hm_f4 (&v)[4]) {
+    struct { const float* u; int ldu, u_split, H0; long u_stride; } h = {h_.u, h_.ldu, h_.u_split, h_.H0, h_.u_stride};
+    const int r = t >> 4, c4 = 4 * (t & 15);
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      v[sp] = hm_f4{0.f, 0.f, 0.f, 0.f};
+      if (sp < h.u_split && c4 < h.H0 && row0 + r < B)
+        v[sp] = *(const GRL_GLOBAL hm_f4*)(HM_G(h.u) + sp * h.u_stride + (long)(row0 + r) * h.ldu + c4);
     }
-    __syncthreads();
-    if (own) {
-      if (t < HT_RB) {
-        s.sv[5][t] = row0 + t < B ? -invB : 0.f;
-        if (row0 + t < B) a.d_out[4][(long)(row0 + t) * a.ld_d] = -invB;
-      }
-      __syncthreads();
-      bwd_head(a.h[5], zsB, true, true, a.da_pi, false);   // gradients of qf1's own weights are not wanted here (policy loss)
-      // sample backward: one lane per (row, j) pair
-      {
-        const float alpha_over_b = expf(a.log_ent_coef[0]) * invB;
-        for (int e = t; e < HT_RB * W; e += 256) {     // refresh s.o as the next A operand: zero beyond 2A
-          const int r = e / W, k = e - r * W;
-          const int row = row0 + r;
-          float v = 0.f;
-          if (k < 2 * A && row < B) {
-            const int j = k < A ? k : k - A;
-            float m, d;
-            ht_sample_bwd_elem(s.ls[r][j], a.eps[(long)row * A + j], s.pi[r][j], s.da[r][j], alpha_over_b, m, d);
-            v = k < A ? m : d;
-            (k < A ? a.dmu : a.dls)[(long)row * a.ld_dm + j] = v;
-          }
-          s.o[r][k] = v;
-        }
-        __syncthreads();
-      }
-      bwd_head(a.h[0], zsA, false, false, nullptr, true);
-    } else {
-      fwd_head(a.h[6], true, false, zsB);       // qf2(s, pi)
-      if (t < HT_RB) {
-        s.sv[1][t] = s.o[t][0];
-        if (row0 + t < B) a.h[6].out[0][row0 + t] = s.o[t][0];
-      }
-      __syncthreads();
-      fwd_head(a.h[1], false, true, zsA);       // vf
-      if (t < HT_RB) {
-        const int row = row0 + t;
-        const float alpha = expf(a.log_ent_coef[0]);
-        const float vb = fminf(s.sv[0][t], s.sv[1][t]) - alpha * s.sv[2][t];
-        const float d = row < B ? (s.o[t][0] - vb) * invB : 0.f;
-        s.sv[5][t] = d;
-        if (row < B) a.d_out[1][(long)row * a.ld_d] = d;
-      }
-      __syncthreads();
-      bwd_head(a.h[1], zsA, true, false, nullptr, true);
+  };
+  auto land_u = [&](const HtHead& h, const hm_f4 (&v)[4], int slot) {
+    const int r = t >> 4, c4 = 4 * (t & 15);
+    hm_f4 acc = v[0];
+#pragma unroll
+    for (int sp = 1; sp < 4; ++sp) acc += v[sp];
+    for (int sp = 4; sp < h.u_split; ++sp)
+      if (c4 < h.H0 && row0 + r < B) acc += *(const GRL_GLOBAL hm_f4*)(HM_G(h.u) + sp * h.u_stride + (long)(row0 + r) * h.ldu + c4);
+    *(hm_f4*)&s.u[slot][r][c4] = acc;
+  };
+  auto get_u = [&](int slot, float (&u0)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u0[i] = s.u[slot][4 * q + i][n];
+  };
+  float uA[4], uB[4], uC[4], uD[4];
+  HmFw fA, fB;
+  HmBw gA;
+  const HtHead& hq = a.h[type <= 1 ? 5 : type];             // second head of the chain; its action input comes from s.pi
+  const HtHead& h0 = a.h[type <= 1 ? 0 : 4];
+  {
+    // ---- issue ...
+    hm_f4 vA[4], vB[4], vC[4], vD[4];
+    issue_u(h0, vA);
+    issue_u(hq, vB);
+    if (type == 1) { issue_u(a.h[6], vC); issue_u(a.h[1], vD); }
+    const float la = HM_G(a.log_ent_coef)[0];
+    float in0[2], rw = 0.f, dn = 0.f;                        // per-row inputs: eps (types 0, 1) or the minibatch action
+    const int nin = type <= 1 ? A : hq.n_xa;                 // <= 32: lane -> (row t / 32 + 8 e, dimension t % 32)
+    const float* inp = type <= 1 ? a.eps : hq.xa;
+    const int ldin = type <= 1 ? A : hq.ld_xa;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = (t >> 5) + 8 * e, j = t & 31;
+      in0[e] = (j < nin && row0 + r < B) ? HM_G(inp)[(long)(row0 + r) * ldin + j] : 0.f;
     }
-  } else {
-    fwd_head(a.h[4], false, type == 2, zsA);    // target vf of next_obs
-    if (t < HT_RB) s.sv[4][t] = s.o[t][0];
-    __syncthreads();
-    const HtHead& h = a.h[type];
-    fwd_head(h, false, true, zsB);              // qf(s, a) on the minibatch actions
-    if (t < HT_RB) {
-      const int row = row0 + t;
-      float d = 0.f;
-      if (row < B) {
-        const float qb = a.rew[row] + (1.f - a.done[row]) * a.gamma * s.sv[4][t];
-        d = (s.o[t][0] - qb) * invB;
-        a.d_out[type][(long)row * a.ld_d] = d;
-      }
-      s.sv[5][t] = d;
+    if (type >= 2 && t < HT_RB && row0 + t < B) { rw = HM_G(a.rew)[row0 + t]; dn = HM_G(a.done)[row0 + t]; }
+    prefetch_fwd(h0, fA);
+    stamp();
+    // ---- ... then consume
+    if (t == 0) s.alpha = expf(la);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = (t >> 5) + 8 * e, j = t & 31;
+      if (j < nin) { if (type <= 1) s.eps[r][j] = in0[e]; else s.pi[r][j] = in0[e]; }
     }
-    __syncthreads();
-    bwd_head(h, zsB, true, false, nullptr, true);
+    if (type >= 2 && t < HT_RB) { s.sv[6][t] = rw; s.sv[7][t] = dn; }
+    land_u(h0, vA, 0);
+    land_u(hq, vB, 1);
+    if (type == 1) { land_u(a.h[6], vC, 2); land_u(a.h[1], vD, 3); }
   }
+  stamp();
+  HM_SYNC();
+  stamp();
+  get_u(0, uA); get_u(1, uB);
+  if (type == 1) { get_u(2, uC); get_u(3, uD); }
+  prefetch_fwd(hq, fB);                       // lands while the first head runs
+
+  // ---------------------------------------------------------------- the chains
+  float zsA[GRL_MAX_LAYERS][4], zsB[GRL_MAX_LAYERS][4], gs[GRL_MAX_LAYERS][4];
+#pragma unroll
+  for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { zsA[ly][i] = 0.f; zsB[ly][i] = 0.f; gs[ly][i] = 0.f; }
+  if (type == 0) {
+    fwd_head(a.h[0], fA, uA, zsA); stamp();     // pi: s.o = [mu | log_std]
+    prefetch_bwd(a.h[5], gA, true, true);       // (lands while the sample and qf1(s, pi) run)
+    sample(); stamp();
+    fwd_head(a.h[5], fB, uB, zsB); stamp();     // qf1(s, pi): s.o[r][0]
+    if (t < HT_RB) { s.sv[0][t] = s.o[t][0]; s.sv[5][t] = row0 + t < B ? -invB : 0.f; }
+    HM_SYNC();
+    float gq[GRL_MAX_LAYERS][4] = {};           // gradients of qf1's own weights are not wanted here (policy loss)
+    bwd_head(a.h[5], gA, zsB, gq, true, true); stamp();
+    prefetch_bwd(a.h[0], gA, false, false);
+    // sample backward; s.o becomes the A operand [dmu | dls] of the pi backward (zero beyond 2A)
+    {
+      const float alpha_over_b = s.alpha * invB;
+      for (int e = t; e < HT_RB * HM_W; e += 256) {
+        const int r = e / HM_W, k = e - r * HM_W;
+        float v = 0.f;
+        if (k < 2 * A && row0 + r < B) {
+          const int j = k < A ? k : k - A;
+          float m, d;
+          ht_sample_bwd_elem(s.ls[r][j], s.eps[r][j], s.pi[r][j], s.da[r][j], alpha_over_b, m, d);
+          v = k < A ? m : d;
+        }
+        s.o[r][k] = v;
+      }
+      HM_SYNC();
+    }
+    bwd_head(a.h[0], gA, zsA, gs, false, false); stamp();
+    // ---- flush
+    store_z(a.h[0], zsA);
+    store_g(a.h[0], gs);
+    for (int e = t; e < HT_RB * A; e += 256) {
+      const int r = e / A, j = e - r * A, row = row0 + r;
+      if (row < B) {
+        HM_GW(a.h[0].out[0])[(long)row * A + j] = s.mu[r][j];
+        HM_GW(a.h[0].out[1])[(long)row * A + j] = s.ls[r][j];
+        HM_GW(a.pi_a)[(long)row * A + j] = s.pi[r][j];
+        HM_GW(a.da_pi)[(long)row * A + j] = s.da[r][j];
+        HM_GW(a.dmu)[(long)row * a.ld_dm + j] = s.o[r][j];
+        HM_GW(a.dls)[(long)row * a.ld_dm + j] = s.o[r][A + j];
+      }
+    }
+    store_rows(a.logp, 1, s.sv[2]);
+    store_rows(a.ent, 1, s.sv[3]);
+    store_rows(a.h[5].out[0], 1, s.sv[0]);
+    store_rows(a.d_out[4], a.ld_d, s.sv[5]);
+  } else if (type == 1) {
+    fwd_head(a.h[0], fA, uA, zsA); stamp();     // pi (not stored: type 0 owns its tensors)
+    prefetch_fwd(a.h[6], fA);
+    sample(); stamp();
+    fwd_head(a.h[5], fB, uB, zsB); stamp();     // qf1(s, pi)
+    prefetch_fwd(a.h[1], fB);
+    if (t < HT_RB) s.sv[0][t] = s.o[t][0];
+    HM_SYNC();
+    fwd_head(a.h[6], fA, uC, zsB); stamp();     // qf2(s, pi)
+    prefetch_bwd(a.h[1], gA, true, false);
+    if (t < HT_RB) s.sv[1][t] = s.o[t][0];
+    HM_SYNC();
+    fwd_head(a.h[1], fB, uD, zsA); stamp();     // vf
+    if (t < HT_RB) {
+      const float vb = fminf(s.sv[0][t], s.sv[1][t]) - s.alpha * s.sv[2][t];
+      s.sv[8][t] = s.o[t][0];
+      s.sv[5][t] = row0 + t < B ? (s.o[t][0] - vb) * invB : 0.f;
+    }
+    HM_SYNC();
+    bwd_head(a.h[1], gA, zsA, gs, true, false); stamp();
+    store_z(a.h[1], zsA);
+    store_g(a.h[1], gs);
+    store_rows(a.h[6].out[0], 1, s.sv[1]);
+    store_rows(a.h[1].out[0], 1, s.sv[8]);
+    store_rows(a.d_out[1], a.ld_d, s.sv[5]);
+  } else {
+    const HtHead& h = a.h[type];
+    fwd_head(a.h[4], fA, uA, zsA); stamp();     // target vf of next_obs
+    prefetch_bwd(h, gA, true, false);
+    if (t < HT_RB) s.sv[4][t] = s.o[t][0];
+    HM_SYNC();
+    fwd_head(h, fB, uB, zsB); stamp();          // qf(s, a) on the minibatch actions (s.pi)
+    if (t < HT_RB) {
+      const float qb = s.sv[6][t] + (1.f - s.sv[7][t]) * a.gamma * s.sv[4][t];
+      s.sv[8][t] = s.o[t][0];
+      s.sv[5][t] = row0 + t < B ? (s.o[t][0] - qb) * invB : 0.f;
+    }
+    HM_SYNC();
+    bwd_head(h, gA, zsB, gs, true, false); stamp();
+    store_z(h, zsB);
+    store_g(h, gs);
+    if (type == 2) store_rows(a.h[4].out[0], 1, s.sv[4]);
+    store_rows(h.out[0], 1, s.sv[8]);
+    store_rows(a.d_out[type], a.ld_d, s.sv[5]);
+  }
+  stamp();
 }
 
 #endif  // GRL_HOSTEMU

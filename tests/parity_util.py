@@ -187,13 +187,16 @@ def check_optimiser_steps(case, backend=None, lib_path=None, n=3):
 
 
 def compare_moments(eng, orc_opts):
-    """Adam moments after n updates against the oracle's (list of adam_init dicts): gradient-level tolerance
-    (1e-3 of the per-tensor max) -- m is a decayed sum of gradients, v of their squares."""
+    """Adam moments after n updates against the oracle's (list of adam_init dicts): m is a decayed sum of the
+    gradients of the n steps, v of their squares.  Later steps see weights that already differ by a fraction of an
+    Adam step (sign-sensitive elements, see compare_params), so the bound is 1e-2 of the per-tensor max: this
+    catches bookkeeping errors (moments swapped, not decayed, not updated), the arithmetic is pinned by
+    check_apply_step."""
     m, v = adam_state(eng)
     for st in orc_opts:
         for n in st["m"]:
-            close_rel_max(m[n], st["m"][n], what="Adam m " + n, floor=1e-20)
-            close_rel_max(v[n], st["v"][n], rel=2e-3, what="Adam v " + n, floor=1e-30)
+            close_rel_max(m[n], st["m"][n], rel=1e-2, what="Adam m " + n, floor=1e-20)
+            close_rel_max(v[n], st["v"][n], rel=2e-2, what="Adam v " + n, floor=1e-30)
 
 
 def compare_params(eng, orc, lr, n_steps):
