@@ -108,6 +108,7 @@ struct Launch {
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
   int n_tiles = 0;
+  Launch* filler = nullptr;     // tiles of a second instantiation carried by the same launch (igemm2_pair_kernel)
 };
 
 struct Op {
@@ -629,9 +630,66 @@ struct grl_ctx {
     return 0;
   }
 
-  // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op
-  void add_launch(std::vector<Op>& ops, const std::string& tag, int variant, std::vector<IgemmProb> probs) {
-    if (probs.empty()) return;
+  // igemm2 instantiation key of a launch (see the dispatch switch in add_launch)
+  static int v2_key(const Launch* l) { return l->variant * 10000 + l->pm * 1000 + l->qm * 100 + l->cfg * 10 + l->flags; }
+  // pairs of instantiations igemm2_pair_kernel is built for: a backward-data stage + weight-gradient fillers
+  static bool pair_ok(const Launch* a, const Launch* b) {
+    if (!a->v2 || !b->v2 || a->sk || b->sk || v2_key(b) != 21001) return false;
+    const int ka = v2_key(a);
+    return ka == 10030 || ka == 10000 || ka == 12130 || ka == 12110 || ka == 12100;
+  }
+
+  // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op.  `filler`: independent problems
+  // of a second instantiation (variant `fvariant`, workgroup shape `fcfg`) whose tiles follow the launch's own in
+  // the same grid; when the pair is not one igemm2_pair_kernel is built for they become a launch of their own.
+  void add_launch(std::vector<Op>& ops, const std::string& tag, int variant, std::vector<IgemmProb> probs,
+                  const std::string& ftag = "", int fvariant = 0, std::vector<IgemmProb> fprobs = {}, int force_cfg = -1) {
+    if (probs.empty()) {
+      if (!fprobs.empty()) add_launch(ops, ftag, fvariant, fprobs, "", 0, {}, 0);
+      return;
+    }
+    if (!fprobs.empty()) {
+      std::vector<Op> tmp_a, tmp_b;
+      add_launch(tmp_a, tag, variant, probs);
+      Launch* la = launches.back();
+      add_launch(tmp_b, ftag, fvariant, fprobs, "", 0, {}, 0);      // fillers keep the 64x64 shape of the merged launch
+      Launch* lb = launches.back();
+      if (tmp_a.size() == 1 && tmp_b.size() == 1 && pair_ok(la, lb)) {
+        la->filler = lb;
+        Op op = tmp_a[0];
+        op.tag = tag;
+        op.flops += tmp_b[0].flops;
+        grl_ctx* self = this;
+        const std::string t2 = tag;
+        op.run = [la, lb, t2](hipStream_t s) {
+          const dim3 grid(la->n_tiles + lb->n_tiles), block(256);
+          const int ka = la->variant * 10000 + la->pm * 1000 + la->qm * 100 + la->cfg * 10 + la->flags;
+#define GRL_I2P(PLv, QLv, PMv, QMv, CF)                                                                                  \
+  hipLaunchKernelGGL((igemm2_pair_kernel<PLv, QLv, PMv, QMv, CF, 0, I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES>), \
+                     grid, block, 0, s, la->d_probs, la->d_tiles, la->n_tiles, lb->d_probs, lb->d_tiles)
+          switch (ka) {
+            case 10030: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3); break;
+            case 10000: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0); break;
+            case 12130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 3); break;
+            case 12110: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 1); break;
+            case 12100: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0); break;
+            default:
+              fprintf(stderr, "grl: no igemm2 pair instantiation for launch '%s' (key %d)\n", t2.c_str(), ka);
+              abort();
+          }
+#undef GRL_I2P
+        };
+        (void)self;
+        if (getenv("GRL_PLAN_DUMP"))
+          fprintf(stderr, "grl plan: %-14s carries %d filler tiles of '%s' behind its own %d\n", tag.c_str(), lb->n_tiles,
+                  ftag.c_str(), la->n_tiles);
+        ops.push_back(std::move(op));
+      } else {
+        for (auto& o : tmp_a) ops.push_back(o);
+        for (auto& o : tmp_b) ops.push_back(o);
+      }
+      return;
+    }
     Launch* l = new Launch();
     l->variant = variant;
     l->probs = std::move(probs);
@@ -662,7 +720,7 @@ struct grl_ctx {
       if (ktail && !(variant == 0 && l->pm == PM_AFFINE && l->qm == QM_AFFINE)) l->v2 = false;
       l->flags = (any_ones ? I2F_ONES : 0) | (ktail ? I2F_KTAIL : 0);
     }
-    l->cfg = l->v2 ? v2_pick_cfg(l->probs, variant, tag) : 0;
+    l->cfg = l->v2 ? (force_cfg >= 0 ? force_cfg : v2_pick_cfg(l->probs, variant, tag)) : 0;
     if (l->v2)   // outputs that can leave as 16-byte stores (igemm2 wide epilogue)
       for (auto& p : l->probs)
         if (al16(p.c) && (p.ldc % 4) == 0 && (p.N % 4) == 0 && (p.slab_stride % 4) == 0 &&
@@ -1303,26 +1361,15 @@ int grl_ctx::plan_sac() {
   }
   // =============================================================== backward through the two CNNs
   std::vector<IgemmProb> wg, wgc[3];   // weight gradients: dense layers / conv layers 1..3
+  std::vector<IgemmProb> bwd_pr[3];    // backward-data stages fc, conv3, conv2 (launched below, once their fillers are known)
   if (cnn) {
     std::vector<ConvBwdClass> bc3 = conv_bwd_tabs(cg[2], B), bc2 = conv_bwd_tabs(cg[1], B);
-    {
-      std::vector<IgemmProb> pr;
-      for (int n = 0; n < 2; ++n)
-        pr.push_back(dense_bwd({{dfeat[n], ldf, 512, P + ex[n].fw}}, B, 0, 1024, g3[n], 1024, a3[n]));
-      add_launch(ops_grads, "fc_bwd", 1, pr);
-    }
-    {
-      std::vector<IgemmProb> pr;
-      for (int n = 0; n < 2; ++n)
-        for (auto& cl : bc3) pr.push_back(conv_bwd(g3[n], cl, cg[2], P + ex[n].w[2], g2[n], a2[n]));
-      add_launch(ops_grads, "conv3_bwd", 1, pr);
-    }
-    {
-      std::vector<IgemmProb> pr;
-      for (int n = 0; n < 2; ++n)
-        for (auto& cl : bc2) pr.push_back(conv_bwd(g2[n], cl, cg[1], P + ex[n].w[1], g1[n], a1[n]));
-      add_launch(ops_grads, "conv2_bwd", 1, pr);
-    }
+    for (int n = 0; n < 2; ++n)
+      bwd_pr[0].push_back(dense_bwd({{dfeat[n], ldf, 512, P + ex[n].fw}}, B, 0, 1024, g3[n], 1024, a3[n]));
+    for (int n = 0; n < 2; ++n)
+      for (auto& cl : bc3) bwd_pr[1].push_back(conv_bwd(g3[n], cl, cg[2], P + ex[n].w[2], g2[n], a2[n]));
+    for (int n = 0; n < 2; ++n)
+      for (auto& cl : bc2) bwd_pr[2].push_back(conv_bwd(g2[n], cl, cg[1], P + ex[n].w[1], g1[n], a1[n]));
     // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
     int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3, tuned with the merged launch (GRL_WG_SPLIT=a,b,c overrides)
     if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
@@ -1418,6 +1465,29 @@ int grl_ctx::plan_sac() {
       }
       wg_ones.clear();
     }
+    // Weight gradients as FILLERS of the backward-data launches (opt-in, GRL_FILLERS=1): each group only needs
+    // tensors that are complete when the stage it rides on starts (fc + head layers: d feat and the head gradients;
+    // conv3: g3 from fc_bwd; conv2: g2 from conv3_bwd), so its tiles share that stage's launch
+    // (igemm2_pair_kernel) and only conv1's (needs g1, the last backward-data result) remain a launch of their own.
+    // Same tiles, same workgroup shape, bit-identical results -- but MEASURED SLOWER on MI355X at B = 256
+    // (fc_bwd 10.9 -> 21.1, conv3_bwd 23.3 -> 30.3, conv2_bwd 29.8 -> 43.5 us, conv1's weight gradient alone 21.0
+    // against 38.5 us for the single merged launch: 116 vs 102.5 us, 3998 vs 4287 updates/s): the 10-us reduction
+    // chunks of the weight gradients lengthen every stage's tail by more than the launch they save, and the
+    // merged launch (747 tiles, heaviest first) was already the better packing.  Kept as a tested switch.
+    const char* nfl = getenv("GRL_FILLERS");
+    const bool fillers = cnn && !wg_merged.empty() && nfl && nfl[0] == '1';
+    if (cnn) {
+      if (fillers) {
+        add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0], "wgrad_dense", 2, wg_merged);
+        add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1], "wgrad_conv3", 2, wgc[2]);
+        add_launch(ops_grads, "conv2_bwd", 1, bwd_pr[2], "wgrad_conv2", 2, wgc[1]);
+        wg_merged.clear(); wgc[2].clear(); wgc[1].clear();
+      } else {
+        add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
+        add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1]);
+        add_launch(ops_grads, "conv2_bwd", 1, bwd_pr[2]);
+      }
+    }
     add_launch(wgrad_ops, "wgrad_dense", 2, wg_ones);
     add_launch(wgrad_ops, "wgrad_dense", 2, wg_plain);
     add_launch(wgrad_ops, "wgrad_small", 2, wg_rest);
@@ -1429,7 +1499,7 @@ int grl_ctx::plan_sac() {
       std::vector<IgemmProb> all;
       for (int l = 2; l >= 0; --l) all.insert(all.end(), wgc[l].begin(), wgc[l].end());
       all.insert(all.end(), wg_merged.begin(), wg_merged.end());
-      add_launch(wgrad_ops, "wgrad_conv", 2, all);
+      add_launch(wgrad_ops, "wgrad_conv", 2, all, "", 0, {}, fillers ? 0 : -1);   // (fillers: conv1 alone keeps the 64x64 shape)
     }
   }
   // ---- schedule: weight gradients ride on the side lane next to the backward-data chain.  In list

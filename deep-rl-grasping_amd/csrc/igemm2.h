@@ -44,11 +44,10 @@ static inline int i2_bn(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 32 : 64); 
 // TEST-ONLY reference of the v2 tile semantics (see hostemu.h): tile = BM x BN of CFG; the ones row
 // (p_ones_i == M-1) is produced by row tile 0 and excluded from the row tiling.
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
+void igemm2_tile(const IgemmProb* probs, const int4 tl) {
   if (threadIdx.x != 0) return;
-  if (((FLAGS & 1) != 0) != (probs[tiles[blockIdx.x].x].p_ones_i >= 0)) abort();
+  if (((FLAGS & 1) != 0) != (probs[tl.x].p_ones_i >= 0)) abort();
   const int BM = i2_bm(CFG), BN = i2_bn(CFG);
-  const int4 tl = tiles[blockIdx.x];
   const IgemmProb& pb = probs[tl.x];
   if ((PM != PM_AFFINE) != (pb.p_tab_i != nullptr && pb.p_tab_r != nullptr)) abort();
   if ((PM == PM_TABLE_MASK) != (pb.p_vmask_i != nullptr)) abort();
@@ -91,6 +90,16 @@ void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
   for (int i = tl.z * BM; i < std::min(Meff, tl.z * BM + BM); ++i) row(i);
   if (pb.p_ones_i >= 0 && tl.z == 0) row(pb.p_ones_i);
 }
+template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
+void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs, tiles[blockIdx.x]);
+}
+// two kinds of tiles in one launch: blocks [0, n_a) run kind A (the launch's own stage), the rest kind B (fillers)
+template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
+void igemm2_pair_kernel(const IgemmProb* pa, const int4* ta, int n_a, const IgemmProb* pb, const int4* tb) {
+  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa, ta[blockIdx.x]);
+  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb, tb[blockIdx.x - n_a]);
+}
 #else
 
 #ifndef I2_ABLATE
@@ -114,9 +123,21 @@ __device__ __forceinline__ f32x4 i2_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) 
 
 // FLAGS: I2F_ONES  -- the problems carry a bias-gradient ones row (p_ones_i == M-1), Q along j, WK == 1
 //        I2F_KTAIL -- K % 4 != 0 (affine operands along r): elements past r_end are zeroed one by one
+// LDS floats one tile of an instantiation needs
+template <int PL, int QL, int CFG>
+struct I2Lds {
+  using C = I2Cfg<CFG>;
+  static constexpr int BKT = 32 * C::WK;
+  static constexpr int PSZ = PL == I2_P_ALONG_R ? C::BM * (BKT + 4) : BKT * (C::BM + 4);
+  static constexpr int QSZ = QL == I2_Q_ALONG_R ? C::BN * (BKT + 4) : BKT * (C::BN + 4);
+  static constexpr int RED = C::WK > 1 ? C::WK * C::BM * (C::BN + 4) : C::BM * (C::BN + 4);
+  static constexpr int value = 2 * (PSZ + QSZ) > RED ? 2 * (PSZ + QSZ) : RED;
+};
+
+// one tile; `lds` is the workgroup's staging area (I2Lds<...>::value floats, 16-byte aligned).  A function, not the
+// kernel, so that one launch can carry tiles of two instantiations (igemm2_pair_kernel).
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
-                                                    const int4* __restrict__ tiles) {
+__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ probs, const int4 tl, float* __restrict__ lds) {
   using C = I2Cfg<CFG>;
   constexpr int BM = C::BM, BN = C::BN, WK = C::WK, FM = C::FM, FN = C::FN, WN = C::WN, WM = C::WM;
   constexpr bool ONES = (FLAGS & I2F_ONES) != 0, KTAIL = (FLAGS & I2F_KTAIL) != 0;
@@ -127,8 +148,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   constexpr int QSZ = QL == I2_Q_ALONG_R ? BN * LDQK : BKT * LDQN;
   constexpr int BUF = PSZ + QSZ;
   constexpr int RED = WK > 1 ? WK * BM * (BN + 4) : BM * (BN + 4);   // k-split partials / output tile of the wide epilogue
-  constexpr int LDSF = 2 * BUF > RED ? 2 * BUF : RED;
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  static_assert((2 * BUF > RED ? 2 * BUF : RED) == I2Lds<PL, QL, CFG>::value, "I2Lds out of step with the tile layout");
 
 #ifdef I2_TIMING
 #define I2_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) { \
@@ -137,7 +157,6 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
 #define I2_STAMP(k) do { } while (0)
 #endif
   I2_STAMP(0);
-  const int4 tl = tiles[blockIdx.x];
   const IgemmProb* __restrict__ pb = probs + tl.x;
   const int N = pb->N, K = pb->K;
   const int ones_i = pb->p_ones_i;
@@ -657,6 +676,25 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     }
   }
   I2_STAMP(4);
+}
+
+template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
+__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
+                                                    const int4* __restrict__ tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[I2Lds<PL, QL, CFG>::value];
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs, tiles[blockIdx.x], lds);
+}
+
+// Two kinds of tiles in one launch: blocks [0, n_a) run kind A -- the stage the launch exists for, on the critical
+// path of the update -- and the remaining blocks kind B, independent work (weight gradients whose operands are
+// already complete) that fills the SIMD time A's few tiles per CU leave idle and rides on A's launch ramp.
+template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
+__global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __restrict__ pa, const int4* __restrict__ ta, int n_a,
+                                                         const IgemmProb* __restrict__ pb, const int4* __restrict__ tb) {
+  constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value;
+  __shared__ __attribute__((aligned(16))) float lds[LA > LB ? LA : LB];
+  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa, ta[blockIdx.x], lds);
+  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb, tb[blockIdx.x - n_a], lds);
 }
 
 #endif  // GRL_HOSTEMU

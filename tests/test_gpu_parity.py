@@ -40,7 +40,7 @@ def test_update_matches_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_HEADS_MFMA", "GRL_NO_V2", "GRL_LANES", "GRL_NO_FUSED_ADAM", "GRL_NO_WGRAD_MERGE", "GRL_NO_SK"])
+@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_HEADS_MFMA", "GRL_NO_V2", "GRL_LANES", "GRL_NO_FUSED_ADAM", "GRL_NO_WGRAD_MERGE", "GRL_NO_SK", "GRL_FILLERS"])
 def test_fallback_paths_match_oracle(monkeypatch, var):
     """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel, the two-lane capture, the separate Adam launch,
     the separate dense weight-gradient launch and conv1 on igemm2_kernel instead of the streaming kernel stay correct."""
@@ -117,7 +117,7 @@ def test_graph_replay_equals_eager(monkeypatch):
         assert np.array_equal(engs[0][n], engs[1][n]), n
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM"])
+@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM", "GRL_FILLERS"])
 def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
     """igemm_sk_kernel accumulates exactly like igemm2_kernel, and the launch-merging / Adam-fusion switches only
     regroup work: parameters after three updates are bit-identical.  (igemm_kernel shares the k-order too, but
