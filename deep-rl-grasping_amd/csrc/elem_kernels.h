@@ -78,6 +78,7 @@ struct GatherArgs {
   // advances rng_step.  Explicit mode reads idx (and the caller has staged eps).
   int use_rng; DevScalars* sc; uint64_t seed;
   int64_t* idx_w; float* eps_w; int n_eps;
+  int rgb_u8; // RGB-D ring with byte colours: per stored observation [hw packed dwords R|G<<8|B<<16][hw float32 depth]
   int vec4;   // img_elems, ldx multiples of 4 and 16-byte aligned rows: a thread moves 4 elements (grid.x = ceil(img_elems / 1024))
   // adam_tick: this launch opens an update -- one thread fixes the Adam step size of the update from the
   // beta powers and advances them (TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power)).
@@ -119,7 +120,15 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
     const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e4 < a.img_elems) {
       const float* rp = which ? a.rp_next : a.rp_obs;
-      const gn_f4 x = *(const gn_f4*)(rp + src * a.img_elems + e4);
+      gn_f4 x;
+      if (a.rgb_u8) {            // one pixel per thread: colours from the packed dword, depth from the float plane
+        const int hwp = a.img_elems >> 2, px = e4 >> 2;
+        const float* ob = rp + src * (2 * hwp);
+        const uint32_t w = ((const uint32_t*)ob)[px];
+        x = gn_f4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), ob[hwp + px]};
+      } else {
+        x = *(const gn_f4*)(rp + src * a.img_elems + e4);
+      }
       gn_d4 mu = {0.0, 0.0, 0.0, 0.0}, sd = {1.0, 1.0, 1.0, 1.0};
       if (a.normalize) { mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4); }
       gn_f4 y;
@@ -140,7 +149,14 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < a.img_elems) {
     const float* rp = which ? a.rp_next : a.rp_obs;
-    const float x = rp[src * a.img_elems + e];
+    float x;
+    if (a.rgb_u8) {
+      const int hwp = a.img_elems >> 2, px = e >> 2, ch = e & 3;
+      const float* ob = rp + src * (2 * hwp);
+      x = ch == 3 ? ob[hwp + px] : (float)((((const uint32_t*)ob)[px] >> (8 * ch)) & 255u);
+    } else {
+      x = rp[src * a.img_elems + e];
+    }
     const float y = norm_elem(x, a.normalize ? a.mean[e] : 0.0, a.normalize ? a.stdv[e] : 1.0,
                               a.normalize, a.clip_obs, a.scale_div);
     if (which) {
@@ -219,6 +235,7 @@ struct IngestArgs {
   int64_t pos, cap;
   float* rp_obs; float* rp_next; float* rp_dobs; float* rp_dnext; float* rp_act; float* rp_rew;
   float* rp_done;
+  int rgb_u8;   // RGB-D ring with byte colours (grl_config.replay_rgb_u8)
 };
 
 __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
@@ -233,7 +250,16 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
     if (e < a.vec_dim) img[dst * a.vec_dim + e] = src[(long)k * a.vec_dim + e];
   } else {
     const int img_elems = a.hw * a.c_img;
-    if (e < img_elems) {
+    if (a.rgb_u8) {
+      if (e < a.hw) {           // one pixel per thread: R, G, B -> one dword (round to nearest, clamped), depth as is
+        const float* p = src + ((long)k * a.hw + e) * a.c_obs;
+        uint32_t w = 0;
+        for (int ch = 0; ch < 3; ++ch) w |= (uint32_t)fminf(fmaxf(rintf(p[ch]), 0.f), 255.f) << (8 * ch);
+        float* ob = img + dst * (2 * a.hw);
+        ((uint32_t*)ob)[e] = w;
+        ob[a.hw + e] = p[3];
+      }
+    } else if (e < img_elems) {
       const int px = e / a.c_img, c = e - px * a.c_img;
       img[dst * img_elems + e] = src[((long)k * a.hw + px) * a.c_obs + c];
     }

@@ -962,8 +962,10 @@ int grl_ctx::plan_sac() {
 
   // ---------------- replay arena
   const int64_t cap = c.replay_capacity;
-  rp_obs = rp.f32(cap * img_elems);
-  rp_next = rp.f32(cap * img_elems);
+  // stored observation: img_elems floats, or (replay_rgb_u8) one packed colour dword + one depth float per pixel
+  const int64_t obs_store = c.replay_rgb_u8 ? 2 * (int64_t)hw * hw : img_elems;
+  rp_obs = rp.f32(cap * obs_store);
+  rp_next = rp.f32(cap * obs_store);
   rp_dobs = rp.f32(cap * std::max(nd, 1));
   rp_dnext = rp.f32(cap * std::max(nd, 1));
   rp_act = rp.f32(cap * A);
@@ -1074,6 +1076,7 @@ int grl_ctx::plan_sac() {
     }
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
     ga.act_out2 = act_p; ga.ld_act2 = Ap;
+    ga.rgb_u8 = c.replay_rgb_u8;
     ga.sc = sc; ga.seed = c.seed; ga.idx_w = idx_buf; ga.eps_w = eps_buf; ga.n_eps = A;
     ga.adam_tick = fused_heads ? 1 : 0;   // otherwise sac_loss_kernel fixes the step size
 #ifndef GRL_HOSTEMU
@@ -1083,7 +1086,7 @@ int grl_ctx::plan_sac() {
     for (int mode = 0; mode < 2; ++mode) {
       ga.use_rng = mode;
       Op op; op.tag = "gather_norm";
-      op.bytes = 2.0 * B * ((double)img_elems * 8 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
+      op.bytes = 2.0 * B * ((double)img_elems * 4 + (double)obs_store * 4 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
       op.run = [ga, per_block](hipStream_t s) {
         hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + per_block - 1) / per_block, ga.B, 2), dim3(256), 0, s, ga);
       };
@@ -2611,6 +2614,13 @@ static int check_cfg(const grl_config* c) {
         c->q_n_value < 1 || c->q_n_value > GRL_MAX_LAYERS)
       return fail(GRL_ERR_INVALID, "tower depths out of range (branch and value towers need >= 1 hidden layer)");
     if (c->q_per && c->batch_size > 1024) return fail(GRL_ERR_INVALID, "prioritised replay supports batch_size <= 1024");
+    if (c->q_per && c->replay_capacity > (int64_t)PER_BLK * PER_BLK)
+      return fail(GRL_ERR_INVALID, "prioritised replay supports up to 1024 x 1024 transitions (two-level segment tree)");
+  }
+  if (c->replay_rgb_u8) {
+    const int c_img = c->obs_channels - ((c->extractor == GRL_EXTRACTOR_AUGMENTED && c->n_direct > 0) ? 1 : 0);
+    if (c->algo != GRL_ALGO_SAC || c->extractor == GRL_EXTRACTOR_MLP || c_img != 4)
+      return fail(GRL_ERR_INVALID, "replay_rgb_u8 needs SAC on RGB-D images with 4 image channels (R, G, B, depth)");
   }
   if (c->extractor == GRL_EXTRACTOR_MLP) {
     if (c->obs_dim < 1) return fail(GRL_ERR_INVALID, "obs_dim must be >= 1 for the MLP extractor");
@@ -2776,7 +2786,8 @@ static int replay_add_dev(grl_handle h, const float* obs, const float* act, cons
   ia.pos = h->rp_pos; ia.cap = c.replay_capacity;
   ia.rp_obs = h->rp_obs; ia.rp_next = h->rp_next; ia.rp_dobs = h->rp_dobs; ia.rp_dnext = h->rp_dnext;
   ia.rp_act = h->rp_act; ia.rp_rew = h->rp_rew; ia.rp_done = h->rp_done;
-  const int elems = h->cnn ? h->img_elems : c.obs_dim;
+  ia.rgb_u8 = (c.algo == GRL_ALGO_SAC) ? c.replay_rgb_u8 : 0;
+  const int elems = h->cnn ? (ia.rgb_u8 ? h->hw * h->hw : h->img_elems) : c.obs_dim;
   hipLaunchKernelGGL(ingest_kernel, dim3((elems + 255) / 256, n, 2), dim3(256), 0, h->stream, ia);
   if (h->per_on)   // new transitions enter with max_priority ** alpha
     hipLaunchKernelGGL(per_add_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->per, h->rp_pos, n,

@@ -24,6 +24,7 @@ class GrlConfig(C.Structure):
         ("q_n_value", C.c_int32), ("q_value", C.c_int32 * GRL_MAX_LAYERS),
         ("q_huber", C.c_int32), ("q_double", C.c_int32), ("q_grad_clip", C.c_float), ("q_trunk_scale", C.c_float),
         ("q_per", C.c_int32), ("q_per_alpha", C.c_float), ("q_per_eps", C.c_float),
+        ("replay_rgb_u8", C.c_int32),
     ]
 
 
@@ -128,7 +129,8 @@ def norm_mode(normalize):
 
 def make_config(extractor, obs_channels=2, n_direct=1, obs_dim=0, act_dim=5, layers=(64, 64), batch_size=64,
                 act_batch=1, replay_capacity=50000, normalize=True, gamma=0.99, lr=3e-4, tau=0.005,
-                clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, target_entropy=None, seed=0, img_hw=64):
+                clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, target_entropy=None, seed=0, img_hw=64,
+                replay_rgb_u8=False):
     cfg = GrlConfig()
     cfg.extractor = {"mlp": 0, "augmented": 1, "nature": 2}.get(extractor, extractor)
     cfg.img_hw, cfg.obs_channels, cfg.n_direct, cfg.obs_dim, cfg.act_dim = img_hw, obs_channels, n_direct, obs_dim, act_dim
@@ -143,6 +145,7 @@ def make_config(extractor, obs_channels=2, n_direct=1, obs_dim=0, act_dim=5, lay
     cfg.clip_obs, cfg.clip_reward, cfg.norm_eps = clip_obs, clip_reward, norm_eps
     cfg.target_entropy = -float(act_dim) if target_entropy is None else target_entropy
     cfg.seed = seed
+    cfg.replay_rgb_u8 = 1 if replay_rgb_u8 else 0
     return cfg
 
 

@@ -95,6 +95,12 @@ typedef struct grl_config {
   int32_t q_per;          /* 1: keep priorities in the replay arena, enable grl_train_step_per  */
   float q_per_alpha;      /* prioritized_replay_alpha (0.6)                                      */
   float q_per_eps;        /* prioritized_replay_eps (1e-6)                                       */
+  /* RGB-D observations (obs_channels 5 = R, G, B, depth, pad; robot.py:201-202): keep the three colour channels of
+     a stored transition as bytes (the camera delivers uint8, sensor.py:126-145) -- one packed dword + one float32
+     depth per pixel, 32 KB per observation instead of 64 KB, so that the reference's 1 M-transition buffer
+     (full_depth_obs.yaml / SAC_full_rgbd) is 65.5 GB of HBM.  Lossless iff the colour values are integers in
+     [0, 255]; the caller vouches for that.  Requires 4 image channels (augmented extractor on 5-channel obs). */
+  int32_t replay_rgb_u8;
 } grl_config;
 
 /* byte sizes of the four caller-provided device arenas */

@@ -18,7 +18,7 @@ GRAD_REL = 1e-3
 
 
 def make_case(extractor="augmented", kind="depth", B=8, n_replay=40, act_dim=5, layers=(64, 64), seed=0,
-              normalize=True, n_steps=2, obs_dim=101):
+              normalize=True, n_steps=2, obs_dim=101, rgb_u8=False):
     case = {"B": B, "n_steps": n_steps, "extractor": extractor, "normalize": normalize}
     if extractor == "mlp":
         rng = np.random.default_rng(seed + 7)
@@ -40,7 +40,7 @@ def make_case(extractor="augmented", kind="depth", B=8, n_replay=40, act_dim=5, 
             spec = osac.SacSpec(extractor="nature", img_channels=C, n_direct=0, act_dim=act_dim, layers=list(layers))
         cfg = _capi.make_config(extractor, obs_channels=C, n_direct=1 if extractor == "augmented" else 0,
                                 act_dim=act_dim, layers=layers, batch_size=B, replay_capacity=n_replay,
-                                normalize=normalize, act_batch=4)
+                                normalize=normalize, act_batch=4, replay_rgb_u8=rgb_u8)
     idx, eps = synthetic.make_noise(n_steps, B, act_dim, n_replay, seed + 1)
     case.update(spec=spec, cfg=cfg, stats=stats, tr=tr, idx=idx, eps=eps,
                 params=osac.init_params(spec, seed))

@@ -73,6 +73,66 @@ def test_one_million_transition_ring():
     eng.close()
 
 
+def _pattern_rgbd(i0, n, dev):
+    """RGB-D transition i: R = i mod 256, G = (i // 256) mod 256, B = (pixel + i) mod 256 (integers, as the camera
+    delivers them), depth = (i mod 8191) / 8192 + pixel / 2^20, direct feature = (i mod 97) / 97."""
+    i = torch.arange(i0, i0 + n, device=dev, dtype=torch.int64)
+    pix = torch.arange(4096, device=dev, dtype=torch.int64)
+    obs = torch.zeros((n, 4096, 5), device=dev)
+    obs[..., 0] = torch.remainder(i, 256).float()[:, None]
+    obs[..., 1] = torch.remainder(i // 256, 256).float()[:, None]
+    obs[..., 2] = torch.remainder(pix[None, :] + i[:, None], 256).float()
+    obs[..., 3] = (torch.remainder(i, 8191).float() / 8192.0)[:, None] + pix.float()[None, :] / float(1 << 20)
+    obs[:, 0, 4] = torch.remainder(i, 97).float() / 97.0
+    return obs.view(n, 64, 64, 5)
+
+
+def test_one_million_transition_rgbd_ring_with_byte_colours():
+    """BASELINE configs[3]: the reference's 1 M-transition buffer on RGB-D observations (64x64x5) resident in HBM.
+    With grl_config.replay_rgb_u8 a stored observation is 32 KB (packed colour dword + float32 depth per pixel):
+    65.5 GB for obs + next_obs.  Far-end reads (offsets beyond 2^31 elements) and the wrap must return exactly
+    what was stored."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * (1 << 30):
+        pytest.skip("needs ~75 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    cfg = _capi.make_config("augmented", obs_channels=5, n_direct=1, act_dim=5, layers=(64, 64), batch_size=8,
+                            replay_capacity=CAP, normalize=False, act_batch=1, seed=3, replay_rgb_u8=True)
+    eng = SacEngine(cfg)
+    assert eng.sizes.replay_bytes < 70 * (1 << 30)          # the float32 layout would need 131 GB
+    eng.set_parameters(init_parameters(eng.table, seed=0))
+    chunk = 20_000
+    for k0 in range(0, CAP, chunk):
+        with torch.cuda.stream(eng.be.stream):
+            eng.replay_add_device(_pattern_rgbd(k0, chunk, dev), torch.zeros((chunk, 5), device=dev),
+                                  torch.arange(k0, k0 + chunk, device=dev, dtype=torch.float32),
+                                  _pattern_rgbd(k0 + 1, chunk, dev), torch.zeros(chunk, device=dev))
+        eng.be.stream.synchronize()
+    assert eng.replay_size() == CAP
+    idx = np.array([[0, 1, 262_143, 262_144, 777_777, CAP - 3, CAP - 2, CAP - 1]], np.int64)   # 262144 * 8192 = 2^31 dwords
+    eps = np.zeros((1, 8, 5), np.float32)
+    eng.train(1, idx, eps)
+    x = eng.fetch("x_obs", (8, 64, 64, 4))
+    xn = eng.fetch("x_next", (8, 64, 64, 4))
+    for k, i in enumerate(idx[0]):
+        for arr, j in ((x, int(i)), (xn, int(i) + 1)):
+            want = _pattern_rgbd(j, 1, dev)[0, :, :, :4].cpu().numpy() / np.float32(255.0)
+            assert np.array_equal(arr[k], want.astype(np.float32)), (int(i), j)
+    assert np.array_equal(eng.fetch("rew", (8,)), idx[0].astype(np.float32))
+    with torch.cuda.stream(eng.be.stream):                   # wrap: 3 more transitions land in slots 0..2
+        eng.replay_add_device(_pattern_rgbd(5_000_000, 3, dev), torch.zeros((3, 5), device=dev),
+                              torch.full((3,), -1.0, device=dev), _pattern_rgbd(5_000_001, 3, dev), torch.zeros(3, device=dev))
+    eng.be.stream.synchronize()
+    eng.train(1, np.array([[0, 2, 3, CAP - 1, 0, 0, 0, 0]], np.int64), eps)
+    r = eng.fetch("rew", (8,))
+    assert r[0] == -1.0 and r[1] == -1.0 and r[2] == 3.0 and r[3] == float(CAP - 1)
+    want = _pattern_rgbd(5_000_000, 1, dev)[0, :, :, :4].cpu().numpy() / np.float32(255.0)
+    assert np.array_equal(eng.fetch("x_obs", (8, 64, 64, 4))[0], want.astype(np.float32))
+    eng.train(32)                                            # device RNG over the full ring
+    assert all(np.isfinite(v) for v in eng.metrics().values())
+    eng.close()
+
+
 def test_prioritised_sampler_over_one_million_priorities():
     cfg = _capi.make_q_config("dqn", 16, 1, 4, branch_hidden=(16,), value_hidden=(16,), batch_size=64,
                               replay_capacity=CAP, lr=1e-3, prioritized=True)

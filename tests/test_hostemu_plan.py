@@ -24,6 +24,8 @@ CASES = {
     # VecNormalize(norm_obs=True, norm_reward=False) / (False, True): each flag honoured on its own
     "depth_norm_obs_only": dict(extractor="augmented", kind="depth", B=4, n_replay=16, normalize="obs"),
     "mlp_norm_reward_only": dict(extractor="mlp", B=8, n_replay=32, normalize="reward"),
+    # RGB-D ring with byte colours (grl_config.replay_rgb_u8): lossless on the camera's integer colours
+    "rgbd_u8_replay": dict(extractor="augmented", kind="rgbd", B=3, n_replay=12, rgb_u8=True),
 }
 
 
