@@ -1,18 +1,25 @@
 #!/usr/bin/env python
-"""Headline benchmark: SAC gradient steps / second on 64x64 depth observations, batch 256 per GPU
-(BASELINE.json metric; config 2 = config/gripper_grasp.yaml --algo SAC, depth 64x64x2, A=5,
-layers [64,64], VecNormalize on).
+"""Benchmarks of the update hot path on MI355X.  Default = the headline: SAC gradient steps / second on 64x64 depth
+observations, batch 256 per GPU (BASELINE.json metric; configs[1] = config/gripper_grasp.yaml --algo SAC, depth
+64x64x2, A=5, layers [64,64], VecNormalize on).
 
-One step = draw a minibatch from the HBM-resident replay (device Philox) + normalise + 3 CNN
-forwards + heads + losses + backward through both trainable CNNs + 3 Adam applies + Polyak update
-(14 kernel launches replayed as one hipGraph).
-Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, data parallel,
-per-GPU batch fixed at 256 (weak scaling), one RCCL all-reduce of the flat fp32 gradient bucket
-per step; `value` counts batch-256 gradient computations per second over the whole job
-(= N x global steps/s).
+One step = draw a minibatch from the HBM-resident replay (device Philox) + normalise + 3 CNN forwards + heads +
+losses + backward through both trainable CNNs + 3 Adam applies + Polyak update, replayed as one hipGraph
+(DESIGN.md section 4).  Inputs are resident in HBM before the timed region.  The timed block (exactly --steps
+updates between barrier + synchronize) is repeated --repeats times; `value` is the MEDIAN block.
+
+N > 1: one process per GPU, data parallel, gradients all-reduced over RCCL per update.  Default per-GPU batch 256
+(weak scaling, `value` = N x global steps/s); `--global-batch G` fixes the GLOBAL batch (G/N per GPU, strong
+scaling: BASELINE configs[4] is `--global-batch 1024` on 8 GPUs).
+
+Other workloads (`--workload`), each with its own roofline and CPU-oracle baseline:
+  sac_rgbd    configs[3]: RGB-D 64x64x5, batch 256, replay with byte colours, + auto-encoder feature latency
+  sac_nature  configs[0] on the GPU: default nature_cnn over both channels, A=3, batch 64, no VecNormalize
+  bdq_per     configs[2]: BDQ 5 branches x 33 bins on 101-d observations, batch 64, prioritised replay over 1 M
+  ae_train    auto-encoder training step, batch 128 (config/encoder.yaml)
 
     python bench.py --gpus 1 --steps 200 --warmup 20
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -26,37 +33,53 @@ for p in (ROOT, os.path.join(ROOT, "deep-rl-grasping_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 MFMA / vector peak
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec
-BATCH = 256
-REPLAY = 100_000            # SURVEY.md 8d bench replay size (3.3 GB resident)
 ACT_DIM = 5
 
+WORKLOADS = {
+    "sac_depth": dict(kind="depth", extractor="augmented", batch=256, act_dim=5, normalize=True, replay=100_000,
+                      metric="SAC grad-steps/sec (64x64 depth, batch 256 per GPU)",
+                      name="configs[1]: gripper_grasp.yaml --algo SAC, depth 64x64x2, batch %d/GPU, A=5, layers [64,64], "
+                           "VecNormalize, %d-transition replay in HBM, device RNG"),
+    "sac_rgbd": dict(kind="rgbd", extractor="augmented", batch=256, act_dim=5, normalize=True, replay=50_000, rgb_u8=True,
+                     metric="SAC grad-steps/sec (64x64 RGB-D, batch 256 per GPU)",
+                     name="configs[3]: SAC on RGB-D 64x64x5 (SAC_full_rgbd/config.yaml), batch %d/GPU, A=5, layers [64,64], "
+                          "VecNormalize, %d-transition replay with byte colours in HBM, device RNG"),
+    "sac_nature": dict(kind="depth", extractor="nature", batch=64, act_dim=3, normalize=False, replay=50_000,
+                       metric="SAC grad-steps/sec (64x64 depth, nature_cnn, batch 64)",
+                       name="configs[0]: simplified_object_picking.yaml --algo SAC with depth observations: default nature_cnn "
+                            "over both channels, batch %d/GPU, A=3, layers [64,64], no VecNormalize, %d-transition replay"),
+}
 
-def fill_replay_on_device(eng, n, seed, device):
+
+# ------------------------------------------------------------------------------------------------ helpers
+def fill_replay_on_device(eng, n, seed, device, kind="depth", act_dim=5):
     """Synthetic transitions with the reference's per-pixel statistics, generated on the GPU."""
+    import numpy as np
+    import torch
     from grasp_rl import synthetic
-    st = synthetic.load_obs_stats("depth")
+    st = synthetic.load_obs_stats(kind)
     mean = torch.from_numpy(st["mean"].astype(np.float32)).to(device)
     std = torch.from_numpy(np.sqrt(st["var"]).astype(np.float32)).to(device)
+    C = mean.shape[-1]
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    chunk = 2048
+    chunk = 2048 if kind == "depth" else 1024
     s = eng.be.stream
     for k0 in range(0, n, chunk):
         m = min(chunk, n - k0)
         with torch.cuda.stream(s):
             def draw():
                 o = mean + std * torch.randn((m,) + tuple(mean.shape), generator=g, device=device)
-                o[..., 0].clamp_(0.02, 2.0)
-                o[..., 1] = 0.0
-                o[:, 0, 0, 1] = torch.rand(m, generator=g, device=device)
+                if kind == "rgbd":
+                    o[..., :3] = o[..., :3].round().clamp_(0, 255)
+                o[..., C - 2].clamp_(0.02, 2.0)
+                o[..., C - 1] = 0.0
+                o[:, 0, 0, C - 1] = torch.rand(m, generator=g, device=device)
                 return o.contiguous()
             obs, nxt = draw(), draw()
-            act = (torch.rand((m, ACT_DIM), generator=g, device=device) * 2 - 1).contiguous()
+            act = (torch.rand((m, act_dim), generator=g, device=device) * 2 - 1).contiguous()
             u = torch.rand(m, generator=g, device=device)
             rew = torch.where(u < 0.8, torch.full_like(u, -200.0),
                               torch.where(u < 0.99, -100.0 + 1000.0 * (torch.rand(m, generator=g, device=device) * 0.06 - 0.03),
@@ -67,18 +90,114 @@ def fill_replay_on_device(eng, n, seed, device):
     return st
 
 
-def cpu_baseline(seconds=15.0):
+def timed_blocks(run, barrier, steps, warmup, repeats, world, device):
+    """`repeats` timed blocks of exactly `steps` updates (barrier + synchronize on both sides, MAX over ranks)."""
+    import torch
+    import torch.distributed as dist
+    run(warmup)
+    times = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        run(steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    return times
+
+
+def profile_pass(eng, go, n):
+    """Per-launch durations: a separate eager pass of the same workload bracketed by hipEvents on the engine's
+    stream (graph replay cannot carry per-kernel events); not part of the timed region."""
+    eng.profile(True)
+    go(n)
+    eng.synchronize()
+    prof = eng.profile_dump()
+    eng.profile(False)
+    return prof
+
+
+def roofline_of(prof, n, dt_step, workload):
+    total = {k: v["avg_ms"] * v["launches"] for k, v in prof.items()}
+    with_flops = [k for k in prof if prof[k]["flops"] > 0]
+    roof = {"measured": "separate eager pass, hipEvents on the engine stream, same workload",
+            "step_kernel_ms": {k: round(total[k] / max(1, n), 5) for k in sorted(total)}}
+    if with_flops:
+        dom = max(with_flops, key=lambda k: total[k])
+        d = prof[dom]
+        ach = d["flops"] / (d["avg_ms"] * 1e-3) / 1e12
+        roof.update({"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(d["avg_ms"], 5),
+                     "flops_per_launch": d["flops"]})
+        tr = pmc_traffic(dom, workload)
+        if tr:
+            roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr[0], "bytes/launch", tr[1]
+        step_flops = sum(v["flops"] * v["launches"] for v in prof.values()) / max(1, n)
+        roof["step_flops"] = step_flops
+        roof["step_achieved"] = round(step_flops / dt_step / 1e12, 3)
+        roof["step_frac"] = round(roof["step_achieved"] / PEAK_F32_TFLOPS, 4)
+    else:                        # no GEMM-shaped launch carries FLOP counts: report the longest launch against HBM
+        dom = max(prof, key=lambda k: total[k])
+        d = prof[dom]
+        ach = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9 if d["bytes"] else 0.0
+        roof.update({"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(d["avg_ms"], 5)})
+    return roof
+
+
+def pmc_traffic(tag, workload="sac_depth"):
+    """HBM bytes per launch of launch `tag` from the newest committed PMC summary of this workload (separate
+    rocprofv3 --pmc passes of this same command, scripts/pmc_traffic.sh: FETCH_SIZE with the gfx950 correction +
+    WRITE_SIZE); counters cannot be collected from inside the timed process, so this is the recorded measurement."""
+    import csv
+    import glob
+    import re
+
+    def version(path):          # r02 ... _v3.csv after r01 ... _v11.csv
+        b = os.path.basename(path)
+        r = re.search(r"r(\d+)_", b)
+        m = re.search(r"_v(\d+)", b)
+        return (int(r.group(1)) if r else 0, int(m.group(1)) if m else -1, path)
+    pat = "*pmc_hbm_traffic*.csv" if workload == "sac_depth" else "*pmc_hbm_traffic_%s*.csv" % workload
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), key=version)
+    if workload == "sac_depth":
+        files = [f for f in files if not re.search(r"traffic_(sac_rgbd|sac_nature|bdq_per|ae_train)", f)]
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get("launch_tag") == tag:
+                        mb = [v for k, v in row.items() if k and k.startswith("HBM_MB_per_launch")][0]
+                        return round(float(mb) * 1048576.0), "profiles/" + os.path.basename(f)
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline_sac(wl, seconds=12.0):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
+    import torch
     from oracle import sac as osac
     from grasp_rl import synthetic
-    spec = osac.SacSpec()
+    st = synthetic.load_obs_stats(wl["kind"])
+    C = st["mean"].shape[-1]
+    B, A = wl["batch"], wl["act_dim"]
+    if wl["extractor"] == "augmented":
+        spec = osac.SacSpec(extractor="augmented", img_channels=C - 1, n_direct=1, act_dim=A, layers=[64, 64])
+    else:
+        spec = osac.SacSpec(extractor="nature", img_channels=C, n_direct=0, act_dim=A, layers=[64, 64])
     orc = osac.SacOracle(spec, seed=0)
-    st = synthetic.load_obs_stats("depth")
-    tr = synthetic.make_transitions(1024, "depth", ACT_DIM, 0, st)
-    idx, eps = synthetic.make_noise(400, BATCH, ACT_DIM, 1024, 1)
+    n_tr = 1024 if wl["kind"] == "depth" else 512
+    tr = synthetic.make_transitions(n_tr, wl["kind"], A, 0, st)
+    idx, eps = synthetic.make_noise(400, B, A, n_tr, 1)
     cores = min(os.cpu_count() or 1, 16)   # the small convs stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(cores)
-    stats = {"mean": st["mean"], "var": st["var"], "ret_var": st["ret_var"]}
+    stats = {"mean": st["mean"], "var": st["var"], "ret_var": st["ret_var"]} if wl["normalize"] else None
 
     def one(s):
         raw = {k: tr[k][idx[s]] for k in ("obs", "act", "rew", "next_obs", "done")}
@@ -92,67 +211,79 @@ def cpu_baseline(seconds=15.0):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
             "sample": "%d oracle SAC updates at batch %d (sampling + float64 normalisation + PyTorch-CPU fp32 step), %.1f s"
-                      % (n, BATCH, dt)}
+                      % (n, B, dt)}
 
 
-def pmc_traffic(tag):
-    """HBM bytes per launch of launch `tag` from the newest committed PMC summary (separate rocprofv3 --pmc
-    passes of this same command, scripts/pmc_traffic.sh: FETCH_SIZE with the gfx950 correction + WRITE_SIZE);
-    counters cannot be collected from inside the timed process, so this is the recorded measurement or None."""
-    import csv
-    import glob
-    import re
+def cpu_baseline_bdq(seconds=8.0):
+    import numpy as np
+    import torch
+    from oracle import dqn as od
+    spec = od.bdq_spec(101, 5, 33, [[64, 64], [32], [32]])
+    spec.lr = 1e-4
+    orc = od.QOracle(spec, od.init_params(spec, 0))
+    rng = np.random.default_rng(0)
+    B = 64
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
 
-    def version(path):          # ..._v11.csv after ..._v9.csv
-        m = re.search(r"_v(\d+)", os.path.basename(path))
-        return (int(m.group(1)) if m else -1, path)
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_hbm_traffic*.csv")),
-                   key=version)
-    for f in reversed(files):
-        try:
-            with open(f) as fh:
-                for row in csv.DictReader(fh):
-                    if row.get("launch_tag") == tag:
-                        mb = [v for k, v in row.items() if k and k.startswith("HBM_MB_per_launch")][0]
-                        return round(float(mb) * 1048576.0), "profiles/" + os.path.basename(f)
-        except (OSError, ValueError, IndexError):
-            continue
-    return None
+    def one():
+        f = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+        batch = {"obs": f(rng.normal(size=(B, 101))), "next_obs": f(rng.normal(size=(B, 101))),
+                 "act": f(rng.integers(0, 33, (B, 5))), "rew": f(rng.normal(size=B)), "done": f(rng.random(B) < 0.07)}
+        orc.step(batch, rng.uniform(0.3, 1.0, B).astype(np.float32))
+    for _ in range(5):
+        one()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d oracle BDQ updates at batch 64 (PyTorch-CPU fp32; minibatch handed over, no sum-tree walk), %.1f s" % (n, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--replay", type=int, default=REPLAY)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_ae(seconds=8.0):
+    import numpy as np
+    import torch
+    from oracle.autoencoder import AeOracle
+    from grasp_rl.autoencoder import glorot_uniform_params
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    orc = AeOracle(glorot_uniform_params(0), lr=2e-4)
+    x = np.random.default_rng(0).uniform(0, 0.5, (128, 64, 64, 1)).astype(np.float32)
+    orc.step(x)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        orc.step(x)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "train-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d oracle auto-encoder training steps at batch 128 (PyTorch-CPU fp32), %.1f s" % (n, dt)}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+
+# ------------------------------------------------------------------------------------------------ workloads
+def run_sac(args, wl_name, world, rank, device):
+    import numpy as np
+    import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     from grasp_rl import _capi
     from grasp_rl.engine import SacEngine
     from grasp_rl.init import init_parameters
     from grasp_rl.parallel import DataParallelSac
-
-    cfg = _capi.make_config("augmented", obs_channels=2, n_direct=1, act_dim=ACT_DIM, layers=(64, 64),
-                            batch_size=BATCH, replay_capacity=args.replay, normalize=True, act_batch=16,
-                            seed=1234 + rank)
+    wl = dict(WORKLOADS[wl_name])
+    strong = args.global_batch is not None
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of GPUs")
+        wl["batch"] = args.global_batch // world
+    replay = args.replay or wl["replay"]
+    C = 5 if wl["kind"] == "rgbd" else 2
+    cfg = _capi.make_config(wl["extractor"], obs_channels=C, n_direct=1 if wl["extractor"] == "augmented" else 0,
+                            act_dim=wl["act_dim"], layers=(64, 64), batch_size=wl["batch"], replay_capacity=replay,
+                            normalize=wl["normalize"], act_batch=16, seed=1234 + rank, replay_rgb_u8=wl.get("rgb_u8", False))
     eng = SacEngine(cfg, device=str(device))
     eng.set_parameters(init_parameters(eng.table, seed=0))       # identical on every rank
-    st = fill_replay_on_device(eng, args.replay, 100 + rank, device)
+    st = fill_replay_on_device(eng, replay, 100 + rank, device, wl["kind"], wl["act_dim"])
     eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
     dp = DataParallelSac(eng) if world > 1 else None
 
@@ -168,62 +299,186 @@ def main():
         if world > 1:
             dist.barrier()
 
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    eng.synchronize()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.barrier()
+    times = timed_blocks(run, barrier, args.steps, args.warmup, args.repeats, world, device)
+    dt = float(np.median(times))
     metrics = eng.metrics()
-
-    roof = None
+    out = {"metric": wl["metric"] if not strong else "SAC grad-steps/sec (64x64 depth, global batch %d)" % args.global_batch,
+           "value": None, "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+           "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    if strong:      # one global step consumes the whole global batch: `value` = global updates / s
+        out["value"] = round(args.steps / dt, 2)
+    else:           # per-GPU batch fixed: batch-sized gradient computations / s over the whole job
+        out["value"] = round(world * args.steps / dt, 2)
+    out["config"] = {"workload": wl["name"] % (wl["batch"], replay) + (" [configs[4]: global batch %d over %d GPU(s)]"
+                                                                        % (args.global_batch, world) if strong else ""),
+                     "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world,
+                     "global_steps_per_s": round(args.steps / dt, 2)}
+    out["repeats"] = {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"}
+    out["losses"] = {k: round(float(v), 6) for k, v in metrics.items()}
     if rank == 0 and not args.no_profile:
-        # per-kernel durations: separate eager pass of the same workload bracketed by hipEvents on the
-        # engine's stream (graph replay cannot carry per-kernel events); not part of the timed region
-        eng.profile(True)
-        eng.train_device(min(args.steps, 50))
-        eng.synchronize()
-        prof = eng.profile_dump()
-        eng.profile(False)
-        total = {k: v["avg_ms"] * v["launches"] for k, v in prof.items()}
-        dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: total[k])
-        d = prof[dom]
-        ach = d["flops"] / (d["avg_ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
-                "avg_launch_ms": round(d["avg_ms"], 5), "flops_per_launch": d["flops"],
-                "measured": "separate eager pass, hipEvents on the engine stream, same workload",
-                "step_kernel_ms": {k: round(total[k] / max(1, min(args.steps, 50)), 5) for k in sorted(total)}}
-        tr = pmc_traffic(dom)
-        if tr:
-            roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr[0], "bytes/launch", tr[1]
-        # whole update: algorithmic FLOPs of every GEMM-shaped launch of one step over the graph-replay step time
-        step_flops = sum(v["flops"] * v["launches"] for v in prof.values()) / max(1, min(args.steps, 50))
-        roof["step_flops"] = step_flops
-        roof["step_achieved"] = round(step_flops / (dt / args.steps) / 1e12, 3)
-        roof["step_frac"] = round(roof["step_achieved"] / PEAK_F32_TFLOPS, 4)
+        n = min(args.steps, 50)
+        prof = profile_pass(eng, eng.train_device, n)
+        out["roofline"] = roofline_of(prof, n, dt / args.steps, wl_name)
+    else:
+        out["roofline"] = None
+    if wl_name == "sac_rgbd" and rank == 0 and world == 1:
+        # "+ pretrained autoencoder features" (configs[3]): latency of the encoder forward the env side calls per step
+        from grasp_rl.autoencoder import glorot_uniform_params
+        P = glorot_uniform_params(0)
+        eng.load_encoder([P[k] for k in list(P)[:8]])
+        frames = np.random.default_rng(0).uniform(0, 0.5, (16, 64, 64, 1)).astype(np.float32)
+        eng.encode(frames)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            eng.encode(frames)
+        out["ae_encode_us_per_call_16_frames"] = round(1e6 * (time.perf_counter() - t0) / 200, 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline_sac(wl)
+    out["cpu_baseline"] = cpu
+    eng.close()
+    if wl_name == "sac_depth" and rank == 0 and world == 1 and not strong and not args.no_learn_loop:
+        from grasp_rl import synthetic
+        try:
+            out["learn_loop"] = {
+                "what": "SAC.learn with 16 SubprocVecEnv workers of a free synthetic env + VecNormalize (host loop cost: "
+                        "pipes, running statistics, staging, act); one update per iteration; not part of `value`",
+                "overlap_env_step": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True, device=str(device)),
+                "strict_order": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False, device=str(device))}
+            out["learn_loop_steps_per_s"] = out["learn_loop"]["overlap_env_step"]["env_steps_per_s"]
+        except Exception as e:      # the headline number must not depend on process spawning
+            out["learn_loop"] = {"error": repr(e)}
+    return out
 
+
+def run_bdq(args, device):
+    import numpy as np
+    import torch
+    from grasp_rl import _capi
+    from grasp_rl.engine import QEngine
+    replay = args.replay or 1_000_000
+    cfg = _capi.make_q_config("bdq", 101, 5, 33, common=(64, 64), branch_hidden=(32,), value_hidden=(32,), batch_size=64,
+                              replay_capacity=replay, lr=1e-4, prioritized=True)
+    eng = QEngine(cfg, device=str(device))
+    rng = np.random.default_rng(0)
+    P = {}
+    for name, _, _, shape, _ in eng.table:
+        if "/target_q_func/" not in name:
+            P[name] = (rng.normal(0.0, 0.1, shape) if len(shape) >= 2 else np.zeros(shape)).astype(np.float32)
+    for name, *_ in eng.table:
+        if "/target_q_func/" in name:
+            P[name] = P[name.replace("/target_q_func", "")].copy()
+    eng.set_parameters(P)
+    g = torch.Generator(device=device)
+    g.manual_seed(0)
+    for k0 in range(0, replay, 65536):
+        m = min(65536, replay - k0)
+        with torch.cuda.stream(eng.be.stream):
+            eng.replay_add_device(torch.randn((m, 101), generator=g, device=device), torch.randint(0, 33, (m, 5), generator=g, device=device).float(),
+                                  torch.randn(m, generator=g, device=device), torch.randn((m, 101), generator=g, device=device),
+                                  (torch.rand(m, generator=g, device=device) < 1.0 / 15.0).float())
+        eng.be.stream.synchronize()
+    go = lambda n: eng.train_per(n, beta=0.4)
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize(device)
+    times = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
+    dt = float(np.median(times))
+    out = {"metric": "BDQ grad-steps/sec (101-d observations, 5 x 33 bins, batch 64, prioritised replay)",
+           "value": round(args.steps / dt, 2), "unit": "grad-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[2]: gripper_grasp.yaml --algo BDQ (layers [[64,64],[32],[32]], num_actions_pad 33, batch "
+                                  "64, lr 1e-4, prioritized_replay) on 101-d auto-encoder observations, %d-transition ring + "
+                                  "priorities in HBM, device RNG" % replay},
+           "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"},
+           "losses": {k: round(float(v), 6) for k, v in eng.metrics().items()}}
+    if not args.no_profile:
+        prof = profile_pass(eng, go, 50)
+        out["roofline"] = roofline_of(prof, 50, dt / args.steps, "bdq_per")
+        out["roofline"]["note"] = "every launch of this update is latency-bound (0.01 GFLOP, < 5 MB): fractions are informational"
+    out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_bdq()
+    eng.close()
+    return out
+
+
+def run_ae(args, device):
+    import numpy as np
+    import torch
+    from grasp_rl.autoencoder import AeEngine, glorot_uniform_params
+    eng = AeEngine(128, 2e-4, device=str(device))
+    eng.set_parameters(glorot_uniform_params(0))
+    x = torch.from_numpy(np.random.default_rng(0).uniform(0, 0.5, (128 * 8, 4096)).astype(np.float32)).to(device)
+    import ctypes as C
+    from grasp_rl._capi import check
+
+    def go(n):          # n training steps on device-resident minibatches (8 distinct ones, cycled)
+        done = 0
+        while done < n:
+            m = min(8, n - done)
+            check(eng.lib, eng.lib.grl_ae_train_step(eng.h, C.c_void_p(x.data_ptr()), m))
+            done += m
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize(device)
+    eng.be.stream.wait_stream(torch.cuda.current_stream(device))
+    times = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
+    dt = float(np.median(times))
+    out = {"metric": "auto-encoder train-steps/sec (64x64x1 depth, batch 128)", "value": round(args.steps / dt, 2),
+           "unit": "train-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SURVEY 8f-3: SimpleAutoEncoder fit step (encoders.py:40-50,70-136; config/encoder.yaml: batch 128, "
+                                  "lr 2e-4): encoder + decoder forward, MSE, backward, Keras-Adam; minibatches resident in HBM"},
+           "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"},
+           "losses": {"reconstruction_mse": round(float(eng.metrics()["policy_loss"]), 6)}}
+    if not args.no_profile:
+        prof = profile_pass(eng, go, 16)
+        out["roofline"] = roofline_of(prof, 16, dt / args.steps, "ae_train")
+    out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_ae()
+    eng.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps updates; value = median block")
+    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_nature", "bdq_per", "ae_train"])
+    ap.add_argument("--global-batch", type=int, default=None, help="fix the GLOBAL batch (strong scaling); per-GPU batch = G / N")
+    ap.add_argument("--replay", type=int, default=None)
+    ap.add_argument("--learn-iters", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-learn-loop", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if world > 1 and not args.workload.startswith("sac_"):
+        raise SystemExit("multi-GPU runs are defined for the SAC workloads")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.workload.startswith("sac_"):
+        out = run_sac(args, args.workload, world, rank, device)
+    elif args.workload == "bdq_per":
+        out = run_bdq(args, device)
+    else:
+        out = run_ae(args, device)
     if rank == 0:
-        value = world * args.steps / dt
-        out = {"metric": "SAC grad-steps/sec (64x64 depth, batch 256 per GPU)", "value": round(value, 2),
-               "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[1]: gripper_grasp.yaml --algo SAC, depth 64x64x2, batch 256/GPU, "
-                                      "A=5, layers [64,64], VecNormalize, %d-transition replay in HBM, device RNG" % args.replay,
-                          "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                          "global_steps_per_s": round(args.steps / dt, 2)},
-               "losses": {k: round(float(v), 6) for k, v in metrics.items()},
-               "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

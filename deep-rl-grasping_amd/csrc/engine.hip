@@ -237,6 +237,10 @@ struct grl_ctx {
   ~grl_ctx() {
     if (pin_in) hipHostFree(pin_in);
     if (pin_out) hipHostFree(pin_out);
+    for (int k = 0; k < 2; ++k) {
+      if (pin_stats[k]) hipHostFree(pin_stats[k]);
+      if (pin_stats_ev[k]) hipEventDestroy(pin_stats_ev[k]);
+    }
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
     for (auto e : lane_ev) hipEventDestroy(e);
@@ -908,6 +912,10 @@ struct grl_ctx {
   float *q_td = nullptr, *q_prio = nullptr, *q_aout = nullptr;
   // pinned host staging of the per-env-step calls (grl_act / grl_encode): pageable copies cost more than the kernels
   float *pin_in = nullptr, *pin_out = nullptr;
+  char* pin_stats[2] = {nullptr, nullptr};          // page-locked mirrors of the VecNormalize statistics span
+  hipEvent_t pin_stats_ev[2] = {nullptr, nullptr};
+  bool pin_stats_used[2] = {false, false};
+  int pin_stats_next = 0;
   size_t pin_in_n = 0, pin_out_n = 0;
   int act_rows = 0;   // rows the act-path output kernel covers (the launches are sized for act_batch: one static graph)
   int64_t q_online_off = 0, q_online_n = 0;
@@ -2748,7 +2756,28 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
   const grl_config& c = h->cfg;
   const double eps = c.norm_eps;
   const int nd = h->cnn ? h->F - 512 : 0;
-  std::vector<double> m(h->img_elems), s(h->img_elems), dm(std::max(nd, 1)), ds(std::max(nd, 1));
+  // The five statistic blocks sit one after the other in the state arena (alignment gaps in between are unused):
+  // they are written into a page-locked mirror of that span and leave as ONE asynchronous copy in stream order.
+  // Two mirrors alternate, each guarded by an event, so the host never waits for the GPU here (the learn loop calls
+  // this before every update: a stream synchronisation plus five blocking copies serialised host and device).
+  char* base = (char*)h->s_mean;
+  const size_t span = (size_t)((char*)h->s_ret + 8 - base);
+  if (!h->pin_stats[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipHostMalloc((void**)&h->pin_stats[k], span, 0));
+      memset(h->pin_stats[k], 0, span);
+      HIPCHK(hipEventCreateWithFlags(&h->pin_stats_ev[k], hipEventDisableTiming));
+    }
+  }
+  const int k = h->pin_stats_next;
+  h->pin_stats_next ^= 1;
+  if (h->pin_stats_used[k]) HIPCHK(hipEventSynchronize(h->pin_stats_ev[k]));   // the copy issued two calls ago
+  char* pm = h->pin_stats[k];
+  double* m = (double*)pm;
+  double* s = (double*)(pm + ((char*)h->s_std - base));
+  double* dm = (double*)(pm + ((char*)h->s_dmean - base));
+  double* ds = (double*)(pm + ((char*)h->s_dstd - base));
+  double* rs = (double*)(pm + ((char*)h->s_ret - base));
   if (h->cnn) {
     const int co = c.obs_channels, ci = h->C_img;
     for (int px = 0; px < h->hw * h->hw; ++px)
@@ -2756,22 +2785,17 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
         m[px * ci + ch] = mean[px * co + ch];
         s[px * ci + ch] = std::sqrt(var[px * co + ch] + eps);
       }
-    for (int k = 0; k < nd; ++k) {
-      dm[k] = mean[k * co + (co - 1)];
-      ds[k] = std::sqrt(var[k * co + (co - 1)] + eps);
+    for (int q = 0; q < nd; ++q) {
+      dm[q] = mean[q * co + (co - 1)];
+      ds[q] = std::sqrt(var[q * co + (co - 1)] + eps);
     }
   } else {
-    for (int k = 0; k < h->img_elems; ++k) { m[k] = mean[k]; s[k] = std::sqrt(var[k] + eps); }
+    for (int q = 0; q < h->img_elems; ++q) { m[q] = mean[q]; s[q] = std::sqrt(var[q] + eps); }
   }
-  const double rs = std::sqrt(ret_var + eps);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(h->s_mean, m.data(), m.size() * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->s_std, s.data(), s.size() * 8, hipMemcpyHostToDevice));
-  if (nd > 0) {
-    HIPCHK(hipMemcpy(h->s_dmean, dm.data(), nd * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->s_dstd, ds.data(), nd * 8, hipMemcpyHostToDevice));
-  }
-  HIPCHK(hipMemcpy(h->s_ret, &rs, 8, hipMemcpyHostToDevice));
+  *rs = std::sqrt(ret_var + eps);
+  HIPCHK(hipMemcpyAsync(base, pm, span, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipEventRecord(h->pin_stats_ev[k], h->stream));
+  h->pin_stats_used[k] = true;
   return GRL_OK;
 }
 

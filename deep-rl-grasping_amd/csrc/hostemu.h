@@ -56,6 +56,7 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t*) { return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t*, int) { return 0; }

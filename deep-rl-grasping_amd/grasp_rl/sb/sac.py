@@ -38,7 +38,7 @@ class SAC:
                  train_freq=1, batch_size=64, tau=0.005, ent_coef="auto", target_update_interval=1,
                  gradient_steps=1, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
                  tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False,
-                 seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None):
+                 seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None, replay_rgb_u8=False):
         if isinstance(policy, str):
             if policy not in _POLICY_NAMES:
                 raise ValueError("unknown policy %r" % policy)
@@ -60,6 +60,9 @@ class SAC:
         if overlap_env_step is None:
             overlap_env_step = os.environ.get("GRL_OVERLAP_ENV_STEP", "0") == "1"
         self.overlap_env_step = bool(overlap_env_step)
+        # Opt-in: RGB-D observations whose colour channels are integers in [0, 255] (the reference's camera: uint8,
+        # sensor.py:126-145) are stored with byte colours -- half the HBM per transition (grl_config.replay_rgb_u8).
+        self.replay_rgb_u8 = bool(replay_rgb_u8)
         self.num_timesteps = 0
         self.n_updates = 0
         self.env = None
@@ -135,7 +138,10 @@ class SAC:
             if not sp.has_finite_bounds(self.observation_space) or np.any(self.observation_space.low != 0) \
                     or np.any(self.observation_space.high != 255):
                 raise NotImplementedError("image observation spaces other than Box(0, 255) are not implemented")
-            cfg = _capi.make_config(extractor, obs_channels=obs_shape[2], n_direct=n_direct, **kw)
+            if self.replay_rgb_u8 and obs_shape[2] - (1 if n_direct > 0 else 0) != 4:
+                raise ValueError("replay_rgb_u8 needs RGB-D observations (R, G, B, depth [+ pad channel])")
+            cfg = _capi.make_config(extractor, obs_channels=obs_shape[2], n_direct=n_direct,
+                                    replay_rgb_u8=self.replay_rgb_u8, **kw)
         self._extractor = extractor
         self.engine = self._engine_factory(cfg, self.device)
         params = init_parameters(self.engine.table, seed=0 if self.seed is None else int(self.seed))
@@ -148,7 +154,11 @@ class SAC:
         vn = self._vec_normalize_env
         if vn is None or not self.engine.cfg.normalize:
             return
-        self.engine.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))
+        stamp = (id(vn.obs_rms), float(vn.obs_rms.count), id(vn.ret_rms), float(vn.ret_rms.count))
+        if stamp == getattr(self, "_norm_stamp", None):
+            return                      # frozen wrapper (training=False) or no env step since the last push
+        self._norm_stamp = stamp
+        self.engine.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))   # asynchronous, stream-ordered
 
     # ------------------------------------------------------------------ acting
     def _act(self, obs, deterministic):

@@ -63,3 +63,98 @@ def make_noise(n_steps, batch, act_dim, replay_size, seed=1):
     idx = rng.integers(0, replay_size, (n_steps, batch), dtype=np.int64)
     eps = rng.standard_normal((n_steps, batch, act_dim)).astype(np.float32)
     return idx, eps
+
+
+class SyntheticGraspEnv:
+    """Stand-in for the reference's PyBullet 'gripper-env-v0' (manipulation_main/gripperEnv/robot.py) for
+    throughput measurements of the learn loop: the same observation / action spaces (robot.py:207-228,
+    actuator.py:54-89) and the attributes sb_helper.py reads, observations drawn from the per-pixel statistics of
+    the reference's real runs, no physics.  One instance per worker process of a ``SubprocVecEnv``; it measures
+    what the HOST LOOP around the engine costs (pipes, VecNormalize, staging), not PyBullet."""
+
+    def __init__(self, kind="depth", episode_len=15, seed=0, act_dim=5, pool=64):
+        from .sb.spaces import Box
+        self.stats = load_obs_stats(kind)
+        C = self.stats["mean"].shape[-1]
+        self.kind = kind
+        self.observation_space = Box(0, 255, shape=(64, 64, C), dtype=np.float32)
+        self.action_space = Box(-1.0, 1.0, shape=(act_dim,), dtype=np.float32)
+        self.depth_obs, self.full_obs = (kind == "depth"), (kind == "rgbd")
+        self.episode_len, self.episode_step, self.episode_rewards = episode_len, 0, 0.0
+        self.history, self.sr_mean = [], 0.0
+        self.curriculum = type("Curriculum", (), {"_lambda": 0.0})()
+        rng = np.random.default_rng(seed)
+        m, v = self.stats["mean"], self.stats["var"]
+        self._pool = rng.normal(m, np.sqrt(v), (pool,) + m.shape).astype(np.float32)   # pre-drawn frames: the env is free
+        if kind == "rgbd":
+            self._pool[..., :3] = np.clip(np.round(self._pool[..., :3]), 0, 255)
+        self._pool[..., C - 1] = 0.0
+        self._pool[:, 0, 0, C - 1] = rng.uniform(0, 1, pool)
+        self._k = 0
+        self._rng = rng
+
+    def is_simplified(self):
+        return False
+
+    def _obs(self):
+        self._k = (self._k + 1) % self._pool.shape[0]
+        return self._pool[self._k]
+
+    def reset(self):
+        self.episode_step, self.episode_rewards = 0, 0.0
+        return self._obs()
+
+    def step(self, action):
+        self.episode_step += 1
+        r = float(-200.0 + 100.0 * np.tanh(np.sum(action)))
+        self.episode_rewards += r
+        done = self.episode_step >= self.episode_len
+        if done:
+            self.history.append(1)
+            self.sr_mean = 1.0
+        return self._obs(), r, done, {"is_success": done, "episode_step": self.episode_step,
+                                      "episode_rewards": self.episode_rewards, "status": 1}
+
+    def close(self):
+        pass
+
+
+def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0"):
+    """Env-steps / second and updates / second of ``SAC.learn`` (train_freq 1, gradient_steps 1: one update per
+    loop iteration, as sb_helper.py:120-128 configures it) with `n_envs` SyntheticGraspEnv worker processes behind
+    SubprocVecEnv + VecNormalize -- BASELINE configs[1]: "16 vectorised PyBullet envs feed a single GPU", with the
+    simulator replaced by a free one.  Returns a dict."""
+    import functools
+    import time
+    from .sb.callbacks import BaseCallback
+    from .sb.policies import AugmentedNatureCnn, SacCnnPolicy
+    from .sb.sac import SAC
+    from .sb.vec_env import SubprocVecEnv, VecNormalize
+
+    class Clock(BaseCallback):
+        def __init__(self, warm):
+            super().__init__()
+            self.warm, self.t0, self.u0 = warm, None, 0
+
+        def _on_step(self):
+            if self.n_calls == self.warm:
+                self.model.engine.synchronize()
+                self.t0, self.u0 = time.perf_counter(), self.model.n_updates
+            return True
+
+    venv = SubprocVecEnv([functools.partial(SyntheticGraspEnv, "depth", 15, s) for s in range(n_envs)])
+    try:
+        env = VecNormalize(venv, norm_obs=True, norm_reward=True, clip_obs=10.0)
+        model = SAC(SacCnnPolicy, env, policy_kwargs={"layers": [64, 64], "cnn_extractor": AugmentedNatureCnn(1)},
+                    buffer_size=buffer_size, batch_size=batch_size, learning_starts=max(batch_size, n_envs),
+                    overlap_env_step=overlap, device=device)
+        clock = Clock(warm)
+        model.learn(total_timesteps=n_envs * (warm + iterations), callback=clock)
+        model.engine.synchronize()
+        dt = time.perf_counter() - clock.t0
+        return {"n_envs": n_envs, "iterations": iterations, "overlap_env_step": bool(overlap),
+                "env_steps_per_s": round(n_envs * iterations / dt, 1),
+                "updates_per_s": round((model.n_updates - clock.u0) / dt, 1),
+                "ms_per_iteration": round(1e3 * dt / iterations, 3)}
+    finally:
+        venv.close()
