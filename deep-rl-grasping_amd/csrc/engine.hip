@@ -217,6 +217,10 @@ struct grl_ctx {
   bool use_lanes = false;
   LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
+  // data parallel, staged (grl_compute_grads_staged): stage 0 ends with the dense (fc + head) gradients final in the
+  // bucket, stage 1 is the convolution backward + its weight gradients + the loss reductions
+  std::vector<Op> ops_stage0, ops_stage1;
+  bool staged_ok = false;
   bool loss_in_reduce = false;
   float grad_scale = 1.f;   // read by the apply op
 
@@ -1371,6 +1375,8 @@ int grl_ctx::plan_sac() {
 
   }
   // =============================================================== backward through the two CNNs
+  bool fillers_on = false, only_vec_dense = false;
+  std::vector<IgemmProb> dense_affine, conv_all;   // dense / conv weight-gradient problems as first built (staged plan)
   std::vector<IgemmProb> wg, wgc[3];   // weight gradients: dense layers / conv layers 1..3
   std::vector<IgemmProb> bwd_pr[3];    // backward-data stages fc, conv3, conv2 (launched below, once their fillers are known)
   if (cnn) {
@@ -1462,6 +1468,9 @@ int grl_ctx::plan_sac() {
     // One launch for all weight gradients: the dense problems (x^T read with affine addresses) are re-expressed
     // with the table addressing of the convolution ones and appended to that launch -- one kernel boundary
     // less, and their short reductions (K = B) fill the tail of the long convolution tiles.
+    dense_affine = wg_ones;                                   // (kept for the staged data-parallel plan below)
+    for (int l = 2; l >= 0; --l) conv_all.insert(conv_all.end(), wgc[l].begin(), wgc[l].end());
+    only_vec_dense = wg_plain.empty() && wg_rest.empty();
     std::vector<IgemmProb> wg_merged;
     const char* nm = getenv("GRL_NO_WGRAD_MERGE");
     if (cnn && !use_lanes && !(nm && nm[0] == '1') && wg_plain.empty() && !wgc[0].empty() && v2_prob_ok(wgc[0][0], 2)) {
@@ -1487,6 +1496,7 @@ int grl_ctx::plan_sac() {
     // merged launch (747 tiles, heaviest first) was already the better packing.  Kept as a tested switch.
     const char* nfl = getenv("GRL_FILLERS");
     const bool fillers = cnn && !wg_merged.empty() && nfl && nfl[0] == '1';
+    fillers_on = fillers;
     if (cnn) {
       if (fillers) {
         add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0], "wgrad_dense", 2, wg_merged);
@@ -1538,6 +1548,27 @@ int grl_ctx::plan_sac() {
     }
     ops_grads.swap(sched);
   }
+  std::vector<Op> st0_ops, st1_ops;     // staged plan without its two reductions (added below)
+  {
+    // ---- staged gradient computation (data parallel): the dense weight gradients -- 90 % of the bucket's bytes --
+    // get a launch of their own right after the feature gradients, so that their all-reduce can travel while the
+    // convolution backward and the convolution weight gradients run (grasp_rl/parallel.py).  Costs two launches
+    // more than the single-exchange plan; same tiles, same arithmetic.
+    staged_ok = cnn && fused_heads && only_vec_dense && !dense_affine.empty() && !conv_all.empty() && !fillers_on && !use_lanes;
+    if (staged_ok) {
+      int cut = -1;
+      for (size_t k = 0; k < ops_grads.size(); ++k)
+        if (ops_grads[k].tag == "heads_dfeat") cut = (int)k;
+      staged_ok = cut >= 0;
+      if (staged_ok) {
+        for (int k = 0; k <= cut; ++k) st0_ops.push_back(ops_grads[k]);
+        add_launch(st0_ops, "wgrad_dense", 2, dense_affine, "", 0, {}, 0);
+        for (size_t k = cut + 1; k < ops_grads.size(); ++k)
+          if (ops_grads[k].tag.compare(0, 5, "wgrad") != 0) st1_ops.push_back(ops_grads[k]);
+        add_launch(st1_ops, "wgrad_conv", 2, conv_all, "", 0, {}, 0);
+      }
+    }
+  }
   {
     d_reduces = upload_vec(wk, reduces);
     std::vector<int2> rt;
@@ -1559,6 +1590,30 @@ int grl_ctx::plan_sac() {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss, aa, 0);
     };
     ops_grads.push_back(op);
+    if (staged_ok) {
+      // reductions of the two stages: convolution descriptors are those that land in the conv variables of a net
+      auto is_conv = [&](const ReduceDesc& r) {
+        for (int n = 0; n < 2; ++n)
+          if (r.dst >= grads + ex[n].w[0] && r.dst < grads + ex[n].fw) return true;
+        return false;
+      };
+      std::vector<int2> rt0, rt1;
+      for (size_t k = 0; k < reduces.size(); ++k)
+        for (int st0 = 0; st0 < reduces[k].n; st0 += 256) (is_conv(reduces[k]) ? rt1 : rt0).push_back(make_int2((int)k, st0));
+      int2* d_rt0 = upload_vec(wk, rt0);
+      int2* d_rt1 = upload_vec(wk, rt1);
+      const int n0 = (int)rt0.size(), n1 = (int)rt1.size();
+      Op r0; r0.tag = "reduce_dense";
+      r0.run = [dr, d_rt0, n0, la, aa](hipStream_t s) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(n0), dim3(256), 0, s, dr, d_rt0, n0, la, 0, aa, 0);
+      };
+      Op r1; r1.tag = "reduce_conv";
+      r1.run = [dr, d_rt1, n1, la, has_loss, aa](hipStream_t s) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(n1 + has_loss), dim3(256), 0, s, dr, d_rt1, n1, la, has_loss, aa, 0);
+      };
+      ops_stage0 = st0_ops; ops_stage0.push_back(r0);
+      ops_stage1 = st1_ops; ops_stage1.push_back(r1);
+    }
     // Full updates (no gradient exchange in between): every trainable element is the sum of one slab
     // column, so Adam + Polyak are applied where the sum is formed -- one launch and one pass over the
     // gradient bucket less.  log_ent_coef, whose gradient comes from the loss workgroup, is applied there.
@@ -2888,6 +2943,49 @@ int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps) {
   }
   HIPCHK(hipGetLastError());
   return GRL_OK;
+}
+
+int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const float* eps) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (stage != 0 && stage != 1) return fail(GRL_ERR_INVALID, "stage must be 0 or 1");
+  if (!h->staged_ok) {          // plans without a staged form: everything in stage 0, one bucket (grl_grad_ranges)
+    if (stage == 1) return GRL_OK;
+    return grl_compute_grads(h, idx, eps);
+  }
+  if (stage == 1) {
+    if (int e = h->run_seq("grads_stage1", {&h->ops_stage1})) return e;
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  if (idx) {
+    if (int e = stage_noise(h, idx, eps, 0)) return e;
+    if (int e = h->run_seq("grads_stage0_explicit", {&h->ops_gather, &h->ops_stage0})) return e;
+  } else {
+    if (int e = h->run_seq("grads_stage0_rng", {&h->ops_rng, &h->ops_stage0})) return e;
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_grad_ranges(grl_handle h, int bucket, int cap, int64_t* offsets, int64_t* numels) {
+  if (!h || !offsets || !numels) return fail(GRL_ERR_INVALID, "null argument");
+  if (bucket != 0 && bucket != 1) return fail(GRL_ERR_INVALID, "bucket must be 0 or 1");
+  std::vector<std::pair<int64_t, int64_t>> r;
+  if (!h->staged_ok) {
+    if (bucket == 0) r.push_back({0, h->n_train});
+  } else if (bucket == 0) {      // dense: fc + heads of the policy net, fc + vf / qf1 / qf2 heads of the value net
+    r.push_back({h->ex[0].fw, h->vf_off - h->ex[0].fw});
+    r.push_back({h->ex[1].fw, h->ent_off - h->ex[1].fw});
+  } else {                       // convolutions of both nets + the entropy coefficient (its gradient comes with the loss sums)
+    r.push_back({h->ex[0].w[0], h->ex[0].fw - h->ex[0].w[0]});
+    r.push_back({h->ex[1].w[0], h->ex[1].fw - h->ex[1].w[0]});
+    r.push_back({h->ent_off, h->n_train - h->ent_off});
+  }
+  if ((int)r.size() > cap) return fail(GRL_ERR_INVALID, "range buffer too small");
+  for (size_t k = 0; k < r.size(); ++k) { offsets[k] = r[k].first; numels[k] = r[k].second; }
+  return (int)r.size();
 }
 
 int grl_apply_grads(grl_handle h, float grad_scale) {

@@ -49,7 +49,7 @@ EXPORTS = [
     "grl_get_metrics", "grl_act", "grl_encoder_load", "grl_encode", "grl_debug_fetch",
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
     "grl_ae_train_step",
-    "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate",
+    "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate", "grl_compute_grads_staged", "grl_grad_ranges",
 ]
 
 
@@ -88,6 +88,8 @@ def load_library(path=None):
     lib.grl_train_step.argtypes = [vp, i32, vp, vp]
     lib.grl_compute_grads.argtypes = [vp, vp, vp]
     lib.grl_apply_grads.argtypes = [vp, C.c_float]
+    lib.grl_compute_grads_staged.argtypes = [vp, i32, vp, vp]
+    lib.grl_grad_ranges.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.grl_q_update_target.argtypes = [vp]
     lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_float, vp]
     lib.grl_ae_train_step.argtypes = [vp, vp, C.c_int]

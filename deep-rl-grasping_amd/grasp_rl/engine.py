@@ -64,6 +64,19 @@ class TorchCudaBackend:
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
 
+    def comm_context(self):
+        """Context whose work runs on a second stream, ordered AFTER everything enqueued on the engine stream so far
+        (the exchange of a finished gradient bucket, overlapping what the engine stream does next)."""
+        if getattr(self, "comm", None) is None:
+            self.comm = self.torch.cuda.Stream(device=self.device)
+        self.comm.wait_stream(self.stream)
+        return self.torch.cuda.stream(self.comm)
+
+    def comm_join(self):
+        """Engine stream waits for the second stream."""
+        if getattr(self, "comm", None) is not None:
+            self.stream.wait_stream(self.comm)
+
     def as_torch(self, t):
         return t
 
@@ -199,6 +212,21 @@ class SacEngine:
         pi, pe, keep = self._noise(idx, eps, 1)
         check(self.lib, self.lib.grl_compute_grads(self.h, pi, pe))
         self._keep = [keep]
+
+    def compute_grads_staged(self, stage, idx=None, eps=None):
+        """Stage 0 / 1 of the gradient computation (grl_compute_grads_staged): bucket 0 is final after stage 0."""
+        if stage == 0:
+            pi, pe, keep = self._noise(idx, eps, 1)
+            check(self.lib, self.lib.grl_compute_grads_staged(self.h, 0, pi, pe))
+            self._keep = [keep]
+        else:
+            check(self.lib, self.lib.grl_compute_grads_staged(self.h, 1, None, None))
+
+    def grad_ranges(self, bucket):
+        """[(offset, numel)] of gradient bucket 0 (final after stage 0) / 1 (final after stage 1)."""
+        offs, nums = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        n = check(self.lib, self.lib.grl_grad_ranges(self.h, bucket, 8, offs, nums))
+        return [(int(offs[k]), int(nums[k])) for k in range(n)]
 
     def apply_grads(self, grad_scale=1.0):
         check(self.lib, self.lib.grl_apply_grads(self.h, float(grad_scale)))

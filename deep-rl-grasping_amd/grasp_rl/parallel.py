@@ -1,11 +1,20 @@
 """Data-parallel SAC update: one process per GPU, per-GPU minibatch fixed, replay sharded by rank
 (each rank samples its own shard), parameters / Adam state / target net replicated.
 
-The only exchange of the path is one all-reduce(sum) of the flat fp32 gradient bucket per update
-(1 342 990 floats = 5.4 MB for depth SAC) issued on the engine's HIP stream through
-``torch.distributed`` (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests), followed by the
-Adam/Polyak kernel with grad_scale = 1/world.  All three SAC losses are batch means, so the mean of
-per-shard gradients equals the gradient of the global batch.
+The only exchange of the path is the all-reduce(sum) of the flat fp32 gradient bucket per update
+(1 342 990 floats = 5.4 MB for depth SAC) through ``torch.distributed`` (backend "nccl" = RCCL
+over xGMI; "gloo" in the CPU tests), followed by the Adam/Polyak kernel with grad_scale = 1/world.  All three
+SAC losses are batch means, so the mean of per-shard gradients equals the gradient of the global batch.
+
+Two schedules:
+  * one bucket: compute_grads -> all_reduce(whole bucket) on the engine stream -> apply_grads;
+  * two buckets, overlapped (default when the engine has a staged plan and world > 1): stage 0 of the gradient
+    computation ends with the fully-connected + head gradients (90 % of the bytes) final; their all-reduce is
+    issued on a second stream and travels over xGMI while stage 1 (convolution backward + convolution weight
+    gradients, ~40 % of the update) runs on the engine stream; the small convolution bucket follows, then
+    apply_grads.  xGMI is point-to-point: a ring all-reduce of 4.8 MB over 8 GPUs is bound by per-link
+    bandwidth and latency, comparable to the update itself -- hiding it is worth the two extra launches of the
+    staged plan (grl_compute_grads_staged, include/grl.h).
 """
 import numpy as np
 import torch
@@ -47,7 +56,7 @@ def share_running_stats(vec_normalize, group=None):
 
 
 class DataParallelSac:
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, overlap=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.eng = engine
@@ -55,6 +64,13 @@ class DataParallelSac:
         self.world = dist.get_world_size(group)
         self.scale = allreduce_mean_scale(self.world)
         self.bucket = engine.be.as_torch(engine.grad_tensor())
+        full = engine.be.as_torch(engine.grads)
+        ranges = [engine.grad_ranges(b) for b in (0, 1)]
+        self.staged = len(ranges[1]) > 0
+        if overlap is None:
+            overlap = self.staged and self.world > 1
+        self.overlap = bool(overlap) and self.staged
+        self.views = [[full[o:o + n] for o, n in r] for r in ranges]     # [bucket][range] views of the grads arena
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s parameters (state arena prefix)."""
@@ -62,12 +78,29 @@ class DataParallelSac:
         with self.eng.be.stream_context():
             dist.broadcast(p, src=src, group=self.group)
 
+    def _step_single(self, idx, eps):
+        self.eng.compute_grads(idx, eps)
+        with self.eng.be.stream_context():
+            allreduce_flat_(self.bucket, self.group)
+        self.eng.apply_grads(self.scale)
+
+    def _step_overlapped(self, idx, eps):
+        eng, be = self.eng, self.eng.be
+        eng.compute_grads_staged(0, idx, eps)
+        with be.comm_context():                      # second stream, ordered after stage 0
+            for v in self.views[0]:
+                allreduce_flat_(v, self.group)
+        eng.compute_grads_staged(1)                  # engine stream: runs while the dense bucket is exchanged
+        with be.stream_context():
+            for v in self.views[1]:
+                allreduce_flat_(v, self.group)
+        be.comm_join()
+        eng.apply_grads(self.scale)
+
     def train(self, n_steps=1, idx=None, eps=None):
+        step = self._step_overlapped if self.overlap else self._step_single
         for s in range(n_steps):
             if idx is None:
-                self.eng.compute_grads()
+                step(None, None)
             else:
-                self.eng.compute_grads(idx[s:s + 1], eps[s:s + 1])
-            with self.eng.be.stream_context():
-                allreduce_flat_(self.bucket, self.group)
-            self.eng.apply_grads(self.scale)
+                step(idx[s:s + 1], eps[s:s + 1])

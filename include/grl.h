@@ -174,6 +174,15 @@ int grl_q_update_target(grl_handle h);
 /* split form for data parallelism: grads -> (caller all-reduces the grads arena) -> apply */
 int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps);
 int grl_apply_grads(grl_handle h, float grad_scale);
+/* The same gradient computation in two stages, for overlapping the exchange with compute: after
+   stage 0 the ranges of bucket 0 (fully-connected + head layers: ~90 % of the bytes) are final in the grads arena,
+   after stage 1 those of bucket 1 (convolutions, entropy coefficient).  Typical use: stage 0 -> start all-reduce of
+   bucket 0 on a second stream -> stage 1 -> all-reduce bucket 1 -> grl_apply_grads.  idx / eps as for
+   grl_compute_grads (stage 0 only).  Handles without a staged plan (vector observations, DQN / BDQ) do everything
+   in stage 0 and report one range covering the whole bucket. */
+int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const float* eps);
+/* contiguous ranges (float offsets into the grads arena) of bucket 0 / 1; returns their number (<= cap) or < 0 */
+int grl_grad_ranges(grl_handle h, int bucket, int cap, int64_t* offsets, int64_t* numels);
 /* host: metrics of the most recent update (synchronises the stream) */
 int grl_get_metrics(grl_handle h, grl_metrics* out);
 

@@ -21,7 +21,8 @@ eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
 bucket = eng.be.as_torch(eng.grad_tensor())
 for name, fn in (("fused train_device(n)", lambda n: eng.train_device(n)),
                  ("split compute/apply", lambda n: [(eng.compute_grads(), eng.apply_grads(1.0)) for _ in range(n)]),
-                 ("split + bucket touch on the stream", lambda n: [(eng.compute_grads(), bucket.mul_(1.0), eng.apply_grads(1.0)) for _ in range(n)])):
+                 ("split + bucket touch on the stream", lambda n: [(eng.compute_grads(), bucket.mul_(1.0), eng.apply_grads(1.0)) for _ in range(n)]),
+                 ("staged (2 buckets) compute / apply", lambda n: [(eng.compute_grads_staged(0), eng.compute_grads_staged(1), eng.apply_grads(1.0)) for _ in range(n)])):
     with torch.cuda.stream(eng.be.stream):
         fn(50); eng.synchronize()
         t0 = time.perf_counter(); fn(500); eng.synchronize()

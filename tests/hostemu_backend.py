@@ -28,6 +28,13 @@ class NumpyHostBackend:
         import contextlib
         return contextlib.nullcontext()
 
+    def comm_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def comm_join(self):
+        pass
+
     def as_torch(self, a):
         import torch
         return torch.from_numpy(a)      # shares memory with the arena: collectives act in place

@@ -37,6 +37,11 @@ def _worker(rank, world, port, lib, out_dir):
     case["cfg"] = _shard_cfg(case["cfg"], B // world)
     eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=lib)
     dp = DataParallelSac(eng)
+    assert dp.staged and dp.overlap                # two-bucket schedule: dense ranges after stage 0, conv after stage 1
+    r0, r1 = eng.grad_ranges(0), eng.grad_ranges(1)
+    covered = sorted(r0 + r1)
+    assert covered[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(covered, covered[1:]))   # a partition ...
+    assert covered[-1][0] + covered[-1][1] == eng.n_trainable                                      # ... of the bucket
     if rank != 0:                                  # replicas must start identical: perturb, then broadcast
         P = eng.get_parameters()
         P["model/pi/fc0/bias:0"] = P["model/pi/fc0/bias:0"] + 1.0
@@ -45,6 +50,13 @@ def _worker(rank, world, port, lib, out_dir):
     lo, hi = rank * (B // world), (rank + 1) * (B // world)
     dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
     P = eng.get_parameters()
+    # the single-bucket schedule (one all-reduce after the whole gradient computation) gives the same bits
+    eng1 = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=lib)
+    dp1 = DataParallelSac(eng1, overlap=False)
+    dp1.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+    P1 = eng1.get_parameters()
+    for k in P:
+        assert np.array_equal(P[k], P1[k]), "staged and single-bucket schedules differ: " + k
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
     dist.destroy_process_group()
 

@@ -32,6 +32,7 @@ def _worker(rank, world, port, out_dir):
     case["cfg"] = cfg
     eng = pu.engine_setup(case)
     dp = DataParallelSac(eng)
+    assert dp.staged and dp.overlap                # two-bucket schedule: the dense bucket travels on a second stream
     if rank != 0:                                  # replicas must start identical: perturb, then broadcast
         P = eng.get_parameters()
         P["model/pi/fc0/bias:0"] = P["model/pi/fc0/bias:0"] + 1.0
@@ -64,3 +65,70 @@ def test_two_ranks_on_one_device_equal_single_engine(tmp_path):
         assert np.array_equal(a, b), "replicas diverged: " + k
         d = np.abs(a.astype(np.float64) - v)
         assert d.max() <= 0.3 * lr * STEPS + 1e-7 and d.mean() <= 0.02 * lr * STEPS + 1e-9, (k, d.max(), d.mean())
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from grasp_rl.parallel import DataParallelSac
+    from grasp_rl.engine import SacEngine
+    case = _case()
+    cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+    cfg.batch_size = B // world
+    case["cfg"] = cfg
+    outs = []
+    for overlap in (True, False):                  # both schedules, over RCCL on the engines' own streams
+        eng = SacEngine(case["cfg"], device="cuda:%d" % rank)
+        eng.set_parameters(case["params"])
+        st = case["stats"]
+        eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
+        tr = case["tr"]
+        eng.replay_add(tr["obs"], tr["act"], tr["rew"], tr["next_obs"], tr["done"])
+        dp = DataParallelSac(eng, overlap=overlap)
+        assert dp.overlap == overlap
+        lo, hi = rank * (B // world), (rank + 1) * (B // world)
+        dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+        eng.synchronize()
+        outs.append(eng.get_parameters())
+        eng.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), "schedules differ: " + k
+    np.savez(os.path.join(out_dir, "rccl%d.npz" % rank), **{k.replace("/", "|"): v for k, v in outs[0].items()})
+    dist.destroy_process_group()
+
+
+def _check_against_single(tmp_path, world, prefix):
+    case = _case()
+    single = pu.engine_setup(case)
+    single.train(STEPS, case["idx"], case["eps"])
+    ref = single.get_parameters()
+    single.close()
+    parts = [np.load(os.path.join(str(tmp_path), "%s%d.npz" % (prefix, r))) for r in range(world)]
+    lr = case["spec"].lr
+    for k, v in ref.items():
+        for p in parts[1:]:
+            assert np.array_equal(parts[0][k.replace("/", "|")], p[k.replace("/", "|")]), "replicas diverged: " + k
+        d = np.abs(parts[0][k.replace("/", "|")].astype(np.float64) - v)
+        assert d.max() <= 0.3 * lr * STEPS + 1e-7 and d.mean() <= 0.02 * lr * STEPS + 1e-9, (k, d.max(), d.mean())
+
+
+def test_rccl_single_rank_group_runs_both_schedules(tmp_path):
+    """backend "nccl" (= RCCL) with a one-rank group on this box's GPU: the collectives are issued on the engine /
+    exchange streams exactly as on N GPUs; result must equal the plain single-engine update."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    _check_against_single(tmp_path, 1, "rccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_rccl_two_gpus_equal_single_engine(tmp_path):
+    """Two ranks on two GPUs, gradients all-reduced by RCCL (two-bucket overlapped and single-bucket schedules)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _check_against_single(tmp_path, 2, "rccl")
