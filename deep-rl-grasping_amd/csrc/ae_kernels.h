@@ -76,22 +76,7 @@ __device__ __forceinline__ long mse_pad_index(long i) {   // i over [N, 64, 64] 
   return n * 4900 + ((r >> 6) + 3) * 70 + (r & 63) + 3;
 }
 #ifdef GRL_HOSTEMU
-inline void mse_kernel(MseArgs a) {
-  if (threadIdx.x != 0) return;
-  const long per = (a.n_total + gridDim.x - 1) / gridDim.x;
-  const long i0 = (long)blockIdx.x * per, i1 = std::min(a.n_total, i0 + per);
-  float s = 0.f, sg = 0.f;
-  for (long i = i0; i < i1; ++i) {
-    const float d = a.out[i] - a.x[i];
-    const float g = 2.f * d / (float)a.n_total;
-    a.g_out[i] = g;
-    if (a.g_pad) a.g_pad[mse_pad_index(i)] = g;
-    s += d * d;
-    sg += g;
-  }
-  a.partial[blockIdx.x] = s;
-  a.partial_g[blockIdx.x] = sg;
-}
+#include "ae_kernels_ref1.h"   // tests/hostemu: the emulation build only
 #else
 __global__ __launch_bounds__(256) void mse_kernel(MseArgs a) {
   __shared__ float red[256], redg[256];

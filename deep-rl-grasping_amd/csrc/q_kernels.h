@@ -29,36 +29,7 @@ struct QFusedArgs {
 };
 
 #ifdef GRL_HOSTEMU
-inline void q_fwd_fused_kernel(QFusedArgs a) {
-  if (threadIdx.x != 0) return;
-  const HtHead& h = a.fwd[blockIdx.y * (a.D + 1) + blockIdx.z];
-  for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row)
-    ht_ref_fwd_head(h, row, nullptr);
-}
-inline void q_bwd_towers_kernel(QFusedArgs a) {
-  if (threadIdx.x != 0) return;
-  const int tw = blockIdx.y;
-  const HtHead& h = a.bwd_tw[tw];
-  for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row) {
-    float dv[2 * HT_MAXA];
-    if (tw < a.D)
-      for (int o = 0; o < a.nb; ++o) dv[o] = a.d_adv[((long)row * a.D + tw) * a.nb + o];
-    else dv[0] = a.d_v[row];
-    ht_ref_bwd_head(h, row, dv, h.n_xa ? a.dh_part + ((long)tw * a.B + row) * a.Ht : nullptr);
-  }
-}
-inline void q_bwd_trunk_kernel(QFusedArgs a) {
-  if (threadIdx.x != 0) return;
-  for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row) {
-    float dz[HT_MAXW];
-    for (int n = 0; n < a.Ht; ++n) {
-      float s = 0.f;
-      for (int p = 0; p <= a.D; ++p) s += a.dh_part[((long)p * a.B + row) * a.Ht + n];
-      dz[n] = s * a.trunk_scale;
-    }
-    ht_ref_bwd_head(*a.bwd_tr, row, nullptr, nullptr, dz);
-  }
-}
+#include "q_kernels_ref1.h"   // tests/hostemu: the emulation build only
 #else
 __global__ __launch_bounds__(256) void q_fwd_fused_kernel(QFusedArgs a) {
   __shared__ HtLds s;

@@ -100,9 +100,19 @@ class DummyVecEnv(VecEnv):
 
 
 def _subproc_worker(remote, parent_remote, env_fn_pickled):
-    """Worker loop of SubprocVecEnv: owns ONE environment, answers commands over a pipe."""
+    """Worker loop of SubprocVecEnv: owns ONE environment, answers commands over a pipe.  After an "shm" command the
+    observations are written into this worker's slot of a shared-memory block and the pipe only carries `None` in
+    their place (a 64x64x5 float32 observation is 80 KB: pickling it through a pipe costs more than the rest of the
+    exchange)."""
     parent_remote.close()
     env = pickle.loads(env_fn_pickled)()
+    shm, slot = None, None
+
+    def out(obs):
+        if slot is None:
+            return obs
+        slot[...] = obs
+        return None
     try:
         while True:
             cmd, data = remote.recv()
@@ -110,11 +120,17 @@ def _subproc_worker(remote, parent_remote, env_fn_pickled):
                 obs, rew, done, info = env.step(data)
                 if done:
                     info = dict(info)
-                    info["terminal_observation"] = obs
+                    info["terminal_observation"] = np.array(obs, copy=True)
                     obs = env.reset()
-                remote.send((obs, rew, done, info))
+                remote.send((out(obs), rew, done, info))
             elif cmd == "reset":
-                remote.send(env.reset())
+                remote.send(out(env.reset()))
+            elif cmd == "shm":
+                from multiprocessing import shared_memory
+                name, index, shape, dtype = data
+                shm = shared_memory.SharedMemory(name=name)
+                slot = np.ndarray(shape, dtype=dtype, buffer=shm.buf, offset=index * int(np.prod(shape)) * np.dtype(dtype).itemsize)
+                remote.send(True)
             elif cmd == "seed":
                 remote.send(env.seed(data) if hasattr(env, "seed") else None)
             elif cmd == "spaces":
@@ -131,6 +147,9 @@ def _subproc_worker(remote, parent_remote, env_fn_pickled):
             elif cmd == "close":
                 if hasattr(env, "close"):
                     env.close()
+                slot = None
+                if shm is not None:
+                    shm.close()
                 remote.close()
                 break
             else:
@@ -147,7 +166,7 @@ class SubprocVecEnv(VecEnv):
     observation in ``info['terminal_observation']``.  ``start_method``: 'forkserver' / 'spawn' keep the
     workers free of this process's HIP context ('fork' after HIP initialisation is unsafe)."""
 
-    def __init__(self, env_fns, start_method=None):
+    def __init__(self, env_fns, start_method=None, shared_memory=True):
         import multiprocessing as mp
         if start_method is None:
             start_method = "forkserver" if "forkserver" in mp.get_all_start_methods() else "spawn"
@@ -169,6 +188,24 @@ class SubprocVecEnv(VecEnv):
         obs_space, act_space = self.remotes[0].recv()
         super().__init__(len(env_fns), obs_space, act_space)
         self.buf_infos = [{} for _ in range(self.num_envs)]
+        # observations through shared memory (array observation spaces): one block, one slot per worker
+        self._shm, self._shm_arr = None, None
+        shape = tuple(getattr(obs_space, "shape", ()) or ())
+        if shared_memory and shape:
+            from multiprocessing import shared_memory as _sm
+            dtype = np.dtype(getattr(obs_space, "dtype", np.float32))
+            self._shm = _sm.SharedMemory(create=True, size=max(1, self.num_envs * int(np.prod(shape)) * dtype.itemsize))
+            self._shm_arr = np.ndarray((self.num_envs,) + shape, dtype=dtype, buffer=self._shm.buf)
+            for i, remote in enumerate(self.remotes):
+                remote.send(("shm", (self._shm.name, i, shape, dtype.str)))
+            for remote in self.remotes:
+                remote.recv()
+
+    def _stack_obs(self, obs):
+        dtype = getattr(self.observation_space, "dtype", np.float32)
+        if self._shm_arr is not None:
+            return np.array(self._shm_arr, dtype=dtype, copy=True)     # the next step overwrites the slots
+        return np.stack(obs).astype(dtype)
 
     def step_async(self, actions):
         for remote, action in zip(self.remotes, actions):
@@ -180,14 +217,13 @@ class SubprocVecEnv(VecEnv):
         self.waiting = False
         obs, rews, dones, infos = zip(*results)
         self.buf_infos = list(infos)
-        return (np.stack(obs).astype(getattr(self.observation_space, "dtype", np.float32)),
-                np.asarray(rews, dtype=np.float32), np.asarray(dones, dtype=bool), list(infos))
+        return (self._stack_obs(obs), np.asarray(rews, dtype=np.float32), np.asarray(dones, dtype=bool), list(infos))
 
     def reset(self):
         for remote in self.remotes:
             remote.send(("reset", None))
         obs = [remote.recv() for remote in self.remotes]
-        return np.stack(obs).astype(getattr(self.observation_space, "dtype", np.float32))
+        return self._stack_obs(obs)
 
     def seed(self, seed=None):
         for i, remote in enumerate(self.remotes):
@@ -204,6 +240,11 @@ class SubprocVecEnv(VecEnv):
             remote.send(("close", None))
         for proc in self.processes:
             proc.join()
+        if self._shm is not None:
+            self._shm_arr = None
+            self._shm.close()
+            self._shm.unlink()
+            self._shm = None
         self.closed = True
 
     def render(self, *a, **k):
@@ -306,9 +347,11 @@ class VecNormalize(VecEnvWrapper):
     def step_wait(self):
         obs, rews, dones, infos = self.venv.step_wait()
         self.old_obs, self.old_rews = obs, rews
-        if self.training:
-            self.obs_rms.update(obs)
-        obs = self.normalize_obs(obs)
+        if self.training or self.norm_obs:
+            obs64 = np.asarray(obs, np.float64)        # one float64 copy shared by the statistics update and the normalisation
+            if self.training:
+                self.obs_rms.update(obs64)
+            obs = self.normalize_obs(obs64)
         if self.training:
             self.ret = self.ret * self.gamma + rews
             self.ret_rms.update(self.ret)
@@ -326,8 +369,9 @@ class VecNormalize(VecEnvWrapper):
 
     def normalize_obs(self, obs):
         if self.norm_obs:
-            obs = np.clip((obs - self.obs_rms.mean) / np.sqrt(self.obs_rms.var + self.epsilon),
-                          -self.clip_obs, self.clip_obs)
+            x = obs - self.obs_rms.mean                 # float64 (the statistics are): same arithmetic as
+            x /= np.sqrt(self.obs_rms.var + self.epsilon)   # clip((obs - mean) / sqrt(var + eps), -c, c), in place
+            obs = np.clip(x, -self.clip_obs, self.clip_obs, out=x)
         return obs
 
     def normalize_reward(self, reward):
