@@ -153,6 +153,54 @@ def main():
             pins["ae_encoding_abs_mean"] = float(np.abs(z).mean())
     pins["b5_autoencoder_mse"] = table
 
+    # ---------------------------------------------------------------- DQN / BDQ zips (B.6: relationships the fork's
+    # un-vendored source leaves as the only evidence)
+    from oracle import dqn as od
+    q = {}
+    for tag, rel in (("bdq_33_big_final", "BDQ_33pads_big/BDQ_33_big.zip"), ("bdq_33_big_best", "BDQ_33pads_big/best_model/best_model.zip"),
+                     ("bdq_8pads_final", "BDQ_8pads/BDQ_simple_8pads.zip"), ("dqn_4pads_final", "DQN_4pads/DQN_simple_4pads.zip")):
+        data, params = fx.load_sb_zip(REF + "/trained_models/" + rel)
+        d = max(float(np.abs(params[k] - params[k.replace("/target_q_func", "")]).max()) for k in params if "/target_q_func/" in k)
+        eps_name = [k for k in params if k.endswith("eps:0")][0]
+        q[tag] = {"source": "trained_models/" + rel, "max_abs_target_minus_online": d,
+                  "target_network_update_freq": data["target_network_update_freq"], "learning_rate": data["learning_rate"],
+                  "stored_eps": float(params[eps_name]), "exploration_final_eps": data["exploration_final_eps"]}
+        # (1) a run's final zip is written right after a target update (total_timesteps is a multiple of the update
+        #     period): target == online BIT FOR BIT -- only a hard copy can do that (Polyak averaging never reaches it);
+        #     the mid-interval best_model zip differs by at most (steps since the copy) x (Adam step <= lr).
+        if tag.endswith("_final"):
+            assert d == 0.0, (tag, d)
+        else:
+            assert 0.0 < d <= data["target_network_update_freq"] * data["learning_rate"], (tag, d)
+        # (2) the `eps` variable holds the value of the exploration schedule at save time (= its final value)
+        assert abs(float(params[eps_name]) - data["exploration_final_eps"]) < 1e-7, tag
+    pins["b6_q_zip_relationships"] = q
+    print("B.6", json.dumps(q, indent=1))
+    # golden vectors: the shipped big BDQ network (5 branches x 33 bins, [[512,256],[128],[128]]-style towers as stored)
+    # on the two real 101-d observations of the SAC-encoder run (the only real feature vectors the reference ships)
+    data, params = fx.load_sb_zip(REF + "/trained_models/BDQ_33pads_big/best_model/best_model.zip")
+    shapes = {k: tuple(v.shape) for k, v in params.items()}
+    common = [shapes["bdq/model/common_net/fully_connected%s/weights:0" % ("" if i == 0 else "_%d" % i)][1]
+              for i in range(8) if "bdq/model/common_net/fully_connected%s/weights:0" % ("" if i == 0 else "_%d" % i) in shapes]
+    n_av = len([k for k in shapes if k.startswith("bdq/model/action_value/") and k.endswith("weights:0")])
+    bins = shapes["bdq/model/action_value/fully_connected_1/weights:0"][1]
+    branch_h = shapes["bdq/model/action_value/fully_connected/weights:0"][1]
+    value_h = shapes["bdq/model/state_value/fully_connected/weights:0"][1]
+    D = n_av // 2
+    obs_dim = shapes["bdq/model/common_net/fully_connected/weights:0"][0]
+    spec_q = od.bdq_spec(obs_dim, D, bins, [common, [branch_h], [value_h]])
+    assert list(od.param_shapes(spec_q).keys()) == list(params.keys())
+    np.savez_compressed(GOLD + "/bdq_33_big_best_model.npz", **{k: v for k, v in params.items()})
+    orc_q = od.QOracle(spec_q, params)
+    obs_q = real_obs[:, :obs_dim].astype(np.float32)
+    qv = orc_q.q_values(obs_q)
+    pins["bdq_real_obs"] = {"spec": {"obs_dim": obs_dim, "branches": D, "bins": bins, "common": common, "branch": branch_h, "value": value_h},
+                            "q_values": np.asarray(qv).tolist(), "greedy_bins": np.asarray(qv).argmax(axis=2).tolist()}
+    # dueling aggregation per branch (Q_d = V + A_d - mean_a A_d): the branch means of Q all equal V, i.e. each other
+    bm = np.asarray(qv).mean(axis=2)
+    assert np.allclose(bm, bm[:, :1], atol=1e-4), bm
+    pins["bdq_real_obs"]["branch_means_of_Q"] = bm.tolist()
+
     with open(GOLD + "/oracle_pins.json", "w") as f:
         json.dump(pins, f, indent=1, sort_keys=True)
     print("wrote", GOLD)

@@ -42,3 +42,30 @@ def test_prioritised_replay_gpu():
     qu.per_check()
     qu.per_check(cap=5000, n_store=5000, B=64, n_steps=3, seed=11)
     qu.per_check(cap=20000, n_store=17000, B=64, n_steps=4, seed=5, case_name="bdq_baseline_config3")
+
+
+def test_shipped_bdq_weights_on_real_observations():
+    """Golden vectors: the reference's trained BDQ network (trained_models/BDQ_33pads_big/best_model: 100-d
+    observations, 3 branches x 33 bins, layers [[512,256],[128],[128]]) on the two real auto-encoder feature vectors
+    the reference ships (tests/golden/oracle_pins.json, made by scripts/make_golden.py): dueling Q-values and greedy bins."""
+    import json
+    import os
+    import numpy as np
+    import parity_util as pu
+    from grasp_rl import _capi
+    from grasp_rl.engine import QEngine
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    pins = json.load(open(os.path.join(gold, "oracle_pins.json")))["bdq_real_obs"]
+    z = np.load(os.path.join(gold, "bdq_33_big_best_model.npz"))
+    sp = pins["spec"]
+    cfg = _capi.make_q_config("bdq", sp["obs_dim"], sp["branches"], sp["bins"], common=tuple(sp["common"]),
+                              branch_hidden=(sp["branch"],), value_hidden=(sp["value"],), batch_size=4, act_batch=2,
+                              replay_capacity=8)
+    eng = QEngine(cfg)
+    eng.set_parameters({k: z[k] for k in z.files})
+    obs = np.load(os.path.join(gold, "vecnorm_encoder.npz"))["real_obs"][:, :sp["obs_dim"]].astype(np.float32)
+    q = eng.q_values(obs)
+    pu.close(q, np.asarray(pins["q_values"], np.float32), atol=2e-5, rtol=2e-4, what="golden BDQ Q-values")
+    assert np.array_equal(q.argmax(axis=2), np.asarray(pins["greedy_bins"]))
+    assert np.allclose(q.mean(axis=2), q.mean(axis=2)[:, :1], atol=1e-4)       # every branch mean equals V (dueling aggregation)
+    eng.close()

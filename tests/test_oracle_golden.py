@@ -114,3 +114,36 @@ def test_losses_and_update_order_on_tiny_case():
     tau = spec.tau
     for t, s in osac.polyak_pairs(spec):               # target uses the POST-update source
         assert np.allclose(orc.P[t], (1 - tau) * before[t] + tau * orc.P[s], atol=1e-7)
+
+
+def test_q_zip_relationships_pin_hard_copy_and_eps_variable():
+    """SURVEY.md B.6 (made by scripts/make_golden.py from the shipped DQN / BDQ zips): a run's FINAL zip has
+    target == online bit for bit (written right after a target update: only a hard copy can do that), the
+    mid-interval best_model zip differs by less than (update period) x (Adam step), and the `eps` variable holds the
+    schedule's final value.  oracle/dqn.py restates exactly that: update_target() copies, nothing else touches the
+    target network."""
+    import json
+    import os
+    from oracle import dqn as od
+    pins = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_pins.json")))
+    rel = pins["b6_q_zip_relationships"]
+    for tag, r in rel.items():
+        if tag.endswith("_final"):
+            assert r["max_abs_target_minus_online"] == 0.0, tag
+        else:
+            assert 0.0 < r["max_abs_target_minus_online"] <= r["target_network_update_freq"] * r["learning_rate"], tag
+        assert abs(r["stored_eps"] - r["exploration_final_eps"]) < 1e-7, tag
+    # the oracle behaves the same way: after update_target the two networks are identical arrays, a training step
+    # moves only the online one
+    spec = od.bdq_spec(12, 2, 5, [[8], [6], [6]])
+    orc = od.QOracle(spec, od.init_params(spec, 0))
+    rng = np.random.default_rng(0)
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    batch = {"obs": f(rng.normal(size=(4, 12))), "next_obs": f(rng.normal(size=(4, 12))), "act": f(rng.integers(0, 5, (4, 2))),
+             "rew": f(rng.normal(size=4)), "done": f(np.zeros(4))}
+    tgt0 = {k: v.copy() for k, v in orc.P.items() if "/target_q_func/" in k}
+    orc.step(batch, np.ones(4, np.float32))
+    assert all(np.array_equal(orc.P[k], v) for k, v in tgt0.items())                       # untouched by the step
+    assert any(not np.array_equal(orc.P[k], orc.P[k.replace("/target_q_func", "")]) for k in tgt0 if orc.P[k].size > 1)
+    orc.update_target()
+    assert all(np.array_equal(orc.P[k], orc.P[k.replace("/target_q_func", "")]) for k in tgt0)

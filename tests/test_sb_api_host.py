@@ -202,6 +202,10 @@ def run_q_sequence(tmp_path, make_model, make_env, n_steps=40):
     assert abs(float(p1[eps_name]) - model.exploration_final_eps) < 1e-6           # schedule finished
     tgt = [k for k in p1 if "target_q_func" in k and k.endswith("weights:0")][0]
     assert not np.array_equal(p0[tgt], p1[tgt])                                      # hard update happened
+    if n_steps % model.target_network_update_freq == 0:
+        # like the reference's final zips (tests/golden/oracle_pins.json: b6_q_zip_relationships): the run ends right
+        # after a target update, so target == online bit for bit
+        assert all(np.array_equal(p1[k], p1[k.replace("/target_q_func", "")]) for k in p1 if "/target_q_func/" in k)
     path = os.path.join(str(tmp_path), "q_model")
     model.save(path)
     agent = type(model).load(path)
