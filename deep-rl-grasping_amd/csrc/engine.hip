@@ -1199,8 +1199,10 @@ int grl_ctx::plan_sac() {
       const HeadsFusedArgs* d_ha = upload_vec(wk, std::vector<HeadsFusedArgs>{ha});
       const int nblk = (B + HT_RB - 1) / HT_RB;
       Op op; op.tag = "heads";
-      op.run = [d_ha, nblk](hipStream_t s) {
-        hipLaunchKernelGGL((heads_fused_kernel<64>), dim3(nblk, 4), dim3(256), 0, s, d_ha);
+      const bool fast = L == 2 && hid[0] == 64 && hid[1] == 64 && B % HT_RB == 0;   // the reference's layers [64, 64]
+      op.run = [d_ha, nblk, fast](hipStream_t s) {
+        if (fast) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, d_ha);
+        else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, d_ha);
       };
       ops_grads.push_back(op);
     } else {

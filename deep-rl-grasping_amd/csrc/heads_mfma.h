@@ -103,7 +103,10 @@ struct HmLds {
 // in has 6 bits, beyond it the wave stalls at issue and a wait for the oldest load drains younger ones too --
 // and (4) no global store is issued before the end of the chain: gfx950 counts stores and loads on the same
 // in-order counter, so a wait for a young load is also a wait for the acknowledgement of every older store.
-template <int W>
+// FAST: the reference's shape -- two hidden layers of 64 units in every head (gripper_grasp.yaml:81 `layers: [64, 64]`)
+// and a batch that is a multiple of 16.  The kernel is bound by instruction issue, and with the widths, the layer
+// count and the row predicate known at compile time most of its address / predicate arithmetic folds away.
+template <int W, bool FAST>
 __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* __restrict__ ap) {
   static_assert(W == HM_W, "layer widths above 64 run on heads_kernels.h");
   constexpr int K4 = HM_K4, LD = HM_LD;
@@ -127,6 +130,9 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
   const HeadsFusedArgs& a = s.args;
   const int row0 = blockIdx.x * HT_RB, type = blockIdx.y, B = a.B, A = a.A;
   const float invB = 1.f / (float)B;
+  auto LY = [](int v) { return FAST ? 2 : v; };          // hidden layers of a head
+  auto WD = [](int v) { return FAST ? (int)HM_W : v; };   // a hidden width
+  auto ROW = [&](int r) { return FAST ? true : (row0 + r) < B; };   // row r of this block exists
   int stamp_k = 0;
   auto stamp = [&]() {
     if (a.stamps && blockIdx.x == 0 && t == 0 && stamp_k < 32) a.stamps[type * 32 + stamp_k] = wall_clock64();
@@ -200,28 +206,28 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
   //  together and waited for once -- read where they are used, each one is a ds_read + wait in a dependent chain)
   auto prefetch_fwd = [&](const HtHead& h_, HmFw& f) {
     const HtHead h = h_;
-    f.b0 = n < h.H0 ? HM_G(h.b0)[n] : 0.f;
-    if (h.n_xa > 0) load_b(f.a0, HmB{h.w0a, nullptr, h.n_xa, h.H0, h.H0, 1, INT_MAX, 0, nullptr, nullptr});
+    f.b0 = n < WD(h.H0) ? HM_G(h.b0)[n] : 0.f;
+    if (h.n_xa > 0) load_b(f.a0, HmB{h.w0a, nullptr, h.n_xa, WD(h.H0), WD(h.H0), 1, INT_MAX, 0, nullptr, nullptr});
 #pragma unroll
     for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly)
-      if (ly < h.L) {
-        load_b(f.hid[ly], HmB{h.w[ly], nullptr, h.hid[ly - 1], h.hid[ly], h.hid[ly], 1, INT_MAX, 0, nullptr, nullptr});
-        f.bh[ly] = n < h.hid[ly] ? HM_G(h.b[ly])[n] : 0.f;
+      if (ly < LY(h.L)) {
+        load_b(f.hid[ly], HmB{h.w[ly], nullptr, WD(h.hid[ly - 1]), WD(h.hid[ly]), WD(h.hid[ly]), 1, INT_MAX, 0, nullptr, nullptr});
+        f.bh[ly] = n < WD(h.hid[ly]) ? HM_G(h.b[ly])[n] : 0.f;
       }
     const int NO = h.n_out * h.out_dim;
-    int HLf = h.hid[0];                       // width of the last hidden layer (static indices: no scratch copy)
+    int HLf = WD(h.hid[0]);                       // width of the last hidden layer (static indices: no scratch copy)
 #pragma unroll
-    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HLf = (ly == h.L - 1) ? h.hid[ly] : HLf;
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HLf = (ly == LY(h.L) - 1) ? WD(h.hid[ly]) : HLf;
     load_b(f.out, HmB{h.ow[0], h.n_out > 1 ? h.ow[1] : nullptr, HLf, NO, h.out_dim, 1,
                       h.n_out > 1 ? h.out_dim : INT_MAX, 0, nullptr, nullptr});
     f.bo = load_bias(h.ob[0], h.n_out > 1 ? h.ob[1] : h.ob[0], h.n_out > 1 ? h.out_dim : INT_MAX, NO);
   };
   auto prefetch_bwd = [&](const HtHead& h_, HmBw& g, bool rank1, bool want_da) {
     const HtHead h = h_;
-    const int L = h.L;
-    int HL = h.hid[0];
+    const int L = LY(h.L);
+    int HL = WD(h.hid[0]);
 #pragma unroll
-    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HL = (ly == L - 1) ? h.hid[ly] : HL;
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HL = (ly == L - 1) ? WD(h.hid[ly]) : HL;
     g.ow = 0.f;
     if (rank1) g.ow = n < HL ? HM_G(h.ow[0])[n] : 0.f;
     else   // element (k, n) = ow[k / out_dim][n * out_dim + k % out_dim]
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
     for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly)
       if (ly < L)   // g_{ly-1} = g_ly . W_ly^T: element (k, m) = w[ly][m * hid[ly] + k]
-        load_b(g.hid[ly], HmB{h.w[ly], nullptr, h.hid[ly], h.hid[ly - 1], 1, h.hid[ly], INT_MAX, 0, nullptr, nullptr});
-    if (want_da) load_b(g.da, HmB{h.w0a, nullptr, h.H0, h.n_xa, 1, h.H0, INT_MAX, 0, nullptr, nullptr});
+        load_b(g.hid[ly], HmB{h.w[ly], nullptr, WD(h.hid[ly]), WD(h.hid[ly - 1]), 1, WD(h.hid[ly]), INT_MAX, 0, nullptr, nullptr});
+    if (want_da) load_b(g.da, HmB{h.w0a, nullptr, WD(h.H0), h.n_xa, 1, WD(h.H0), INT_MAX, 0, nullptr, nullptr});
   };
 
   int cur = 0;   // s.z[cur] holds the input of the next MFMA stage
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
   // feature partial sums of the rows (already added up); the action part of the input is s.pi (an MFMA stage of its
   // own: K = n_xa).  Outputs land in s.o[row][k*out_dim+o].  No global stores (flush at the end of the kernel).
   auto fwd_head = [&](const HtHead& h_, const HmFw& f, const float (&u0)[4], float (&zsv)[GRL_MAX_LAYERS][4]) {
-    struct { int L, H0, n_xa, no, hid[GRL_MAX_LAYERS]; } h = {h_.L, h_.H0, h_.n_xa, h_.n_out * h_.out_dim, {h_.hid[0], h_.hid[1], h_.hid[2], h_.hid[3]}};
+    struct { int L, H0, n_xa, no, hid[GRL_MAX_LAYERS]; } h = {LY(h_.L), WD(h_.H0), h_.n_xa, h_.n_out * h_.out_dim, {WD(h_.hid[0]), WD(h_.hid[1]), WD(h_.hid[2]), WD(h_.hid[3])}};
     // ---- layer 0
     {
       hm_f4 acc = {u0[0], u0[1], u0[2], u0[3]};
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * q + i;
-        const float v = (n < h.H0 && row0 + r < B) ? fmaxf(acc[i] + f.b0, 0.f) : 0.f;
+        const float v = (n < WD(h.H0) && ROW(r)) ? fmaxf(acc[i] + f.b0, 0.f) : 0.f;
         zsv[0][i] = v;
         s.z[cur][r][n] = v;
       }
@@ -257,13 +263,13 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     // ---- hidden layers
 #pragma unroll
     for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) {
-      if (ly < h.L) {
+      if (ly < LY(h.L)) {
         hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
         mma(acc, s.z[cur], f.hid[ly]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * q + i;
-          const float v = (n < h.hid[ly] && row0 + r < B) ? fmaxf(acc[i] + f.bh[ly], 0.f) : 0.f;
+          const float v = (n < WD(h.hid[ly]) && ROW(r)) ? fmaxf(acc[i] + f.bh[ly], 0.f) : 0.f;
           zsv[ly][i] = v;
           s.z[cur ^ 1][r][n] = v;
         }
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
       mma(acc, s.z[cur], f.out);
       if (n < h.no) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s.o[4 * q + i][n] = row0 + 4 * q + i < B ? acc[i] + f.bo : 0.f;
+        for (int i = 0; i < 4; ++i) s.o[4 * q + i][n] = ROW(4 * q + i) ? acc[i] + f.bo : 0.f;
       }
     }
     HM_SYNC();
@@ -288,11 +294,11 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
   // pre-activations in the result layout (stored at the end); with want_da the gradient w.r.t. the action -> s.da.
   auto bwd_head = [&](const HtHead& h_, const HmBw& g, const float (&zsv)[GRL_MAX_LAYERS][4], float (&gsv)[GRL_MAX_LAYERS][4],
                       bool rank1, bool want_da) {
-    struct { int L, n_xa, hid[GRL_MAX_LAYERS]; } h = {h_.L, h_.n_xa, {h_.hid[0], h_.hid[1], h_.hid[2], h_.hid[3]}};
-    const int L = h.L;
-    int HL = h.hid[0];
+    struct { int L, n_xa, hid[GRL_MAX_LAYERS]; } h = {LY(h_.L), h_.n_xa, {WD(h_.hid[0]), WD(h_.hid[1]), WD(h_.hid[2]), WD(h_.hid[3])}};
+    const int L = LY(h.L);
+    int HL = WD(h.hid[0]);
 #pragma unroll
-    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HL = (ly == L - 1) ? h.hid[ly] : HL;
+    for (int ly = 1; ly < GRL_MAX_LAYERS; ++ly) HL = (ly == L - 1) ? WD(h.hid[ly]) : HL;
     // ---- output layer(s) -> gradient of the last hidden pre-activation
     {
       hm_f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
         float zl = 0.f;                         // activation of the last hidden layer (static register indices)
 #pragma unroll
         for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) zl = (ly == L - 1) ? zsv[ly][i] : zl;
-        const float v = (n < HL && row0 + r < B && zl > 0.f) ? acc[i] : 0.f;
+        const float v = (n < HL && ROW(r) && zl > 0.f) ? acc[i] : 0.f;
         s.z[cur][r][n] = v;
 #pragma unroll
         for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) gsv[ly][i] = (ly == L - 1) ? v : gsv[ly][i];
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * q + i;
-          const float v = (n < h.hid[ly - 1] && row0 + r < B && zsv[ly - 1][i] > 0.f) ? acc[i] : 0.f;
+          const float v = (n < WD(h.hid[ly - 1]) && ROW(r) && zsv[ly - 1][i] > 0.f) ? acc[i] : 0.f;
           s.z[cur ^ 1][r][n] = v;
           gsv[ly - 1][i] = v;
         }
@@ -370,10 +376,10 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
     for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) {
       float* zp = ly == 0 ? h.z0 : h.z[ly];
-      if (ly < h.L && zp && n < h.hid[ly]) {
+      if (ly < LY(h.L) && zp && n < WD(h.hid[ly])) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (row0 + 4 * q + i < B) HM_GW(zp)[(long)(row0 + 4 * q + i) * h.hid[ly] + n] = zsv[ly][i];
+          if (ROW(4 * q + i)) HM_GW(zp)[(long)(row0 + 4 * q + i) * WD(h.hid[ly]) + n] = zsv[ly][i];
       }
     }
   };
@@ -382,28 +388,28 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
     for (int ly = 0; ly < GRL_MAX_LAYERS; ++ly) {
       float* gp = ly == 0 ? h.g0 : h.g[ly];
-      const int ldg = ly == 0 ? h.ldg0 : h.hid[ly];
-      if (ly < h.L && gp && n < h.hid[ly]) {
+      const int ldg = ly == 0 ? h.ldg0 : WD(h.hid[ly]);
+      if (ly < LY(h.L) && gp && n < WD(h.hid[ly])) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (row0 + 4 * q + i < B) HM_GW(gp)[(long)(row0 + 4 * q + i) * ldg + n] = gsv[ly][i];
+          if (ROW(4 * q + i)) HM_GW(gp)[(long)(row0 + 4 * q + i) * ldg + n] = gsv[ly][i];
       }
     }
   };
   auto store_rows = [&](float* dst, int ld, const float* src_row0) {   // one scalar per row, lanes 0..15
-    if (t < HT_RB && row0 + t < B) HM_GW(dst)[(long)(row0 + t) * ld] = src_row0[t];
+    if (t < HT_RB && ROW(t)) HM_GW(dst)[(long)(row0 + t) * ld] = src_row0[t];
   };
 
   // ---------------------------------------------------------------- round trip 2, one burst
   // layer-0 partial sums of a head: the 16 x 64 tile of each split as ONE 16-byte load per thread (row t / 16,
   // columns 4 (t % 16) ..), added in split order
   auto issue_u = [&](const HtHead& h_, hm_f4 (&v)[4]) {
-    struct { const float* u; int ldu, u_split, H0; long u_stride; } h = {h_.u, h_.ldu, h_.u_split, h_.H0, h_.u_stride};
+    struct { const float* u; int ldu, u_split, H0; long u_stride; } h = {h_.u, h_.ldu, h_.u_split, WD(h_.H0), h_.u_stride};
     const int r = t >> 4, c4 = 4 * (t & 15);
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) {
       v[sp] = hm_f4{0.f, 0.f, 0.f, 0.f};
-      if (sp < h.u_split && c4 < h.H0 && row0 + r < B)
+      if (sp < h.u_split && c4 < WD(h.H0) && ROW(r))
         v[sp] = *(const GRL_GLOBAL hm_f4*)(HM_G(h.u) + sp * h.u_stride + (long)(row0 + r) * h.ldu + c4);
     }
   };
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
     for (int sp = 1; sp < 4; ++sp) acc += v[sp];
     for (int sp = 4; sp < h.u_split; ++sp)
-      if (c4 < h.H0 && row0 + r < B) acc += *(const GRL_GLOBAL hm_f4*)(HM_G(h.u) + sp * h.u_stride + (long)(row0 + r) * h.ldu + c4);
+      if (c4 < WD(h.H0) && ROW(r)) acc += *(const GRL_GLOBAL hm_f4*)(HM_G(h.u) + sp * h.u_stride + (long)(row0 + r) * h.ldu + c4);
     *(hm_f4*)&s.u[slot][r][c4] = acc;
   };
   auto get_u = [&](int slot, float (&u0)[4]) {
@@ -439,9 +445,9 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int r = (t >> 5) + 8 * e, j = t & 31;
-      in0[e] = (j < nin && row0 + r < B) ? HM_G(inp)[(long)(row0 + r) * ldin + j] : 0.f;
+      in0[e] = (j < nin && ROW(r)) ? HM_G(inp)[(long)(row0 + r) * ldin + j] : 0.f;
     }
-    if (type >= 2 && t < HT_RB && row0 + t < B) { rw = HM_G(a.rew)[row0 + t]; dn = HM_G(a.done)[row0 + t]; }
+    if (type >= 2 && t < HT_RB && ROW(t)) { rw = HM_G(a.rew)[row0 + t]; dn = HM_G(a.done)[row0 + t]; }
     prefetch_fwd(h0, fA);
     stamp();
     // ---- ... then consume
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     prefetch_bwd(a.h[5], gA, true, true);       // (lands while the sample and qf1(s, pi) run)
     sample(); stamp();
     fwd_head(a.h[5], fB, uB, zsB); stamp();     // qf1(s, pi): s.o[r][0]
-    if (t < HT_RB) { s.sv[0][t] = s.o[t][0]; s.sv[5][t] = row0 + t < B ? -invB : 0.f; }
+    if (t < HT_RB) { s.sv[0][t] = s.o[t][0]; s.sv[5][t] = ROW(t) ? -invB : 0.f; }
     HM_SYNC();
     float gq[GRL_MAX_LAYERS][4] = {};           // gradients of qf1's own weights are not wanted here (policy loss)
     bwd_head(a.h[5], gA, zsB, gq, true, true); stamp();
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
       for (int e = t; e < HT_RB * HM_W; e += 256) {
         const int r = e / HM_W, k = e - r * HM_W;
         float v = 0.f;
-        if (k < 2 * A && row0 + r < B) {
+        if (k < 2 * A && ROW(r)) {
           const int j = k < A ? k : k - A;
           float m, d;
           ht_sample_bwd_elem(s.ls[r][j], s.eps[r][j], s.pi[r][j], s.da[r][j], alpha_over_b, m, d);
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     if (t < HT_RB) {
       const float vb = fminf(s.sv[0][t], s.sv[1][t]) - s.alpha * s.sv[2][t];
       s.sv[8][t] = s.o[t][0];
-      s.sv[5][t] = row0 + t < B ? (s.o[t][0] - vb) * invB : 0.f;
+      s.sv[5][t] = ROW(t) ? (s.o[t][0] - vb) * invB : 0.f;
     }
     HM_SYNC();
     bwd_head(a.h[1], gA, zsA, gs, true, false); stamp();
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     if (t < HT_RB) {
       const float qb = s.sv[6][t] + (1.f - s.sv[7][t]) * a.gamma * s.sv[4][t];
       s.sv[8][t] = s.o[t][0];
-      s.sv[5][t] = row0 + t < B ? (s.o[t][0] - qb) * invB : 0.f;
+      s.sv[5][t] = ROW(t) ? (s.o[t][0] - qb) * invB : 0.f;
     }
     HM_SYNC();
     bwd_head(h, gA, zsB, gs, true, false); stamp();

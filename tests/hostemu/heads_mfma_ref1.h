@@ -62,7 +62,7 @@ inline void hm_ref_bwd(const HtHead& h, int row, const float* zs, const float* d
     }
 }
 
-template <int W>
+template <int W, bool FAST>
 void heads_fused_kernel(const HeadsFusedArgs* ap) {
   if (threadIdx.x != 0) return;
   const HeadsFusedArgs& a = *ap;
