@@ -64,12 +64,21 @@ class TorchCudaBackend:
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
 
-    def comm_context(self):
-        """Context whose work runs on a second stream, ordered AFTER everything enqueued on the engine stream so far
-        (the exchange of a finished gradient bucket, overlapping what the engine stream does next)."""
+    def comm_fork(self):
+        """Marks the current end of the engine stream: a later `comm_context(fork)` starts its work there."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def comm_context(self, fork=None):
+        """Context whose work runs on a second stream, ordered after `fork` (default: everything enqueued on the engine
+        stream so far): the exchange of a finished gradient bucket, overlapping what the engine stream does next."""
         if getattr(self, "comm", None) is None:
             self.comm = self.torch.cuda.Stream(device=self.device)
-        self.comm.wait_stream(self.stream)
+        if fork is None:
+            self.comm.wait_stream(self.stream)
+        else:
+            self.comm.wait_event(fork)
         return self.torch.cuda.stream(self.comm)
 
     def comm_join(self):

@@ -31,6 +31,19 @@ def allreduce_flat_(flat, group=None):
     return flat
 
 
+def allreduce_ranges_(views, group=None):
+    """Sum-all-reduce of the contiguous ranges of one bucket.  With RCCL the ranges go out as ONE grouped call
+    (ncclGroupStart / End through torch's coalescing manager): a collective call costs tens of microseconds of host
+    time, comparable to the whole update."""
+    if len(views) > 1 and views[0].is_cuda and hasattr(dist, "_coalescing_manager") and dist.get_backend(group) == "nccl":
+        with dist._coalescing_manager(group=group, device=views[0].device, async_ops=False):
+            for v in views:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    else:
+        for v in views:
+            allreduce_flat_(v, group)
+
+
 def gather_moments(mean, var, count, group=None):
     """All-gather of one batch's (mean, var, count); returns them in rank order (float64 throughout)."""
     mean, var = np.asarray(mean, np.float64), np.asarray(var, np.float64)
@@ -87,13 +100,12 @@ class DataParallelSac:
     def _step_overlapped(self, idx, eps):
         eng, be = self.eng, self.eng.be
         eng.compute_grads_staged(0, idx, eps)
-        with be.comm_context():                      # second stream, ordered after stage 0
-            for v in self.views[0]:
-                allreduce_flat_(v, self.group)
-        eng.compute_grads_staged(1)                  # engine stream: runs while the dense bucket is exchanged
+        fork = be.comm_fork()                        # the second stream will start where stage 0 ends ...
+        eng.compute_grads_staged(1)                  # ... but stage 1 is enqueued FIRST: the host time of the collective
+        with be.comm_context(fork):                  #     calls below must not delay it (measured: it did, by 60 us)
+            allreduce_ranges_(self.views[0], self.group)     # dense bucket: travels while stage 1 runs
         with be.stream_context():
-            for v in self.views[1]:
-                allreduce_flat_(v, self.group)
+            allreduce_ranges_(self.views[1], self.group)     # convolution bucket, after stage 1
         be.comm_join()
         eng.apply_grads(self.scale)
 

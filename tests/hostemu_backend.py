@@ -28,7 +28,10 @@ class NumpyHostBackend:
         import contextlib
         return contextlib.nullcontext()
 
-    def comm_context(self):
+    def comm_fork(self):
+        return None
+
+    def comm_context(self, fork=None):
         import contextlib
         return contextlib.nullcontext()
 
