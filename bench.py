@@ -319,7 +319,7 @@ def run_sac(args, wl_name, world, rank, device):
     if rank == 0 and not args.no_profile:
         n = min(args.steps, 50)
         prof = profile_pass(eng, eng.train_device, n)
-        out["roofline"] = roofline_of(prof, n, dt / args.steps, wl_name)
+        out["roofline"] = roofline_of(prof, n, dt / args.steps, wl_name if not strong else wl_name + "_gb%d" % args.global_batch)
     else:
         out["roofline"] = None
     if wl_name == "sac_rgbd" and rank == 0 and world == 1:

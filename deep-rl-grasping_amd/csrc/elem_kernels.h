@@ -707,6 +707,8 @@ struct AdamArgs {
 
 struct ReduceDesc {
   float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
+  int32_t vec;   // 1: n, slab_stride multiples of 4 and dst / src 16-byte aligned -- a thread sums 4 consecutive outputs
+  int32_t pad_;  //    (tile = 1024 outputs instead of 256); set by the host (reduce_tiles)
 };
 
 // flat work list: block b sums 256 consecutive outputs of descriptor tiles[b].x starting at tiles[b].y
@@ -722,6 +724,52 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
   }
   const int2 tl = tiles[blockIdx.x];
   const ReduceDesc d = descs[tl.x];
+#ifndef GRL_HOSTEMU
+  if (d.vec) {
+    // four consecutive outputs per thread, 16-byte accesses throughout (the pass is HBM-bound: a quarter of the
+    // memory instructions for the same bytes).  Per element the arithmetic is the scalar path's, in the same order.
+    typedef float rs_f4 __attribute__((ext_vector_type(4)));
+    const int i = tl.y + 4 * threadIdx.x;
+    if (i < d.n) {
+      const int64_t e = fuse_adam ? (d.dst + i) - aa.grads : 0;
+      const int64_t kp = e - aa.src_ofs;
+      const bool pol = fuse_adam && kp >= 0 && kp < aa.n_polyak;     // variables are padded to quads: no straddling
+      rs_f4 p = {0.f, 0.f, 0.f, 0.f}, m = p, v = p, tg = p;
+      if (fuse_adam) {
+        p = *(const rs_f4*)(aa.params + e); m = *(const rs_f4*)(aa.m + e); v = *(const rs_f4*)(aa.v + e);
+        if (pol) tg = *(const rs_f4*)(aa.target + kp);
+      }
+      const float* __restrict__ src = d.src + i;
+      rs_f4 s = {0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 8 <= d.splits; k += 8) {
+        rs_f4 vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = *(const rs_f4*)(src + (long)(k + u) * d.slab_stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += vv[u];
+      }
+      for (; k < d.splits; ++k) s += *(const rs_f4*)(src + (long)k * d.slab_stride);
+      *(rs_f4*)(d.dst + i) = s;
+      if (fuse_adam) {
+        const float alpha = aa.sc->adam_alpha;
+        float pe[4] = {p.x, p.y, p.z, p.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
+        const float ge[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) adam_elem(ge[u] * aa.grad_scale, pe[u], me[u], ve[u], alpha, aa.eps);
+        p = rs_f4{pe[0], pe[1], pe[2], pe[3]}; m = rs_f4{me[0], me[1], me[2], me[3]}; v = rs_f4{ve[0], ve[1], ve[2], ve[3]};
+        *(rs_f4*)(aa.params + e) = p; *(rs_f4*)(aa.m + e) = m; *(rs_f4*)(aa.v + e) = v;
+        if (pol) {
+          rs_f4 t2;
+          t2.x = (1.f - aa.tau) * tg.x + aa.tau * p.x; t2.y = (1.f - aa.tau) * tg.y + aa.tau * p.y;
+          t2.z = (1.f - aa.tau) * tg.z + aa.tau * p.z; t2.w = (1.f - aa.tau) * tg.w + aa.tau * p.w;
+          *(rs_f4*)(aa.target + kp) = t2;
+        }
+      }
+    }
+    return;
+  }
+#endif
   const int i = tl.y + threadIdx.x;
   if (i < d.n) {
     // fused apply: the element's Adam state is requested before the slab sums (independent loads)

@@ -862,10 +862,31 @@ struct grl_ctx {
   }
 
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
+  // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors
+  // whose geometry allows 16-byte accesses are marked (vec) and cut into tiles of 1024 outputs, the others of 256
+  std::vector<int2> reduce_tiles(std::function<bool(const ReduceDesc&)> pick = nullptr) {
+    std::vector<int2> rt;
+    for (size_t k = 0; k < reduces.size(); ++k) {
+      ReduceDesc& r = reduces[k];
+#ifdef GRL_HOSTEMU
+      r.vec = 0;
+#else
+      const char* nv = getenv("GRL_NO_VEC_REDUCE");   // test switch: the one-output-per-thread form everywhere
+      r.vec = (!(nv && atoi(nv)) && r.n % 4 == 0 && r.slab_stride % 4 == 0 &&
+               (((uintptr_t)r.dst | (uintptr_t)r.src) & 15) == 0) ? 1 : 0;
+#endif
+      if (pick && !pick(r)) continue;
+      const int step = r.vec ? 1024 : 256;
+      for (int st0 = 0; st0 < r.n; st0 += step) rt.push_back(make_int2((int)k, st0));
+    }
+    return rt;
+  }
+
   void add_wgrad(std::vector<IgemmProb>& probs, IgemmProb p, int64_t w_off, int64_t w_rows_off, int rows,
                  int64_t b_off) {
     probs.push_back(p);
     ReduceDesc r;
+    memset(&r, 0, sizeof(r));
     r.src = p.c; r.splits = p.split; r.slab_stride = p.slab_stride;
     r.dst = grads + w_off + w_rows_off * p.N; r.n = rows * p.N;
     reduces.push_back(r);
@@ -1572,10 +1593,8 @@ int grl_ctx::plan_sac() {
     }
   }
   {
+    std::vector<int2> rt = reduce_tiles();          // (marks the 16-byte-eligible descriptors: before the upload)
     d_reduces = upload_vec(wk, reduces);
-    std::vector<int2> rt;
-    for (size_t k = 0; k < reduces.size(); ++k)
-      for (int st0 = 0; st0 < reduces[k].n; st0 += 256) rt.push_back(make_int2((int)k, st0));
     int2* d_rt = upload_vec(wk, rt);
     const int ntiles = (int)rt.size();
     ReduceDesc* dr = d_reduces;
@@ -1599,9 +1618,8 @@ int grl_ctx::plan_sac() {
           if (r.dst >= grads + ex[n].w[0] && r.dst < grads + ex[n].fw) return true;
         return false;
       };
-      std::vector<int2> rt0, rt1;
-      for (size_t k = 0; k < reduces.size(); ++k)
-        for (int st0 = 0; st0 < reduces[k].n; st0 += 256) (is_conv(reduces[k]) ? rt1 : rt0).push_back(make_int2((int)k, st0));
+      std::vector<int2> rt0 = reduce_tiles([&](const ReduceDesc& r) { return !is_conv(r); });
+      std::vector<int2> rt1 = reduce_tiles(is_conv);
       int2* d_rt0 = upload_vec(wk, rt0);
       int2* d_rt1 = upload_vec(wk, rt1);
       const int n0 = (int)rt0.size(), n1 = (int)rt1.size();
@@ -2159,10 +2177,8 @@ int grl_ctx::plan_q() {
     add_launch(ops_grads, "q_wgrad", 2, wg);
   }
   {
+    std::vector<int2> rt = reduce_tiles();
     d_reduces = upload_vec(wk, reduces);
-    std::vector<int2> rt;
-    for (size_t k = 0; k < reduces.size(); ++k)
-      for (int st0 = 0; st0 < reduces[k].n; st0 += 256) rt.push_back(make_int2((int)k, st0));
     int2* d_rt = upload_vec(wk, rt);
     const int ntiles = (int)rt.size();
     ReduceDesc* dr = d_reduces;
@@ -2510,11 +2526,13 @@ int grl_ctx::plan_ae() {
     wgc.push_back(p);
     for (int kh = 0; kh < 7; ++kh) {
       ReduceDesc r;
+      memset(&r, 0, sizeof(r));
       r.src = p.c + (int64_t)kh * 8 * 32; r.splits = p.split; r.slab_stride = p.slab_stride;
       r.dst = grads + ew[0] + (int64_t)kh * 7 * 32; r.n = 7 * 32;
       reduces.push_back(r);
     }
     ReduceDesc rb;
+    memset(&rb, 0, sizeof(rb));
     rb.src = p.c + (int64_t)56 * 32; rb.splits = p.split; rb.slab_stride = p.slab_stride; rb.dst = grads + eb[0]; rb.n = 32;
     reduces.push_back(rb);
   }
@@ -2527,10 +2545,8 @@ int grl_ctx::plan_ae() {
     add_launch(ops_ae, "ae_wgrad_dense", 2, wgd);
   }
   {
+    std::vector<int2> rt = reduce_tiles();
     d_reduces = upload_vec(wk, reduces);
-    std::vector<int2> rt;
-    for (size_t k = 0; k < reduces.size(); ++k)
-      for (int st0 = 0; st0 < reduces[k].n; st0 += 256) rt.push_back(make_int2((int)k, st0));
     int2* d_rt = upload_vec(wk, rt);
     const int ntiles = (int)rt.size();
     ReduceDesc* dr = d_reduces;
