@@ -369,11 +369,30 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(SampleBwdArgs a) {
 }
 
 // one element of TF-1.x Adam (A.5; epsilon outside the bias correction, which lives in alpha)
+// The fused multiply-adds are spelled out and contraction is off inside: the scalar, the 4-wide and the stand-alone
+// forms of the optimiser must round identically (test_launch_plan_switches_do_not_touch_arithmetic), which is not
+// something to leave to where the compiler happens to contract.
 __device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v, float alpha, float eps) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
   const float omb1 = 1.f - 0.9f, omb2 = 1.f - 0.999f;
-  m = m + (g - m) * omb1;
-  v = v + (g * g - v) * omb2;
+  m = fmaf(g - m, omb1, m);
+  v = fmaf(fmaf(g, g, -v), omb2, v);
   p = p - (m * alpha) / (sqrtf(v) + eps);
+}
+__device__ __forceinline__ float grad_scaled(float g, float scale) {   // data-parallel mean: never folded into an fma
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  return g * scale;
+}
+// Polyak average of one element (A.4): (1-tau)*target + tau*source
+__device__ __forceinline__ float polyak_elem(float tg, float p, float tau) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  return fmaf(tau, p, (1.f - tau) * tg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,13 +775,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
         float pe[4] = {p.x, p.y, p.z, p.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
         const float ge[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) adam_elem(ge[u] * aa.grad_scale, pe[u], me[u], ve[u], alpha, aa.eps);
+        for (int u = 0; u < 4; ++u) adam_elem(grad_scaled(ge[u], aa.grad_scale), pe[u], me[u], ve[u], alpha, aa.eps);
         p = rs_f4{pe[0], pe[1], pe[2], pe[3]}; m = rs_f4{me[0], me[1], me[2], me[3]}; v = rs_f4{ve[0], ve[1], ve[2], ve[3]};
         *(rs_f4*)(aa.params + e) = p; *(rs_f4*)(aa.m + e) = m; *(rs_f4*)(aa.v + e) = v;
         if (pol) {
           rs_f4 t2;
-          t2.x = (1.f - aa.tau) * tg.x + aa.tau * p.x; t2.y = (1.f - aa.tau) * tg.y + aa.tau * p.y;
-          t2.z = (1.f - aa.tau) * tg.z + aa.tau * p.z; t2.w = (1.f - aa.tau) * tg.w + aa.tau * p.w;
+          t2.x = polyak_elem(tg.x, p.x, aa.tau); t2.y = polyak_elem(tg.y, p.y, aa.tau);
+          t2.z = polyak_elem(tg.z, p.z, aa.tau); t2.w = polyak_elem(tg.w, p.w, aa.tau);
           *(rs_f4*)(aa.target + kp) = t2;
         }
       }
@@ -791,9 +810,9 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
     for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
     d.dst[i] = s;
     if (fuse_adam) {   // the update every trainable tensor gets from adam_polyak_kernel, element by element
-      adam_elem(s * aa.grad_scale, p, m, v, aa.sc->adam_alpha, aa.eps);
+      adam_elem(grad_scaled(s, aa.grad_scale), p, m, v, aa.sc->adam_alpha, aa.eps);
       aa.params[e] = p; aa.m[e] = m; aa.v[e] = v;
-      if (pol) aa.target[kp] = (1.f - aa.tau) * tg + aa.tau * p;
+      if (pol) aa.target[kp] = polyak_elem(tg, p, aa.tau);
     }
   }
 }
@@ -803,17 +822,16 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
 // target <- (1-tau)*target + tau*source for the leading `n_polyak` floats of model/values_fn.
 __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
   const float alpha = a.sc->adam_alpha;
-  const float omt = 1.f - a.tau;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_train;
        i += (int64_t)gridDim.x * 256) {
-    const float g = a.grads[i] * a.grad_scale;
+    const float g = grad_scaled(a.grads[i], a.grad_scale);
     float m = a.m[i], v = a.v[i], p = a.params[i];
     adam_elem(g, p, m, v, alpha, a.eps);
     a.m[i] = m;
     a.v[i] = v;
     a.params[i] = p;
     const int64_t k = i - a.src_ofs;
-    if (k >= 0 && k < a.n_polyak) a.target[k] = omt * a.target[k] + a.tau * p;
+    if (k >= 0 && k < a.n_polyak) a.target[k] = polyak_elem(a.target[k], p, a.tau);
   }
 }
 
