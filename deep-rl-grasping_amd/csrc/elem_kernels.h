@@ -727,7 +727,9 @@ struct AdamArgs {
 struct ReduceDesc {
   float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
   int32_t vec;   // 1: n, slab_stride multiples of 4 and dst / src 16-byte aligned -- a thread sums 4 consecutive outputs
-  int32_t pad_;  //    (tile = 1024 outputs instead of 256); set by the host (reduce_tiles)
+                 //    (tile = 1024 outputs instead of 256); set by the host (reduce_tiles)
+  int32_t row_len, src_ld;   // row_len > 0: output i comes from src[(i / row_len) * src_ld + i % row_len] -- a column
+                             // block of a slab whose rows hold several variables side by side (conv1 of both nets)
 };
 
 // flat work list: block b sums 256 consecutive outputs of descriptor tiles[b].x starting at tiles[b].y
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
         p = *(const rs_f4*)(aa.params + e); m = *(const rs_f4*)(aa.m + e); v = *(const rs_f4*)(aa.v + e);
         if (pol) tg = *(const rs_f4*)(aa.target + kp);
       }
-      const float* __restrict__ src = d.src + i;
+      const float* __restrict__ src = d.src + (d.row_len > 0 ? (long)(i / d.row_len) * d.src_ld + i % d.row_len : i);
       rs_f4 s = {0.f, 0.f, 0.f, 0.f};
       int k = 0;
       for (; k + 8 <= d.splits; k += 8) {
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
     const int64_t kp = e - aa.src_ofs;
     const bool pol = fuse_adam && kp >= 0 && kp < aa.n_polyak;
     if (fuse_adam) { p = aa.params[e]; m = aa.m[e]; v = aa.v[e]; if (pol) tg = aa.target[kp]; }
-    const float* __restrict__ src = d.src + i;
+    const float* __restrict__ src = d.src + (d.row_len > 0 ? (long)(i / d.row_len) * d.src_ld + i % d.row_len : i);
     float s = 0.f;
     int k = 0;
     for (; k + 8 <= d.splits; k += 8) {

@@ -77,7 +77,11 @@ struct Upload {
 
 struct ConvGeom {
   int H, W, C, KH, KW, S, pad, OH, OW, Cout;
+  int ldx = 0, ldy = 0;   // pixel strides of the input / output tensors when wider than C / Cout (0: dense) -- the
+                          // layer-1 activations of the two trained networks sit side by side in one buffer
   int K() const { return KH * KW * C; }
+  int LX() const { return ldx ? ldx : C; }
+  int LY() const { return ldy ? ldy : Cout; }
 };
 
 struct ConvFwdTabs {
@@ -192,6 +196,7 @@ struct grl_ctx {
   HeadGrad gPI, gVF, gQF1, gQF2, gQF1PI;
   float *da_pi, *dmu, *dls;
   float *dfeat[2], *g3[2], *g2[2], *g1[2];
+  int ld1 = 32;   // pixel stride of a1 / g1 (64: the two trained networks side by side)
   float* act_p = nullptr;            // [B, Ap] row-padded copy of the minibatch actions (Ap = rup(A, 4))
   int Ap = 0, ld_d = 1, ld_dm = 0;   // strides of the packed output-gradient buffers (fused heads)
   bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
@@ -393,7 +398,7 @@ struct grl_ctx {
         for (int ow = 0; ow < g.OW; ++ow) {
           const int m = (b * g.OH + oh) * g.OW + ow;
           const int ih0 = oh * g.S - g.pad, iw0 = ow * g.S - g.pad;
-          ti[m] = ((b * g.H + ih0) * g.W + iw0) * g.C;
+          ti[m] = ((b * g.H + ih0) * g.W + iw0) * g.LX();
           uint64_t bits = 0;
           for (int kh = 0; kh < g.KH; ++kh)
             for (int kw = 0; kw < g.KW; ++kw)
@@ -405,7 +410,7 @@ struct grl_ctx {
       for (int kw = 0; kw < g.KW; ++kw)
         for (int c = 0; c < g.C; ++c) {
           const int r = (kh * g.KW + kw) * g.C + c;
-          tr[r] = (kh * g.W + kw) * g.C + c;
+          tr[r] = (kh * g.W + kw) * g.LX() + c;
           tp[r] = (uint8_t)(kh * g.KW + kw);
         }
     t.tab_i = upload_vec(wk, ti);
@@ -443,7 +448,7 @@ struct grl_ctx {
           for (int i = 0; i < IHc; ++i)
             for (int j = 0; j < IWc; ++j) {
               const int m = (b * IHc + i) * IWc + j;
-              ti[m] = ((b * g.OH + i) * g.OW + j) * g.Cout;
+              ti[m] = ((b * g.OH + i) * g.OW + j) * g.LY();
               uint64_t bits = 0;
               for (int jj = 0; jj < TJ; ++jj)
                 for (int ll = 0; ll < TL; ++ll) {
@@ -454,13 +459,13 @@ struct grl_ctx {
                 }
               vm[m] = bits;
               const int ih = g.S * i + ph - g.pad, iw = g.S * j + pw - g.pad;
-              ct[m] = (ih >= 0 && iw >= 0 && ih < g.H && iw < g.W) ? ((b * g.H + ih) * g.W + iw) * g.C : -1;
+              ct[m] = (ih >= 0 && iw >= 0 && ih < g.H && iw < g.W) ? ((b * g.H + ih) * g.W + iw) * g.LX() : -1;
             }
         for (int jj = 0; jj < TJ; ++jj)
           for (int ll = 0; ll < TL; ++ll)
             for (int co = 0; co < g.Cout; ++co) {
               const int r = (jj * TL + ll) * g.Cout + co;
-              tr[r] = -(jj * g.OW + ll) * g.Cout + co;
+              tr[r] = -(jj * g.OW + ll) * g.LY() + co;
               tp[r] = (uint8_t)(jj * TL + ll);
               const int kh = std::min(ph + g.S * jj, g.KH - 1), kw = std::min(pw + g.S * ll, g.KW - 1);
               qt[r] = ((kh * g.KW + kw) * g.C) * g.Cout + co;
@@ -556,7 +561,7 @@ struct grl_ctx {
     p.p_base[0] = x; p.p_tab_i = t.tab_i; p.p_tab_r = t.tab_r; p.p_vmask_i = t.vmask; p.p_tap_r = t.tap;
     single_part(p);
     p.q_base[0] = w; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
-    p.c = y; p.ldc = g.Cout; p.bias = bias; p.act = act; p.act_alpha = alpha;
+    p.c = y; p.ldc = g.LY(); p.bias = bias; p.act = act; p.act_alpha = alpha;
     p.vflags = t.vec4 ? VF_P_TABS : 0;
     set_split(p, 1);
     return p;
@@ -575,15 +580,16 @@ struct grl_ctx {
     return p;
   }
 
+  // (n_side > 1: the output gradients of n_side networks side by side in gy's rows -- one problem, N = n_side * Cout)
   static IgemmProb conv_wgrad(const float* x, const ConvFwdTabs& t, const ConvGeom& g, const float* gy,
-                              float* slab, int split_target) {
+                              float* slab, int split_target, int n_side = 1) {
     IgemmProb p = blank();
-    p.M = g.K() + 1; p.N = g.Cout; p.K = t.M;
+    p.M = g.K() + 1; p.N = n_side * g.Cout; p.K = t.M;
     p.p_base[0] = x; p.p_tab_i = t.tab_r; p.p_tab_r = t.tab_i; single_part(p);
     if (t.vmask) { p.p_vmask_i = t.vmask; p.p_tap_r = t.tap; p.p_mask_swap = 1; }   // padded conv: skip out-of-image taps
     p.p_ones_i = g.K();
-    p.q_base[0] = gy; p.q_ld_r[0] = g.Cout; p.q_ld_j[0] = 1;
-    p.c = slab; p.ldc = g.Cout;
+    p.q_base[0] = gy; p.q_ld_r[0] = g.LY(); p.q_ld_j[0] = 1;
+    p.c = slab; p.ldc = p.N;
     p.vflags = t.vec4 ? VF_P_TABS : 0;
     set_split(p, split_target);
     return p;
@@ -759,7 +765,7 @@ struct grl_ctx {
         for (int t0 = 0; t0 < nt; t0 += per) work.push_back(make_int4((int)pi, t0, std::min(per, nt - t0), 0));
       }
       l->n_tiles = (int)work.size();
-      l->d_probs = upload_vec(wk, l->probs);
+      l->d_probs = upload_vec(wk, per_tile_descs(l->probs, work));
       l->d_tiles = upload_vec(wk, work);
       launches.push_back(l);
       if (getenv("GRL_PLAN_DUMP"))
@@ -792,11 +798,12 @@ struct grl_ctx {
         for (int ti = 0; ti < (Mt + BMt - 1) / BMt; ++ti)
           for (int tj = 0; tj < (p.N + BNt - 1) / BNt; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
     }
+    if (variant == 2) tiles = xcd_order(tiles, l->probs, BMt, BNt);
     l->n_tiles = (int)tiles.size();
     if (getenv("GRL_PLAN_DUMP"))
       fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu  tiles %d\n", tag.c_str(),
               variant, l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size(), l->n_tiles);
-    l->d_probs = upload_vec(wk, l->probs);
+    l->d_probs = upload_vec(wk, per_tile_descs(l->probs, tiles));
     l->d_tiles = upload_vec(wk, tiles);
     launches.push_back(l);
     Op op;
@@ -861,6 +868,66 @@ struct grl_ctx {
     ops.push_back(std::move(op));
   }
 
+  // One descriptor COPY per workgroup, in work-list order.  A workgroup's first operand load sits at the end of a chain
+  // of dependent memory round trips (~1.2 us each on MI355X): work-list entry -> problem descriptor -> address tables ->
+  // data.  Indexing the descriptors by blockIdx like the work list itself lets the first two travel together.
+  static std::vector<IgemmProb> per_tile_descs(const std::vector<IgemmProb>& probs, const std::vector<int4>& tiles) {
+    std::vector<IgemmProb> out;
+    out.reserve(tiles.size());
+    for (const int4& t : tiles) out.push_back(probs[t.x]);
+    return out;
+  }
+
+  // XCD-aware order of a weight-gradient work list.  The tiles of one reduction chunk read the same rows of the output
+  // gradient and overlapping input patches (conv2: 8 row tiles over one 768-pixel chunk; the dense layer: every tile of
+  // a row band reads the whole batch of d feat), but the 8 XCDs have private L2s and workgroup b runs on XCD b % 8
+  // (MI355X_MICROARCH.md, "Workgroup dispatch"; an observation, used for speed only): in list order those tiles land on
+  // 8 different L2s and each fetches its operands from HBM -- 158 MB per launch where ~50 MB are distinct.  Here the
+  // tiles are grouped by chunk, the groups dealt to 8 queues (least work first, heavy groups first) and the list is
+  // re-emitted so that position i comes from queue i % 8.  Same tiles, same arithmetic; GRL_NO_XCD_ORDER=1 keeps the
+  // list order (test / measurement switch).
+  static std::vector<int4> xcd_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt) {
+    if (const char* e = getenv("GRL_NO_XCD_ORDER")) if (atoi(e)) return tiles;
+    constexpr int NX = 8;
+    struct Grp { std::vector<int4> t; double w = 0; };
+    std::vector<Grp> groups;
+    std::map<std::tuple<int, int, int>, size_t> at;
+    for (const int4& t : tiles) {
+      const IgemmProb& p = probs[t.x];
+      const int ntj = (p.N + BNt - 1) / BNt;
+      const int band = std::max(1, 16 / ntj);                         // row tiles per group: at most ~16 tiles share an L2 set
+      const auto key = std::make_tuple(t.x, t.y, t.z / band);
+      auto it = at.find(key);
+      if (it == at.end()) { it = at.emplace(key, groups.size()).first; groups.emplace_back(); }
+      Grp& g = groups[it->second];
+      g.t.push_back(t);
+      g.w += (double)std::min(p.K, p.k_chunk);
+    }
+    (void)BMt;
+    std::vector<std::vector<int4>> q(NX);
+    double load[NX] = {0};
+    for (const Grp& g : groups) {                                      // groups arrive heaviest problem first
+      int best = 0;
+      for (int x = 1; x < NX; ++x)
+        if (load[x] < load[best]) best = x;
+      q[best].insert(q[best].end(), g.t.begin(), g.t.end());
+      load[best] += g.w;
+    }
+    std::vector<int4> out;
+    out.reserve(tiles.size());
+    size_t head[NX] = {0};
+    for (size_t i = 0; i < tiles.size(); ++i) {
+      int x = (int)(i % NX);
+      if (head[x] >= q[x].size()) {                                    // this queue ran dry: the tail loses its affinity
+        size_t most = 0;
+        for (int y = 0; y < NX; ++y)
+          if (q[y].size() - head[y] > most) { most = q[y].size() - head[y]; x = y; }
+      }
+      out.push_back(q[x][head[x]++]);
+    }
+    return out;
+  }
+
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
   // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors
   // whose geometry allows 16-byte accesses are marked (vec) and cut into tiles of 1024 outputs, the others of 256
@@ -872,7 +939,7 @@ struct grl_ctx {
       r.vec = 0;
 #else
       const char* nv = getenv("GRL_NO_VEC_REDUCE");   // test switch: the one-output-per-thread form everywhere
-      r.vec = (!(nv && atoi(nv)) && r.n % 4 == 0 && r.slab_stride % 4 == 0 &&
+      r.vec = (!(nv && atoi(nv)) && r.n % 4 == 0 && r.slab_stride % 4 == 0 && r.row_len % 4 == 0 && r.src_ld % 4 == 0 &&
                (((uintptr_t)r.dst | (uintptr_t)r.src) & 15) == 0) ? 1 : 0;
 #endif
       if (pick && !pick(r)) continue;
@@ -1024,8 +1091,18 @@ int grl_ctx::plan_sac() {
   if (cnn) {
     x_obs = wk.f32((int64_t)B * img_elems);
     x_next = wk.f32((int64_t)B * img_elems);
+    // Layer-1 activations of the two TRAINED networks (and their gradients below) sit side by side, pixel stride 64:
+    // pi in columns 0..31, values_fn in 32..63.  Both networks read the same observations, so conv1's weight
+    // gradient becomes ONE product obs-patches^T x [dY_pi | dY_vf] (N = 64: full 64x64 tiles, the gathered patches
+    // read once) instead of two half-empty ones.  The target network's buffer keeps the stride (columns 32..63 idle)
+    // so that one set of conv2 tables serves all three.  GRL_NO_CONV1_SIDE=1: separate dense buffers (test switch).
+    {
+      const char* ns = getenv("GRL_NO_CONV1_SIDE");
+      ld1 = (ns && atoi(ns)) ? 32 : 64;
+    }
+    float* a1_pair = ld1 == 64 ? wk.f32((int64_t)B * 225 * 64) : nullptr;
     for (int n = 0; n < 3; ++n) {
-      a1[n] = wk.f32((int64_t)B * 225 * 32);
+      a1[n] = ld1 == 32 ? wk.f32((int64_t)B * 225 * 32) : (n < 2 ? a1_pair + 32 * n : wk.f32((int64_t)B * 225 * 64));
       a2[n] = wk.f32((int64_t)B * 36 * 64);
       a3[n] = wk.f32((int64_t)B * 16 * 64);
     }
@@ -1078,13 +1155,15 @@ int grl_ctx::plan_sac() {
     zero_once.push_back({dmu, (size_t)B * ld_dm * 4});
     zero_once.push_back({dls, (size_t)B * ld_dm * 4});
   }
-  if (cnn)
+  if (cnn) {
+    float* g1_pair = ld1 == 64 ? wk.f32((int64_t)B * 225 * 64) : nullptr;
     for (int n = 0; n < 2; ++n) {
       dfeat[n] = wk.f32((int64_t)B * ldf);
       g3[n] = wk.f32((int64_t)B * 16 * 64);
       g2[n] = wk.f32((int64_t)B * 36 * 64);
-      g1[n] = wk.f32((int64_t)B * 225 * 32);
+      g1[n] = ld1 == 64 ? g1_pair + 32 * n : wk.f32((int64_t)B * 225 * 32);
     }
+  }
 
   const float* P = params;
   const float* T = params;   // target block uses absolute offsets too
@@ -1130,7 +1209,12 @@ int grl_ctx::plan_sac() {
   ConvGeom cg[3];
   ConvFwdTabs ft[3];
   if (cnn) {
-    for (int l = 0; l < 3; ++l) { cg[l] = cnn_geom(l, C_img); ft[l] = conv_fwd_tabs(cg[l], B); }
+    for (int l = 0; l < 3; ++l) {
+      cg[l] = cnn_geom(l, C_img);
+      if (l == 0) cg[l].ldy = ld1;
+      if (l == 1) cg[l].ldx = ld1;
+      ft[l] = conv_fwd_tabs(cg[l], B);
+    }
     const float* xin[3] = {x_obs, x_obs, x_next};
     const char* tags[3] = {"conv1_fwd", "conv2_fwd", "conv3_fwd"};
     for (int l = 0; l < 3; ++l) {
@@ -1413,9 +1497,24 @@ int grl_ctx::plan_sac() {
     // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
     int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3, tuned with the merged launch (GRL_WG_SPLIT=a,b,c overrides)
     if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
+    if (ld1 == 64) {   // conv1 of both networks: one problem over the side-by-side gradient buffer, columns 32n.. -> net n
+      IgemmProb p = conv_wgrad(x_obs, ft[0], cg[0], g1[0], nullptr, wsplit[0], 2);
+      p.c = wk.f32(p.slab_stride * p.split);
+      wgc[0].push_back(p);
+      for (int n = 0; n < 2; ++n) {
+        ReduceDesc r;
+        memset(&r, 0, sizeof(r));
+        r.src = p.c + 32 * n; r.splits = p.split; r.slab_stride = p.slab_stride; r.row_len = 32; r.src_ld = 64;
+        r.dst = grads + ex[n].w[0]; r.n = cg[0].K() * 32;
+        reduces.push_back(r);
+        ReduceDesc rb = r;
+        rb.src = p.c + (int64_t)p.p_ones_i * 64 + 32 * n; rb.dst = grads + ex[n].b[0]; rb.n = 32;
+        reduces.push_back(rb);
+      }
+    }
     for (int n = 0; n < 2; ++n) {
       const float* xin = x_obs;
-      {
+      if (ld1 != 64) {
         IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, wsplit[0]);
         p.c = wk.f32(p.slab_stride * p.split);
         add_wgrad(wgc[0], p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
@@ -1690,9 +1789,11 @@ int grl_ctx::plan_sac() {
       aa1 = wk.f32((int64_t)NA * 225 * 32); aa2 = wk.f32((int64_t)NA * 36 * 64); aa3 = wk.f32((int64_t)NA * 16 * 64);
       float* io[4] = {ax, aa1, aa2, aa3};
       for (int l = 0; l < 3; ++l) {
-        ConvFwdTabs t = conv_fwd_tabs(cg[l], NA);
+        ConvGeom ag = cg[l];
+        ag.ldx = ag.ldy = 0;                      // the acting pass keeps dense buffers of its own
+        ConvFwdTabs t = conv_fwd_tabs(ag, NA);
         add_launch(ops_act, "act_conv", 0,
-                   {conv_fwd(io[l], t, cg[l], P + ex[0].w[l], P + ex[0].b[l], io[l + 1], ACT_RELU, 0.f)});
+                   {conv_fwd(io[l], t, ag, P + ex[0].w[l], P + ex[0].b[l], io[l + 1], ACT_RELU, 0.f)});
       }
       add_launch(ops_act, "act_fc", 0,
                  {dense_fwd(aa3, 1024, 1024, nullptr, 0, 0, NA, P + ex[0].fw, 512, P + ex[0].fb, afeat, ldf, ACT_RELU)});
@@ -1739,7 +1840,7 @@ int grl_ctx::plan_sac() {
   if (cnn) {
     dbg["x_obs"] = {x_obs, (int64_t)B * img_elems};
     dbg["x_next"] = {x_next, (int64_t)B * img_elems};
-    dbg["a1_pi"] = {a1[0], (int64_t)B * 225 * 32};
+    dbg["a1_pi"] = {a1[0], (int64_t)B * 225 * 32};   // (side-by-side layout: the first half of the pair buffer, stride 64)
     dbg["a2_pi"] = {a2[0], (int64_t)B * 36 * 64};
     dbg["a3_pi"] = {a3[0], (int64_t)B * 1024};
     dbg["g1_vf"] = {g1[1], (int64_t)B * 225 * 32};
@@ -3210,3 +3311,10 @@ int grl_profile_dump(grl_handle h, char* buf, int cap) {
 }
 
 }  // extern "C"
+
+#ifdef GRL_TILE_TRACE
+// measurement build only (scripts/tile_trace.sh): copy the per-workgroup records of the last weight-gradient launch
+extern "C" int grl_debug_tile_trace(unsigned long long* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grl::grl_tile_trace), (size_t)n_words * 8);
+}
+#endif

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
 
   // flat tile list: {problem, split, i-tile, j-tile}; heavy problems first (built on the host)
   const int4 tl = tiles[blockIdx.x];
-  const IgemmProb* __restrict__ pb = probs + tl.x;
+  const IgemmProb* __restrict__ pb = probs + blockIdx.x;   // one descriptor COPY per tile (see add_launch): no tile -> descriptor hop
   const int M = pb->M, N = pb->N, K = pb->K;
   const int i0 = tl.z * BI, j0 = tl.w * BJ;
   const int r_begin = tl.y * pb->k_chunk;

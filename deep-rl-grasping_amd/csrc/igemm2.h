@@ -79,7 +79,7 @@ struct I2Lds {
 // one tile; `lds` is the workgroup's staging area (I2Lds<...>::value floats, 16-byte aligned).  A function, not the
 // kernel, so that one launch can carry tiles of two instantiations (igemm2_pair_kernel).
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ probs, const int4 tl, float* __restrict__ lds) {
+__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, const int4 tl, float* __restrict__ lds) {
   using C = I2Cfg<CFG>;
   constexpr int BM = C::BM, BN = C::BN, WK = C::WK, FM = C::FM, FN = C::FN, WN = C::WN, WM = C::WM;
   constexpr bool ONES = (FLAGS & I2F_ONES) != 0, KTAIL = (FLAGS & I2F_KTAIL) != 0;
@@ -94,12 +94,11 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ probs,
 
 #ifdef I2_TIMING
 #define I2_STAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) { \
-    unsigned long long* d_ = (unsigned long long*)probs[0].dbg_t; if (d_) d_[(blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 16 : 8)) + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    unsigned long long* d_ = (unsigned long long*)pb->dbg_t; if (d_) d_[(blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 16 : 8)) + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define I2_STAMP(k) do { } while (0)
 #endif
   I2_STAMP(0);
-  const IgemmProb* __restrict__ pb = probs + tl.x;
   const int N = pb->N, K = pb->K;
   const int ones_i = pb->p_ones_i;
   const int M = ONES ? pb->M - 1 : pb->M;   // rows tiled; the ones row is handled by row tile 0
@@ -620,11 +619,37 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ probs,
   I2_STAMP(4);
 }
 
+#ifdef GRL_TILE_TRACE
+// Measurement build only (scripts/tile_trace.sh): every workgroup of a weight-gradient launch records
+// {start, end (100 MHz device clock), HW_ID | XCC_ID << 32, tile} -- the schedule of the launch as the hardware ran it.
+__device__ unsigned long long grl_tile_trace[6 * 4096];
+#endif
+
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
                                                     const int4* __restrict__ tiles) {
   __shared__ __attribute__((aligned(16))) float lds[I2Lds<PL, QL, CFG>::value];
-  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs, tiles[blockIdx.x], lds);
+#ifdef GRL_TILE_TRACE
+  unsigned long long t0 = 0, c0 = 0;
+  if (PL == I2_P_ALONG_I) { t0 = wall_clock64(); c0 = __builtin_amdgcn_s_memtime(); }
+#endif
+  // `probs` holds one descriptor copy per workgroup (add_launch): the tile entry and the descriptor are fetched side
+  // by side instead of one after the other -- one dependent memory round trip less before the first operand load
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds);
+#ifdef GRL_TILE_TRACE
+  if (PL == I2_P_ALONG_I && threadIdx.x == 0 && blockIdx.x < 4096) {
+    const int4 tl = tiles[blockIdx.x];
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // HW_REG_XCC_ID[3:0]
+    unsigned long long* d = grl_tile_trace + 6 * blockIdx.x;
+    d[0] = t0; d[1] = wall_clock64(); d[4] = c0; d[5] = __builtin_amdgcn_s_memtime();
+    const IgemmProb* pb = probs + blockIdx.x;
+    const int chunk = min(pb->K - tl.y * pb->k_chunk, pb->k_chunk);
+    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40);
+    d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
+           ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
+  }
+#endif
 }
 
 // Two kinds of tiles in one launch: blocks [0, n_a) run kind A -- the stage the launch exists for, on the critical
@@ -635,8 +660,8 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
                                                          const IgemmProb* __restrict__ pb, const int4* __restrict__ tb) {
   constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value;
   __shared__ __attribute__((aligned(16))) float lds[LA > LB ? LA : LB];
-  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa, ta[blockIdx.x], lds);
-  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb, tb[blockIdx.x - n_a], lds);
+  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + blockIdx.x, ta[blockIdx.x], lds);
+  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + (blockIdx.x - n_a), tb[blockIdx.x - n_a], lds);
 }
 
 #endif  // GRL_HOSTEMU

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void igemm_sk_kernel(const IgemmProb* __restri
   float* Qs = lds + 2 * PSZ;
 
   const int4 wk = work[blockIdx.x];
-  const IgemmProb* __restrict__ pb = probs + wk.x;
+  const IgemmProb* __restrict__ pb = probs + blockIdx.x;   // per-workgroup descriptor copy (add_launch)
   const int M = pb->M, N = pb->N;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   typedef const GRL_GLOBAL int32_t* gci32;

@@ -4,11 +4,11 @@
 // TEST-ONLY reference of the v2 tile semantics (see hostemu.h): tile = BM x BN of CFG; the ones row
 // (p_ones_i == M-1) is produced by row tile 0 and excluded from the row tiling.
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-void igemm2_tile(const IgemmProb* probs, const int4 tl) {
+void igemm2_tile(const IgemmProb* probs, const int4 tl) {   // probs: THIS tile's descriptor copy
   if (threadIdx.x != 0) return;
-  if (((FLAGS & 1) != 0) != (probs[tl.x].p_ones_i >= 0)) abort();
+  if (((FLAGS & 1) != 0) != (probs[0].p_ones_i >= 0)) abort();
   const int BM = i2_bm(CFG), BN = i2_bn(CFG);
-  const IgemmProb& pb = probs[tl.x];
+  const IgemmProb& pb = probs[0];
   if ((PM != PM_AFFINE) != (pb.p_tab_i != nullptr && pb.p_tab_r != nullptr)) abort();
   if ((PM == PM_TABLE_MASK) != (pb.p_vmask_i != nullptr)) abort();
   if ((QM == QM_TABLE) != (pb.q_tab_r != nullptr)) abort();
@@ -52,11 +52,11 @@ void igemm2_tile(const IgemmProb* probs, const int4 tl) {
 }
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
 void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
-  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs, tiles[blockIdx.x]);
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x]);
 }
 // two kinds of tiles in one launch: blocks [0, n_a) run kind A (the launch's own stage), the rest kind B (fillers)
 template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
 void igemm2_pair_kernel(const IgemmProb* pa, const int4* ta, int n_a, const IgemmProb* pb, const int4* tb) {
-  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa, ta[blockIdx.x]);
-  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb, tb[blockIdx.x - n_a]);
+  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + blockIdx.x, ta[blockIdx.x]);
+  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + (blockIdx.x - n_a), tb[blockIdx.x - n_a]);
 }

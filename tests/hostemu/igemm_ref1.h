@@ -6,7 +6,7 @@ template <int PM, int QM, bool P_CONTIG_R, bool Q_CONTIG_J, int NP>
 void igemm_kernel(const IgemmProb* probs, const int4* tiles) {
   if (threadIdx.x != 0) return;
   const int4 tl = tiles[blockIdx.x];
-  const IgemmProb& pb = probs[tl.x];
+  const IgemmProb& pb = probs[blockIdx.x];   // per-workgroup descriptor copy
   // the launch-time mode must agree with what the descriptor carries
   if ((PM != PM_AFFINE) != (pb.p_tab_i != nullptr && pb.p_tab_r != nullptr)) abort();
   if ((PM == PM_TABLE_MASK) != (pb.p_vmask_i != nullptr)) abort();

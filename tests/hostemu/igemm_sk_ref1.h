@@ -6,7 +6,7 @@ template <int K>
 void igemm_sk_kernel(const IgemmProb* probs, const int4* work) {
   if (threadIdx.x != 0) return;
   const int4 wk = work[blockIdx.x];
-  const IgemmProb& pb = probs[wk.x];
+  const IgemmProb& pb = probs[blockIdx.x];   // per-workgroup descriptor copy
   if (pb.K != K || pb.N > 32 || !pb.p_tab_i || pb.p_vmask_i || pb.q_tab_r || pb.c_tab_i || pb.relu_mask || pb.accumulate ||
       pb.split != 1)
     abort();
