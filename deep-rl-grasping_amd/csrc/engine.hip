@@ -113,6 +113,7 @@ struct Launch {
   int4* d_tiles = nullptr;
   int n_tiles = 0;
   Launch* filler = nullptr;     // tiles of a second instantiation carried by the same launch (igemm2_pair_kernel)
+  unsigned dyn_lds = 0;         // extra LDS bytes requested per workgroup: caps the workgroups a CU holds at once
 };
 
 struct Op {
@@ -783,27 +784,28 @@ struct grl_ctx {
     }
     const int BMt = l->v2 ? i2_bm(l->cfg) : 64, BNt = l->v2 ? i2_bn(l->cfg) : 64;
 
-    std::vector<int4> tiles;
-    std::vector<int> order(l->probs.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return std::min(l->probs[a].K, l->probs[a].k_chunk) > std::min(l->probs[b].K, l->probs[b].k_chunk);
-    });
     double flops = 0;
-    for (int pi : order) {
-      const IgemmProb& p = l->probs[pi];
-      flops += 2.0 * p.M * p.N * p.K;
-      const int Mt = (l->v2 && p.p_ones_i >= 0) ? p.M - 1 : p.M;   // v2: the ones row rides on row tile 0
-      for (int s = 0; s < p.split; ++s)
-        for (int ti = 0; ti < (Mt + BMt - 1) / BMt; ++ti)
-          for (int tj = 0; tj < (p.N + BNt - 1) / BNt; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
-    }
+    for (auto& p : l->probs) flops += 2.0 * p.M * p.N * p.K;
+    std::vector<int4> tiles = tile_list(l->probs, l->v2, BMt, BNt);
     if (variant == 2) tiles = xcd_order(tiles, l->probs, BMt, BNt);
+    if (variant == 2 && l->v2) {
+      if (const char* e = getenv("GRL_WG_DYNLDS")) l->dyn_lds = (unsigned)atoi(e);
+    }
     l->n_tiles = (int)tiles.size();
     if (getenv("GRL_PLAN_DUMP"))
       fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu  tiles %d\n", tag.c_str(),
               variant, l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size(), l->n_tiles);
-    l->d_probs = upload_vec(wk, per_tile_descs(l->probs, tiles));
+    {
+      std::vector<IgemmProb> descs = per_tile_descs(l->probs, tiles);
+#ifdef GRL_TILE_TRACE
+      unsigned long long* tr = (unsigned long long*)wk.take(descs.size() * 48);   // measurement build: one 6-word record per workgroup
+      zero_once.push_back({tr, descs.size() * 48});
+      for (size_t i = 0; i < descs.size(); ++i) descs[i].dbg_t = tr + 6 * i;
+      static int trace_seq = 0;
+      dbg["trace" + std::to_string(trace_seq++) + "_" + tag] = {(const float*)tr, (int64_t)descs.size() * 12};
+#endif
+      l->d_probs = upload_vec(wk, descs);
+    }
     l->d_tiles = upload_vec(wk, tiles);
     launches.push_back(l);
     Op op;
@@ -814,7 +816,7 @@ struct grl_ctx {
       if (l->v2) {
         const int key = l->variant * 10000 + l->pm * 1000 + l->qm * 100 + l->cfg * 10 + l->flags;
 #define GRL_I2(PLv, QLv, PMv, QMv, CF, FL) \
-  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, 0, s, l->d_probs, l->d_tiles)
+  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, l->dyn_lds, s, l->d_probs, l->d_tiles)
 #define GRL_I2_CFGS(base, PLv, QLv, PMv, QMv, FL)                           \
   case base + 0 + FL: GRL_I2(PLv, QLv, PMv, QMv, 0, FL); break;              \
   case base + 10 + FL: GRL_I2(PLv, QLv, PMv, QMv, 1, FL); break;             \
@@ -868,6 +870,80 @@ struct grl_ctx {
     ops.push_back(std::move(op));
   }
 
+  // work list of a launch: {problem, reduction chunk, row tile, column tile}, longest reduction chunks first
+  static std::vector<int4> tile_list(const std::vector<IgemmProb>& probs, bool v2, int BMt, int BNt) {
+    std::vector<int4> tiles;
+    std::vector<int> order(probs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return std::min(probs[a].K, probs[a].k_chunk) > std::min(probs[b].K, probs[b].k_chunk);
+    });
+    for (int pi : order) {
+      const IgemmProb& p = probs[pi];
+      const int Mt = (v2 && p.p_ones_i >= 0) ? p.M - 1 : p.M;   // v2: the ones row rides on row tile 0
+      for (int s = 0; s < p.split; ++s)
+        for (int ti = 0; ti < (Mt + BMt - 1) / BMt; ++ti)
+          for (int tj = 0; tj < (p.N + BNt - 1) / BNt; ++tj) tiles.push_back(make_int4(pi, s, ti, tj));
+    }
+    return tiles;
+  }
+
+  // Reduction splits of the three convolution weight gradients, chosen with the placement model of xcd_order: the
+  // merged launch lasts as long as its fullest CU works (0.48 us per 32-deep slab it holds, scripts/tile_trace.py) and
+  // every extra split adds a slab the reduction pass has to write and read back (~4 TB/s effective).  The dense
+  // problems of the same launch enter with their shapes only.  Measured at the headline shape: hand-tuned 72/12/6
+  // (fullest CU 56 slabs) 4 560 updates/s, model's choice (49 slabs) 4 590.
+  void pick_wgrad_splits(const ConvGeom* cg, const ConvFwdTabs* ft, int n_side, int wsplit[3]) {
+    auto shape = [](int M, int N, int K, int split) {
+      IgemmProb p = blank();
+      p.M = M; p.N = N; p.K = K; p.p_ones_i = M - 1;
+      set_split(p, split);
+      return p;
+    };
+    std::vector<IgemmProb> light;
+    for (int n = 0; n < 2; ++n) light.push_back(shape(1024 + 1, 512, B, 1));
+    const MlpP* ms[4] = {&m_pi, &m_vf, &m_qf1, &m_qf2};
+    for (const MlpP* m : ms) {
+      int d = m->in_dim;
+      for (int l = 0; l < L; ++l) { light.push_back(shape(d + 1, hid[l], B, 1)); d = hid[l]; }
+      for (int k = 0; k < m->n_out; ++k) light.push_back(shape(d + 1, m->out_dim, B, 1));
+    }
+    double best = 1e30;
+    const int rows[3] = {(ft[0].M + 31) / 32, (ft[1].M + 31) / 32, (ft[2].M + 31) / 32};   // 32-deep slabs of each reduction
+    auto cands = [](int r) {   // splits that give chunks of 12 .. 32 slabs
+      std::vector<int> v;
+      int last = -1;
+      for (int per = 32; per >= 12; --per) {
+        const int s = std::max(1, (r + per - 1) / per);
+        if (s != last) v.push_back(s);
+        last = s;
+      }
+      return v;
+    };
+    for (int s1 : cands(rows[0]))
+      for (int s2 : cands(rows[1]))
+        for (int s3 : cands(rows[2])) {
+          std::vector<IgemmProb> pr;
+          double slab_bytes = 0;
+          const int sp[3] = {s1, s2, s3};
+          for (int l = 2; l >= 0; --l) {
+            const int reps = (l == 0 && n_side > 1) ? 1 : 2;
+            const int N = (l == 0 && n_side > 1) ? n_side * cg[l].Cout : cg[l].Cout;
+            for (int n = 0; n < reps; ++n) {
+              pr.push_back(shape(cg[l].K() + 1, N, ft[l].M, sp[l]));
+              slab_bytes += 4.0 * pr.back().M * N * pr.back().split;
+            }
+          }
+          pr.insert(pr.end(), light.begin(), light.end());
+          double mx = 0;
+          xcd_order(tile_list(pr, true, 64, 64), pr, 64, 64, &mx);
+          const double cost = 0.48 * mx + 2.0 * slab_bytes / 4e6;   // us
+          if (cost < best) { best = cost; wsplit[0] = s1; wsplit[1] = s2; wsplit[2] = s3; }
+        }
+    if (getenv("GRL_PLAN_DUMP"))
+      fprintf(stderr, "grl plan: weight-gradient reduction splits %d / %d / %d (model cost %.1f us)\n", wsplit[0], wsplit[1], wsplit[2], best);
+  }
+
   // One descriptor COPY per workgroup, in work-list order.  A workgroup's first operand load sits at the end of a chain
   // of dependent memory round trips (~1.2 us each on MI355X): work-list entry -> problem descriptor -> address tables ->
   // data.  Indexing the descriptors by blockIdx like the work list itself lets the first two travel together.
@@ -886,7 +962,8 @@ struct grl_ctx {
   // tiles are grouped by chunk, the groups dealt to 8 queues (least work first, heavy groups first) and the list is
   // re-emitted so that position i comes from queue i % 8.  Same tiles, same arithmetic; GRL_NO_XCD_ORDER=1 keeps the
   // list order (test / measurement switch).
-  static std::vector<int4> xcd_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt) {
+  static std::vector<int4> xcd_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt,
+                                     double* model_max = nullptr) {
     if (const char* e = getenv("GRL_NO_XCD_ORDER")) if (atoi(e)) return tiles;
     constexpr int NX = 8;
     struct Grp { std::vector<int4> t; double w = 0; };
@@ -913,6 +990,34 @@ struct grl_ctx {
       q[best].insert(q[best].end(), g.t.begin(), g.t.end());
       load[best] += g.w;
     }
+    // Inside an XCD the workgroups go to its 32 CUs round-robin and (at <= 4 workgroups per CU) all at once: list
+    // position j of a queue lands on CU j % 32 (scripts/tile_trace.py shows the schedule as the hardware ran it).  A CU
+    // then works through the SUM of the reductions it holds, so each queue is arranged longest-processing-time-first
+    // over 32 bins -- bin c owns positions c, c + 32, ... -- instead of heavy-first order (57 vs 47 slabs on the
+    // fullest CU at the headline shape).
+    auto slabs_of = [&](const int4& t) {
+      const IgemmProb& p = probs[t.x];
+      return (std::min(p.K - t.y * p.k_chunk, p.k_chunk) + 31) / 32;
+    };
+    for (int x = 0; x < NX; ++x) {
+      std::vector<int4>& qx = q[x];
+      const int n = (int)qx.size();
+      if (n <= 32) continue;
+      std::stable_sort(qx.begin(), qx.end(), [&](const int4& a, const int4& b) { return slabs_of(a) > slabs_of(b); });
+      std::vector<std::vector<int4>> bin(32);
+      int load[32] = {0};
+      for (const int4& t : qx) {
+        int best = -1;
+        for (int c = 0; c < 32; ++c) {
+          const int cap = (n - c + 31) / 32;
+          if ((int)bin[c].size() >= cap) continue;
+          if (best < 0 || load[c] < load[best]) best = c;
+        }
+        bin[best].push_back(t);
+        load[best] += slabs_of(t);
+      }
+      for (int j = 0; j < n; ++j) qx[j] = bin[j % 32][j / 32];
+    }
     std::vector<int4> out;
     out.reserve(tiles.size());
     size_t head[NX] = {0};
@@ -924,6 +1029,19 @@ struct grl_ctx {
           if (q[y].size() - head[y] > most) { most = q[y].size() - head[y]; x = y; }
       }
       out.push_back(q[x][head[x]++]);
+    }
+    {   // reduction slabs each CU ends up holding if workgroup b lands on XCD b % 8, CU (b / 8) % 32
+      double cu[256] = {0}, tot = 0, mx = 0;
+      for (size_t i = 0; i < out.size(); ++i) {
+        const double w = slabs_of(out[i]);
+        cu[(i % 8) * 32 + (i / 8) % 32] += w;
+        tot += w;
+      }
+      for (double c : cu) mx = std::max(mx, c);
+      if (model_max) *model_max = mx + (out.size() > 1024 ? 1e6 : 0);   // more than 4 per CU: not all resident, the model does not hold
+      else if (getenv("GRL_PLAN_DUMP"))
+        fprintf(stderr, "grl plan: weight-gradient list of %zu tiles: %.0f slabs, per CU avg %.1f max %.0f (round-robin placement model)\n",
+                out.size(), tot, tot / 256, mx);
     }
     return out;
   }
@@ -1495,7 +1613,8 @@ int grl_ctx::plan_sac() {
     for (int n = 0; n < 2; ++n)
       for (auto& cl : bc2) bwd_pr[2].push_back(conv_bwd(g2[n], cl, cg[1], P + ex[n].w[1], g1[n], a1[n]));
     // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
-    int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3, tuned with the merged launch (GRL_WG_SPLIT=a,b,c overrides)
+    int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3 (GRL_WG_SPLIT=a,b,c overrides the model's choice)
+    pick_wgrad_splits(cg, ft, ld1 == 64 ? 2 : 1, wsplit);
     if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
     if (ld1 == 64) {   // conv1 of both networks: one problem over the side-by-side gradient buffer, columns 32n.. -> net n
       IgemmProb p = conv_wgrad(x_obs, ft[0], cg[0], g1[0], nullptr, wsplit[0], 2);
@@ -3311,10 +3430,3 @@ int grl_profile_dump(grl_handle h, char* buf, int cap) {
 }
 
 }  // extern "C"
-
-#ifdef GRL_TILE_TRACE
-// measurement build only (scripts/tile_trace.sh): copy the per-workgroup records of the last weight-gradient launch
-extern "C" int grl_debug_tile_trace(unsigned long long* out, int n_words) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grl::grl_tile_trace), (size_t)n_words * 8);
-}
-#endif

@@ -76,6 +76,15 @@ struct I2Lds {
   static constexpr int value = 2 * (PSZ + QSZ) > RED ? 2 * (PSZ + QSZ) : RED;
 };
 
+#ifdef GRL_TILE_TRACE
+// Measurement build only (scripts/tile_trace.sh): every workgroup of every igemm2 launch records, in the 6-word slot its
+// descriptor copy points to (dbg_t), {start, end (100 MHz device clock), HW_ID | XCC_ID << 32 | slabs << 40, tile,
+// first barrier passed, reduction loop done} -- the schedule of the launch as the hardware ran it.
+#define I2_TRACE(k) do { if (threadIdx.x == 0 && pb->dbg_t) ((unsigned long long*)pb->dbg_t)[k] = wall_clock64(); } while (0)
+#else
+#define I2_TRACE(k) do { } while (0)
+#endif
+
 // one tile; `lds` is the workgroup's staging area (I2Lds<...>::value floats, 16-byte aligned).  A function, not the
 // kernel, so that one launch can carry tiles of two instantiations (igemm2_pair_kernel).
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
@@ -328,6 +337,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   __syncthreads();
 
   I2_STAMP(2);
+  I2_TRACE(4);
   constexpr int NMF = 16 * FM * FN;            // MFMAs of one slab per wave
   constexpr int NST = NVP + NVQ;               // staged vectors per thread and slab
   static_assert(2 * NST + 1 <= NMF - 3 - (ONES ? 1 : 0), "staging work must fit into the MFMA gaps of a slab");
@@ -408,6 +418,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   if (s < nslab) slab_body(s, pv, qv, p_kb, q_kb, tbA);
 
   I2_STAMP(3);
+  I2_TRACE(5);
   // ------------------------------------------------------------------ epilogue
   const gf32 cbase = (gf32)(pb->c + (long)tl.y * pb->slab_stride);
   const int ldc = pb->ldc;
@@ -619,32 +630,26 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   I2_STAMP(4);
 }
 
-#ifdef GRL_TILE_TRACE
-// Measurement build only (scripts/tile_trace.sh): every workgroup of a weight-gradient launch records
-// {start, end (100 MHz device clock), HW_ID | XCC_ID << 32, tile} -- the schedule of the launch as the hardware ran it.
-__device__ unsigned long long grl_tile_trace[6 * 4096];
-#endif
 
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
                                                     const int4* __restrict__ tiles) {
   __shared__ __attribute__((aligned(16))) float lds[I2Lds<PL, QL, CFG>::value];
 #ifdef GRL_TILE_TRACE
-  unsigned long long t0 = 0, c0 = 0;
-  if (PL == I2_P_ALONG_I) { t0 = wall_clock64(); c0 = __builtin_amdgcn_s_memtime(); }
+  const unsigned long long t0 = wall_clock64();
 #endif
   // `probs` holds one descriptor copy per workgroup (add_launch): the tile entry and the descriptor are fetched side
   // by side instead of one after the other -- one dependent memory round trip less before the first operand load
   igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds);
 #ifdef GRL_TILE_TRACE
-  if (PL == I2_P_ALONG_I && threadIdx.x == 0 && blockIdx.x < 4096) {
+  const IgemmProb* pb = probs + blockIdx.x;
+  if (threadIdx.x == 0 && pb->dbg_t) {
     const int4 tl = tiles[blockIdx.x];
     const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
     const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // HW_REG_XCC_ID[3:0]
-    unsigned long long* d = grl_tile_trace + 6 * blockIdx.x;
-    d[0] = t0; d[1] = wall_clock64(); d[4] = c0; d[5] = __builtin_amdgcn_s_memtime();
-    const IgemmProb* pb = probs + blockIdx.x;
     const int chunk = min(pb->K - tl.y * pb->k_chunk, pb->k_chunk);
+    unsigned long long* d = (unsigned long long*)pb->dbg_t;
+    d[0] = t0; d[1] = wall_clock64();
     d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40);
     d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
            ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);

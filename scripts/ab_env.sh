@@ -1,11 +1,8 @@
 #!/bin/bash
-# development: A/B an environment switch of the launch plan, e.g.  scripts/ab_env.sh GRL_NO_XCD=1
+# development: A/B environment switches of the launch plan on one box, e.g.  scripts/ab_env.sh GRL_NO_XCD_ORDER=1 "GRL_WG_DYNLDS=20480 GRL_X=1"
+q() { python bench.py --no-learn-loop --no-cpu-baseline --repeats 3 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['step_kernel_ms']
+print('%9.1f updates/s | ' % d['value'] + ' '.join('%s %.1f' % (n.replace('_fwd','F').replace('_bwd','B'), 1e3*v) for n, v in sorted(k.items(), key=lambda kv: -kv[1])))"; }
 for setting in "_DUMMY=0" "$@"; do
-  echo "== $setting"
-  env $setting timeout 200 python bench.py --steps 600 --warmup 50 --no-cpu-baseline 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.readlines()[-1])
-print(d['value'], d['ms_per_step'])
-for k, v in sorted(d['roofline']['step_kernel_ms'].items(), key=lambda kv: -kv[1]): print('   %-14s %.1f' % (k, 1e3 * v))
-"
+  printf "%-34s: " "$setting"; env $setting bash -c "$(declare -f q); q"
 done

@@ -6,5 +6,5 @@
 set -e
 cd "$(dirname "$0")/.."
 sfx="$1"; shift || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DGRL_TILE_TRACE "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -DGRL_TILE_TRACE "$@" \
   deep-rl-grasping_amd/csrc/engine.hip -o deep-rl-grasping_amd/grasp_rl/libgrl_trace${sfx}.so
