@@ -964,7 +964,7 @@ struct grl_ctx {
   // list order (test / measurement switch).
   static std::vector<int4> xcd_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt,
                                      double* model_max = nullptr) {
-    if (const char* e = getenv("GRL_NO_XCD_ORDER")) if (atoi(e)) return tiles;
+    if (const char* e = getenv("GRL_NO_XCD_ORDER")) if (atoi(e) && !model_max) return tiles;   // (the split chooser still models the ordered list)
     constexpr int NX = 8;
     struct Grp { std::vector<int4> t; double w = 0; };
     std::vector<Grp> groups;
@@ -1604,6 +1604,14 @@ int grl_ctx::plan_sac() {
   std::vector<IgemmProb> dense_affine, conv_all;   // dense / conv weight-gradient problems as first built (staged plan)
   std::vector<IgemmProb> wg, wgc[3];   // weight gradients: dense layers / conv layers 1..3
   std::vector<IgemmProb> bwd_pr[3];    // backward-data stages fc, conv3, conv2 (launched below, once their fillers are known)
+  // Measured and rejected on top of the merged weight-gradient launch (MI355X, B = 256, updates/s; conv2_bwd needs 46 KB of
+  // LDS, so a CU holds three of its 1024 tiles and the launch runs as a wave of 768 plus a third-full wave of 256):
+  //  * every weight gradient except conv1's riding on conv2_bwd's launch, longest tiles first, conv1 (the only consumer
+  //    of conv2_bwd's result) as a launch of its own: the pair launch takes 57.7 us against 31.8 + 36.5, but conv1 alone
+  //    costs 13.2 us (one short tile per CU) and its 225 slabs another 8 us of reduction: 4 395 against 4 600;
+  //  * only the dense layers' weight gradients (303 tiles of 8 slabs, the length of a conv2_bwd tile) riding behind
+  //    conv2_bwd's tiles: they start when the first wave drains (18 us) and end at 36 us instead of 28: conv2_bwd
+  //    31.8 -> 41.2 us, the weight-gradient launch 36.6 -> 28.2 us, reduction +2.5 us: 4 519 against 4 580.
   if (cnn) {
     std::vector<ConvBwdClass> bc3 = conv_bwd_tabs(cg[2], B), bc2 = conv_bwd_tabs(cg[1], B);
     for (int n = 0; n < 2; ++n)

@@ -665,8 +665,28 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
                                                          const IgemmProb* __restrict__ pb, const int4* __restrict__ tb) {
   constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value;
   __shared__ __attribute__((aligned(16))) float lds[LA > LB ? LA : LB];
-  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + blockIdx.x, ta[blockIdx.x], lds);
-  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + (blockIdx.x - n_a), tb[blockIdx.x - n_a], lds);
+  const int b = (int)blockIdx.x;
+  const bool is_a = b < n_a;
+  const int k = is_a ? b : b - n_a;
+#ifdef GRL_TILE_TRACE
+  const unsigned long long t0 = wall_clock64();
+#endif
+  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], lds);
+  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + k, tb[k], lds);
+#ifdef GRL_TILE_TRACE
+  const IgemmProb* pq = is_a ? pa + k : pb + k;
+  if (threadIdx.x == 0 && pq->dbg_t) {
+    const int4 tl = is_a ? ta[k] : tb[k];
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    const int chunk = min(pq->K - tl.y * pq->k_chunk, pq->k_chunk);
+    unsigned long long* d = (unsigned long long*)pq->dbg_t;
+    d[0] = t0; d[1] = wall_clock64();
+    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40);
+    d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
+           ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
+  }
+#endif
 }
 
 #endif  // GRL_HOSTEMU

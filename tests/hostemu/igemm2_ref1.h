@@ -57,6 +57,9 @@ void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
 // two kinds of tiles in one launch: blocks [0, n_a) run kind A (the launch's own stage), the rest kind B (fillers)
 template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
 void igemm2_pair_kernel(const IgemmProb* pa, const int4* ta, int n_a, const IgemmProb* pb, const int4* tb) {
-  if ((int)blockIdx.x < n_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + blockIdx.x, ta[blockIdx.x]);
-  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + (blockIdx.x - n_a), tb[blockIdx.x - n_a]);
+  const int b = (int)blockIdx.x;
+  const bool is_a = b < n_a;
+  const int k = is_a ? b : b - n_a;
+  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k]);
+  else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + k, tb[k]);
 }
