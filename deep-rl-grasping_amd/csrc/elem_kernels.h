@@ -763,6 +763,14 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
       const float* __restrict__ src = d.src + (d.row_len > 0 ? (long)(i / d.row_len) * d.src_ld + i % d.row_len : i);
       rs_f4 s = {0.f, 0.f, 0.f, 0.f};
       int k = 0;
+      // the pass is a chain of load batches per thread (~1 us each): 16 slabs in flight, summed in slab order
+      for (; k + 16 <= d.splits; k += 16) {
+        rs_f4 vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vv[u] = *(const rs_f4*)(src + (long)(k + u) * d.slab_stride);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += vv[u];
+      }
       for (; k + 8 <= d.splits; k += 8) {
         rs_f4 vv[8];
 #pragma unroll

@@ -893,7 +893,7 @@ struct grl_ctx {
   // every extra split adds a slab the reduction pass has to write and read back (~4 TB/s effective).  The dense
   // problems of the same launch enter with their shapes only.  Measured at the headline shape: hand-tuned 72/12/6
   // (fullest CU 56 slabs) 4 560 updates/s, model's choice (49 slabs) 4 590.
-  void pick_wgrad_splits(const ConvGeom* cg, const ConvFwdTabs* ft, int n_side, int wsplit[3]) {
+  void pick_wgrad_splits(const ConvGeom* cg, const ConvFwdTabs* ft, int n_side, int wsplit[3], int rider_budget) {
     auto shape = [](int M, int N, int K, int split) {
       IgemmProb p = blank();
       p.M = M; p.N = N; p.K = K; p.p_ones_i = M - 1;
@@ -908,6 +908,7 @@ struct grl_ctx {
       for (int l = 0; l < L; ++l) { light.push_back(shape(d + 1, hid[l], B, 1)); d = hid[l]; }
       for (int k = 0; k < m->n_out; ++k) light.push_back(shape(d + 1, m->out_dim, B, 1));
     }
+    take_riders(light, rider_budget);   // the dense problems that will ride on conv3_bwd's launch (same rule as the plan)
     double best = 1e30;
     const int rows[3] = {(ft[0].M + 31) / 32, (ft[1].M + 31) / 32, (ft[2].M + 31) / 32};   // 32-deep slabs of each reduction
     auto cands = [](int r) {   // splits that give chunks of 12 .. 32 slabs
@@ -937,11 +938,42 @@ struct grl_ctx {
           pr.insert(pr.end(), light.begin(), light.end());
           double mx = 0;
           xcd_order(tile_list(pr, true, 64, 64), pr, 64, 64, &mx);
-          const double cost = 0.48 * mx + 2.0 * slab_bytes / 4e6;   // us
+          // us: the fullest CU's slabs + the reduction pass: slab bytes written and read back, and its per-thread chain of
+          // load batches, which grows with the largest split (measured 13.5 / 15.0 / 19.3 us at 57 / 86-113 / 225 splits)
+          const double cost = 0.48 * mx + 2.0 * slab_bytes / 4e6 + 0.02 * std::max(s1, std::max(s2, s3));
           if (cost < best) { best = cost; wsplit[0] = s1; wsplit[1] = s2; wsplit[2] = s3; }
         }
     if (getenv("GRL_PLAN_DUMP"))
       fprintf(stderr, "grl plan: weight-gradient reduction splits %d / %d / %d (model cost %.1f us)\n", wsplit[0], wsplit[1], wsplit[2], best);
+  }
+
+  // tiles a launch of these problems will have, and its workgroup shape (mirrors add_launch; -1: not on igemm2_kernel)
+  static int planned_tiles(const std::vector<IgemmProb>& probs, int variant, const std::string& tag, int* cfg_out) {
+    const char* nv2 = getenv("GRL_NO_V2");
+    bool v2 = !(nv2 && nv2[0] == '1');
+    for (auto& p : probs) v2 = v2 && v2_prob_ok(p, variant) && (p.K % 4) == 0 && p.p_ones_i < 0;
+    if (!v2 || probs.empty()) return -1;
+    const int cfg = v2_pick_cfg(probs, variant, tag);
+    if (cfg_out) *cfg_out = cfg;
+    return (int)tile_list(probs, true, i2_bm(cfg), i2_bn(cfg)).size();
+  }
+  // Slots the last dispatch round of a launch leaves empty (workgroup b lands on XCD b % 8, CU (b / 8) % 32: a launch of
+  // T tiles fills T / 256 rounds completely and T % 256 CUs once more).  Only for launches a CU holds completely.
+  static int free_slots(int tiles, int max_per_cu) {
+    if (tiles <= 0) return 0;
+    const int rounds = (tiles + 255) / 256;
+    return rounds <= max_per_cu ? rounds * 256 - tiles : 0;
+  }
+  // problems of `from` (in order) whose 64x64 tiles fit into `budget` slots; they are removed from `from`
+  static std::vector<IgemmProb> take_riders(std::vector<IgemmProb>& from, int budget) {
+    std::vector<IgemmProb> out, rest;
+    for (auto& p : from) {
+      const int Mt = p.p_ones_i >= 0 ? p.M - 1 : p.M;
+      const int t = p.split * ((Mt + 63) / 64) * ((p.N + 63) / 64);
+      if (t <= budget) { out.push_back(p); budget -= t; } else rest.push_back(p);
+    }
+    from = rest;
+    return out;
   }
 
   // One descriptor COPY per workgroup, in work-list order.  A workgroup's first operand load sits at the end of a chain
@@ -1601,6 +1633,8 @@ int grl_ctx::plan_sac() {
   }
   // =============================================================== backward through the two CNNs
   bool fillers_on = false, only_vec_dense = false;
+  int rider_budget = 0;                            // empty slots of conv3_bwd's last dispatch round (see below)
+  std::vector<Op> conv3_bwd_plain;                 // conv3_bwd without riders, for the staged data-parallel plan
   std::vector<IgemmProb> dense_affine, conv_all;   // dense / conv weight-gradient problems as first built (staged plan)
   std::vector<IgemmProb> wg, wgc[3];   // weight gradients: dense layers / conv layers 1..3
   std::vector<IgemmProb> bwd_pr[3];    // backward-data stages fc, conv3, conv2 (launched below, once their fillers are known)
@@ -1621,8 +1655,23 @@ int grl_ctx::plan_sac() {
     for (int n = 0; n < 2; ++n)
       for (auto& cl : bc2) bwd_pr[2].push_back(conv_bwd(g2[n], cl, cg[1], P + ex[n].w[1], g1[n], a1[n]));
     // conv / fc weight gradients (split reductions land in slabs, summed by reduce_slabs)
+    // conv3_bwd (576 tiles of the 32x64 shape at B = 256, three per CU) fills two dispatch rounds and a quarter of the third:
+    // 192 CUs hold two tiles, 64 hold three, and the launch lasts as long as those 64.  Dense-layer weight gradients
+    // whose operands are complete by then (d feat, head gradients) and whose tiles are as long as conv3_bwd's (reduction
+    // = the batch, 8 slabs) ride in the empty slots of that round -- list positions 576.. land exactly on the CUs that
+    // hold two -- and leave the merged weight-gradient launch.  GRL_NO_CONV3_RIDERS=1 switches it off.
+    {
+      int cfg3 = -1;
+      const int t3 = planned_tiles(bwd_pr[1], 1, "conv3_bwd", &cfg3);
+      const char* nr = getenv("GRL_NO_CONV3_RIDERS");
+      const char* nfl0 = getenv("GRL_FILLERS");
+      const char* nm0 = getenv("GRL_NO_WGRAD_MERGE");
+      const char* le0 = getenv("GRL_LANES");
+      const bool off = (nr && atoi(nr)) || (nfl0 && nfl0[0] == '1') || (nm0 && nm0[0] == '1') || (le0 && le0[0] == '1');
+      rider_budget = (!off && cfg3 == 3) ? free_slots(t3, 3) : 0;
+    }
     int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3 (GRL_WG_SPLIT=a,b,c overrides the model's choice)
-    pick_wgrad_splits(cg, ft, ld1 == 64 ? 2 : 1, wsplit);
+    pick_wgrad_splits(cg, ft, ld1 == 64 ? 2 : 1, wsplit, rider_budget);
     if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
     if (ld1 == 64) {   // conv1 of both networks: one problem over the side-by-side gradient buffer, columns 32n.. -> net n
       IgemmProb p = conv_wgrad(x_obs, ft[0], cg[0], g1[0], nullptr, wsplit[0], 2);
@@ -1754,7 +1803,9 @@ int grl_ctx::plan_sac() {
         wg_merged.clear(); wgc[2].clear(); wgc[1].clear();
       } else {
         add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
-        add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1]);
+        std::vector<IgemmProb> riders = take_riders(wg_merged, rider_budget);
+        if (!riders.empty()) add_launch(conv3_bwd_plain, "conv3_bwd", 1, bwd_pr[1]);
+        add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1], "wgrad_dense", 2, riders);
         add_launch(ops_grads, "conv2_bwd", 1, bwd_pr[2]);
       }
     }
@@ -1812,8 +1863,11 @@ int grl_ctx::plan_sac() {
       if (staged_ok) {
         for (int k = 0; k <= cut; ++k) st0_ops.push_back(ops_grads[k]);
         add_launch(st0_ops, "wgrad_dense", 2, dense_affine, "", 0, {}, 0);
-        for (size_t k = cut + 1; k < ops_grads.size(); ++k)
-          if (ops_grads[k].tag.compare(0, 5, "wgrad") != 0) st1_ops.push_back(ops_grads[k]);
+        for (size_t k = cut + 1; k < ops_grads.size(); ++k) {
+          if (ops_grads[k].tag.compare(0, 5, "wgrad") == 0) continue;
+          if (ops_grads[k].tag == "conv3_bwd" && !conv3_bwd_plain.empty()) st1_ops.push_back(conv3_bwd_plain[0]);   // (riders belong to stage 0 here)
+          else st1_ops.push_back(ops_grads[k]);
+        }
         add_launch(st1_ops, "wgrad_conv", 2, conv_all, "", 0, {}, 0);
       }
     }

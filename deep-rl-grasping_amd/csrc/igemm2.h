@@ -661,7 +661,8 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
     const int chunk = min(pb->K - tl.y * pb->k_chunk, pb->k_chunk);
     unsigned long long* d = (unsigned long long*)pb->dbg_t;
     d[0] = t0; d[1] = wall_clock64();
-    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40);
+    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40) |
+           ((unsigned long long)CFG << 56);
     d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
            ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
   }
@@ -693,7 +694,8 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
     const int chunk = min(pq->K - tl.y * pq->k_chunk, pq->k_chunk);
     unsigned long long* d = (unsigned long long*)pq->dbg_t;
     d[0] = t0; d[1] = wall_clock64();
-    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40);
+    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40) |
+           ((unsigned long long)(is_a ? CFGa : CFGb) << 56);
     d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
            ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
   }

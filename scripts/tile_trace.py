@@ -34,7 +34,8 @@ with torch.cuda.stream(eng.be.stream):
 detail = sys.argv[sys.argv.index("--detail") + 1] if "--detail" in sys.argv else "wgrad_conv"
 TAGS = ["conv2_fwd", "conv3_fwd", "fc_fwd", "heads_l0", "heads_dfeat", "fc_bwd", "conv3_bwd", "conv2_bwd", "wgrad_conv",
         "wgrad_dense", "wgrad_small", "heads_fwd", "heads_bwd"]
-SLAB_US = 1024 / 2400.0      # 16 dependent 32x32x2 MFMAs (64 cycles each) per wave and 32-deep slab at 2.4 GHz
+SLAB_US = 1024 / 2400.0      # 16 dependent 32x32x2 MFMAs (64 cycles each) per wave and 32-deep slab at 2.4 GHz (64x64, 128x32
+                             # shapes); the 32x64 shapes split the reduction over wave pairs / quads: 8 MFMAs per wave and slab
 
 
 def load(name):
@@ -60,6 +61,8 @@ for seq in range(40):
         hw = (rec[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
         xcc = (rec[:, 2] >> np.uint64(32)).astype(np.int64) & 0xf
         nslab = (rec[:, 2] >> np.uint64(40)).astype(np.int64) & 0xffff
+        cfg = int((rec[0, 2] >> np.uint64(56)) & np.uint64(0xf))
+        slab_us = SLAB_US * (0.5 if cfg in (2, 3) else 1.0)
         cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
         cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
         prob = (rec[:, 3] & np.uint64(0xffff)).astype(np.int64)
@@ -73,7 +76,7 @@ for seq in range(40):
         mx = max(cu_slabs.values())
         print("%-12s %5d %7.1f  | %4.1f (%4.1f..%4.1f)  %5.1f / %.2f  %4.1f (%4.1f..%4.1f) %8d | %5.1f / %3d (%3d CUs) %6.1f us" %
               (tag, n, us(t1.max()), st.mean(), st.min(), st.max(), lp.mean(), (lp / np.maximum(1, nslab)).mean(), ep.mean(), ep.min(), ep.max(),
-               nslab.sum(), nslab.sum() / 256.0, mx, len(cu_slabs), mx * SLAB_US))
+               nslab.sum(), nslab.sum() / 256.0, mx, len(cu_slabs), mx * slab_us))
         if tag != detail:
             continue
         print("  late starts: last start %.1f us" % us(t0.max()))
@@ -92,6 +95,6 @@ for seq in range(40):
             ch = rows[lo:lo + 32]
             sl = np.array([r[0] for r in ch]); en = np.array([r[1] for r in ch])
             print("    CUs %3d..%3d  slabs %3d..%3d  tiles %s  end mean %5.1f  MFMA-bound %5.1f  ratio %.2f" %
-                  (lo, lo + len(ch) - 1, sl.min(), sl.max(), sorted(set(r[2] for r in ch)), en.mean(), SLAB_US * sl.mean(), SLAB_US * sl.mean() / en.mean()))
+                  (lo, lo + len(ch) - 1, sl.min(), sl.max(), sorted(set(r[2] for r in ch)), en.mean(), slab_us * sl.mean(), slab_us * sl.mean() / en.mean()))
         grid = np.arange(0, us(t1.max()), 2.0)
         print("  running workgroups over time (2 us steps): " + " ".join("%d" % int(((us(t0) <= g) & (us(t1) > g)).sum()) for g in grid))

@@ -41,7 +41,7 @@ def test_update_matches_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_HEADS_MFMA", "GRL_NO_V2", "GRL_LANES", "GRL_NO_FUSED_ADAM", "GRL_NO_WGRAD_MERGE", "GRL_NO_SK", "GRL_FILLERS"])
+@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_HEADS_MFMA", "GRL_NO_V2", "GRL_LANES", "GRL_NO_FUSED_ADAM", "GRL_NO_WGRAD_MERGE", "GRL_NO_SK", "GRL_FILLERS", "GRL_NO_CONV3_RIDERS"])
 def test_fallback_paths_match_oracle(monkeypatch, var):
     """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel, the two-lane capture, the separate Adam launch,
     the separate dense weight-gradient launch and conv1 on igemm2_kernel instead of the streaming kernel stay correct."""
