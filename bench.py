@@ -286,6 +286,15 @@ def run_sac(args, wl_name, world, rank, device):
     st = fill_replay_on_device(eng, replay, 100 + rank, device, wl["kind"], wl["act_dim"])
     eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
     dp = DataParallelSac(eng) if world > 1 else None
+    if dp is not None and dp.overlap:
+        # the two-bucket overlapped schedule is the default; should the grouped RCCL calls be refused by this
+        # torch / RCCL build (the same on every rank), fall back to the single-bucket exchange rather than fail
+        try:
+            dp.train(1)
+            eng.synchronize()
+        except Exception as exc:   # noqa: BLE001
+            sys.stderr.write("bench: overlapped data-parallel schedule failed (%s); using one bucket\n" % exc)
+            dp.overlap = False
 
     def run(n):
         if dp is None:
@@ -312,7 +321,7 @@ def run_sac(args, wl_name, world, rank, device):
         out["value"] = round(world * args.steps / dt, 2)
     out["config"] = {"workload": wl["name"] % (wl["batch"], replay) + (" [configs[4]: global batch %d over %d GPU(s)]"
                                                                         % (args.global_batch, world) if strong else ""),
-                     "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world,
+                     "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world + ("" if dp is None else (" two gradient buckets, dense all-reduce under the conv backward" if dp.overlap else " one gradient bucket")),
                      "global_steps_per_s": round(args.steps / dt, 2)}
     out["repeats"] = {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"}
     out["losses"] = {k: round(float(v), 6) for k, v in metrics.items()}
