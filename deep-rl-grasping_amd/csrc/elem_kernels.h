@@ -80,7 +80,6 @@ struct GatherArgs {
   int64_t* idx_w; float* eps_w; int n_eps;
   int rgb_u8; // RGB-D ring with byte colours: per stored observation [hw packed dwords R|G<<8|B<<16][hw float32 depth]
   int vec4;   // img_elems, ldx multiples of 4 and 16-byte aligned rows: a thread moves 4 elements (grid.x = ceil(img_elems / 1024))
-  int rows;   // minibatch rows per workgroup (1..4): grid.y = ceil(B / rows)
   // adam_tick: this launch opens an update -- one thread fixes the Adam step size of the update from the
   // beta powers and advances them (TF ApplyAdam: alpha_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power)).
   // Done here, a whole launch chain before the first consumer, so that the fused reduce + Adam launch
@@ -100,31 +99,19 @@ __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int no
 }
 
 __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
-  // A workgroup moves one 1024-element (vec4) or 256-element span of `rows` consecutive minibatch rows: the float64
-  // statistics of the span -- 4x the bytes of the observation floats they normalise -- are loaded once and reused for
-  // every row, and the rows' (independent, random) replay reads are all in flight together.
-  constexpr int RMAX = 4;
-  const int R = a.rows < 1 ? 1 : (a.rows > RMAX ? RMAX : a.rows);
-  const int b0 = blockIdx.y * R;
+  const int b = blockIdx.y;
   const int which = blockIdx.z;   // 0: obs, 1: next_obs
+  int64_t src;
   uint64_t step = 0;
-  if (a.use_rng) step = a.sc->rng_step;
-  int64_t srcs[RMAX];
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    const int b = b0 + r;
-    srcs[r] = 0;
-    if (r < R && b < a.B) {
-      if (a.use_rng) {
-        const int64_t size = a.sc->replay_size;
-        uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, 0u};
-        philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-        const uint64_t u = ((uint64_t)c[0] << 32) | c[1];
-        srcs[r] = size > 0 ? (int64_t)__umul64hi(u, (uint64_t)size) : 0;
-      } else {
-        srcs[r] = a.idx[b];
-      }
-    }
+  if (a.use_rng) {
+    step = a.sc->rng_step;
+    const int64_t size = a.sc->replay_size;
+    uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, 0u};
+    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const uint64_t u = ((uint64_t)c[0] << 32) | c[1];
+    src = size > 0 ? (int64_t)__umul64hi(u, (uint64_t)size) : 0;
+  } else {
+    src = a.idx[b];
   }
 #ifndef GRL_HOSTEMU
   if (a.vec4) {
@@ -133,39 +120,27 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
     const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e4 < a.img_elems) {
       const float* rp = which ? a.rp_next : a.rp_obs;
-      gn_f4 x[RMAX];
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        x[r] = gn_f4{0.f, 0.f, 0.f, 0.f};
-        if (r < R && b0 + r < a.B) {
-          if (a.rgb_u8) {            // one pixel per thread: colours from the packed dword, depth from the float plane
-            const int hwp = a.img_elems >> 2, px = e4 >> 2;
-            const float* ob = rp + srcs[r] * (2 * hwp);
-            const uint32_t w = ((const uint32_t*)ob)[px];
-            x[r] = gn_f4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), ob[hwp + px]};
-          } else {
-            x[r] = *(const gn_f4*)(rp + srcs[r] * a.img_elems + e4);
-          }
-        }
+      gn_f4 x;
+      if (a.rgb_u8) {            // one pixel per thread: colours from the packed dword, depth from the float plane
+        const int hwp = a.img_elems >> 2, px = e4 >> 2;
+        const float* ob = rp + src * (2 * hwp);
+        const uint32_t w = ((const uint32_t*)ob)[px];
+        x = gn_f4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), ob[hwp + px]};
+      } else {
+        x = *(const gn_f4*)(rp + src * a.img_elems + e4);
       }
       gn_d4 mu = {0.0, 0.0, 0.0, 0.0}, sd = {1.0, 1.0, 1.0, 1.0};
       if (a.normalize) { mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4); }
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        const int b = b0 + r;
-        if (r < R && b < a.B) {
-          gn_f4 y;
-          y.x = norm_elem(x[r].x, mu.x, sd.x, a.normalize, a.clip_obs, a.scale_div);
-          y.y = norm_elem(x[r].y, mu.y, sd.y, a.normalize, a.clip_obs, a.scale_div);
-          y.z = norm_elem(x[r].z, mu.z, sd.z, a.normalize, a.clip_obs, a.scale_div);
-          y.w = norm_elem(x[r].w, mu.w, sd.w, a.normalize, a.clip_obs, a.scale_div);
-          if (which) {
-            *(gn_f4*)(a.x_next + (long)b * a.ldx + e4) = y;
-          } else {
-            *(gn_f4*)(a.x_obs + (long)b * a.ldx + e4) = y;
-            if (a.x_obs2) *(gn_f4*)(a.x_obs2 + (long)b * a.ldx + e4) = y;
-          }
-        }
+      gn_f4 y;
+      y.x = norm_elem(x.x, mu.x, sd.x, a.normalize, a.clip_obs, a.scale_div);
+      y.y = norm_elem(x.y, mu.y, sd.y, a.normalize, a.clip_obs, a.scale_div);
+      y.z = norm_elem(x.z, mu.z, sd.z, a.normalize, a.clip_obs, a.scale_div);
+      y.w = norm_elem(x.w, mu.w, sd.w, a.normalize, a.clip_obs, a.scale_div);
+      if (which) {
+        *(gn_f4*)(a.x_next + (long)b * a.ldx + e4) = y;
+      } else {
+        *(gn_f4*)(a.x_obs + (long)b * a.ldx + e4) = y;
+        if (a.x_obs2) *(gn_f4*)(a.x_obs2 + (long)b * a.ldx + e4) = y;
       }
     }
   } else
@@ -174,33 +149,26 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < a.img_elems) {
     const float* rp = which ? a.rp_next : a.rp_obs;
-    for (int r = 0; r < R && b0 + r < a.B; ++r) {
-      const int b = b0 + r;
-      const int64_t src = srcs[r];
-      float x;
-      if (a.rgb_u8) {
-        const int hwp = a.img_elems >> 2, px = e >> 2, ch = e & 3;
-        const float* ob = rp + src * (2 * hwp);
-        x = ch == 3 ? ob[hwp + px] : (float)((((const uint32_t*)ob)[px] >> (8 * ch)) & 255u);
-      } else {
-        x = rp[src * a.img_elems + e];
-      }
-      const float y = norm_elem(x, a.normalize ? a.mean[e] : 0.0, a.normalize ? a.stdv[e] : 1.0,
-                                a.normalize, a.clip_obs, a.scale_div);
-      if (which) {
-        a.x_next[(long)b * a.ldx + e] = y;
-      } else {
-        a.x_obs[(long)b * a.ldx + e] = y;
-        if (a.x_obs2) a.x_obs2[(long)b * a.ldx + e] = y;
-      }
+    float x;
+    if (a.rgb_u8) {
+      const int hwp = a.img_elems >> 2, px = e >> 2, ch = e & 3;
+      const float* ob = rp + src * (2 * hwp);
+      x = ch == 3 ? ob[hwp + px] : (float)((((const uint32_t*)ob)[px] >> (8 * ch)) & 255u);
+    } else {
+      x = rp[src * a.img_elems + e];
+    }
+    const float y = norm_elem(x, a.normalize ? a.mean[e] : 0.0, a.normalize ? a.stdv[e] : 1.0,
+                              a.normalize, a.clip_obs, a.scale_div);
+    if (which) {
+      a.x_next[(long)b * a.ldx + e] = y;
+    } else {
+      a.x_obs[(long)b * a.ldx + e] = y;
+      if (a.x_obs2) a.x_obs2[(long)b * a.ldx + e] = y;
     }
   }
   }
   if (blockIdx.x == 0) {
     const int t = threadIdx.x;
-    for (int r = 0; r < R && b0 + r < a.B; ++r) {
-    const int b = b0 + r;
-    const int64_t src = srcs[r];
     if (t < a.n_direct) {
       const float* rp = which ? a.rp_dnext : a.rp_dobs;
       const float x = rp[src * a.n_direct + t];
@@ -220,13 +188,13 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
         if (a.act_out2) a.act_out2[(long)b * a.ld_act2 + t] = av;
       }
       if (t == 64) {
-        float rw = a.rp_rew[src];
+        float r = a.rp_rew[src];
         if (a.normalize_rew) {
-          double z = (double)rw / a.ret_std[0];
+          double z = (double)r / a.ret_std[0];
           z = z < -a.clip_rew ? -a.clip_rew : (z > a.clip_rew ? a.clip_rew : z);
-          rw = (float)z;
+          r = (float)z;
         }
-        a.rew_out[b] = rw;
+        a.rew_out[b] = r;
       }
       if (t == 65) a.done_out[b] = a.rp_done[src];
       if (a.use_rng) {
@@ -244,7 +212,6 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
           if (j0 + 1 < a.n_eps) a.eps_w[b * a.n_eps + j0 + 1] = rad * sn;
         }
       }
-    }
     }
   }
   // rng_step itself is advanced by the (single-workgroup) loss reduction later in the update: a counter

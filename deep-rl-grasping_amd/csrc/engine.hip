@@ -1345,18 +1345,12 @@ int grl_ctx::plan_sac() {
     ga.vec4 = (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
 #endif
     const int per_block = ga.vec4 ? 1024 : 256;
-    {   // rows per workgroup (GRL_GATHER_ROWS overrides).  Measured at B = 256: depth 4 583 / 4 610 / 4 555 updates/s with
-        // 1 / 2 / 4 rows, RGB-D 3 730 / 3 779 / 3 758 -- two rows halve the statistics traffic, four leave too few loads in flight
-      const long wgs1 = (long)((img_elems + per_block - 1) / per_block) * B * 2;
-      ga.rows = wgs1 >= 2048 ? 2 : 1;
-      if (const char* e = getenv("GRL_GATHER_ROWS")) ga.rows = std::max(1, std::min(4, atoi(e)));
-    }
     for (int mode = 0; mode < 2; ++mode) {
       ga.use_rng = mode;
       Op op; op.tag = "gather_norm";
       op.bytes = 2.0 * B * ((double)img_elems * 4 + (double)obs_store * 4 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
       op.run = [ga, per_block](hipStream_t s) {
-        hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + per_block - 1) / per_block, (ga.B + ga.rows - 1) / ga.rows, 2), dim3(256), 0, s, ga);
+        hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + per_block - 1) / per_block, ga.B, 2), dim3(256), 0, s, ga);
       };
       (mode ? ops_rng : ops_gather).push_back(op);
     }
@@ -2250,10 +2244,9 @@ int grl_ctx::plan_q() {
     ga.x_obs = feat[0]; ga.x_obs2 = nullptr; ga.x_next = feat[2]; ga.ldx = ldf;
     ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
-    ga.rows = 1;
     Op op; op.tag = "gather_norm";
     op.run = [ga](hipStream_t s) {
-      hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, (ga.B + ga.rows - 1) / ga.rows, 2), dim3(256), 0, s, ga);
+      hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
     };
     ops_grads.push_back(op);
   }

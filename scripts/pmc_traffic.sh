@@ -14,6 +14,8 @@ tag_of={}                      # grid size (threads) of an implicit-GEMM launch 
 for line in open('gpurun_out/pmct_plan.txt'):
     m=re.match(r'grl plan: (\S+) .* tiles (\d+)', line)
     if m: tag_of.setdefault(str(int(m.group(2))*256), m.group(1))
+    m2 = re.match(r"grl plan: (\S+) +carries (\d+) filler tiles of '(\S+)' behind its own (\d+)", line)   # pair launch: one grid
+    if m2: tag_of[str((int(m2.group(2)) + int(m2.group(4))) * 256)] = m2.group(1) + '+' + m2.group(3)
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(lambda: collections.Counter())
 for f in sorted(glob.glob('gpurun_out/pmct_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):

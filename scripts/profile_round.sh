@@ -39,6 +39,8 @@ tag_of = {}
 for line in open(out + '/plan.txt'):
     m = re.match(r'grl plan: (\S+) .* tiles (\d+)', line)
     if m: tag_of.setdefault(str(int(m.group(2)) * 256), m.group(1))
+    m2 = re.match(r"grl plan: (\S+) +carries (\d+) filler tiles of '(\S+)' behind its own (\d+)", line)   # pair launch: one grid
+    if m2: tag_of[str((int(m2.group(2)) + int(m2.group(4))) * 256)] = m2.group(1) + '+' + m2.group(3)
 def collect(pattern):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
     for fpath in sorted(glob.glob(out + pattern, recursive=True)):
