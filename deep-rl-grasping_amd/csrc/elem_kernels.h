@@ -497,6 +497,8 @@ struct QLossArgs {
   float* td; float* priority;             // [B, D], [B]
   DevScalars* sc;
   float* row_part; unsigned* counter;     // [3 B] per-row partial sums, completion counter (zero between launches)
+  int defer_finish;                       // 1: the batch sums / metrics are formed by a later launch from row_part (q_finish_sums):
+                                          //    this kernel then needs no device-scope fence, counter or last-workgroup pass
 };
 
 __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3) {
@@ -551,6 +553,31 @@ __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3)
   s3[2] += prio * invD;
 }
 
+// batch means of the row partial sums + RNG tick (the part of q_loss_finish that does not feed the optimiser)
+__device__ __forceinline__ void q_metrics(DevScalars* sc, int B, float loss, float qm, float tdm) {
+  const float invB = 1.f / (float)B;
+  sc->policy_loss = loss * invB;     // reported as the TD loss
+  sc->mean_qf1 = qm * invB;
+  sc->value_loss = tdm * invB;       // mean |td|
+  if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch was drawn by the device RNG
+}
+// deferred form: one workgroup (256 threads) sums row_part in the fixed tree order of q_loss_kernel's last workgroup
+__device__ __forceinline__ void q_finish_sums(DevScalars* sc, const float* row_part, int B, float (*red)[256]) {
+  const int t = threadIdx.x;           // workgroups of 256 threads or more: the first 256 carry the sums, all reach the barriers
+  if (t < 256) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int r = t; r < B; r += 256) { s0 += row_part[3 * r]; s1 += row_part[3 * r + 1]; s2 += row_part[3 * r + 2]; }
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+  }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off)
+      for (int k = 0; k < 3; ++k) red[k][t] += red[k][t + off];
+    __syncthreads();
+  }
+  if (t == 0) q_metrics(sc, B, red[0][0], red[1][0], red[2][0]);
+}
+
 __device__ __forceinline__ void q_loss_finish(const QLossArgs& a, float loss, float qm, float tdm) {
   DevScalars* sc = a.sc;
   const float invB = 1.f / (float)a.B;
@@ -579,7 +606,10 @@ __global__ __launch_bounds__(256) void q_loss_rows_kernel(QLossArgs a) {
       for (int k = 0; k < 3; ++k) red[k][t] += red[k][t + off];
     __syncthreads();
   }
-  if (t == 0) q_loss_finish(a, red[0][0], red[1][0], red[2][0]);
+  if (t == 0) {
+    if (a.defer_finish) q_metrics(a.sc, a.B, red[0][0], red[1][0], red[2][0]);   // (single workgroup: nothing to defer but the optimiser tick)
+    else q_loss_finish(a, red[0][0], red[1][0], red[2][0]);
+  }
 }
 
 // One wavefront per minibatch row, lane = bin (n <= 64): the bin loops of q_loss_row become wave reductions
@@ -593,7 +623,78 @@ __device__ __forceinline__ float q_wave_sum(float v) {
 __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int D = a.D, n = a.n;
-  if (b < a.B) {
+  constexpr int DM = 8;      // branches whose operands are requested up front (one memory round trip instead of 2 D)
+  if (b < a.B && D <= DM) {
+    const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
+    const bool on = lane < n;
+    float xs[DM], xt[DM], x0[DM];
+    int ais[DM];
+    const float* sel = a.double_q ? a.adv1 : a.adv2;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) {
+      xs[d] = -INFINITY; xt[d] = 0.f; x0[d] = 0.f; ais[d] = 0;
+      if (d < D) {
+        const long o = ((long)b * D + d) * n + lane;
+        if (on) { xs[d] = sel[o]; xt[d] = a.adv2[o]; x0[d] = a.adv0[o]; }
+        ais[d] = (int)a.act[b * D + d];
+      }
+    }
+    const float v2b = a.v2[b], v0b = a.v0[b], rewb = a.rew[b], doneb = a.done[b], w = a.weights[b];
+    float qbest = 0.f;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) {
+      if (d < D) {
+        float sv = xs[d];
+        const float tg = xt[d];
+        int si = lane;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {      // arg max, ties -> lowest bin (the sequential scan keeps the first maximum)
+          const float ov = __shfl_xor(sv, m, 64);
+          const int oi = __shfl_xor(si, m, 64);
+          if (ov > sv || (ov == sv && oi < si)) { sv = ov; si = oi; }
+        }
+        const float mean2 = q_wave_sum(tg);
+        qbest += v2b + __shfl(tg, si, 64) - mean2 * invn;
+      }
+    }
+    qbest *= invD;
+    const float y = rewb + a.gamma * (1.f - doneb) * qbest;
+    float dv = 0.f, prio = 0.f, lossb = 0.f, qs = 0.f;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) {
+      if (d < D) {
+        const long o = ((long)b * D + d) * n + lane;
+        const float ad = x0[d];
+        const float mean0 = q_wave_sum(ad) * invn;
+        const int ai = ais[d];
+        const float q_sel = v0b + __shfl(ad, ai, 64) - mean0;
+        const float tdv = q_sel - y;
+        prio += fabsf(tdv);
+        qs += q_sel;
+        float err, dfd;
+        if (a.huber) {
+          const float at = fabsf(tdv);
+          err = at < 1.f ? 0.5f * tdv * tdv : at - 0.5f;
+          dfd = fminf(fmaxf(tdv, -1.f), 1.f);
+        } else {
+          err = tdv * tdv;
+          dfd = 2.f * tdv;
+        }
+        lossb += err;
+        const float g = w * invB * invD * dfd;
+        dv += g;
+        if (on) a.d_adv0[o] = g * ((lane == ai ? 1.f : 0.f) - invn);
+        if (lane == 0) a.td[b * D + d] = tdv;
+      }
+    }
+    if (lane == 0) {
+      a.d_v0[b] = dv;
+      a.priority[b] = prio;
+      a.row_part[3 * b] = w * lossb * invD;
+      a.row_part[3 * b + 1] = qs * invD;
+      a.row_part[3 * b + 2] = prio * invD;
+    }
+  } else if (b < a.B) {
     const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
     const bool on = lane < n;
     float qbest = 0.f;
@@ -647,6 +748,7 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
       a.row_part[3 * b + 2] = prio * invD;
     }
   }
+  if (a.defer_finish) return;   // uniform: the sums are formed from row_part by the launch that applies the update
   // ---- last workgroup: batch sums in row order
   __shared__ int last;
   __threadfence();
@@ -826,6 +928,93 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
     }
   }
 }
+
+// DQN / BDQ full update: slab sums -> per-variable clip_by_norm -> Adam in ONE launch, one workgroup per variable
+// (= per reduction descriptor: the host checks that every trainable variable is exactly one descriptor).  The sums stay
+// in LDS between the phases.  Arithmetic and summation orders are those of reduce_slabs_kernel (slabs in order),
+// clip_by_norm_kernel (strided partial sums, tree -- over 1024 instead of 256 threads) and adam_polyak_kernel: three launches at the launch floor
+// (4.8 + 8.6 + 4.8 us under graph replay) become one.
+#define GRL_QAPPLY_MAX 16384   /* floats of LDS for the summed gradient of one variable */
+#ifdef GRL_HOSTEMU
+#include "elem_kernels_ref4.h"   // tests/hostemu: the emulation build only
+#else
+// (1024 threads: the largest variable of the reference networks, 101 x 64, is then one batch of loads per phase)
+__global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDesc* __restrict__ descs, int n_desc, float clip, AdamArgs aa,
+                                                                 const float* row_part, int rows, int finish) {
+  __shared__ float gsum[GRL_QAPPLY_MAX];
+  constexpr int NT = 1024;
+  __shared__ float red3[3][256];
+  __shared__ float red[NT];
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x == n_desc) {      // extra workgroup: batch means of the loss launch's row sums (deferred q_loss_finish)
+    if (finish) q_finish_sums(const_cast<DevScalars*>(aa.sc), row_part, rows, red3);
+    return;
+  }
+  const ReduceDesc d = descs[blockIdx.x];
+  constexpr int U = 8;                  // elements per thread in flight: the loops below are chains of load batches
+  float ss = 0.f;
+  for (int base = 0; base < d.n; base += NT * U) {
+    float acc[U];
+    const float* sp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + t;
+      const int ic = i < d.n ? i : 0;
+      sp[u] = d.src + (d.row_len > 0 ? (long)(ic / d.row_len) * d.src_ld + ic % d.row_len : ic);
+      acc[u] = 0.f;
+    }
+    for (int k = 0; k < d.splits; ++k) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = sp[u][(long)k * d.slab_stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] += v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {       // (ascending i per thread, then a tree over the 1024 partial sums)
+      const int i = base + u * NT + t;
+      if (i < d.n) { gsum[i] = acc[u]; ss += acc[u] * acc[u]; }
+    }
+  }
+  float sc = 1.f;
+  if (clip > 0.f) {
+    red[t] = ss;
+    __syncthreads();
+    for (int off = NT / 2; off > 0; off >>= 1) {
+      if (t < off) red[t] += red[t + off];
+      __syncthreads();
+    }
+    sc = clip / fmaxf(sqrtf(red[0]), clip);
+  }
+  const float alpha = aa.sc->adam_alpha;
+  const int64_t e0 = d.dst - aa.grads;
+  for (int base = 0; base < d.n; base += NT * U) {
+    float p[U], m[U], v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + t;
+      const int64_t e = e0 + (i < d.n ? i : 0);
+      p[u] = aa.params[e]; m[u] = aa.m[e]; v[u] = aa.v[e];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + t;
+      if (i < d.n) {
+        float g = gsum[i];
+        if (clip > 0.f) g *= sc;
+        d.dst[i] = g;
+        adam_elem(grad_scaled(g, aa.grad_scale), p[u], m[u], v[u], alpha, aa.eps);
+        aa.params[e0 + i] = p[u]; aa.m[e0 + i] = m[u]; aa.v[e0 + i] = v[u];
+      }
+    }
+  }
+}
+// the batch means alone (split compute / apply path of a plan whose loss launch defers them)
+__global__ __launch_bounds__(256) void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
+  __shared__ float red3[3][256];
+  q_finish_sums(sc, row_part, rows, red3);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // TF-1.x Adam (A.5) over the flat trainable block, fused with the Polyak target update (A.4):

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <map>
 #include <string>
 #include <vector>
@@ -2065,6 +2066,11 @@ struct QNetAct {
 }  // namespace
 
 int grl_ctx::plan_q() {
+  // 1 once the plan ends with the fused reduction + clip + Adam launch: the loss launch then leaves its batch sums to it
+  // (no device-scope fence / last-workgroup pass) and the gather launch fixes the Adam step size.  Read at launch time.
+  auto q_defer = std::make_shared<int>(0);
+  float* q_row_part = nullptr;
+  int q_finish = 0;
   const grl_config& c = cfg;
   cnn = false;
   const int D = c.q_branches, nb = c.q_bins, Lc = c.q_n_common, Lb = c.q_n_branch, Lv = c.q_n_value;
@@ -2244,9 +2250,12 @@ int grl_ctx::plan_q() {
     ga.x_obs = feat[0]; ga.x_obs2 = nullptr; ga.x_next = feat[2]; ga.ldx = ldf;
     ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
+    ga.sc = sc;
     Op op; op.tag = "gather_norm";
-    op.run = [ga](hipStream_t s) {
-      hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + 255) / 256, ga.B, 2), dim3(256), 0, s, ga);
+    op.run = [ga, q_defer](hipStream_t s) {
+      GatherArgs g2 = ga;
+      g2.adam_tick = *q_defer;        // deferred loss sums: the Adam step size of the update is fixed here, as in the SAC plan
+      hipLaunchKernelGGL(gather_norm_kernel, dim3((g2.img_elems + 255) / 256, g2.B, 2), dim3(256), 0, s, g2);
     };
     ops_grads.push_back(op);
   }
@@ -2370,14 +2379,23 @@ int grl_ctx::plan_q() {
     qa.d_adv0 = gact.adv; qa.d_v0 = gact.v; qa.td = q_td; qa.priority = q_prio; qa.sc = sc;
     qa.row_part = wk.f32(3 * (int64_t)B);
     qa.counter = (unsigned*)wk.take(16);
+    qa.defer_finish = 0;
     zero_once.push_back({qa.counter, 16});
-    Op op; op.tag = "q_loss";
-    op.run = [qa](hipStream_t s) {
+    q_row_part = qa.row_part;
 #ifdef GRL_HOSTEMU
-      hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, qa);
+    q_finish = 1;
 #else
-      if (qa.n <= 64) hipLaunchKernelGGL(q_loss_kernel, dim3((qa.B + 3) / 4), dim3(256), 0, s, qa);
-      else hipLaunchKernelGGL(q_loss_rows_kernel, dim3(1), dim3(256), 0, s, qa);
+    q_finish = qa.n <= 64 ? 1 : 0;     // (the one-workgroup fallback for > 64 bins forms its sums itself)
+#endif
+    Op op; op.tag = "q_loss";
+    op.run = [qa, q_defer](hipStream_t s) {
+      QLossArgs q2 = qa;
+      q2.defer_finish = *q_defer;
+#ifdef GRL_HOSTEMU
+      hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, q2);
+#else
+      if (q2.n <= 64) hipLaunchKernelGGL(q_loss_kernel, dim3((q2.B + 3) / 4), dim3(256), 0, s, q2);
+      else hipLaunchKernelGGL(q_loss_rows_kernel, dim3(1), dim3(256), 0, s, q2);
 #endif
     };
     ops_grads.push_back(op);
@@ -2497,6 +2515,46 @@ int grl_ctx::plan_q() {
       hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, s, aa);
     };
     ops_apply.push_back(op);
+  }
+  {
+    // Full updates: reduction + clip + Adam as one launch (q_reduce_clip_adam_kernel) when every trainable variable is
+    // exactly one reduction descriptor and fits the kernel's LDS buffer.  GRL_NO_FUSED_QAPPLY=1 keeps the three launches.
+    const char* nf = getenv("GRL_NO_FUSED_QAPPLY");
+    bool ok = !(nf && atoi(nf)) && !ops_grads.empty() && ops_grads.back().tag == "reduce_slabs";
+    size_t n_tr = 0;
+    for (auto& v : vars) {
+      if (!v.trainable) continue;
+      ++n_tr;
+      int hits = 0;
+      for (auto& r : reduces) hits += (r.dst == grads + v.off && r.n == v.numel && r.n <= GRL_QAPPLY_MAX) ? 1 : 0;
+      ok = ok && hits == 1;
+    }
+    ok = ok && n_tr == reduces.size();
+    if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: q_apply       reduction + clip + Adam in one launch: %s (%zu variables)\n", ok ? "yes" : "no", n_tr);
+    if (ok) {
+      ops_grads_apply.assign(ops_grads.begin(), ops_grads.end() - 1);
+      Op op; op.tag = "q_apply";
+      grl_ctx* self = this;
+      const ReduceDesc* dr = d_reduces;
+      const int nd = (int)reduces.size();
+      const float clip = c.q_grad_clip;
+      const float* rp = q_row_part; const int rows = B, fin = q_finish;
+      op.run = [self, dr, nd, clip, rp, rows, fin](hipStream_t s) {
+        AdamArgs aa;
+        aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
+        aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
+        aa.src_ofs = 0; aa.n_polyak = 0; aa.target = self->params + self->tgt_off;
+        hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + 1), dim3(1024), 0, s, dr, nd, clip, aa, rp, rows, fin);
+      };
+      ops_grads_apply.push_back(op);
+      *q_defer = 1;
+      if (fin) {     // split compute / apply path of this plan: the batch means as a launch of their own, behind the reduction
+        Op fo; fo.tag = "q_finish";
+        DevScalars* scp = sc;
+        fo.run = [scp, rp, rows](hipStream_t s) { hipLaunchKernelGGL(q_finish_kernel, dim3(1), dim3(256), 0, s, scp, rp, rows); };
+        ops_grads.push_back(fo);
+      }
+    }
   }
   // =============================================================== act path: Q-values of n observations
   {
@@ -3332,9 +3390,13 @@ int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u) {
   for (int s = 0; s < n_steps; ++s) {
     if (u) {
       HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 4, hipMemcpyDeviceToDevice, h->stream));
-      if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
+      if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update})) return e;
+      } else if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
     } else {
-      if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
+      if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update})) return e;
+      } else if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
     }
   }
   HIPCHK(hipGetLastError());

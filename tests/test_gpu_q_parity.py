@@ -18,6 +18,13 @@ def test_q_update_per_layer_gemm_fallback(name, monkeypatch):
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 
+@pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
+def test_q_update_three_launch_apply(name, monkeypatch):
+    """GRL_NO_FUSED_QAPPLY=1: slab reduction, clip_by_norm and Adam as three launches instead of the fused one."""
+    monkeypatch.setenv("GRL_NO_FUSED_QAPPLY", "1")
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+
+
 def test_q_update_with_vecnormalize():
     qu.run_and_compare(qu.make_q_case(normalize=True, **qu.CASES["bdq"]))
 
