@@ -81,6 +81,18 @@ struct I2Lds {
 // descriptor copy points to (dbg_t), {start, end (100 MHz device clock), HW_ID | XCC_ID << 32 | slabs << 40, tile,
 // first barrier passed, reduction loop done} -- the schedule of the launch as the hardware ran it.
 #define I2_TRACE(k) do { if (threadIdx.x == 0 && pb->dbg_t) ((unsigned long long*)pb->dbg_t)[k] = wall_clock64(); } while (0)
+__device__ __forceinline__ void i2_trace_record(const IgemmProb* pb, const int4 tl, unsigned long long t0, int cfg) {
+  if (threadIdx.x != 0 || !pb->dbg_t) return;
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // HW_REG_XCC_ID[3:0]
+  const int chunk = min(pb->K - tl.y * pb->k_chunk, pb->k_chunk);
+  unsigned long long* d = (unsigned long long*)pb->dbg_t;
+  d[0] = t0; d[1] = wall_clock64();
+  d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40) |
+         ((unsigned long long)cfg << 56);
+  d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
+         ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
+}
 #else
 #define I2_TRACE(k) do { } while (0)
 #endif
@@ -653,19 +665,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
   // by side instead of one after the other -- one dependent memory round trip less before the first operand load
   igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds);
 #ifdef GRL_TILE_TRACE
-  const IgemmProb* pb = probs + blockIdx.x;
-  if (threadIdx.x == 0 && pb->dbg_t) {
-    const int4 tl = tiles[blockIdx.x];
-    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // HW_REG_XCC_ID[3:0]
-    const int chunk = min(pb->K - tl.y * pb->k_chunk, pb->k_chunk);
-    unsigned long long* d = (unsigned long long*)pb->dbg_t;
-    d[0] = t0; d[1] = wall_clock64();
-    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40) |
-           ((unsigned long long)CFG << 56);
-    d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
-           ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
-  }
+  i2_trace_record(probs + blockIdx.x, tiles[blockIdx.x], t0, CFG);
 #endif
 }
 
@@ -686,19 +686,7 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
   if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], lds);
   else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + k, tb[k], lds);
 #ifdef GRL_TILE_TRACE
-  const IgemmProb* pq = is_a ? pa + k : pb + k;
-  if (threadIdx.x == 0 && pq->dbg_t) {
-    const int4 tl = is_a ? ta[k] : tb[k];
-    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
-    const int chunk = min(pq->K - tl.y * pq->k_chunk, pq->k_chunk);
-    unsigned long long* d = (unsigned long long*)pq->dbg_t;
-    d[0] = t0; d[1] = wall_clock64();
-    d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)((chunk + 31) / 32) << 40) |
-           ((unsigned long long)(is_a ? CFGa : CFGb) << 56);
-    d[3] = (unsigned long long)(unsigned)tl.x | ((unsigned long long)(unsigned)tl.y << 16) |
-           ((unsigned long long)(unsigned)tl.z << 32) | ((unsigned long long)gridDim.x << 48);
-  }
+  i2_trace_record(is_a ? pa + k : pb + k, is_a ? ta[k] : tb[k], t0, is_a ? CFGa : CFGb);
 #endif
 }
 
