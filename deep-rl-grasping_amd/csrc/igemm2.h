@@ -321,6 +321,17 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   // Every piece of staging work sits in the shadow of one MFMA of the (dependent, in-order) chain;
   // per slab only the fragment reads after the barrier are exposed.
   const int nslab = (r_end - r_begin + BKT - 1) / BKT;
+  // epilogue constants, requested here: read after the reduction loop they are one more scalar round trip (~0.5 us)
+  // in front of the output-offset / mask loads of every tile
+  const gf32 cbase = (gf32)(pb->c + (long)tl.y * pb->slab_stride);
+  const int ldc = pb->ldc;
+  const gci32 cT = (gci32)pb->c_tab_i;
+  const gcf32 bias = (gcf32)pb->bias;
+  const gcf32 rmask = (gcf32)pb->relu_mask;
+  const int act = pb->act;
+  const float alpha = pb->act_alpha;
+  const int accumulate = pb->accumulate;
+  const float oscale = pb->out_scale != 0.f ? pb->out_scale : 1.f;
   I2_STAMP(1);
   // prologue: slab 0 goes through its own registers so that slab 1 can be requested before slab 0 has
   // landed (one memory round trip less before the first MFMA)
@@ -443,15 +454,6 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   I2_STAMP(3);
   I2_TRACE(5);
   // ------------------------------------------------------------------ epilogue
-  const gf32 cbase = (gf32)(pb->c + (long)tl.y * pb->slab_stride);
-  const int ldc = pb->ldc;
-  const gci32 cT = (gci32)pb->c_tab_i;
-  const gcf32 bias = (gcf32)pb->bias;
-  const gcf32 rmask = (gcf32)pb->relu_mask;
-  const int act = pb->act;
-  const float alpha = pb->act_alpha;
-  const int accumulate = pb->accumulate;
-  const float oscale = pb->out_scale != 0.f ? pb->out_scale : 1.f;
   auto emit = [&](int i, int j, float a, float bj) {
     long off;
     if (cT) {
