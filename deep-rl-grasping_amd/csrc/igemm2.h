@@ -332,6 +332,20 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   const float alpha = pb->act_alpha;
   const int accumulate = pb->accumulate;
   const float oscale = pb->out_scale != 0.f ? pb->out_scale : 1.f;
+  // ... and so are the scatter offsets of the wide epilogue (conv backward-data: output rows through c_tab_i): fetched
+  // after the loop they sit in front of the ReLU-mask loads that need them -- two dependent round trips per tile
+  const bool cvec = (pb->vflags & VF_C_VEC) != 0;
+  constexpr int EP_NC4 = BN / 4, EP_RSTEP = 256 / EP_NC4, EP_NQ = BM / EP_RSTEP;
+  int ct_pre[EP_NQ];
+#pragma unroll
+  for (int e = 0; e < EP_NQ; ++e) ct_pre[e] = 0;
+  if (cT && cvec) {
+#pragma unroll
+    for (int e = 0; e < EP_NQ; ++e) {
+      const int i = i0 + t / EP_NC4 + e * EP_RSTEP;
+      ct_pre[e] = cT[i < M ? i : 0];
+    }
+  }
   I2_STAMP(1);
   // prologue: slab 0 goes through its own registers so that slab 1 can be requested before slab 0 has
   // landed (one memory round trip less before the first MFMA)
@@ -508,10 +522,10 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   // Row-per-lane dword stores drain at ~7 B/clk/CU (store-issue bound): a 64x64 tile then spends
   // longer in its epilogue than in three slabs of MFMAs.  When the output allows 16-byte accesses
   // (VF_C_VEC) the tile goes through LDS once and leaves as dwordx4 stores, 4 columns per lane.
-  const bool cvec = (pb->vflags & VF_C_VEC) != 0;
   constexpr int LDC_S = BN + 4;
   auto wide_out = [&](float* tile) {   // tile[BM][LDC_S] holds acc (already summed over the k split)
     constexpr int NC4 = BN / 4, RSTEP = 256 / NC4, NQ = BM / RSTEP;
+    static_assert(NC4 == EP_NC4 && NQ == EP_NQ, "prefetched scatter offsets follow the wide epilogue's row mapping");
     const int c4 = t % NC4, rl0 = t / NC4;
     const int j = j0 + 4 * c4;
     if (j >= N) return;
@@ -525,7 +539,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
       ok[e] = i < M;
       const int ic = ok[e] ? i : 0;
       if (cT) {
-        const int o = cT[ic];
+        const int o = ct_pre[e];
         ok[e] = ok[e] && o >= 0;
         off[e] = (long)(o >= 0 ? o : 0) + j;
       } else {
