@@ -26,6 +26,7 @@ CASES = {
     "depth_norm_obs_only": dict(extractor="augmented", kind="depth", B=8, n_replay=16, normalize="obs"),
     "mlp_norm_reward_only": dict(extractor="mlp", B=16, n_replay=32, normalize="reward"),
     "rgbd_u8_replay": dict(extractor="augmented", kind="rgbd", B=9, n_replay=20, rgb_u8=True),
+    "depth_augmented_b128": dict(extractor="augmented", kind="depth", B=128, n_replay=300),   # per-rank shape of configs[4]
 }
 
 
