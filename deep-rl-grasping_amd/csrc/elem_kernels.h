@@ -98,6 +98,51 @@ __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int no
   return scale_div != 1.f ? y / scale_div : y;
 }
 
+// One minibatch row (observation, next observation, action, reward, done) by the 256 threads of a workgroup: what the
+// blocks (*, b, 0..1) of gather_norm_kernel do for row b, element by element -- for launches that already own a row
+// (the prioritised sampler knows the replay index of its row and gathers it on the spot, per_kernels.h).
+__device__ __forceinline__ void gather_row_device(const GatherArgs& a, int b, int64_t src) {
+  const int t = threadIdx.x;
+  for (int which = 0; which < 2; ++which) {
+    const float* rp = which ? a.rp_next : a.rp_obs;
+    float* dst = which ? a.x_next : a.x_obs;
+    for (int e = t; e < a.img_elems; e += 256) {
+      const float y = norm_elem(rp[src * a.img_elems + e], a.normalize ? a.mean[e] : 0.0, a.normalize ? a.stdv[e] : 1.0,
+                                a.normalize, a.clip_obs, a.scale_div);
+      dst[(long)b * a.ldx + e] = y;
+      if (!which && a.x_obs2) a.x_obs2[(long)b * a.ldx + e] = y;
+    }
+    if (t < a.n_direct) {
+      const float* rd = which ? a.rp_dnext : a.rp_dobs;
+      const float y = norm_elem(rd[src * a.n_direct + t], a.normalize ? a.dmean[t] : 0.0, a.normalize ? a.dstd[t] : 1.0,
+                                a.normalize, a.clip_obs, a.scale_div);
+      if (which) a.d_next[(long)b * a.ldd + t] = y;
+      else { a.d_obs0[(long)b * a.ldd + t] = y; a.d_obs1[(long)b * a.ldd + t] = y; }
+    }
+  }
+  if (t < a.act_dim) {
+    const float av = a.rp_act[src * a.act_dim + t];
+    a.act_out[(long)b * a.ld_act + t] = av;
+    if (a.act_out2) a.act_out2[(long)b * a.ld_act2 + t] = av;
+  }
+  if (t == 64) {
+    float r = a.rp_rew[src];
+    if (a.normalize_rew) {
+      double z = (double)r / a.ret_std[0];
+      z = z < -a.clip_rew ? -a.clip_rew : (z > a.clip_rew ? a.clip_rew : z);
+      r = (float)z;
+    }
+    a.rew_out[b] = r;
+  }
+  if (t == 65) a.done_out[b] = a.rp_done[src];
+}
+// the Adam step size of the update that starts (TF ApplyAdam), and the beta powers for the next one
+__device__ __forceinline__ void adam_tick_device(DevScalars* sc) {
+  sc->adam_alpha = sc->lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
+  sc->beta1_power *= 0.9f;
+  sc->beta2_power *= 0.999f;
+}
+
 __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   const int b = blockIdx.y;
   const int which = blockIdx.z;   // 0: obs, 1: next_obs
@@ -218,12 +263,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   // bumped by the last of these 8192 workgroups would serialise 8192 same-address atomics (~100 us)
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     if (a.use_rng) a.sc->rng_used = 1u;
-    if (a.adam_tick) {
-      DevScalars* sc = a.sc;
-      sc->adam_alpha = sc->lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
-      sc->beta1_power *= 0.9f;
-      sc->beta2_power *= 0.999f;
-    }
+    if (a.adam_tick) adam_tick_device(a.sc);
   }
 }
 
@@ -928,93 +968,6 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
     }
   }
 }
-
-// DQN / BDQ full update: slab sums -> per-variable clip_by_norm -> Adam in ONE launch, one workgroup per variable
-// (= per reduction descriptor: the host checks that every trainable variable is exactly one descriptor).  The sums stay
-// in LDS between the phases.  Arithmetic and summation orders are those of reduce_slabs_kernel (slabs in order),
-// clip_by_norm_kernel (strided partial sums, tree -- over 1024 instead of 256 threads) and adam_polyak_kernel: three launches at the launch floor
-// (4.8 + 8.6 + 4.8 us under graph replay) become one.
-#define GRL_QAPPLY_MAX 16384   /* floats of LDS for the summed gradient of one variable */
-#ifdef GRL_HOSTEMU
-#include "elem_kernels_ref4.h"   // tests/hostemu: the emulation build only
-#else
-// (1024 threads: the largest variable of the reference networks, 101 x 64, is then one batch of loads per phase)
-__global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDesc* __restrict__ descs, int n_desc, float clip, AdamArgs aa,
-                                                                 const float* row_part, int rows, int finish) {
-  __shared__ float gsum[GRL_QAPPLY_MAX];
-  constexpr int NT = 1024;
-  __shared__ float red3[3][256];
-  __shared__ float red[NT];
-  const int t = threadIdx.x;
-  if ((int)blockIdx.x == n_desc) {      // extra workgroup: batch means of the loss launch's row sums (deferred q_loss_finish)
-    if (finish) q_finish_sums(const_cast<DevScalars*>(aa.sc), row_part, rows, red3);
-    return;
-  }
-  const ReduceDesc d = descs[blockIdx.x];
-  constexpr int U = 8;                  // elements per thread in flight: the loops below are chains of load batches
-  float ss = 0.f;
-  for (int base = 0; base < d.n; base += NT * U) {
-    float acc[U];
-    const float* sp[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * NT + t;
-      const int ic = i < d.n ? i : 0;
-      sp[u] = d.src + (d.row_len > 0 ? (long)(ic / d.row_len) * d.src_ld + ic % d.row_len : ic);
-      acc[u] = 0.f;
-    }
-    for (int k = 0; k < d.splits; ++k) {
-      float v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = sp[u][(long)k * d.slab_stride];
-#pragma unroll
-      for (int u = 0; u < U; ++u) acc[u] += v[u];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {       // (ascending i per thread, then a tree over the 1024 partial sums)
-      const int i = base + u * NT + t;
-      if (i < d.n) { gsum[i] = acc[u]; ss += acc[u] * acc[u]; }
-    }
-  }
-  float sc = 1.f;
-  if (clip > 0.f) {
-    red[t] = ss;
-    __syncthreads();
-    for (int off = NT / 2; off > 0; off >>= 1) {
-      if (t < off) red[t] += red[t + off];
-      __syncthreads();
-    }
-    sc = clip / fmaxf(sqrtf(red[0]), clip);
-  }
-  const float alpha = aa.sc->adam_alpha;
-  const int64_t e0 = d.dst - aa.grads;
-  for (int base = 0; base < d.n; base += NT * U) {
-    float p[U], m[U], v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * NT + t;
-      const int64_t e = e0 + (i < d.n ? i : 0);
-      p[u] = aa.params[e]; m[u] = aa.m[e]; v[u] = aa.v[e];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * NT + t;
-      if (i < d.n) {
-        float g = gsum[i];
-        if (clip > 0.f) g *= sc;
-        d.dst[i] = g;
-        adam_elem(grad_scaled(g, aa.grad_scale), p[u], m[u], v[u], alpha, aa.eps);
-        aa.params[e0 + i] = p[u]; aa.m[e0 + i] = m[u]; aa.v[e0 + i] = v[u];
-      }
-    }
-  }
-}
-// the batch means alone (split compute / apply path of a plan whose loss launch defers them)
-__global__ __launch_bounds__(256) void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
-  __shared__ float red3[3][256];
-  q_finish_sums(sc, row_part, rows, red3);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // TF-1.x Adam (A.5) over the flat trainable block, fused with the Polyak target update (A.4):

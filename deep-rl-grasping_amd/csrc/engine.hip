@@ -32,6 +32,7 @@
 #include "per_kernels.h"
 #include "ae_kernels.h"
 #include "q_kernels.h"
+#include "q_apply_kernels.h"
 #include "igemm_sk.h"
 
 namespace grl {
@@ -224,6 +225,7 @@ struct grl_ctx {
   bool use_lanes = false;
   LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
+  std::vector<Op> ops_grads_apply_per;   // DQN / BDQ with prioritised replay: ... and the priority write-back
   // data parallel, staged (grl_compute_grads_staged): stage 0 ends with the dense (fc + head) gradients final in the
   // bucket, stage 1 is the convolution backward + its weight gradients + the loss reductions
   std::vector<Op> ops_stage0, ops_stage1;
@@ -1151,6 +1153,7 @@ struct grl_ctx {
   int per_blocks = 0;
   float* per_u = nullptr;
   std::vector<Op> ops_per_rng, ops_per_u, ops_per_update;
+  std::vector<Op> ops_per_rng_g, ops_per_u_g;   // ... the sampler launches that also gather their rows (fully fused PER update)
   int qD = 0, qN = 0;
   float *q_td = nullptr, *q_prio = nullptr, *q_aout = nullptr;
   // pinned host staging of the per-env-step calls (grl_act / grl_encode): pageable copies cost more than the kernels
@@ -2069,6 +2072,8 @@ int grl_ctx::plan_q() {
   // 1 once the plan ends with the fused reduction + clip + Adam launch: the loss launch then leaves its batch sums to it
   // (no device-scope fence / last-workgroup pass) and the gather launch fixes the Adam step size.  Read at launch time.
   auto q_defer = std::make_shared<int>(0);
+  auto q_ga = std::make_shared<GatherArgs>();   // the minibatch gather of this plan (filled below; the prioritised sampler can run it)
+  memset(q_ga.get(), 0, sizeof(GatherArgs));
   float* q_row_part = nullptr;
   int q_finish = 0;
   const grl_config& c = cfg;
@@ -2207,14 +2212,18 @@ int grl_ctx::plan_q() {
       pa.u = mode ? per_u : nullptr;
       const int nb = per_blocks;
       grl_ctx* self = this;
-      Op op; op.tag = "per_sample";
-      op.run = [self, pa, nb, mode](hipStream_t s) {
-        PerArgs q = pa;
-        q.prio_in = self->q_prio;
-        hipLaunchKernelGGL(per_blocksum_kernel, dim3(nb), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb);   // RNG mode: marks rng_used, q_loss ticks
-      };
-      (mode ? ops_per_u : ops_per_rng).push_back(op);
+      for (int with_gather = 0; with_gather < 2; ++with_gather) {
+        Op op; op.tag = "per_sample";
+        op.run = [self, pa, nb, mode, with_gather, q_ga, q_defer](hipStream_t s) {
+          PerArgs q = pa;
+          q.prio_in = self->q_prio;
+          GatherArgs g = *q_ga;
+          g.adam_tick = *q_defer;
+          hipLaunchKernelGGL(per_blocksum_kernel, dim3(nb), dim3(256), 0, s, q);
+          hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb, g, with_gather);   // RNG mode: marks rng_used, q_loss ticks
+        };
+        (with_gather ? (mode ? ops_per_u_g : ops_per_rng_g) : (mode ? ops_per_u : ops_per_rng)).push_back(op);
+      }
     }
     {
       grl_ctx* self = this;
@@ -2251,6 +2260,7 @@ int grl_ctx::plan_q() {
     ga.d_obs0 = ga.d_obs1 = ga.d_next = feat[0]; ga.ldd = ldf;
     ga.act_out = act; ga.ld_act = A; ga.rew_out = rew; ga.done_out = done;
     ga.sc = sc;
+    *q_ga = ga;
     Op op; op.tag = "gather_norm";
     op.run = [ga, q_defer](hipStream_t s) {
       GatherArgs g2 = ga;
@@ -2539,14 +2549,28 @@ int grl_ctx::plan_q() {
       const int nd = (int)reduces.size();
       const float clip = c.q_grad_clip;
       const float* rp = q_row_part; const int rows = B, fin = q_finish;
-      op.run = [self, dr, nd, clip, rp, rows, fin](hipStream_t s) {
-        AdamArgs aa;
-        aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
-        aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
-        aa.src_ofs = 0; aa.n_polyak = 0; aa.target = self->params + self->tgt_off;
-        hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + 1), dim3(1024), 0, s, dr, nd, clip, aa, rp, rows, fin);
+      auto apply_op = [self, dr, nd, clip, rp, rows, fin](bool with_per) {
+        return [self, dr, nd, clip, rp, rows, fin, with_per](hipStream_t s) {
+          AdamArgs aa;
+          aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
+          aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
+          aa.src_ofs = 0; aa.n_polyak = 0; aa.target = self->params + self->tgt_off;
+          PerArgs q = self->per;
+          q.prio_in = self->q_prio;
+          // prioritised replay: one more workgroup writes the new priorities back (per_update_kernel's work)
+          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + (with_per ? 2 : 1)), dim3(1024), 0, s, dr, nd, clip, aa, rp, rows, fin,
+                             q, (const int64_t*)self->idx_buf);
+        };
       };
+      op.run = apply_op(false);
       ops_grads_apply.push_back(op);
+      if (per_on && B <= 1024) {
+        for (size_t k = 0; k + 1 < ops_grads_apply.size(); ++k)
+          if (ops_grads_apply[k].tag != "gather_norm") ops_grads_apply_per.push_back(ops_grads_apply[k]);   // (the sampler gathers its rows)
+        Op po; po.tag = "q_apply";
+        po.run = apply_op(true);
+        ops_grads_apply_per.push_back(po);
+      }
       *q_defer = 1;
       if (fin) {     // split compute / apply path of this plan: the batch means as a launch of their own, behind the reduction
         Op fo; fo.tag = "q_finish";
@@ -3390,11 +3414,15 @@ int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u) {
   for (int s = 0; s < n_steps; ++s) {
     if (u) {
       HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 4, hipMemcpyDeviceToDevice, h->stream));
-      if (!h->ops_grads_apply.empty()) {
+      if (!h->ops_grads_apply_per.empty()) {
+        if (int e = h->run_seq("per_u", {&h->ops_per_u_g, &h->ops_grads_apply_per})) return e;
+      } else if (!h->ops_grads_apply.empty()) {
         if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update})) return e;
       } else if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
     } else {
-      if (!h->ops_grads_apply.empty()) {
+      if (!h->ops_grads_apply_per.empty()) {
+        if (int e = h->run_seq("per_rng", {&h->ops_per_rng_g, &h->ops_grads_apply_per})) return e;
+      } else if (!h->ops_grads_apply.empty()) {
         if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update})) return e;
       } else if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
     }

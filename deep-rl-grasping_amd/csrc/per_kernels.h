@@ -101,7 +101,9 @@ __device__ __forceinline__ int per_tree_walk(const double* tr, double& rem) {
   return i - PER_BLK;
 }
 
-__global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks) {
+// g / do_gather: the row's transition is gathered (and VecNormalized) right here once its replay index is known -- the
+// gather launch of the update disappears; the launch also opens the update (Adam step size) when g.adam_tick is set.
+__global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
   __shared__ double tr[2 * PER_BLK];
   __shared__ float smin[256];
   const int t = threadIdx.x, k = blockIdx.x;
@@ -143,8 +145,12 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
   __syncthreads();
   per_tree_build(tr);
   const int i = per_tree_walk(tr, rem);
+  const int64_t idx = min(b0 + (int64_t)i, size - 1);     // a mass that rounds up to the total walks off the stored range
+  if (do_gather) {
+    gather_row_device(g, k, idx);
+    if (g.adam_tick && k == 0 && t == 0) adam_tick_device(g.sc);
+  }
   if (t == 0) {
-    const int64_t idx = min(b0 + (int64_t)i, size - 1);   // a mass that rounds up to the total walks off the stored range
     a.idx_out[k] = idx;
     const double ps = (double)a.p[idx] / total, pm = (double)pmin / total;
     a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));
@@ -159,28 +165,35 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
 #ifdef GRL_HOSTEMU
 #include "per_kernels_ref2.h"   // tests/hostemu: the emulation build only
 #else
-__global__ __launch_bounds__(256) void per_update_kernel(PerArgs a, const int64_t* idx) {
-  __shared__ int64_t sidx[1024];
-  __shared__ float smax[256];
+// (workgroups of 256 threads or more: the first 256 do the work, all reach the barriers)
+__device__ __forceinline__ void per_update_body(const PerArgs& a, const int64_t* idx, int64_t* sidx, float* smax) {
   const int t = threadIdx.x;
-  for (int k = t; k < a.B; k += 256) sidx[k] = idx[k];
+  if (t < 256)
+    for (int k = t; k < a.B; k += 256) sidx[k] = idx[k];
   __syncthreads();
   float mx = 0.f;
-  for (int k = t; k < a.B; k += 256) {
-    const float pr = a.prio_in[k] + a.eps;
-    mx = fmaxf(mx, pr);
-    const int64_t me = sidx[k];
-    bool later = false;
-    for (int j = k + 1; j < a.B; ++j) later = later || sidx[j] == me;
-    if (!later) a.p[me] = powf(pr, a.alpha);
+  if (t < 256) {
+    for (int k = t; k < a.B; k += 256) {
+      const float pr = a.prio_in[k] + a.eps;
+      mx = fmaxf(mx, pr);
+      const int64_t me = sidx[k];
+      bool later = false;
+      for (int j = k + 1; j < a.B; ++j) later = later || sidx[j] == me;
+      if (!later) a.p[me] = powf(pr, a.alpha);
+    }
+    smax[t] = mx;
   }
-  smax[t] = mx;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if (t < off) smax[t] = fmaxf(smax[t], smax[t + off]);
     __syncthreads();
   }
   if (t == 0) a.st->max_priority = fmaxf(a.st->max_priority, smax[0]);
+}
+__global__ __launch_bounds__(256) void per_update_kernel(PerArgs a, const int64_t* idx) {
+  __shared__ int64_t sidx[1024];
+  __shared__ float smax[256];
+  per_update_body(a, idx, sidx, smax);
 }
 #endif
 

@@ -1,0 +1,100 @@
+// q_apply_kernels.h -- the tail of a DQN / BDQ update as one launch: slab reduction, per-variable clip_by_norm, Adam,
+// the batch means of the loss launch and (prioritised replay) the priority write-back.
+#pragma once
+#include "elem_kernels.h"
+#include "per_kernels.h"
+
+namespace grl {
+
+// DQN / BDQ full update: slab sums -> per-variable clip_by_norm -> Adam in ONE launch, one workgroup per variable
+// (= per reduction descriptor: the host checks that every trainable variable is exactly one descriptor).  The sums stay
+// in LDS between the phases.  Arithmetic and summation orders are those of reduce_slabs_kernel (slabs in order),
+// clip_by_norm_kernel (strided partial sums, tree -- over 1024 instead of 256 threads) and adam_polyak_kernel: three launches at the launch floor
+// (4.8 + 8.6 + 4.8 us under graph replay) become one.
+#define GRL_QAPPLY_MAX 16384   /* floats of LDS for the summed gradient of one variable */
+#ifdef GRL_HOSTEMU
+#include "q_apply_kernels_ref1.h"   // tests/hostemu: the emulation build only
+#else
+// (1024 threads: the largest variable of the reference networks, 101 x 64, is then one batch of loads per phase)
+__global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDesc* __restrict__ descs, int n_desc, float clip, AdamArgs aa,
+                                                                 const float* row_part, int rows, int finish, PerArgs per, const int64_t* per_idx) {
+  __shared__ __attribute__((aligned(16))) float gsum[GRL_QAPPLY_MAX];   // (also the index scratch of the write-back block)
+  constexpr int NT = 1024;
+  __shared__ float red3[3][256];
+  __shared__ float red[NT];
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x == n_desc) {      // extra workgroup: batch means of the loss launch's row sums (deferred q_loss_finish)
+    if (finish) q_finish_sums(const_cast<DevScalars*>(aa.sc), row_part, rows, red3);
+    return;
+  }
+  if ((int)blockIdx.x == n_desc + 1) {  // second extra workgroup (prioritised replay): priority write-back of this minibatch
+    per_update_body(per, per_idx, (int64_t*)gsum, red);
+    return;
+  }
+  const ReduceDesc d = descs[blockIdx.x];
+  constexpr int U = 8;                  // elements per thread in flight: the loops below are chains of load batches
+  float ss = 0.f;
+  for (int base = 0; base < d.n; base += NT * U) {
+    float acc[U];
+    const float* sp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + t;
+      const int ic = i < d.n ? i : 0;
+      sp[u] = d.src + (d.row_len > 0 ? (long)(ic / d.row_len) * d.src_ld + ic % d.row_len : ic);
+      acc[u] = 0.f;
+    }
+    for (int k = 0; k < d.splits; ++k) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = sp[u][(long)k * d.slab_stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] += v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {       // (ascending i per thread, then a tree over the 1024 partial sums)
+      const int i = base + u * NT + t;
+      if (i < d.n) { gsum[i] = acc[u]; ss += acc[u] * acc[u]; }
+    }
+  }
+  float sc = 1.f;
+  if (clip > 0.f) {
+    red[t] = ss;
+    __syncthreads();
+    for (int off = NT / 2; off > 0; off >>= 1) {
+      if (t < off) red[t] += red[t + off];
+      __syncthreads();
+    }
+    sc = clip / fmaxf(sqrtf(red[0]), clip);
+  }
+  const float alpha = aa.sc->adam_alpha;
+  const int64_t e0 = d.dst - aa.grads;
+  for (int base = 0; base < d.n; base += NT * U) {
+    float p[U], m[U], v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + t;
+      const int64_t e = e0 + (i < d.n ? i : 0);
+      p[u] = aa.params[e]; m[u] = aa.m[e]; v[u] = aa.v[e];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + t;
+      if (i < d.n) {
+        float g = gsum[i];
+        if (clip > 0.f) g *= sc;
+        d.dst[i] = g;
+        adam_elem(grad_scaled(g, aa.grad_scale), p[u], m[u], v[u], alpha, aa.eps);
+        aa.params[e0 + i] = p[u]; aa.m[e0 + i] = m[u]; aa.v[e0 + i] = v[u];
+      }
+    }
+  }
+}
+// the batch means alone (split compute / apply path of a plan whose loss launch defers them)
+__global__ __launch_bounds__(256) void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
+  __shared__ float red3[3][256];
+  q_finish_sums(sc, row_part, rows, red3);
+}
+#endif
+
+}  // namespace grl

@@ -28,8 +28,7 @@ inline void per_blocksum_kernel(PerArgs a) {
   a.bsum[blockIdx.x] = per_tree_root(tr, PER_BLK);
   a.bmin[blockIdx.x] = m;
 }
-inline void per_sample_kernel(PerArgs a, int n_blocks) {
-  if (threadIdx.x != 0) return;
+inline void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
   const int k = blockIdx.x;
   const int64_t size = a.sc->replay_size;
   static thread_local double tr[2 * PER_BLK];
@@ -53,6 +52,11 @@ inline void per_sample_kernel(PerArgs a, int n_blocks) {
   for (int i = 0; i < PER_BLK; ++i) tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? (double)a.p[b0 + i] : 0.0;
   per_tree_root(tr, PER_BLK);
   const int64_t i = std::min<int64_t>(b0 + per_tree_walk(tr, PER_BLK, rem), size - 1);
+  if (do_gather) {                       // (every emulated thread walks the tree, as on the device, then gathers its elements)
+    gather_row_device(g, k, i);
+    if (g.adam_tick && k == 0 && threadIdx.x == 0) adam_tick_device(g.sc);
+  }
+  if (threadIdx.x != 0) return;
   a.idx_out[k] = i;
   const double ps = (double)a.p[i] / total, pm = (double)pmin / total;
   a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));

@@ -1,4 +1,4 @@
-// elem_kernels_ref4.h -- TEST-ONLY reference form of q_reduce_clip_adam_kernel (csrc/elem_kernels.h): sequential loops over
+// q_apply_kernels_ref1.h -- TEST-ONLY reference form of the kernels of csrc/q_apply_kernels.h: sequential loops over
 // the same descriptors, included by that header ONLY in the g++ emulation build (-DGRL_HOSTEMU -I tests/hostemu,
 // tests/conftest.py).  Never part of libgrl.so.  No include guard: it is pasted once, inside namespace grl.
 inline void q_finish_ref(DevScalars* sc, const float* row_part, int rows) {
@@ -10,7 +10,11 @@ inline void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
   if (threadIdx.x == 0) q_finish_ref(sc, row_part, rows);
 }
 inline void q_reduce_clip_adam_kernel(const ReduceDesc* descs, int n_desc, float clip, AdamArgs aa, const float* row_part, int rows,
-                                      int finish) {
+                                      int finish, PerArgs per, const int64_t* per_idx) {
+  if ((int)blockIdx.x == n_desc + 1) {   // priority write-back (prioritised replay)
+    if (threadIdx.x == 0) per_update_ref(per, per_idx);
+    return;
+  }
   if (threadIdx.x != 0) return;
   if ((int)blockIdx.x == n_desc) {
     if (finish) q_finish_ref(const_cast<DevScalars*>(aa.sc), row_part, rows);
