@@ -140,6 +140,13 @@ int main(int argc, char** argv) {
       int4* dt;
       CK(hipMalloc(&dt, tiles.size() * sizeof(int4)));
       CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+      {   // the kernels index the descriptors by workgroup: one copy per tile, in work-list order (engine.hip: per_tile_descs)
+        std::vector<IgemmProb> per_tile;
+        for (const int4& t : tiles) per_tile.push_back(probs[t.x]);
+        CK(hipFree(dprobs));
+        CK(hipMalloc(&dprobs, per_tile.size() * sizeof(IgemmProb)));
+        CK(hipMemcpy(dprobs, per_tile.data(), per_tile.size() * sizeof(IgemmProb), hipMemcpyHostToDevice));
+      }
       dim3 grid((unsigned)tiles.size()), block(256);
       auto run = [&] {
         if (cfg < 0) {
