@@ -122,6 +122,19 @@ def profile_pass(eng, go, n):
 
 
 def roofline_of(prof, n, dt_step, workload):
+    """Roofline block of the bench line.  Every number is reproducible from what the line and `profiles/` carry:
+
+    * `frac` / `achieved` of the dominant launch = its ALGORITHMIC FLOPs (2*M*N*K over taps and rows that exist;
+      `flops_per_launch`) / `avg_launch_ms`, the launch's average duration in this process's eager pass, timed with
+      hipEvents on the engine stream (`timing`: graph replay cannot carry per-kernel events);
+    * `frac_graph`: the same FLOPs over the kernel-trace average of the committed rocprofv3 summary of this command
+      under hipGraph replay (`graph_source`; launches run 5-7 % shorter back to back inside the graph) -- a recorded
+      measurement, like `traffic`;
+    * `step_flops` = algorithmic FLOPs of one update (what the path needs: valid taps only, no backward-data of the
+      first convolution -- the observations need no gradient), `step_flops_executed` = what the MFMAs execute
+      (equal unless GRL_NO_EXACT_TAP selects the masked parity-class form); `step_frac` = step_flops / ms_per_step /
+      peak, i.e. from the timed graph-replay blocks that `value` comes from;
+    * `memory`: the HBM-bound launches of the update: algorithmic bytes / eager duration / 8 TB/s."""
     total = {k: v["avg_ms"] * v["launches"] for k, v in prof.items()}
     with_flops = [k for k in prof if prof[k]["flops"] > 0]
     roof = {"measured": "separate eager pass, hipEvents on the engine stream, same workload",
@@ -131,22 +144,61 @@ def roofline_of(prof, n, dt_step, workload):
         d = prof[dom]
         ach = d["flops"] / (d["avg_ms"] * 1e-3) / 1e12
         roof.update({"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(d["avg_ms"], 5),
-                     "flops_per_launch": d["flops"]})
+                     "frac": round(ach / PEAK_F32_TFLOPS, 4), "timing": "eager pass, hipEvents", "traffic": None,
+                     "avg_launch_ms": round(d["avg_ms"], 5), "flops_per_launch": d["flops"],
+                     "flops_executed_per_launch": d.get("flops_executed", d["flops"])})
         tr = pmc_traffic(dom, workload)
         if tr:
             roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr[0], "bytes/launch", tr[1]
+        gr = graph_trace_avg(dom, workload)
+        if gr:
+            roof["graph_avg_launch_ms"] = round(gr[0], 5)
+            roof["frac_graph"] = round(d["flops"] / (gr[0] * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)
+            roof["graph_source"] = gr[1]
         step_flops = sum(v["flops"] * v["launches"] for v in prof.values()) / max(1, n)
+        step_exec = sum(v.get("flops_executed", v["flops"]) * v["launches"] for v in prof.values()) / max(1, n)
         roof["step_flops"] = step_flops
+        roof["step_flops_executed"] = step_exec
+        roof["step_flops_is"] = ("algorithmic: 2*M*N*K of every product over existing taps / rows; no backward-data of the "
+                                 "first convolution")
         roof["step_achieved"] = round(step_flops / dt_step / 1e12, 3)
         roof["step_frac"] = round(roof["step_achieved"] / PEAK_F32_TFLOPS, 4)
+        roof["step_timing"] = "ms_per_step of the timed graph-replay blocks"
     else:                        # no GEMM-shaped launch carries FLOP counts: report the longest launch against HBM
         dom = max(prof, key=lambda k: total[k])
         d = prof[dom]
         ach = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9 if d["bytes"] else 0.0
         roof.update({"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(d["avg_ms"], 5)})
+    mem = []
+    for k in sorted(prof):
+        d = prof[k]
+        if d["bytes"] > 0 and d["flops"] == 0 and d["avg_ms"] > 0:
+            gbs = d["bytes"] / (d["avg_ms"] * 1e-3) / 1e9
+            mem.append({"kernel": k, "bound": "hbm", "bytes_per_launch": d["bytes"], "avg_launch_ms": round(d["avg_ms"], 5),
+                        "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    if mem:
+        roof["memory"] = mem
     return roof
+
+
+def graph_trace_avg(tag, workload="sac_depth"):
+    """Average duration (ms) of launch `tag` under hipGraph replay, from the newest committed rocprofv3 kernel-trace
+    summary of this workload (`profiles/rNN_rocprofv3_summary_<workload>.txt`, written by scripts/profile_round.sh
+    from `rocprofv3 --kernel-trace --stats -- python bench.py ...`; lines `launch <tag> calls <n> avg <us> us`)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary_%s.txt" % workload)))
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                for line in fh:
+                    m = re.match(r"launch\s+(\S+)\s+calls\s+(\d+)\s+avg\s+([0-9.]+)\s+us", line)
+                    if m and m.group(1) == tag:
+                        return float(m.group(3)) * 1e-3, "profiles/" + os.path.basename(f)
+        except OSError:
+            continue
+    return None
 
 
 def pmc_traffic(tag, workload="sac_depth"):
@@ -467,6 +519,8 @@ def main():
     ap.add_argument("--no-learn-loop", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("GRL_LIBRARY"):
+        raise SystemExit("bench.py measures the in-tree libgrl.so: unset GRL_LIBRARY (a test-only override)")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -101,6 +101,7 @@ struct ConvBwdClass {
   uint8_t* tap;
   int M, K;
   bool vec4_p, vec4_q;
+  float alg_frac = 1.f;   // existing (row, tap) pairs / (M * tap positions): what the masked form multiplies that is not zero
 };
 
 struct Launch {
@@ -126,14 +127,15 @@ struct Op {
   int lane = 0;
   bool fork = false, join = false;
   std::function<void(hipStream_t)> run;
-  double flops = 0;   // algorithmic FLOPs of one launch
+  double flops = 0;   // algorithmic FLOPs of one launch (2 * M * N * K over the taps / rows that exist)
+  double flops_exec = 0;   // FLOPs the launch's MFMAs execute (>= flops: masked taps of the parity-class backward-data form)
   double bytes = 0;   // algorithmic HBM bytes of one launch
 };
 
 struct ProfAcc {
   double ms = 0;
   int64_t n = 0;
-  double flops = 0, bytes = 0;
+  double flops = 0, flops_exec = 0, bytes = 0;
 };
 
 struct ExtractorP {
@@ -203,6 +205,7 @@ struct grl_ctx {
   float* act_p = nullptr;            // [B, Ap] row-padded copy of the minibatch actions (Ap = rup(A, 4))
   int Ap = 0, ld_d = 1, ld_dm = 0;   // strides of the packed output-gradient buffers (fused heads)
   bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
+  bool exact_tap = true;             // conv backward-data over exactly the taps that exist (conv_bwd_tabs_exact)
   bool heads_mfma = false;           // heads_mfma.h: forward + backward of all heads as ONE launch on 16x16x4 MFMAs
   float *u_l0[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // layer-0 feature partials: pi, vf, qf1, qf2, target
   int l0_split = 1;
@@ -448,6 +451,7 @@ struct grl_ctx {
         std::vector<int32_t> ti(c.M), tr(c.K), qt(c.K), ct(c.M);
         std::vector<uint64_t> vm(c.M);
         std::vector<uint8_t> tp(c.K);
+        double live_taps = 0;
         for (int b = 0; b < Bn; ++b)
           for (int i = 0; i < IHc; ++i)
             for (int j = 0; j < IWc; ++j) {
@@ -464,7 +468,9 @@ struct grl_ctx {
               vm[m] = bits;
               const int ih = g.S * i + ph - g.pad, iw = g.S * j + pw - g.pad;
               ct[m] = (ih >= 0 && iw >= 0 && ih < g.H && iw < g.W) ? ((b * g.H + ih) * g.W + iw) * g.LX() : -1;
+              if (ct[m] >= 0) live_taps += __builtin_popcountll(bits);
             }
+        c.alg_frac = (float)(live_taps / ((double)c.M * TJ * TL));
         for (int jj = 0; jj < TJ; ++jj)
           for (int ll = 0; ll < TL; ++ll)
             for (int co = 0; co < g.Cout; ++co) {
@@ -482,6 +488,79 @@ struct grl_ctx {
         c.c_tab_i = upload_vec(wk, ct);
         c.vmask = upload_vec(wk, vm);
         c.tap = upload_vec(wk, tp);
+        out.push_back(c);
+      }
+    return out;
+  }
+
+  // The same transposed gather with EXACT taps.  In the parity form above every class reduces over all TJ x TL tap
+  // positions and border pixels multiply zeros for the taps that fall outside the output (3x3 s1 over 6x6: 4 of 9
+  // taps exist on average, 2.25x the MACs; 4x4 s2 over 15x15 padded to 16x16: 1.78x).  Here the input pixels of a
+  // parity class are split further by their valid-tap set per dimension -- rows i' of one (ph, tap-set) group times
+  // columns j' of one (pw, tap-set) group form a problem whose reduction covers exactly the taps that exist, K =
+  // nh * nw * Cout, no validity masks (PM_TABLE).  Taps keep the order of the parity form and a dropped tap is a run
+  // of 2 * 32 exact zeros there, so the sums are bit-identical.  Pixels no output touches (conv2: row / column 14)
+  // belong to no problem: `untouched` lists them (offsets of their first channel) and the caller keeps them zero.
+  std::vector<ConvBwdClass> conv_bwd_tabs_exact(const ConvGeom& g, int Bn, std::vector<int32_t>* untouched) {
+    std::vector<ConvBwdClass> out;
+    struct Grp { int par; std::vector<int> taps; std::vector<int> pos, img; };   // parity, tap indices jj, i' values, image coords
+    auto groups = [&](int Himg, int KHh, int OHh) {
+      std::vector<Grp> gs;
+      const int IHc = (Himg + g.pad + g.S - 1) / g.S, TJ = (KHh + g.S - 1) / g.S;
+      for (int ph = 0; ph < g.S; ++ph)
+        for (int i = 0; i < IHc; ++i) {
+          const int ih = g.S * i + ph - g.pad;
+          if (ih < 0 || ih >= Himg) continue;
+          std::vector<int> taps;
+          for (int jj = 0; jj < TJ; ++jj)
+            if (i - jj >= 0 && i - jj < OHh && ph + g.S * jj < KHh) taps.push_back(jj);
+          Grp* at = nullptr;
+          for (auto& q : gs)
+            if (q.par == ph && q.taps == taps) at = &q;
+          if (!at) { gs.push_back(Grp{ph, taps, {}, {}}); at = &gs.back(); }
+          at->pos.push_back(i);
+          at->img.push_back(ih);
+        }
+      return gs;
+    };
+    const std::vector<Grp> gh = groups(g.H, g.KH, g.OH), gw = groups(g.W, g.KW, g.OW);
+    for (const Grp& a : gh)
+      for (const Grp& b : gw) {
+        if (a.taps.empty() || b.taps.empty()) {
+          if (untouched)
+            for (int bb = 0; bb < Bn; ++bb)
+              for (int ih : a.img)
+                for (int iw : b.img) untouched->push_back(((bb * g.H + ih) * g.W + iw) * g.LX());
+          continue;
+        }
+        ConvBwdClass c;
+        const int nh = (int)a.taps.size(), nw = (int)b.taps.size();
+        c.M = Bn * (int)a.pos.size() * (int)b.pos.size();
+        c.K = nh * nw * g.Cout;
+        std::vector<int32_t> ti(c.M), tr(c.K), qt(c.K), ct(c.M);
+        int m = 0;
+        for (int bb = 0; bb < Bn; ++bb)
+          for (size_t x = 0; x < a.pos.size(); ++x)
+            for (size_t y = 0; y < b.pos.size(); ++y, ++m) {
+              ti[m] = ((bb * g.OH + a.pos[x]) * g.OW + b.pos[y]) * g.LY();
+              ct[m] = ((bb * g.H + a.img[x]) * g.W + b.img[y]) * g.LX();
+            }
+        for (int x = 0; x < nh; ++x)
+          for (int y = 0; y < nw; ++y)
+            for (int co = 0; co < g.Cout; ++co) {
+              const int r = (x * nw + y) * g.Cout + co;
+              const int jj = a.taps[x], ll = b.taps[y];
+              tr[r] = -(jj * g.OW + ll) * g.LY() + co;
+              qt[r] = (((a.par + g.S * jj) * g.KW + (b.par + g.S * ll)) * g.C) * g.Cout + co;
+            }
+        c.vec4_p = all_mod4(ti) && runs4(tr, tr.size(), true);
+        c.vec4_q = runs4(qt, qt.size(), true) && (g.Cout % 4 == 0);
+        c.tab_i = upload_vec(wk, ti);
+        c.tab_r = upload_vec(wk, tr);
+        c.q_tab_r = upload_vec(wk, qt);
+        c.c_tab_i = upload_vec(wk, ct);
+        c.vmask = nullptr;
+        c.tap = nullptr;
         out.push_back(c);
       }
     return out;
@@ -580,6 +659,7 @@ struct grl_ctx {
     p.q_base[0] = w; p.q_tab_r = c.q_tab_r; p.q_ld_j[0] = g.Cout;
     p.c = dx; p.c_tab_i = c.c_tab_i; p.relu_mask = mask;
     p.vflags = (c.vec4_p ? VF_P_TABS : 0) | (c.vec4_q ? VF_Q_TAB : 0) | ((g.C % 4 == 0) ? VF_CT4 : 0);
+    p.alg_frac = c.alg_frac;
     set_split(p, 1);
     return p;
   }
@@ -654,7 +734,7 @@ struct grl_ctx {
   static bool pair_ok(const Launch* a, const Launch* b) {
     if (!a->v2 || !b->v2 || a->sk || b->sk || v2_key(b) != 21001) return false;
     const int ka = v2_key(a);
-    return ka == 10030 || ka == 10000 || ka == 12130 || ka == 12110 || ka == 12100;
+    return ka == 10030 || ka == 10000 || ka == 12130 || ka == 12110 || ka == 12100 || ka == 11130 || ka == 11110 || ka == 11100;
   }
 
   // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op.  `filler`: independent problems
@@ -668,7 +748,16 @@ struct grl_ctx {
     }
     if (!fprobs.empty()) {
       std::vector<Op> tmp_a, tmp_b;
+      {   // the fillers will occupy list positions n_a..: let the placement of the launch's own tiles count them in
+        lpt_extra_tiles = 0; lpt_extra_w = 0;
+        for (auto& p : fprobs) {
+          const int Mt = p.p_ones_i >= 0 ? p.M - 1 : p.M;
+          lpt_extra_tiles += p.split * ((Mt + 63) / 64) * ((p.N + 63) / 64);
+          lpt_extra_w = std::max(lpt_extra_w, (double)((std::min(p.K, p.k_chunk) + 31) / 32));
+        }
+      }
       add_launch(tmp_a, tag, variant, probs);
+      lpt_extra_tiles = 0; lpt_extra_w = 0;
       Launch* la = launches.back();
       add_launch(tmp_b, ftag, fvariant, fprobs, "", 0, {}, 0);      // fillers keep the 64x64 shape of the merged launch
       Launch* lb = launches.back();
@@ -677,6 +766,7 @@ struct grl_ctx {
         Op op = tmp_a[0];
         op.tag = tag;
         op.flops += tmp_b[0].flops;
+        op.flops_exec += tmp_b[0].flops_exec;
         grl_ctx* self = this;
         const std::string t2 = tag;
         op.run = [la, lb, t2](hipStream_t s) {
@@ -691,6 +781,9 @@ struct grl_ctx {
             case 12130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 3); break;
             case 12110: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 1); break;
             case 12100: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0); break;
+            case 11130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 3); break;
+            case 11110: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 1); break;
+            case 11100: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0); break;
             default:
               fprintf(stderr, "grl: no igemm2 pair instantiation for launch '%s' (key %d)\n", t2.c_str(), ka);
               abort();
@@ -777,7 +870,7 @@ struct grl_ctx {
                 tag.c_str(), l->sk, l->probs.size(), per, l->n_tiles);
       Op op;
       op.tag = tag;
-      op.flops = flops;
+      op.flops = op.flops_exec = flops;
       op.run = [l](hipStream_t s) {
         if (l->sk == 64) hipLaunchKernelGGL((igemm_sk_kernel<64>), dim3(l->n_tiles), dim3(256), 0, s, l->d_probs, l->d_tiles);
         else hipLaunchKernelGGL((igemm_sk_kernel<32>), dim3(l->n_tiles), dim3(256), 0, s, l->d_probs, l->d_tiles);
@@ -787,10 +880,14 @@ struct grl_ctx {
     }
     const int BMt = l->v2 ? i2_bm(l->cfg) : 64, BNt = l->v2 ? i2_bn(l->cfg) : 64;
 
-    double flops = 0;
-    for (auto& p : l->probs) flops += 2.0 * p.M * p.N * p.K;
+    double flops = 0, flops_alg = 0;
+    for (auto& p : l->probs) {
+      flops += 2.0 * p.M * p.N * p.K;
+      flops_alg += 2.0 * p.M * p.N * p.K * (p.alg_frac > 0.f ? (double)p.alg_frac : 1.0);
+    }
     std::vector<int4> tiles = tile_list(l->probs, l->v2, BMt, BNt);
     if (variant == 2) tiles = xcd_order(tiles, l->probs, BMt, BNt);
+    if (variant == 1 && l->v2) tiles = lpt_order(tiles, l->probs, BMt, BNt, lpt_extra_tiles, lpt_extra_w, tag);
     if (variant == 2 && l->v2) {
       if (const char* e = getenv("GRL_WG_DYNLDS")) l->dyn_lds = (unsigned)atoi(e);
     }
@@ -813,7 +910,8 @@ struct grl_ctx {
     launches.push_back(l);
     Op op;
     op.tag = tag;
-    op.flops = flops;
+    op.flops = flops_alg;
+    op.flops_exec = flops;
     op.run = [l, tag](hipStream_t s) {
       dim3 grid(l->n_tiles), block(256);
       if (l->v2) {
@@ -831,7 +929,8 @@ struct grl_ctx {
           GRL_I2_CFGS(1000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0)          // VALID conv forward
           GRL_I2_CFGS(2000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE_MASK, QM_AFFINE, 0)     // padded conv forward
           GRL_I2_CFGS(10000, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0)        // dense backward-data
-          GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data
+          GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data, masked taps
+          GRL_I2_CFGS(11100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0)          // conv backward-data, exact taps
           GRL_I2_CFGS(10100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 0)         // dense backward-data over several kernels
           case 20000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, 0); break;         // dense weight gradient
           case 20001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, I2F_ONES); break;  //   ... with bias row
@@ -860,6 +959,7 @@ struct grl_ctx {
         case 1001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 1); break;       // dense backward-data
         case 3001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 3); break;       //   ... summed over heads
         case 1211: GRL_IGEMM(PM_TABLE_MASK, QM_TABLE, true, false, 1); break;    // conv backward-data
+        case 1111: GRL_IGEMM(PM_TABLE, QM_TABLE, true, false, 1); break;         //   ... over exact taps
         case 1011: GRL_IGEMM(PM_AFFINE, QM_TABLE, true, false, 1); break;        // dense backward-data over several kernels
         case 1002: GRL_IGEMM(PM_AFFINE, QM_AFFINE, false, true, 1); break;       // dense weight gradient
         case 1102: GRL_IGEMM(PM_TABLE, QM_AFFINE, false, true, 1); break;        // conv weight gradient
@@ -1081,6 +1181,54 @@ struct grl_ctx {
     return out;
   }
 
+  // Placement-aware order of a backward-data work list whose tiles differ in length (exact taps: 1 .. 9 tap positions).
+  // Same placement model as xcd_order: list position b runs on CU (b % 8) * 32 + (b / 8) % 32, i.e. positions congruent
+  // mod 256 share a CU, all of a launch's workgroups are resident at once and a CU works through the SUM of what it
+  // holds.  Longest-processing-time-first over 256 bins (bin c owns positions c, c + 256, ...); `extra_tiles` filler
+  // tiles of weight `extra_w` will follow at positions n.. (riders of igemm2_pair_kernel) and are counted into their
+  // bins beforehand.  Same tiles, same arithmetic; GRL_NO_LPT_ORDER=1 keeps the list order (measurement switch).
+  int lpt_extra_tiles = 0;
+  double lpt_extra_w = 0;
+  static std::vector<int4> lpt_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt,
+                                     int extra_tiles, double extra_w, const std::string& tag) {
+    const int n = (int)tiles.size();
+    const double area = (double)BMt * BNt / 4096.0;
+    auto w_of = [&](const int4& t) {
+      const IgemmProb& p = probs[t.x];
+      return area * ((std::min(p.K - t.y * p.k_chunk, p.k_chunk) + 31) / 32);
+    };
+    bool uniform = true;
+    for (const int4& t : tiles) uniform = uniform && w_of(t) == w_of(tiles[0]);
+    if (const char* e = getenv("GRL_NO_LPT_ORDER")) if (atoi(e)) uniform = true;
+    if (uniform || n <= 256) return tiles;
+    constexpr int NB = 256;
+    std::vector<double> load(NB, 0.0);
+    for (int k = 0; k < extra_tiles; ++k) load[(n + k) % NB] += extra_w;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w_of(tiles[a]) > w_of(tiles[b]); });
+    std::vector<std::vector<int4>> bin(NB);
+    for (int i : order) {
+      int best = -1;
+      for (int c = 0; c < NB; ++c) {
+        const int cap = (n - c + NB - 1) / NB;
+        if ((int)bin[c].size() >= cap) continue;
+        if (best < 0 || load[c] < load[best]) best = c;
+      }
+      bin[best].push_back(tiles[i]);
+      load[best] += w_of(tiles[i]);
+    }
+    std::vector<int4> out(n);
+    for (int j = 0; j < n; ++j) out[j] = bin[j % NB][j / NB];
+    if (getenv("GRL_PLAN_DUMP")) {
+      double tot = 0, mx = 0;
+      for (double c : load) { tot += c; mx = std::max(mx, c); }
+      fprintf(stderr, "grl plan: %-14s placement: %d tiles + %d fillers, 64x64-slab units per CU avg %.1f max %.1f\n", tag.c_str(), n,
+              extra_tiles, tot / NB, mx);
+    }
+    return out;
+  }
+
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
   // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors
   // whose geometry allows 16-byte accesses are marked (vec) and cut into tiles of 1024 outputs, the others of 256
@@ -1151,7 +1299,7 @@ struct grl_ctx {
   PerArgs per;                      // prioritised replay (cfg.q_per): device arrays + kernel arguments
   bool per_on = false;
   int per_blocks = 0;
-  float* per_u = nullptr;
+  double* per_u = nullptr;
   std::vector<Op> ops_per_rng, ops_per_u, ops_per_update;
   std::vector<Op> ops_per_rng_g, ops_per_u_g;   // ... the sampler launches that also gather their rows (fully fused PER update)
   int qD = 0, qN = 0;
@@ -1651,7 +1799,15 @@ int grl_ctx::plan_sac() {
   //    conv2_bwd's tiles: they start when the first wave drains (18 us) and end at 36 us instead of 28: conv2_bwd
   //    31.8 -> 41.2 us, the weight-gradient launch 36.6 -> 28.2 us, reduction +2.5 us: 4 519 against 4 580.
   if (cnn) {
-    std::vector<ConvBwdClass> bc3 = conv_bwd_tabs(cg[2], B), bc2 = conv_bwd_tabs(cg[1], B);
+    // backward-data with exact taps (conv_bwd_tabs_exact); GRL_NO_EXACT_TAP=1 keeps the masked parity-class form
+    // (bit-identical results, 1.8-2.25x the MACs: test / measurement switch)
+    const char* net = getenv("GRL_NO_EXACT_TAP");
+    exact_tap = !(net && atoi(net));
+    std::vector<int32_t> untouched;
+    std::vector<ConvBwdClass> bc3 = exact_tap ? conv_bwd_tabs_exact(cg[2], B, nullptr) : conv_bwd_tabs(cg[2], B);
+    std::vector<ConvBwdClass> bc2 = exact_tap ? conv_bwd_tabs_exact(cg[1], B, &untouched) : conv_bwd_tabs(cg[1], B);
+    if (!untouched.empty())   // input pixels of conv2 that no output window covers (row / column 14): their gradient is zero
+      for (int n = 0; n < 2; ++n) zero_once.push_back({g1[n], (size_t)(((int64_t)B * 225 - 1) * ld1 + 32) * 4});
     for (int n = 0; n < 2; ++n)
       bwd_pr[0].push_back(dense_bwd({{dfeat[n], ldf, 512, P + ex[n].fw}}, B, 0, 1024, g3[n], 1024, a3[n]));
     for (int n = 0; n < 2; ++n)
@@ -2200,12 +2356,14 @@ int grl_ctx::plan_q() {
   if (per_on) {
     memset(&per, 0, sizeof(per));
     per_blocks = (int)((cap + PER_BLK - 1) / PER_BLK);
-    per.p = rp.f32(cap);
+    per.p = (double*)rp.take((size_t)cap * 8);
     per.bsum = (double*)rp.take((size_t)per_blocks * 8);
-    per.bmin = rp.f32(per_blocks);
+    per.bmin = (double*)rp.take((size_t)per_blocks * 8);
     per.st = (PerState*)rp.take(sizeof(PerState));
-    per_u = wk.f32(B);
+    per_u = (double*)wk.take((size_t)B * 8);
     per.sc = sc; per.seed = c.seed; per.B = B; per.alpha = c.q_per_alpha; per.eps = c.q_per_eps;
+    per.alpha64 = c.q_per_alpha64 != 0.0 ? c.q_per_alpha64 : (double)c.q_per_alpha;
+    per.stratified = c.q_per_stratified != 0;
     per.idx_out = idx_buf; per.w_out = eps_buf; per.prio_in = nullptr;   // set below (q_prio)
     for (int mode = 0; mode < 2; ++mode) {
       PerArgs pa = per;
@@ -2619,7 +2777,7 @@ int grl_ctx::plan_q() {
   dbg["td"] = {q_td, (int64_t)B * D};
   dbg["idx_raw"] = {(const float*)idx_buf, (int64_t)2 * B};     // int64 viewed as float pairs
   dbg["weights"] = {eps_buf, B};
-  if (per_on) dbg["per_p"] = {per.p, cap};
+  if (per_on) dbg["per_p"] = {(const float*)per.p, 2 * cap};   // float64 leaves, handed out as raw 4-byte words
   dbg["priority"] = {q_prio, B};
   dbg["rew"] = {rew, B}; dbg["done"] = {done, B}; dbg["act"] = {act, (int64_t)B * A};
   dbg["grads"] = {grads, n_train};
@@ -2978,6 +3136,7 @@ int grl_ctx::run_ops(std::vector<Op>& ops) {
     HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
     ProfAcc& a = prof_acc[ops[i].tag];
     a.ms += ms; a.n += 1; a.flops += ops[i].flops; a.bytes += ops[i].bytes;
+    a.flops_exec += ops[i].flops_exec > 0 ? ops[i].flops_exec : ops[i].flops;
   }
   return GRL_OK;
 }
@@ -3129,10 +3288,10 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
   hipError_t e = hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("scalar init: ") + hipGetErrorString(e)); }
   if (h->per_on) {
-    hipMemset(h->per.p, 0, (size_t)cfg->replay_capacity * 4);
+    hipMemset(h->per.p, 0, (size_t)cfg->replay_capacity * 8);
     PerState ps;
     memset(&ps, 0, sizeof(ps));
-    ps.max_priority = 1.f; ps.p_min = 1.f; ps.beta = 1.f;
+    ps.max_priority = 1.f; ps.p_min = 1.0; ps.beta = 1.0;
     e = hipMemcpy(h->per.st, &ps, sizeof(ps), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("per init: ") + hipGetErrorString(e)); }
   }
@@ -3405,15 +3564,17 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   return GRL_OK;
 }
 
-int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u) {
+int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u) {
   if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (!h->per_on) return fail(GRL_ERR_STATE, "prioritised replay is not enabled (grl_config.q_per)");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
-  HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 4, hipMemcpyHostToDevice, h->stream));
+  if (!(beta > 0.0)) return fail(GRL_ERR_INVALID, "beta must be positive (PrioritizedReplayBuffer.sample asserts beta > 0)");
+  if (h->rp_size < 2) return fail(GRL_ERR_STATE, "prioritised sampling needs at least two stored transitions (sum(0, len - 1))");
+  HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 8, hipMemcpyHostToDevice, h->stream));
   for (int s = 0; s < n_steps; ++s) {
     if (u) {
-      HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 4, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
       if (!h->ops_grads_apply_per.empty()) {
         if (int e = h->run_seq("per_u", {&h->ops_per_u_g, &h->ops_grads_apply_per})) return e;
       } else if (!h->ops_grads_apply.empty()) {
@@ -3565,15 +3726,16 @@ int grl_profile_query(grl_handle h, const char* name, double* avg_ms, int64_t* l
   return GRL_OK;
 }
 
-/* list profiled tags: writes "tag:avg_ms:launches:flops_per_launch:bytes_per_launch\n" lines */
+/* list profiled tags: writes "tag:avg_ms:launches:flops_per_launch:bytes_per_launch:executed_flops_per_launch\n" lines */
 int grl_profile_dump(grl_handle h, char* buf, int cap) {
   if (!h || !buf || cap < 1) return fail(GRL_ERR_INVALID, "bad argument");
   std::string s;
   for (auto& kv : h->prof_acc) {
     char line[256];
-    snprintf(line, sizeof(line), "%s:%.6f:%lld:%.0f:%.0f\n", kv.first.c_str(),
+    snprintf(line, sizeof(line), "%s:%.6f:%lld:%.0f:%.0f:%.0f\n", kv.first.c_str(),
              kv.second.n ? kv.second.ms / kv.second.n : 0.0, (long long)kv.second.n,
-             kv.second.n ? kv.second.flops / kv.second.n : 0.0, kv.second.n ? kv.second.bytes / kv.second.n : 0.0);
+             kv.second.n ? kv.second.flops / kv.second.n : 0.0, kv.second.n ? kv.second.bytes / kv.second.n : 0.0,
+             kv.second.n ? kv.second.flops_exec / kv.second.n : 0.0);
     s += line;
   }
   strncpy(buf, s.c_str(), cap - 1);

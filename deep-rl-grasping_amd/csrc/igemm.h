@@ -64,6 +64,8 @@ struct IgemmProb {
   // 16 bytes at a time: base, row offsets and N are multiples of 4 floats (igemm2 epilogue)
   uint32_t vflags;
   void* dbg_t;            // I2_TIMING builds (scripts/igemm_bench.hip): s_memtime stamps of three workgroups
+  float alg_frac;         // host only (profiling): share of the M*N*K MACs that are algorithmic -- the masked parity form of
+                          // the conv backward-data multiplies zeros for taps outside the output; 0 means 1
 };
 enum { VF_P_TABS = 1u, VF_Q_TAB = 2u, VF_C_VEC = 4u, VF_CT4 = 8u };   // VF_CT4 (host): scatter-table offsets are multiples of 4   // VF_C_VEC is also read by the igemm2 epilogue
 

@@ -1,16 +1,23 @@
 // per_kernels.h -- proportional prioritised replay on the device (DQN / BDQ: `prioritized_replay: True`,
-// /root/reference/config/gripper_grasp.yaml:102, simplified_object_picking.yaml:101,110; the sampler is
-// stable-baselines 2.10.1 `PrioritizedReplayBuffer` [SURVEY.md A.6]):
+// /root/reference/config/gripper_grasp.yaml:102, simplified_object_picking.yaml:101,110).  The sampler is
+// stable-baselines 2.10.1 `PrioritizedReplayBuffer` + `SegmentTree` (un-vendored dependency; restated operation by
+// operation in oracle/per.py, whose header quotes the published code):
 //
-//   add:     p[i] = max_priority ** alpha
-//   sample:  mass_k = (u_k + k) * total / B  (stratified), idx_k = smallest i with prefix_sum(i+1) > mass_k
-//            w_k = (p[idx_k]/total * N) ** -beta / (p_min/total * N) ** -beta
-//   update:  p[idx_k] = (|td_k| + eps) ** alpha ; max_priority = max(max_priority, |td_k| + eps)
+//   add:     leaf[i] = max_priority ** alpha                              (float64 power of the float32 running maximum)
+//   sample:  total_s = it_sum.sum(0, len(storage) - 1)                    = reduce over [0, size - 2]: the published code
+//                                                                           leaves the last stored transition out
+//            mass_k  = u_k * total_s                                      (2.10.x: np.random.random(size=B) * total)
+//                      u_k * L + k * L, L = total_s / B                   (q_per_stratified: baselines / SB < 2.10)
+//            idx_k   = find_prefixsum_idx(mass_k)                         (left child if its sum > mass, else subtract, right)
+//            w_k     = (leaf[idx_k] / root * N) ** -beta / (min_leaf / root * N) ** -beta
+//   update:  leaf[idx_k] = float32(|td_k| + eps) ** float32(alpha)        (NumPy: float32 array ** Python float), stored
+//            max_priority = max(max_priority, |td_k| + eps)                 as float64 like the reference's tree
 //
-// Instead of the sum / min segment trees of the reference implementation (pointer chasing, one update
-// at a time) the ring is cut into blocks of 1024 priorities: a block-sum pass (HBM-bound, 4 B/transition)
-// followed by one workgroup per sample that scans the <= 1024 block sums and then the one block that
-// contains its mass, both as LDS segment trees in float64 with the reference's association order.
+// The leaves are FLOAT64 like the reference's `_value` array (8 B per stored transition).  Instead of the array
+// segment trees (pointer chasing, one update at a time on the host) the ring is cut into blocks of 1024 leaves: a
+// block-sum pass (HBM-bound) followed by one workgroup per sample that rebuilds the upper tree over the <= 1024 block
+// sums and then the sub-tree of the one block that contains its mass, both in LDS with the reference's association
+// order (node = left + right over the next power of two), and walks them exactly like `find_prefixsum_idx`.
 #pragma once
 #include "elem_kernels.h"
 
@@ -19,66 +26,94 @@ namespace grl {
 enum { PER_BLK = 1024 };
 
 struct PerState {          // lives in the replay arena next to the priorities
-  double total;            // sum of p over the stored transitions
-  float p_min;             // min of p over the stored transitions
+  double total;            // it_sum.sum(): root of the sum tree
+  double total_s;          // it_sum.sum(0, size - 1): the mass the sampler spreads (excludes the last stored leaf)
+  double p_min;            // it_min.min()
+  double tail_w;           // right-nested sum of the sampled range inside the block that holds leaf size - 2
+  double beta;             // importance-weight exponent of the current call (annealed by the host)
   float max_priority;      // running max of (|td| + eps), starts at 1
-  float beta;              // importance-weight exponent of the current call (annealed by the host)
   float pad;
 };
 
 struct PerArgs {
-  float* p;                // [cap] priority ** alpha
+  double* p;               // [cap] leaves of the sum tree: priority ** alpha
   double* bsum;            // [n_blocks]
-  float* bmin;             // [n_blocks]
+  double* bmin;            // [n_blocks]
   PerState* st;
   DevScalars* sc;          // replay_size, rng_step
   uint64_t seed;
   int B;
-  float alpha, eps;
-  const float* u;          // [B] explicit uniforms in [0,1) (parity tests) or nullptr: Philox
+  int stratified;          // 0: mass = u * total (stable-baselines 2.10.x)   1: u * L + k * L (baselines / SB < 2.10)
+  float alpha, eps;        // float32(prioritized_replay_alpha), float32(prioritized_replay_eps): the update's operands
+  double alpha64;          // prioritized_replay_alpha as the Python float (the add's exponent)
+  const double* u;         // [B] explicit uniforms in [0,1) (parity tests) or nullptr: Philox, 53 bits
   int64_t* idx_out;        // [B]
   float* w_out;            // [B]
   const float* prio_in;    // [B] |td| summed over branches (q_loss_kernel)
 };
 
+// float32 power the way NumPy / glibc deliver it (correctly rounded in all but ~1e-8 of the cases): evaluated in
+// float64 and rounded once
+__device__ __forceinline__ float per_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// `reduce(0, e)` of the reference's SegmentTree over one 1024-leaf tree `tr` (node 1 = root, leaves at 1024 + i):
+// _reduce_helper descends towards leaf e and adds the left sibling whenever it turns right, the recursion returning
+// `left + (rest)` -- a right-nested sum along the path.  `stop_val(depth)` supplies the value of the node the descent
+// ends in when it runs out of this tree (depth 10) before a node's range ends exactly at e.
+template <class F>
+__device__ __forceinline__ double per_prefix_reduce(const double* tr, int64_t e, int64_t leaf_span, F below) {
+  int node = 1, n = 0;
+  int64_t ns = 0, ne = (int64_t)PER_BLK * leaf_span - 1;
+  double c[10], fin = 0.0;
+  for (int d = 0;; ++d) {
+    if (ne == e) { fin = tr[node]; break; }
+    if (d == 10) { fin = below(); break; }
+    const int64_t mid = (ns + ne) >> 1;
+    if (e <= mid) { node = 2 * node; ne = mid; }
+    else { c[n++] = tr[2 * node]; node = 2 * node + 1; ns = mid + 1; }
+  }
+  for (int k = n - 1; k >= 0; --k) fin = c[k] + fin;
+  return fin;
+}
+
 // new transitions enter with the maximal priority seen so far
 __global__ __launch_bounds__(256) void per_add_kernel(PerArgs a, int64_t pos, int n, int64_t cap) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k < n) a.p[(pos + k) % cap] = powf(a.st->max_priority, a.alpha);
+  if (k < n) a.p[(pos + k) % cap] = pow((double)a.st->max_priority, a.alpha64);
 }
 
 // The sums follow the association order of the reference's SumSegmentTree (stable_baselines/common/
 // segment_tree.py, v2.10.1): a binary tree over the next power of two >= capacity, node = left + right in
 // float64, and the sampler walks it from the root (left child if its sum exceeds the remaining mass, else
-// subtract it and go right).  A block of 1024 priorities is an aligned subtree of height 10, the block sums
+// subtract it and go right).  A block of 1024 leaves is an aligned subtree of height 10, the block sums
 // are the leaves of the upper tree: both trees are rebuilt level by level in LDS and walked exactly like the
-// reference walks its array, so the drawn index is bit-identical to oracle/per.py on the same priorities.
+// reference walks its array, so the drawn index is bit-identical to oracle/per.py on the same leaves.
+
+// one uniform in [0, 1) with 53 random bits (np.random.random's resolution) for sample k of minibatch `step`
+__device__ __forceinline__ double per_uniform(const PerArgs& a, int k) {
+  if (a.u) return a.u[k];
+  const uint64_t step = a.sc->rng_step;
+  uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)k, 0x50455221u};
+  philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
+}
+// mass of sample k.  Products and the sum are separate roundings (no contraction), as NumPy evaluates them.
+__device__ __forceinline__ double per_mass(const PerArgs& a, int k, double u, double total_s) {
+#pragma clang fp contract(off)
+  if (!a.stratified) return u * total_s;
+  const double every_range_len = total_s / (double)a.B;
+  const double m0 = u * every_range_len, m1 = (double)k * every_range_len;
+  return m0 + m1;
+}
+__device__ __forceinline__ float per_weight(double leaf, double total, double pmin, int64_t size, double beta) {
+  const double p_min = pmin / total, max_weight = pow(p_min * (double)size, -beta);
+  const double p_sample = leaf / total;
+  return (float)(pow(p_sample * (double)size, -beta) / max_weight);
+}
+
 #ifdef GRL_HOSTEMU
 #include "per_kernels_ref1.h"   // tests/hostemu: the emulation build only
 #else
-__global__ __launch_bounds__(256) void per_blocksum_kernel(PerArgs a) {
-  __shared__ double ss[256];
-  __shared__ float sm[256];
-  const int t = threadIdx.x;
-  const int64_t size = a.sc->replay_size;
-  const int64_t i0 = (int64_t)blockIdx.x * PER_BLK + 4 * t;
-  double v[4];
-  float m = INFINITY;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    v[e] = 0.0;
-    if (i0 + e < size) { const float x = a.p[i0 + e]; v[e] = (double)x; m = fminf(m, x); }
-  }
-  ss[t] = (v[0] + v[1]) + (v[2] + v[3]);    // the aligned 4-leaf subtree
-  sm[t] = m;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {   // adjacent pairs: node = left + right, level by level
-    if ((t & (2 * off - 1)) == 0) { ss[t] = ss[t] + ss[t + off]; sm[t] = fminf(sm[t], sm[t + off]); }
-    __syncthreads();
-  }
-  if (t == 0) { a.bsum[blockIdx.x] = ss[0]; a.bmin[blockIdx.x] = sm[0]; }
-}
-
 // tr[1024 + i] holds leaf i (all 1024 written, barrier done by the caller): builds the internal nodes
 // tr[1 .. 1024) level by level; returns the root.  Ends with a barrier.
 __device__ __forceinline__ double per_tree_build(double* tr) {
@@ -101,38 +136,67 @@ __device__ __forceinline__ int per_tree_walk(const double* tr, double& rem) {
   return i - PER_BLK;
 }
 
+__global__ __launch_bounds__(256) void per_blocksum_kernel(PerArgs a) {
+  __shared__ double tr[2 * PER_BLK];
+  __shared__ double sm[256];
+  const int t = threadIdx.x;
+  const int64_t size = a.sc->replay_size;
+  const int64_t i0 = (int64_t)blockIdx.x * PER_BLK + 4 * t;
+  double m = INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double v = 0.0;
+    if (i0 + e < size) { v = a.p[i0 + e]; m = fmin(m, v); }
+    tr[PER_BLK + 4 * t + e] = v;
+  }
+  sm[t] = m;
+  __syncthreads();
+  const double root = per_tree_build(tr);
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) sm[t] = fmin(sm[t], sm[t + off]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    a.bsum[blockIdx.x] = root;
+    a.bmin[blockIdx.x] = sm[0];
+    // the block that holds leaf e = size - 2, the last one of the reference's sum(0, size - 1): its part of that sum
+    const int64_t e = size - 2;
+    if (e >= 0 && e / PER_BLK == (int64_t)blockIdx.x)
+      a.st->tail_w = per_prefix_reduce(tr, e % PER_BLK, 1, [] { return 0.0; });
+  }
+}
+
 // g / do_gather: the row's transition is gathered (and VecNormalized) right here once its replay index is known -- the
 // gather launch of the update disappears; the launch also opens the update (Adam step size) when g.adam_tick is set.
 __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
   __shared__ double tr[2 * PER_BLK];
-  __shared__ float smin[256];
+  __shared__ double smin[256];
+  __shared__ double s_total_s;
   const int t = threadIdx.x, k = blockIdx.x;
   const int64_t size = a.sc->replay_size;
   // ---- upper tree: leaves = block sums (zero beyond n_blocks, like the unused leaves of the reference's tree)
-  float m = INFINITY;
+  double m = INFINITY;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int j = 4 * t + e;
     tr[PER_BLK + j] = j < n_blocks ? a.bsum[j] : 0.0;
-    if (j < n_blocks) m = fminf(m, a.bmin[j]);
+    if (j < n_blocks) m = fmin(m, a.bmin[j]);
   }
   smin[t] = m;
   __syncthreads();
   const double total = per_tree_build(tr);
   for (int off = 128; off > 0; off >>= 1) {
-    if (t < off) smin[t] = fminf(smin[t], smin[t + off]);
+    if (t < off) smin[t] = fmin(smin[t], smin[t + off]);
     __syncthreads();
   }
-  const float pmin = smin[0];
-  float u;
-  if (a.u) u = a.u[k];
-  else {
-    const uint64_t step = a.sc->rng_step;
-    uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)k, 0x50455221u};
-    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-    u = (float)(c[0] >> 8) * (1.f / 16777216.f);
+  const double pmin = smin[0];
+  if (t == 0) {
+    const double tail = a.st->tail_w;
+    s_total_s = size >= 2 ? per_prefix_reduce(tr, size - 2, PER_BLK, [tail] { return tail; }) : 0.0;
   }
-  double rem = ((double)u + (double)k) * total / (double)a.B;
+  __syncthreads();
+  const double total_s = s_total_s;
+  double rem = per_mass(a, k, per_uniform(a, k), total_s);
   const int j = per_tree_walk(tr, rem);
   __syncthreads();                                   // everyone is done reading the upper tree
   // ---- the subtree of block j
@@ -140,27 +204,26 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int i = 4 * t + e;
-    tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? (double)a.p[b0 + i] : 0.0;
+    tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? a.p[b0 + i] : 0.0;
   }
   __syncthreads();
   per_tree_build(tr);
   const int i = per_tree_walk(tr, rem);
-  const int64_t idx = min(b0 + (int64_t)i, size - 1);     // a mass that rounds up to the total walks off the stored range
+  const int64_t idx = min(b0 + (int64_t)i, size - 1);     // (a mass that rounds up to the full total would walk off the stored range)
   if (do_gather) {
     gather_row_device(g, k, idx);
     if (g.adam_tick && k == 0 && t == 0) adam_tick_device(g.sc);
   }
   if (t == 0) {
     a.idx_out[k] = idx;
-    const double ps = (double)a.p[idx] / total, pm = (double)pmin / total;
-    a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));
-    if (k == 0) { a.st->total = total; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }   // q_loss_kernel advances rng_step
+    a.w_out[k] = per_weight(a.p[idx], total, pmin, size, a.st->beta);
+    if (k == 0) { a.st->total = total; a.st->total_s = total_s; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }   // q_loss_kernel advances rng_step
   }
 }
 #endif
 
 // priorities of the minibatch just trained on.  A transition drawn twice keeps the value of its LAST
-// occurrence (what a Python loop over the batch leaves behind): every sample writes unless a later sample
+// occurrence (what NumPy's fancy assignment leaves behind): every sample writes unless a later sample
 // names the same index.  One workgroup; B <= 1024.
 #ifdef GRL_HOSTEMU
 #include "per_kernels_ref2.h"   // tests/hostemu: the emulation build only
@@ -179,7 +242,7 @@ __device__ __forceinline__ void per_update_body(const PerArgs& a, const int64_t*
       const int64_t me = sidx[k];
       bool later = false;
       for (int j = k + 1; j < a.B; ++j) later = later || sidx[j] == me;
-      if (!later) a.p[me] = powf(pr, a.alpha);
+      if (!later) a.p[me] = (double)per_powf(pr, a.alpha);
     }
     smax[t] = mx;
   }

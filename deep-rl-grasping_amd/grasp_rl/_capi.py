@@ -24,7 +24,7 @@ class GrlConfig(C.Structure):
         ("q_n_value", C.c_int32), ("q_value", C.c_int32 * GRL_MAX_LAYERS),
         ("q_huber", C.c_int32), ("q_double", C.c_int32), ("q_grad_clip", C.c_float), ("q_trunk_scale", C.c_float),
         ("q_per", C.c_int32), ("q_per_alpha", C.c_float), ("q_per_eps", C.c_float),
-        ("replay_rgb_u8", C.c_int32),
+        ("replay_rgb_u8", C.c_int32), ("q_per_stratified", C.c_int32), ("q_per_alpha64", C.c_double),
     ]
 
 
@@ -91,7 +91,7 @@ def load_library(path=None):
     lib.grl_compute_grads_staged.argtypes = [vp, i32, vp, vp]
     lib.grl_grad_ranges.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.grl_q_update_target.argtypes = [vp]
-    lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_float, vp]
+    lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_double, vp]
     lib.grl_ae_train_step.argtypes = [vp, vp, C.c_int]
     lib.grl_ae_reconstruct.argtypes = [vp, vp, vp]
     lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]
@@ -176,8 +176,10 @@ def make_ae_config(batch_size=128, lr=2e-4, act_batch=16):
 def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(64, 64), value_hidden=(64, 64),
                   batch_size=32, act_batch=1, replay_capacity=50000, normalize=False, gamma=0.99, lr=5e-4,
                   double_q=True, grad_clip=10.0, clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, seed=0,
-                  prioritized=False, per_alpha=0.6, per_eps=1e-6):
-    """DQN (algo='dqn': separate dueling towers) / BDQ (algo='bdq': shared trunk + branches)."""
+                  prioritized=False, per_alpha=0.6, per_eps=1e-6, per_stratified=False):
+    """DQN (algo='dqn': separate dueling towers) / BDQ (algo='bdq': shared trunk + branches).
+    per_stratified: False = stable-baselines 2.10.x sampler (mass = random(batch) * total), True = the stratified
+    sampler of OpenAI baselines / stable-baselines < 2.10 (include/grl.h, grl_config.q_per_stratified)."""
     cfg = make_config("mlp", obs_dim=obs_dim, act_dim=n_branches, layers=(1,), batch_size=batch_size,
                       act_batch=act_batch, replay_capacity=replay_capacity, normalize=normalize, gamma=gamma, lr=lr,
                       clip_obs=clip_obs, clip_reward=clip_reward, norm_eps=norm_eps, seed=seed)
@@ -195,4 +197,5 @@ def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(6
     cfg.q_grad_clip = grad_clip
     cfg.q_trunk_scale = 1.0 / (n_branches + 1) if (algo == "bdq" and len(common) > 0) else 1.0
     cfg.q_per, cfg.q_per_alpha, cfg.q_per_eps = (1 if prioritized else 0), per_alpha, per_eps
+    cfg.q_per_alpha64, cfg.q_per_stratified = float(per_alpha), (1 if per_stratified else 0)
     return cfg

@@ -295,8 +295,9 @@ class SacEngine:
         check(self.lib, self.lib.grl_profile_dump(self.h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            tag, ms, n, fl, by = line.split(":")
-            out[tag] = {"avg_ms": float(ms), "launches": int(n), "flops": float(fl), "bytes": float(by)}
+            tag, ms, n, fl, by, fx = line.split(":")
+            out[tag] = {"avg_ms": float(ms), "launches": int(n), "flops": float(fl), "bytes": float(by),
+                        "flops_executed": float(fx)}
         return out
 
 
@@ -336,12 +337,13 @@ class QEngine(SacEngine):
 
     # ---- prioritised replay on the device (cfg.q_per; csrc/per_kernels.h)
     def train_per(self, n_steps=1, beta=1.0, u=None):
-        """n_steps updates on minibatches drawn proportionally to priority**alpha (stratified), with
-        importance weights (N p)^-beta / max; priorities are refreshed on the device afterwards.
-        u: optional host array [n_steps, B] of uniforms in [0, 1) (parity tests); None = device RNG."""
+        """n_steps updates on minibatches drawn proportionally to the stored priority**alpha leaves, with importance
+        weights (N p)^-beta / max; the leaves of the trained transitions are refreshed on the device afterwards
+        (stable-baselines PrioritizedReplayBuffer.sample / update_priorities).
+        u: optional host array [n_steps, B] of float64 uniforms in [0, 1) (parity tests); None = device RNG."""
         pu, keep = None, None
         if u is not None:
-            u = np.ascontiguousarray(u, dtype=np.float32).reshape(n_steps, self.B)
+            u = np.ascontiguousarray(u, dtype=np.float64).reshape(n_steps, self.B)
             keep = self.be.to_device(u)
             pu = C.c_void_p(self.be.ptr(keep))
         check(self.lib, self.lib.grl_train_step_per(self.h, n_steps, float(beta), pu))
@@ -354,8 +356,12 @@ class QEngine(SacEngine):
         return self.fetch("weights", (self.B,))
 
     def stored_priorities(self):
-        """priority**alpha of every slot of the ring (zeros where nothing is stored)"""
-        return self.fetch("per_p", (int(self.cfg.replay_capacity),))
+        """float64 leaves priority**alpha of every slot of the ring (zeros where nothing is stored)"""
+        return self.fetch("per_p", (2 * int(self.cfg.replay_capacity),)).view(np.float64).copy()
+
+    def store_priorities(self, leaves):
+        """Overwrite the float64 leaves (parity tests only)."""
+        self.store("per_p", np.ascontiguousarray(leaves, np.float64).view(np.float32))
 
     def td_errors(self):
         return self.fetch("td", (self.B, self.D))

@@ -119,6 +119,98 @@ class SyntheticGraspEnv:
         pass
 
 
+class ReachGraspEnv:
+    """LEARNABLE surrogate of the reference's grasping task, for evidence that the update path learns (the metric's
+    second half, "grasp success": `manipulation_main/utils.py:10-44` prints `Mean success rate` from `info['is_success']`;
+    PyBullet is not available here, so the physics is replaced by a task with the same interface and a known optimum).
+
+    An object ("blob", a disc 0.3 m closer to the camera than the table) sits at p in [-0.8, 0.8]^2 of the camera image;
+    the first two action dimensions are the commanded x / y of the gripper (the reference's action = [dx, dy, dz, dyaw,
+    open], actuator.py:54-89).  Reward per step = 1 - |a_xy - p| (dense, like the shaped reward of gripper_grasp.yaml:
+    39-47 in spirit; centred so that a random policy's return is ~0); the object stays put for one 15-step episode;
+    the gripper closes linearly over the episode, so the width feature (pixel [0, 0] of the pad channel, robot.py:
+    199-204) is 1 - t/T -- with a fixed horizon and an unobservable clock the bootstrapped targets carry a time-to-go
+    term 100x the variance of the action-dependent reward (measured with the CPU oracle as the learner,
+    scripts/learn_check_oracle.py: no learning in 40 000 updates without it, 0.89 success after 20 000 with it).
+    `is_success` = the last command of the episode is within `tol` of the object.  A uniformly random policy succeeds in
+    ~7 % of the episodes (tol 0.3).
+
+    kind 'depth'  -> obs [64, 64, 2] float32 exactly as robot.py:183-205 builds it (depth image + pad channel carrying the
+                     gripper width in pixel [0, 0]), Box(0, 255) so the SB CNN policies accept it;
+    kind 'vector' -> obs [101]: the 100-d 'auto-encoder feature' stand-in (two 50-bin Gaussian bumps at p_x, p_y) + the
+                     width, the shape sensor.py:220-222 hands to the MLP policies and to DQN / BDQ.
+    action 'box' (SAC, BDQ: Box(-1, 1, [5])) or 'discrete' (DQN: Discrete(n); action k commands x = -1 + 2k/(n-1) and the
+    reward only looks at p_x)."""
+
+    def __init__(self, kind="depth", episode_len=15, seed=0, act_dim=5, action="box", n_discrete=12, tol=0.3):
+        from .sb.spaces import Box, Discrete
+        self.kind, self.episode_len, self.tol = kind, int(episode_len), float(tol)
+        if kind == "depth":
+            self.observation_space = Box(0, 255, shape=(64, 64, 2), dtype=np.float32)
+        else:
+            self.observation_space = Box(-np.inf, np.inf, shape=(101,), dtype=np.float32)
+        self.discrete = action == "discrete"
+        self.action_space = Discrete(n_discrete) if self.discrete else Box(-1.0, 1.0, shape=(act_dim,), dtype=np.float32)
+        self.n_discrete = n_discrete
+        self.depth_obs, self.full_obs = (kind == "depth"), False
+        self.episode_step, self.episode_rewards = 0, 0.0
+        self.history, self.sr_mean = [], 0.0
+        self.curriculum = type("Curriculum", (), {"_lambda": 0.0})()
+        self._rng = np.random.default_rng(seed)
+        yy, xx = np.mgrid[0:64, 0:64].astype(np.float32)
+        self._yy, self._xx = yy, xx
+        self._centres = np.linspace(-1.0, 1.0, 50, dtype=np.float32)
+        self._p = np.zeros(2, np.float32)
+        self._width = 0.5
+
+    def is_simplified(self):
+        return False
+
+    def _obs(self):
+        if self.kind == "depth":
+            cx, cy = 31.5 + 30.0 * self._p[0], 31.5 + 30.0 * self._p[1]
+            img = 0.6 + 0.01 * self._rng.standard_normal((64, 64)).astype(np.float32)
+            img[(self._xx - cx) ** 2 + (self._yy - cy) ** 2 <= 36.0] = 0.3
+            o = np.zeros((64, 64, 2), np.float32)
+            o[..., 0] = img
+            o[0, 0, 1] = self._width
+            return o
+        o = np.empty(101, np.float32)
+        o[:50] = np.exp(-0.5 * ((self._centres - self._p[0]) / 0.08) ** 2)
+        o[50:100] = np.exp(-0.5 * ((self._centres - self._p[1]) / 0.08) ** 2)
+        o[100] = self._width
+        return o + 0.01 * self._rng.standard_normal(o.shape).astype(np.float32)
+
+    def reset(self):
+        self.episode_step, self.episode_rewards = 0, 0.0
+        self._p = self._rng.uniform(-0.8, 0.8, 2).astype(np.float32)
+        self._width = 1.0
+        return self._obs()
+
+    def distance(self, action):
+        if self.discrete:
+            return abs(-1.0 + 2.0 * int(action) / (self.n_discrete - 1) - float(self._p[0]))
+        a = np.clip(np.asarray(action, np.float32).reshape(-1)[:2], -1.0, 1.0)
+        return float(np.sqrt(np.sum((a - self._p) ** 2)))
+
+    def step(self, action):
+        self.episode_step += 1
+        d = self.distance(action)
+        r = 1.0 - d
+        self.episode_rewards += r
+        done = self.episode_step >= self.episode_len
+        self._width = 1.0 - self.episode_step / float(self.episode_len)
+        ok = bool(d < self.tol)
+        if done:
+            self.history.append(int(ok))
+            self.sr_mean = float(np.mean(self.history[-100:]))
+        return self._obs(), r, done, {"is_success": ok, "episode_step": self.episode_step,
+                                      "episode_rewards": self.episode_rewards, "status": int(ok), "distance": d}
+
+    def close(self):
+        pass
+
+
 def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0"):
     """Env-steps / second and updates / second of ``SAC.learn`` (train_freq 1, gradient_steps 1: one update per
     loop iteration, as sb_helper.py:120-128 configures it) with `n_envs` SyntheticGraspEnv worker processes behind

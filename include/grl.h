@@ -101,6 +101,14 @@ typedef struct grl_config {
      (full_depth_obs.yaml / SAC_full_rgbd) is 65.5 GB of HBM.  Lossless iff the colour values are integers in
      [0, 255]; the caller vouches for that.  Requires 4 image channels (augmented extractor on 5-channel obs). */
   int32_t replay_rgb_u8;
+  /* prioritised replay, continued.  q_per_stratified: 0 = stable-baselines 2.10.x `_sample_proportional`
+     (mass = np.random.random(size=batch) * total; the version setup.py:7-12 pins), 1 = the stratified form of
+     OpenAI baselines / stable-baselines < 2.10 (mass_k = random() * L + k * L, L = total / batch).
+     q_per_alpha64: prioritized_replay_alpha as the Python float the reference passes (the exponent of
+     `max_priority ** alpha` at add time; q_per_alpha is its float32 rounding, the exponent NumPy uses for the
+     float32 priorities of an update); 0 = use q_per_alpha. */
+  int32_t q_per_stratified;
+  double q_per_alpha64;
 } grl_config;
 
 /* byte sizes of the four caller-provided device arenas */
@@ -165,10 +173,13 @@ int64_t grl_replay_size(grl_handle h);
    DQN / BDQ handles: `eps` carries the prioritised-replay importance weights [n_steps*batch]
    (NULL with idx == NULL: uniform sampling on the device, weights 1). */
 int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
-/* DQN / BDQ with q_per: n_steps updates on minibatches drawn proportionally to priority**alpha
-   (stratified), importance weights (N p)^-beta / max, then priorities <- (|td| + eps)**alpha.
-   u_or_null: DEVICE pointer to [n_steps*batch] uniforms in [0,1) (parity tests); NULL = device Philox. */
-int grl_train_step_per(grl_handle h, int n_steps, float beta, const float* u_or_null);
+/* DQN / BDQ with q_per (stable-baselines DQN.learn with prioritized_replay=True: replay_buffer.sample(batch_size,
+   beta=...) -> _train_step(importance weights) -> update_priorities(|td| + eps)): n_steps updates on minibatches drawn
+   proportionally to the float64 leaves priority**alpha (csrc/per_kernels.h restates the segment-tree arithmetic),
+   importance weights (N p)^-beta / max, then leaves <- float32(|td| + eps) ** float32(alpha).  beta > 0, at least two
+   stored transitions.  u_or_null: DEVICE pointer to [n_steps*batch] float64 uniforms in [0,1) (what np.random.random
+   delivers; parity tests); NULL = device Philox, 53 bits per draw. */
+int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u_or_null);
 /* DQN / BDQ: hard copy of the online network into the target network (target_network_update_freq) */
 int grl_q_update_target(grl_handle h);
 /* split form for data parallelism: grads -> (caller all-reduces the grads arena) -> apply */
@@ -223,7 +234,8 @@ int64_t grl_debug_store(grl_handle h, const char* name, const float* in, int64_t
 int grl_profile_enable(grl_handle h, int on);
 /* host: average ms per launch of the kernel tagged `name` since enable; "" lists tags into name_out */
 int grl_profile_query(grl_handle h, const char* name, double* avg_ms, int64_t* launches);
-/* host: one "tag:avg_ms:launches:flops_per_launch:bytes_per_launch" line per profiled tag */
+/* host: one "tag:avg_ms:launches:flops_per_launch:bytes_per_launch:executed_flops_per_launch" line per profiled tag
+   (flops = algorithmic 2*M*N*K over taps that exist; executed >= flops only for the masked backward-data form) */
 int grl_profile_dump(grl_handle h, char* buf, int cap);
 
 #ifdef __cplusplus

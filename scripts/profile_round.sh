@@ -25,6 +25,13 @@ GRL_PLAN_DUMP=1 timeout 200 python bench.py --steps 2 --warmup 1 $ARGS 2> $OUT/p
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, re, sys, os
 out = sys.argv[1]
+# ---- launch tags by grid size
+tag_of = {}
+for line in open(out + '/plan.txt'):
+    m = re.match(r'grl plan: (\S+) .* tiles (\d+)', line)
+    if m: tag_of.setdefault(str(int(m.group(2)) * 256), m.group(1))
+    m2 = re.match(r"grl plan: (\S+) +carries (\d+) filler tiles of '(\S+)' behind its own (\d+)", line)   # pair launch: one grid
+    if m2: tag_of[str((int(m2.group(2)) + int(m2.group(4))) * 256)] = m2.group(1) + '+' + m2.group(3)
 # ---- (1) kernel stats of the grl:: kernels
 rows = list(csv.DictReader(open(glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True)[0])))
 with open(out + '/kernel_summary.txt', 'w') as f:
@@ -34,13 +41,21 @@ with open(out + '/kernel_summary.txt', 'w') as f:
             n = r['Name'].replace('void ', '').split('(')[0][:96]
             f.write("%-98s calls %5s avg %8.2f us  min %7.2f  total %9.1f us\n" % (n, r['Calls'], float(r['AverageNs']) / 1e3, float(r['MinNs']) / 1e3, float(r['TotalDurationNs']) / 1e3))
     f.write(open(out + '/bench_under_trace.json').read()[:600] + "\n")
-# ---- launch tags by grid size
-tag_of = {}
-for line in open(out + '/plan.txt'):
-    m = re.match(r'grl plan: (\S+) .* tiles (\d+)', line)
-    if m: tag_of.setdefault(str(int(m.group(2)) * 256), m.group(1))
-    m2 = re.match(r"grl plan: (\S+) +carries (\d+) filler tiles of '(\S+)' behind its own (\d+)", line)   # pair launch: one grid
-    if m2: tag_of[str((int(m2.group(2)) + int(m2.group(4))) * 256)] = m2.group(1) + '+' + m2.group(3)
+# ---- (1b) per-LAUNCH averages under graph replay (kernel trace grouped by kernel + grid -> launch tag): the lines bench.py's
+# roofline.frac_graph reads ("launch <tag> calls <n> avg <us> us ...")
+tr = glob.glob(out + '/trace/**/*kernel_trace.csv', recursive=True)
+if tr:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        if 'grl::' not in r['Kernel_Name']: continue
+        nm = r['Kernel_Name'].replace('void ', '').split('(')[0][:60]
+        g = str(int(r.get('Grid_Size', r.get('Grid_Size_X', '0'))))
+        t = tag_of.get(g, '') if 'igemm' in nm else nm.replace('grl::', '').replace('_kernel', '').split('<')[0]
+        per[(t or nm + ':' + g).split('+')[0]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    with open(out + '/kernel_summary.txt', 'a') as f:
+        f.write("per launch tag (kernel trace grouped by kernel + grid size; tags from GRL_PLAN_DUMP):\n")
+        for t, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            f.write("launch %-16s calls %5d avg %8.2f us  min %7.2f  total %9.1f us\n" % (t, len(v), sum(v) / len(v), min(v), sum(v)))
 def collect(pattern):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
     for fpath in sorted(glob.glob(out + pattern, recursive=True)):

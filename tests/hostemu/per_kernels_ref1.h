@@ -19,37 +19,33 @@ inline void per_blocksum_kernel(PerArgs a) {
   const int64_t size = a.sc->replay_size;
   const int64_t i0 = (int64_t)blockIdx.x * PER_BLK;
   static thread_local double tr[2 * PER_BLK];
-  float m = INFINITY;
+  double m = INFINITY;
   for (int i = 0; i < PER_BLK; ++i) {
     const bool in = i0 + i < size;
-    tr[PER_BLK + i] = in ? (double)a.p[i0 + i] : 0.0;
-    if (in) m = fminf(m, a.p[i0 + i]);
+    tr[PER_BLK + i] = in ? a.p[i0 + i] : 0.0;
+    if (in) m = fmin(m, a.p[i0 + i]);
   }
   a.bsum[blockIdx.x] = per_tree_root(tr, PER_BLK);
   a.bmin[blockIdx.x] = m;
+  const int64_t e = size - 2;
+  if (e >= 0 && e / PER_BLK == (int64_t)blockIdx.x) a.st->tail_w = per_prefix_reduce(tr, e % PER_BLK, 1, [] { return 0.0; });
 }
 inline void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
   const int k = blockIdx.x;
   const int64_t size = a.sc->replay_size;
   static thread_local double tr[2 * PER_BLK];
-  float pmin = INFINITY;
+  double pmin = INFINITY;
   for (int j = 0; j < PER_BLK; ++j) {
     tr[PER_BLK + j] = j < n_blocks ? a.bsum[j] : 0.0;
-    if (j < n_blocks) pmin = fminf(pmin, a.bmin[j]);
+    if (j < n_blocks) pmin = fmin(pmin, a.bmin[j]);
   }
   const double total = per_tree_root(tr, PER_BLK);
-  float u;
-  if (a.u) u = a.u[k];
-  else {
-    const uint64_t step = a.sc->rng_step;
-    uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)k, 0x50455221u};
-    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-    u = (float)(c[0] >> 8) * (1.f / 16777216.f);
-  }
-  double rem = ((double)u + (double)k) * total / (double)a.B;
+  const double tail = a.st->tail_w;
+  const double total_s = size >= 2 ? per_prefix_reduce(tr, size - 2, PER_BLK, [tail] { return tail; }) : 0.0;
+  double rem = per_mass(a, k, per_uniform(a, k), total_s);
   const int j = per_tree_walk(tr, PER_BLK, rem);
   const int64_t b0 = (int64_t)j * PER_BLK;
-  for (int i = 0; i < PER_BLK; ++i) tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? (double)a.p[b0 + i] : 0.0;
+  for (int i = 0; i < PER_BLK; ++i) tr[PER_BLK + i] = (j < n_blocks && b0 + i < size) ? a.p[b0 + i] : 0.0;
   per_tree_root(tr, PER_BLK);
   const int64_t i = std::min<int64_t>(b0 + per_tree_walk(tr, PER_BLK, rem), size - 1);
   if (do_gather) {                       // (every emulated thread walks the tree, as on the device, then gathers its elements)
@@ -58,7 +54,6 @@ inline void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gath
   }
   if (threadIdx.x != 0) return;
   a.idx_out[k] = i;
-  const double ps = (double)a.p[i] / total, pm = (double)pmin / total;
-  a.w_out[k] = (float)(pow(ps * (double)size, -(double)a.st->beta) / pow(pm * (double)size, -(double)a.st->beta));
-  if (k == 0) { a.st->total = total; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }
+  a.w_out[k] = per_weight(a.p[i], total, pmin, size, a.st->beta);
+  if (k == 0) { a.st->total = total; a.st->total_s = total_s; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }
 }

@@ -5,7 +5,7 @@ inline void per_update_ref(const PerArgs& a, const int64_t* idx) {
   float mx = a.st->max_priority;
   for (int k = 0; k < a.B; ++k) {
     const float pr = a.prio_in[k] + a.eps;
-    a.p[idx[k]] = powf(pr, a.alpha);
+    a.p[idx[k]] = (double)per_powf(pr, a.alpha);
     mx = fmaxf(mx, pr);
   }
   a.st->max_priority = mx;

@@ -106,10 +106,23 @@ def run_and_compare(case, backend=None, lib_path=None):
 
 # ---------------------------------------------------------------------------------------------------
 # prioritised replay on the device (csrc/per_kernels.h) against oracle/per.py, draw for draw
-def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps=4, seed=3, case_name="dqn"):
-    """Fill, then alternate (sample with explicit uniforms -> update -> priorities written back).  The drawn
-    indices must EQUAL the oracle's segment-tree walk over the same float32 priorities; the importance weights
-    and the stored priorities must match the oracle within float tolerances."""
+def _leaves_equal(dev, ref, exact, what):
+    """float64 leaves: bit-equal; `exact=False` (GPU, leaves written by `add` after max_priority left 1.0) allows the
+    last bit of a FLOAT64 pow to differ between the device's math library and libm."""
+    if exact:
+        assert np.array_equal(dev, ref), "%s: %d leaves differ, max rel %.3e" % (
+            what, int((dev != ref).sum()), float(np.max(np.abs(dev - ref) / np.maximum(np.abs(ref), 1e-300))))
+    else:
+        assert np.all(np.abs(dev - ref) <= np.spacing(np.abs(ref))), what
+
+
+def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps=5, seed=3, case_name="dqn",
+              stratified=False):
+    """Fill, then alternate (sample with explicit float64 uniforms -> update -> leaves written back) for n_steps
+    rounds, then add across the ring wrap and sample again.  The oracle (stable-baselines' segment trees, restated in
+    oracle/per.py) and the device evolve INDEPENDENTLY: the only values handed from one to the other are the
+    uniforms and, as in DQN.learn, the TD errors of the minibatch.  After every round the drawn indices must be
+    EQUAL and the float64 leaves bit-identical; the importance weights agree to float32 rounding."""
     from oracle.per import PerOracle
     rng = np.random.default_rng(seed)
     c = dict(CASES[case_name])
@@ -117,43 +130,45 @@ def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps
     case = make_q_case(n_replay=n_store, n_steps=n_steps, **c)
     case["cfg"].replay_capacity = cap
     case["cfg"].q_per, case["cfg"].q_per_alpha, case["cfg"].q_per_eps = 1, 0.6, 1e-6
+    case["cfg"].q_per_alpha64, case["cfg"].q_per_stratified = 0.6, int(stratified)
     eng = q_engine_setup(case, backend=backend, lib_path=lib_path)
-    orc = PerOracle(cap, 0.6, 1e-6)
+    on_cpu = backend is not None
+    orc = PerOracle(cap, 0.6, 1e-6, stratified=stratified)
     orc.add(n_store)
     p0 = eng.stored_priorities()
-    assert np.array_equal(p0[:n_store], orc.p[:n_store]) and not p0[n_store:].any()
-    for s in range(n_steps):
-        beta = 0.4 + 0.15 * s
-        u = rng.random(B).astype(np.float32)
-        # index work is bit-exact: hand the oracle the float32 priorities the device holds (its own powf results
-        # may differ from NumPy's in the last bit -- checked separately below with a tolerance) and require the
-        # segment-tree walk over them to name the SAME transitions
-        orc.p[:] = eng.stored_priorities()
+    assert p0.dtype == np.float64 and np.array_equal(p0, orc.leaves) and not p0[n_store:].any()
+
+    def one_round(s, beta):
+        u = rng.random(B)                               # float64, like np.random.random
         eng.train_per(1, beta, u[None])
         idx = eng.sampled_indices()
+        ref_idx, ref_w = orc.sample(u, beta)
+        assert np.array_equal(idx, ref_idx), (s, idx, ref_idx)
+        assert idx.max() <= orc.size - 2                # the published sum(0, len - 1) never draws the newest transition
         w = eng.importance_weights()
-        ref_idx, ref_w, mass, prefix = orc.sample(u, beta)
-        assert np.array_equal(idx, ref_idx), (idx, ref_idx)
-        # (and the walk's answer owns the stratified mass of the sequential float64 prefix sums up to rounding)
-        tol = 1e-9 * prefix[-1]
-        assert np.all((prefix[idx] <= mass + tol) & (mass < prefix[idx + 1] + tol))
-        assert np.allclose(w, ref_w, rtol=2e-5, atol=1e-7), (w, ref_w)
+        assert np.allclose(w, ref_w.astype(np.float32), rtol=1e-6, atol=0), (w, ref_w)
         assert w.max() <= 1.0 + 1e-6 and w.min() > 0
-        prio = eng.priorities()                        # sum_d |td_d| of the minibatch just trained on
-        orc.update(idx, prio)
-        p = eng.stored_priorities()
-        assert np.allclose(p[:n_store], orc.p[:n_store], rtol=2e-6, atol=0), np.abs(p[:n_store] - orc.p[:n_store]).max()
-    # new transitions enter with the maximal priority seen so far, ring wrap included
+        orc.update(idx, eng.priorities())               # |td| of the minibatch just trained on (sum over branches)
+        return idx
+
+    for s in range(n_steps):
+        one_round(s, 0.4 + 0.1 * s)
+        _leaves_equal(eng.stored_priorities(), orc.leaves, True, "leaves after update %d" % s)
+    assert float(orc._max_priority) > 1.0              # the TD errors of these cases exceed 1: `add` now takes a float64 power
+    # new transitions enter with max_priority ** alpha, ring wrap included; then sampling goes on over the mixed leaves
     tr = case["tr"]
     k = cap - n_store + 7
     eng.replay_add(tr["obs"][:k], tr["act"][:k], tr["rew"][:k], tr["next_obs"][:k], tr["done"][:k])
     orc.add(k)
-    p = eng.stored_priorities()
-    assert np.allclose(p, orc.p, rtol=2e-6, atol=0)
-    # device RNG path: runs, indices in range, deterministic stratification (one draw per stratum)
+    _leaves_equal(eng.stored_priorities(), orc.leaves, on_cpu, "leaves after add")
+    if on_cpu:
+        for s in range(2):
+            one_round(n_steps + s, 0.9 + 0.05 * s)
+            _leaves_equal(eng.stored_priorities(), orc.leaves, True, "leaves after update %d" % (n_steps + s))
+    # device RNG path: runs, indices in range
     eng.train_per(2, 1.0)
     idx = eng.sampled_indices()
     assert idx.min() >= 0 and idx.max() < cap
-    tot = p.astype(np.float64).sum()
+    tot = float(orc._it_sum.sum())
     eng.close()
     return tot

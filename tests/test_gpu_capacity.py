@@ -135,7 +135,7 @@ def test_one_million_transition_rgbd_ring_with_byte_colours():
 
 def test_prioritised_sampler_over_one_million_priorities():
     cfg = _capi.make_q_config("dqn", 16, 1, 4, branch_hidden=(16,), value_hidden=(16,), batch_size=64,
-                              replay_capacity=CAP, lr=1e-3, prioritized=True)
+                              replay_capacity=CAP, lr=1e-3, prioritized=True, per_stratified=True)
     eng = QEngine(cfg)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
@@ -159,30 +159,35 @@ def test_prioritised_sampler_over_one_million_priorities():
             done = torch.zeros(chunk, device=dev)
             eng.replay_add_device(obs, act, rew, nxt, done)
         eng.be.stream.synchronize()
-    # all priorities equal: stratified sampling with u = 0.5 must hit the middle of every stratum exactly
-    u = np.full((1, 64), 0.5, np.float32)
+    # all leaves 1.0: the stratified sampler with u = 0.5 must hit the middle of every stratum of the sampled range
+    # [0, CAP - 2] (the published sum(0, len - 1) leaves the newest transition out) exactly
+    u = np.full((1, 64), 0.5)
     eng.train_per(1, beta=0.4, u=u)
     idx = eng.sampled_indices()
-    want = ((np.arange(64) + 0.5) * CAP / 64).astype(np.int64)
+    want = np.floor((np.arange(64) + 0.5) * ((CAP - 1) / 64.0)).astype(np.int64)
     assert np.array_equal(idx, want), (idx[:4], want[:4])
     w = eng.importance_weights()
     assert np.allclose(w, 1.0, atol=1e-6)
-    # arbitrary priorities over the whole ring: the drawn indices must EQUAL the oracle's segment-tree walk over
-    # the same one million float32 values (2^20-leaf tree, 1024 blocks of 1024), weights within float tolerance
+    # arbitrary leaves over the whole ring as the common INITIAL state, then five sample -> update rounds in which the
+    # oracle (stable-baselines' trees, 2^20 leaves) and the device (1024 blocks of 1024) evolve independently: equal
+    # indices, bit-identical float64 leaves, weights to float32 rounding
     from oracle.per import PerOracle
     prng = np.random.default_rng(21)
-    pvals = (prng.gamma(0.7, 1.0, CAP).astype(np.float32) + np.float32(1e-6)) ** np.float32(0.6)
-    pvals[prng.integers(0, CAP, 1000)] *= np.float32(300.0)          # a few very heavy transitions
-    eng.store("per_p", pvals)
-    orc = PerOracle(CAP, 0.6, 1e-6)
+    pvals = ((prng.gamma(0.7, 1.0, CAP).astype(np.float32) + np.float32(1e-6)) ** np.float32(0.6)).astype(np.float64)
+    pvals[prng.integers(0, CAP, 1000)] *= 300.0                     # a few very heavy transitions
+    eng.store_priorities(pvals)
+    orc = PerOracle(CAP, 0.6, 1e-6, stratified=True)
     orc.add(CAP)
-    for trial in range(3):
-        orc.p[:] = eng.stored_priorities()
-        uu = prng.random(64).astype(np.float32)
+    orc._it_sum[np.arange(CAP)] = pvals
+    orc._it_min[np.arange(CAP)] = pvals
+    for trial in range(5):
+        uu = prng.random(64)
         eng.train_per(1, beta=0.7, u=uu[None])
-        ref_idx, ref_w, _, _ = orc.sample(uu, 0.7)
+        ref_idx, ref_w = orc.sample(uu, 0.7)
         assert np.array_equal(eng.sampled_indices(), ref_idx), trial
-        assert np.allclose(eng.importance_weights(), ref_w, rtol=2e-5, atol=1e-7)
+        assert np.allclose(eng.importance_weights(), ref_w.astype(np.float32), rtol=1e-6, atol=0)
+        orc.update(ref_idx, eng.priorities())
+        assert np.array_equal(eng.stored_priorities(), orc.leaves), trial
     # after the write-back the trained transitions carry new priorities; sampling keeps working
     eng.train_per(20, beta=0.5)
     idx = eng.sampled_indices()

@@ -43,6 +43,8 @@ def test_prioritised_replay_plan(hostemu_lib):
     """Sampler / priority write-back / add semantics of the device PER against oracle/per.py (CPU, host emulation)."""
     from hostemu_backend import NumpyHostBackend
     qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib)
-    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=4096, n_store=4096, B=32, n_steps=2, seed=9)
-    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=2500, n_store=2100, B=64, n_steps=2, seed=5,
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, stratified=True)
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=4096, n_store=4096, B=32, n_steps=5, seed=9)
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=2500, n_store=2100, B=64, n_steps=5, seed=5,
                  case_name="bdq_baseline_config3")
+    qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=1024, n_store=1023, B=8, n_steps=5, seed=2)   # leaf size - 2 ends a block

@@ -268,53 +268,57 @@ def test_dueling_aggregation_is_value_plus_centred_advantage():
 
 
 # ----------------------------------------------------------------------------------------------- prioritised replay
-class _SumTree:
-    """stable-baselines `SumSegmentTree` restated from its description: a binary heap over `capacity` leaves
-    (power of two), `find_prefixsum_idx` walks down choosing the left child while its sum exceeds the mass."""
-
-    def __init__(self, cap):
-        self.cap = 1
-        while self.cap < cap:
-            self.cap *= 2
-        self.t = np.zeros(2 * self.cap, np.float64)
-
-    def set(self, i, v):
-        i += self.cap
-        self.t[i] = v
-        i //= 2
-        while i >= 1:
-            self.t[i] = self.t[2 * i] + self.t[2 * i + 1]
-            i //= 2
-
-    def total(self):
-        return self.t[1]
-
-    def find(self, mass):
-        i = 1
-        while i < self.cap:
-            if self.t[2 * i] > mass:
-                i = 2 * i
-            else:
-                mass -= self.t[2 * i]
-                i = 2 * i + 1
-        return i - self.cap
-
-
-def test_proportional_sampler_equals_the_sum_tree_walk():
-    rng = np.random.default_rng(15)
+@pytest.mark.parametrize("stratified", [False, True])
+def test_proportional_sampler_against_cumulative_sums(stratified):
+    """oracle/per.py restates stable-baselines' segment trees; an implementation that shares nothing with it -- a
+    float64 cumulative sum + binary search over the sampled range [0, size - 2] -- must name the same transitions
+    for every mass that is not within rounding of an interval boundary, and the closed-form weights must agree."""
+    rng = np.random.default_rng(15 + int(stratified))
     n, B = 300, 32
-    o = oper.PerOracle(512, alpha=0.6)
+    o = oper.PerOracle(512, alpha=0.6, stratified=stratified)
     o.add(n)
-    pr = rng.uniform(0.01, 5.0, size=n).astype(np.float32)
-    o.update(np.arange(n), pr)
-    tree = _SumTree(512)
-    for i in range(n):
-        tree.set(i, float(o.p[i]))
-    u = rng.uniform(size=B)
-    idx, w, mass, _ = o.sample(u, beta=0.4)
-    assert np.isclose(tree.total(), o.p[:n].astype(np.float64).sum(), rtol=1e-12)
-    want = np.array([tree.find((u[k] + k) * tree.total() / B) for k in range(B)])
-    assert np.array_equal(idx, want)
-    p = o.p[:n].astype(np.float64) / tree.total()
-    assert np.allclose(w, (n * p[idx]) ** -0.4 / (n * p.min()) ** -0.4, rtol=1e-6)
-    assert np.isclose(float(o.max_priority), float(pr.max()) + 1e-6, rtol=1e-6)
+    assert np.array_equal(o.leaves[:n], np.ones(n)) and not o.leaves[n:].any()
+    td = rng.uniform(0.01, 5.0, size=n).astype(np.float32)
+    o.update(np.arange(n), td)
+    leaves = o.leaves[:n].copy()
+    want = ((td + np.float32(1e-6)).astype(np.float64) ** float(np.float32(0.6))).astype(np.float32).astype(np.float64)
+    assert np.array_equal(leaves, want)                       # float32 power, stored as float64
+    cum = np.cumsum(leaves[:n - 1])                            # sum(0, len - 1): the newest transition is left out
+    u = rng.random(B)
+    mass = o.masses(u)
+    assert np.isclose(o._it_sum.sum(0, n - 1), cum[-1], rtol=1e-13)
+    if stratified:
+        assert np.allclose(mass, (u + np.arange(B)) * cum[-1] / B, rtol=1e-13)
+    else:
+        assert np.allclose(mass, u * cum[-1], rtol=1e-13)
+    idx, w = o.sample(u, beta=0.4)
+    ref = np.searchsorted(cum, mass, side="right")
+    clear = np.abs(cum[np.minimum(ref, n - 2)] - mass) > 1e-9 * cum[-1]
+    assert clear.sum() >= B - 1 and np.array_equal(idx[clear], ref[clear])
+    assert idx.max() <= n - 2
+    total = leaves.sum()
+    assert np.allclose(w, (n * leaves[idx] / total) ** -0.4 / (n * leaves.min() / total) ** -0.4, rtol=1e-12)
+    assert float(o._max_priority) == float(np.max(td + np.float32(1e-6)))
+    # a repeated index keeps the value of its last occurrence (NumPy fancy assignment), and add() after the update
+    # takes the float64 power of the float32 running maximum
+    o.update(np.array([5, 7, 5]), np.array([0.5, 0.25, 2.0], np.float32))
+    assert o.leaves[5] == np.float64(np.float32(float(np.float32(2.0) + np.float32(1e-6)) ** float(np.float32(0.6))))
+    o.add(3)
+    assert np.array_equal(o.leaves[n:n + 3], np.full(3, np.float64(o._max_priority) ** 0.6))
+
+
+def test_segment_tree_prefix_reduce_is_right_nested():
+    """`sum(0, end)` of the published SegmentTree adds the left siblings along the path to its last leaf as
+    left + (left' + (...)): checked against that closed form written out by hand on a 16-leaf tree."""
+    rng = np.random.default_rng(3)
+    t = oper.SumSegmentTree(16)
+    vals = rng.uniform(0.1, 3.0, 11)
+    t[np.arange(11)] = vals
+    v = t._value
+    # reduce over [0, 9]: node(0..7) + (node(8..9))
+    assert t.sum(0, 10) == v[2] + v[6 * 2]
+    # reduce over [0, 10]: node(0..7) + (node(8..9) + leaf 10)
+    assert t.sum(0, 11) == v[2] + (v[12] + v[16 + 10])
+    # reduce over [0, 6]: node(0..3) + (node(4..5) + leaf 6)
+    assert t.sum(0, 7) == v[4] + (v[10] + v[16 + 6])
+    assert t.sum() == v[1]
