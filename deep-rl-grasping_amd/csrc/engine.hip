@@ -2202,6 +2202,7 @@ int grl_ctx::plan_sac() {
   dbg["grads"] = {grads, n_train};
   dbg["adam_m"] = {adam_m, n_train};
   dbg["adam_v"] = {adam_v, n_train};
+  dbg["idx_raw"] = {(const float*)idx_buf, (int64_t)2 * B};     // replay indices of the last minibatch: int64 viewed as float pairs
   return GRL_OK;
 }
 

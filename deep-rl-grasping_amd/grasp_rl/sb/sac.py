@@ -9,6 +9,13 @@ raw transition -> every ``train_freq`` steps ``gradient_steps`` updates.
 Differences to stable-baselines, all opt-in: vectorised envs with ``num_envs > 1`` are accepted
 (stable-baselines 2 asserts a single env); ``ent_coef`` must be 'auto' / 'auto_<init>' and
 ``target_update_interval`` 1 (what the reference uses: zip JSON).
+
+Updates per env step.  stable-baselines runs ``gradient_steps`` updates every ``train_freq`` calls of ``env.step``
+and its env is a single environment, so its defaults (1, 1) mean ONE UPDATE PER ENVIRONMENT STEP.  With N
+sub-environments one ``env.step`` is N environment steps; ``gradient_steps=None`` (the default here) resolves to
+``N * train_freq // train_freq = N`` updates per vectorised step and so keeps that ratio (for N = 1 it is
+stable-baselines' 1).  An explicit integer is taken literally (``gradient_steps=1`` with 16 envs = one update per
+16 environment steps).  The k updates of one loop iteration are ONE ``grl_train_step(k)`` call.
 """
 import os
 import time
@@ -36,7 +43,7 @@ class SAC:
 
     def __init__(self, policy, env, gamma=0.99, learning_rate=3e-4, buffer_size=50000, learning_starts=100,
                  train_freq=1, batch_size=64, tau=0.005, ent_coef="auto", target_update_interval=1,
-                 gradient_steps=1, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
+                 gradient_steps=None, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
                  tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False,
                  seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None, replay_rgb_u8=False):
         if isinstance(policy, str):
@@ -90,6 +97,7 @@ class SAC:
             self._vec_normalize_env = unwrap_vec_normalize(env)
             if self.engine is not None and self.n_envs > self.engine.cfg.act_batch:
                 raise ValueError("env has more sub-environments than the model was built for")
+            self._norm_stamp = None     # a new wrapper: its statistics must reach the device whatever their counts are
         self.env = env
 
     def get_env(self):
@@ -143,6 +151,7 @@ class SAC:
             cfg = _capi.make_config(extractor, obs_channels=obs_shape[2], n_direct=n_direct,
                                     replay_rgb_u8=self.replay_rgb_u8, **kw)
         self._extractor = extractor
+        self._norm_stamp = None         # a new engine starts with zero statistics
         self.engine = self._engine_factory(cfg, self.device)
         params = init_parameters(self.engine.table, seed=0 if self.seed is None else int(self.seed))
         params["model/log_ent_coef:0"] = np.float32(np.log(self._ent_init)).reshape(())
@@ -154,7 +163,9 @@ class SAC:
         vn = self._vec_normalize_env
         if vn is None or not self.engine.cfg.normalize:
             return
-        stamp = (id(vn.obs_rms), float(vn.obs_rms.count), id(vn.ret_rms), float(vn.ret_rms.count))
+        # (identity + counts + a content checksum: in-place edits of the arrays and re-loaded pickles are seen too)
+        stamp = (id(vn.obs_rms), float(vn.obs_rms.count), id(vn.ret_rms), float(vn.ret_rms.count),
+                 float(np.sum(vn.obs_rms.mean)), float(np.sum(vn.obs_rms.var)), float(np.sum(vn.ret_rms.var)))
         if stamp == getattr(self, "_norm_stamp", None):
             return                      # frozen wrapper (training=False) or no env step since the last push
         self._norm_stamp = stamp
@@ -222,17 +233,18 @@ class SAC:
                 if self.action_noise is not None:
                     action = np.clip(action + self.action_noise(), -1, 1)
                 unscaled_action = self._unscale(action)
-            def run_updates():
+            def run_updates(step_index=step):
+                # the updates that follow vectorised env step `step_index` (0-based): N * step_index environment steps
+                # precede it -- the same count in the strict and in the overlapped order
                 callback.on_rollout_end()
-                for _ in range(self.gradient_steps):
-                    if eng.replay_size() < self.batch_size or self.num_timesteps < self.learning_starts:
-                        break
-                    self.n_updates += 1
+                k = N if self.gradient_steps is None else int(self.gradient_steps)
+                done_steps = N * step_index
+                if k > 0 and eng.replay_size() >= self.batch_size and done_steps + N >= self.learning_starts:
+                    self.n_updates += k
                     self._sync_norm_stats()
                     if callable(self.learning_rate):    # SB: frac = 1 - step / total (step = index of this env step)
-                        done_steps = max(0, self.num_timesteps - N)
                         eng.set_learning_rate(self.learning_rate(1.0 - done_steps / max(1, total_timesteps)))
-                    eng.train(1)
+                    eng.train(k)
                 callback.on_rollout_start()
 
             self.env.step_async(unscaled_action.reshape((N,) + tuple(self.action_space.shape)))

@@ -250,3 +250,90 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
                 "ms_per_iteration": round(1e3 * dt / iterations, 3)}
     finally:
         venv.close()
+
+
+# ------------------------------------------------------------------------------------------------ learning evidence
+def evaluate_success(model, kind="depth", action="box", episodes=200, seed=10_000, n_discrete=12, vec_normalize=None):
+    """`Mean success rate` of the reference's evaluation loop (manipulation_main/utils.py:10-44: deterministic
+    `model.predict`, `info['is_success']` of the last step) over fresh ReachGraspEnv episodes.  Observations are
+    normalised with the frozen statistics of `vec_normalize` (what `run(args)` does with the saved vecnormalize.pkl)."""
+    env = ReachGraspEnv(kind, seed=seed, action=action, n_discrete=n_discrete)
+    ok, dist = [], []
+    for _ in range(episodes):
+        obs, done = env.reset(), False
+        while not done:
+            o = vec_normalize.normalize_obs(obs[None])[0] if vec_normalize is not None else obs
+            act, _ = model.predict(o, deterministic=True)
+            obs, _, done, info = env.step(act)
+        ok.append(float(info["is_success"]))
+        dist.append(info["distance"])
+    return float(np.mean(ok)), float(np.mean(dist))
+
+
+def learn_reach(algo="sac", kind="depth", total_timesteps=30_000, n_envs=16, device="cuda:0", seed=0, engine_factory=None,
+                eval_episodes=200, **model_kwargs):
+    """Train `algo` ('sac' | 'dqn' | 'bdq') on ReachGraspEnv through the stable-baselines surface the reference drives
+    (sb_helper.py:104-128 / 159-165 / 210-224: VecNormalize(norm_obs, norm_reward, clip_obs 10) + model.learn), then run the
+    reference's evaluation.  Returns dict(train_success = mean is_success of the last 200 TRAINING episodes (the
+    reference's monitor column `s`, trained_models/*/log_file.monitor.csv), eval_success, eval_distance, updates, seconds)."""
+    import time
+    from .sb.callbacks import BaseCallback
+    from .sb.dqn import BDQ, DQN
+    from .sb.policies import AugmentedNatureCnn, SacCnnPolicy, SacMlpPolicy
+    from .sb.sac import SAC
+    from .sb.vec_env import DummyVecEnv, VecNormalize
+
+    class Successes(BaseCallback):
+        def __init__(self):
+            super().__init__()
+            self.s = []
+
+        def _on_step(self):
+            for d, info in zip(np.atleast_1d(self.locals["done"]), self.locals["info"]):
+                if d:
+                    self.s.append(float(info["is_success"]))
+            return True
+
+    action = "discrete" if algo == "dqn" else "box"
+    N = n_envs if algo == "sac" else 1
+    venv = DummyVecEnv([(lambda s=s: ReachGraspEnv(kind, seed=seed * 1000 + s, action=action)) for s in range(N)])
+    env = VecNormalize(venv, norm_obs=True, norm_reward=True, clip_obs=10.0)
+    if algo == "sac":
+        if kind == "depth":
+            policy, pk = SacCnnPolicy, {"layers": [64, 64], "cnn_extractor": AugmentedNatureCnn(1)}
+        else:
+            policy, pk = SacMlpPolicy, {"layers": [64, 64]}
+        kw = dict(buffer_size=100_000, batch_size=256, learning_starts=max(256, N), seed=seed)
+        kw.update(model_kwargs)
+        cls = SAC
+        args = (policy, env)
+        kw["policy_kwargs"] = pk
+    elif algo == "dqn":     # config/gripper_grasp.yaml DQN block: lr 1e-3, batch 32, prioritized_replay
+        kw = dict(learning_rate=1e-3, batch_size=32, prioritized_replay=True, seed=seed)
+        kw.update(model_kwargs)
+        cls, args = DQN, ("MlpPolicy", env)
+    else:                   # ... BDQ block: lr 1e-4, batch 64, layers [[64,64],[32],[32]], 33 bins, eps 0.3 -> 0.1
+        kw = dict(learning_rate=1e-4, batch_size=64, buffer_size=100_000, num_actions_pad=33, learning_starts=1000,
+                  target_network_update_freq=1000, exploration_fraction=0.3, exploration_final_eps=0.1,
+                  prioritized_replay=True, policy_kwargs={"layers": [[64, 64], [32], [32]]}, seed=seed)
+        kw.update(model_kwargs)
+        cls, args = BDQ, ("MlpActPolicy", env)
+    old = cls._engine_factory
+    if engine_factory is not None:
+        cls._engine_factory = staticmethod(engine_factory)
+    try:
+        model = cls(*args, device=device, **kw)
+    finally:
+        cls._engine_factory = old
+    cb = Successes()
+    t0 = time.perf_counter()
+    model.learn(total_timesteps=total_timesteps, callback=cb)
+    model.engine.synchronize()
+    secs = time.perf_counter() - t0
+    env.training = False
+    ev, dist = evaluate_success(model, kind, action, eval_episodes, vec_normalize=env)
+    out = {"algo": algo, "kind": kind, "env_steps": int(model.num_timesteps), "updates": int(model.n_updates),
+           "episodes": len(cb.s), "train_success": float(np.mean(cb.s[-200:])) if cb.s else 0.0,
+           "eval_success": ev, "eval_distance": dist, "seconds": round(secs, 2), "metrics": model.engine.metrics()}
+    model.engine.close()
+    return out

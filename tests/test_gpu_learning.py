@@ -1,0 +1,123 @@
+"""Evidence that the update path LEARNS -- the second half of BASELINE.json's metric ("grasp success@1k eps";
+the reference prints `Mean success rate` from info['is_success'], manipulation_main/utils.py:10-44, and logs it as
+column `s` of log_file.monitor.csv).  PyBullet is not available, so the task is grasp_rl.synthetic.ReachGraspEnv
+(same observation / action interface, known optimum); everything else is the reference's pipeline:
+VecNormalize(norm_obs, norm_reward, clip_obs 10) -> model.learn -> deterministic model.predict evaluation.
+
+Budgets were set with the CPU oracle as the learner (scripts/learn_check_oracle.py) and the host-emulation engine.
+
+Plus two long-horizon checks of the device state that one-to-four-update parity tests cannot see: a 200-update
+trajectory against the oracle on identical index / noise streams, and a 20 000-update soak on the device RNG.
+"""
+import numpy as np
+import pytest
+
+import parity_util as pu
+from grasp_rl import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sac_cnn_learns_to_reach_through_model_learn():
+    """SAC + augmented Nature-CNN on 64x64 depth observations, 16 envs, the reference's hyper-parameters
+    (ent_coef auto, lr 3e-4, gamma 0.99, batch 256): success >= 0.8 over the last 200 training episodes AND in the
+    deterministic evaluation (a uniformly random policy: 0.07)."""
+    r = synthetic.learn_reach("sac", "depth", total_timesteps=40_000, n_envs=16)
+    print(r)
+    assert all(np.isfinite(v) for v in r["metrics"].values())
+    assert r["updates"] >= 39_000
+    assert r["train_success"] >= 0.8 and r["eval_success"] >= 0.8, r
+
+
+def test_sac_mlp_learns_on_encoder_features():
+    """The as-shipped AE-MLP variant (configs[0] / SAC_full_rgbd-style vector observations, sacMlp)."""
+    r = synthetic.learn_reach("sac", "vector", total_timesteps=30_000, n_envs=16, batch_size=64)
+    print(r)
+    assert r["train_success"] >= 0.8 and r["eval_success"] >= 0.8, r
+
+
+def test_dqn_with_prioritised_replay_learns():
+    """DQN block of config/gripper_grasp.yaml (lr 1e-3, batch 32, prioritized_replay) on the 101-d vector task,
+    Discrete(12): random policy 0.27."""
+    r = synthetic.learn_reach("dqn", "vector", total_timesteps=25_000)
+    print(r)
+    assert all(np.isfinite(v) for v in r["metrics"].values())
+    assert r["eval_success"] >= 0.8, r
+
+
+def test_bdq_with_prioritised_replay_learns():
+    """BDQ block of config/gripper_grasp.yaml (5 branches x 33 bins, lr 1e-4, batch 64, eps 0.3 -> 0.1): random 0.07."""
+    r = synthetic.learn_reach("bdq", "vector", total_timesteps=50_000)
+    print(r)
+    assert all(np.isfinite(v) for v in r["metrics"].values())
+    assert r["eval_success"] >= 0.8, r
+
+
+# ------------------------------------------------------------------------------------------------------------------
+METRICS = ("policy_loss", "qf1_loss", "qf2_loss", "value_loss", "ent_coef_loss", "ent_coef", "entropy", "mean_qf1", "mean_v")
+
+
+def trajectory_check(case, eng, n_steps, every, rel=0.02, floors=None):
+    """`n_steps` updates on identical minibatch indices and policy noise, device vs oracle: the nine logged metrics
+    stay within `rel` (relative to max(|ref|, floor of that metric)), ent_coef within 1 %, nothing NaN."""
+    from oracle import sac as osac
+    spec, tr = case["spec"], case["tr"]
+    orc = osac.SacOracle(spec, case["params"])
+    floors = floors or {}
+    worst = {}
+    for s in range(n_steps):
+        ii = case["idx"][s]
+        raw = {k: tr[k][ii] for k in ("obs", "act", "rew", "next_obs", "done")}
+        d = orc.step(osac.prepare_batch(spec, raw, case["stats"]), case["eps"][s])
+        eng.train(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
+        if (s + 1) % every == 0 or s == n_steps - 1:
+            m = eng.metrics()
+            ref = {"policy_loss": d["policy_loss"], "qf1_loss": d["qf1_loss"], "qf2_loss": d["qf2_loss"],
+                   "value_loss": d["value_loss"], "ent_coef_loss": d["ent_loss"], "ent_coef": d["ent_coef"],
+                   "entropy": np.mean(d["entropy"]), "mean_qf1": np.mean(d["qf1"]), "mean_v": np.mean(d["v"])}
+            for k in METRICS:
+                a, b = float(m[k]), float(ref[k])
+                assert np.isfinite(a), (s, k)
+                tol = (0.01 if k == "ent_coef" else rel) * max(abs(b), floors.get(k, 1e-3))
+                worst[k] = max(worst.get(k, 0.0), abs(a - b) / max(abs(b), floors.get(k, 1e-3)))
+                assert abs(a - b) <= tol, "update %d: %s device %.6g oracle %.6g" % (s + 1, k, a, b)
+    return worst
+
+
+def test_200_update_trajectory_follows_the_oracle():
+    case = pu.make_case(extractor="augmented", kind="depth", B=32, n_replay=256, n_steps=200, seed=4)
+    eng = pu.engine_setup(case)
+    # metrics that pass through zero are compared against an absolute floor of their natural scale
+    worst = trajectory_check(case, eng, 200, every=10, floors={"policy_loss": 0.5, "ent_coef_loss": 0.05, "mean_qf1": 0.05,
+                                                               "mean_v": 0.05, "qf1_loss": 0.05, "qf2_loss": 0.05,
+                                                               "value_loss": 0.05})
+    print("worst relative deviation over 200 updates:", {k: round(v, 5) for k, v in worst.items()})
+    eng.close()
+
+
+def test_20000_update_soak_on_the_device_rng():
+    """20 000 updates with device-drawn indices and noise: every metric finite, the entropy coefficient and the
+    Polyak target alive, and the replay indices the device draws uniform over the ring (chi-square)."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=4096, n_steps=1, seed=9)
+    eng = pu.engine_setup(case)
+    counts = np.zeros(4096, np.int64)
+    p0 = eng.get_parameters()
+    for chunk in range(200):
+        eng.train_device(100)
+        idx = eng.fetch("idx_raw", (2 * 256,)).view(np.int64)
+        assert idx.min() >= 0 and idx.max() < 4096
+        np.add.at(counts, idx, 1)
+        if chunk % 50 == 49:
+            m = eng.metrics()
+            assert all(np.isfinite(v) for v in m.values()), (chunk, m)
+    m = eng.metrics()
+    assert 1e-4 < m["ent_coef"] < 1.0 and m["ent_coef"] != 1.0        # log alpha moved from its initial 0 and stayed sane
+    n = counts.sum()
+    chi2 = float(((counts - n / 4096.0) ** 2 / (n / 4096.0)).sum())
+    # chi-square with 4095 degrees of freedom: mean 4095, sd 90.5; +-5 sd
+    assert abs(chi2 - 4095.0) < 5 * 90.5, chi2
+    p1 = eng.get_parameters()
+    moved = max(float(np.abs(p1[k] - p0[k]).max()) for k in p0 if k.startswith("target/"))
+    assert np.isfinite(moved) and moved > 1e-3                          # the Polyak target followed
+    assert all(np.isfinite(v).all() for v in p1.values())
+    eng.close()

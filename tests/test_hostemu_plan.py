@@ -94,3 +94,16 @@ def test_act_matches_oracle(hostemu_lib):
     pu.close(eng.act(obs, True), orc.act(obs, True), what="deterministic action")
     pu.close(eng.act(obs, False, eps), orc.act(obs, False, eps), what="stochastic action")
     eng.close()
+
+
+def test_60_update_trajectory_follows_the_oracle(hostemu_lib):
+    """The long-trajectory comparison of tests/test_gpu_learning.py (200 updates of the CNN on the GPU), here on the
+    MLP variant through the emulation build: identical index / noise streams, nine metrics within 2 %."""
+    from test_gpu_learning import trajectory_check
+    case = pu.make_case(extractor="mlp", B=16, n_replay=128, n_steps=60, seed=4)
+    eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    worst = trajectory_check(case, eng, 60, every=10, floors={"policy_loss": 0.5, "ent_coef_loss": 0.05, "mean_qf1": 0.05,
+                                                              "mean_v": 0.05, "qf1_loss": 0.05, "qf2_loss": 0.05,
+                                                              "value_loss": 0.05})
+    assert max(worst.values()) < 0.02
+    eng.close()
