@@ -85,6 +85,10 @@ struct GatherArgs {
   // Done here, a whole launch chain before the first consumer, so that the fused reduce + Adam launch
   // can read it from any workgroup without ordering against the workgroup that produces the losses.
   int adam_tick;
+  // prefetching launches (the gather of update t+1 riding on the last launch of update t, reduce_slabs_gather_kernel):
+  // rng_ahead = 1 draws with counter rng_step + 1 (the counter still holds update t's value while that launch runs);
+  // quiet = 1: neither mark rng_used nor touch the Adam step size -- the update it prepares has not started yet
+  int rng_ahead, quiet;
 };
 
 __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int normalize, double clip,
@@ -143,13 +147,12 @@ __device__ __forceinline__ void adam_tick_device(DevScalars* sc) {
   sc->beta2_power *= 0.999f;
 }
 
-__global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
-  const int b = blockIdx.y;
-  const int which = blockIdx.z;   // 0: obs, 1: next_obs
+// block (bx, b, which) of the gather grid: elements [bx * per_block, ...) of row b of obs (which 0) / next_obs (1)
+__device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int bx, const int b, const int which) {
   int64_t src;
   uint64_t step = 0;
   if (a.use_rng) {
-    step = a.sc->rng_step;
+    step = a.sc->rng_step + (uint64_t)a.rng_ahead;
     const int64_t size = a.sc->replay_size;
     uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, 0u};
     philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   if (a.vec4) {
     typedef float gn_f4 __attribute__((ext_vector_type(4)));
     typedef double gn_d4 __attribute__((ext_vector_type(4)));
-    const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int e4 = (bx * 256 + threadIdx.x) * 4;
     if (e4 < a.img_elems) {
       const float* rp = which ? a.rp_next : a.rp_obs;
       gn_f4 x;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   } else
 #endif
   {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = bx * 256 + threadIdx.x;
   if (e < a.img_elems) {
     const float* rp = which ? a.rp_next : a.rp_obs;
     float x;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
     }
   }
   }
-  if (blockIdx.x == 0) {
+  if (bx == 0) {
     const int t = threadIdx.x;
     if (t < a.n_direct) {
       const float* rp = which ? a.rp_dnext : a.rp_dobs;
@@ -261,10 +264,13 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   }
   // rng_step itself is advanced by the (single-workgroup) loss reduction later in the update: a counter
   // bumped by the last of these 8192 workgroups would serialise 8192 same-address atomics (~100 us)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+  if (bx == 0 && b == 0 && which == 0 && threadIdx.x == 0 && !a.quiet) {
     if (a.use_rng) a.sc->rng_used = 1u;
     if (a.adam_tick) adam_tick_device(a.sc);
   }
+}
+__global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
+  gather_norm_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -452,6 +458,7 @@ struct LossArgs {
   // fused apply (reduce_slabs_kernel with fuse_adam): this workgroup also applies Adam to log_ent_coef, the
   // one trainable scalar whose gradient is produced here
   float* ent_param; float* ent_m; float* ent_v;
+  int keep_rng;   // 1: leave rng_step alone (multi-update calls whose head launch advances the counter, engine.hip "prefetch")
 };
 
 #ifdef GRL_HOSTEMU
@@ -513,7 +520,7 @@ __device__ __forceinline__ void sac_loss_body(const LossArgs& a, int fuse_adam =
       sc->beta2_power *= 0.999f;
     }
     if (fuse_adam) adam_elem(a.g_log_ent_coef[0], a.ent_param[0], a.ent_m[0], a.ent_v[0], sc->adam_alpha, 1e-8f);
-    if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch came from the device RNG
+    if (sc->rng_used && !a.keep_rng) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch came from the device RNG
   }
 }
 __global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }
@@ -878,14 +885,13 @@ struct ReduceDesc {
 // (slab loads are independent: unrolled so several are in flight; the add order stays k = 0, 1, ...)
 // ... and, as workgroup n_tiles when has_loss is set, the batch reductions of the SAC losses (metrics,
 // entropy-coefficient gradient, Adam step size): they are needed by the apply kernel only.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
-                                                          const int2* __restrict__ tiles, int n_tiles,
-                                                          LossArgs la, int has_loss, AdamArgs aa, int fuse_adam) {
-  if ((int)blockIdx.x >= n_tiles) {
+__device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__ descs, const int2* __restrict__ tiles, int n_tiles,
+                                                  const LossArgs& la, int has_loss, const AdamArgs& aa, int fuse_adam, const int blk) {
+  if (blk >= n_tiles) {
     if (has_loss) sac_loss_body(la, fuse_adam);
     return;
   }
-  const int2 tl = tiles[blockIdx.x];
+  const int2 tl = tiles[blk];
   const ReduceDesc d = descs[tl.x];
 #ifndef GRL_HOSTEMU
   if (d.vec) {
@@ -967,6 +973,24 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
       if (pol) aa.target[kp] = polyak_elem(tg, p, aa.tau);
     }
   }
+}
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
+                                                          const int2* __restrict__ tiles, int n_tiles,
+                                                          LossArgs la, int has_loss, AdamArgs aa, int fuse_adam) {
+  reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)blockIdx.x);
+}
+// The same launch carrying, behind its own workgroups, the replay gather of the NEXT update (grid gx x B x 2 of
+// gather_norm_kernel, linearised): inside a multi-update call nothing is added to the replay between updates, every
+// reader of the minibatch tensors of update t has finished when this last launch of update t starts, and both halves
+// are memory / latency bound -- they overlap instead of paying two launches (engine.hip, "prefetch").
+__global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDesc* __restrict__ descs,
+                                                                 const int2* __restrict__ tiles, int n_tiles,
+                                                                 LossArgs la, int has_loss, AdamArgs aa, int fuse_adam,
+                                                                 GatherArgs ga, int gx) {
+  const int nb = n_tiles + has_loss;
+  if ((int)blockIdx.x < nb) { reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)blockIdx.x); return; }
+  const int r = (int)blockIdx.x - nb;
+  gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -228,6 +228,12 @@ struct grl_ctx {
   bool use_lanes = false;
   LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
+  // SAC, calls of several updates on the device RNG: the next minibatch is gathered inside the last launch of an update
+  std::vector<Op> ops_pf_first, ops_pf_mid, ops_pf_last;
+  Op pf_heads[2];
+  GatherArgs pf_ga;
+  int pf_gx = 0;
+  bool prefetch_ok = false;
   std::vector<Op> ops_grads_apply_per;   // DQN / BDQ with prioritised replay: ... and the priority write-back
   // data parallel, staged (grl_compute_grads_staged): stage 0 ends with the dense (fc + head) gradients final in the
   // bucket, stage 1 is the convolution backward + its weight gradients + the loss reductions
@@ -1497,6 +1503,8 @@ int grl_ctx::plan_sac() {
     ga.vec4 = (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
 #endif
     const int per_block = ga.vec4 ? 1024 : 256;
+    pf_ga = ga;
+    pf_gx = (ga.img_elems + per_block - 1) / per_block;
     for (int mode = 0; mode < 2; ++mode) {
       ga.use_rng = mode;
       Op op; op.tag = "gather_norm";
@@ -1603,15 +1611,23 @@ int grl_ctx::plan_sac() {
           dbg["heads_stamps"] = {(const float*)ha.stamps, 4 * 32 * 2};
         }
       }
-      const HeadsFusedArgs* d_ha = upload_vec(wk, std::vector<HeadsFusedArgs>{ha});
+      // argument blocks: [0] the plain update, [1] / [2] updates of a prefetching multi-update call whose head launch
+      // opens the update (Adam step size) and, from the second update on, advances the RNG counter
+      HeadsFusedArgs hb = ha, hc = ha;
+      hb.sc = hc.sc = sc; hb.tick = hc.tick = 1; hb.rng_advance = 0; hc.rng_advance = 1;
+      const HeadsFusedArgs* d_ha = upload_vec(wk, std::vector<HeadsFusedArgs>{ha, hb, hc});
       const int nblk = (B + HT_RB - 1) / HT_RB;
-      Op op; op.tag = "heads";
       const bool fast = L == 2 && hid[0] == 64 && hid[1] == 64 && B % HT_RB == 0;   // the reference's layers [64, 64]
-      op.run = [d_ha, nblk, fast](hipStream_t s) {
-        if (fast) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, d_ha);
-        else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, d_ha);
-      };
-      ops_grads.push_back(op);
+      for (int v = 0; v < 3; ++v) {
+        Op op; op.tag = "heads";
+        const HeadsFusedArgs* dv = d_ha + v;
+        op.run = [dv, nblk, fast](hipStream_t s) {
+          if (fast) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, dv);
+          else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, dv);
+        };
+        if (v == 0) ops_grads.push_back(op);
+        else pf_heads[v - 1] = op;
+      }
     } else {
     Op op; op.tag = "heads_fwd";
     op.run = [fa](hipStream_t s) {
@@ -2087,6 +2103,46 @@ int grl_ctx::plan_sac() {
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss, aa, 1);
       };
       ops_grads_apply.push_back(fo);
+      // ---- "prefetch": a call of n >= 2 updates on the device RNG gathers the minibatch of update t+1 inside the LAST
+      // launch of update t (reduce_slabs_gather_kernel): nothing enters the replay between the updates of one call, the
+      // Philox counter makes the draw independent of when it happens, and every reader of update t's minibatch tensors
+      // has finished when that launch starts.  Same kernels, same arithmetic, one launch (and one dependent latency
+      // chain) less per update.  The head launch opens the update instead of the gather (see HeadsFusedArgs).
+      //   first : gather (does not touch the Adam step size) | body, heads[tick] | reduce + Adam + gather(t+1, counter + 1)
+      //   middle:                                              body, heads[tick, counter += 1] | reduce + Adam + gather(t+1)
+      //   last  :                                              body, heads[tick, counter += 1] | reduce + Adam (counter += 1)
+      const char* npf = getenv("GRL_NO_GATHER_PREFETCH");
+      if (heads_mfma && !(npf && atoi(npf)) && !use_lanes) {
+        GatherArgs g1 = pf_ga;
+        g1.use_rng = 1; g1.adam_tick = 0; g1.quiet = 0; g1.rng_ahead = 0;
+        const int gx = pf_gx;
+        {
+          Op op; op.tag = "gather_norm";
+          op.bytes = ops_rng[0].bytes;
+          op.run = [g1, gx](hipStream_t s) { hipLaunchKernelGGL(gather_norm_kernel, dim3(gx, g1.B, 2), dim3(256), 0, s, g1); };
+          ops_pf_first.push_back(op);
+        }
+        GatherArgs g2 = g1;
+        g2.quiet = 1; g2.rng_ahead = 1;
+        LossArgs lk = la;
+        lk.keep_rng = 1;
+        Op ro; ro.tag = "reduce_adam";
+        ro.join = true;
+        ro.bytes = fo.bytes + ops_rng[0].bytes;
+        ro.run = [dr, d_rt, ntiles, lk, has_loss, aa, g2, gx](hipStream_t s) {
+          hipLaunchKernelGGL(reduce_slabs_gather_kernel, dim3(ntiles + has_loss + gx * g2.B * 2), dim3(256), 0, s, dr, d_rt, ntiles, lk,
+                             has_loss, aa, 1, g2, gx);
+        };
+        for (int v = 0; v < 3; ++v) {     // 0 first, 1 middle, 2 last
+          std::vector<Op>& dst = v == 0 ? ops_pf_first : (v == 1 ? ops_pf_mid : ops_pf_last);
+          for (size_t k = 0; k + 1 < ops_grads_apply.size(); ++k) {
+            if (ops_grads_apply[k].tag == "heads") dst.push_back(pf_heads[v == 0 ? 0 : 1]);
+            else dst.push_back(ops_grads_apply[k]);
+          }
+          dst.push_back(v == 2 ? fo : ro);
+        }
+        prefetch_ok = true;
+      }
     }
   }
 
@@ -3549,6 +3605,16 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
+  if (!idx && n_steps >= 2 && h->prefetch_ok && !h->prof) {   // device RNG, several updates: prefetching sequences (plan_sac)
+    for (int s = 0; s < n_steps; ++s) {
+      const bool first = s == 0, last = s == n_steps - 1;
+      if (int e = h->run_seq(first ? "pf_first" : (last ? "pf_last" : "pf_mid"),
+                             {first ? &h->ops_pf_first : (last ? &h->ops_pf_last : &h->ops_pf_mid)}))
+        return e;
+    }
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
   for (int s = 0; s < n_steps; ++s) {
     if (idx) {
       if (int e = stage_noise(h, idx, eps, s)) return e;

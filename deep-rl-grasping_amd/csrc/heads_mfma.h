@@ -45,6 +45,12 @@ struct HeadsFusedArgs {
   float* d_out[5];        // [B] (stride ld_d): 1 d_v, 2 d_qf1, 3 d_qf2, 4 d_qf1_pi
   int ld_d;
   unsigned long long* stamps;   // development aid (GRL_HEADS_STAMPS=1): [4 types][32] wall-clock stamps of row block 0
+  // multi-update calls that prefetch the next minibatch (engine.hip "prefetch"): this launch sits between the last
+  // launch of the previous update (which read the Adam step size and drew the indices of THIS update with counter
+  // rng_step + 1) and the last launch of this one, so one thread opens the update here instead of in the gather
+  DevScalars* sc;
+  int tick;          // fix the Adam step size of this update and advance the beta powers (adam_tick_device)
+  int rng_advance;   // rng_step += 1: this update's minibatch was drawn a launch chain ago with rng_step + 1
 };
 
 #ifdef GRL_HOSTEMU
@@ -128,6 +134,10 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
   }
   HM_SYNC();
   const HeadsFusedArgs& a = s.args;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0 && a.sc) {
+    if (a.rng_advance) a.sc->rng_step += 1;
+    if (a.tick) adam_tick_device(a.sc);
+  }
   const int row0 = blockIdx.x * HT_RB, type = blockIdx.y, B = a.B, A = a.A;
   const float invB = 1.f / (float)B;
   auto LY = [](int v) { return FAST ? 2 : v; };          // hidden layers of a head

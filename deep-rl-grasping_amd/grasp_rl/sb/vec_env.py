@@ -426,13 +426,26 @@ class _CompatUnpickler(pickle.Unpickler):
     _OTHER = {("collections", "OrderedDict"), ("collections", "deque"), ("copyreg", "_reconstructor"),
               ("copy_reg", "_reconstructor"), ("_codecs", "encode")}
 
+    # NumPy globals a pickled array / dtype / scalar / random state needs -- named one by one: a wildcard over the
+    # numpy package would also hand out callables such as numpy.testing._private.utils.runstring (an exec wrapper)
+    _NUMPY = {("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float64"), ("numpy", "float32"), ("numpy", "int64"),
+              ("numpy", "int32"), ("numpy", "bool_"), ("numpy", "uint8"),
+              ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+              ("numpy.core.numeric", "_frombuffer"),
+              ("numpy.random", "__RandomState_ctor"), ("numpy.random._pickle", "__randomstate_ctor"),
+              ("numpy.random._pickle", "__generator_ctor"), ("numpy.random._pickle", "__bit_generator_ctor"),
+              ("numpy.random.mtrand", "RandomState"), ("numpy.random._mt19937", "MT19937"),
+              ("numpy.random._pcg64", "PCG64"), ("numpy.random._generator", "Generator")}
+
     def find_class(self, module, name):
         if module.startswith("numpy"):
-            for m in (module, module.replace("numpy.core", "numpy._core"), module.replace("numpy._core", "numpy.core")):
-                try:
-                    return super().find_class(m, name)
-                except (ImportError, AttributeError):
-                    continue
+            canon = module.replace("numpy._core", "numpy.core")
+            if (canon, name) in self._NUMPY:
+                for m in (module, module.replace("numpy.core", "numpy._core"), canon):
+                    try:
+                        return super().find_class(m, name)
+                    except (ImportError, AttributeError):
+                        continue
         top = module.split(".")[0]
         if top in ("stable_baselines", "gym", "gymnasium", "grasp_rl"):
             if (name,) in self._MAP:

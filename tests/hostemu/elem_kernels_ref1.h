@@ -32,6 +32,6 @@ inline void sac_loss_body(const LossArgs& a, int fuse_adam = 0) {
     sc->beta2_power *= 0.999f;
   }
   if (fuse_adam) adam_elem(-mean_lp_h, a.ent_param[0], a.ent_m[0], a.ent_v[0], sc->adam_alpha, 1e-8f);
-  if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }
+  if (sc->rng_used && !a.keep_rng) { sc->rng_step += 1; sc->rng_used = 0u; }
 }
 inline void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }

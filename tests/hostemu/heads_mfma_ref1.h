@@ -66,6 +66,10 @@ template <int W, bool FAST>
 void heads_fused_kernel(const HeadsFusedArgs* ap) {
   if (threadIdx.x != 0) return;
   const HeadsFusedArgs& a = *ap;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && a.sc) {
+    if (a.rng_advance) a.sc->rng_step += 1;
+    if (a.tick) adam_tick_device(a.sc);
+  }
   const int type = blockIdx.y;
   const float alpha = expf(a.log_ent_coef[0]);
   const float invB = 1.f / (float)a.B;

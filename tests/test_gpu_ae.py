@@ -14,6 +14,12 @@ def test_ae_training_step_matches_oracle():
     au.ae_check(B=8, n_steps=3)
 
 
+def test_ae_training_step_matches_oracle_at_the_configured_batch():
+    """config/encoder.yaml / `bench.py --workload ae_train`: batch 128 (other reduction splits, riders and tile
+    lists than B = 8)."""
+    au.ae_check(B=128, n_steps=2)
+
+
 def test_simple_autoencoder_train_surface(tmp_path):
     from grasp_rl.autoencoder import SimpleAutoEncoder
     cfg = {"network": [{"filters": 32, "kernel_size": 7, "strides": 2}, {"filters": 32, "kernel_size": 5, "strides": 2},

@@ -31,7 +31,7 @@ def test_sac_cnn_learns_to_reach_through_model_learn():
 
 def test_sac_mlp_learns_on_encoder_features():
     """The as-shipped AE-MLP variant (configs[0] / SAC_full_rgbd-style vector observations, sacMlp)."""
-    r = synthetic.learn_reach("sac", "vector", total_timesteps=30_000, n_envs=16, batch_size=64)
+    r = synthetic.learn_reach("sac", "vector", total_timesteps=48_000, n_envs=16, batch_size=64)
     print(r)
     assert r["train_success"] >= 0.8 and r["eval_success"] >= 0.8, r
 
@@ -47,7 +47,7 @@ def test_dqn_with_prioritised_replay_learns():
 
 def test_bdq_with_prioritised_replay_learns():
     """BDQ block of config/gripper_grasp.yaml (5 branches x 33 bins, lr 1e-4, batch 64, eps 0.3 -> 0.1): random 0.07."""
-    r = synthetic.learn_reach("bdq", "vector", total_timesteps=50_000)
+    r = synthetic.learn_reach("bdq", "vector", total_timesteps=80_000)
     print(r)
     assert all(np.isfinite(v) for v in r["metrics"].values())
     assert r["eval_success"] >= 0.8, r

@@ -84,6 +84,20 @@ def test_rgbd_config_b256():
     eng.close()
 
 
+def test_rgbd_u8_replay_config_b256():
+    """The configuration `bench.py --workload sac_rgbd` runs (configs[3] with the byte-colour ring, grl_config.replay_rgb_u8)
+    at its batch size: the camera's integer colours survive the packed ring bit-exactly (compare_first_step asserts the
+    normalised minibatch) and the update matches the oracle."""
+    case = pu.make_case(extractor="augmented", kind="rgbd", B=256, n_replay=400, n_steps=2, rgb_u8=True)
+    ref, orc = pu.oracle_run(case)
+    eng = pu.engine_setup(case)
+    eng.train(1, case["idx"][:1], case["eps"][:1])
+    pu.compare_first_step(eng, case, ref[0])
+    eng.train(1, case["idx"][1:2], case["eps"][1:2])
+    pu.compare_params(eng, orc, case["spec"].lr, 2)
+    eng.close()
+
+
 def test_cpu_reference_config_nature_b64():
     """BASELINE configs[0]: simplified_object_picking.yaml with depth observations -> sacCnn with the default
     nature_cnn over both channels, default layers [64,64], A=3, batch 64, no VecNormalize
@@ -244,3 +258,27 @@ def test_error_paths():
     with pytest.raises(_capi.GrlError):
         eng.set_parameters({"nope": np.zeros(3)})
     eng.close()
+
+
+def test_multi_update_call_prefetch_is_bit_identical_b256(monkeypatch):
+    """Headline shape, device RNG: one call of 6 updates (the gather of update t+1 rides on the last launch of update t,
+    the head launch opens each update) == 6 calls of one update == the same with GRL_NO_GATHER_PREFETCH=1: parameters,
+    Adam moments and the last drawn indices bit for bit."""
+    def run(split, off=False):
+        if off:
+            monkeypatch.setenv("GRL_NO_GATHER_PREFETCH", "1")
+        case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=512, n_steps=1)
+        eng = pu.engine_setup(case)
+        for n in split:
+            eng.train(n)
+        out = (eng.get_parameters(), eng.fetch("adam_m").copy(), eng.fetch("adam_v").copy(), eng.fetch("idx_raw").copy(),
+               eng.metrics())
+        eng.close()
+        if off:
+            monkeypatch.delenv("GRL_NO_GATHER_PREFETCH")
+        return out
+    ref = run([1] * 6)
+    for got in (run([6]), run([2, 4]), run([6], off=True)):
+        assert all(np.array_equal(ref[0][n], got[0][n]) for n in ref[0])
+        assert all(np.array_equal(a, b) for a, b in zip(ref[1:4], got[1:4]))
+        assert ref[4] == got[4]

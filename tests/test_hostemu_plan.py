@@ -107,3 +107,43 @@ def test_60_update_trajectory_follows_the_oracle(hostemu_lib):
                                                               "value_loss": 0.05})
     assert max(worst.values()) < 0.02
     eng.close()
+
+
+def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_lib, monkeypatch):
+    """A call of n updates on the device RNG gathers minibatch t+1 inside the last launch of update t
+    (reduce_slabs_gather_kernel) and opens each update in the head launch: parameters, Adam state and the RNG counter
+    must equal n single-update calls bit for bit (and the switch GRL_NO_GATHER_PREFETCH=1 must change nothing)."""
+    def run(split, env=None):
+        if env:
+            monkeypatch.setenv(*env)
+        case = pu.make_case(extractor="mlp", B=16, n_replay=64, n_steps=1)
+        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+        for n in split:
+            eng.train(n)
+        P = eng.get_parameters()
+        extra = [eng.fetch("adam_m").copy(), eng.fetch("adam_v").copy(), eng.fetch("idx_raw").copy()]
+        m = eng.metrics()
+        eng.close()
+        if env:
+            monkeypatch.delenv(env[0])
+        return P, extra, m
+    Pa, xa, ma = run([1, 1, 1, 1, 1])
+    for split in ([5], [2, 3], [3, 1, 1]):
+        Pb, xb, mb = run(split)
+        for n in Pa:
+            assert np.array_equal(Pa[n], Pb[n]), (split, n)
+        for a, b in zip(xa, xb):
+            assert np.array_equal(a, b), split
+        assert ma == mb
+    Pc, xc, _ = run([5], env=("GRL_NO_GATHER_PREFETCH", "1"))
+    assert all(np.array_equal(Pa[n], Pc[n]) for n in Pa) and all(np.array_equal(a, b) for a, b in zip(xa, xc))
+    # the CNN plan too (one shape)
+    case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=1)
+    outs = []
+    for split in ([1, 1, 1], [3]):
+        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+        for n in split:
+            eng.train(n)
+        outs.append(eng.get_parameters())
+        eng.close()
+    assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])

@@ -305,6 +305,17 @@ def test_untrusted_pickles_cannot_name_arbitrary_callables(tmp_path, monkeypatch
     data = save_util.json_to_data(blob)                       # refused -> rebuilt from readable attributes -> None
     assert data["gamma"] == 0.9 and data["policy_kwargs"] is None and not (tmp_path / "pwned").exists()
 
+    # globals inside the numpy package are allowed one by one, not by prefix: numpy.testing's exec wrapper is refused
+    class EvilNumpy:
+        def __reduce__(self):
+            from numpy.testing._private.utils import runstring
+            return (runstring, ("open(%r, 'w').write('x')" % str(tmp_path / "pwned2"), {}))
+    with open(tmp_path / "vn2.pkl", "wb") as f:
+        pickle.dump(EvilNumpy(), f)
+    with pytest.raises(pickle.UnpicklingError):
+        VecNormalize.load(str(tmp_path / "vn2.pkl"), venv)
+    assert not (tmp_path / "pwned2").exists()
+
 
 def test_extractor_is_inferred_when_the_closure_is_not_unpickled(tmp_path, emulated_engine):
     """A zip saved with the reference's cloudpickled `cnn_extractor` closure loads without executing the pickle:
