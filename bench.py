@@ -404,12 +404,32 @@ def run_sac(args, wl_name, world, rank, device):
         try:
             out["learn_loop"] = {
                 "what": "SAC.learn with 16 SubprocVecEnv workers of a free synthetic env + VecNormalize (host loop cost: "
-                        "pipes, running statistics, staging, act); one update per iteration; not part of `value`",
+                        "pipes, running statistics, staging, act); default = one update per environment step, i.e. 16 "
+                        "updates per loop iteration (stable-baselines' ratio on its single env); not part of `value`",
                 "overlap_env_step": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True, device=str(device)),
-                "strict_order": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False, device=str(device))}
+                "strict_order": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False, device=str(device)),
+                "strict_order_device_norm": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False,
+                                                                      device=str(device), device_norm=True),
+                "one_update_per_iteration": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
+                                                                      device=str(device), gradient_steps=1),
+                "one_update_per_iteration_device_norm": synthetic.learn_loop_rate(
+                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=True)}
+            out["learn_loop_updates_per_s"] = out["learn_loop"]["strict_order"]["updates_per_s"]
             out["learn_loop_steps_per_s"] = out["learn_loop"]["overlap_env_step"]["env_steps_per_s"]
         except Exception as e:      # the headline number must not depend on process spawning
             out["learn_loop"] = {"error": repr(e)}
+    if wl_name == "sac_depth" and rank == 0 and world == 1 and not strong and not args.no_success:
+        # the metric's second half ("grasp success"): the reference's pipeline (VecNormalize -> model.learn -> deterministic
+        # evaluation, utils.py:10-44) on the learnable surrogate task, 16 envs, batch 256 -- see tests/test_gpu_learning.py
+        from grasp_rl import synthetic
+        try:
+            r = synthetic.learn_reach("sac", "depth", total_timesteps=args.success_steps, n_envs=16, device=str(device))
+            out["success_rate"] = {"task": "grasp_rl.synthetic.ReachGraspEnv (depth 64x64x2, 15-step episodes; random policy 0.07)",
+                                   "env_steps": r["env_steps"], "updates": r["updates"], "episodes": r["episodes"],
+                                   "train_success_last_200_episodes": r["train_success"], "eval_success_200_episodes": r["eval_success"],
+                                   "eval_mean_distance": round(r["eval_distance"], 4), "seconds": r["seconds"]}
+        except Exception as e:      # noqa: BLE001
+            out["success_rate"] = {"error": repr(e)}
     return out
 
 
@@ -517,6 +537,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-learn-loop", action="store_true")
+    ap.add_argument("--no-success", action="store_true", help="skip the learning run behind `success_rate`")
+    ap.add_argument("--success-steps", type=int, default=40_000)
     args = ap.parse_args()
 
     if os.environ.get("GRL_LIBRARY"):

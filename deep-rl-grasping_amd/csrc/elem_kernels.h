@@ -326,23 +326,87 @@ struct ActIngestArgs {
   float scale_div;
   float* x; int ldx;
   float* d; int ldd;
+  // normalize = 1: obs are RAW observations, VecNormalize.normalize_obs is applied here with the statistics kept on
+  // the device (grl_norm_update) -- the same float64 expression as at replay-sample time (norm_elem)
+  int normalize; double clip_obs;
+  const double* mean; const double* stdv; const double* dmean; const double* dstd;
 };
 
 __global__ __launch_bounds__(256) void act_ingest_kernel(ActIngestArgs a) {
   const int k = blockIdx.y;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (a.vec_dim > 0) {
-    if (e < a.vec_dim) a.x[(long)k * a.ldx + e] = a.obs[(long)k * a.vec_dim + e];
+    if (e < a.vec_dim) {
+      const float x = a.obs[(long)k * a.vec_dim + e];
+      a.x[(long)k * a.ldx + e] = a.normalize ? norm_elem(x, a.mean[e], a.stdv[e], 1, a.clip_obs, a.scale_div) : x;
+    }
     return;
   }
   const int img_elems = a.hw * a.c_img;
   if (e < img_elems) {
     const int px = e / a.c_img, c = e - px * a.c_img;
-    a.x[(long)k * a.ldx + e] = a.obs[((long)k * a.hw + px) * a.c_obs + c] / a.scale_div;
+    const float x = a.obs[((long)k * a.hw + px) * a.c_obs + c];
+    a.x[(long)k * a.ldx + e] = a.normalize ? norm_elem(x, a.mean[e], a.stdv[e], 1, a.clip_obs, a.scale_div) : x / a.scale_div;
   }
-  if (blockIdx.x == 0 && threadIdx.x < a.n_direct)
-    a.d[(long)k * a.ldd + threadIdx.x] =
-        a.obs[((long)k * a.hw + threadIdx.x) * a.c_obs + (a.c_obs - 1)] / a.scale_div;
+  if (blockIdx.x == 0 && threadIdx.x < a.n_direct) {
+    const int q = threadIdx.x;
+    const float x = a.obs[((long)k * a.hw + q) * a.c_obs + (a.c_obs - 1)];
+    a.d[(long)k * a.ldd + q] = a.normalize ? norm_elem(x, a.dmean[q], a.dstd[q], 1, a.clip_obs, a.scale_div) : x / a.scale_div;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// VecNormalize running statistics on the device (stable-baselines RunningMeanStd.update + update_from_moments, reached
+// from VecNormalize.step_wait at every env step; wrapper created at sb_helper.py:117-119).  One thread per element of
+// the env-layout observation:
+//   batch_mean = np.mean(obs, axis=0), batch_var = np.var(obs, axis=0)   -- FLOAT32 like the observations DummyVecEnv
+//       hands over (row-by-row accumulation, sum / n; mean of squared deviations from that mean)
+//   delta = batch_mean - mean;  tot = count + n;  new_mean = mean + delta * n / tot
+//   m2 = var * count + batch_var * n + delta**2 * count * n / (count + n);  new_var = m2 / (count + n)     -- float64,
+//       except `batch_var * n`, which NumPy evaluates in float32 (float32 array times Python int)
+// and the derived arrays the sampling / acting kernels read (mean, sqrt(var + eps) in their image / direct layout).
+// count is double buffered (count[parity] read by every thread, count[parity ^ 1] written by one).
+struct NormUpdateArgs {
+  const float* obs; int n, elems;
+  double* mean; double* var; double* count; int parity;
+  double eps;
+  int hw, c_obs, c_img, n_direct, vec;
+  double* s_mean; double* s_std; double* s_dmean; double* s_dstd;
+};
+__global__ __launch_bounds__(256) void norm_update_kernel(NormUpdateArgs a) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const double cnt = a.count[a.parity], bc = (double)a.n;
+  if (e < a.elems) {
+    float acc = a.obs[e];
+    for (int i = 1; i < a.n; ++i) acc += a.obs[(long)i * a.elems + e];
+    const float bm = acc / (float)a.n;
+    float d0 = a.obs[e] - bm;
+    float acc2 = d0 * d0;
+    for (int i = 1; i < a.n; ++i) {
+      const float d = a.obs[(long)i * a.elems + e] - bm;
+      acc2 += d * d;
+    }
+    const float bv = acc2 / (float)a.n;
+    const double mean = a.mean[e], var = a.var[e];
+    const double delta = (double)bm - mean;
+    const double tot = cnt + bc;
+    const double new_mean = mean + delta * bc / tot;
+    const double m_a = var * cnt;
+    const double m_b = (double)(bv * (float)a.n);
+    const double m2 = m_a + m_b + delta * delta * cnt * bc / (cnt + bc);
+    const double new_var = m2 / (cnt + bc);
+    a.mean[e] = new_mean;
+    a.var[e] = new_var;
+    const double sd = sqrt(new_var + a.eps);
+    if (a.vec) { a.s_mean[e] = new_mean; a.s_std[e] = sd; }
+    else {
+      const int px = e / a.c_obs, ch = e - px * a.c_obs;
+      if (ch < a.c_img) { a.s_mean[px * a.c_img + ch] = new_mean; a.s_std[px * a.c_img + ch] = sd; }
+      else if (ch == a.c_obs - 1 && px < a.n_direct) { a.s_dmean[px] = new_mean; a.s_dstd[px] = sd; }
+    }
+  }
+  if (e == 0) a.count[a.parity ^ 1] = cnt + bc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -987,9 +1051,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDe
                                                                  const int2* __restrict__ tiles, int n_tiles,
                                                                  LossArgs la, int has_loss, AdamArgs aa, int fuse_adam,
                                                                  GatherArgs ga, int gx) {
-  const int nb = n_tiles + has_loss;
-  if ((int)blockIdx.x < nb) { reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)blockIdx.x); return; }
-  const int r = (int)blockIdx.x - nb;
+  // the two kinds of workgroups are dealt out in proportion (block x is a reduction block iff the running count
+  // floor(x * nb / total) steps there): dispatched one kind after the other the launch ran as two phases
+  const long nb = n_tiles + has_loss, total = (long)gridDim.x, x = (long)blockIdx.x;
+  const long before = x * nb / total, upto = (x + 1) * nb / total;
+  if (upto > before) { reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)before); return; }
+  const int r = (int)(x - before);
   gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
 }
 

@@ -182,6 +182,13 @@ struct grl_ctx {
   float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grads = nullptr;
   DevScalars* sc = nullptr;
   double *s_mean = nullptr, *s_std = nullptr, *s_dmean = nullptr, *s_dstd = nullptr, *s_ret = nullptr;
+  // VecNormalize running statistics kept on the device (grl_norm_update): mean / var over the env-layout observation,
+  // count double buffered; n_stage receives the raw observations of one env step
+  double *n_mean = nullptr, *n_var = nullptr, *n_count = nullptr;
+  float* n_stage = nullptr;
+  int64_t n_elems = 0;
+  int n_parity = 0;
+  std::vector<Op> ops_act_norm;   // the act path with VecNormalize applied to raw observations by the ingest launch
   // replay
   float *rp_obs, *rp_next, *rp_dobs, *rp_dnext, *rp_act, *rp_rew, *rp_done;
   int64_t rp_pos = 0, rp_size = 0;
@@ -1361,11 +1368,15 @@ int grl_ctx::plan_sac() {
   adam_m = st.f32(n_train);
   adam_v = st.f32(n_train);
   sc = (DevScalars*)st.take(sizeof(DevScalars));
+  n_count = (double*)st.take(16);
   s_mean = (double*)st.take((size_t)img_elems * 8);
   s_std = (double*)st.take((size_t)img_elems * 8);
   s_dmean = (double*)st.take((size_t)std::max(nd, 1) * 8);
   s_dstd = (double*)st.take((size_t)std::max(nd, 1) * 8);
   s_ret = (double*)st.take(8);
+  n_elems = cnn ? (int64_t)hw * hw * c.obs_channels : c.obs_dim;
+  n_mean = (double*)st.take((size_t)n_elems * 8);     // (directly behind s_ret: grl_set_obs_stats uploads the span in one copy)
+  n_var = (double*)st.take((size_t)n_elems * 8);
   grads = gr.f32(n_train);
 
   // ---------------- replay arena
@@ -1388,6 +1399,7 @@ int grl_ctx::plan_sac() {
   stg_act = wk.f32((int64_t)stg_n * A);
   stg_rew = wk.f32(stg_n);
   stg_done = wk.f32(stg_n);
+  n_stage = wk.f32(stg_n * obs_elems);
 
   // ---------------- training workspace
   idx_buf = (int64_t*)wk.take((size_t)B * 8);
@@ -2174,13 +2186,19 @@ int grl_ctx::plan_sac() {
     ia.obs = stg_obs; ia.n = NA; ia.hw = hw * hw; ia.c_obs = c.obs_channels; ia.c_img = C_img; ia.n_direct = nd;
     ia.vec_dim = cnn ? 0 : c.obs_dim; ia.scale_div = cnn ? 255.f : 1.f;
     ia.x = cnn ? ax : afeat; ia.ldx = cnn ? img_elems : ldf; ia.d = afeat + 512; ia.ldd = ldf;
+    ActIngestArgs ian = ia;
+    ian.normalize = 1; ian.clip_obs = c.clip_obs;
+    ian.mean = s_mean; ian.stdv = s_std; ian.dmean = s_dmean; ian.dstd = s_dstd;
     {
-      Op op; op.tag = "act_ingest";
       const int elems = cnn ? img_elems : c.obs_dim;
-      op.run = [ia, elems](hipStream_t s) {
-        hipLaunchKernelGGL(act_ingest_kernel, dim3((elems + 255) / 256, ia.n), dim3(256), 0, s, ia);
-      };
-      ops_act.push_back(op);
+      for (int v = 0; v < 2; ++v) {
+        const ActIngestArgs iv = v ? ian : ia;
+        Op op; op.tag = "act_ingest";
+        op.run = [iv, elems](hipStream_t s) {
+          hipLaunchKernelGGL(act_ingest_kernel, dim3((elems + 255) / 256, iv.n), dim3(256), 0, s, iv);
+        };
+        (v ? ops_act_norm : ops_act).push_back(op);
+      }
     }
     if (cnn) {
       aa1 = wk.f32((int64_t)NA * 225 * 32); aa2 = wk.f32((int64_t)NA * 36 * 64); aa3 = wk.f32((int64_t)NA * 16 * 64);
@@ -2198,6 +2216,7 @@ int grl_ctx::plan_sac() {
     for (int l = 0; l < L; ++l)
       add_launch(ops_act, "act_head", 0, {head_layer(m_pi, P, ahPI, l, afeat, ldf, F, nullptr, 0, 0, NA)});
     add_launch(ops_act, "act_head", 0, {head_out(m_pi, P, ahPI, 0, NA), head_out(m_pi, P, ahPI, 1, NA)});
+    for (size_t k = 1; k < ops_act.size(); ++k) ops_act_norm.push_back(ops_act[k]);
     // final tanh (+ sampling): two variants so that each is a static graph
     for (int det = 0; det < 2; ++det) {
       const float* mu = ahPI.out[0]; const float* ls = ahPI.out[1]; const float* ep = a_eps; float* ao = a_out;
@@ -3344,6 +3363,13 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
   s0.lr = cfg->lr;
   hipError_t e = hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("scalar init: ") + hipGetErrorString(e)); }
+  if (h->n_mean) {   // RunningMeanStd(): mean 0, var 1, count 1e-4
+    std::vector<double> ones((size_t)h->n_elems, 1.0);
+    const double c2[2] = {1e-4, 1e-4};
+    hipMemset(h->n_mean, 0, (size_t)h->n_elems * 8);
+    hipMemcpy(h->n_var, ones.data(), ones.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(h->n_count, c2, 16, hipMemcpyHostToDevice);
+  }
   if (h->per_on) {
     hipMemset(h->per.p, 0, (size_t)cfg->replay_capacity * 8);
     PerState ps;
@@ -3414,7 +3440,7 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
   // Two mirrors alternate, each guarded by an event, so the host never waits for the GPU here (the learn loop calls
   // this before every update: a stream synchronisation plus five blocking copies serialised host and device).
   char* base = (char*)h->s_mean;
-  const size_t span = (size_t)((char*)h->s_ret + 8 - base);
+  const size_t span = h->n_mean ? (size_t)((char*)(h->n_var + h->n_elems) - base) : (size_t)((char*)h->s_ret + 8 - base);
   if (!h->pin_stats[0]) {
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipHostMalloc((void**)&h->pin_stats[k], span, 0));
@@ -3446,9 +3472,55 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
     for (int q = 0; q < h->img_elems; ++q) { m[q] = mean[q]; s[q] = std::sqrt(var[q] + eps); }
   }
   *rs = std::sqrt(ret_var + eps);
+  if (h->n_mean) {   // the running statistics grl_norm_update continues from (env layout)
+    memcpy(pm + ((char*)h->n_mean - base), mean, (size_t)h->n_elems * 8);
+    memcpy(pm + ((char*)h->n_var - base), var, (size_t)h->n_elems * 8);
+  }
   HIPCHK(hipMemcpyAsync(base, pm, span, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipEventRecord(h->pin_stats_ev[k], h->stream));
   h->pin_stats_used[k] = true;
+  return GRL_OK;
+}
+
+int grl_set_ret_var(grl_handle h, double ret_var) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  const double sd = std::sqrt(ret_var + (double)h->cfg.norm_eps);
+  HIPCHK(hipMemcpyAsync(h->s_ret, &sd, 8, hipMemcpyHostToDevice, h->stream));   // (pageable source: staged before returning)
+  return GRL_OK;
+}
+
+int grl_set_obs_count(grl_handle h, double count) {
+  if (!h || !h->n_count) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  const double c2[2] = {count, count};
+  HIPCHK(hipMemcpyAsync(h->n_count, c2, 16, hipMemcpyHostToDevice, h->stream));
+  return GRL_OK;
+}
+
+int grl_norm_update(grl_handle h, const float* obs, int n) {
+  if (!h || !obs || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  if (n > h->stg_n) return fail(GRL_ERR_INVALID, "more observations than one env step of act_batch environments");
+  const grl_config& c = h->cfg;
+  HIPCHK(hipMemcpyAsync(h->n_stage, obs, (size_t)n * h->n_elems * 4, hipMemcpyHostToDevice, h->stream));
+  NormUpdateArgs a;
+  memset(&a, 0, sizeof(a));
+  a.obs = h->n_stage; a.n = n; a.elems = (int)h->n_elems;
+  a.mean = h->n_mean; a.var = h->n_var; a.count = h->n_count; a.parity = h->n_parity; a.eps = c.norm_eps;
+  a.hw = h->hw * h->hw; a.c_obs = c.obs_channels; a.c_img = h->C_img; a.n_direct = h->cnn ? h->F - 512 : 0; a.vec = h->cnn ? 0 : 1;
+  a.s_mean = h->s_mean; a.s_std = h->s_std; a.s_dmean = h->s_dmean; a.s_dstd = h->s_dstd;
+  hipLaunchKernelGGL(norm_update_kernel, dim3((unsigned)((h->n_elems + 255) / 256)), dim3(256), 0, h->stream, a);
+  h->n_parity ^= 1;
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_get_obs_stats(grl_handle h, double* mean, double* var, double* count) {
+  if (!h || !mean || !var || !count) return fail(GRL_ERR_INVALID, "null argument");
+  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(mean, h->n_mean, (size_t)h->n_elems * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(var, h->n_var, (size_t)h->n_elems * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(count, h->n_count + h->n_parity, 8, hipMemcpyDeviceToHost));
   return GRL_OK;
 }
 
@@ -3693,8 +3765,11 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
   return GRL_OK;
 }
 
-int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps, float* out) {
+int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, float* out) {
   if (!h || !obs || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  const int deterministic = flags & 1;
+  const bool raw = (flags & 2) != 0;      // raw observations: VecNormalize applied on the device (grl_norm_update statistics)
+  if (raw && h->ops_act_norm.empty()) return fail(GRL_ERR_STATE, "this handle has no normalising act path");
   if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
   const bool q = h->cfg.algo != GRL_ALGO_SAC;   // DQN / BDQ: Q-values [n, D*bins]
   if (!q && !deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
@@ -3710,7 +3785,8 @@ int grl_act(grl_handle h, const float* obs, int n, int deterministic, const floa
     if (int e = h->run_seq("act", {&h->ops_act})) return e;
   } else {
     // the launches cover act_batch rows whatever n is (rows beyond n hold stale observations: computed, not returned)
-    if (int e = h->run_seq(deterministic ? "act_det" : "act_sto", {&h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
+    if (int e = h->run_seq(std::string(deterministic ? "act_det" : "act_sto") + (raw ? "_n" : ""),
+                           {raw ? &h->ops_act_norm : &h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
       return e;
   }
   HIPCHK(hipMemcpyAsync(h->pin_out, q ? h->q_aout : h->a_out, n_out * 4, hipMemcpyDeviceToHost, h->stream));

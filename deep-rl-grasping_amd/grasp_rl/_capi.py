@@ -50,6 +50,7 @@ EXPORTS = [
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
     "grl_ae_train_step",
     "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate", "grl_compute_grads_staged", "grl_grad_ranges",
+    "grl_norm_update", "grl_set_obs_count", "grl_set_ret_var", "grl_get_obs_stats",
 ]
 
 
@@ -92,6 +93,10 @@ def load_library(path=None):
     lib.grl_grad_ranges.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.grl_q_update_target.argtypes = [vp]
     lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_double, vp]
+    lib.grl_norm_update.argtypes = [vp, f32p, i32]
+    lib.grl_set_obs_count.argtypes = [vp, C.c_double]
+    lib.grl_set_ret_var.argtypes = [vp, C.c_double]
+    lib.grl_get_obs_stats.argtypes = [vp, dp, dp, C.POINTER(C.c_double)]
     lib.grl_ae_train_step.argtypes = [vp, vp, C.c_int]
     lib.grl_ae_reconstruct.argtypes = [vp, vp, vp]
     lib.grl_get_metrics.argtypes = [vp, C.POINTER(GrlMetrics)]

@@ -176,6 +176,25 @@ class SacEngine:
         var = np.ascontiguousarray(var, dtype=np.float64)
         check(self.lib, self.lib.grl_set_obs_stats(self.h, mean.ctypes.data, var.ctypes.data, float(ret_var)))
 
+    # ---- VecNormalize running statistics kept on the device (grl_norm_update; SAC handles)
+    def norm_update(self, obs):
+        """RunningMeanStd.update(obs) of one env step's raw observations [n, ...] on the device (stream-ordered)."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        check(self.lib, self.lib.grl_norm_update(self.h, obs.ctypes.data, obs.shape[0]))
+
+    def set_obs_count(self, count):
+        check(self.lib, self.lib.grl_set_obs_count(self.h, float(count)))
+
+    def set_ret_var(self, ret_var):
+        check(self.lib, self.lib.grl_set_ret_var(self.h, float(ret_var)))
+
+    def get_obs_stats(self, shape):
+        """(mean, var, count) of the device statistics, float64, in the observation's shape (synchronises)."""
+        mean, var = np.empty(shape, np.float64), np.empty(shape, np.float64)
+        cnt = C.c_double()
+        check(self.lib, self.lib.grl_get_obs_stats(self.h, mean.ctypes.data, var.ctypes.data, C.byref(cnt)))
+        return mean, var, cnt.value
+
     def set_learning_rate(self, lr):
         check(self.lib, self.lib.grl_set_learning_rate(self.h, float(lr)))
 
@@ -249,7 +268,8 @@ class SacEngine:
         self.be.synchronize()
 
     # ------------------------------------------------------------------ inference
-    def act(self, obs, deterministic=True, eps=None):
+    def act(self, obs, deterministic=True, eps=None, raw=False):
+        """raw=True: `obs` are un-normalised observations, VecNormalize is applied on the device (norm_update statistics)."""
         obs = np.ascontiguousarray(obs, dtype=np.float32)
         n = obs.shape[0]
         out = np.empty((n, self.A), np.float32)
@@ -257,7 +277,8 @@ class SacEngine:
         if not deterministic:
             eps = np.ascontiguousarray(eps, dtype=np.float32).reshape(n, self.A)
             pe = eps.ctypes.data
-        check(self.lib, self.lib.grl_act(self.h, obs.ctypes.data, n, 1 if deterministic else 0, pe, out.ctypes.data))
+        flags = (1 if deterministic else 0) | (2 if raw else 0)
+        check(self.lib, self.lib.grl_act(self.h, obs.ctypes.data, n, flags, pe, out.ctypes.data))
         return out
 
     def load_encoder(self, weights):

@@ -45,7 +45,8 @@ class SAC:
                  train_freq=1, batch_size=64, tau=0.005, ent_coef="auto", target_update_interval=1,
                  gradient_steps=None, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
                  tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False,
-                 seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None, replay_rgb_u8=False):
+                 seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None, replay_rgb_u8=False,
+                 device_norm=None):
         if isinstance(policy, str):
             if policy not in _POLICY_NAMES:
                 raise ValueError("unknown policy %r" % policy)
@@ -70,6 +71,13 @@ class SAC:
         # Opt-in: RGB-D observations whose colour channels are integers in [0, 255] (the reference's camera: uint8,
         # sensor.py:126-145) are stored with byte colours -- half the HBM per transition (grl_config.replay_rgb_u8).
         self.replay_rgb_u8 = bool(replay_rgb_u8)
+        # Opt-in: keep the VecNormalize observation statistics on the device (grl_norm_update) while learning.  The
+        # wrapper then hands RAW observations to this loop (callbacks see them as `new_obs`); actions and minibatches
+        # are normalised where the engine consumes them, with the same arithmetic.  The wrapper's host copy is
+        # refreshed whenever it is pickled / saved / synchronised into an evaluation env, and when learn() returns.
+        if device_norm is None:
+            device_norm = os.environ.get("GRL_DEVICE_NORM", "0") == "1"
+        self.device_norm = bool(device_norm)
         self.num_timesteps = 0
         self.n_updates = 0
         self.env = None
@@ -151,6 +159,8 @@ class SAC:
             cfg = _capi.make_config(extractor, obs_channels=obs_shape[2], n_direct=n_direct,
                                     replay_rgb_u8=self.replay_rgb_u8, **kw)
         self._extractor = extractor
+        if self.seed is not None and hasattr(self.action_space, "seed"):     # BaseRLModel.set_random_seed: action_space.seed(seed)
+            self.action_space.seed(int(self.seed))
         self._norm_stamp = None         # a new engine starts with zero statistics
         self.engine = self._engine_factory(cfg, self.device)
         params = init_parameters(self.engine.table, seed=0 if self.seed is None else int(self.seed))
@@ -163,6 +173,12 @@ class SAC:
         vn = self._vec_normalize_env
         if vn is None or not self.engine.cfg.normalize:
             return
+        if vn.hands_out_raw_observations:        # observation statistics live on the device: only the return variance moves
+            stamp = ("dev", float(vn.ret_rms.count))
+            if stamp != getattr(self, "_norm_stamp", None):
+                self._norm_stamp = stamp
+                self.engine.set_ret_var(float(vn.ret_rms.var))
+            return
         # (identity + counts + a content checksum: in-place edits of the arrays and re-loaded pickles are seen too)
         stamp = (id(vn.obs_rms), float(vn.obs_rms.count), id(vn.ret_rms), float(vn.ret_rms.count),
                  float(np.sum(vn.obs_rms.mean)), float(np.sum(vn.obs_rms.var)), float(np.sum(vn.ret_rms.var)))
@@ -172,7 +188,7 @@ class SAC:
         self.engine.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))   # asynchronous, stream-ordered
 
     # ------------------------------------------------------------------ acting
-    def _act(self, obs, deterministic):
+    def _act(self, obs, deterministic, raw=False):
         obs = np.asarray(obs, np.float32)
         n = obs.shape[0]
         out = np.empty((n, int(np.prod(self.action_space.shape))), np.float32)
@@ -180,7 +196,7 @@ class SAC:
         for k0 in range(0, n, cap):
             chunk = obs[k0:k0 + cap]
             eps = None if deterministic else self._rng.standard_normal((chunk.shape[0], out.shape[1])).astype(np.float32)
-            out[k0:k0 + cap] = self.engine.act(chunk, deterministic, eps)
+            out[k0:k0 + cap] = self.engine.act(chunk, deterministic, eps, raw=raw) if raw else self.engine.act(chunk, deterministic, eps)
         return out
 
     def _unscale(self, a):
@@ -219,6 +235,10 @@ class SAC:
         start = time.time()
         # stable-baselines hands callbacks a FileWriter when tensorboard_log is set, None otherwise
         writer = logger.SummaryWriter(self.tensorboard_log, tb_log_name) if self.tensorboard_log else None
+        if self.device_norm and vn is not None and vn.norm_obs and eng.cfg.normalize in (1, 2):
+            vn.attach_device(eng)
+            self._norm_stamp = None
+        raw_obs = vn is not None and vn.hands_out_raw_observations
         obs = self.env.reset()
         obs_ = vn.get_original_obs() if vn is not None else obs
         callback.on_training_start(locals(), globals())
@@ -229,7 +249,7 @@ class SAC:
                 unscaled_action = np.stack([np.asarray(self.action_space.sample(), np.float32) for _ in range(N)])
                 action = self._scale(unscaled_action)
             else:
-                action = self._act(obs, deterministic=False)
+                action = self._act(obs, deterministic=False, raw=raw_obs)
                 if self.action_noise is not None:
                     action = np.clip(action + self.action_noise(), -1, 1)
                 unscaled_action = self._unscale(action)
@@ -303,6 +323,9 @@ class SAC:
                     logger.logkv("total timesteps", self.num_timesteps)
                     logger.dumpkvs()
         callback.on_training_end()
+        if raw_obs:
+            vn.detach_device()         # the wrapper carries the statistics again (and normalises on the host from here on)
+            self._norm_stamp = None
         if writer is not None:
             writer.close()
         return self

@@ -323,17 +323,43 @@ class VecNormalize(VecEnvWrapper):
         self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
         self.old_obs = np.array([])
         self.old_rews = np.array([])
+        self._dev = None
+
+    # -- observation statistics on the device (opt-in, grasp_rl.sb.SAC(device_norm=True)) -------------------------
+    def attach_device(self, engine):
+        """From now on `obs_rms` is maintained by the engine (grl_norm_update: the same float32 batch moments and
+        float64 Chan merge, on the GPU) and, while training, `step_wait` / `reset` hand out RAW observations for the
+        engine to normalise where it consumes them (grl_act flag 2, sample-time gather).  The host copy is refreshed by
+        `pull_device_stats` -- automatically before pickling / `save` and in `sync_envs_normalization`."""
+        self._dev = engine
+        engine.set_obs_stats(self.obs_rms.mean, self.obs_rms.var, float(self.ret_rms.var))
+        engine.set_obs_count(self.obs_rms.count)
+
+    def detach_device(self):
+        if self._dev is not None:
+            self.pull_device_stats()
+        self._dev = None
+
+    def pull_device_stats(self):
+        if self._dev is not None:
+            self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count = self._dev.get_obs_stats(tuple(self.observation_space.shape))
+
+    @property
+    def hands_out_raw_observations(self):
+        return self._dev is not None and self.training and self.norm_obs
 
     # -- pickling: everything but the wrapped env (stable-baselines convention) ------------------
     def __getstate__(self):
+        self.pull_device_stats()
         state = self.__dict__.copy()
-        for k in ("venv", "class_attributes", "ret"):
+        for k in ("venv", "class_attributes", "ret", "_dev"):
             state.pop(k, None)
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self.venv = None
+        self._dev = None
 
     def set_venv(self, venv):
         if self.venv is not None:
@@ -347,11 +373,12 @@ class VecNormalize(VecEnvWrapper):
     def step_wait(self):
         obs, rews, dones, infos = self.venv.step_wait()
         self.old_obs, self.old_rews = obs, rews
-        if self.training or self.norm_obs:
-            obs64 = np.asarray(obs, np.float64)        # one float64 copy shared by the statistics update and the normalisation
+        if self.hands_out_raw_observations:
+            self._dev.norm_update(obs)                 # statistics on the device; the consumer normalises there too
+        else:
             if self.training:
-                self.obs_rms.update(obs64)
-            obs = self.normalize_obs(obs64)
+                self.obs_rms.update(obs)               # batch moments in the observations' own dtype (float32), as NumPy forms them
+            obs = self.normalize_obs(obs)
         if self.training:
             self.ret = self.ret * self.gamma + rews
             self.ret_rms.update(self.ret)
@@ -363,6 +390,9 @@ class VecNormalize(VecEnvWrapper):
         obs = self.venv.reset()
         self.old_obs = obs
         self.ret = np.zeros(self.num_envs)
+        if self.hands_out_raw_observations:
+            self._dev.norm_update(obs)
+            return obs
         if self.training:
             self.obs_rms.update(obs)
         return self.normalize_obs(obs)
@@ -479,6 +509,7 @@ def sync_envs_normalization(env, eval_env):
     a, b = env, eval_env
     while isinstance(a, VecEnvWrapper) and isinstance(b, VecEnvWrapper):
         if isinstance(a, VecNormalize) and isinstance(b, VecNormalize):
+            a.pull_device_stats()
             b.obs_rms = copy.deepcopy(a.obs_rms)
             b.ret_rms = copy.deepcopy(a.ret_rms)
         a, b = a.venv, b.venv

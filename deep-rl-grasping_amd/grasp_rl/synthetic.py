@@ -211,11 +211,13 @@ class ReachGraspEnv:
         pass
 
 
-def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0"):
-    """Env-steps / second and updates / second of ``SAC.learn`` (train_freq 1, gradient_steps 1: one update per
-    loop iteration, as sb_helper.py:120-128 configures it) with `n_envs` SyntheticGraspEnv worker processes behind
+def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0",
+                    gradient_steps=None, device_norm=False):
+    """Env-steps / second and updates / second of ``SAC.learn`` with `n_envs` SyntheticGraspEnv worker processes behind
     SubprocVecEnv + VecNormalize -- BASELINE configs[1]: "16 vectorised PyBullet envs feed a single GPU", with the
-    simulator replaced by a free one.  Returns a dict."""
+    simulator replaced by a free one.  gradient_steps None = one update per ENVIRONMENT step (stable-baselines' ratio
+    with train_freq 1 / gradient_steps 1 on its single env, sb_helper.py:120-128: n_envs updates per loop iteration);
+    1 = one update per loop iteration.  Returns a dict."""
     import functools
     import time
     from .sb.callbacks import BaseCallback
@@ -239,12 +241,13 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
         env = VecNormalize(venv, norm_obs=True, norm_reward=True, clip_obs=10.0)
         model = SAC(SacCnnPolicy, env, policy_kwargs={"layers": [64, 64], "cnn_extractor": AugmentedNatureCnn(1)},
                     buffer_size=buffer_size, batch_size=batch_size, learning_starts=max(batch_size, n_envs),
-                    overlap_env_step=overlap, device=device)
+                    overlap_env_step=overlap, device=device, gradient_steps=gradient_steps, device_norm=device_norm)
         clock = Clock(warm)
         model.learn(total_timesteps=n_envs * (warm + iterations), callback=clock)
         model.engine.synchronize()
         dt = time.perf_counter() - clock.t0
         return {"n_envs": n_envs, "iterations": iterations, "overlap_env_step": bool(overlap),
+                "gradient_steps": n_envs if gradient_steps is None else gradient_steps, "device_norm": bool(device_norm),
                 "env_steps_per_s": round(n_envs * iterations / dt, 1),
                 "updates_per_s": round((model.n_updates - clock.u0) / dt, 1),
                 "ms_per_iteration": round(1e3 * dt / iterations, 3)}

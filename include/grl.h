@@ -159,6 +159,18 @@ int grl_set_learning_rate(grl_handle h, float lr);
 /* VecNormalize statistics (host float64, HWC layout of the observation space or [obs_dim]);
    obs_var/ret_var are variances, epsilon is added inside.  Copied before returning. */
 int grl_set_obs_stats(grl_handle h, const double* obs_mean, const double* obs_var, double ret_var);
+/* The same statistics maintained ON THE DEVICE (SAC handles).  VecNormalize.step_wait -> obs_rms.update(obs)
+   (stable-baselines RunningMeanStd.update / update_from_moments, wrapper created at sb_helper.py:117-119): merges the
+   batch moments of the n raw observations of one env step (HOST pointer, env layout [n, 64, 64, C+1] or [n, obs_dim],
+   n <= max(act_batch, 64)) into the running mean / variance / count in device memory -- float32 batch moments like
+   NumPy forms them from the float32 observations, float64 Chan merge -- and refreshes the sample-time statistics;
+   stream-ordered, no synchronisation.  grl_set_obs_stats loads a starting point (vecnormalize.pkl), grl_set_obs_count
+   its count (RunningMeanStd starts at 1e-4), grl_set_ret_var pushes the host-side return variance alone, and
+   grl_get_obs_stats (host, synchronises) copies mean / var [env layout] and count out for pickling. */
+int grl_norm_update(grl_handle h, const float* obs, int n);
+int grl_set_obs_count(grl_handle h, double count);
+int grl_set_ret_var(grl_handle h, double ret_var);
+int grl_get_obs_stats(grl_handle h, double* obs_mean, double* obs_var, double* count);
 
 /* append n raw (un-normalised) transitions; host pointers, obs in env layout [n,H,W,C] or [n,D] */
 int grl_replay_add(grl_handle h, const float* obs, const float* act, const float* rew,
@@ -197,10 +209,12 @@ int grl_grad_ranges(grl_handle h, int bucket, int cap, int64_t* offsets, int64_t
 /* host: metrics of the most recent update (synchronises the stream) */
 int grl_get_metrics(grl_handle h, grl_metrics* out);
 
-/* host: actor forward for n <= act_batch already-normalised observations (env layout, host ptr);
+/* host: actor forward for n <= act_batch observations (env layout, host ptr); flags bit 0: deterministic action,
+   bit 1 (SAC handles): the observations are RAW and VecNormalize.normalize_obs is applied on the device with the
+   statistics grl_norm_update maintains (otherwise they are already normalised, as VecNormalize hands them out);
    eps_or_null: [n,act_dim] noise for stochastic actions (host).  Synchronises the stream.
    DQN / BDQ handles: out receives the dueling Q-values [n, q_branches*q_bins]. */
-int grl_act(grl_handle h, const float* obs, int n, int deterministic, const float* eps_or_null,
+int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps_or_null,
             float* out_actions);
 
 /* GRL_ALGO_AE handles: n_steps minibatch updates of the depth auto-encoder (forward, mean-squared

@@ -162,14 +162,19 @@ def normalize_reward(r, ret_var, clip=10.0, eps=1e-8):
 
 
 def rms_update(mean, var, count, x):
-    """RunningMeanStd.update_from_moments (float64, Chan et al.; A.1 step 2)."""
-    x = np.asarray(x, np.float64)
-    bm, bv, bn = x.mean(axis=0), x.var(axis=0), x.shape[0]
-    delta = bm - mean
-    tot = count + bn
-    new_mean = mean + delta * bn / tot
-    m2 = var * count + bv * bn + np.square(delta) * count * bn / tot
-    return new_mean, m2 / tot, tot
+    """stable-baselines 2.10.1 RunningMeanStd.update + update_from_moments (A.1 step 2): batch moments with
+    np.mean / np.var IN THE DTYPE OF x (float32 for the observations DummyVecEnv hands to VecNormalize, float64 for
+    the returns), float64 parallel (Chan et al.) merge -- expression by expression as published."""
+    x = np.asarray(x)
+    batch_mean, batch_var, batch_count = np.mean(x, axis=0), np.var(x, axis=0), x.shape[0]
+    delta = batch_mean - mean
+    tot_count = count + batch_count
+    new_mean = mean + delta * batch_count / tot_count
+    m_a = var * count
+    m_b = batch_var * batch_count
+    m_2 = m_a + m_b + np.square(delta) * count * batch_count / (count + batch_count)
+    new_var = m_2 / (count + batch_count)
+    return new_mean, new_var, tot_count
 
 
 def prepare_batch(spec, raw, stats, norm_obs=True, norm_reward=True):

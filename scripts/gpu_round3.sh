@@ -11,7 +11,7 @@ for st in $STAGES; do
   case $st in
     tests)
       echo "== pytest ${PYTEST_ARGS-}" >> $LOG
-      timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q ${PYTEST_ARGS-} --timeout 900 -rA 2>&1 | grep -v "^PASSED\|^$" | tail -${PYTEST_TAIL:-60} >> $LOG
+      timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q ${PYTEST_ARGS-} ${PYTEST_K:+-k "$PYTEST_K"} --timeout 900 -rA 2>&1 | grep -v "^PASSED\|^$" | tail -${PYTEST_TAIL:-60} >> $LOG
       ;;
     ab)
       echo "== A/B (updates/s | per-launch us, eager pass)" >> $LOG

@@ -5,7 +5,7 @@
 #   NAME=sac_depth BENCH_ARGS="" bash scripts/profile_round.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 NAME=${NAME:-sac_depth}
-ARGS="${BENCH_ARGS:-} --no-cpu-baseline --no-profile --no-learn-loop --repeats 1"
+ARGS="${BENCH_ARGS:-} --no-cpu-baseline --no-profile --no-learn-loop --no-success --repeats 1"
 OUT=$R/gpurun_out/prof_$NAME
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

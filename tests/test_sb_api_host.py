@@ -352,3 +352,76 @@ def test_monitor_logs_are_readable_by_results_plotter(tmp_path):
         assert {"r", "l", "t", "s"} <= set(ref.columns) and len(ref) > 1000
         xs, ys = ts2xy(ref, "timesteps", y_column="s")
         assert np.all(np.diff(xs) > 0) and ys.min() >= 0.0 and ys.max() <= 1.0        # running success rate
+
+
+def test_running_statistics_on_the_device_equal_the_host_wrapper(hostemu_lib, emulated_engine):
+    """grl_norm_update (RunningMeanStd.update on the device) against the host wrapper's NumPy restatement, bit for bit:
+    float32 batch moments, float64 Chan merge, count; then the raw-observation act path (grl_act flag 2) against acting
+    on host-normalised observations."""
+    from grasp_rl import _capi
+    rng = np.random.default_rng(3)
+    for obs_shape, extractor in (((64, 64, 2), "augmented"), ((37,), "mlp")):
+        if extractor == "mlp":
+            cfg = _capi.make_config("mlp", obs_dim=37, act_dim=5, layers=(64, 64), batch_size=4, replay_capacity=8,
+                                    normalize=True, act_batch=6)
+        else:
+            cfg = _capi.make_config("augmented", obs_channels=2, n_direct=1, act_dim=5, layers=(64, 64), batch_size=4,
+                                    replay_capacity=8, normalize=True, act_batch=6)
+        eng = SacEngine(cfg, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+        from grasp_rl.init import init_parameters
+        eng.set_parameters(init_parameters(eng.table, seed=1))
+        from grasp_rl.sb.running_mean_std import RunningMeanStd
+        rms = RunningMeanStd(shape=obs_shape)
+        for n in (6, 1, 5, 6):
+            x = (rng.normal(0.4, 0.3, (n,) + obs_shape) * rng.uniform(0.5, 2.0, obs_shape)).astype(np.float32)
+            if extractor != "mlp":
+                x[..., 1] = 0.0
+                x[:, 0, 0, 1] = rng.uniform(0, 1, n)
+            rms.update(x)
+            eng.norm_update(x)
+            mean, var, count = eng.get_obs_stats(obs_shape)
+            assert count == rms.count
+            assert np.array_equal(mean, rms.mean) and np.array_equal(var, rms.var)
+        # acting on raw observations == acting on clip((obs - mean) / sqrt(var + eps), +-10) formed by the host
+        x = (rng.normal(0.4, 0.3, (4,) + obs_shape)).astype(np.float32)
+        xn = np.clip((x - rms.mean) / np.sqrt(rms.var + 1e-8), -10.0, 10.0)
+        a_host = eng.act(xn.astype(np.float32), deterministic=True)
+        a_dev = eng.act(x, deterministic=True, raw=True)
+        assert np.array_equal(a_host, a_dev)
+        # a loaded pickle's statistics continue on the device
+        eng.set_obs_stats(rms.mean * 0.5, rms.var * 2.0, 3.0)
+        eng.set_obs_count(123.0)
+        rms.mean, rms.var, rms.count = rms.mean * 0.5, rms.var * 2.0, 123.0
+        x = rng.normal(0.2, 0.5, (3,) + obs_shape).astype(np.float32)
+        rms.update(x)
+        eng.norm_update(x)
+        mean, var, count = eng.get_obs_stats(obs_shape)
+        assert count == rms.count and np.array_equal(mean, rms.mean) and np.array_equal(var, rms.var)
+        eng.close()
+
+
+def test_learning_with_device_statistics_equals_the_host_path(tmp_path, emulated_engine):
+    """SAC(device_norm=True): the wrapper hands out raw observations while learning, statistics / normalisation run in
+    the engine -- parameters after learn() and the pickled statistics equal the default (host) path bit for bit."""
+    outs = []
+    for dev in (False, True):
+        env = DummyVecEnv([(lambda s=s: FakeGraspEnv("depth", seed=s)) for s in range(3)])
+        env = VecNormalize(env, norm_obs=True, norm_reward=True, clip_obs=10.)
+        m = sb.SAC(sacCnn, env, policy_kwargs={"layers": [64, 64], "cnn_extractor": create_augmented_nature_cnn(1)},
+                   buffer_size=64, batch_size=4, learning_starts=6, seed=5, device_norm=dev)
+        seen = []
+
+        class Peek(BaseCallback):
+            def _on_step(self):
+                seen.append(float(np.abs(self.locals["new_obs"]).max()))
+                return True
+        m.learn(total_timesteps=30, callback=Peek())
+        env.save(str(tmp_path / ("vn%d.pkl" % dev)))
+        outs.append((m.get_parameters(), env.obs_rms.mean.copy(), env.obs_rms.var.copy(), env.obs_rms.count, seen))
+        assert env._dev is None                                  # detached again: the wrapper normalises on the host
+        assert np.abs(env.reset()).max() <= 10.0
+    (Pa, ma, va, ca, _), (Pb, mb, vb, cb, _) = outs
+    assert ca == cb and np.array_equal(ma, mb) and np.array_equal(va, vb)
+    assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
+    vn = VecNormalize.load(str(tmp_path / "vn1.pkl"), DummyVecEnv([lambda: FakeGraspEnv("depth", seed=9)]))
+    assert np.array_equal(vn.obs_rms.mean, ma) and vn.obs_rms.count == ca
