@@ -538,7 +538,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-learn-loop", action="store_true")
     ap.add_argument("--no-success", action="store_true", help="skip the learning run behind `success_rate`")
-    ap.add_argument("--success-steps", type=int, default=40_000)
+    ap.add_argument("--success-steps", type=int, default=48_000)
     args = ap.parse_args()
 
     if os.environ.get("GRL_LIBRARY"):

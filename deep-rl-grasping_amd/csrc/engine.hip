@@ -34,6 +34,7 @@
 #include "q_kernels.h"
 #include "q_apply_kernels.h"
 #include "igemm_sk.h"
+#include "dp_kernels.h"
 
 namespace grl {
 
@@ -249,6 +250,13 @@ struct grl_ctx {
   bool loss_in_reduce = false;
   float grad_scale = 1.f;   // read by the apply op
 
+  // data parallel without a host round trip per update (grl_allreduce_*, csrc/dp_kernels.h)
+  DpArgs dp;
+  bool dp_on = false;
+  void* dp_buf = nullptr;                // this rank's exchange buffer (the one device allocation the library makes)
+  void* dp_peer[DP_MAX_WORLD] = {nullptr};
+  std::vector<Op> ops_dp;                // publish | reduce + push | Adam + Polyak on the exchanged bucket
+
   // graphs
   std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences, keyed by what they contain
   hipStream_t side = nullptr;                     // second capture lane (independent weight-gradient launches)
@@ -270,6 +278,9 @@ struct grl_ctx {
       if (pin_stats[k]) hipHostFree(pin_stats[k]);
       if (pin_stats_ev[k]) hipEventDestroy(pin_stats_ev[k]);
     }
+    for (int p = 0; p < DP_MAX_WORLD; ++p)
+      if (dp_peer[p]) (void)hipIpcCloseMemHandle(dp_peer[p]);
+    if (dp_buf) (void)hipFree(dp_buf);
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
     for (auto e : lane_ev) hipEventDestroy(e);
@@ -3793,6 +3804,120 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   memcpy(out, h->pin_out, n_out * 4);
+  return GRL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- data parallel, in-graph
+static size_t dp_layout(int64_t n, size_t* src_off, size_t* res_off) {
+  const size_t ctl = (size_t)rup((int64_t)sizeof(DpCtl), 256);
+  const size_t arr = (size_t)rup(n * 4, 256);
+  *src_off = ctl;
+  *res_off = ctl + arr;
+  return ctl + 2 * arr;
+}
+
+int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
+  if (!h || !handle_out) return fail(GRL_ERR_INVALID, "null argument");
+  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "the exchange step is defined for SAC handles");
+  if (world < 1 || world > DP_MAX_WORLD || rank < 0 || rank >= world) return fail(GRL_ERR_INVALID, "bad rank / world size");
+  if (h->dp_buf) return fail(GRL_ERR_STATE, "grl_allreduce_init was already called on this handle");
+  size_t so, ro;
+  const size_t bytes = dp_layout(h->n_train, &so, &ro);
+  // fine-grained: flag and data stores of a peer become visible to a kernel that is already running
+  hipError_t e = hipExtMallocWithFlags(&h->dp_buf, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) { h->dp_buf = nullptr; return fail(GRL_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e)); }
+  HIPCHK(hipMemset(h->dp_buf, 0, bytes));
+  hipIpcMemHandle_t mh;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "grl.h documents 64-byte handles");
+  e = hipIpcGetMemHandle(&mh, h->dp_buf);
+  if (e != hipSuccess) {
+    (void)hipFree(h->dp_buf); h->dp_buf = nullptr;
+    return fail(GRL_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+  }
+  memcpy(handle_out, &mh, 64);
+  memset(&h->dp, 0, sizeof(h->dp));
+  h->dp.rank = rank; h->dp.world = world; h->dp.n = h->n_train;
+  h->dp.chunk = rup((h->n_train + world - 1) / world, 4);
+  h->dp.grads = h->grads;
+  return GRL_OK;
+}
+
+int grl_allreduce_connect(grl_handle h, const void* handles) {
+  if (!h || !handles) return fail(GRL_ERR_INVALID, "null argument");
+  if (!h->dp_buf) return fail(GRL_ERR_STATE, "call grl_allreduce_init first");
+  if (h->dp_on) return fail(GRL_ERR_STATE, "already connected");
+  size_t so, ro;
+  dp_layout(h->n_train, &so, &ro);
+  DpArgs& d = h->dp;
+  for (int p = 0; p < d.world; ++p) {
+    char* base = (char*)h->dp_buf;
+    if (p != d.rank) {
+      hipIpcMemHandle_t mh;
+      memcpy(&mh, (const char*)handles + 64 * (size_t)p, 64);
+      void* ptr = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&ptr, mh, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return fail(GRL_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(p) + "): " + hipGetErrorString(e));
+      h->dp_peer[p] = ptr;
+      base = (char*)ptr;
+    }
+    d.ctl[p] = (DpCtl*)base;
+    d.src[p] = (float*)(base + so);
+    d.res[p] = (float*)(base + ro);
+  }
+  const DpArgs da = d;
+  grl_ctx* self = h;
+  {
+    Op op; op.tag = "dp_publish"; op.bytes = 8.0 * (double)d.n;
+    const int blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, (d.n / 4 + 255) / 256));
+    op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_publish_kernel, dim3(blocks), dim3(256), 0, s, da); };
+    h->ops_dp.push_back(op);
+  }
+  {
+    Op op; op.tag = "dp_reduce_push"; op.bytes = 8.0 * (double)d.chunk * d.world;
+    const int blocks = (int)std::min<int64_t>(256, std::max<int64_t>(1, (d.chunk / 4 + 255) / 256));
+    op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_reduce_push_kernel, dim3(blocks), dim3(256), 0, s, da); };
+    h->ops_dp.push_back(op);
+  }
+  {
+    Op op; op.tag = "dp_apply"; op.bytes = (double)h->n_train * 4 * 7 + (double)h->n_polyak * 4 * 2;
+    op.run = [self, da](hipStream_t s) {
+      AdamArgs aa;
+      memset(&aa, 0, sizeof(aa));
+      aa.params = self->params; aa.grads = da.res[da.rank]; aa.m = self->adam_m; aa.v = self->adam_v;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f / (float)da.world; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
+      aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
+      const int blocks = (int)std::min<int64_t>(1024, (self->n_train + 255) / 256);
+      hipLaunchKernelGGL(dp_apply_kernel, dim3(blocks), dim3(256), 0, s, aa, da);
+    };
+    h->ops_dp.push_back(op);
+  }
+  h->dp_on = true;
+  return GRL_OK;
+}
+
+int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps) {
+  if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  for (int s = 0; s < n_steps; ++s) {
+    if (idx) {
+      if (int e = stage_noise(h, idx, eps, s)) return e;
+      if (int e = h->run_seq("dp_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_dp})) return e;
+    } else if (int e = h->run_seq("dp_rng", {&h->ops_rng, &h->ops_grads, &h->ops_dp})) return e;
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error) {
+  if (!h || !h->dp_buf) return fail(GRL_ERR_STATE, "no exchange buffer");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DpCtl c;
+  HIPCHK(hipMemcpy(&c, h->dp_buf, sizeof(c), hipMemcpyDeviceToHost));
+  if (exchanges) *exchanges = c.epoch;
+  if (error) *error = (int)c.error;
+  if (c.error) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
   return GRL_OK;
 }
 

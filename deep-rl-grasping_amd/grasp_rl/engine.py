@@ -176,6 +176,28 @@ class SacEngine:
         var = np.ascontiguousarray(var, dtype=np.float64)
         check(self.lib, self.lib.grl_set_obs_stats(self.h, mean.ctypes.data, var.ctypes.data, float(ret_var)))
 
+    # ---- data parallel with the exchange inside the update graph (grl_allreduce_*, csrc/dp_kernels.h)
+    def allreduce_init(self, rank, world):
+        """Allocates this rank's exchange buffer; returns its 64-byte IPC handle (bytes) for the out-of-band exchange."""
+        buf = C.create_string_buffer(64)
+        check(self.lib, self.lib.grl_allreduce_init(self.h, int(rank), int(world), buf))
+        return buf.raw
+
+    def allreduce_connect(self, handles):
+        """handles: the 64-byte handles of all ranks, in rank order."""
+        blob = b"".join(handles)
+        check(self.lib, self.lib.grl_allreduce_connect(self.h, C.c_char_p(blob)))
+
+    def train_allreduce(self, n_steps=1, idx=None, eps=None):
+        pi, pe, keep = self._noise(idx, eps, n_steps)
+        check(self.lib, self.lib.grl_train_step_allreduce(self.h, n_steps, pi, pe))
+        self._keep = [keep]
+
+    def allreduce_status(self):
+        n, err = C.c_int64(), C.c_int()
+        check(self.lib, self.lib.grl_allreduce_status(self.h, C.byref(n), C.byref(err)))
+        return n.value
+
     # ---- VecNormalize running statistics kept on the device (grl_norm_update; SAC handles)
     def norm_update(self, obs):
         """RunningMeanStd.update(obs) of one env step's raw observations [n, ...] on the device (stream-ordered)."""

@@ -116,3 +116,35 @@ class DataParallelSac:
                 step(None, None)
             else:
                 step(idx[s:s + 1], eps[s:s + 1])
+
+
+class DataParallelInGraph:
+    """The exchange inside the library (include/grl.h: grl_allreduce_init / connect / grl_train_step_allreduce,
+    csrc/dp_kernels.h): a two-shot all-reduce over IPC-mapped exchange buffers, captured in the update's hipGraph --
+    one C call per update, no collective library, no Python between compute and apply.  ``torch.distributed`` (any
+    backend; gloo is enough) is used ONCE, to hand the 64-byte buffer handles around.  Needs
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment (dmabuf IPC).  Every replica receives bit-identical sums: each
+    1/world chunk is added by its owner in rank order.  `train` raises if a peer did not arrive (bounded waits)."""
+
+    def __init__(self, engine, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.eng, self.group = engine, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        mine = engine.allreduce_init(self.rank, self.world)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        engine.allreduce_connect(handles)
+        dist.barrier(group=group)          # every rank has mapped every buffer before the first exchange starts
+
+    def broadcast_parameters(self, src=0):
+        P = [self.eng.get_parameters() if self.rank == src else None]
+        dist.broadcast_object_list(P, src=src, group=self.group)
+        self.eng.set_parameters(P[0])
+
+    def train(self, n_steps=1, idx=None, eps=None):
+        self.eng.train_allreduce(n_steps, idx, eps)
+
+    def check(self):
+        """Synchronises; raises if an exchange timed out.  Returns the number of completed exchanges."""
+        return self.eng.allreduce_status()

@@ -70,6 +70,18 @@ static inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
 static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
 
+// exchange-buffer plumbing of the data-parallel path (csrc/dp_kernels.h): plain host memory, "IPC handles" carry the
+// pointer (one process only)
+struct hipIpcMemHandle_t { char reserved[64]; };
+enum { hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1 };
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { *p = calloc(1, n); return *p ? 0 : 1; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n); return *p ? 0 : 1; }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return 0; }
+static inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof(*p)); return 0; }
+static inline hipError_t hipIpcCloseMemHandle(void*) { return 0; }
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
+
 template <class K, class... Args>
 static inline void hostemu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
   gridDim = grid;

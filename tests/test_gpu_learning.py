@@ -22,10 +22,10 @@ def test_sac_cnn_learns_to_reach_through_model_learn():
     """SAC + augmented Nature-CNN on 64x64 depth observations, 16 envs, the reference's hyper-parameters
     (ent_coef auto, lr 3e-4, gamma 0.99, batch 256): success >= 0.8 over the last 200 training episodes AND in the
     deterministic evaluation (a uniformly random policy: 0.07)."""
-    r = synthetic.learn_reach("sac", "depth", total_timesteps=40_000, n_envs=16)
+    r = synthetic.learn_reach("sac", "depth", total_timesteps=48_000, n_envs=16)
     print(r)
     assert all(np.isfinite(v) for v in r["metrics"].values())
-    assert r["updates"] >= 39_000
+    assert r["updates"] >= 47_000
     assert r["train_success"] >= 0.8 and r["eval_success"] >= 0.8, r
 
 

@@ -147,3 +147,23 @@ def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_
         outs.append(eng.get_parameters())
         eng.close()
     assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
+
+
+def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
+    """grl_allreduce_init / connect / grl_train_step_allreduce with world = 1 (the peer is the rank itself): the
+    publish -> reduce + push -> apply chain must leave exactly the parameters of compute_grads + apply_grads(1.0).
+    (Two ranks in two processes run on the GPU box: tests/test_gpu_data_parallel.py.)"""
+    case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=3)
+    a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    h = a.allreduce_init(0, 1)
+    assert len(h) == 64
+    a.allreduce_connect([h])
+    for s in range(3):
+        a.train_allreduce(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
+        b.compute_grads(case["idx"][s:s + 1], case["eps"][s:s + 1])
+        b.apply_grads(1.0)
+    assert a.allreduce_status() == 3
+    Pa, Pb = a.get_parameters(), b.get_parameters()
+    assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
+    a.close(); b.close()
