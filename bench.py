@@ -15,6 +15,7 @@ scaling: BASELINE configs[4] is `--global-batch 1024` on 8 GPUs).
 Other workloads (`--workload`), each with its own roofline and CPU-oracle baseline:
   sac_rgbd    configs[3]: RGB-D 64x64x5, batch 256, replay with byte colours, + auto-encoder feature latency
   sac_nature  configs[0] on the GPU: default nature_cnn over both channels, A=3, batch 64, no VecNormalize
+  sac_mlp     configs[0] as shipped (depth_observation False): sacMlp on 100-d auto-encoder features, A=3, batch 64
   bdq_per     configs[2]: BDQ 5 branches x 33 bins on 101-d observations, batch 64, prioritised replay over 1 M
   ae_train    auto-encoder training step, batch 128 (config/encoder.yaml)
 
@@ -50,10 +51,31 @@ WORKLOADS = {
                        metric="SAC grad-steps/sec (64x64 depth, nature_cnn, batch 64)",
                        name="configs[0]: simplified_object_picking.yaml --algo SAC with depth observations: default nature_cnn "
                             "over both channels, batch %d/GPU, A=3, layers [64,64], no VecNormalize, %d-transition replay"),
+    "sac_mlp": dict(kind="vector", extractor="mlp", batch=64, act_dim=3, normalize=False, replay=50_000, obs_dim=100,
+                    metric="SAC grad-steps/sec (100-d auto-encoder features, sacMlp, batch 64)",
+                    name="configs[0] as shipped: simplified_object_picking.yaml --algo SAC (depth_observation False: sacMlp on the "
+                         "100-d auto-encoder features, sensor.py:220-222), batch %d/GPU, A=3, layers [64,64], no VecNormalize, "
+                         "%d-transition replay"),
 }
 
 
 # ------------------------------------------------------------------------------------------------ helpers
+def fill_replay_vectors(eng, n, seed, device, obs_dim, act_dim):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for k0 in range(0, n, 65536):
+        m = min(65536, n - k0)
+        with torch.cuda.stream(eng.be.stream):
+            obs = (0.5 + 0.3 * torch.randn((m, obs_dim), generator=g, device=device)).contiguous()
+            nxt = (0.5 + 0.3 * torch.randn((m, obs_dim), generator=g, device=device)).contiguous()
+            act = (torch.rand((m, act_dim), generator=g, device=device) * 2 - 1).contiguous()
+            rew = (-150.0 + 300.0 * torch.randn(m, generator=g, device=device)).contiguous()
+            done = (torch.rand(m, generator=g, device=device) < 1.0 / 15.0).float().contiguous()
+            eng.replay_add_device(obs, act, rew, nxt, done)
+        eng.be.stream.synchronize()
+
+
 def fill_replay_on_device(eng, n, seed, device, kind="depth", act_dim=5):
     """Synthetic transitions with the reference's per-pixel statistics, generated on the GPU."""
     import numpy as np
@@ -236,9 +258,27 @@ def cpu_baseline_sac(wl, seconds=12.0):
     import torch
     from oracle import sac as osac
     from grasp_rl import synthetic
+    B, A = wl["batch"], wl["act_dim"]
+    if wl["extractor"] == "mlp":
+        import numpy as np
+        D = wl["obs_dim"]
+        spec = osac.SacSpec(extractor="mlp", obs_dim=D, act_dim=A, layers=[64, 64])
+        orc = osac.SacOracle(spec, seed=0)
+        tr = synthetic.make_vector_transitions(4096, np.full(D, 0.5), np.full(D, 0.09), A, 0)
+        idx, eps = synthetic.make_noise(4000, B, A, 4096, 1)
+        cores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(cores)
+        for s in range(20):
+            orc.step(osac.prepare_batch(spec, {k: tr[k][idx[s]] for k in ("obs", "act", "rew", "next_obs", "done")}, None), eps[s])
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds and n < 3900:
+            orc.step(osac.prepare_batch(spec, {k: tr[k][idx[20 + n]] for k in ("obs", "act", "rew", "next_obs", "done")}, None), eps[20 + n])
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+                "sample": "%d oracle SAC-MLP updates at batch %d (sampling + PyTorch-CPU fp32 step), %.1f s" % (n, B, dt)}
     st = synthetic.load_obs_stats(wl["kind"])
     C = st["mean"].shape[-1]
-    B, A = wl["batch"], wl["act_dim"]
     if wl["extractor"] == "augmented":
         spec = osac.SacSpec(extractor="augmented", img_channels=C - 1, n_direct=1, act_dim=A, layers=[64, 64])
     else:
@@ -313,6 +353,42 @@ def cpu_baseline_ae(seconds=8.0):
             "sample": "%d oracle auto-encoder training steps at batch 128 (PyTorch-CPU fp32), %.1f s" % (n, dt)}
 
 
+def make_data_parallel(eng, kind, world, rank, device, init):
+    """The exchange step for N > 1.  'auto': the in-graph two-shot all-reduce over IPC-mapped buffers
+    (grasp_rl.parallel.DataParallelInGraph) if it can be set up AND proves itself on three updates (no time-out, replicas
+    bit-identical across ranks -- checked with a checksum all-reduce), otherwise RCCL with one gradient bucket."""
+    import torch
+    import torch.distributed as dist
+    from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
+    if kind in ("auto", "ingraph"):
+        ok = torch.ones(1, device=device)
+        dp = None
+        try:
+            dp = DataParallelInGraph(eng)
+            dp.train(3)
+            dp.check()
+            P = eng.get_parameters()
+            chk = torch.tensor([float(sum(float(v.astype("float64").sum()) for v in P.values()))], dtype=torch.float64, device=device)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if float(lo) != float(hi):
+                raise RuntimeError("replicas differ after the in-graph exchange")
+        except Exception as exc:   # noqa: BLE001
+            sys.stderr.write("bench[rank %d]: in-graph exchange unavailable (%s)\n" % (rank, exc))
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if float(ok) > 0:
+            return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph" % world
+        if kind == "ingraph":
+            raise SystemExit("--dp ingraph: the in-graph exchange could not be set up on every rank")
+        eng.set_parameters(init)           # the aborted attempt may have left the replicas out of step
+        eng.reset_optimizer()
+    dp = DataParallelSac(eng, overlap=(kind == "rccl-overlap"))
+    return dp, "dp%d, RCCL all-reduce, %s" % (world, "two gradient buckets (dense bucket under the conv backward)" if dp.overlap
+                                              else "one gradient bucket")
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def run_sac(args, wl_name, world, rank, device):
     import numpy as np
@@ -330,23 +406,23 @@ def run_sac(args, wl_name, world, rank, device):
         wl["batch"] = args.global_batch // world
     replay = args.replay or wl["replay"]
     C = 5 if wl["kind"] == "rgbd" else 2
-    cfg = _capi.make_config(wl["extractor"], obs_channels=C, n_direct=1 if wl["extractor"] == "augmented" else 0,
-                            act_dim=wl["act_dim"], layers=(64, 64), batch_size=wl["batch"], replay_capacity=replay,
-                            normalize=wl["normalize"], act_batch=16, seed=1234 + rank, replay_rgb_u8=wl.get("rgb_u8", False))
+    if wl["extractor"] == "mlp":
+        cfg = _capi.make_config("mlp", obs_dim=wl["obs_dim"], act_dim=wl["act_dim"], layers=(64, 64), batch_size=wl["batch"],
+                                replay_capacity=replay, normalize=wl["normalize"], act_batch=16, seed=1234 + rank)
+    else:
+        cfg = _capi.make_config(wl["extractor"], obs_channels=C, n_direct=1 if wl["extractor"] == "augmented" else 0,
+                                act_dim=wl["act_dim"], layers=(64, 64), batch_size=wl["batch"], replay_capacity=replay,
+                                normalize=wl["normalize"], act_batch=16, seed=1234 + rank, replay_rgb_u8=wl.get("rgb_u8", False))
     eng = SacEngine(cfg, device=str(device))
     eng.set_parameters(init_parameters(eng.table, seed=0))       # identical on every rank
-    st = fill_replay_on_device(eng, replay, 100 + rank, device, wl["kind"], wl["act_dim"])
-    eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
-    dp = DataParallelSac(eng) if world > 1 else None
-    if dp is not None and dp.overlap:
-        # the two-bucket overlapped schedule is the default; should the grouped RCCL calls be refused by this
-        # torch / RCCL build (the same on every rank), fall back to the single-bucket exchange rather than fail
-        try:
-            dp.train(1)
-            eng.synchronize()
-        except Exception as exc:   # noqa: BLE001
-            sys.stderr.write("bench: overlapped data-parallel schedule failed (%s); using one bucket\n" % exc)
-            dp.overlap = False
+    if wl["extractor"] == "mlp":
+        fill_replay_vectors(eng, replay, 100 + rank, device, wl["obs_dim"], wl["act_dim"])
+    else:
+        st = fill_replay_on_device(eng, replay, 100 + rank, device, wl["kind"], wl["act_dim"])
+        eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
+    dp, dp_kind = None, "dp%d" % world
+    if world > 1:
+        dp, dp_kind = make_data_parallel(eng, args.dp, world, rank, device, init_parameters(eng.table, seed=0))
 
     def run(n):
         if dp is None:
@@ -373,9 +449,11 @@ def run_sac(args, wl_name, world, rank, device):
         out["value"] = round(world * args.steps / dt, 2)
     out["config"] = {"workload": wl["name"] % (wl["batch"], replay) + (" [configs[4]: global batch %d over %d GPU(s)]"
                                                                         % (args.global_batch, world) if strong else ""),
-                     "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world + ("" if dp is None else (" two gradient buckets, dense all-reduce under the conv backward" if dp.overlap else " one gradient bucket")),
+                     "global_batch": wl["batch"] * world, "parallelism": dp_kind,
                      "global_steps_per_s": round(args.steps / dt, 2)}
     out["repeats"] = {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"}
+    if args.same_device and world > 1:
+        out["config"]["validation_only"] = "all %d ranks share cuda:0 (--same-device): not a scaling measurement" % world
     out["losses"] = {k: round(float(v), 6) for k, v in metrics.items()}
     if rank == 0 and not args.no_profile:
         n = min(args.steps, 50)
@@ -530,13 +608,19 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps updates; value = median block")
-    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_nature", "bdq_per", "ae_train"])
+    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_nature", "sac_mlp", "bdq_per", "ae_train"])
     ap.add_argument("--global-batch", type=int, default=None, help="fix the GLOBAL batch (strong scaling); per-GPU batch = G / N")
     ap.add_argument("--replay", type=int, default=None)
     ap.add_argument("--learn-iters", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-learn-loop", action="store_true")
+    ap.add_argument("--dp", default="auto", choices=["auto", "ingraph", "rccl", "rccl-overlap"],
+                    help="exchange step for N > 1 (auto: in-graph IPC all-reduce when it verifies, else RCCL one bucket)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="validation aid: gloo lets the N-rank path run where RCCL cannot (ranks sharing one GPU)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="validation aid: every rank uses cuda:0 (a 1-GPU box); the reported rate is then NOT a scaling number")
     ap.add_argument("--no-success", action="store_true", help="skip the learning run behind `success_rate`")
     ap.add_argument("--success-steps", type=int, default=48_000)
     args = ap.parse_args()
@@ -552,11 +636,15 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     if world > 1 and not args.workload.startswith("sac_"):
         raise SystemExit("multi-GPU runs are defined for the SAC workloads")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     if args.workload.startswith("sac_"):
         out = run_sac(args, args.workload, world, rank, device)
     elif args.workload == "bdq_per":

@@ -610,6 +610,8 @@ struct QLossArgs {
   float* row_part; unsigned* counter;     // [3 B] per-row partial sums, completion counter (zero between launches)
   int defer_finish;                       // 1: the batch sums / metrics are formed by a later launch from row_part (q_finish_sums):
                                           //    this kernel then needs no device-scope fence, counter or last-workgroup pass
+  int loss_sum;                           // BDQ reading switch (grl_config.q_loss_sum_branches): TD loss SUMMED over the branches
+                                          //    instead of averaged (gradients D times larger; target and priorities unchanged)
 };
 
 __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3) {
@@ -652,14 +654,14 @@ __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3)
       dfd = 2.f * tdv;
     }
     lossb += err;
-    const float g = w * invB * invD * dfd;
+    const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
     dv += g;
     float* ga = a.d_adv0 + ((long)b * D + d) * n;
     for (int k = 0; k < n; ++k) ga[k] = g * ((k == ai ? 1.f : 0.f) - invn);
   }
   a.d_v0[b] = dv;
   a.priority[b] = prio;
-  s3[0] += w * lossb * invD;
+  s3[0] += w * lossb * (a.loss_sum ? 1.f : invD);
   s3[1] += qs * invD;
   s3[2] += prio * invD;
 }
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
           dfd = 2.f * tdv;
         }
         lossb += err;
-        const float g = w * invB * invD * dfd;
+        const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
         dv += g;
         if (on) a.d_adv0[o] = g * ((lane == ai ? 1.f : 0.f) - invn);
         if (lane == 0) a.td[b * D + d] = tdv;
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
     if (lane == 0) {
       a.d_v0[b] = dv;
       a.priority[b] = prio;
-      a.row_part[3 * b] = w * lossb * invD;
+      a.row_part[3 * b] = w * lossb * (a.loss_sum ? 1.f : invD);
       a.row_part[3 * b + 1] = qs * invD;
       a.row_part[3 * b + 2] = prio * invD;
     }
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
         dfd = 2.f * tdv;
       }
       lossb += err;
-      const float g = w * invB * invD * dfd;
+      const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
       dv += g;
       if (on) a.d_adv0[o] = g * ((lane == ai ? 1.f : 0.f) - invn);
       if (lane == 0) a.td[b * D + d] = tdv;
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
     if (lane == 0) {
       a.d_v0[b] = dv;
       a.priority[b] = prio;
-      a.row_part[3 * b] = w * lossb * invD;
+      a.row_part[3 * b] = w * lossb * (a.loss_sum ? 1.f : invD);
       a.row_part[3 * b + 1] = qs * invD;
       a.row_part[3 * b + 2] = prio * invD;
     }

@@ -2635,6 +2635,7 @@ int grl_ctx::plan_q() {
     qa.row_part = wk.f32(3 * (int64_t)B);
     qa.counter = (unsigned*)wk.take(16);
     qa.defer_finish = 0;
+    qa.loss_sum = (c.algo == GRL_ALGO_BDQ && c.q_loss_sum_branches) ? 1 : 0;
     zero_once.push_back({qa.counter, 16});
     q_row_part = qa.row_part;
 #ifdef GRL_HOSTEMU

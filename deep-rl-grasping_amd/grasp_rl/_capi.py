@@ -25,6 +25,7 @@ class GrlConfig(C.Structure):
         ("q_huber", C.c_int32), ("q_double", C.c_int32), ("q_grad_clip", C.c_float), ("q_trunk_scale", C.c_float),
         ("q_per", C.c_int32), ("q_per_alpha", C.c_float), ("q_per_eps", C.c_float),
         ("replay_rgb_u8", C.c_int32), ("q_per_stratified", C.c_int32), ("q_per_alpha64", C.c_double),
+        ("q_loss_sum_branches", C.c_int32),
     ]
 
 
@@ -186,7 +187,8 @@ def make_ae_config(batch_size=128, lr=2e-4, act_batch=16):
 def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(64, 64), value_hidden=(64, 64),
                   batch_size=32, act_batch=1, replay_capacity=50000, normalize=False, gamma=0.99, lr=5e-4,
                   double_q=True, grad_clip=10.0, clip_obs=10.0, clip_reward=10.0, norm_eps=1e-8, seed=0,
-                  prioritized=False, per_alpha=0.6, per_eps=1e-6, per_stratified=False):
+                  prioritized=False, per_alpha=0.6, per_eps=1e-6, per_stratified=False, loss_sum_branches=False,
+                  trunk_rescale=True):
     """DQN (algo='dqn': separate dueling towers) / BDQ (algo='bdq': shared trunk + branches).
     per_stratified: False = stable-baselines 2.10.x sampler (mass = random(batch) * total), True = the stratified
     sampler of OpenAI baselines / stable-baselines < 2.10 (include/grl.h, grl_config.q_per_stratified)."""
@@ -205,7 +207,8 @@ def make_q_config(algo, obs_dim, n_branches, n_bins, common=(), branch_hidden=(6
     cfg.q_huber = 1 if algo == "dqn" else 0
     cfg.q_double = 1 if double_q else 0
     cfg.q_grad_clip = grad_clip
-    cfg.q_trunk_scale = 1.0 / (n_branches + 1) if (algo == "bdq" and len(common) > 0) else 1.0
+    cfg.q_trunk_scale = 1.0 / (n_branches + 1) if (algo == "bdq" and len(common) > 0 and trunk_rescale) else 1.0
+    cfg.q_loss_sum_branches = 1 if (algo == "bdq" and loss_sum_branches) else 0
     cfg.q_per, cfg.q_per_alpha, cfg.q_per_eps = (1 if prioritized else 0), per_alpha, per_eps
     cfg.q_per_alpha64, cfg.q_per_stratified = float(per_alpha), (1 if per_stratified else 0)
     return cfg

@@ -196,3 +196,20 @@ class SimpleAutoEncoder:
     @property
     def encoding_shape(self):
         return (100,)
+
+
+class DeferredEncoder:
+    """What an ENV WORKER holds in place of the encoder when environments are vectorised.  The
+    reference's sensor calls ``self._encoder.encode(img)`` with a batch of one inside every environment
+    (gripperEnv/sensor.py:220-222); with N environments in N worker processes that would be N HIP contexts and N
+    batch-1 launches per step.  This object keeps the sensor code unchanged -- ``encode`` returns the (filtered) depth
+    image itself, flattened to 4096 floats, and ``encoding_shape`` says so -- and
+    ``grasp_rl.sb.vec_env.VecBatchedEncoder`` in the parent process encodes the images of ALL environments in ONE
+    ``grl_encode`` call per step.  No GPU, no libgrl in the worker."""
+    encoding_shape = (64 * 64,)
+
+    def encode(self, imgs):
+        return np.ascontiguousarray(imgs, np.float32).reshape(-1, 64 * 64)
+
+    def predict(self, imgs):      # (only the sensor's visualisation calls this)
+        raise RuntimeError("DeferredEncoder does not reconstruct: visualise through the parent's SimpleAutoEncoder")

@@ -8,13 +8,14 @@ SAC losses are batch means, so the mean of per-shard gradients equals the gradie
 
 Two schedules:
   * one bucket: compute_grads -> all_reduce(whole bucket) on the engine stream -> apply_grads;
-  * two buckets, overlapped (default when the engine has a staged plan and world > 1): stage 0 of the gradient
+  * two buckets, overlapped (opt-in: ``overlap=True`` / GRL_DP_OVERLAP=1): stage 0 of the gradient
     computation ends with the fully-connected + head gradients (90 % of the bytes) final; their all-reduce is
     issued on a second stream and travels over xGMI while stage 1 (convolution backward + convolution weight
     gradients, ~40 % of the update) runs on the engine stream; the small convolution bucket follows, then
     apply_grads.  xGMI is point-to-point: a ring all-reduce of 4.8 MB over 8 GPUs is bound by per-link
     bandwidth and latency, comparable to the update itself -- hiding it is worth the two extra launches of the
-    staged plan (grl_compute_grads_staged, include/grl.h).
+    staged plan (grl_compute_grads_staged, include/grl.h);
+  * ``DataParallelInGraph`` (below): the exchange as kernels of the update's own graph over IPC-mapped buffers.
 """
 import numpy as np
 import torch
@@ -36,12 +37,15 @@ def allreduce_ranges_(views, group=None):
     (ncclGroupStart / End through torch's coalescing manager): a collective call costs tens of microseconds of host
     time, comparable to the whole update."""
     if len(views) > 1 and views[0].is_cuda and hasattr(dist, "_coalescing_manager") and dist.get_backend(group) == "nccl":
-        with dist._coalescing_manager(group=group, device=views[0].device, async_ops=False):
-            for v in views:
-                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
-    else:
-        for v in views:
-            allreduce_flat_(v, group)
+        try:        # private API: only the fast path (no `device=`: that also runs the legacy start / end wrapping)
+            with dist._coalescing_manager(group=group, async_ops=False):
+                for v in views:
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+            return
+        except TypeError:       # a torch whose signature differs: one collective per range
+            pass
+    for v in views:
+        allreduce_flat_(v, group)
 
 
 def gather_moments(mean, var, count, group=None):
@@ -80,8 +84,9 @@ class DataParallelSac:
         full = engine.be.as_torch(engine.grads)
         ranges = [engine.grad_ranges(b) for b in (0, 1)]
         self.staged = len(ranges[1]) > 0
-        if overlap is None:
-            overlap = self.staged and self.world > 1
+        if overlap is None:     # opt-in (GRL_DP_OVERLAP=1): the staged plan costs +16 % on-GPU and has no multi-GPU measurement yet
+            import os
+            overlap = os.environ.get("GRL_DP_OVERLAP", "0") == "1"
         self.overlap = bool(overlap) and self.staged
         self.views = [[full[o:o + n] for o, n in r] for r in ranges]     # [bucket][range] views of the grads arena
 

@@ -311,6 +311,43 @@ class VecEnvWrapper(VecEnv):
         return getattr(self.venv, name)
 
 
+class VecBatchedEncoder(VecEnvWrapper):
+    """Auto-encoder features for vectorised environments, batched.  The wrapped environments run with
+    ``grasp_rl.autoencoder.DeferredEncoder`` (their observation = the 4096 floats of the filtered depth image followed
+    by the other sensor readings, robot.py:185-190); this wrapper replaces the image part by
+    ``encoder.encode(images of all N environments)`` -- one device call per step instead of one per environment -- and
+    presents the observation space the reference's env would have had ([100 + k], sensor.py:196).  `encoder`: a
+    ``SimpleAutoEncoder`` (weights loaded); terminal observations in ``info`` are encoded in the same call."""
+
+    def __init__(self, venv, encoder, n_pixels=64 * 64):
+        self.encoder, self.n_pixels = encoder, int(n_pixels)
+        raw = int(np.prod(venv.observation_space.shape))
+        if raw <= self.n_pixels:
+            raise ValueError("the wrapped observation must be [image pixels | other sensor readings]")
+        self.n_extra = raw - self.n_pixels
+        dim = int(np.prod(encoder.encoding_shape)) + self.n_extra
+        space = sp.Box(-np.inf, np.inf, shape=(dim,), dtype=np.float32)
+        super().__init__(venv, observation_space=space)
+
+    def _encode(self, raw):
+        raw = np.asarray(raw, np.float32).reshape(-1, self.n_pixels + self.n_extra)
+        z = self.encoder.encode(raw[:, :self.n_pixels].reshape(-1, 64, 64, 1))
+        return np.concatenate([np.asarray(z, np.float32).reshape(raw.shape[0], -1), raw[:, self.n_pixels:]], axis=1)
+
+    def reset(self):
+        return self._encode(self.venv.reset())
+
+    def step_wait(self):
+        obs, rews, dones, infos = self.venv.step_wait()
+        term = [i for i, inf in enumerate(infos) if isinstance(inf, dict) and "terminal_observation" in inf]
+        rows = [obs] + [np.asarray(infos[i]["terminal_observation"], np.float32).reshape(1, -1) for i in term]
+        z = self._encode(np.concatenate([np.asarray(r, np.float32).reshape(-1, self.n_pixels + self.n_extra) for r in rows]))
+        n = np.asarray(obs).shape[0]
+        for k, i in enumerate(term):
+            infos[i] = dict(infos[i], terminal_observation=z[n + k])
+        return z[:n], rews, dones, infos
+
+
 class VecNormalize(VecEnvWrapper):
     def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
                  gamma=0.99, epsilon=1e-8):

@@ -109,6 +109,11 @@ typedef struct grl_config {
      float32 priorities of an update); 0 = use q_per_alpha. */
   int32_t q_per_stratified;
   double q_per_alpha64;
+  /* BDQ: the `bdq_sb` fork's source is not available (.gitmodules:1-3, no pinned commit), so two aggregation choices of
+     its update are switches rather than citations (oracle/dqn.py): q_loss_sum_branches = 1 sums the squared TD errors
+     over the action branches instead of averaging them (default 0: mean, Tavakoli et al. 2018 eq. 6);
+     q_trunk_scale above = 1 disables the 1/(D+1) rescaling of the gradient entering the shared trunk. */
+  int32_t q_loss_sum_branches;
 } grl_config;
 
 /* byte sizes of the four caller-provided device arenas */

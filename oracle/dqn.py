@@ -38,6 +38,13 @@ class QSpec:
     lr: float = 5e-4
     grad_clip: float = 10.0
     double_q: bool = True
+    # BDQ: the two aggregation choices with a defensible alternative reading of the (unavailable) fork -- switches, not
+    # citations.  Nothing the reference ships discriminates them: trained_models/BDQ_8pads/logs.full.csv logs mean_loss
+    # next to mean_td_errors over 25 022 rows, but their ratio loss / td^2 ranges from 0.0017 to 1.8 (importance
+    # weights, heavy-tailed TD errors and unknown logging windows), compatible with either aggregation; the zips store
+    # hyper-parameters only (note prioritized_replay_eps = 1e8 there: priorities are effectively uniform).
+    loss_sum_branches: bool = False   # True: sum_d td_d^2 instead of mean_d (gradients D times larger before clipping)
+    trunk_rescale: bool = True        # False: no 1/(D+1) scaling of the gradient entering the shared trunk
 
     @property
     def scope(self):
@@ -49,7 +56,7 @@ class QSpec:
 
     @property
     def trunk_scale(self):
-        return 1.0 / (self.n_branches + 1) if (self.algo == "bdq" and self.common) else 1.0
+        return 1.0 / (self.n_branches + 1) if (self.algo == "bdq" and self.common and self.trunk_rescale) else 1.0
 
 
 def bdq_spec(obs_dim, act_dim, num_actions_pad, layers, **kw):
@@ -188,7 +195,7 @@ class QOracle:
             err = torch.where(td.abs() < 1.0, 0.5 * td ** 2, td.abs() - 0.5)
         else:
             err = td ** 2
-        loss = torch.mean(w * err.mean(dim=1))
+        loss = torch.mean(w * (err.sum(dim=1) if (spec.algo == "bdq" and spec.loss_sum_branches) else err.mean(dim=1)))
         gs = torch.autograd.grad(loss, [T[n] for n in self.train_names])
         G = {n: g.numpy().copy() for n, g in zip(self.train_names, gs)}
         return {"loss": float(loss.detach()), "td": td.detach().numpy(), "q_sel": q_sel.detach().numpy(),

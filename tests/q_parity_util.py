@@ -16,16 +16,23 @@ CASES = {
     # BASELINE configs[2] exactly: gripper_grasp.yaml:104-118 (layers [[64,64],[32],[32]], num_actions_pad 33,
     # batch 64) on the 101-d auto-encoder observation (100 features + gripper width), 5 action dimensions
     "bdq_baseline_config3": dict(algo="bdq", obs_dim=101, D=5, bins=33, common=(64, 64), branch=(32,), value=(32,), B=64, lr=1e-4),
+    # the alternative readings of the unavailable bdq_sb fork (oracle/dqn.py switches): TD loss summed over the
+    # branches; no 1/(D+1) rescaling of the trunk gradient
+    "bdq_loss_sum": dict(algo="bdq", obs_dim=20, D=3, bins=5, common=(16, 16), branch=(8,), value=(8,), B=8, loss_sum=True),
+    "bdq_no_trunk_rescale": dict(algo="bdq", obs_dim=20, D=3, bins=5, common=(16, 16), branch=(8,), value=(8,), B=8,
+                                 trunk_rescale=False),
 }
 
 
 def make_q_case(algo, obs_dim, D, bins, common, branch, value, B, n_replay=40, n_steps=3, seed=0, lr=1e-3,
-                normalize=False):
+                normalize=False, loss_sum=False, trunk_rescale=True):
     rng = np.random.default_rng(seed)
     spec = od.QSpec(algo=algo, obs_dim=obs_dim, n_branches=D, n_bins=bins, common=list(common),
-                    branch_hidden=list(branch), value_hidden=list(value), gamma=0.97, lr=lr)
+                    branch_hidden=list(branch), value_hidden=list(value), gamma=0.97, lr=lr,
+                    loss_sum_branches=loss_sum, trunk_rescale=trunk_rescale)
     cfg = _capi.make_q_config(algo, obs_dim, D, bins, common, branch, value, batch_size=B, act_batch=4,
-                              replay_capacity=n_replay, gamma=0.97, lr=lr, normalize=normalize)
+                              replay_capacity=n_replay, gamma=0.97, lr=lr, normalize=normalize,
+                              loss_sum_branches=loss_sum, trunk_rescale=trunk_rescale)
     mean, var = rng.uniform(0.2, 0.8, obs_dim), rng.uniform(0.05, 0.2, obs_dim)
     tr = {"obs": rng.normal(mean, np.sqrt(var), (n_replay, obs_dim)).astype(np.float32),
           "next_obs": rng.normal(mean, np.sqrt(var), (n_replay, obs_dim)).astype(np.float32),

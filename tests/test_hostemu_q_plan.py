@@ -7,7 +7,7 @@ from hostemu_backend import NumpyHostBackend
 from oracle import dqn as od
 
 
-@pytest.mark.parametrize("name", ["dqn", "bdq", "bdq_5_branches", "bdq_baseline_config3"])
+@pytest.mark.parametrize("name", ["dqn", "bdq", "bdq_5_branches", "bdq_baseline_config3", "bdq_loss_sum", "bdq_no_trunk_rescale"])
 def test_q_plan_matches_oracle(hostemu_lib, name):
     case = qu.make_q_case(**qu.CASES[name])
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
