@@ -36,7 +36,7 @@ def _worker(rank, world, port, lib, out_dir):
     case = _case()
     case["cfg"] = _shard_cfg(case["cfg"], B // world)
     eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=lib)
-    dp = DataParallelSac(eng)
+    dp = DataParallelSac(eng, overlap=True)
     assert dp.staged and dp.overlap                # two-bucket schedule: dense ranges after stage 0, conv after stage 1
     r0, r1 = eng.grad_ranges(0), eng.grad_ranges(1)
     covered = sorted(r0 + r1)

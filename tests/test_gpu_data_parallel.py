@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_dir):
     cfg.batch_size = B // world
     case["cfg"] = cfg
     eng = pu.engine_setup(case)
-    dp = DataParallelSac(eng)
+    dp = DataParallelSac(eng, overlap=True)
     assert dp.staged and dp.overlap                # two-bucket schedule: the dense bucket travels on a second stream
     if rank != 0:                                  # replicas must start identical: perturb, then broadcast
         P = eng.get_parameters()
