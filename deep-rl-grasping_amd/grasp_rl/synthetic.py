@@ -321,13 +321,17 @@ def learn_reach(algo="sac", kind="depth", total_timesteps=30_000, n_envs=16, dev
                   prioritized_replay=True, policy_kwargs={"layers": [[64, 64], [32], [32]]}, seed=seed)
         kw.update(model_kwargs)
         cls, args = BDQ, ("MlpActPolicy", env)
-    old = cls._engine_factory
+    old = cls.__dict__.get("_engine_factory")          # (the staticmethod object itself, not the unwrapped function)
     if engine_factory is not None:
         cls._engine_factory = staticmethod(engine_factory)
     try:
         model = cls(*args, device=device, **kw)
     finally:
-        cls._engine_factory = old
+        if engine_factory is not None:
+            if old is not None:
+                cls._engine_factory = old
+            else:
+                del cls._engine_factory
     cb = Successes()
     t0 = time.perf_counter()
     model.learn(total_timesteps=total_timesteps, callback=cb)

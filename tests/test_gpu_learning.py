@@ -22,10 +22,10 @@ def test_sac_cnn_learns_to_reach_through_model_learn():
     """SAC + augmented Nature-CNN on 64x64 depth observations, 16 envs, the reference's hyper-parameters
     (ent_coef auto, lr 3e-4, gamma 0.99, batch 256): success >= 0.8 over the last 200 training episodes AND in the
     deterministic evaluation (a uniformly random policy: 0.07)."""
-    r = synthetic.learn_reach("sac", "depth", total_timesteps=48_000, n_envs=16)
+    r = synthetic.learn_reach("sac", "depth", total_timesteps=72_000, n_envs=16)
     print(r)
     assert all(np.isfinite(v) for v in r["metrics"].values())
-    assert r["updates"] >= 47_000
+    assert r["updates"] >= 71_000
     assert r["train_success"] >= 0.8 and r["eval_success"] >= 0.8, r
 
 
@@ -57,57 +57,76 @@ def test_bdq_with_prioritised_replay_learns():
 METRICS = ("policy_loss", "qf1_loss", "qf2_loss", "value_loss", "ent_coef_loss", "ent_coef", "entropy", "mean_qf1", "mean_v")
 
 
-# Tolerances of the long-trajectory comparison.  The first update agrees to 1e-4 (tests/test_gpu_parity.py); afterwards two
-# fp32-faithful implementations drift apart because Adam turns rounding-level gradient differences into +-lr steps.  The
-# means of the network outputs, the policy loss and the entropy terms stay within 2 % (entropy coefficient 1 %); the three
-# regression losses are RESIDUALS (0.5 mean((target - prediction)^2), a few per cent of the signal they are formed
-# from) and amplify the same drift: 10 %.  Measured: host-emulation build vs oracle, 30 updates, B = 32: value_loss 2.0 %,
-# everything else <= 0.7 %; MI355X vs oracle: printed by the test.
+# The long-trajectory comparison.  The first update agrees with the oracle to 1e-4 (tests/test_gpu_parity.py; gradients
+# to ~5e-7 of their maximum).  Afterwards ANY two fp32-faithful implementations drift apart: the SAC update map is
+# chaotic on this problem -- two copies of the ORACLE whose initial parameters differ by a relative 1e-6 (the "twin",
+# run inside the test) are 10x further apart every ~40 updates.  The device is therefore held to
+#   * the strict tolerance REL (2 %; entropy coefficient 1 %; the three regression losses, which are residuals of a few
+#     per cent of the signal they are formed from, 10 %) for the first 100 updates, and
+#   * the amplification envelope afterwards: at every checkpoint its deviation from the oracle may not exceed
+#     max(REL, ENVELOPE x the twin's deviation at that checkpoint) -- drift that grows like the twin's is chaos, drift
+#     that grows faster would be an error accumulating in the device state (Adam moments, Polyak target, log alpha).
+# Deviations are relative to max(|oracle value|, FLOORS[metric]) (metrics that pass through zero).
 REL = {"policy_loss": 0.02, "ent_coef_loss": 0.02, "ent_coef": 0.01, "entropy": 0.02, "mean_qf1": 0.02, "mean_v": 0.02,
        "qf1_loss": 0.10, "qf2_loss": 0.10, "value_loss": 0.10}
 FLOORS = {"policy_loss": 0.5, "ent_coef_loss": 0.05, "mean_qf1": 0.05, "mean_v": 0.05, "qf1_loss": 0.05, "qf2_loss": 0.05,
           "value_loss": 0.05, "entropy": 0.5}
+ENVELOPE = 30.0
 
 
-def trajectory_check(case, eng, n_steps, every, rel=None, floors=None):
-    """`n_steps` updates on identical minibatch indices and policy noise, device vs oracle: the nine logged metrics
-    stay within REL (relative to max(|ref|, floor of that metric's natural scale)), nothing NaN.  Returns the worst
-    relative deviation per metric."""
+def _metrics_of(d):
+    return {"policy_loss": float(d["policy_loss"]), "qf1_loss": float(d["qf1_loss"]), "qf2_loss": float(d["qf2_loss"]),
+            "value_loss": float(d["value_loss"]), "ent_coef_loss": float(d["ent_loss"]), "ent_coef": float(d["ent_coef"]),
+            "entropy": float(np.mean(d["entropy"])), "mean_qf1": float(np.mean(d["qf1"])), "mean_v": float(np.mean(d["v"]))}
+
+
+def trajectory_check(case, eng, n_steps, every, strict_until=None, twin_eps=1e-6, floors=None):
+    """`n_steps` updates on identical minibatch indices and policy noise: device vs oracle (and oracle vs its perturbed
+    twin).  Returns (worst device deviation per metric, table of (update, device deviation, twin deviation))."""
     from oracle import sac as osac
     spec, tr = case["spec"], case["tr"]
     orc = osac.SacOracle(spec, case["params"])
+    rng = np.random.default_rng(123)
+    twin = osac.SacOracle(spec, {k: (v * (1.0 + twin_eps * rng.standard_normal(v.shape))).astype(np.float32)
+                                 for k, v in case["params"].items()})
     floors = dict(FLOORS, **(floors or {}))
-    worst = {}
+    strict_until = n_steps if strict_until is None else strict_until
+    worst, table = {}, []
     for s in range(n_steps):
         ii = case["idx"][s]
         raw = {k: tr[k][ii] for k in ("obs", "act", "rew", "next_obs", "done")}
-        d = orc.step(osac.prepare_batch(spec, raw, case["stats"]), case["eps"][s])
+        batch = osac.prepare_batch(spec, raw, case["stats"])
+        d = orc.step(batch, case["eps"][s])
+        dt = twin.step(batch, case["eps"][s])
         eng.train(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
         if (s + 1) % every == 0 or s == n_steps - 1:
-            m = eng.metrics()
-            ref = {"policy_loss": d["policy_loss"], "qf1_loss": d["qf1_loss"], "qf2_loss": d["qf2_loss"],
-                   "value_loss": d["value_loss"], "ent_coef_loss": d["ent_loss"], "ent_coef": d["ent_coef"],
-                   "entropy": np.mean(d["entropy"]), "mean_qf1": np.mean(d["qf1"]), "mean_v": np.mean(d["v"])}
+            m, ref, tw = eng.metrics(), _metrics_of(d), _metrics_of(dt)
+            row = {}
             for k in METRICS:
-                a, b = float(m[k]), float(ref[k])
+                a, b = float(m[k]), ref[k]
                 assert np.isfinite(a), (s, k)
-                dev = abs(a - b) / max(abs(b), floors.get(k, 1e-3))
+                scale = max(abs(b), floors.get(k, 1e-3))
+                dev, tdev = abs(a - b) / scale, abs(tw[k] - b) / scale
+                row[k] = (dev, tdev)
                 worst[k] = max(worst.get(k, 0.0), dev)
-                lim = rel if rel is not None else REL[k]
-                assert dev <= lim, "update %d: %s device %.6g oracle %.6g (%.2f %% > %.0f %%)" % (s + 1, k, a, b, 100 * dev, 100 * lim)
-    return worst
+                lim = REL[k] if s + 1 <= strict_until else max(REL[k], ENVELOPE * tdev)
+                assert dev <= lim, "update %d: %s device %.6g oracle %.6g twin %.6g (%.2f %% > %.2f %%)" % (
+                    s + 1, k, a, b, tw[k], 100 * dev, 100 * lim)
+            table.append((s + 1, row))
+    return worst, table
 
 
 def test_200_update_trajectory_follows_the_oracle():
     case = pu.make_case(extractor="augmented", kind="depth", B=32, n_replay=256, n_steps=200, seed=4)
     eng = pu.engine_setup(case)
     try:
-        worst = trajectory_check(case, eng, 200, every=10, rel=10.0)      # collect first (the report is the evidence) ...
+        worst, table = trajectory_check(case, eng, 200, every=10, strict_until=100)
     finally:
         eng.close()
-    print("worst relative deviation over 200 updates:", {k: round(v, 5) for k, v in worst.items()})
-    for k, v in worst.items():                                              # ... then judge
-        assert v <= REL[k], (k, v, REL[k])
+    for upd, row in table:
+        if upd % 50 == 0:
+            print("update %3d  device / twin deviation %%: " % upd + "  ".join("%s %.3f/%.3f" % (k, 100 * row[k][0], 100 * row[k][1]) for k in METRICS))
+    print("worst device deviation over 200 updates:", {k: round(v, 5) for k, v in worst.items()})
 
 
 def test_20000_update_soak_on_the_device_rng():

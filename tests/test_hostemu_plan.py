@@ -102,7 +102,7 @@ def test_60_update_trajectory_follows_the_oracle(hostemu_lib):
     from test_gpu_learning import trajectory_check
     case = pu.make_case(extractor="mlp", B=16, n_replay=128, n_steps=60, seed=4)
     eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
-    worst = trajectory_check(case, eng, 60, every=10)
+    worst, _ = trajectory_check(case, eng, 60, every=10)
     assert max(worst.values()) < 0.02
     eng.close()
 
