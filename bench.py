@@ -491,7 +491,10 @@ def run_sac(args, wl_name, world, rank, device):
                 "one_update_per_iteration": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
                                                                       device=str(device), gradient_steps=1),
                 "one_update_per_iteration_device_norm": synthetic.learn_loop_rate(
-                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=True)}
+                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=True),
+                "one_update_per_iteration_device_norm_4_workers": synthetic.learn_loop_rate(
+                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=True,
+                    envs_per_worker=4)}
             out["learn_loop_updates_per_s"] = out["learn_loop"]["strict_order"]["updates_per_s"]
             out["learn_loop_steps_per_s"] = out["learn_loop"]["overlap_env_step"]["env_steps_per_s"]
         except Exception as e:      # the headline number must not depend on process spawning

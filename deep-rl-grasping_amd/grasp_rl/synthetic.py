@@ -212,7 +212,7 @@ class ReachGraspEnv:
 
 
 def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0",
-                    gradient_steps=None, device_norm=False):
+                    gradient_steps=None, device_norm=False, envs_per_worker=1):
     """Env-steps / second and updates / second of ``SAC.learn`` with `n_envs` SyntheticGraspEnv worker processes behind
     SubprocVecEnv + VecNormalize -- BASELINE configs[1]: "16 vectorised PyBullet envs feed a single GPU", with the
     simulator replaced by a free one.  gradient_steps None = one update per ENVIRONMENT step (stable-baselines' ratio
@@ -236,7 +236,8 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
                 self.t0, self.u0 = time.perf_counter(), self.model.n_updates
             return True
 
-    venv = SubprocVecEnv([functools.partial(SyntheticGraspEnv, "depth", 15, s) for s in range(n_envs)])
+    venv = SubprocVecEnv([functools.partial(SyntheticGraspEnv, "depth", 15, s) for s in range(n_envs)],
+                         envs_per_worker=envs_per_worker)
     try:
         env = VecNormalize(venv, norm_obs=True, norm_reward=True, clip_obs=10.0)
         model = SAC(SacCnnPolicy, env, policy_kwargs={"layers": [64, 64], "cnn_extractor": AugmentedNatureCnn(1)},
@@ -248,6 +249,7 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
         dt = time.perf_counter() - clock.t0
         return {"n_envs": n_envs, "iterations": iterations, "overlap_env_step": bool(overlap),
                 "gradient_steps": n_envs if gradient_steps is None else gradient_steps, "device_norm": bool(device_norm),
+                "worker_processes": (n_envs + envs_per_worker - 1) // envs_per_worker,
                 "env_steps_per_s": round(n_envs * iterations / dt, 1),
                 "updates_per_s": round((model.n_updates - clock.u0) / dt, 1),
                 "ms_per_iteration": round(1e3 * dt / iterations, 3)}

@@ -47,3 +47,28 @@ def test_subproc_matches_dummy_and_supports_the_reference_calls():
     finally:
         sub.close()
         ref.close()
+
+
+def test_several_envs_per_worker_behave_like_one_each():
+    """envs_per_worker=2 (5 envs on 3 worker processes): identical observations / rewards / resets / attribute routing."""
+    fns = [functools.partial(_make, s) for s in range(5)]
+    ref = DummyVecEnv(fns)
+    sub = SubprocVecEnv(fns, envs_per_worker=2)
+    try:
+        assert sub.num_envs == 5 and len(sub.processes) == 3
+        assert np.array_equal(ref.reset(), sub.reset())
+        rng = np.random.default_rng(1)
+        for _ in range(11):
+            a = rng.uniform(-1, 1, (5, 3)).astype(np.float32)
+            r1, r2 = ref.step(a), sub.step(a)
+            for x, y in zip(r1[:3], r2[:3]):
+                assert np.array_equal(x, y)
+            for i1, i2 in zip(r1[3], r2[3]):
+                assert ("terminal_observation" in i1) == ("terminal_observation" in i2)
+        sub.set_attr("episode_len", 7, indices=[3, 0])
+        assert sub.get_attr("episode_len") == [7, 5, 5, 7, 5]
+        assert sub.get_attr("episode_len", indices=[4, 3]) == [5, 7]
+        assert sub.env_method("is_simplified", indices=2) == [False]
+    finally:
+        sub.close()
+        ref.close()
