@@ -2786,6 +2786,15 @@ int grl_ctx::plan_q() {
       ok = ok && hits == 1;
     }
     ok = ok && n_tr == reduces.size();
+    for (auto& r : reduces) ok = ok && r.row_len == 0;     // the kernel reads plain (non-strided) slabs
+#ifndef GRL_HOSTEMU
+    if (ok) {   // ~71 KB of static LDS per workgroup: fits gfx950's 160 KB; any device that offers less keeps the three launches
+      int dev = 0, lds = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+          lds < (int)(GRL_QAPPLY_MAX * 4 + 1024 * 4 + 3 * 256 * 4))
+        ok = false;
+    }
+#endif
     if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: q_apply       reduction + clip + Adam in one launch: %s (%zu variables)\n", ok ? "yes" : "no", n_tr);
     if (ok) {
       ops_grads_apply.assign(ops_grads.begin(), ops_grads.end() - 1);

@@ -211,6 +211,8 @@ class _QModel:
                 callback.on_rollout_end()
                 if vn is not None and eng.cfg.normalize:
                     eng.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))
+                if callable(self.learning_rate):    # stable-baselines evaluates the schedule per update: lr(1 - step / total)
+                    eng.set_learning_rate(self.learning_rate(1.0 - (self.num_timesteps - 1) / max(1, total_timesteps)))
                 if self.prioritized_replay:
                     eng.train_per(1, beta_schedule.value(self.num_timesteps))
                 else:
