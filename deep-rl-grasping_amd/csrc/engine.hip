@@ -115,6 +115,7 @@ struct Launch {
   std::vector<IgemmProb> probs;
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
+  int32_t* d_pre = nullptr;     // per-tile preambles (igemm2.h, I2F_PRE): the table entries a tile needs before its first load
   int n_tiles = 0;
   Launch* filler = nullptr;     // tiles of a second instantiation carried by the same launch (igemm2_pair_kernel)
   unsigned dyn_lds = 0;         // extra LDS bytes requested per workgroup: caps the workgroups a CU holds at once
@@ -311,9 +312,11 @@ struct grl_ctx {
   }
 
   // ---------------------------------------------------------------- helpers
+  std::map<const void*, std::vector<int32_t>> htab;   // host copies of the int32 addressing tables (plan time only: preambles)
   template <class T>
   T* upload_vec(Arena& a, const std::vector<T>& v) {
     T* d = (T*)a.take(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if constexpr (std::is_same<T, int32_t>::value) htab[(const void*)d] = v;
     if (!dry && !v.empty()) {
       Upload u;
       u.dst = d;
@@ -758,7 +761,8 @@ struct grl_ctx {
   static bool pair_ok(const Launch* a, const Launch* b) {
     if (!a->v2 || !b->v2 || a->sk || b->sk || v2_key(b) != 21001) return false;
     const int ka = v2_key(a);
-    return ka == 10030 || ka == 10000 || ka == 12130 || ka == 12110 || ka == 12100 || ka == 11130 || ka == 11110 || ka == 11100;
+    return ka == 10030 || ka == 10000 || ka == 12130 || ka == 12110 || ka == 12100 || ka == 11130 || ka == 11110 || ka == 11100 ||
+           ka == 11134 || ka == 11114 || ka == 11104;
   }
 
   // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op.  `filler`: independent problems
@@ -783,7 +787,9 @@ struct grl_ctx {
       add_launch(tmp_a, tag, variant, probs);
       lpt_extra_tiles = 0; lpt_extra_w = 0;
       Launch* la = launches.back();
+      suppress_pre = true;                                          // (the pair kernel's filler side is one fixed instantiation)
       add_launch(tmp_b, ftag, fvariant, fprobs, "", 0, {}, 0);      // fillers keep the 64x64 shape of the merged launch
+      suppress_pre = false;
       Launch* lb = launches.back();
       if (tmp_a.size() == 1 && tmp_b.size() == 1 && pair_ok(la, lb)) {
         la->filler = lb;
@@ -796,9 +802,10 @@ struct grl_ctx {
         op.run = [la, lb, t2](hipStream_t s) {
           const dim3 grid(la->n_tiles + lb->n_tiles), block(256);
           const int ka = la->variant * 10000 + la->pm * 1000 + la->qm * 100 + la->cfg * 10 + la->flags;
-#define GRL_I2P(PLv, QLv, PMv, QMv, CF)                                                                                  \
-  hipLaunchKernelGGL((igemm2_pair_kernel<PLv, QLv, PMv, QMv, CF, 0, I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES>), \
-                     grid, block, 0, s, la->d_probs, la->d_tiles, la->n_tiles, lb->d_probs, lb->d_tiles)
+#define GRL_I2PF(PLv, QLv, PMv, QMv, CF, FLv)                                                                            \
+  hipLaunchKernelGGL((igemm2_pair_kernel<PLv, QLv, PMv, QMv, CF, FLv, I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES>), \
+                     grid, block, 0, s, la->d_probs, la->d_tiles, la->n_tiles, lb->d_probs, lb->d_tiles, (const int*)la->d_pre)
+#define GRL_I2P(PLv, QLv, PMv, QMv, CF) GRL_I2PF(PLv, QLv, PMv, QMv, CF, 0)
           switch (ka) {
             case 10030: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3); break;
             case 10000: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0); break;
@@ -808,11 +815,15 @@ struct grl_ctx {
             case 11130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 3); break;
             case 11110: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 1); break;
             case 11100: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0); break;
+            case 11134: GRL_I2PF(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 3, I2F_PRE); break;
+            case 11114: GRL_I2PF(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 1, I2F_PRE); break;
+            case 11104: GRL_I2PF(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0, I2F_PRE); break;
             default:
               fprintf(stderr, "grl: no igemm2 pair instantiation for launch '%s' (key %d)\n", t2.c_str(), ka);
               abort();
           }
 #undef GRL_I2P
+#undef GRL_I2PF
         };
         (void)self;
         if (getenv("GRL_PLAN_DUMP"))
@@ -916,6 +927,43 @@ struct grl_ctx {
       if (const char* e = getenv("GRL_WG_DYNLDS")) l->dyn_lds = (unsigned)atoi(e);
     }
     l->n_tiles = (int)tiles.size();
+    {   // per-tile preambles (I2F_PRE): unmasked table addressing of the three convolution directions
+      const char* np = getenv("GRL_NO_PREAMBLE");
+      bool ok = l->v2 && !suppress_pre && !(np && atoi(np)) && l->pm == PM_TABLE &&
+                ((variant == 0 && l->qm == QM_AFFINE && l->flags == 0) || (variant == 1 && l->qm == QM_TABLE && l->flags == 0) ||
+                 (variant == 2 && l->qm == QM_AFFINE && l->flags == I2F_ONES && l->cfg <= 1));
+      for (auto& p : l->probs)
+        ok = ok && htab.count(p.p_tab_i) && htab.count(p.p_tab_r) && (!p.q_tab_r || htab.count(p.q_tab_r)) &&
+             (!p.c_tab_i || htab.count(p.c_tab_i));
+      if (ok) {
+        const int BKTt = 32 * (l->cfg == 2 ? 4 : (l->cfg == 3 ? 2 : 1));
+        const int ROWo = 0, PKo = BMt, QKo = BMt + 3 * BKTt, CTo = BMt + 6 * BKTt, STR = 2 * BMt + 6 * BKTt;
+        std::vector<int32_t> pre((size_t)tiles.size() * STR, 0);
+        for (size_t ti = 0; ti < tiles.size(); ++ti) {
+          const int4& t = tiles[ti];
+          const IgemmProb& p = l->probs[t.x];
+          const std::vector<int32_t>&hi = htab[p.p_tab_i], &hr = htab[p.p_tab_r];
+          const std::vector<int32_t>* hq = p.q_tab_r ? &htab[p.q_tab_r] : nullptr;
+          const std::vector<int32_t>* hc = p.c_tab_i ? &htab[p.c_tab_i] : nullptr;
+          const int Meff = p.p_ones_i >= 0 ? p.M - 1 : p.M;
+          const int i0 = t.z * BMt, r_begin = t.y * p.k_chunk, r_end = std::min(p.K, r_begin + p.k_chunk);
+          int32_t* o = pre.data() + ti * STR;
+          for (int x = 0; x < BMt; ++x) {
+            const int i = i0 + x;
+            o[ROWo + x] = hi[(size_t)(i < Meff ? i : i0)];
+            if (hc) o[CTo + x] = (*hc)[(size_t)(i < Meff ? i : 0)];
+          }
+          for (int k = 0; k < 3 * BKTt; ++k) {
+            const int r = r_begin + k, rc = r < r_end ? r : r_begin;
+            o[PKo + k] = hr[(size_t)rc];
+            if (hq) o[QKo + k] = (*hq)[(size_t)rc];
+          }
+        }
+        l->d_pre = upload_vec(wk, pre);
+        htab.erase((const void*)l->d_pre);          // (not an addressing table)
+        l->flags |= I2F_PRE;
+      }
+    }
     if (getenv("GRL_PLAN_DUMP"))
       fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu  tiles %d\n", tag.c_str(),
               variant, l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size(), l->n_tiles);
@@ -941,7 +989,7 @@ struct grl_ctx {
       if (l->v2) {
         const int key = l->variant * 10000 + l->pm * 1000 + l->qm * 100 + l->cfg * 10 + l->flags;
 #define GRL_I2(PLv, QLv, PMv, QMv, CF, FL) \
-  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, l->dyn_lds, s, l->d_probs, l->d_tiles)
+  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, l->dyn_lds, s, l->d_probs, l->d_tiles, (const int*)l->d_pre)
 #define GRL_I2_CFGS(base, PLv, QLv, PMv, QMv, FL)                           \
   case base + 0 + FL: GRL_I2(PLv, QLv, PMv, QMv, 0, FL); break;              \
   case base + 10 + FL: GRL_I2(PLv, QLv, PMv, QMv, 1, FL); break;             \
@@ -955,6 +1003,10 @@ struct grl_ctx {
           GRL_I2_CFGS(10000, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0)        // dense backward-data
           GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data, masked taps
           GRL_I2_CFGS(11100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0)          // conv backward-data, exact taps
+          GRL_I2_CFGS(1000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, I2F_PRE)    // ... the same with per-tile preambles
+          GRL_I2_CFGS(11100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, I2F_PRE)
+          case 21005: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES | I2F_PRE); break;
+          case 21015: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 1, I2F_ONES | I2F_PRE); break;
           GRL_I2_CFGS(10100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 0)         // dense backward-data over several kernels
           case 20000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, 0); break;         // dense weight gradient
           case 20001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, I2F_ONES); break;  //   ... with bias row
@@ -1213,6 +1265,7 @@ struct grl_ctx {
   // bins beforehand.  Same tiles, same arithmetic; GRL_NO_LPT_ORDER=1 keeps the list order (measurement switch).
   int lpt_extra_tiles = 0;
   double lpt_extra_w = 0;
+  bool suppress_pre = false;
   static std::vector<int4> lpt_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt,
                                      int extra_tiles, double extra_w, const std::string& tag) {
     const int n = (int)tiles.size();
@@ -3373,6 +3426,7 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
     if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
   }
   h->uploads.clear();
+  h->htab.clear();
   for (auto& z : h->zero_once) hipMemset(z.first, 0, z.second);
   // state: zero Adam moments, scalars; stats = identity
   hipMemset(h->adam_m, 0, (size_t)h->n_train * 4);

@@ -29,7 +29,7 @@ namespace grl {
 
 enum { I2_P_ALONG_R = 0, I2_P_ALONG_I = 1 };
 enum { I2_Q_ALONG_R = 0, I2_Q_ALONG_J = 1 };
-enum { I2F_ONES = 1, I2F_KTAIL = 2 };
+enum { I2F_ONES = 1, I2F_KTAIL = 2, I2F_PRE = 4 };
 
 template <int CFG> struct I2Cfg;
 template <> struct I2Cfg<0> { static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, WK = 1, FM = 1, FN = 1; };
@@ -39,6 +39,12 @@ template <> struct I2Cfg<3> { static constexpr int BM = 32, BN = 64, WM = 1, WN 
 
 static inline int i2_bm(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 128 : 32); }   // cfg 2, 3: 32
 static inline int i2_bn(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 32 : 64); }
+
+// preamble of one tile, in ints: [BM row terms | 3*BKT P column terms | 3*BKT Q row terms | BM output offsets]
+template <int CFG> struct I2Pre {
+  static constexpr int BM = I2Cfg<CFG>::BM, BKT = 32 * I2Cfg<CFG>::WK;
+  static constexpr int ROW = 0, PK = BM, QK = BM + 3 * BKT, CT = BM + 6 * BKT, STRIDE = 2 * BM + 6 * BKT;
+};
 
 #ifdef GRL_HOSTEMU
 #include "igemm2_ref1.h"   // tests/hostemu: the emulation build only
@@ -65,6 +71,12 @@ __device__ __forceinline__ f32x4 i2_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) 
 
 // FLAGS: I2F_ONES  -- the problems carry a bias-gradient ones row (p_ones_i == M-1), Q along j, WK == 1
 //        I2F_KTAIL -- K % 4 != 0 (affine operands along r): elements past r_end are zeroed one by one
+//        I2F_PRE   -- table-addressed launches (no masks): the table entries a tile needs BEFORE its first operand load --
+//                     its BM row terms, the column / row terms of its first three reduction slabs, its BM output offsets --
+//                     come from a per-tile PREAMBLE indexed by blockIdx (a kernel argument), i.e. they are requested at
+//                     kernel start together with the descriptor instead of after it: one dependent memory round trip
+//                     less in front of the first MFMA (start -> first barrier of the backward-data launches was 3.3-4.1 us
+//                     with three round trips, profiles/r03_tile_schedule_sac_depth.txt).  Same values, same arithmetic.
 // LDS floats one tile of an instantiation needs
 template <int PL, int QL, int CFG>
 struct I2Lds {
@@ -100,10 +112,14 @@ __device__ __forceinline__ void i2_trace_record(const IgemmProb* pb, const int4 
 // one tile; `lds` is the workgroup's staging area (I2Lds<...>::value floats, 16-byte aligned).  A function, not the
 // kernel, so that one launch can carry tiles of two instantiations (igemm2_pair_kernel).
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, const int4 tl, float* __restrict__ lds) {
+__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, const int4 tl, float* __restrict__ lds,
+                                            const int* __restrict__ pre_ = nullptr) {
   using C = I2Cfg<CFG>;
   constexpr int BM = C::BM, BN = C::BN, WK = C::WK, FM = C::FM, FN = C::FN, WN = C::WN, WM = C::WM;
   constexpr bool ONES = (FLAGS & I2F_ONES) != 0, KTAIL = (FLAGS & I2F_KTAIL) != 0;
+  constexpr bool PRE = (FLAGS & I2F_PRE) != 0;
+  static_assert(!PRE || PM == PM_TABLE, "the preamble serves table-addressed, unmasked P operands");
+  const gci32 pre = (gci32)pre_;
   constexpr int BKT = 32 * WK;                 // reduction depth staged per barrier
   // Row strides of the two layouts of an operand.  K-contiguous rows (operand along r) are NOT padded: the 16-byte
   // chunks of a row are XOR-swizzled with row bits instead (i2_swz), which keeps the four ds_read_b128 per slab
@@ -169,14 +185,14 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
       const int i = i0 + p_l + e * PSTEP;
       p_fok[e] = i < M;
       const int ic = p_fok[e] ? i : i0;
-      p_fix[e] = PM != PM_AFFINE ? pTi[ic] : ic * pLi;
+      p_fix[e] = PRE ? pre[I2Pre<CFG>::ROW + p_l + e * PSTEP] : (PM != PM_AFFINE ? pTi[ic] : ic * pLi);
       p_vm[e] = PM == PM_TABLE_MASK ? pVm[ic] : ~0ull;
     }
   } else {
     const int i = i0 + 4 * p_q;
     p_fok[0] = i < M;
     const int ic = p_fok[0] ? i : i0;
-    p_fix[0] = PM != PM_AFFINE ? pTi[ic] : ic;
+    p_fix[0] = PRE ? pre[I2Pre<CFG>::ROW + 4 * p_q] : (PM != PM_AFFINE ? pTi[ic] : ic);
     p_vm[0] = ~0ull;
   }
   constexpr int QNQ = QL == I2_Q_ALONG_R ? BKT / 4 : BN / 4;
@@ -224,6 +240,18 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
         const int r = QL == I2_Q_ALONG_R ? r0 + 4 * q_q : r0 + q_l + e * QSTEP;
         tb.q[e] = qTr[r < r_end ? r : r_begin];
       }
+    }
+  };
+  // the same entries for slab k = 0, 1, 2 of this tile's reduction chunk from the preamble (filled by the host with the
+  // clamping of fetch_tabs applied)
+  auto fetch_tabs_pre = [&](int k, Tabs& tb) {
+#pragma unroll
+    for (int e = 0; e < NTP; ++e)
+      tb.p[e] = pre[I2Pre<CFG>::PK + k * BKT + (PL == I2_P_ALONG_R ? 4 * p_q : p_l + e * PSTEP)];
+    if (QM == QM_TABLE) {
+#pragma unroll
+      for (int e = 0; e < NTQ; ++e)
+        tb.q[e] = pre[I2Pre<CFG>::QK + k * BKT + (QL == I2_Q_ALONG_R ? 4 * q_q : q_l + e * QSTEP)];
     }
   };
   Tabs tbA, tbB;
@@ -343,7 +371,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
 #pragma unroll
     for (int e = 0; e < EP_NQ; ++e) {
       const int i = i0 + t / EP_NC4 + e * EP_RSTEP;
-      ct_pre[e] = cT[i < M ? i : 0];
+      ct_pre[e] = PRE ? pre[I2Pre<CFG>::CT + t / EP_NC4 + e * EP_RSTEP] : cT[i < M ? i : 0];
     }
   }
   I2_STAMP(1);
@@ -354,9 +382,15 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
     unsigned p_kb0 = 0xfu, q_kb0 = 0xfu;
     Tabs tb0;
     tb0.tap = 0;
-    fetch_tabs(r_begin, tb0);
-    fetch_tabs(r_begin + BKT, tbA);
-    fetch_tabs(r_begin + 2 * BKT, tbB);
+    if (PRE) {
+      fetch_tabs_pre(0, tb0);
+      fetch_tabs_pre(1, tbA);
+      fetch_tabs_pre(2, tbB);
+    } else {
+      fetch_tabs(r_begin, tb0);
+      fetch_tabs(r_begin + BKT, tbA);
+      fetch_tabs(r_begin + 2 * BKT, tbB);
+    }
 #pragma unroll
     for (int e = 0; e < NVP; ++e) load_p(r_begin, e, pv0, p_kb0, tb0);
 #pragma unroll
@@ -672,14 +706,15 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
 
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
 __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
-                                                    const int4* __restrict__ tiles) {
+                                                    const int4* __restrict__ tiles, const int* __restrict__ pre) {
   __shared__ __attribute__((aligned(16))) float lds[I2Lds<PL, QL, CFG>::value];
 #ifdef GRL_TILE_TRACE
   const unsigned long long t0 = wall_clock64();
 #endif
   // `probs` holds one descriptor copy per workgroup (add_launch): the tile entry and the descriptor are fetched side
   // by side instead of one after the other -- one dependent memory round trip less before the first operand load
-  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds);
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds,
+                                          (FLAGS & I2F_PRE) ? pre + (size_t)blockIdx.x * I2Pre<CFG>::STRIDE : nullptr);
 #ifdef GRL_TILE_TRACE
   i2_trace_record(probs + blockIdx.x, tiles[blockIdx.x], t0, CFG);
 #endif
@@ -690,7 +725,8 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
 // already complete) that fills the SIMD time A's few tiles per CU leave idle and rides on A's launch ramp.
 template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
 __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __restrict__ pa, const int4* __restrict__ ta, int n_a,
-                                                         const IgemmProb* __restrict__ pb, const int4* __restrict__ tb) {
+                                                         const IgemmProb* __restrict__ pb, const int4* __restrict__ tb,
+                                                         const int* __restrict__ pre_a) {
   constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value;
   __shared__ __attribute__((aligned(16))) float lds[LA > LB ? LA : LB];
   const int b = (int)blockIdx.x;
@@ -699,7 +735,7 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
 #ifdef GRL_TILE_TRACE
   const unsigned long long t0 = wall_clock64();
 #endif
-  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], lds);
+  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], lds, (FLa & I2F_PRE) ? pre_a + (size_t)k * I2Pre<CFGa>::STRIDE : nullptr);
   else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + k, tb[k], lds);
 #ifdef GRL_TILE_TRACE
   i2_trace_record(is_a ? pa + k : pb + k, is_a ? ta[k] : tb[k], t0, is_a ? CFGa : CFGb);

@@ -156,9 +156,9 @@ int main(int argc, char** argv) {
         } else {
 #define RUN2(CF)                                                                                                            \
   if (cfg == CF) {                                                                                                          \
-    if (sh.variant == 0) hipLaunchKernelGGL((igemm2_kernel<I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, CF, 0>), grid, block, 0, 0, dprobs, dt); \
-    if (sh.variant == 1) hipLaunchKernelGGL((igemm2_kernel<I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, CF, 0>), grid, block, 0, 0, dprobs, dt); \
-    if (sh.variant == 2) hipLaunchKernelGGL((igemm2_kernel<I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, CF, 0>), grid, block, 0, 0, dprobs, dt); \
+    if (sh.variant == 0) hipLaunchKernelGGL((igemm2_kernel<I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, CF, 0>), grid, block, 0, 0, dprobs, dt, (const int*)nullptr); \
+    if (sh.variant == 1) hipLaunchKernelGGL((igemm2_kernel<I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, CF, 0>), grid, block, 0, 0, dprobs, dt, (const int*)nullptr); \
+    if (sh.variant == 2) hipLaunchKernelGGL((igemm2_kernel<I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, CF, 0>), grid, block, 0, 0, dprobs, dt, (const int*)nullptr); \
   }
           RUN2(0) RUN2(1) RUN2(2)
         }
