@@ -927,9 +927,12 @@ struct grl_ctx {
       if (const char* e = getenv("GRL_WG_DYNLDS")) l->dyn_lds = (unsigned)atoi(e);
     }
     l->n_tiles = (int)tiles.size();
-    {   // per-tile preambles (I2F_PRE): unmasked table addressing of the three convolution directions
-      const char* np = getenv("GRL_NO_PREAMBLE");
-      bool ok = l->v2 && !suppress_pre && !(np && atoi(np)) && l->pm == PM_TABLE &&
+    {   // per-tile preambles (I2F_PRE): unmasked table addressing of the three convolution directions.  Opt-in
+        // (GRL_PREAMBLE=1): measured neutral on MI355X at B = 256 (5 102 against 5 092 updates/s on one box) -- the 2 - 4 us
+        // between a workgroup's start and its first barrier are the operand loads of 400 - 800 workgroups arriving at
+        // once, not the table hop in front of them.  Kept as a tested switch (bit-identical results).
+      const char* np = getenv("GRL_PREAMBLE");
+      bool ok = l->v2 && !suppress_pre && (np && atoi(np)) && l->pm == PM_TABLE &&
                 ((variant == 0 && l->qm == QM_AFFINE && l->flags == 0) || (variant == 1 && l->qm == QM_TABLE && l->flags == 0) ||
                  (variant == 2 && l->qm == QM_AFFINE && l->flags == I2F_ONES && l->cfg <= 1));
       for (auto& p : l->probs)

@@ -75,8 +75,8 @@ __device__ __forceinline__ f32x4 i2_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) 
 //                     its BM row terms, the column / row terms of its first three reduction slabs, its BM output offsets --
 //                     come from a per-tile PREAMBLE indexed by blockIdx (a kernel argument), i.e. they are requested at
 //                     kernel start together with the descriptor instead of after it: one dependent memory round trip
-//                     less in front of the first MFMA (start -> first barrier of the backward-data launches was 3.3-4.1 us
-//                     with three round trips, profiles/r03_tile_schedule_sac_depth.txt).  Same values, same arithmetic.
+//                     less in front of the first MFMA.  Same values, same arithmetic.  MEASURED NEUTRAL (engine.hip,
+//                     add_launch): opt-in with GRL_PREAMBLE=1, covered by the bit-identity tests.
 // LDS floats one tile of an instantiation needs
 template <int PL, int QL, int CFG>
 struct I2Lds {

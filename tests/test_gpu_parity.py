@@ -133,7 +133,7 @@ def test_graph_replay_equals_eager(monkeypatch):
         assert np.array_equal(engs[0][n], engs[1][n]), n
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM", "GRL_FILLERS", "GRL_NO_VEC_REDUCE", "GRL_NO_CONV1_SIDE", "GRL_NO_XCD_ORDER", "GRL_NO_EXACT_TAP", "GRL_NO_LPT_ORDER", "GRL_NO_PREAMBLE"])
+@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM", "GRL_FILLERS", "GRL_NO_VEC_REDUCE", "GRL_NO_CONV1_SIDE", "GRL_NO_XCD_ORDER", "GRL_NO_EXACT_TAP", "GRL_NO_LPT_ORDER", "GRL_PREAMBLE"])
 def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
     """igemm_sk_kernel accumulates exactly like igemm2_kernel, and the launch-merging / Adam-fusion switches only
     regroup work (exact-tap backward-data drops runs of exact zeros; the preambles carry the same table entries):

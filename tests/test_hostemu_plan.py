@@ -165,3 +165,17 @@ def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
     Pa, Pb = a.get_parameters(), b.get_parameters()
     assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
     a.close(); b.close()
+
+
+def test_per_tile_preambles_carry_the_table_entries(hostemu_lib, monkeypatch):
+    """GRL_PREAMBLE=1: the convolution launches take their rows' and first slabs' table entries from per-tile preambles
+    built on the host; the emulation kernels read them where the device kernels do -- same results as the table path."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=5, n_replay=20, n_steps=2)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GRL_PREAMBLE", flag)
+        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+        eng.train(2, case["idx"], case["eps"])
+        outs.append(eng.get_parameters())
+        eng.close()
+    assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
