@@ -1,0 +1,737 @@
+// capi.inl: the C ABI of include/grl.h (extern "C" entry points over grl_ctx) -- part of engine.hip (included there, same translation unit: the plans are methods of grl_ctx).
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+static int check_cfg(const grl_config* c) {
+  if (!c) return fail(GRL_ERR_INVALID, "null config");
+  if (c->algo == GRL_ALGO_AE) {
+    if (c->batch_size < 1 || c->batch_size > 4096) return fail(GRL_ERR_INVALID, "batch_size out of range");
+    if (c->replay_capacity < 1) return fail(GRL_ERR_INVALID, "replay_capacity must be >= 1");
+    return GRL_OK;
+  }
+  if (c->extractor < 0 || c->extractor > 2) return fail(GRL_ERR_INVALID, "extractor must be 0..2");
+  if (c->n_layers < 1 || c->n_layers > GRL_MAX_LAYERS) return fail(GRL_ERR_INVALID, "n_layers out of range");
+  for (int l = 0; l < c->n_layers; ++l)
+    if (c->layers[l] < 1 || c->layers[l] > 4096) return fail(GRL_ERR_INVALID, "layer width out of range");
+  if (c->batch_size < 1 || c->batch_size > 65536) return fail(GRL_ERR_INVALID, "batch_size out of range");
+  if (c->act_dim < 1 || c->act_dim > 64) return fail(GRL_ERR_INVALID, "act_dim out of range");
+  if (c->replay_capacity < 1) return fail(GRL_ERR_INVALID, "replay_capacity must be >= 1");
+  if (c->algo < 0 || c->algo > 3) return fail(GRL_ERR_INVALID, "algo must be 0..3");
+  if (c->algo != GRL_ALGO_SAC) {
+    if (c->extractor != GRL_EXTRACTOR_MLP) return fail(GRL_ERR_INVALID, "DQN/BDQ run on vector observations (MLP extractor)");
+    if (c->q_branches < 1 || c->q_branches > 16 || c->q_branches != c->act_dim)
+      return fail(GRL_ERR_INVALID, "q_branches must be 1..16 and equal act_dim");
+    if (c->q_bins < 2 || c->q_bins > 1024) return fail(GRL_ERR_INVALID, "q_bins out of range");
+    if (c->q_n_common < 0 || c->q_n_common > GRL_MAX_LAYERS || c->q_n_branch < 1 || c->q_n_branch > GRL_MAX_LAYERS ||
+        c->q_n_value < 1 || c->q_n_value > GRL_MAX_LAYERS)
+      return fail(GRL_ERR_INVALID, "tower depths out of range (branch and value towers need >= 1 hidden layer)");
+    if (c->q_per && c->batch_size > 1024) return fail(GRL_ERR_INVALID, "prioritised replay supports batch_size <= 1024");
+    if (c->q_per && c->replay_capacity > (int64_t)PER_BLK * PER_BLK)
+      return fail(GRL_ERR_INVALID, "prioritised replay supports up to 1024 x 1024 transitions (two-level segment tree)");
+  }
+  if (c->replay_rgb_u8) {
+    const int c_img = c->obs_channels - ((c->extractor == GRL_EXTRACTOR_AUGMENTED && c->n_direct > 0) ? 1 : 0);
+    if (c->algo != GRL_ALGO_SAC || c->extractor == GRL_EXTRACTOR_MLP || c_img != 4)
+      return fail(GRL_ERR_INVALID, "replay_rgb_u8 needs SAC on RGB-D images with 4 image channels (R, G, B, depth)");
+  }
+  if (c->extractor == GRL_EXTRACTOR_MLP) {
+    if (c->obs_dim < 1) return fail(GRL_ERR_INVALID, "obs_dim must be >= 1 for the MLP extractor");
+  } else {
+    if (c->img_hw != 64) return fail(GRL_ERR_INVALID, "only 64x64 images (camera_info.yaml) are supported");
+    if (c->obs_channels < 1 || c->obs_channels > 8) return fail(GRL_ERR_INVALID, "obs_channels out of range");
+    if (c->extractor == GRL_EXTRACTOR_AUGMENTED && (c->n_direct < 0 || c->n_direct > 64))
+      return fail(GRL_ERR_INVALID, "n_direct out of range");
+    if (c->extractor == GRL_EXTRACTOR_AUGMENTED && c->n_direct > 0 && c->obs_channels < 2)
+      return fail(GRL_ERR_INVALID, "augmented extractor needs >= 2 observation channels");
+  }
+  return GRL_OK;
+}
+
+extern "C" {
+
+const char* grl_last_error(void) { return g_err.c_str(); }
+int grl_version(void) { return 1; }
+
+int grl_query_sizes(const grl_config* cfg, grl_sizes* out) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!out) return fail(GRL_ERR_INVALID, "null out");
+  grl_ctx ctx;
+  ctx.cfg = *cfg;
+  ctx.dry = true;
+  if (int e = ctx.plan()) return e;
+  out->state_bytes = ctx.st.off + 256;
+  out->grads_bytes = ctx.gr.off + 256;
+  out->work_bytes = ctx.wk.off + 256;
+  out->replay_bytes = ctx.rp.off + 256;
+  out->n_params = ctx.n_params;
+  out->n_trainable = ctx.n_train;
+  return GRL_OK;
+}
+
+int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) {
+  if (int e = check_cfg(cfg)) return e;
+  if (!bufs || !out || !bufs->state || !bufs->grads || !bufs->work || !bufs->replay)
+    return fail(GRL_ERR_INVALID, "null buffers");
+  grl_ctx* h = new grl_ctx();
+  h->cfg = *cfg;
+  h->st.base = (char*)bufs->state; h->gr.base = (char*)bufs->grads;
+  h->wk.base = (char*)bufs->work; h->rp.base = (char*)bufs->replay;
+  if (int e = h->plan()) { delete h; return e; }
+  const char* ng = getenv("GRL_NO_GRAPH");
+  h->use_graph = !(ng && ng[0] == '1');
+  for (auto& u : h->uploads) {
+    hipError_t e = hipMemcpy(u.dst, u.bytes.data(), u.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
+  }
+  h->uploads.clear();
+  h->htab.clear();
+  for (auto& z : h->zero_once) hipMemset(z.first, 0, z.second);
+  // state: zero Adam moments, scalars; stats = identity
+  hipMemset(h->adam_m, 0, (size_t)h->n_train * 4);
+  hipMemset(h->adam_v, 0, (size_t)h->n_train * 4);
+  hipMemset(h->grads, 0, (size_t)h->n_train * 4);
+  DevScalars s0;
+  memset(&s0, 0, sizeof(s0));
+  s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
+  s0.lr = cfg->lr;
+  hipError_t e = hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("scalar init: ") + hipGetErrorString(e)); }
+  if (h->n_mean) {   // RunningMeanStd(): mean 0, var 1, count 1e-4
+    std::vector<double> ones((size_t)h->n_elems, 1.0);
+    const double c2[2] = {1e-4, 1e-4};
+    hipMemset(h->n_mean, 0, (size_t)h->n_elems * 8);
+    hipMemcpy(h->n_var, ones.data(), ones.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(h->n_count, c2, 16, hipMemcpyHostToDevice);
+  }
+  if (h->per_on) {
+    hipMemset(h->per.p, 0, (size_t)cfg->replay_capacity * 8);
+    PerState ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.max_priority = 1.f; ps.p_min = 1.0; ps.beta = 1.0;
+    e = hipMemcpy(h->per.st, &ps, sizeof(ps), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("per init: ") + hipGetErrorString(e)); }
+  }
+  *out = h;
+  return GRL_OK;
+}
+
+int grl_destroy(grl_handle h) {
+  if (!h) return GRL_OK;
+  hipStreamSynchronize(h->stream);
+  delete h;
+  return GRL_OK;
+}
+
+int grl_set_stream(grl_handle h, void* s) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if ((hipStream_t)s != h->stream) h->drop_graphs();
+  h->stream = (hipStream_t)s;
+  return GRL_OK;
+}
+
+int grl_param_count(grl_handle h) { return h ? (int)h->vars.size() : fail(GRL_ERR_INVALID, "null handle"); }
+
+int grl_param_info(grl_handle h, int i, char* name, int cap, int64_t* off, int64_t* numel, int32_t* ndim,
+                   int64_t shape[4], int32_t* trainable) {
+  if (!h || i < 0 || i >= (int)h->vars.size()) return fail(GRL_ERR_INVALID, "bad parameter index");
+  const Var& v = h->vars[i];
+  if (name && cap > 0) { strncpy(name, v.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (off) *off = v.off;
+  if (numel) *numel = v.numel;
+  if (ndim) *ndim = v.ndim;
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = v.shape[k];
+  if (trainable) *trainable = v.trainable ? 1 : 0;
+  return GRL_OK;
+}
+
+int grl_reset_optimizer(grl_handle h) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  HIPCHK(hipMemsetAsync(h->adam_m, 0, (size_t)h->n_train * 4, h->stream));
+  HIPCHK(hipMemsetAsync(h->adam_v, 0, (size_t)h->n_train * 4, h->stream));
+  DevScalars s0;
+  HIPCHK(hipMemcpy(&s0, h->sc, sizeof(s0), hipMemcpyDeviceToHost));
+  s0.beta1_power = 0.9f; s0.beta2_power = 0.999f;
+  HIPCHK(hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice));
+  return GRL_OK;
+}
+
+int grl_set_learning_rate(grl_handle h, float lr) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (!(lr >= 0.f)) return fail(GRL_ERR_INVALID, "learning rate must be >= 0");
+  // the step size lives in device memory (the captured graphs read it), set in stream order
+  hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, h->stream, &h->sc->lr, lr);
+  return GRL_OK;
+}
+
+int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, double ret_var) {
+  if (!h || !mean || !var) return fail(GRL_ERR_INVALID, "null argument");
+  const grl_config& c = h->cfg;
+  const double eps = c.norm_eps;
+  const int nd = h->cnn ? h->F - 512 : 0;
+  // The five statistic blocks sit one after the other in the state arena (alignment gaps in between are unused):
+  // they are written into a page-locked mirror of that span and leave as ONE asynchronous copy in stream order.
+  // Two mirrors alternate, each guarded by an event, so the host never waits for the GPU here (the learn loop calls
+  // this before every update: a stream synchronisation plus five blocking copies serialised host and device).
+  char* base = (char*)h->s_mean;
+  const size_t span = h->n_mean ? (size_t)((char*)(h->n_var + h->n_elems) - base) : (size_t)((char*)h->s_ret + 8 - base);
+  if (!h->pin_stats[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipHostMalloc((void**)&h->pin_stats[k], span, 0));
+      memset(h->pin_stats[k], 0, span);
+      HIPCHK(hipEventCreateWithFlags(&h->pin_stats_ev[k], hipEventDisableTiming));
+    }
+  }
+  const int k = h->pin_stats_next;
+  h->pin_stats_next ^= 1;
+  if (h->pin_stats_used[k]) HIPCHK(hipEventSynchronize(h->pin_stats_ev[k]));   // the copy issued two calls ago
+  char* pm = h->pin_stats[k];
+  double* m = (double*)pm;
+  double* s = (double*)(pm + ((char*)h->s_std - base));
+  double* dm = (double*)(pm + ((char*)h->s_dmean - base));
+  double* ds = (double*)(pm + ((char*)h->s_dstd - base));
+  double* rs = (double*)(pm + ((char*)h->s_ret - base));
+  if (h->cnn) {
+    const int co = c.obs_channels, ci = h->C_img;
+    for (int px = 0; px < h->hw * h->hw; ++px)
+      for (int ch = 0; ch < ci; ++ch) {
+        m[px * ci + ch] = mean[px * co + ch];
+        s[px * ci + ch] = std::sqrt(var[px * co + ch] + eps);
+      }
+    for (int q = 0; q < nd; ++q) {
+      dm[q] = mean[q * co + (co - 1)];
+      ds[q] = std::sqrt(var[q * co + (co - 1)] + eps);
+    }
+  } else {
+    for (int q = 0; q < h->img_elems; ++q) { m[q] = mean[q]; s[q] = std::sqrt(var[q] + eps); }
+  }
+  *rs = std::sqrt(ret_var + eps);
+  if (h->n_mean) {   // the running statistics grl_norm_update continues from (env layout)
+    memcpy(pm + ((char*)h->n_mean - base), mean, (size_t)h->n_elems * 8);
+    memcpy(pm + ((char*)h->n_var - base), var, (size_t)h->n_elems * 8);
+  }
+  HIPCHK(hipMemcpyAsync(base, pm, span, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipEventRecord(h->pin_stats_ev[k], h->stream));
+  h->pin_stats_used[k] = true;
+  return GRL_OK;
+}
+
+int grl_set_ret_var(grl_handle h, double ret_var) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  const double sd = std::sqrt(ret_var + (double)h->cfg.norm_eps);
+  HIPCHK(hipMemcpyAsync(h->s_ret, &sd, 8, hipMemcpyHostToDevice, h->stream));   // (pageable source: staged before returning)
+  return GRL_OK;
+}
+
+int grl_set_obs_count(grl_handle h, double count) {
+  if (!h || !h->n_count) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  const double c2[2] = {count, count};
+  HIPCHK(hipMemcpyAsync(h->n_count, c2, 16, hipMemcpyHostToDevice, h->stream));
+  return GRL_OK;
+}
+
+int grl_norm_update(grl_handle h, const float* obs, int n) {
+  if (!h || !obs || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  if (n > h->stg_n) return fail(GRL_ERR_INVALID, "more observations than one env step of act_batch environments");
+  const grl_config& c = h->cfg;
+  HIPCHK(hipMemcpyAsync(h->n_stage, obs, (size_t)n * h->n_elems * 4, hipMemcpyHostToDevice, h->stream));
+  NormUpdateArgs a;
+  memset(&a, 0, sizeof(a));
+  a.obs = h->n_stage; a.n = n; a.elems = (int)h->n_elems;
+  a.mean = h->n_mean; a.var = h->n_var; a.count = h->n_count; a.parity = h->n_parity; a.eps = c.norm_eps;
+  a.hw = h->hw * h->hw; a.c_obs = c.obs_channels; a.c_img = h->C_img; a.n_direct = h->cnn ? h->F - 512 : 0; a.vec = h->cnn ? 0 : 1;
+  a.s_mean = h->s_mean; a.s_std = h->s_std; a.s_dmean = h->s_dmean; a.s_dstd = h->s_dstd;
+  hipLaunchKernelGGL(norm_update_kernel, dim3((unsigned)((h->n_elems + 255) / 256)), dim3(256), 0, h->stream, a);
+  h->n_parity ^= 1;
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_get_obs_stats(grl_handle h, double* mean, double* var, double* count) {
+  if (!h || !mean || !var || !count) return fail(GRL_ERR_INVALID, "null argument");
+  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(mean, h->n_mean, (size_t)h->n_elems * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(var, h->n_var, (size_t)h->n_elems * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(count, h->n_count + h->n_parity, 8, hipMemcpyDeviceToHost));
+  return GRL_OK;
+}
+
+static int replay_add_dev(grl_handle h, const float* obs, const float* act, const float* rew, const float* nxt,
+                          const float* done, int n) {
+  const grl_config& c = h->cfg;
+  IngestArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.obs = obs; ia.next_obs = nxt; ia.act = act; ia.rew = rew; ia.done = done;
+  ia.n = n; ia.hw = h->hw * h->hw; ia.c_obs = c.obs_channels; ia.c_img = h->C_img;
+  ia.n_direct = h->cnn ? h->F - 512 : 0; ia.act_dim = h->A; ia.vec_dim = h->cnn ? 0 : c.obs_dim;
+  ia.pos = h->rp_pos; ia.cap = c.replay_capacity;
+  ia.rp_obs = h->rp_obs; ia.rp_next = h->rp_next; ia.rp_dobs = h->rp_dobs; ia.rp_dnext = h->rp_dnext;
+  ia.rp_act = h->rp_act; ia.rp_rew = h->rp_rew; ia.rp_done = h->rp_done;
+  ia.rgb_u8 = (c.algo == GRL_ALGO_SAC) ? c.replay_rgb_u8 : 0;
+  const int elems = h->cnn ? (ia.rgb_u8 ? h->hw * h->hw : h->img_elems) : c.obs_dim;
+  hipLaunchKernelGGL(ingest_kernel, dim3((elems + 255) / 256, n, 2), dim3(256), 0, h->stream, ia);
+  if (h->per_on)   // new transitions enter with max_priority ** alpha
+    hipLaunchKernelGGL(per_add_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->per, h->rp_pos, n,
+                       (int64_t)c.replay_capacity);
+  h->rp_pos = (h->rp_pos + n) % c.replay_capacity;
+  h->rp_size = std::min<int64_t>(c.replay_capacity, h->rp_size + n);
+  HIPCHK(hipMemcpyAsync(&h->sc->replay_size, &h->rp_size, 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_replay_add_device(grl_handle h, const float* obs, const float* act, const float* rew,
+                          const float* next_obs, const float* done, int n) {
+  if (!h || !obs || !act || !rew || !next_obs || !done || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (n > h->cfg.replay_capacity) return fail(GRL_ERR_INVALID, "n exceeds replay capacity");
+  return replay_add_dev(h, obs, act, rew, next_obs, done, n);
+}
+
+// host buffer -> pinned staging -> device (and back): hipMemcpyAsync from pageable memory is a synchronous
+// staged copy; through page-locked buffers the per-call overhead is a host memcpy plus a true async DMA
+static int pin_reserve(grl_handle h, size_t in_floats, size_t out_floats) {
+  if (in_floats > h->pin_in_n) {
+    if (h->pin_in) hipHostFree(h->pin_in);
+    h->pin_in = nullptr; h->pin_in_n = 0;
+    HIPCHK(hipHostMalloc((void**)&h->pin_in, in_floats * 4, 0));
+    h->pin_in_n = in_floats;
+  }
+  if (out_floats > h->pin_out_n) {
+    if (h->pin_out) hipHostFree(h->pin_out);
+    h->pin_out = nullptr; h->pin_out_n = 0;
+    HIPCHK(hipHostMalloc((void**)&h->pin_out, out_floats * 4, 0));
+    h->pin_out_n = out_floats;
+  }
+  return GRL_OK;
+}
+
+int grl_replay_add(grl_handle h, const float* obs, const float* act, const float* rew, const float* next_obs,
+                   const float* done, int n) {
+  if (!h || !obs || !act || !rew || !next_obs || !done || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  const int64_t oe = h->cnn ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
+  // (pageable copies: for these sizes -- 64 KB per transition -- an extra host copy into pinned staging costs
+  // more than it saves: 77 -> 90 us for 16 transitions, 150 -> 214 us for 64; measured with scripts/act_bench.py)
+  for (int k0 = 0; k0 < n; k0 += h->stg_n) {
+    const int m = std::min(h->stg_n, n - k0);
+    HIPCHK(hipMemcpyAsync(h->stg_obs, obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_next, next_obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_act, act + (int64_t)k0 * h->A, (size_t)m * h->A * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_rew, rew + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stg_done, done + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    if (int e = replay_add_dev(h, h->stg_obs, h->stg_act, h->stg_rew, h->stg_next, h->stg_done, m)) return e;
+    HIPCHK(hipStreamSynchronize(h->stream));   // staging buffers are reused by the next chunk
+  }
+  return GRL_OK;
+}
+
+int64_t grl_replay_size(grl_handle h) { return h ? h->rp_size : -1; }
+
+static int stage_noise(grl_handle h, const int64_t* idx, const float* eps, int step) {
+  HIPCHK(hipMemcpyAsync(h->idx_buf, idx + (int64_t)step * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
+  const int64_t per = h->cfg.algo == GRL_ALGO_SAC ? (int64_t)h->B * h->A : (int64_t)h->B;   // Q: importance weights
+  HIPCHK(hipMemcpyAsync(h->eps_buf, eps + (int64_t)step * per, (size_t)per * 4, hipMemcpyDeviceToDevice, h->stream));
+  return GRL_OK;
+}
+
+int grl_compute_grads(grl_handle h, const int64_t* idx, const float* eps) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  if (idx) {
+    if (int e = stage_noise(h, idx, eps, 0)) return e;
+    if (int e = h->run_seq("grads_explicit", {&h->ops_gather, &h->ops_grads})) return e;
+  } else {
+    if (int e = h->run_seq("grads_rng", {&h->ops_rng, &h->ops_grads})) return e;
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const float* eps) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (stage != 0 && stage != 1) return fail(GRL_ERR_INVALID, "stage must be 0 or 1");
+  if (!h->staged_ok) {          // plans without a staged form: everything in stage 0, one bucket (grl_grad_ranges)
+    if (stage == 1) return GRL_OK;
+    return grl_compute_grads(h, idx, eps);
+  }
+  if (stage == 1) {
+    if (int e = h->run_seq("grads_stage1", {&h->ops_stage1})) return e;
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  if (idx) {
+    if (int e = stage_noise(h, idx, eps, 0)) return e;
+    if (int e = h->run_seq("grads_stage0_explicit", {&h->ops_gather, &h->ops_stage0})) return e;
+  } else {
+    if (int e = h->run_seq("grads_stage0_rng", {&h->ops_rng, &h->ops_stage0})) return e;
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_grad_ranges(grl_handle h, int bucket, int cap, int64_t* offsets, int64_t* numels) {
+  if (!h || !offsets || !numels) return fail(GRL_ERR_INVALID, "null argument");
+  if (bucket != 0 && bucket != 1) return fail(GRL_ERR_INVALID, "bucket must be 0 or 1");
+  std::vector<std::pair<int64_t, int64_t>> r;
+  if (!h->staged_ok) {
+    if (bucket == 0) r.push_back({0, h->n_train});
+  } else if (bucket == 0) {      // dense: fc + heads of the policy net, fc + vf / qf1 / qf2 heads of the value net
+    r.push_back({h->ex[0].fw, h->vf_off - h->ex[0].fw});
+    r.push_back({h->ex[1].fw, h->ent_off - h->ex[1].fw});
+  } else {                       // convolutions of both nets + the entropy coefficient (its gradient comes with the loss sums)
+    r.push_back({h->ex[0].w[0], h->ex[0].fw - h->ex[0].w[0]});
+    r.push_back({h->ex[1].w[0], h->ex[1].fw - h->ex[1].w[0]});
+    r.push_back({h->ent_off, h->n_train - h->ent_off});
+  }
+  if ((int)r.size() > cap) return fail(GRL_ERR_INVALID, "range buffer too small");
+  for (size_t k = 0; k < r.size(); ++k) { offsets[k] = r[k].first; numels[k] = r[k].second; }
+  return (int)r.size();
+}
+
+int grl_apply_grads(grl_handle h, float grad_scale) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (grad_scale != h->apply_graph_scale) {   // the scale is baked into the captured kernel arguments
+    auto it = h->graphs.find("apply");
+    if (it != h->graphs.end()) { (void)hipGraphExecDestroy(it->second); h->graphs.erase(it); }
+    h->apply_graph_scale = grad_scale;
+  }
+  h->grad_scale = grad_scale;
+  if (int e = h->run_seq("apply", {&h->ops_apply})) return e;
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* eps) {
+  if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (h->cfg.algo == GRL_ALGO_AE) return fail(GRL_ERR_STATE, "auto-encoder handles train with grl_ae_train_step");
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  h->grad_scale = 1.f;
+  if (!idx && n_steps >= 2 && h->prefetch_ok && !h->prof) {   // device RNG, several updates: prefetching sequences (plan_sac)
+    for (int s = 0; s < n_steps; ++s) {
+      const bool first = s == 0, last = s == n_steps - 1;
+      if (int e = h->run_seq(first ? "pf_first" : (last ? "pf_last" : "pf_mid"),
+                             {first ? &h->ops_pf_first : (last ? &h->ops_pf_last : &h->ops_pf_mid)}))
+        return e;
+    }
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    if (idx) {
+      if (int e = stage_noise(h, idx, eps, s)) return e;
+      if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads_apply})) return e;
+      } else if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
+    } else {
+      if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads_apply})) return e;
+      } else if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u) {
+  if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->per_on) return fail(GRL_ERR_STATE, "prioritised replay is not enabled (grl_config.q_per)");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  h->grad_scale = 1.f;
+  if (!(beta > 0.0)) return fail(GRL_ERR_INVALID, "beta must be positive (PrioritizedReplayBuffer.sample asserts beta > 0)");
+  if (h->rp_size < 2) return fail(GRL_ERR_STATE, "prioritised sampling needs at least two stored transitions (sum(0, len - 1))");
+  HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 8, hipMemcpyHostToDevice, h->stream));
+  for (int s = 0; s < n_steps; ++s) {
+    if (u) {
+      HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
+      if (!h->ops_grads_apply_per.empty()) {
+        if (int e = h->run_seq("per_u", {&h->ops_per_u_g, &h->ops_grads_apply_per})) return e;
+      } else if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update})) return e;
+      } else if (int e = h->run_seq("per_u", {&h->ops_per_u, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
+    } else {
+      if (!h->ops_grads_apply_per.empty()) {
+        if (int e = h->run_seq("per_rng", {&h->ops_per_rng_g, &h->ops_grads_apply_per})) return e;
+      } else if (!h->ops_grads_apply.empty()) {
+        if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update})) return e;
+      } else if (int e = h->run_seq("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update})) return e;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_ae_train_step(grl_handle h, const float* imgs, int n_steps) {
+  if (!h || !imgs || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (h->cfg.algo != GRL_ALGO_AE) return fail(GRL_ERR_STATE, "not an auto-encoder handle (grl_config.algo)");
+  const size_t per = (size_t)h->B * 4096;
+  for (int s = 0; s < n_steps; ++s) {
+    HIPCHK(hipMemcpyAsync(h->ae_x, imgs + per * s, per * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (int e = h->run_seq("ae_step", {&h->ops_ae})) return e;
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_ae_reconstruct(grl_handle h, const float* imgs, float* out) {
+  if (!h || !imgs || !out) return fail(GRL_ERR_INVALID, "null argument");
+  if (h->cfg.algo != GRL_ALGO_AE) return fail(GRL_ERR_STATE, "not an auto-encoder handle (grl_config.algo)");
+  const size_t per = (size_t)h->B * 4096;
+  HIPCHK(hipMemcpyAsync(h->ae_x, imgs, per * 4, hipMemcpyDeviceToDevice, h->stream));
+  if (int e = h->run_seq("ae_fwd", {&h->ops_ae_fwd})) return e;
+  HIPCHK(hipMemcpyAsync(out, h->ae_out, per * 4, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_get_metrics(grl_handle h, grl_metrics* out) {
+  if (!h || !out) return fail(GRL_ERR_INVALID, "null argument");
+  DevScalars s;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(&s, h->sc, sizeof(s), hipMemcpyDeviceToHost));
+  out->policy_loss = s.policy_loss; out->qf1_loss = s.qf1_loss; out->qf2_loss = s.qf2_loss;
+  out->value_loss = s.value_loss; out->ent_coef_loss = s.ent_loss; out->ent_coef = s.ent_coef;
+  out->entropy = s.entropy; out->mean_qf1 = s.mean_qf1; out->mean_v = s.mean_v;
+  return GRL_OK;
+}
+
+int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, float* out) {
+  if (!h || !obs || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  const int deterministic = flags & 1;
+  const bool raw = (flags & 2) != 0;      // raw observations: VecNormalize applied on the device (grl_norm_update statistics)
+  if (raw && h->ops_act_norm.empty()) return fail(GRL_ERR_STATE, "this handle has no normalising act path");
+  if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
+  const bool q = h->cfg.algo != GRL_ALGO_SAC;   // DQN / BDQ: Q-values [n, D*bins]
+  if (!q && !deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
+  const int64_t oe = (!q && h->cnn) ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
+  const size_t n_in = (size_t)n * oe, n_eps = (!q && !deterministic) ? (size_t)n * h->A : 0;
+  const size_t n_out = q ? (size_t)n * h->qD * h->qN : (size_t)n * h->A;
+  if (int e = pin_reserve(h, n_in + n_eps, n_out)) return e;
+  memcpy(h->pin_in, obs, n_in * 4);
+  if (n_eps) memcpy(h->pin_in + n_in, eps, n_eps * 4);
+  HIPCHK(hipMemcpyAsync(h->stg_obs, h->pin_in, n_in * 4, hipMemcpyHostToDevice, h->stream));
+  if (n_eps) HIPCHK(hipMemcpyAsync(h->a_eps, h->pin_in + n_in, n_eps * 4, hipMemcpyHostToDevice, h->stream));
+  if (q) {
+    if (int e = h->run_seq("act", {&h->ops_act})) return e;
+  } else {
+    // the launches cover act_batch rows whatever n is (rows beyond n hold stale observations: computed, not returned)
+    if (int e = h->run_seq(std::string(deterministic ? "act_det" : "act_sto") + (raw ? "_n" : ""),
+                           {raw ? &h->ops_act_norm : &h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
+      return e;
+  }
+  HIPCHK(hipMemcpyAsync(h->pin_out, q ? h->q_aout : h->a_out, n_out * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  memcpy(out, h->pin_out, n_out * 4);
+  return GRL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- data parallel, in-graph
+static size_t dp_layout(int64_t n, size_t* src_off, size_t* res_off) {
+  const size_t ctl = (size_t)rup((int64_t)sizeof(DpCtl), 256);
+  const size_t arr = (size_t)rup(n * 4, 256);
+  *src_off = ctl;
+  *res_off = ctl + arr;
+  return ctl + 2 * arr;
+}
+
+int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
+  if (!h || !handle_out) return fail(GRL_ERR_INVALID, "null argument");
+  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "the exchange step is defined for SAC handles");
+  if (world < 1 || world > DP_MAX_WORLD || rank < 0 || rank >= world) return fail(GRL_ERR_INVALID, "bad rank / world size");
+  if (h->dp_buf) return fail(GRL_ERR_STATE, "grl_allreduce_init was already called on this handle");
+  size_t so, ro;
+  const size_t bytes = dp_layout(h->n_train, &so, &ro);
+  // fine-grained: flag and data stores of a peer become visible to a kernel that is already running
+  hipError_t e = hipExtMallocWithFlags(&h->dp_buf, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) { h->dp_buf = nullptr; return fail(GRL_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e)); }
+  HIPCHK(hipMemset(h->dp_buf, 0, bytes));
+  hipIpcMemHandle_t mh;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "grl.h documents 64-byte handles");
+  e = hipIpcGetMemHandle(&mh, h->dp_buf);
+  if (e != hipSuccess) {
+    (void)hipFree(h->dp_buf); h->dp_buf = nullptr;
+    return fail(GRL_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+  }
+  memcpy(handle_out, &mh, 64);
+  memset(&h->dp, 0, sizeof(h->dp));
+  h->dp.rank = rank; h->dp.world = world; h->dp.n = h->n_train;
+  h->dp.chunk = rup((h->n_train + world - 1) / world, 4);
+  h->dp.grads = h->grads;
+  return GRL_OK;
+}
+
+int grl_allreduce_connect(grl_handle h, const void* handles) {
+  if (!h || !handles) return fail(GRL_ERR_INVALID, "null argument");
+  if (!h->dp_buf) return fail(GRL_ERR_STATE, "call grl_allreduce_init first");
+  if (h->dp_on) return fail(GRL_ERR_STATE, "already connected");
+  size_t so, ro;
+  dp_layout(h->n_train, &so, &ro);
+  DpArgs& d = h->dp;
+  for (int p = 0; p < d.world; ++p) {
+    char* base = (char*)h->dp_buf;
+    if (p != d.rank) {
+      hipIpcMemHandle_t mh;
+      memcpy(&mh, (const char*)handles + 64 * (size_t)p, 64);
+      void* ptr = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&ptr, mh, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return fail(GRL_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(p) + "): " + hipGetErrorString(e));
+      h->dp_peer[p] = ptr;
+      base = (char*)ptr;
+    }
+    d.ctl[p] = (DpCtl*)base;
+    d.src[p] = (float*)(base + so);
+    d.res[p] = (float*)(base + ro);
+  }
+  const DpArgs da = d;
+  grl_ctx* self = h;
+  {
+    Op op; op.tag = "dp_publish"; op.bytes = 8.0 * (double)d.n;
+    const int blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, (d.n / 4 + 255) / 256));
+    op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_publish_kernel, dim3(blocks), dim3(256), 0, s, da); };
+    h->ops_dp.push_back(op);
+  }
+  {
+    Op op; op.tag = "dp_reduce_push"; op.bytes = 8.0 * (double)d.chunk * d.world;
+    const int blocks = (int)std::min<int64_t>(256, std::max<int64_t>(1, (d.chunk / 4 + 255) / 256));
+    op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_reduce_push_kernel, dim3(blocks), dim3(256), 0, s, da); };
+    h->ops_dp.push_back(op);
+  }
+  {
+    Op op; op.tag = "dp_apply"; op.bytes = (double)h->n_train * 4 * 7 + (double)h->n_polyak * 4 * 2;
+    op.run = [self, da](hipStream_t s) {
+      AdamArgs aa;
+      memset(&aa, 0, sizeof(aa));
+      aa.params = self->params; aa.grads = da.res[da.rank]; aa.m = self->adam_m; aa.v = self->adam_v;
+      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f / (float)da.world; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
+      aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
+      const int blocks = (int)std::min<int64_t>(1024, (self->n_train + 255) / 256);
+      hipLaunchKernelGGL(dp_apply_kernel, dim3(blocks), dim3(256), 0, s, aa, da);
+    };
+    h->ops_dp.push_back(op);
+  }
+  h->dp_on = true;
+  return GRL_OK;
+}
+
+int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps) {
+  if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
+  if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
+  if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  for (int s = 0; s < n_steps; ++s) {
+    if (idx) {
+      if (int e = stage_noise(h, idx, eps, s)) return e;
+      if (int e = h->run_seq("dp_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_dp})) return e;
+    } else if (int e = h->run_seq("dp_rng", {&h->ops_rng, &h->ops_grads, &h->ops_dp})) return e;
+  }
+  HIPCHK(hipGetLastError());
+  return GRL_OK;
+}
+
+int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error) {
+  if (!h || !h->dp_buf) return fail(GRL_ERR_STATE, "no exchange buffer");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  DpCtl c;
+  HIPCHK(hipMemcpy(&c, h->dp_buf, sizeof(c), hipMemcpyDeviceToHost));
+  if (exchanges) *exchanges = c.epoch;
+  if (error) *error = (int)c.error;
+  if (c.error) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
+  return GRL_OK;
+}
+
+int grl_q_update_target(grl_handle h) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (h->cfg.algo == GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "SAC has no hard target update");
+  HIPCHK(hipMemcpyAsync(h->params + h->tgt_off, h->params + h->q_online_off, (size_t)h->q_online_n * 4,
+                        hipMemcpyDeviceToDevice, h->stream));
+  return GRL_OK;
+}
+
+int grl_encoder_load(grl_handle h, const float* const* w, const int64_t* numels, int n_arrays) {
+  if (!h || !w || !numels || n_arrays != 8) return fail(GRL_ERR_INVALID, "expected 8 weight arrays");
+  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "grl_encoder_load is for SAC handles (auto-encoder handles encode with their own parameters)");
+  const int64_t wn[8] = {7 * 7 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 32, 32, 2048 * 100, 100};
+  for (int k = 0; k < 8; ++k)
+    if (numels[k] != wn[k]) return fail(GRL_ERR_INVALID, "encoder weight " + std::to_string(k) + " has the wrong size");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 8; ++k) HIPCHK(hipMemcpy(h->enc_w[k], w[k], (size_t)wn[k] * 4, hipMemcpyHostToDevice));
+  h->enc_loaded = true;
+  return GRL_OK;
+}
+
+int grl_encode(grl_handle h, const float* depth, int n, float* out) {
+  if (!h || !depth || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->enc_loaded) return fail(GRL_ERR_STATE, "grl_encoder_load has not been called");
+  if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
+  if (int e = pin_reserve(h, (size_t)n * 4096, (size_t)n * 100)) return e;
+  memcpy(h->pin_in, depth, (size_t)n * 4096 * 4);
+  HIPCHK(hipMemcpyAsync(h->ex_in, h->pin_in, (size_t)n * 4096 * 4, hipMemcpyHostToDevice, h->stream));
+  if (int e = h->run_seq("encode", {&h->ops_enc})) return e;
+  HIPCHK(hipMemcpyAsync(h->pin_out, h->eout, (size_t)n * 100 * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  memcpy(out, h->pin_out, (size_t)n * 100 * 4);
+  return GRL_OK;
+}
+
+int64_t grl_debug_fetch(grl_handle h, const char* name, float* out, int64_t cap) {
+  if (!h || !name || !out) return fail(GRL_ERR_INVALID, "null argument");
+  auto it = h->dbg.find(name);
+  if (it == h->dbg.end()) return fail(GRL_ERR_INVALID, std::string("unknown tensor ") + name);
+  const int64_t n = std::min(cap, it->second.second);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(GRL_ERR_HIP, "sync failed");
+  hipError_t e = hipMemcpy(out, it->second.first, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(GRL_ERR_HIP, hipGetErrorString(e));
+  return n;
+}
+
+int64_t grl_debug_store(grl_handle h, const char* name, const float* in, int64_t n) {
+  if (!h || !name || !in) return fail(GRL_ERR_INVALID, "null argument");
+  auto it = h->dbg.find(name);
+  if (it == h->dbg.end()) return fail(GRL_ERR_INVALID, std::string("unknown tensor ") + name);
+  if (n > it->second.second) return fail(GRL_ERR_INVALID, std::string("too many values for ") + name);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(GRL_ERR_HIP, "sync failed");
+  hipError_t e = hipMemcpy(const_cast<float*>(it->second.first), in, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(GRL_ERR_HIP, hipGetErrorString(e));
+  return n;
+}
+
+int grl_profile_enable(grl_handle h, int on) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  h->prof = on != 0;
+  if (on) h->prof_acc.clear();
+  return GRL_OK;
+}
+
+int grl_profile_query(grl_handle h, const char* name, double* avg_ms, int64_t* launches) {
+  if (!h || !name) return fail(GRL_ERR_INVALID, "null argument");
+  auto it = h->prof_acc.find(name);
+  if (it == h->prof_acc.end()) return fail(GRL_ERR_INVALID, std::string("no profile for ") + name);
+  if (avg_ms) *avg_ms = it->second.n ? it->second.ms / it->second.n : 0.0;
+  if (launches) *launches = it->second.n;
+  return GRL_OK;
+}
+
+/* list profiled tags: writes "tag:avg_ms:launches:flops_per_launch:bytes_per_launch:executed_flops_per_launch\n" lines */
+int grl_profile_dump(grl_handle h, char* buf, int cap) {
+  if (!h || !buf || cap < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  std::string s;
+  for (auto& kv : h->prof_acc) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s:%.6f:%lld:%.0f:%.0f:%.0f\n", kv.first.c_str(),
+             kv.second.n ? kv.second.ms / kv.second.n : 0.0, (long long)kv.second.n,
+             kv.second.n ? kv.second.flops / kv.second.n : 0.0, kv.second.n ? kv.second.bytes / kv.second.n : 0.0,
+             kv.second.n ? kv.second.flops_exec / kv.second.n : 0.0);
+    s += line;
+  }
+  strncpy(buf, s.c_str(), cap - 1);
+  buf[cap - 1] = 0;
+  return GRL_OK;
+}
+
+}  // extern "C"

@@ -41,7 +41,7 @@ def hostemu_lib():
     src = os.path.join(PKG, "csrc", "engine.hip")
     csrc = os.path.join(PKG, "csrc")
     emu = os.path.join(ROOT, "tests", "hostemu")
-    deps = [os.path.join(d, f) for d in (csrc, emu) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))]
+    deps = [os.path.join(d, f) for d in (csrc, emu) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".inl"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DGRL_HOSTEMU", "-I", emu, "-x", "c++", src,
