@@ -118,6 +118,7 @@ struct Launch {
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
   int32_t* d_pre = nullptr;     // per-tile preambles (igemm2.h, I2F_PRE): the table entries a tile needs before its first load
+  std::vector<int4> h_tiles;    // host copy of the work list (chain_ops derives the tile dependencies from it)
   int n_tiles = 0;
   Launch* filler = nullptr;     // tiles of a second instantiation carried by the same launch (igemm2_pair_kernel)
   unsigned dyn_lds = 0;         // extra LDS bytes requested per workgroup: caps the workgroups a CU holds at once
@@ -131,6 +132,7 @@ struct Op {
   int lane = 0;
   bool fork = false, join = false;
   std::function<void(hipStream_t)> run;
+  Launch* launch = nullptr;   // the igemm2 launch behind a plain (single-instantiation) op: what chain_ops merges
   double flops = 0;   // algorithmic FLOPs of one launch (2 * M * N * K over the taps / rows that exist)
   double flops_exec = 0;   // FLOPs the launch's MFMAs execute (>= flops: masked taps of the parity-class backward-data form)
   double bytes = 0;   // algorithmic HBM bytes of one launch
@@ -987,6 +989,8 @@ struct grl_ctx {
     launches.push_back(l);
     Op op;
     op.tag = tag;
+    op.launch = l;
+    l->h_tiles = tiles;
     op.flops = flops_alg;
     op.flops_exec = flops;
     op.run = [l, tag](hipStream_t s) {
@@ -1310,6 +1314,145 @@ struct grl_ctx {
     }
     return out;
   }
+
+  // ---------------------------------------------------------------- dependent stages in one launch (igemm2_chain_kernel)
+  // Replaces runs of consecutive ops {tags[0], tags[1][, tags[2]]} of `list` by one op whose launch carries the tiles of
+  // all of them, later stages waiting per tile for the earlier tiles that write their operands.  Conditions: every op is a
+  // plain igemm2 launch of the 32x64 / 48 KB shape (three workgroups per CU), the total fits 3 x 256 workgroups -- i.e.
+  // the whole launch is resident at once -- and the instantiation triple is one the kernel is built for.  The
+  // dependencies come from the address ranges: a consumer tile reads rows [i0, i0 + 32) of its (affine, row-major) P
+  // operand; every producer tile whose output rows intersect that range must have finished.  Same tiles, same
+  // arithmetic: results are bit-identical to the separate launches.  A waiting tile cannot keep its producers from running
+  // whatever else shares the machine: workgroups are dispatched in index order, so every producer of a tile was dispatched
+  // before it.
+  // OPT-IN (GRL_CHAIN=1), MEASURED SLOWER on MI355X at B = 256: conv3_fwd+fc_fwd+heads_l0 72.1 us against 18.3 + 17.7 + 8.3,
+  // heads_dfeat+fc_bwd 30.3 against 8.3 + 12.8 (4168 against 5084 updates/s on one box).  The 8 XCDs have private L2s, so
+  // every hand-over is a device-scope release / acquire pair -- a write-back of the producer XCD's L2 and an invalidation
+  // of the consumer XCD's, 300+ times per launch -- and each invalidation throws away the dense-layer weights the other
+  // tiles of that XCD were sharing (with an acquire per POLL it was 198 us).  A launch boundary does the same flush once.
+  std::map<std::vector<Launch*>, Op> chain_cache;
+  bool chain_ops(std::vector<Op>& list, const std::vector<std::string>& tags) {
+    const char* nc = getenv("GRL_CHAIN");
+    if (!nc || !atoi(nc)) return false;
+    for (size_t k = 0; k + tags.size() <= list.size(); ++k) {
+      bool match = true;
+      for (size_t j = 0; j < tags.size(); ++j) match = match && list[k + j].tag == tags[j] && list[k + j].launch != nullptr;
+      if (!match) continue;
+      std::vector<Launch*> ls;
+      for (size_t j = 0; j < tags.size(); ++j) ls.push_back(list[k + j].launch);
+      auto it = chain_cache.find(ls);
+      if (it == chain_cache.end()) {
+        int total = 0, keys[3] = {-1, -1, -1};
+        bool ok = true;
+        for (size_t j = 0; j < ls.size(); ++j) {
+          Launch* l = ls[j];
+          ok = ok && l->v2 && !l->sk && !l->filler && l->cfg == 3 && (int)l->h_tiles.size() == l->n_tiles;
+          keys[j] = v2_key(l);
+          total += l->n_tiles;
+          if (j > 0)      // consumers: affine P along r (rows of a row-major tensor)
+            ok = ok && l->pm == PM_AFFINE && (l->variant == 0 || l->variant == 1);
+        }
+        const bool fwd3t = ls.size() == 3 && keys[0] == 1030 && keys[1] == 30 && keys[2] == 30 + I2F_KTAIL;
+        const bool fwd3 = fwd3t || (ls.size() == 3 && keys[0] == 1030 && keys[1] == 30 && keys[2] == 30);
+        const bool bwd2 = ls.size() == 2 && keys[0] == 10130 && keys[1] == 10030;
+        ok = ok && total <= 768 && (fwd3 || bwd2);
+        if (!ok) {
+          if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: %s ... not chained (keys %d %d %d, %d tiles)\n", tags[0].c_str(), keys[0], keys[1], keys[2], total);
+          return false;
+        }
+        // ---- counters: one per consumer row group (stage, operand tensor, first row); targets = intersecting producer tiles
+        struct Grp { int stage; const float* base; int i0; long lo, hi; int target; };
+        std::vector<Grp> grps;
+        std::vector<std::vector<int4>> dep(ls.size());
+        for (size_t j = 0; j < ls.size(); ++j) dep[j].assign(ls[j]->n_tiles, make_int4(-1, 0, -1, -1));
+        auto group_of = [&](int stage, const IgemmProb& p, int i0) {
+          for (size_t g = 0; g < grps.size(); ++g)
+            if (grps[g].stage == stage && grps[g].base == p.p_base[0] && grps[g].i0 == i0) return (int)g;
+          const int i1 = std::min(p.M, i0 + 32) - 1;
+          Grp g{stage, p.p_base[0], i0, (long)i0 * p.p_ld_i[0], (long)i1 * p.p_ld_i[0] + p.K, 0};
+          grps.push_back(g);
+          return (int)grps.size() - 1;
+        };
+        for (size_t j = 1; j < ls.size(); ++j)
+          for (int t = 0; t < ls[j]->n_tiles; ++t) {
+            const int4& tl = ls[j]->h_tiles[t];
+            dep[j][t].x = group_of((int)j, ls[j]->probs[tl.x], tl.z * 32);
+          }
+        for (size_t j = 0; j + 1 < ls.size(); ++j)
+          for (int t = 0; t < ls[j]->n_tiles; ++t) {
+            const int4& tl = ls[j]->h_tiles[t];
+            const IgemmProb& p = ls[j]->probs[tl.x];
+            if (p.c_tab_i || p.split != 1) { ok = false; break; }
+            const int r0 = tl.z * 32, r1 = std::min(p.M, r0 + 32) - 1, c0 = tl.w * 64, c1 = std::min(p.N, c0 + 64);
+            int n_sig = 0;
+            for (size_t g = 0; g < grps.size(); ++g) {
+              if (grps[g].stage != (int)j + 1) continue;
+              const long off = p.c - grps[g].base;                       // producer output relative to the consumer's operand
+              const long lo = off + (long)r0 * p.ldc + c0, hi = off + (long)r1 * p.ldc + c1;
+              if (hi <= grps[g].lo || lo >= grps[g].hi) continue;
+              grps[g].target += 1;
+              if (n_sig == 0) dep[j][t].z = (int)g;
+              else if (n_sig == 1) dep[j][t].w = (int)g;
+              else ok = false;
+              ++n_sig;
+            }
+          }
+        for (auto& g : grps) ok = ok && g.target > 0;
+        if (!ok) return false;
+        for (size_t j = 1; j < ls.size(); ++j)
+          for (auto& d : dep[j]) d.y = grps[d.x].target;
+        ChainArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        for (size_t j = 0; j < ls.size(); ++j) {
+          ca.p[j] = ls[j]->d_probs; ca.t[j] = ls[j]->d_tiles; ca.n[j] = ls[j]->n_tiles;
+          ca.dep[j] = upload_vec(wk, dep[j]);
+        }
+        ca.n_cnt = (int)grps.size();
+        ca.cnt = (int*)wk.take((size_t)(ca.n_cnt + 2) * 4);
+        zero_once.push_back({ca.cnt, (size_t)(ca.n_cnt + 2) * 4});
+        chain_err.push_back(ca.cnt + ca.n_cnt + 1);
+        Op op;
+        op.tag = tags[0];
+        for (size_t j = 1; j < tags.size(); ++j) op.tag += "+" + tags[j];
+        for (size_t j = 0; j < tags.size(); ++j) { op.flops += list[k + j].flops; op.flops_exec += list[k + j].flops_exec; }
+        const int n_all = total;
+        op.run = [ca, n_all, fwd3, fwd3t](hipStream_t s) {
+          if (fwd3 && !fwd3t)
+            hipLaunchKernelGGL((igemm2_chain_kernel<I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 3, 0,
+                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, 0,
+                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, 0>),
+                               dim3(n_all), dim3(256), 0, s, ca);
+          else if (fwd3)
+            hipLaunchKernelGGL((igemm2_chain_kernel<I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 3, 0,
+                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, 0,
+                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, I2F_KTAIL>),
+                               dim3(n_all), dim3(256), 0, s, ca);
+          else
+            hipLaunchKernelGGL((igemm2_chain_kernel<I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 3, 0,
+                                                     I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3, 0,
+                                                     I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3, 0>),
+                               dim3(n_all), dim3(256), 0, s, ca);
+        };
+        if (getenv("GRL_PLAN_DUMP"))
+        {
+          fprintf(stderr, "grl plan: %-14s one launch of %d dependent tiles (%zu stages, %zu row-group counters; producers per group:", op.tag.c_str(),
+                  n_all, ls.size(), grps.size());
+          for (size_t j = 1; j < ls.size(); ++j) {
+            int lo = 1 << 30, hi = 0;
+            for (auto& g : grps) if (g.stage == (int)j) { lo = std::min(lo, g.target); hi = std::max(hi, g.target); }
+            fprintf(stderr, " stage %zu %d..%d", j, lo, hi);
+          }
+          fprintf(stderr, ")\n");
+        }
+        it = chain_cache.emplace(ls, op).first;
+      }
+      list.erase(list.begin() + k, list.begin() + k + tags.size());
+      list.insert(list.begin() + k, it->second);
+      return true;
+    }
+    return false;
+  }
+  std::vector<int*> chain_err;     // error flags of the chained launches (a bounded wait ran out): checked by grl_get_metrics
 
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
   // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors

@@ -744,4 +744,90 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
 
 #endif  // GRL_HOSTEMU
 
+// Up to three DEPENDENT stages in one launch (engine.hip, chain_ops): blocks [0, n0) run stage 0, the next n1 stage 1,
+// the next n2 stage 2 -- each stage its own instantiation -- and a tile of stage s + 1 waits, before it touches its operands,
+// until the stage-s tiles that write them have finished (a counter per consumer row group: every producer tile adds 1 behind
+// a device-scope fence, the consumer's thread 0 polls with an acquire load).  ALL workgroups of the launch are resident at
+// once (the host only chains launches whose tiles fit: <= 3 x 256 workgroups of the 48 KB shape), so a waiting tile can never
+// keep its producers from running; the wait is bounded all the same (a time-out raises cnt[n_cnt + 1], read by the host).
+// What it was meant to buy over three launches: no boundary and no drained machine between the stages -- a consumer starts
+// the moment ITS producers are done.  What it costs on a chip of 8 XCDs with private L2s: every hand-over is a device-scope
+// release / acquire, i.e. an L2 write-back on the producer's XCD and an L2 invalidation on the consumer's, and the
+// invalidations evict the operands the neighbouring tiles share.  Measured slower than the launches it replaces (engine.hip,
+// chain_ops, has the numbers): OPT-IN, GRL_CHAIN=1.  The last workgroup to finish
+// zeroes the counters for the next launch (graph replay).
+struct ChainArgs {
+  const IgemmProb* p[3];
+  const int4* t[3];
+  const int4* dep[3];     // per tile {counter to wait on (-1: none), its target, counter to signal (-1: none), second counter to signal}
+  int n[3];
+  int* cnt;               // [n_cnt] dependency counters, [n_cnt] finished workgroups, [n_cnt + 1] error flag
+  int n_cnt;
+};
+enum { CHAIN_SPIN_LIMIT = 1 << 21 };
+
+#ifdef GRL_HOSTEMU
+// TEST-ONLY sequential form: blocks run in index order, producers first, so every wait is already satisfied
+template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb,
+          int PLc, int QLc, int PMc, int QMc, int CFGc, int FLc>
+void igemm2_chain_kernel(ChainArgs a) {
+  const int b = (int)blockIdx.x;
+  const int kind = b < a.n[0] ? 0 : (b < a.n[0] + a.n[1] ? 1 : 2);
+  const int k = b - (kind == 0 ? 0 : (kind == 1 ? a.n[0] : a.n[0] + a.n[1]));
+  const int4 d = a.dep[kind][k];
+  if (d.x >= 0 && a.cnt[d.x] < d.y) abort();
+  if (kind == 0) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(a.p[0] + k, a.t[0][k]);
+  else if (kind == 1) igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(a.p[1] + k, a.t[1][k]);
+  else igemm2_tile<PLc, QLc, PMc, QMc, CFGc, FLc>(a.p[2] + k, a.t[2][k]);
+  if (threadIdx.x != 255) return;            // (the emulated "threads" of a block run one after the other: signal after the last)
+  if (d.z >= 0) a.cnt[d.z] += 1;
+  if (d.w >= 0) a.cnt[d.w] += 1;
+  if (++a.cnt[a.n_cnt] == (int)gridDim.x)
+    for (int i = 0; i <= a.n_cnt; ++i) a.cnt[i] = 0;
+}
+#else
+template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb,
+          int PLc, int QLc, int PMc, int QMc, int CFGc, int FLc>
+__global__ __launch_bounds__(256) void igemm2_chain_kernel(ChainArgs a) {
+  constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value, LC = I2Lds<PLc, QLc, CFGc>::value;
+  __shared__ __attribute__((aligned(16))) float lds[(LA > LB ? LA : LB) > LC ? (LA > LB ? LA : LB) : LC];
+  const int b = (int)blockIdx.x;
+  const int kind = b < a.n[0] ? 0 : (b < a.n[0] + a.n[1] ? 1 : 2);
+  const int k = b - (kind == 0 ? 0 : (kind == 1 ? a.n[0] : a.n[0] + a.n[1]));
+  const int4 d = a.dep[kind][k];
+#ifdef GRL_TILE_TRACE
+  const unsigned long long t0 = wall_clock64();
+#endif
+  if (d.x >= 0) {
+    if (threadIdx.x == 0) {
+      // poll RELAXED (an acquire per poll would invalidate this XCD's L2 under the producers still running on it -- measured:
+      // 4x the time of the separate launches), then ONE acquire fence once the count is there
+      int spins = 0;
+      while (__hip_atomic_load(a.cnt + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.y) {
+        if (++spins > CHAIN_SPIN_LIMIT) { a.cnt[a.n_cnt + 1] = 1; break; }
+        __builtin_amdgcn_s_sleep(16);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the L1 of this CU and the L2 of this XCD drop their stale lines)
+    }
+    __syncthreads();
+  }
+  if (kind == 0) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(a.p[0] + k, a.t[0][k], lds);
+  else if (kind == 1) igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(a.p[1] + k, a.t[1][k], lds);
+  else igemm2_tile<PLc, QLc, PMc, QMc, CFGc, FLc>(a.p[2] + k, a.t[2][k], lds);
+#ifdef GRL_TILE_TRACE
+  i2_trace_record(a.p[kind] + k, a.t[kind][k], t0, kind == 0 ? CFGa : (kind == 1 ? CFGb : CFGc));
+#endif
+  __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged by the L2 (the L1 writes through) ...
+  __syncthreads();                 // ... and of every wave of the tile;
+  if (threadIdx.x == 0) {
+    if (d.z >= 0 || d.w >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE write-back of this XCD's L2 makes them visible device-wide
+    if (d.z >= 0) __hip_atomic_fetch_add(a.cnt + d.z, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d.w >= 0) __hip_atomic_fetch_add(a.cnt + d.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int done = __hip_atomic_fetch_add(a.cnt + a.n_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1)
+      for (int i = 0; i <= a.n_cnt; ++i) a.cnt[i] = 0;      // every workgroup has passed its wait: ready for the next launch
+  }
+}
+#endif
+
 }  // namespace grl

@@ -813,6 +813,15 @@ int grl_ctx::plan_sac() {
     }
   }
 
+  // ---- dependent stages as one launch (igemm2_chain_kernel; opt-in GRL_CHAIN=1, measured slower -- engine.hip, chain_ops):
+  // conv3_fwd -> fc_fwd -> heads_l0 and heads_dfeat -> fc_bwd.  Applied to the lists of full updates (the staged
+  // data-parallel lists keep their launches).
+  for (std::vector<Op>* lst : {&ops_grads, &ops_grads_apply, &ops_pf_first, &ops_pf_mid, &ops_pf_last}) {
+    if (lst->empty()) continue;
+    chain_ops(*lst, {"conv3_fwd", "fc_fwd", "heads_l0"});
+    chain_ops(*lst, {"heads_dfeat", "fc_bwd"});
+  }
+
   // =============================================================== apply
   {
     Op op; op.tag = "adam_polyak";

@@ -133,7 +133,7 @@ def test_graph_replay_equals_eager(monkeypatch):
         assert np.array_equal(engs[0][n], engs[1][n]), n
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM", "GRL_FILLERS", "GRL_NO_VEC_REDUCE", "GRL_NO_CONV1_SIDE", "GRL_NO_XCD_ORDER", "GRL_NO_EXACT_TAP", "GRL_NO_LPT_ORDER", "GRL_PREAMBLE"])
+@pytest.mark.parametrize("var", ["GRL_NO_SK", "GRL_NO_WGRAD_MERGE", "GRL_NO_FUSED_ADAM", "GRL_FILLERS", "GRL_NO_VEC_REDUCE", "GRL_NO_CONV1_SIDE", "GRL_NO_XCD_ORDER", "GRL_NO_EXACT_TAP", "GRL_NO_LPT_ORDER", "GRL_PREAMBLE", "GRL_CHAIN"])
 def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
     """igemm_sk_kernel accumulates exactly like igemm2_kernel, and the launch-merging / Adam-fusion switches only
     regroup work (exact-tap backward-data drops runs of exact zeros; the preambles carry the same table entries):
@@ -145,6 +145,24 @@ def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
         monkeypatch.setenv(var, flag)
         eng = pu.engine_setup(case)
         eng.train(3, case["idx"], case["eps"])
+        outs.append(eng.get_parameters())
+        eng.close()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+
+
+def test_dependent_stage_launches_are_bit_identical_at_full_batch(monkeypatch):
+    """conv3_fwd -> fc_fwd -> heads_l0 and heads_dfeat -> fc_bwd as single launches whose tiles wait for their producers
+    (igemm2.h: igemm2_chain_kernel; 696 and 384 workgroups on all 8 XCDs at B = 256): 40 updates in 2-update calls
+    (graph replay, counters re-armed by the kernel) leave bit-identical parameters, and no wait timed out."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=600, n_steps=40)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GRL_CHAIN", flag)
+        eng = pu.engine_setup(case)
+        for s in range(0, 40, 2):
+            eng.train(2, case["idx"][s:s + 2], case["eps"][s:s + 2])
+        eng.metrics()          # raises if a bounded wait ran out
         outs.append(eng.get_parameters())
         eng.close()
     for n in outs[0]:
