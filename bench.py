@@ -15,6 +15,7 @@ scaling: BASELINE configs[4] is `--global-batch 1024` on 8 GPUs).
 Other workloads (`--workload`), each with its own roofline and CPU-oracle baseline:
   sac_rgbd    configs[3]: RGB-D 64x64x5, batch 256, replay with byte colours, + auto-encoder feature latency
   sac_nature  configs[0] on the GPU: default nature_cnn over both channels, A=3, batch 64, no VecNormalize
+  sac_depth_128  the shipped table-clearing SAC config with layers [128,128], batch 64
   sac_mlp     configs[0] as shipped (depth_observation False): sacMlp on 100-d auto-encoder features, A=3, batch 64
   bdq_per     configs[2]: BDQ 5 branches x 33 bins on 101-d observations, batch 64, prioritised replay over 1 M
   ae_train    auto-encoder training step, batch 128 (config/encoder.yaml)
@@ -47,6 +48,11 @@ WORKLOADS = {
                      metric="SAC grad-steps/sec (64x64 RGB-D, batch 256 per GPU)",
                      name="configs[3]: SAC on RGB-D 64x64x5 (SAC_full_rgbd/config.yaml), batch %d/GPU, A=5, layers [64,64], "
                           "VecNormalize, %d-transition replay with byte colours in HBM, device RNG"),
+    "sac_depth_128": dict(kind="depth", extractor="augmented", batch=64, act_dim=5, normalize=True, replay=100_000, layers=(128, 128),
+                          metric="SAC grad-steps/sec (64x64 depth, layers [128,128], batch 64)",
+                          name="trained_models/table_clearing/SAC_real_2m_buffer_128/config.yaml: SAC, depth 64x64x2, batch %d/GPU, A=5, "
+                               "layers [128,128] (heads_fused_kernel<128>: two column blocks per wave), VecNormalize, "
+                               "%d-transition replay in HBM, device RNG"),
     "sac_nature": dict(kind="depth", extractor="nature", batch=64, act_dim=3, normalize=False, replay=50_000,
                        metric="SAC grad-steps/sec (64x64 depth, nature_cnn, batch 64)",
                        name="configs[0]: simplified_object_picking.yaml --algo SAC with depth observations: default nature_cnn "
@@ -262,7 +268,7 @@ def cpu_baseline_sac(wl, seconds=12.0):
     if wl["extractor"] == "mlp":
         import numpy as np
         D = wl["obs_dim"]
-        spec = osac.SacSpec(extractor="mlp", obs_dim=D, act_dim=A, layers=[64, 64])
+        spec = osac.SacSpec(extractor="mlp", obs_dim=D, act_dim=A, layers=list(wl.get("layers", (64, 64))))
         orc = osac.SacOracle(spec, seed=0)
         tr = synthetic.make_vector_transitions(4096, np.full(D, 0.5), np.full(D, 0.09), A, 0)
         idx, eps = synthetic.make_noise(4000, B, A, 4096, 1)
@@ -280,9 +286,9 @@ def cpu_baseline_sac(wl, seconds=12.0):
     st = synthetic.load_obs_stats(wl["kind"])
     C = st["mean"].shape[-1]
     if wl["extractor"] == "augmented":
-        spec = osac.SacSpec(extractor="augmented", img_channels=C - 1, n_direct=1, act_dim=A, layers=[64, 64])
+        spec = osac.SacSpec(extractor="augmented", img_channels=C - 1, n_direct=1, act_dim=A, layers=list(wl.get("layers", (64, 64))))
     else:
-        spec = osac.SacSpec(extractor="nature", img_channels=C, n_direct=0, act_dim=A, layers=[64, 64])
+        spec = osac.SacSpec(extractor="nature", img_channels=C, n_direct=0, act_dim=A, layers=list(wl.get("layers", (64, 64))))
     orc = osac.SacOracle(spec, seed=0)
     n_tr = 1024 if wl["kind"] == "depth" else 512
     tr = synthetic.make_transitions(n_tr, wl["kind"], A, 0, st)
@@ -407,11 +413,11 @@ def run_sac(args, wl_name, world, rank, device):
     replay = args.replay or wl["replay"]
     C = 5 if wl["kind"] == "rgbd" else 2
     if wl["extractor"] == "mlp":
-        cfg = _capi.make_config("mlp", obs_dim=wl["obs_dim"], act_dim=wl["act_dim"], layers=(64, 64), batch_size=wl["batch"],
+        cfg = _capi.make_config("mlp", obs_dim=wl["obs_dim"], act_dim=wl["act_dim"], layers=wl.get("layers", (64, 64)), batch_size=wl["batch"],
                                 replay_capacity=replay, normalize=wl["normalize"], act_batch=16, seed=1234 + rank)
     else:
         cfg = _capi.make_config(wl["extractor"], obs_channels=C, n_direct=1 if wl["extractor"] == "augmented" else 0,
-                                act_dim=wl["act_dim"], layers=(64, 64), batch_size=wl["batch"], replay_capacity=replay,
+                                act_dim=wl["act_dim"], layers=wl.get("layers", (64, 64)), batch_size=wl["batch"], replay_capacity=replay,
                                 normalize=wl["normalize"], act_batch=16, seed=1234 + rank, replay_rgb_u8=wl.get("rgb_u8", False))
     eng = SacEngine(cfg, device=str(device))
     eng.set_parameters(init_parameters(eng.table, seed=0))       # identical on every rank
@@ -611,7 +617,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps updates; value = median block")
-    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_nature", "sac_mlp", "bdq_per", "ae_train"])
+    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_depth_128", "sac_nature", "sac_mlp", "bdq_per", "ae_train"])
     ap.add_argument("--global-batch", type=int, default=None, help="fix the GLOBAL batch (strong scaling); per-GPU batch = G / N")
     ap.add_argument("--replay", type=int, default=None)
     ap.add_argument("--learn-iters", type=int, default=200)

@@ -253,8 +253,12 @@ int grl_ctx::plan_sac() {
     fa.B = B; fa.A = A; fa.eps = eps_buf; fa.pi_a = pi_a; fa.logp = logp; fa.ent = ent;
     {
       const char* nm = getenv("GRL_NO_HEADS_MFMA");
-      heads_mfma = !(nm && nm[0] == '1') && 2 * A <= 64;      // heads_mfma.h: layer widths (and 2A) up to 64
-      for (int l = 0; l < L; ++l) heads_mfma = heads_mfma && hid[l] <= 64;
+      // heads_mfma.h: any layers up to 64 wide with 2A <= 64, and the shipped wide shape -- layers [128, 128], A <= 8,
+      // whole 16-row blocks (the general form at that width runs out of registers: those stay on heads_kernels.h)
+      heads_mfma = !(nm && nm[0] == '1') && 2 * A <= 64;
+      bool narrow = true;
+      for (int l = 0; l < L; ++l) narrow = narrow && hid[l] <= 64;
+      heads_mfma = heads_mfma && (narrow || (L == 2 && hid[0] == 128 && hid[1] == 128 && A <= 8 && B % HT_RB == 0));
     }
     if (heads_mfma) {
       // forward and backward of every head in one launch (heads_mfma.h); d_out / gradients as in the backward args below
@@ -284,12 +288,18 @@ int grl_ctx::plan_sac() {
       hb.sc = hc.sc = sc; hb.tick = hc.tick = 1; hb.rng_advance = 0; hc.rng_advance = 1;
       const HeadsFusedArgs* d_ha = upload_vec(wk, std::vector<HeadsFusedArgs>{ha, hb, hc});
       const int nblk = (B + HT_RB - 1) / HT_RB;
-      const bool fast = L == 2 && hid[0] == 64 && hid[1] == 64 && B % HT_RB == 0;   // the reference's layers [64, 64]
+      int wmax = 0;
+      for (int l = 0; l < L; ++l) wmax = std::max(wmax, hid[l]);
+      const bool wide = wmax > 64;            // two column blocks per wave (heads_mfma.h, W = 128)
+      // the reference's shapes: layers [64, 64] (gripper_grasp.yaml) and [128, 128] (SAC_real_2m_buffer_128/config.yaml)
+      // (the 128-wide fast form also splits its few-output stages over the waves: 2A <= 16)
+      const bool fast = L == 2 && hid[0] == hid[1] && (hid[0] == 64 || (hid[0] == 128 && A <= 8)) && B % HT_RB == 0;
       for (int v = 0; v < 3; ++v) {
         Op op; op.tag = "heads";
         const HeadsFusedArgs* dv = d_ha + v;
-        op.run = [dv, nblk, fast](hipStream_t s) {
-          if (fast) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, dv);
+        op.run = [dv, nblk, fast, wide](hipStream_t s) {
+          if (wide) hipLaunchKernelGGL((heads_fused_kernel<128, true>), dim3(nblk, 4), dim3(256), 0, s, dv);
+          else if (fast) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, dv);
           else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, dv);
         };
         if (v == 0) ops_grads.push_back(op);

@@ -26,6 +26,9 @@ CASES = {
     "depth_norm_obs_only": dict(extractor="augmented", kind="depth", B=8, n_replay=16, normalize="obs"),
     "mlp_norm_reward_only": dict(extractor="mlp", B=16, n_replay=32, normalize="reward"),
     "rgbd_u8_replay": dict(extractor="augmented", kind="rgbd", B=9, n_replay=20, rgb_u8=True),
+    "mlp_layers_128_64": dict(extractor="mlp", B=20, n_replay=64, layers=(128, 64), obs_dim=37),     # two column blocks per wave, ragged
+    "mlp_layers_96_72": dict(extractor="mlp", B=17, n_replay=64, layers=(96, 72), obs_dim=29, act_dim=7),
+    "depth_layers128_b64": dict(extractor="augmented", kind="depth", B=64, n_replay=200, layers=(128, 128)),   # SAC_real_2m_buffer_128/config.yaml
     "depth_augmented_b128": dict(extractor="augmented", kind="depth", B=128, n_replay=300),   # per-rank shape of configs[4]
 }
 
