@@ -366,11 +366,11 @@ def make_data_parallel(eng, kind, world, rank, device, init):
     import torch
     import torch.distributed as dist
     from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
-    if kind in ("auto", "ingraph"):
+    if kind in ("auto", "ingraph", "ingraph-overlap"):
         ok = torch.ones(1, device=device)
         dp = None
         try:
-            dp = DataParallelInGraph(eng)
+            dp = DataParallelInGraph(eng, overlap=(kind == "ingraph-overlap"))
             dp.train(3)
             dp.check()
             P = eng.get_parameters()
@@ -385,8 +385,9 @@ def make_data_parallel(eng, kind, world, rank, device, init):
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
         if float(ok) > 0:
-            return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph" % world
-        if kind == "ingraph":
+            return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph%s" % (
+                world, " (dense bucket on a side lane under the conv backward)" if dp.overlap else "")
+        if kind != "auto":
             raise SystemExit("--dp ingraph: the in-graph exchange could not be set up on every rank")
         eng.set_parameters(init)           # the aborted attempt may have left the replicas out of step
         eng.reset_optimizer()
@@ -624,7 +625,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-learn-loop", action="store_true")
-    ap.add_argument("--dp", default="auto", choices=["auto", "ingraph", "rccl", "rccl-overlap"],
+    ap.add_argument("--dp", default="auto", choices=["auto", "ingraph", "ingraph-overlap", "rccl", "rccl-overlap"],
                     help="exchange step for N > 1 (auto: in-graph IPC all-reduce when it verifies, else RCCL one bucket)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="validation aid: gloo lets the N-rank path run where RCCL cannot (ranks sharing one GPU)")

@@ -536,90 +536,176 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
 }
 
 // ---------------------------------------------------------------------------------------------- data parallel, in-graph
-static size_t dp_layout(int64_t n, size_t* src_off, size_t* res_off) {
-  const size_t ctl = (size_t)rup((int64_t)sizeof(DpCtl), 256);
-  const size_t arr = (size_t)rup(n * 4, 256);
-  *src_off = ctl;
-  *res_off = ctl + arr;
-  return ctl + 2 * arr;
-}
+// this rank's two exchange allocations: flags = [DP_CHANNELS x DpCtl] (fine-grained), data = [src | red] (bucket-shaped each)
+static size_t dp_ctl_stride() { return (size_t)rup((int64_t)sizeof(DpCtl), 256); }
+static size_t dp_arr_bytes(int64_t n) { return (size_t)rup(n * 4, 256); }
 
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
   if (!h || !handle_out) return fail(GRL_ERR_INVALID, "null argument");
   if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "the exchange step is defined for SAC handles");
   if (world < 1 || world > DP_MAX_WORLD || rank < 0 || rank >= world) return fail(GRL_ERR_INVALID, "bad rank / world size");
   if (h->dp_buf) return fail(GRL_ERR_STATE, "grl_allreduce_init was already called on this handle");
-  size_t so, ro;
-  const size_t bytes = dp_layout(h->n_train, &so, &ro);
-  // fine-grained: flag and data stores of a peer become visible to a kernel that is already running
-  hipError_t e = hipExtMallocWithFlags(&h->dp_buf, bytes, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) { h->dp_buf = nullptr; return fail(GRL_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e)); }
-  HIPCHK(hipMemset(h->dp_buf, 0, bytes));
-  hipIpcMemHandle_t mh;
-  static_assert(sizeof(hipIpcMemHandle_t) == 64, "grl.h documents 64-byte handles");
-  e = hipIpcGetMemHandle(&mh, h->dp_buf);
+  if (h->n_train % 4 || h->n_train * 4 >= (int64_t)1 << 31) return fail(GRL_ERR_STATE, "the gradient bucket is not a whole number of 16-byte groups below 2 GB");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64 && GRL_ALLREDUCE_HANDLE_BYTES == 128, "grl.h documents two 64-byte handles");
+  const size_t fbytes = DP_CHANNELS * dp_ctl_stride(), dbytes = 3 * dp_arr_bytes(h->n_train);   // src | red | gathered
+  // flags fine-grained: stores of a peer become visible to a kernel that is already running (and polling); the data
+  // ordinary device memory, ordered by the fences around the flags (csrc/dp_kernels.h)
+  hipError_t e = hipExtMallocWithFlags(&h->dp_flags, fbytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) { h->dp_flags = nullptr; return fail(GRL_ERR_HIP, std::string("exchange flags: ") + hipGetErrorString(e)); }
+  e = hipMalloc(&h->dp_buf, dbytes);
   if (e != hipSuccess) {
-    (void)hipFree(h->dp_buf); h->dp_buf = nullptr;
+    (void)hipFree(h->dp_flags); h->dp_flags = nullptr; h->dp_buf = nullptr;
+    return fail(GRL_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e));
+  }
+  HIPCHK(hipMemset(h->dp_flags, 0, fbytes));
+  HIPCHK(hipMemset(h->dp_buf, 0, dbytes));
+  HIPCHK(hipDeviceSynchronize());
+  hipIpcMemHandle_t mh[2];
+  e = hipIpcGetMemHandle(&mh[0], h->dp_flags);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&mh[1], h->dp_buf);
+  if (e != hipSuccess) {
+    (void)hipFree(h->dp_buf); (void)hipFree(h->dp_flags); h->dp_buf = h->dp_flags = nullptr;
     return fail(GRL_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
   }
-  memcpy(handle_out, &mh, 64);
+  memcpy(handle_out, mh, GRL_ALLREDUCE_HANDLE_BYTES);
   memset(&h->dp, 0, sizeof(h->dp));
-  h->dp.rank = rank; h->dp.world = world; h->dp.n = h->n_train;
-  h->dp.chunk = rup((h->n_train + world - 1) / world, 4);
-  h->dp.grads = h->grads;
+  h->dp.rank = rank; h->dp.world = world;
   return GRL_OK;
+}
+
+// arguments of one channel over the given pieces of the bucket
+static DpArgs dp_channel(grl_ctx* h, int channel, const std::vector<std::pair<int64_t, int64_t>>& pieces, char* const* flags,
+                         char* const* data) {
+  DpArgs d;
+  memset(&d, 0, sizeof(d));
+  d.rank = h->dp.rank; d.world = h->dp.world; d.grads = h->grads;
+  d.n_ranges = (int)pieces.size();
+  int64_t v = 0;
+  for (size_t k = 0; k < pieces.size(); ++k) { d.start[k] = pieces[k].first; d.vstart[k] = v; v += pieces[k].second; }
+  for (size_t k = pieces.size(); k <= DP_MAX_RANGES; ++k) d.vstart[k] = v;
+  d.n = v;
+  d.chunk = rup((v + d.world - 1) / d.world, 4);
+  for (int p = 0; p < d.world; ++p) {
+    d.ctl[p] = (DpCtl*)(flags[p] + (size_t)channel * dp_ctl_stride());
+    d.src[p] = (float*)data[p];
+    d.red[p] = (float*)(data[p] + dp_arr_bytes(h->n_train));
+  }
+  return d;
+}
+// grids of the three exchange kernels (GRL_DP_BLOCKS=publish,reduce,apply overrides: tuning aid)
+static int dp_blocks(int which, int64_t quads, int dflt) {
+  int v[3] = {0, 0, 0};
+  if (const char* e = getenv("GRL_DP_BLOCKS")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+  const int cap = v[which] > 0 ? v[which] : dflt;
+  return (int)std::min<int64_t>(cap, std::max<int64_t>(1, (quads + 255) / 256));
+}
+static Op dp_publish_op(const DpArgs& da) {
+  Op op; op.tag = "dp_publish"; op.bytes = 8.0 * (double)da.n;
+  const int blocks = dp_blocks(0, da.n / 4, 256);
+  op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_publish_kernel, dim3(blocks), dim3(256), 0, s, da); };
+  return op;
+}
+static Op dp_reduce_op(const DpArgs& da) {
+  Op op; op.tag = "dp_reduce"; op.bytes = 4.0 * (double)da.chunk * (da.world + 1);
+  const int blocks = dp_blocks(1, da.chunk / 4, 256);
+  op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_reduce_kernel, dim3(blocks), dim3(256), 0, s, da); };
+  return op;
+}
+static Op dp_gather_op(const DpArgs& da) {
+  Op op; op.tag = "dp_gather"; op.bytes = 8.0 * (double)da.n;
+  const int blocks = dp_blocks(0, da.n / 4, 256);
+  op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_gather_kernel, dim3(blocks), dim3(256), 0, s, da); };
+  return op;
+}
+static Op dp_apply_op(grl_ctx* self, const DpArgs& da, const DpArgs& db) {
+  Op op; op.tag = "dp_apply"; op.bytes = (double)self->n_train * 4 * 7 + (double)self->n_polyak * 4 * 2;
+  op.join = true;
+  op.run = [self, da, db](hipStream_t s) {
+    AdamArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.params = self->params; aa.grads = nullptr; aa.m = self->adam_m; aa.v = self->adam_v;
+    aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f / (float)da.world; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
+    aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
+    const int blocks = dp_blocks(2, self->n_train / 4, 512);
+    hipLaunchKernelGGL(dp_apply_kernel, dim3(blocks), dim3(256), 0, s, aa, da, db);
+  };
+  return op;
 }
 
 int grl_allreduce_connect(grl_handle h, const void* handles) {
   if (!h || !handles) return fail(GRL_ERR_INVALID, "null argument");
   if (!h->dp_buf) return fail(GRL_ERR_STATE, "call grl_allreduce_init first");
   if (h->dp_on) return fail(GRL_ERR_STATE, "already connected");
-  size_t so, ro;
-  dp_layout(h->n_train, &so, &ro);
-  DpArgs& d = h->dp;
-  for (int p = 0; p < d.world; ++p) {
-    char* base = (char*)h->dp_buf;
-    if (p != d.rank) {
-      hipIpcMemHandle_t mh;
-      memcpy(&mh, (const char*)handles + 64 * (size_t)p, 64);
-      void* ptr = nullptr;
-      hipError_t e = hipIpcOpenMemHandle(&ptr, mh, hipIpcMemLazyEnablePeerAccess);
-      if (e != hipSuccess) return fail(GRL_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(p) + "): " + hipGetErrorString(e));
-      h->dp_peer[p] = ptr;
-      base = (char*)ptr;
+  char* flags[DP_MAX_WORLD];
+  char* data[DP_MAX_WORLD];
+  for (int p = 0; p < h->dp.world; ++p) {
+    flags[p] = (char*)h->dp_flags;
+    data[p] = (char*)h->dp_buf;
+    if (p != h->dp.rank) {
+      hipIpcMemHandle_t mh[2];
+      memcpy(mh, (const char*)handles + (size_t)GRL_ALLREDUCE_HANDLE_BYTES * p, GRL_ALLREDUCE_HANDLE_BYTES);
+      void* ptr[2] = {nullptr, nullptr};
+      for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipIpcOpenMemHandle(&ptr[k], mh[k], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(GRL_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(p) + "): " + hipGetErrorString(e));
+        h->dp_peer[2 * p + k] = ptr[k];
+      }
+      flags[p] = (char*)ptr[0];
+      data[p] = (char*)ptr[1];
     }
-    d.ctl[p] = (DpCtl*)base;
-    d.src[p] = (float*)(base + so);
-    d.res[p] = (float*)(base + ro);
   }
-  const DpArgs da = d;
-  grl_ctx* self = h;
-  {
-    Op op; op.tag = "dp_publish"; op.bytes = 8.0 * (double)d.n;
-    const int blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, (d.n / 4 + 255) / 256));
-    op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_publish_kernel, dim3(blocks), dim3(256), 0, s, da); };
-    h->ops_dp.push_back(op);
-  }
-  {
-    Op op; op.tag = "dp_reduce_push"; op.bytes = 8.0 * (double)d.chunk * d.world;
-    const int blocks = (int)std::min<int64_t>(256, std::max<int64_t>(1, (d.chunk / 4 + 255) / 256));
-    op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_reduce_push_kernel, dim3(blocks), dim3(256), 0, s, da); };
-    h->ops_dp.push_back(op);
-  }
-  {
-    Op op; op.tag = "dp_apply"; op.bytes = (double)h->n_train * 4 * 7 + (double)h->n_polyak * 4 * 2;
-    op.run = [self, da](hipStream_t s) {
-      AdamArgs aa;
-      memset(&aa, 0, sizeof(aa));
-      aa.params = self->params; aa.grads = da.res[da.rank]; aa.m = self->adam_m; aa.v = self->adam_v;
-      aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f / (float)da.world; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
-      aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
-      const int blocks = (int)std::min<int64_t>(1024, (self->n_train + 255) / 256);
-      hipLaunchKernelGGL(dp_apply_kernel, dim3(blocks), dim3(256), 0, s, aa, da);
-    };
-    h->ops_dp.push_back(op);
+  DpArgs none;
+  memset(&none, 0, sizeof(none));
+  // ---- the plain update: one exchange of the whole bucket behind the gradient computation
+  h->dp = dp_channel(h, 0, {{0, h->n_train}}, flags, data);
+  h->ops_dp = {dp_publish_op(h->dp), dp_reduce_op(h->dp), dp_apply_op(h, h->dp, none)};
+  // ---- the overlapped update (grl_allreduce_set_overlap): the staged plan (grl_compute_grads_staged) with both exchanges in
+  // the graph.  After heads_dfeat a SIDE LANE forms the dense layers' weight gradients, reduces them and exchanges them on
+  // channel 0 -- 90 % of the bytes -- while the main lane runs the backward through the convolutions and their weight
+  // gradients; the small convolution bucket follows on channel 1; Adam waits for both.  Same tiles, same sums: parameters
+  // are bit-identical to the plain update's.
+  h->ops_dp_overlap.clear();
+  if (h->staged_ok) {
+    std::vector<std::pair<int64_t, int64_t>> dense, conv;
+    int64_t off[8], num[8];
+    for (int b = 0; b < 2; ++b) {
+      const int nr = grl_grad_ranges(h, b, 8, off, num);
+      if (nr < 0) return nr;
+      for (int k = 0; k < nr; ++k) (b == 0 ? dense : conv).push_back({off[k], num[k]});
+    }
+    bool ok = dense.size() <= DP_MAX_RANGES && conv.size() <= DP_MAX_RANGES;
+    for (auto& r : dense) ok = ok && r.first % 4 == 0 && r.second % 4 == 0;
+    for (auto& r : conv) ok = ok && r.first % 4 == 0 && r.second % 4 == 0;
+    int cut = -1;
+    for (size_t k = 0; k < h->ops_stage0.size(); ++k)
+      if (h->ops_stage0[k].tag == "heads_dfeat") cut = (int)k;
+    if (ok && cut >= 0) {
+      DpArgs d0 = dp_channel(h, 0, dense, flags, data);
+      const DpArgs d1 = dp_channel(h, 1, conv, flags, data);
+      d0.gathered = (float*)((char*)h->dp_buf + 2 * dp_arr_bytes(h->n_train));     // the side lane also pulls the dense sums
+      std::vector<Op>& L = h->ops_dp_overlap;
+      for (int k = 0; k <= cut; ++k) L.push_back(h->ops_stage0[k]);
+      bool first = true;
+      auto side = [&](Op o) { o.lane = 1; o.fork = first; o.join = false; first = false; L.push_back(o); };
+      for (size_t k = cut + 1; k < h->ops_stage0.size(); ++k) side(h->ops_stage0[k]);     // wgrad_dense, reduce_dense
+      side(dp_publish_op(d0));
+      side(dp_reduce_op(d0));
+      side(dp_gather_op(d0));
+      for (Op o : h->ops_stage1) { o.join = false; L.push_back(o); }
+      L.push_back(dp_publish_op(d1));
+      L.push_back(dp_reduce_op(d1));
+      L.push_back(dp_apply_op(h, d0, d1));       // (joins the side lane)
+    }
   }
   h->dp_on = true;
+  return GRL_OK;
+}
+
+int grl_allreduce_set_overlap(grl_handle h, int on) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
+  if (on && h->ops_dp_overlap.empty()) return fail(GRL_ERR_STATE, "this configuration has no staged plan: the exchange cannot be overlapped");
+  h->dp_overlap = on != 0;
   return GRL_OK;
 }
 
@@ -628,24 +714,29 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  std::vector<Op> none;
+  std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->ops_grads;
+  std::vector<Op>* tail = h->dp_overlap ? &none : &h->ops_dp;
   for (int s = 0; s < n_steps; ++s) {
     if (idx) {
       if (int e = stage_noise(h, idx, eps, s)) return e;
-      if (int e = h->run_seq("dp_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_dp})) return e;
-    } else if (int e = h->run_seq("dp_rng", {&h->ops_rng, &h->ops_grads, &h->ops_dp})) return e;
+      if (int e = h->run_seq(h->dp_overlap ? "dpo_explicit" : "dp_explicit", {&h->ops_gather, body, tail})) return e;
+    } else if (int e = h->run_seq(h->dp_overlap ? "dpo_rng" : "dp_rng", {&h->ops_rng, body, tail})) return e;
   }
   HIPCHK(hipGetLastError());
   return GRL_OK;
 }
 
 int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error) {
-  if (!h || !h->dp_buf) return fail(GRL_ERR_STATE, "no exchange buffer");
+  if (!h || !h->dp_flags) return fail(GRL_ERR_STATE, "no exchange buffer");
   HIPCHK(hipStreamSynchronize(h->stream));
-  DpCtl c;
-  HIPCHK(hipMemcpy(&c, h->dp_buf, sizeof(c), hipMemcpyDeviceToHost));
-  if (exchanges) *exchanges = c.epoch;
-  if (error) *error = (int)c.error;
-  if (c.error) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
+  DpCtl c[DP_CHANNELS];
+  for (int k = 0; k < DP_CHANNELS; ++k)
+    HIPCHK(hipMemcpy(&c[k], (char*)h->dp_flags + k * dp_ctl_stride(), sizeof(DpCtl), hipMemcpyDeviceToHost));
+  if (exchanges) *exchanges = c[0].epoch;          // (channel 0 takes part in every update, plain or overlapped)
+  const int err = (int)(c[0].error | c[1].error);
+  if (error) *error = err;
+  if (err) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
   return GRL_OK;
 }
 

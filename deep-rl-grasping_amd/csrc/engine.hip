@@ -258,9 +258,12 @@ struct grl_ctx {
   // data parallel without a host round trip per update (grl_allreduce_*, csrc/dp_kernels.h)
   DpArgs dp;
   bool dp_on = false;
-  void* dp_buf = nullptr;                // this rank's exchange buffer (the one device allocation the library makes)
-  void* dp_peer[DP_MAX_WORLD] = {nullptr};
+  void* dp_buf = nullptr;                // this rank's exchange data (src | red) and flags: the only device allocations the
+  void* dp_flags = nullptr;              // library makes itself (IPC export needs allocations of their own)
+  void* dp_peer[2 * DP_MAX_WORLD] = {nullptr};
   std::vector<Op> ops_dp;                // publish | reduce + push | Adam + Polyak on the exchanged bucket
+  std::vector<Op> ops_dp_overlap;        // the whole overlapped update: staged gradients, two exchanges (one on a side lane), Adam
+  bool dp_overlap = false;
 
   // graphs
   std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences, keyed by what they contain
@@ -283,9 +286,10 @@ struct grl_ctx {
       if (pin_stats[k]) hipHostFree(pin_stats[k]);
       if (pin_stats_ev[k]) hipEventDestroy(pin_stats_ev[k]);
     }
-    for (int p = 0; p < DP_MAX_WORLD; ++p)
+    for (int p = 0; p < 2 * DP_MAX_WORLD; ++p)
       if (dp_peer[p]) (void)hipIpcCloseMemHandle(dp_peer[p]);
     if (dp_buf) (void)hipFree(dp_buf);
+    if (dp_flags) (void)hipFree(dp_flags);
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
     for (auto e : lane_ev) hipEventDestroy(e);

@@ -177,16 +177,23 @@ class SacEngine:
         check(self.lib, self.lib.grl_set_obs_stats(self.h, mean.ctypes.data, var.ctypes.data, float(ret_var)))
 
     # ---- data parallel with the exchange inside the update graph (grl_allreduce_*, csrc/dp_kernels.h)
+    HANDLE_BYTES = 128          # include/grl.h: GRL_ALLREDUCE_HANDLE_BYTES (two 64-byte IPC handles: flags, data)
+
     def allreduce_init(self, rank, world):
-        """Allocates this rank's exchange buffer; returns its 64-byte IPC handle (bytes) for the out-of-band exchange."""
-        buf = C.create_string_buffer(64)
+        """Allocates this rank's exchange memory; returns its 128 bytes of IPC handles for the out-of-band exchange."""
+        buf = C.create_string_buffer(self.HANDLE_BYTES)
         check(self.lib, self.lib.grl_allreduce_init(self.h, int(rank), int(world), buf))
         return buf.raw
 
     def allreduce_connect(self, handles):
-        """handles: the 64-byte handles of all ranks, in rank order."""
+        """handles: the 128-byte handle blobs of all ranks, in rank order."""
         blob = b"".join(handles)
         check(self.lib, self.lib.grl_allreduce_connect(self.h, C.c_char_p(blob)))
+
+    def allreduce_set_overlap(self, on=True):
+        """Exchange the dense bucket on a side lane of the update's graph while the convolution backward runs
+        (include/grl.h: grl_allreduce_set_overlap).  Raises when the configuration has no staged plan."""
+        check(self.lib, self.lib.grl_allreduce_set_overlap(self.h, 1 if on else 0))
 
     def train_allreduce(self, n_steps=1, idx=None, eps=None):
         pi, pe, keep = self._noise(idx, eps, n_steps)

@@ -127,11 +127,11 @@ class DataParallelInGraph:
     """The exchange inside the library (include/grl.h: grl_allreduce_init / connect / grl_train_step_allreduce,
     csrc/dp_kernels.h): a two-shot all-reduce over IPC-mapped exchange buffers, captured in the update's hipGraph --
     one C call per update, no collective library, no Python between compute and apply.  ``torch.distributed`` (any
-    backend; gloo is enough) is used ONCE, to hand the 64-byte buffer handles around.  Needs
+    backend; gloo is enough) is used ONCE, to hand the 128-byte handle blobs around.  Needs
     HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment (dmabuf IPC).  Every replica receives bit-identical sums: each
     1/world chunk is added by its owner in rank order.  `train` raises if a peer did not arrive (bounded waits)."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, overlap=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.eng, self.group = engine, group
@@ -140,6 +140,9 @@ class DataParallelInGraph:
         handles = [None] * self.world
         dist.all_gather_object(handles, mine, group=group)
         engine.allreduce_connect(handles)
+        self.overlap = bool(overlap)
+        if self.overlap:                   # dense bucket exchanged on a side lane of the graph, under the conv backward
+            engine.allreduce_set_overlap(True)
         dist.barrier(group=group)          # every rank has mapped every buffer before the first exchange starts
 
     def broadcast_parameters(self, src=0):

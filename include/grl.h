@@ -210,21 +210,30 @@ int grl_apply_grads(grl_handle h, float grad_scale);
    in stage 0 and report one range covering the whole bucket. */
 int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const float* eps);
 /* The exchange step inside the library (csrc/dp_kernels.h): a two-shot all-reduce written for this
-   path -- reduce-scatter by the owner of each 1/world chunk in rank order, all-gather by push -- over exchange
-   buffers that every rank exports with hipIpcGetMemHandle and maps from its peers (xGMI between the GPUs of a node).
-     grl_allreduce_init     allocates this rank's exchange buffer (the only device memory the library allocates itself:
-                            IPC export needs an allocation of its own) and writes its 64-byte handle to handle_out;
-                            the host exchanges the handles of all ranks out of band (any transport: files, MPI,
-                            torch.distributed.all_gather_object);
-     grl_allreduce_connect  handles = world x 64 bytes in rank order; maps the peers' buffers;
+   path -- reduce-scatter by the owner of each 1/world chunk in rank order, all-gather by pull inside the Adam kernel --
+   over exchange buffers that every rank exports with hipIpcGetMemHandle and maps from its peers (xGMI between the GPUs of a node).
+     grl_allreduce_init     allocates this rank's exchange memory -- a few hundred bytes of fine-grained flags and an
+                            ordinary buffer of three bucket-sized arrays (the only device memory the library allocates
+                            itself: IPC export needs allocations of its own) -- and writes their two IPC handles,
+                            GRL_ALLREDUCE_HANDLE_BYTES = 128 bytes, to handle_out; the host exchanges the handles of all
+                            ranks out of band (any transport: files, MPI, torch.distributed.all_gather_object);
+     grl_allreduce_connect  handles = world x GRL_ALLREDUCE_HANDLE_BYTES in rank order; maps the peers' memory;
      grl_train_step_allreduce   n_steps data-parallel updates, each ONE graph: minibatch from this rank's replay shard,
                             gradients, exchange, Adam + Polyak with the mean gradient -- what grl_compute_grads ->
                             all-reduce -> grl_apply_grads(1 / world) does with a collective library in between.  Every
                             replica receives bit-identical sums.  All ranks must call it the same number of times;
      grl_allreduce_status   host: exchanges completed; error != 0 (and a negative return) if a bounded wait for a peer ran
-                            out -- the kernels never hang. */
+                            out -- the kernels never hang;
+     grl_allreduce_set_overlap   on = 1: grl_train_step_allreduce runs the staged plan (grl_compute_grads_staged) with BOTH
+                            exchanges in its graph -- bucket 0 (dense layers, ~90 % of the bytes) is reduced and exchanged on
+                            a side lane of the graph while the backward through the convolutions runs, bucket 1 follows,
+                            Adam waits for both (SURVEY.md 8e "overlapped with the backward").  Same sums, bit-identical
+                            parameters.  All ranks must choose alike.  GRL_ERR_STATE when the handle has no staged plan
+                            (vector observations); off by default. */
+#define GRL_ALLREDUCE_HANDLE_BYTES 128
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out);
 int grl_allreduce_connect(grl_handle h, const void* handles);
+int grl_allreduce_set_overlap(grl_handle h, int on);
 int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
 int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error);
 /* contiguous ranges (float offsets into the grads arena) of bucket 0 / 1; returns their number (<= cap) or < 0 */

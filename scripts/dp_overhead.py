@@ -16,7 +16,7 @@ cfg = _capi.make_config("augmented", obs_channels=2, n_direct=1, act_dim=5, laye
                         replay_capacity=20000, normalize=True, act_batch=16, seed=1)
 eng = SacEngine(cfg, device=str(dev))
 eng.set_parameters(init_parameters(eng.table, seed=0))
-st = bench.fill_replay_on_device(eng, 20000, 100, dev)
+st = bench.fill_replay_on_device(eng, 20000, 100, dev, "depth", 5)
 eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
 bucket = eng.be.as_torch(eng.grad_tensor())
 for name, fn in (("fused train_device(n)", lambda n: eng.train_device(n)),
@@ -29,3 +29,23 @@ for name, fn in (("fused train_device(n)", lambda n: eng.train_device(n)),
         dt = time.perf_counter() - t0
         t1 = time.perf_counter(); fn(500); host = time.perf_counter() - t1; eng.synchronize()
     print("%-40s %.1f us/update (host-side enqueue %.1f us/update)" % (name, 1e6 * dt / 500, 1e6 * host / 500))
+
+# the in-graph exchange with world = 1 (the rank exchanges with itself: every kernel of the N-rank update runs, nothing waits)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+eng.allreduce_connect([eng.allreduce_init(0, 1)])
+for name, ov in (("in-graph exchange, plain (world 1)", False), ("in-graph exchange, overlapped (world 1)", True)):
+    eng.allreduce_set_overlap(ov)
+    eng.train_allreduce(50); eng.synchronize()
+    t0 = time.perf_counter(); eng.train_allreduce(500); eng.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-40s %.1f us/update, %d exchanges, no time-out" % (name, 1e6 * dt / 500, eng.allreduce_status()))
+
+# per-launch times of the exchange (eager pass, hipEvents)
+eng.profile(True)
+for ov in (False, True):
+    eng.allreduce_set_overlap(ov)
+    eng.train_allreduce(30)
+    eng.synchronize()
+    d = eng.profile_dump()
+    print("overlapped" if ov else "plain", " ".join("%s %.1f" % (k, 1e3 * v["avg_ms"]) for k, v in sorted(d.items()) if k.startswith(("dp_", "reduce", "wgrad"))))
+eng.profile(False)

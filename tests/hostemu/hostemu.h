@@ -77,6 +77,7 @@ enum { hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1 };
 static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { *p = calloc(1, n); return *p ? 0 : 1; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n); return *p ? 0 : 1; }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return 0; }
 static inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof(*p)); return 0; }
 static inline hipError_t hipIpcCloseMemHandle(void*) { return 0; }

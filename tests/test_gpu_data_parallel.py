@@ -134,7 +134,7 @@ def test_rccl_two_gpus_equal_single_engine(tmp_path):
     _check_against_single(tmp_path, 2, "rccl")
 
 
-def _ingraph_worker(rank, world, port, out_dir):
+def _ingraph_worker(rank, world, port, out_dir, overlap=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -153,7 +153,7 @@ def _ingraph_worker(rank, world, port, out_dir):
     ref.close()
     # the in-graph exchange over IPC-mapped buffers
     eng = pu.engine_setup(case)
-    dp = DataParallelInGraph(eng)
+    dp = DataParallelInGraph(eng, overlap=overlap)
     dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
     assert dp.check() == STEPS
     P = eng.get_parameters()
@@ -166,6 +166,20 @@ def _ingraph_worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, "ig%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
     eng.close()
     dist.destroy_process_group()
+
+
+def test_overlapped_in_graph_exchange_two_processes_on_one_gpu(tmp_path):
+    """grl_allreduce_set_overlap: the staged plan with the dense bucket's exchange on a side lane of the graph (channel 0)
+    and the convolution bucket's after it (channel 1).  Same sums: bit-identical to the gloo exchange and between the
+    replicas, explicit minibatches and device RNG."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ingraph_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "ig0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "ig1.npz"))
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
 
 
 def test_in_graph_exchange_two_processes_on_one_gpu(tmp_path):

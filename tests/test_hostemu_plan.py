@@ -147,6 +147,37 @@ def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_
     assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
 
 
+def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
+    """grl_allreduce_set_overlap with world = 1: the staged plan, the dense pieces of the bucket exchanged on channel 0 and
+    the convolution pieces on channel 1 (several disjoint ranges each), Adam waiting for both -- exactly the parameters of
+    compute_grads + apply_grads(1.0), also over a wrap of the per-rank chunking (ragged piece sizes)."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=3)
+    a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    a.allreduce_connect([a.allreduce_init(0, 1)])
+    a.allreduce_set_overlap(True)
+    for s in range(3):
+        a.train_allreduce(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
+        b.compute_grads(case["idx"][s:s + 1], case["eps"][s:s + 1])
+        b.apply_grads(1.0)
+    assert a.allreduce_status() == 3
+    a.allreduce_set_overlap(False)                 # and back to the plain exchange on the same handle
+    a.train_allreduce(1, case["idx"][:1], case["eps"][:1])
+    b.compute_grads(case["idx"][:1], case["eps"][:1])
+    b.apply_grads(1.0)
+    assert a.allreduce_status() == 4
+    Pa, Pb = a.get_parameters(), b.get_parameters()
+    assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
+    a.close(); b.close()
+    # vector observations have no staged plan: the switch says so
+    case = pu.make_case(extractor="mlp", B=8, n_replay=32, n_steps=1)
+    c = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    c.allreduce_connect([c.allreduce_init(0, 1)])
+    with pytest.raises(RuntimeError):
+        c.allreduce_set_overlap(True)
+    c.close()
+
+
 def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
     """grl_allreduce_init / connect / grl_train_step_allreduce with world = 1 (the peer is the rank itself): the
     publish -> reduce + push -> apply chain must leave exactly the parameters of compute_grads + apply_grads(1.0).
@@ -155,7 +186,7 @@ def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
     a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     h = a.allreduce_init(0, 1)
-    assert len(h) == 64
+    assert len(h) == 128
     a.allreduce_connect([h])
     for s in range(3):
         a.train_allreduce(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
