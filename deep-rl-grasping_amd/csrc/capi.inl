@@ -599,6 +599,17 @@ static int dp_blocks(int which, int64_t quads, int dflt) {
   const int cap = v[which] > 0 ? v[which] : dflt;
   return (int)std::min<int64_t>(cap, std::max<int64_t>(1, (quads + 255) / 256));
 }
+// the reduction that ends a gradient computation, publishing its sums on channel `da` as it forms them
+static Op dp_reduce_publish_op(grl_ctx* self, const grl_ctx::ReducePlan& rp, const DpArgs& da, const char* tag) {
+  Op op; op.tag = tag; op.bytes = 8.0 * (double)da.n;
+  const ReduceDesc* dr = self->d_reduces;
+  const LossArgs la = self->loss_args;
+  const AdamArgs aa = self->adam_base;
+  op.run = [dr, rp, la, aa, da](hipStream_t s) {
+    hipLaunchKernelGGL(dp_reduce_slabs_publish_kernel, dim3(rp.n + rp.has_loss), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da);
+  };
+  return op;
+}
 static Op dp_publish_op(const DpArgs& da) {
   Op op; op.tag = "dp_publish"; op.bytes = 8.0 * (double)da.n;
   const int blocks = dp_blocks(0, da.n / 4, 256);
@@ -658,7 +669,19 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
   memset(&none, 0, sizeof(none));
   // ---- the plain update: one exchange of the whole bucket behind the gradient computation
   h->dp = dp_channel(h, 0, {{0, h->n_train}}, flags, data);
-  h->ops_dp = {dp_publish_op(h->dp), dp_reduce_op(h->dp), dp_apply_op(h, h->dp, none)};
+  // (GRL_DP_FUSED_PUBLISH=1: the final reduction publishes its sums itself instead of a copy kernel behind it
+  // (dp_reduce_slabs_publish_kernel).  Bit-identical; MEASURED SLOWER on MI355X -- 25.7 us against 9.9 + 11.0, the update
+  // 232 against 225 us at world 1: 1 300 small blocks each ending in a drain + barrier + counter -- kept as a tested opt-in.)
+  const char* cp = getenv("GRL_DP_FUSED_PUBLISH");
+  const bool fused_publish = cp && atoi(cp) && h->red_all.tiles && !h->ops_grads.empty() && h->ops_grads.back().tag == "reduce_slabs";
+  h->dp_body.assign(h->ops_grads.begin(), h->ops_grads.end() - (fused_publish ? 1 : 0));
+  if (fused_publish) {
+    Op rp = dp_reduce_publish_op(h, h->red_all, h->dp, "reduce_publish");
+    rp.join = true;                                       // (takes the place of reduce_slabs, which joins the side lane)
+    h->ops_dp = {rp, dp_reduce_op(h->dp), dp_apply_op(h, h->dp, none)};
+  } else {
+    h->ops_dp = {dp_publish_op(h->dp), dp_reduce_op(h->dp), dp_apply_op(h, h->dp, none)};
+  }
   // ---- the overlapped update (grl_allreduce_set_overlap): the staged plan (grl_compute_grads_staged) with both exchanges in
   // the graph.  After heads_dfeat a SIDE LANE forms the dense layers' weight gradients, reduces them and exchanges them on
   // channel 0 -- 90 % of the bytes -- while the main lane runs the backward through the convolutions and their weight
@@ -687,12 +710,13 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
       for (int k = 0; k <= cut; ++k) L.push_back(h->ops_stage0[k]);
       bool first = true;
       auto side = [&](Op o) { o.lane = 1; o.fork = first; o.join = false; first = false; L.push_back(o); };
-      for (size_t k = cut + 1; k < h->ops_stage0.size(); ++k) side(h->ops_stage0[k]);     // wgrad_dense, reduce_dense
-      side(dp_publish_op(d0));
+      const bool fp = fused_publish && h->ops_stage0.back().tag == "reduce_dense" && h->ops_stage1.back().tag == "reduce_conv";
+      for (size_t k = cut + 1; k + (fp ? 1 : 0) < h->ops_stage0.size(); ++k) side(h->ops_stage0[k]);     // wgrad_dense (, reduce_dense)
+      side(fp ? dp_reduce_publish_op(h, h->red_dense, d0, "reduce_dense_publish") : dp_publish_op(d0));
       side(dp_reduce_op(d0));
       side(dp_gather_op(d0));
-      for (Op o : h->ops_stage1) { o.join = false; L.push_back(o); }
-      L.push_back(dp_publish_op(d1));
+      for (size_t k = 0; k + (fp ? 1 : 0) < h->ops_stage1.size(); ++k) { Op o = h->ops_stage1[k]; o.join = false; L.push_back(o); }
+      L.push_back(fp ? dp_reduce_publish_op(h, h->red_conv, d1, "reduce_conv_publish") : dp_publish_op(d1));
       L.push_back(dp_reduce_op(d1));
       L.push_back(dp_apply_op(h, d0, d1));       // (joins the side lane)
     }
@@ -715,7 +739,7 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   std::vector<Op> none;
-  std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->ops_grads;
+  std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->dp_body;
   std::vector<Op>* tail = h->dp_overlap ? &none : &h->ops_dp;
   for (int s = 0; s < n_steps; ++s) {
     if (idx) {

@@ -149,6 +149,22 @@ __global__ __launch_bounds__(256) void dp_publish_kernel(DpArgs a) {
     for (int p = 0; p < a.world; ++p) dp_store_flag(&a.ctl[p]->ready[a.rank], e);
 }
 
+// The last launch of the gradient computation (reduce_slabs_kernel: every trainable element = the sum of its split-reduction
+// slabs; the loss workgroup forms the entropy coefficient's gradient) publishing what it sums: each sum also goes, write-through,
+// into this rank's src -- no copy kernel.  The pieces of the channel are exactly what the launch's descriptors cover.
+__global__ __launch_bounds__(256) void dp_reduce_slabs_publish_kernel(const ReduceDesc* __restrict__ descs, const int2* __restrict__ tiles,
+                                                                     int n_tiles, LossArgs la, int has_loss, AdamArgs aa, DpArgs a) {
+  DpCtl* mine = a.ctl[a.rank];
+  const uint32_t e = mine->epoch + 1u;
+  reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, 0, (int)blockIdx.x, a.src[a.rank]);
+  if (has_loss && (int)blockIdx.x == n_tiles) {
+    __syncthreads();
+    if (threadIdx.x == 0) st_sys_f1(a.src[a.rank] + (la.g_log_ent_coef - aa.grads), la.g_log_ent_coef[0]);
+  }
+  if (dp_block_done(&mine->cnt_publish))
+    for (int p = 0; p < a.world; ++p) dp_store_flag(&a.ctl[p]->ready[a.rank], e);
+}
+
 __global__ __launch_bounds__(256) void dp_reduce_kernel(DpArgs a) {
   DpCtl* mine = a.ctl[a.rank];
   const uint32_t e = mine->epoch + 1u;

@@ -951,8 +951,33 @@ struct ReduceDesc {
 // (slab loads are independent: unrolled so several are in flight; the add order stays k = 0, 1, ...)
 // ... and, as workgroup n_tiles when has_loss is set, the batch reductions of the SAC losses (metrics,
 // entropy-coefficient gradient, Adam step size): they are needed by the apply kernel only.
+// System-scope WRITE-THROUGH stores (buffer store with sc0 | sc1 / a system-scope atomic store): what a kernel uses for data
+// that another GPU reads while kernels are running -- nothing stays dirty in an L2, a drained store has reached memory
+// (csrc/dp_kernels.h: the exchange step of the data-parallel update).
+#ifdef GRL_HOSTEMU
+struct sys_f4 { float v[4]; };
+static inline void st_sys_quad(float* base, int64_t quad, const float (&v)[4]) { for (int k = 0; k < 4; ++k) base[4 * quad + k] = v[k]; }
+static inline void st_sys_f1(float* p, float v) { *p = v; }
+#else
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_rsrc(const float* p) {
+  const uint64_t a = (uint64_t)p;     // (made provably wave-uniform: no waterfall loop around the buffer instructions)
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+enum { SYS_SCOPE = 1 | 16 };     // buffer-instruction cache policy: sc0 | sc1
+__device__ __forceinline__ void st_sys_quad(float* base, int64_t quad, const float (&v)[4]) {
+  typedef unsigned int sys_u4 __attribute__((ext_vector_type(4)));
+  typedef float sys_f4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sys_u4, sys_f4{v[0], v[1], v[2], v[3]}), sys_rsrc(base), (int)(quad << 4), 0, SYS_SCOPE);
+}
+__device__ __forceinline__ void st_sys_f1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#endif
+
+// mirror (optional): a second, bucket-shaped array that receives every sum write-through (the exchange buffer of the
+// data-parallel update: the reduction publishes the gradients itself, no copy kernel)
 __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__ descs, const int2* __restrict__ tiles, int n_tiles,
-                                                  const LossArgs& la, int has_loss, const AdamArgs& aa, int fuse_adam, const int blk) {
+                                                  const LossArgs& la, int has_loss, const AdamArgs& aa, int fuse_adam, const int blk,
+                                                  float* mirror = nullptr) {
   if (blk >= n_tiles) {
     if (has_loss) sac_loss_body(la, fuse_adam);
     return;
@@ -994,6 +1019,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
       }
       for (; k < d.splits; ++k) s += *(const rs_f4*)(src + (long)k * d.slab_stride);
       *(rs_f4*)(d.dst + i) = s;
+      if (mirror) { const float sv[4] = {s.x, s.y, s.z, s.w}; st_sys_quad(mirror, ((d.dst + i) - aa.grads) >> 2, sv); }
       if (fuse_adam) {
         const float alpha = aa.sc->adam_alpha;
         float pe[4] = {p.x, p.y, p.z, p.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
@@ -1033,6 +1059,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
     }
     for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
     d.dst[i] = s;
+    if (mirror) st_sys_f1(mirror + ((d.dst + i) - aa.grads), s);
     if (fuse_adam) {   // the update every trainable tensor gets from adam_polyak_kernel, element by element
       adam_elem(grad_scaled(s, aa.grad_scale), p, m, v, aa.sc->adam_alpha, aa.eps);
       aa.params[e] = p; aa.m[e] = m; aa.v[e] = v;

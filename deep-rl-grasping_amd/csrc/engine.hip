@@ -261,7 +261,13 @@ struct grl_ctx {
   void* dp_buf = nullptr;                // this rank's exchange data (src | red) and flags: the only device allocations the
   void* dp_flags = nullptr;              // library makes itself (IPC export needs allocations of their own)
   void* dp_peer[2 * DP_MAX_WORLD] = {nullptr};
-  std::vector<Op> ops_dp;                // publish | reduce + push | Adam + Polyak on the exchanged bucket
+  // the reductions that end the gradient computation, kept for the exchange step (which publishes from inside them):
+  // whole bucket / dense pieces / convolution pieces (+ the loss workgroup where has_loss)
+  struct ReducePlan { const int2* tiles = nullptr; int n = 0; int has_loss = 0; };
+  ReducePlan red_all, red_dense, red_conv;
+  AdamArgs adam_base;
+  std::vector<Op> ops_dp;                // reduce + publish | reduce-scatter | Adam + Polyak on the exchanged bucket (replaces the last op of ops_grads)
+  std::vector<Op> dp_body;               // ops_grads without its final reduction (the exchange's first kernel forms the sums)
   std::vector<Op> ops_dp_overlap;        // the whole overlapped update: staged gradients, two exchanges (one on a side lane), Adam
   bool dp_overlap = false;
 

@@ -744,6 +744,8 @@ int grl_ctx::plan_sac() {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles + has_loss), dim3(256), 0, s, dr, d_rt, ntiles, la, has_loss, aa, 0);
     };
     ops_grads.push_back(op);
+    adam_base = aa;
+    red_all.tiles = d_rt; red_all.n = ntiles; red_all.has_loss = has_loss;
     if (staged_ok) {
       // reductions of the two stages: convolution descriptors are those that land in the conv variables of a net
       auto is_conv = [&](const ReduceDesc& r) {
@@ -764,6 +766,8 @@ int grl_ctx::plan_sac() {
       r1.run = [dr, d_rt1, n1, la, has_loss, aa](hipStream_t s) {
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(n1 + has_loss), dim3(256), 0, s, dr, d_rt1, n1, la, has_loss, aa, 0);
       };
+      red_dense.tiles = d_rt0; red_dense.n = n0; red_dense.has_loss = 0;
+      red_conv.tiles = d_rt1; red_conv.n = n1; red_conv.has_loss = has_loss;
       ops_stage0 = st0_ops; ops_stage0.push_back(r0);
       ops_stage1 = st1_ops; ops_stage1.push_back(r1);
     }

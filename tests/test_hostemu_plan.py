@@ -147,10 +147,12 @@ def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_
     assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
 
 
-def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
+@pytest.mark.parametrize("fused_publish", ["0", "1"])
+def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib, monkeypatch, fused_publish):
     """grl_allreduce_set_overlap with world = 1: the staged plan, the dense pieces of the bucket exchanged on channel 0 and
     the convolution pieces on channel 1 (several disjoint ranges each), Adam waiting for both -- exactly the parameters of
     compute_grads + apply_grads(1.0), also over a wrap of the per-rank chunking (ragged piece sizes)."""
+    monkeypatch.setenv("GRL_DP_FUSED_PUBLISH", fused_publish)     # (1: the reductions publish their sums themselves; opt-in)
     case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=3)
     a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
