@@ -367,10 +367,8 @@ def make_data_parallel(eng, kind, world, rank, device, init):
     import torch.distributed as dist
     from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
     if kind in ("auto", "ingraph", "ingraph-overlap"):
-        ok = torch.ones(1, device=device)
-        dp = None
-        try:
-            dp = DataParallelInGraph(eng, overlap=(kind == "ingraph-overlap"))
+        def verified(dp):
+            """three updates, no time-out, replicas bit-identical on every rank (a checksum travels)"""
             dp.train(3)
             dp.check()
             P = eng.get_parameters()
@@ -380,16 +378,38 @@ def make_data_parallel(eng, kind, world, rank, device, init):
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             if float(lo) != float(hi):
                 raise RuntimeError("replicas differ after the in-graph exchange")
+
+        def agreed(flag):          # every rank takes the same path
+            t = torch.tensor([1.0 if flag else 0.0], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t) > 0
+
+        dp, ok = None, True
+        try:
+            dp = DataParallelInGraph(eng)
         except Exception as exc:   # noqa: BLE001
             sys.stderr.write("bench[rank %d]: in-graph exchange unavailable (%s)\n" % (rank, exc))
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
-        if float(ok) > 0:
-            return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph%s" % (
-                world, " (dense bucket on a side lane under the conv backward)" if dp.overlap else "")
+            ok = False
+        if agreed(ok):
+            # 'auto' prefers the overlapped update (dense bucket exchanged on a side lane of the graph under the convolution
+            # backward: the wire time of 90 % of the bytes is hidden), then the plain one
+            for overlap in ([True, False] if kind == "auto" else [kind == "ingraph-overlap"]):
+                ok = True
+                try:
+                    eng.allreduce_set_overlap(overlap)
+                    dp.overlap = overlap
+                    verified(dp)
+                except Exception as exc:   # noqa: BLE001
+                    sys.stderr.write("bench[rank %d]: in-graph exchange (%s) rejected (%s)\n" % (rank, "overlapped" if overlap else "plain", exc))
+                    ok = False
+                if agreed(ok):
+                    return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph%s" % (
+                        world, " (dense bucket on a side lane under the conv backward)" if overlap else "")
+                eng.set_parameters(init)           # the aborted attempt may have left the replicas out of step
+                eng.reset_optimizer()
         if kind != "auto":
-            raise SystemExit("--dp ingraph: the in-graph exchange could not be set up on every rank")
-        eng.set_parameters(init)           # the aborted attempt may have left the replicas out of step
+            raise SystemExit("--dp %s: the in-graph exchange could not be set up on every rank" % kind)
+        eng.set_parameters(init)
         eng.reset_optimizer()
     dp = DataParallelSac(eng, overlap=(kind == "rccl-overlap"))
     return dp, "dp%d, RCCL all-reduce, %s" % (world, "two gradient buckets (dense bucket under the conv backward)" if dp.overlap
@@ -626,7 +646,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-learn-loop", action="store_true")
     ap.add_argument("--dp", default="auto", choices=["auto", "ingraph", "ingraph-overlap", "rccl", "rccl-overlap"],
-                    help="exchange step for N > 1 (auto: in-graph IPC all-reduce when it verifies, else RCCL one bucket)")
+                    help="exchange step for N > 1 (auto: in-graph IPC all-reduce -- overlapped, else plain -- when it verifies, else RCCL one bucket)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="validation aid: gloo lets the N-rank path run where RCCL cannot (ranks sharing one GPU)")
     ap.add_argument("--same-device", action="store_true",
