@@ -3,17 +3,18 @@
 // update's hipGraph -- no host round trip and no collective library call per update.  RCCL (grasp_rl/parallel.py)
 // stays as the baseline path.
 //
-// Every rank owns TWO allocations, both exported with hipIpcGetMemHandle and mapped by all peers (over xGMI between the
+// Every rank owns TWO allocations (flags, data), both exported with hipIpcGetMemHandle and mapped by all peers (over xGMI between the
 // GPUs of a node; two processes on one GPU map each other's buffers the same way):
 //
 //   flags (fine-grained, a few hundred bytes): per channel (DpCtl)
 //       ready[p]  written by rank p (remotely) once its gradients of exchange e sit in ITS src          -> e
 //       done[q]   written by rank q (remotely) once the sums of ITS chunk of exchange e sit in ITS red  -> e
 //       epoch (completed exchanges), error, block counters
-//   data (ordinary device memory: cached, full bandwidth): src[n] this rank's gradients as published, red[n] the sums of the
-//       chunk this rank owns.  (Round 3 first kept the data fine-grained as well: 5.4 MB then took 53 us to publish, 31 us
-//       to reduce and 28 us to apply on one MI355X -- uncached accesses run at ~0.1-0.2 TB/s.  Only the flags, which a
-//       RUNNING kernel polls, need that; the data is ordered by the fences around them.)
+//   data: src[n] this rank's gradients as published, red[n] the sums of the chunk this rank owns, gathered[n] (overlapped
+//       update).  Stored write-through and loaded at system scope (below), so its caching policy does not matter to the
+//       kernels: fine-grained by default (the conservative choice between GPUs), ordinary device memory with
+//       GRL_DP_COARSE_DATA=1 -- 226 us per update either way on one MI355X.  (Round 3 first fenced every access instead:
+//       5.4 MB then took 53 us to publish, 31 us to reduce and 28 us to apply; it was the fences, not the memory type.)
 //
 //   publish   grads -> src (16-byte copies); the last block stores ready[me] = e into every rank's flags
 //   reduce    reduce-scatter: rank r owns chunk r = [r*c, (r+1)*c); it waits for ready[*] == e and adds the chunk of all

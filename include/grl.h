@@ -212,8 +212,8 @@ int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const 
 /* The exchange step inside the library (csrc/dp_kernels.h): a two-shot all-reduce written for this
    path -- reduce-scatter by the owner of each 1/world chunk in rank order, all-gather by pull inside the Adam kernel --
    over exchange buffers that every rank exports with hipIpcGetMemHandle and maps from its peers (xGMI between the GPUs of a node).
-     grl_allreduce_init     allocates this rank's exchange memory -- a few hundred bytes of fine-grained flags and an
-                            ordinary buffer of three bucket-sized arrays (the only device memory the library allocates
+     grl_allreduce_init     allocates this rank's exchange memory -- a few hundred bytes of flags and a
+                            buffer of three bucket-sized arrays, both fine-grained (the only device memory the library allocates
                             itself: IPC export needs allocations of its own) -- and writes their two IPC handles,
                             GRL_ALLREDUCE_HANDLE_BYTES = 128 bytes, to handle_out; the host exchanges the handles of all
                             ranks out of band (any transport: files, MPI, torch.distributed.all_gather_object);
