@@ -817,10 +817,13 @@ __global__ __launch_bounds__(256) void igemm2_chain_kernel(ChainArgs a) {
 #ifdef GRL_TILE_TRACE
   i2_trace_record(a.p[kind] + k, a.t[kind][k], t0, kind == 0 ? CFGa : (kind == 1 ? CFGb : CFGc));
 #endif
-  __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged by the L2 (the L1 writes through) ...
-  __syncthreads();                 // ... and of every wave of the tile;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave acknowledged by the L2 (the L1 writes through) ...
+  __syncthreads();                                    // ... and of every wave of the tile;
   if (threadIdx.x == 0) {
-    if (d.z >= 0 || d.w >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE write-back of this XCD's L2 makes them visible device-wide
+    if (d.z >= 0 || d.w >= 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE write-back of this XCD's L2 makes them visible device-wide
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (restated: the compiler drops the wait behind the write-back when its
+    }                                                      //  scoreboard shows nothing outstanding -- cdna_hip_programming.md, G16 pitfall 12)
     if (d.z >= 0) __hip_atomic_fetch_add(a.cnt + d.z, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d.w >= 0) __hip_atomic_fetch_add(a.cnt + d.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int done = __hip_atomic_fetch_add(a.cnt + a.n_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
