@@ -412,26 +412,26 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
   if (!idx && n_steps >= 2 && h->prefetch_ok && !h->prof) {   // device RNG, several updates: prefetching sequences (plan_sac)
-    for (int s = 0; s < n_steps; ++s) {
-      const bool first = s == 0, last = s == n_steps - 1;
-      if (int e = h->run_seq(first ? "pf_first" : (last ? "pf_last" : "pf_mid"),
-                             {first ? &h->ops_pf_first : (last ? &h->ops_pf_last : &h->ops_pf_mid)}))
-        return e;
-    }
+    // first | middle updates, grouped several to a graph (run_repeated) | last
+    if (int e = h->run_seq("pf_first", {&h->ops_pf_first})) return e;
+    if (n_steps > 2)
+      if (int e = h->run_repeated("pf_mid", {&h->ops_pf_mid}, n_steps - 2)) return e;
+    if (int e = h->run_seq("pf_last", {&h->ops_pf_last})) return e;
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
+  if (!idx) {      // device RNG: identical updates, several to a graph
+    if (!h->ops_grads_apply.empty()) {
+      if (int e = h->run_repeated("full_rng", {&h->ops_rng, &h->ops_grads_apply}, n_steps)) return e;
+    } else if (int e = h->run_repeated("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply}, n_steps)) return e;
     HIPCHK(hipGetLastError());
     return GRL_OK;
   }
   for (int s = 0; s < n_steps; ++s) {
-    if (idx) {
-      if (int e = stage_noise(h, idx, eps, s)) return e;
-      if (!h->ops_grads_apply.empty()) {
-        if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads_apply})) return e;
-      } else if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
-    } else {
-      if (!h->ops_grads_apply.empty()) {
-        if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads_apply})) return e;
-      } else if (int e = h->run_seq("full_rng", {&h->ops_rng, &h->ops_grads, &h->ops_apply})) return e;
-    }
+    if (int e = stage_noise(h, idx, eps, s)) return e;
+    if (!h->ops_grads_apply.empty()) {
+      if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads_apply})) return e;
+    } else if (int e = h->run_seq("full_explicit", {&h->ops_gather, &h->ops_grads, &h->ops_apply})) return e;
   }
   HIPCHK(hipGetLastError());
   return GRL_OK;
@@ -445,6 +445,15 @@ int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u) 
   if (!(beta > 0.0)) return fail(GRL_ERR_INVALID, "beta must be positive (PrioritizedReplayBuffer.sample asserts beta > 0)");
   if (h->rp_size < 2) return fail(GRL_ERR_STATE, "prioritised sampling needs at least two stored transitions (sum(0, len - 1))");
   HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 8, hipMemcpyHostToDevice, h->stream));
+  if (!u) {        // device Philox: identical updates, several to a graph
+    if (!h->ops_grads_apply_per.empty()) {
+      if (int e = h->run_repeated("per_rng", {&h->ops_per_rng_g, &h->ops_grads_apply_per}, n_steps)) return e;
+    } else if (!h->ops_grads_apply.empty()) {
+      if (int e = h->run_repeated("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update}, n_steps)) return e;
+    } else if (int e = h->run_repeated("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads, &h->ops_apply, &h->ops_per_update}, n_steps)) return e;
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
   for (int s = 0; s < n_steps; ++s) {
     if (u) {
       HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -745,11 +754,13 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   std::vector<Op> none;
   std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->dp_body;
   std::vector<Op>* tail = h->dp_overlap ? &none : &h->ops_dp;
-  for (int s = 0; s < n_steps; ++s) {
-    if (idx) {
+  if (!idx) {      // device RNG: identical updates, several to a graph
+    if (int e = h->run_repeated(h->dp_overlap ? "dpo_rng" : "dp_rng", {&h->ops_rng, body, tail}, n_steps)) return e;
+  } else {
+    for (int s = 0; s < n_steps; ++s) {
       if (int e = stage_noise(h, idx, eps, s)) return e;
       if (int e = h->run_seq(h->dp_overlap ? "dpo_explicit" : "dp_explicit", {&h->ops_gather, body, tail})) return e;
-    } else if (int e = h->run_seq(h->dp_overlap ? "dpo_rng" : "dp_rng", {&h->ops_rng, body, tail})) return e;
+    }
   }
   HIPCHK(hipGetLastError());
   return GRL_OK;

@@ -325,6 +325,28 @@ struct grl_ctx {
     return GRL_OK;
   }
 
+  // `count` identical updates (device RNG: nothing changes on the host between them): groups of up to GRL_GRAPH_UPDATES
+  // (default 16, powers of two) go out as ONE graph -- no graph boundary between the updates of a group (measured on
+  // MI355X, SAC depth B = 256: 5 090 -> 5 194 / 5 227 / 5 232 updates/s at 4 / 8 / 16 per graph)
+  int run_repeated(const std::string& key, const std::vector<std::vector<Op>*>& one, int count) {
+    const char* ge = getenv("GRL_GRAPH_UPDATES");
+    const int max_group = ge ? std::max(1, std::min(64, atoi(ge))) : 16;
+    while (count > 0) {
+      int group = 1;
+      while (2 * group <= max_group && 2 * group <= count) group *= 2;
+      if (group == 1 || !graphs_on()) {
+        if (int e = run_seq(key, one)) return e;
+        count -= 1;
+        continue;
+      }
+      std::vector<std::vector<Op>*> seq;
+      for (int g = 0; g < group; ++g) seq.insert(seq.end(), one.begin(), one.end());
+      if (int e = run_seq(key + "_x" + std::to_string(group), seq)) return e;
+      count -= group;
+    }
+    return GRL_OK;
+  }
+
   // ---------------------------------------------------------------- helpers
   std::map<const void*, std::vector<int32_t>> htab;   // host copies of the int32 addressing tables (plan time only: preambles)
   template <class T>

@@ -172,6 +172,25 @@ def test_dependent_stage_launches_are_bit_identical_at_full_batch(monkeypatch):
         assert np.array_equal(outs[0][n], outs[1][n]), n
 
 
+@pytest.mark.parametrize("kind", ["sac_cnn", "sac_mlp"])
+def test_updates_grouped_into_one_graph_are_bit_identical(monkeypatch, kind):
+    """Calls of several updates on the device RNG send their identical updates out in groups of up to 16 per hipGraph
+    (engine.hip: run_repeated; GRL_GRAPH_UPDATES=1 keeps one graph per update): same kernels in the same order --
+    parameters after 37 updates (1 + 32 + 2 + 1 + 1 as first / 16+16 / 2 / 1 / last) are bit-identical."""
+    case = (pu.make_case(extractor="augmented", kind="depth", B=32, n_replay=200, n_steps=1) if kind == "sac_cnn"
+            else pu.make_case(extractor="mlp", B=64, n_replay=256, n_steps=1))
+    outs = []
+    for flag in ("1", "16"):
+        monkeypatch.setenv("GRL_GRAPH_UPDATES", flag)
+        eng = pu.engine_setup(case)
+        eng.train_device(37)
+        eng.train_device(3)
+        outs.append(eng.get_parameters())
+        eng.close()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+
+
 def test_split_api_equals_fused_and_is_deterministic():
     case = pu.make_case(extractor="augmented", kind="depth", B=16, n_replay=64, n_steps=3)
     outs = []
