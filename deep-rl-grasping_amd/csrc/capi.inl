@@ -412,6 +412,17 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
   if (!idx && n_steps >= 2 && h->prefetch_ok && !h->prof) {   // device RNG, several updates: prefetching sequences (plan_sac)
+    // short calls (what SAC.learn issues: n = number of environments) are ONE graph, cached per n
+    const char* ge = getenv("GRL_GRAPH_UPDATES");
+    if (n_steps <= 32 && !(ge && atoi(ge) == 1)) {
+      std::vector<std::vector<Op>*> seq;
+      seq.push_back(&h->ops_pf_first);
+      for (int s = 0; s < n_steps - 2; ++s) seq.push_back(&h->ops_pf_mid);
+      seq.push_back(&h->ops_pf_last);
+      if (int e = h->run_seq("pf_call_" + std::to_string(n_steps), seq)) return e;
+      HIPCHK(hipGetLastError());
+      return GRL_OK;
+    }
     // first | middle updates, grouped several to a graph (run_repeated) | last
     if (int e = h->run_seq("pf_first", {&h->ops_pf_first})) return e;
     if (n_steps > 2)
