@@ -765,7 +765,15 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   std::vector<Op> none;
   std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->dp_body;
   std::vector<Op>* tail = h->dp_overlap ? &none : &h->ops_dp;
-  if (!idx) {      // device RNG: identical updates, several to a graph
+  const char* npf = getenv("GRL_NO_GATHER_PREFETCH");
+  if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !h->ops_pfdp_mid.empty() && !(npf && atoi(npf)) &&
+      h->ops_dp.size() == 3 && h->ops_dp[0].tag == "dp_publish") {
+    // plain exchange on the device RNG: the prefetching sequences (the gather of update t+1 rides on the reduction of update t)
+    if (int e = h->run_seq("dpp_first", {&h->ops_pfdp_first, &h->ops_dp})) return e;
+    if (n_steps > 2)
+      if (int e = h->run_repeated("dpp_mid", {&h->ops_pfdp_mid, &h->ops_dp}, n_steps - 2)) return e;
+    if (int e = h->run_seq("dpp_last", {&h->ops_pfdp_last, &h->ops_dp})) return e;
+  } else if (!idx) {      // device RNG: identical updates, several to a graph
     if (int e = h->run_repeated(h->dp_overlap ? "dpo_rng" : "dp_rng", {&h->ops_rng, body, tail}, n_steps)) return e;
   } else {
     for (int s = 0; s < n_steps; ++s) {

@@ -267,6 +267,7 @@ struct grl_ctx {
   ReducePlan red_all, red_dense, red_conv;
   AdamArgs adam_base;
   std::vector<Op> ops_dp;                // reduce + publish | reduce-scatter | Adam + Polyak on the exchanged bucket (replaces the last op of ops_grads)
+  std::vector<Op> ops_pfdp_first, ops_pfdp_mid, ops_pfdp_last;   // prefetching sequences whose last launch sums without applying (plan_sac)
   std::vector<Op> dp_body;               // ops_grads without its final reduction (the exchange's first kernel forms the sums)
   std::vector<Op> ops_dp_overlap;        // the whole overlapped update: staged gradients, two exchanges (one on a side lane), Adam
   bool dp_overlap = false;

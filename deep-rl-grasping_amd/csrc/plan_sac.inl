@@ -822,6 +822,21 @@ int grl_ctx::plan_sac() {
           }
           dst.push_back(v == 2 ? fo : ro);
         }
+        // the same three sequences for the data-parallel update (grl_train_step_allreduce): the final launch forms the sums
+        // WITHOUT applying them (the exchange follows, Adam runs in dp_apply_kernel) and still carries the next gather
+        Op rd; rd.tag = "reduce_slabs";
+        rd.join = true;
+        rd.bytes = ro.bytes;
+        rd.run = [dr, d_rt, ntiles, lk, has_loss, aa, g2, gx](hipStream_t s) {
+          hipLaunchKernelGGL(reduce_slabs_gather_kernel, dim3(ntiles + has_loss + gx * g2.B * 2), dim3(256), 0, s, dr, d_rt, ntiles, lk,
+                             has_loss, aa, 0, g2, gx);
+        };
+        for (int v = 0; v < 3; ++v) {
+          const std::vector<Op>& src = v == 0 ? ops_pf_first : (v == 1 ? ops_pf_mid : ops_pf_last);
+          std::vector<Op>& dst = v == 0 ? ops_pfdp_first : (v == 1 ? ops_pfdp_mid : ops_pfdp_last);
+          dst.assign(src.begin(), src.end() - 1);
+          dst.push_back(v == 2 ? ops_grads.back() : rd);
+        }
         prefetch_ok = true;
       }
     }

@@ -180,6 +180,25 @@ def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(host
     c.close()
 
 
+def test_in_graph_exchange_on_the_device_rng_prefetches_like_the_fused_update(hostemu_lib):
+    """Several data-parallel updates per call on the device RNG: the gather of update t+1 rides on the (unfused) reduction of
+    update t, the exchange and Adam follow -- with one rank exactly the parameters, moments and RNG position of
+    grl_train_step(n) on a second handle, call after call."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=16, n_replay=48, n_steps=1)
+    a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    a.allreduce_connect([a.allreduce_init(0, 1)])
+    for n in (5, 1, 2):
+        a.train_allreduce(n)
+        b.train_device(n)
+    assert a.allreduce_status() == 8
+    Pa, Pb = a.get_parameters(), b.get_parameters()
+    assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
+    for name in ("idx_raw", "adam_m", "adam_v"):
+        assert np.array_equal(a.fetch(name), b.fetch(name)), name
+    a.close(); b.close()
+
+
 def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
     """grl_allreduce_init / connect / grl_train_step_allreduce with world = 1 (the peer is the rank itself): the
     publish -> reduce + push -> apply chain must leave exactly the parameters of compute_grads + apply_grads(1.0).
