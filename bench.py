@@ -652,7 +652,7 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="validation aid: every rank uses cuda:0 (a 1-GPU box); the reported rate is then NOT a scaling number")
     ap.add_argument("--no-success", action="store_true", help="skip the learning run behind `success_rate`")
-    ap.add_argument("--success-steps", type=int, default=48_000)
+    ap.add_argument("--success-steps", type=int, default=80_000)
     args = ap.parse_args()
 
     if os.environ.get("GRL_LIBRARY"):
