@@ -258,7 +258,16 @@ int grl_ctx::plan_sac() {
       heads_mfma = !(nm && nm[0] == '1') && 2 * A <= 64;
       bool narrow = true;
       for (int l = 0; l < L; ++l) narrow = narrow && hid[l] <= 64;
-      heads_mfma = heads_mfma && (narrow || (L == 2 && hid[0] == 128 && hid[1] == 128 && A <= 8 && B % HT_RB == 0));
+      bool wide_ok = L == 2 && hid[0] == 128 && hid[1] == 128 && A <= 8 && B % HT_RB == 0;
+#ifndef GRL_HOSTEMU
+      if (!narrow && wide_ok) {   // the 128-wide kernel keeps 75 KB of static LDS per workgroup: fits gfx950's 160 KB; a device that offers less keeps the VALU chains
+        int dev = 0, lds = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+            lds < (int)sizeof(HmLds<128>))
+          wide_ok = false;
+      }
+#endif
+      heads_mfma = heads_mfma && (narrow || wide_ok);
     }
     if (heads_mfma) {
       // forward and backward of every head in one launch (heads_mfma.h); d_out / gradients as in the backward args below
