@@ -391,22 +391,51 @@ def make_data_parallel(eng, kind, world, rank, device, init):
             sys.stderr.write("bench[rank %d]: in-graph exchange unavailable (%s)\n" % (rank, exc))
             ok = False
         if agreed(ok):
-            # 'auto' prefers the overlapped update (dense bucket exchanged on a side lane of the graph under the convolution
-            # backward: the wire time of 90 % of the bytes is hidden), then the plain one
+            # 'auto': both in-graph variants are verified, then TIMED on 48 updates each (max over ranks), and the faster one
+            # runs -- overlapped (dense bucket exchanged on a side lane of the graph under the convolution backward: the wire
+            # time of 90 % of the bytes is hidden, at +28 us of on-GPU work) or plain; which wins depends on the link
+            # rate and on N
+            good, ms = [], {}
             for overlap in ([True, False] if kind == "auto" else [kind == "ingraph-overlap"]):
                 ok = True
                 try:
                     eng.allreduce_set_overlap(overlap)
+                except Exception:   # noqa: BLE001   (no staged plan for this configuration: the same on every rank)
+                    continue
+                try:
                     dp.overlap = overlap
                     verified(dp)
+                    if kind == "auto":
+                        dp.train(16)
+                        eng.synchronize()
+                        dist.barrier()
+                        t0 = time.perf_counter()
+                        dp.train(48)
+                        eng.synchronize()
+                        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        ms[overlap] = 1e3 * float(t) / 48
+                        dp.check()
                 except Exception as exc:   # noqa: BLE001
                     sys.stderr.write("bench[rank %d]: in-graph exchange (%s) rejected (%s)\n" % (rank, "overlapped" if overlap else "plain", exc))
                     ok = False
                 if agreed(ok):
-                    return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph%s" % (
-                        world, " (dense bucket on a side lane under the conv backward)" if overlap else "")
-                eng.set_parameters(init)           # the aborted attempt may have left the replicas out of step
+                    good.append(overlap)
+                else:
+                    break                          # a time-out leaves the flags out of step: no further in-graph attempt
+            if good:
+                overlap = min(good, key=lambda o: ms.get(o, 0.0)) if kind == "auto" else good[0]
+                eng.allreduce_set_overlap(overlap)
+                dp.overlap = overlap
+                eng.set_parameters(init)           # the timed run starts from the common initial state
                 eng.reset_optimizer()
+                note = ""
+                if len(ms) == 2:
+                    note = "; chosen by timing: overlapped %.4f ms, plain %.4f ms per update" % (ms[True], ms[False])
+                return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph%s%s" % (
+                    world, " (dense bucket on a side lane under the conv backward)" if overlap else "", note)
+            eng.set_parameters(init)               # the aborted attempt may have left the replicas out of step
+            eng.reset_optimizer()
         if kind != "auto":
             raise SystemExit("--dp %s: the in-graph exchange could not be set up on every rank" % kind)
         eng.set_parameters(init)
