@@ -160,7 +160,7 @@ def roofline_of(prof, n, dt_step, workload):
       measurement, like `traffic`;
     * `step_flops` = algorithmic FLOPs of one update (what the path needs: valid taps only, no backward-data of the
       first convolution -- the observations need no gradient), `step_flops_executed` = what the MFMAs execute
-      (equal unless GRL_NO_EXACT_TAP selects the masked parity-class form); `step_frac` = step_flops / ms_per_step /
+      (equal for the SAC update: its backward-data runs over exact taps; the auto-encoder's masked form executes more); `step_frac` = step_flops / ms_per_step /
       peak, i.e. from the timed graph-replay blocks that `value` comes from;
     * `memory`: the HBM-bound launches of the update: algorithmic bytes / eager duration / 8 TB/s."""
     total = {k: v["avg_ms"] * v["launches"] for k, v in prof.items()}
@@ -359,87 +359,88 @@ def cpu_baseline_ae(seconds=8.0):
             "sample": "%d oracle auto-encoder training steps at batch 128 (PyTorch-CPU fp32), %.1f s" % (n, dt)}
 
 
+IN_GRAPH_VARIANTS = {      # --dp -> [(mode, overlap)] tried in this order
+    "auto": [("oneshot", False), ("twoshot", False), ("twoshot", True)],
+    "ingraph": [("auto", False)], "ingraph-oneshot": [("oneshot", False)], "ingraph-twoshot": [("twoshot", False)],
+    "ingraph-overlap": [("twoshot", True)]}
+
+
 def make_data_parallel(eng, kind, world, rank, device, init):
-    """The exchange step for N > 1.  'auto': the in-graph two-shot all-reduce over IPC-mapped buffers
-    (grasp_rl.parallel.DataParallelInGraph) if it can be set up AND proves itself on three updates (no time-out, replicas
-    bit-identical across ranks -- checked with a checksum all-reduce), otherwise RCCL with one gradient bucket."""
+    """The exchange step for N > 1.  The in-graph all-reduces over IPC-mapped buffers (grasp_rl.parallel.DataParallelInGraph:
+    one-shot, two-shot, two-shot with the dense bucket overlapped) are set up, each VERIFIED on three updates (no time-out,
+    replicas bit-identical across ranks -- a checksum travels) and, with 'auto', TIMED on 48 updates (max over ranks); the
+    fastest verified variant runs.  Otherwise RCCL with one gradient bucket.  Every decision is collective: a rank whose
+    local attempt fails still executes the same sequence of collectives as its peers."""
     import torch
     import torch.distributed as dist
     from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
-    if kind in ("auto", "ingraph", "ingraph-overlap"):
-        def verified(dp):
-            """three updates, no time-out, replicas bit-identical on every rank (a checksum travels)"""
-            dp.train(3)
-            dp.check()
-            P = eng.get_parameters()
-            chk = torch.tensor([float(sum(float(v.astype("float64").sum()) for v in P.values()))], dtype=torch.float64, device=device)
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if float(lo) != float(hi):
-                raise RuntimeError("replicas differ after the in-graph exchange")
 
-        def agreed(flag):          # every rank takes the same path
-            t = torch.tensor([1.0 if flag else 0.0], device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return float(t) > 0
+    def agreed(flag):          # every rank takes the same path
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t) > 0
 
-        dp, ok = None, True
+    def attempt(fn, what):
         try:
-            dp = DataParallelInGraph(eng)
+            fn()
+            return True
         except Exception as exc:   # noqa: BLE001
-            sys.stderr.write("bench[rank %d]: in-graph exchange unavailable (%s)\n" % (rank, exc))
-            ok = False
-        if agreed(ok):
-            # 'auto': both in-graph variants are verified, then TIMED on 48 updates each (max over ranks), and the faster one
-            # runs -- overlapped (dense bucket exchanged on a side lane of the graph under the convolution backward: the wire
-            # time of 90 % of the bytes is hidden, at +28 us of on-GPU work) or plain; which wins depends on the link
-            # rate and on N (DESIGN.md section 7)
-            good, ms = [], {}
-            for overlap in ([True, False] if kind == "auto" else [kind == "ingraph-overlap"]):
-                ok = True
-                try:
-                    eng.allreduce_set_overlap(overlap)
-                except Exception:   # noqa: BLE001   (no staged plan for this configuration: the same on every rank)
+            sys.stderr.write("bench[rank %d]: in-graph exchange, %s: %s\n" % (rank, what, exc))
+            return False
+
+    if kind in IN_GRAPH_VARIANTS:
+        box = {}
+        ok = agreed(attempt(lambda: box.setdefault("dp", DataParallelInGraph(eng, mode="twoshot")), "set-up"))
+        good, ms = [], {}
+        if ok:
+            dp = box["dp"]
+            for mode, overlap in IN_GRAPH_VARIANTS[kind]:
+                name = mode + ("+overlap" if overlap else "")
+                # (switching is itself collective: drain, barrier, switch, barrier; a configuration without a staged plan
+                # refuses `overlap` on every rank alike)
+                if not agreed(attempt(lambda: dp.set_mode(mode, overlap), name)):
                     continue
-                try:
-                    dp.overlap = overlap
-                    verified(dp)
-                    if kind == "auto":
+                if not agreed(attempt(lambda: (dp.train(3), dp.check()), name + " (3 updates)")):
+                    break                          # a time-out poisons the channel on every rank: no further in-graph attempt
+                P = eng.get_parameters()
+                chk = torch.tensor([float(sum(float(v.astype("float64").sum()) for v in P.values()))], dtype=torch.float64, device=device)
+                lo, hi = chk.clone(), chk.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                if float(lo) != float(hi):         # (the same verdict on every rank)
+                    sys.stderr.write("bench[rank %d]: replicas differ after the in-graph exchange (%s)\n" % (rank, name))
+                    continue
+                if len(IN_GRAPH_VARIANTS[kind]) > 1:
+                    def timed():
                         dp.train(16)
                         eng.synchronize()
                         dist.barrier()
                         t0 = time.perf_counter()
                         dp.train(48)
                         eng.synchronize()
-                        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                        ms[overlap] = 1e3 * float(t) / 48
+                        box["t"] = time.perf_counter() - t0
                         dp.check()
-                except Exception as exc:   # noqa: BLE001
-                    sys.stderr.write("bench[rank %d]: in-graph exchange (%s) rejected (%s)\n" % (rank, "overlapped" if overlap else "plain", exc))
-                    ok = False
-                if agreed(ok):
-                    good.append(overlap)
-                else:
-                    break                          # a time-out leaves the flags out of step: no further in-graph attempt
-            if good:
-                overlap = min(good, key=lambda o: ms.get(o, 0.0)) if kind == "auto" else good[0]
-                eng.allreduce_set_overlap(overlap)
-                dp.overlap = overlap
-                eng.set_parameters(init)           # the timed run starts from the common initial state
-                eng.reset_optimizer()
-                note = ""
-                if len(ms) == 2:
-                    note = "; chosen by timing: overlapped %.4f ms, plain %.4f ms per update" % (ms[True], ms[False])
-                return dp, "dp%d, two-shot all-reduce over IPC-mapped buffers inside the update graph%s%s" % (
-                    world, " (dense bucket on a side lane under the conv backward)" if overlap else "", note)
-            eng.set_parameters(init)               # the aborted attempt may have left the replicas out of step
-            eng.reset_optimizer()
-        if kind != "auto":
-            raise SystemExit("--dp %s: the in-graph exchange could not be set up on every rank" % kind)
-        eng.set_parameters(init)
+                    if not agreed(attempt(timed, name + " (timing)")):
+                        break
+                    t = torch.tensor([box["t"]], dtype=torch.float64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    ms[(mode, overlap)] = 1e3 * float(t) / 48
+                good.append((mode, overlap))
+        eng.set_parameters(init)                   # the timed run starts from the common initial state
         eng.reset_optimizer()
+        if good:
+            mode, overlap = min(good, key=lambda v: ms.get(v, 0.0))
+            dp.set_mode(mode, overlap)
+            note = ""
+            if ms:
+                note = "; chosen by timing (ms per update): " + ", ".join("%s%s %.4f" % (m, "+overlap" if o else "", ms[(m, o)]) for m, o in good)
+            resolved = mode if mode != "auto" else ("oneshot" if world <= 2 else "twoshot")
+            return dp, "dp%d, %s all-reduce over IPC-mapped buffers inside the update graph%s%s" % (
+                world, {"oneshot": "one-shot", "twoshot": "two-shot"}[resolved],
+                " (dense bucket on a side lane under the conv backward)" if overlap else "", note)
+        if kind != "auto":
+            raise SystemExit("--dp %s: the in-graph exchange could not be set up / verified on every rank" % kind)
+        sys.stderr.write("bench[rank %d]: no in-graph variant verified: falling back to RCCL\n" % rank)
     dp = DataParallelSac(eng, overlap=(kind == "rccl-overlap"))
     return dp, "dp%d, RCCL all-reduce, %s" % (world, "two gradient buckets (dense bucket under the conv backward)" if dp.overlap
                                               else "one gradient bucket")
@@ -674,8 +675,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-learn-loop", action="store_true")
-    ap.add_argument("--dp", default="auto", choices=["auto", "ingraph", "ingraph-overlap", "rccl", "rccl-overlap"],
-                    help="exchange step for N > 1 (auto: in-graph IPC all-reduce -- overlapped, else plain -- when it verifies, else RCCL one bucket)")
+    ap.add_argument("--dp", default="auto", choices=["auto", "ingraph", "ingraph-oneshot", "ingraph-twoshot", "ingraph-overlap", "rccl", "rccl-overlap"],
+                    help="exchange step for N > 1 (auto: the fastest in-graph IPC all-reduce that verifies -- one-shot, two-shot, two-shot overlapped -- else RCCL one bucket)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="validation aid: gloo lets the N-rank path run where RCCL cannot (ranks sharing one GPU)")
     ap.add_argument("--same-device", action="store_true",
@@ -686,6 +687,7 @@ def main():
 
     if os.environ.get("GRL_LIBRARY"):
         raise SystemExit("bench.py measures the in-tree libgrl.so: unset GRL_LIBRARY (a test-only override)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (exchange buffers): must be set before HIP initialises
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -699,7 +701,6 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:

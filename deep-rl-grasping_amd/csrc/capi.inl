@@ -85,7 +85,6 @@ int grl_create(const grl_config* cfg, const grl_buffers* bufs, grl_handle* out) 
     if (e != hipSuccess) { delete h; return fail(GRL_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e)); }
   }
   h->uploads.clear();
-  h->htab.clear();
   for (auto& z : h->zero_once) hipMemset(z.first, 0, z.second);
   // state: zero Adam moments, scalars; stats = identity
   hipMemset(h->adam_m, 0, (size_t)h->n_train * 4);
@@ -174,7 +173,7 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
   // Two mirrors alternate, each guarded by an event, so the host never waits for the GPU here (the learn loop calls
   // this before every update: a stream synchronisation plus five blocking copies serialised host and device).
   char* base = (char*)h->s_mean;
-  const size_t span = h->n_mean ? (size_t)((char*)(h->n_var + h->n_elems) - base) : (size_t)((char*)h->s_ret + 8 - base);
+  const size_t span = (size_t)((char*)h->s_ret + 8 - base);
   if (!h->pin_stats[0]) {
     for (int k = 0; k < 2; ++k) {
       HIPCHK(hipHostMalloc((void**)&h->pin_stats[k], span, 0));
@@ -206,10 +205,6 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
     for (int q = 0; q < h->img_elems; ++q) { m[q] = mean[q]; s[q] = std::sqrt(var[q] + eps); }
   }
   *rs = std::sqrt(ret_var + eps);
-  if (h->n_mean) {   // the running statistics grl_norm_update continues from (env layout)
-    memcpy(pm + ((char*)h->n_mean - base), mean, (size_t)h->n_elems * 8);
-    memcpy(pm + ((char*)h->n_var - base), var, (size_t)h->n_elems * 8);
-  }
   HIPCHK(hipMemcpyAsync(base, pm, span, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipEventRecord(h->pin_stats_ev[k], h->stream));
   h->pin_stats_used[k] = true;
@@ -223,8 +218,12 @@ int grl_set_ret_var(grl_handle h, double ret_var) {
   return GRL_OK;
 }
 
-int grl_set_obs_count(grl_handle h, double count) {
-  if (!h || !h->n_count) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+int grl_set_running_stats(grl_handle h, const double* mean, const double* var, double count) {
+  if (!h || !mean || !var) return fail(GRL_ERR_INVALID, "null argument");
+  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  // (rare: once per attach / load; pageable sources are staged before hipMemcpyAsync returns)
+  HIPCHK(hipMemcpyAsync(h->n_mean, mean, (size_t)h->n_elems * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->n_var, var, (size_t)h->n_elems * 8, hipMemcpyHostToDevice, h->stream));
   const double c2[2] = {count, count};
   HIPCHK(hipMemcpyAsync(h->n_count, c2, 16, hipMemcpyHostToDevice, h->stream));
   return GRL_OK;
@@ -242,7 +241,16 @@ int grl_norm_update(grl_handle h, const float* obs, int n) {
   a.mean = h->n_mean; a.var = h->n_var; a.count = h->n_count; a.parity = h->n_parity; a.eps = c.norm_eps;
   a.hw = h->hw * h->hw; a.c_obs = c.obs_channels; a.c_img = h->C_img; a.n_direct = h->cnn ? h->F - 512 : 0; a.vec = h->cnn ? 0 : 1;
   a.s_mean = h->s_mean; a.s_std = h->s_std; a.s_dmean = h->s_dmean; a.s_dstd = h->s_dstd;
-  hipLaunchKernelGGL(norm_update_kernel, dim3((unsigned)((h->n_elems + 255) / 256)), dim3(256), 0, h->stream, a);
+  const dim3 grid((unsigned)((h->n_elems + 255) / 256));
+  if (h->dp_on) {   // data parallel: the batch moments of all ranks, merged in rank order by every replica (dp_kernels.h)
+    if (h->dp_err_host && *h->dp_err_host) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
+    DpNormArgs na = h->dp_norm;
+    na.nu = a;
+    hipLaunchKernelGGL(dp_norm_moments_kernel, grid, dim3(256), 0, h->stream, na);
+    hipLaunchKernelGGL(dp_norm_merge_kernel, grid, dim3(256), 0, h->stream, na);
+  } else {
+    hipLaunchKernelGGL(norm_update_kernel, grid, dim3(256), 0, h->stream, a);
+  }
   h->n_parity ^= 1;
   HIPCHK(hipGetLastError());
   return GRL_OK;
@@ -413,8 +421,7 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   h->grad_scale = 1.f;
   if (!idx && n_steps >= 2 && h->prefetch_ok && !h->prof) {   // device RNG, several updates: prefetching sequences (plan_sac)
     // short calls (what SAC.learn issues: n = number of environments) are ONE graph, cached per n
-    const char* ge = getenv("GRL_GRAPH_UPDATES");
-    if (n_steps <= 32 && !(ge && atoi(ge) == 1)) {
+    if (n_steps <= 32 && tune_int("graph_updates", 16) != 1) {
       std::vector<std::vector<Op>*> seq;
       seq.push_back(&h->ops_pf_first);
       for (int s = 0; s < n_steps - 2; ++s) seq.push_back(&h->ops_pf_mid);
@@ -516,11 +523,6 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
   out->policy_loss = s.policy_loss; out->qf1_loss = s.qf1_loss; out->qf2_loss = s.qf2_loss;
   out->value_loss = s.value_loss; out->ent_coef_loss = s.ent_loss; out->ent_coef = s.ent_coef;
   out->entropy = s.entropy; out->mean_qf1 = s.mean_qf1; out->mean_v = s.mean_v;
-  for (int* e : h->chain_err) {     // a bounded wait of a dependent-stage launch ran out (igemm2_chain_kernel): results are not valid
-    int v = 0;
-    HIPCHK(hipMemcpy(&v, e, sizeof(v), hipMemcpyDeviceToHost));
-    if (v) return fail(GRL_ERR_STATE, "a dependent-stage launch timed out waiting for its producers (GRL_CHAIN=1 was set)");
-  }
   return GRL_OK;
 }
 
@@ -556,9 +558,10 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
 }
 
 // ---------------------------------------------------------------------------------------------- data parallel, in-graph
-// this rank's two exchange allocations: flags = [DP_CHANNELS x DpCtl] (fine-grained), data = [src | red] (bucket-shaped each)
+// this rank's two exchange allocations: flags = [DP_CHANNELS x DpCtl] (fine-grained), data = [src | red | gathered | 2 moment blocks]
 static size_t dp_ctl_stride() { return (size_t)rup((int64_t)sizeof(DpCtl), 256); }
 static size_t dp_arr_bytes(int64_t n) { return (size_t)rup(n * 4, 256); }
+static size_t dp_mom_bytes(int64_t elems) { return (size_t)rup((2 * elems + 4) * 4, 256); }
 
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
   if (!h || !handle_out) return fail(GRL_ERR_INVALID, "null argument");
@@ -567,22 +570,28 @@ int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
   if (h->dp_buf) return fail(GRL_ERR_STATE, "grl_allreduce_init was already called on this handle");
   if (h->n_train % 4 || h->n_train * 4 >= (int64_t)1 << 31) return fail(GRL_ERR_STATE, "the gradient bucket is not a whole number of 16-byte groups below 2 GB");
   static_assert(sizeof(hipIpcMemHandle_t) == 64 && GRL_ALLREDUCE_HANDLE_BYTES == 128, "grl.h documents two 64-byte handles");
-  const size_t fbytes = DP_CHANNELS * dp_ctl_stride(), dbytes = 3 * dp_arr_bytes(h->n_train);   // src | red | gathered
-  // flags fine-grained: stores of a peer become visible to a kernel that is already running (and polling); the data
-  // ordinary device memory, ordered by the fences around the flags (csrc/dp_kernels.h)
+  const size_t fbytes = DP_CHANNELS * dp_ctl_stride();
+  const size_t dbytes = 3 * dp_arr_bytes(h->n_train) + 2 * dp_mom_bytes(h->n_elems);
+  // flags fine-grained: stores of a peer become visible to a kernel that is already running (and polling)
   hipError_t e = hipExtMallocWithFlags(&h->dp_flags, fbytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) { h->dp_flags = nullptr; return fail(GRL_ERR_HIP, std::string("exchange flags: ") + hipGetErrorString(e)); }
-  // the data as well unless GRL_DP_COARSE_DATA=1: the exchange kernels store it write-through and load it at system scope, so
-  // its caching policy costs nothing measurable on one GPU (225 us per update either way) and fine-grained is the
-  // conservative choice between GPUs
-  const char* cd = getenv("GRL_DP_COARSE_DATA");
-  e = (cd && atoi(cd)) ? hipMalloc(&h->dp_buf, dbytes) : hipExtMallocWithFlags(&h->dp_buf, dbytes, hipDeviceMallocFinegrained);
+  // the data as well unless GRL_TUNE dp_coarse=1: the exchange kernels store it write-through and load it at system scope,
+  // so its caching policy costs nothing measurable on one GPU and fine-grained is the conservative choice between GPUs
+  e = tune_int("dp_coarse", 0) ? hipMalloc(&h->dp_buf, dbytes) : hipExtMallocWithFlags(&h->dp_buf, dbytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
     (void)hipFree(h->dp_flags); h->dp_flags = nullptr; h->dp_buf = nullptr;
     return fail(GRL_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e));
   }
   HIPCHK(hipMemset(h->dp_flags, 0, fbytes));
   HIPCHK(hipMemset(h->dp_buf, 0, dbytes));
+  for (int k = 0; k < DP_CHANNELS; ++k) {     // the first exchange (epoch 1) uses source buffer 1
+    const uint32_t one = 1u;
+    HIPCHK(hipMemcpy((char*)h->dp_flags + k * dp_ctl_stride() + offsetof(DpCtl, next_buf), &one, 4, hipMemcpyHostToDevice));
+  }
+  if (!h->dp_err_host) {     // page-locked mailbox: a kernel that gives up waiting tells the host without a device read
+    HIPCHK(hipHostMalloc((void**)&h->dp_err_host, 64, 0));
+    *h->dp_err_host = 0u;
+  }
   HIPCHK(hipDeviceSynchronize());
   hipIpcMemHandle_t mh[2];
   e = hipIpcGetMemHandle(&mh[0], h->dp_flags);
@@ -602,13 +611,15 @@ static DpArgs dp_channel(grl_ctx* h, int channel, const std::vector<std::pair<in
                          char* const* data) {
   DpArgs d;
   memset(&d, 0, sizeof(d));
-  d.rank = h->dp.rank; d.world = h->dp.world; d.grads = h->grads;
+  d.rank = h->dp.rank; d.world = h->dp.world;
   d.n_ranges = (int)pieces.size();
   int64_t v = 0;
   for (size_t k = 0; k < pieces.size(); ++k) { d.start[k] = pieces[k].first; d.vstart[k] = v; v += pieces[k].second; }
   for (size_t k = pieces.size(); k <= DP_MAX_RANGES; ++k) d.vstart[k] = v;
   d.n = v;
-  d.chunk = rup((v + d.world - 1) / d.world, 4);
+  d.chunk = rup((v + d.world - 1) / d.world, 4);      // (the last ranks' chunks may be short or empty)
+  d.timeout_ticks = (uint64_t)std::max(1, tune_int("dp_timeout_ms", 120000)) * 100000ull;     // 100 MHz wall clock
+  d.host_err = h->dp_err_host;
   for (int p = 0; p < d.world; ++p) {
     d.ctl[p] = (DpCtl*)(flags[p] + (size_t)channel * dp_ctl_stride());
     d.src[p] = (float*)data[p];
@@ -616,54 +627,67 @@ static DpArgs dp_channel(grl_ctx* h, int channel, const std::vector<std::pair<in
   }
   return d;
 }
-// grids of the three exchange kernels (GRL_DP_BLOCKS=publish,reduce,apply overrides: tuning aid)
-static int dp_blocks(int which, int64_t quads, int dflt) {
+// grids of the exchange kernels (GRL_TUNE dp_blocks=reduce/gather/apply overrides: tuning aid).  Default: one quad per
+// thread, no grid-stride loop -- each thread issues its loads in one batch (measured: the looping 512-block form took
+// 19 us for the 5.4 MB bucket where the slab reduction with fused Adam, one quad per thread, takes 12)
+static int dp_blocks(int which, int64_t quads) {
   int v[3] = {0, 0, 0};
-  if (const char* e = getenv("GRL_DP_BLOCKS")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
-  const int cap = v[which] > 0 ? v[which] : dflt;
-  return (int)std::min<int64_t>(cap, std::max<int64_t>(1, (quads + 255) / 256));
+  tune_int3("dp_blocks", v);
+  const int64_t all = std::max<int64_t>(1, (quads + 255) / 256);
+  return (int)(v[which] > 0 ? std::min<int64_t>(v[which], all) : std::min<int64_t>(all, 4096));
 }
-// the reduction that ends a gradient computation, publishing its sums on channel `da` as it forms them
-static Op dp_reduce_publish_op(grl_ctx* self, const grl_ctx::ReducePlan& rp, const DpArgs& da, const char* tag) {
+// K1: the reduction that ends a gradient computation, publishing its sums on channel `da` as it forms them; with `ga`
+// it also carries the replay gather of the next update (multi-update calls on the device RNG)
+static Op dp_k1_op(grl_ctx* self, const grl_ctx::ReducePlan& rp, const DpArgs& da, const LossArgs& la, const GatherArgs* ga, int gx,
+                   const char* tag) {
   Op op; op.tag = tag; op.bytes = 8.0 * (double)da.n;
+  op.join = true;                                       // (takes the place of reduce_slabs, which joins the side lane)
   const ReduceDesc* dr = self->d_reduces;
-  const LossArgs la = self->loss_args;
   const AdamArgs aa = self->adam_base;
-  op.run = [dr, rp, la, aa, da](hipStream_t s) {
-    hipLaunchKernelGGL(dp_reduce_slabs_publish_kernel, dim3(rp.n + rp.has_loss), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da);
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  if (ga) g = *ga;
+  const int gxx = ga ? gx : 0;
+  op.run = [dr, rp, la, aa, da, g, gxx](hipStream_t s) {
+    const int nb = rp.n + rp.has_loss + (gxx > 0 ? gxx * g.B * 2 : 0);
+    hipLaunchKernelGGL(dp_reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da, g, gxx);
   };
-  return op;
-}
-static Op dp_publish_op(const DpArgs& da) {
-  Op op; op.tag = "dp_publish"; op.bytes = 8.0 * (double)da.n;
-  const int blocks = dp_blocks(0, da.n / 4, 256);
-  op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_publish_kernel, dim3(blocks), dim3(256), 0, s, da); };
   return op;
 }
 static Op dp_reduce_op(const DpArgs& da) {
   Op op; op.tag = "dp_reduce"; op.bytes = 4.0 * (double)da.chunk * (da.world + 1);
-  const int blocks = dp_blocks(1, da.chunk / 4, 256);
+  const int blocks = dp_blocks(0, da.chunk / 4);
   op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_reduce_kernel, dim3(blocks), dim3(256), 0, s, da); };
   return op;
 }
 static Op dp_gather_op(const DpArgs& da) {
   Op op; op.tag = "dp_gather"; op.bytes = 8.0 * (double)da.n;
-  const int blocks = dp_blocks(0, da.n / 4, 256);
+  const int blocks = dp_blocks(1, da.n / 4);
   op.run = [da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_gather_kernel, dim3(blocks), dim3(256), 0, s, da); };
   return op;
+}
+static AdamArgs dp_adam_args(grl_ctx* self, int world) {
+  AdamArgs aa;
+  memset(&aa, 0, sizeof(aa));
+  aa.params = self->params; aa.grads = nullptr; aa.m = self->adam_m; aa.v = self->adam_v;
+  aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f / (float)world; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
+  aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
+  return aa;
 }
 static Op dp_apply_op(grl_ctx* self, const DpArgs& da, const DpArgs& db) {
   Op op; op.tag = "dp_apply"; op.bytes = (double)self->n_train * 4 * 7 + (double)self->n_polyak * 4 * 2;
   op.join = true;
-  op.run = [self, da, db](hipStream_t s) {
-    AdamArgs aa;
-    memset(&aa, 0, sizeof(aa));
-    aa.params = self->params; aa.grads = nullptr; aa.m = self->adam_m; aa.v = self->adam_v;
-    aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = 1.f / (float)da.world; aa.tau = self->cfg.tau; aa.eps = 1e-8f;
-    aa.src_ofs = self->vf_off; aa.n_polyak = self->n_polyak; aa.target = self->params + self->tgt_off;
-    const int blocks = dp_blocks(2, self->n_train / 4, 512);
-    hipLaunchKernelGGL(dp_apply_kernel, dim3(blocks), dim3(256), 0, s, aa, da, db);
-  };
+  const AdamArgs aa = dp_adam_args(self, da.world);
+  const int blocks = dp_blocks(2, std::max(da.chunk, db.chunk) / 4);     // (a block walks the owners' chunks one after the other)
+  op.run = [aa, da, db, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_apply_kernel, dim3(blocks), dim3(256), 0, s, aa, da, db); };
+  return op;
+}
+static Op dp_apply_oneshot_op(grl_ctx* self, const DpArgs& da) {
+  Op op; op.tag = "dp_apply1"; op.bytes = (double)self->n_train * 4 * (6 + da.world) + (double)self->n_polyak * 4 * 2;
+  op.join = true;
+  const AdamArgs aa = dp_adam_args(self, da.world);
+  const int blocks = dp_blocks(2, da.n / 4);
+  op.run = [aa, da, blocks](hipStream_t s) { hipLaunchKernelGGL(dp_apply_oneshot_kernel, dim3(blocks), dim3(256), 0, s, aa, da); };
   return op;
 }
 
@@ -671,6 +695,8 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
   if (!h || !handles) return fail(GRL_ERR_INVALID, "null argument");
   if (!h->dp_buf) return fail(GRL_ERR_STATE, "call grl_allreduce_init first");
   if (h->dp_on) return fail(GRL_ERR_STATE, "already connected");
+  if (h->ops_grads.empty() || h->ops_grads.back().tag != "reduce_slabs" || !h->red_all.tiles)
+    return fail(GRL_ERR_STATE, "this plan does not end in the slab reduction the exchange publishes from");
   char* flags[DP_MAX_WORLD];
   char* data[DP_MAX_WORLD];
   for (int p = 0; p < h->dp.world; ++p) {
@@ -691,26 +717,37 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
   }
   DpArgs none;
   memset(&none, 0, sizeof(none));
-  // ---- the plain update: one exchange of the whole bucket behind the gradient computation
+  // ---- the plain update: one exchange of the whole bucket; the gradient computation's last launch publishes (K1)
   h->dp = dp_channel(h, 0, {{0, h->n_train}}, flags, data);
-  // (GRL_DP_FUSED_PUBLISH=1: the final reduction publishes its sums itself instead of a copy kernel behind it
-  // (dp_reduce_slabs_publish_kernel).  Bit-identical; MEASURED SLOWER on MI355X -- 25.7 us against 9.9 + 11.0, the update
-  // 232 against 225 us at world 1: 1 300 small blocks each ending in a drain + barrier + counter -- kept as a tested opt-in.)
-  const char* cp = getenv("GRL_DP_FUSED_PUBLISH");
-  const bool fused_publish = cp && atoi(cp) && h->red_all.tiles && !h->ops_grads.empty() && h->ops_grads.back().tag == "reduce_slabs";
-  h->dp_body.assign(h->ops_grads.begin(), h->ops_grads.end() - (fused_publish ? 1 : 0));
-  if (fused_publish) {
-    Op rp = dp_reduce_publish_op(h, h->red_all, h->dp, "reduce_publish");
-    rp.join = true;                                       // (takes the place of reduce_slabs, which joins the side lane)
-    h->ops_dp = {rp, dp_reduce_op(h->dp), dp_apply_op(h, h->dp, none)};
-  } else {
-    h->ops_dp = {dp_publish_op(h->dp), dp_reduce_op(h->dp), dp_apply_op(h, h->dp, none)};
+  DpArgs d1s = h->dp;
+  d1s.oneshot = 1;
+  h->dp_body.assign(h->ops_grads.begin(), h->ops_grads.end() - 1);
+  for (int one = 0; one < 2; ++one) {
+    const DpArgs& d = one ? d1s : h->dp;
+    std::vector<Op>& tail = one ? h->ops_dp1 : h->ops_dp;
+    tail.clear();
+    tail.push_back(dp_k1_op(h, h->red_all, d, h->loss_args, nullptr, 0, "reduce_publish"));
+    if (one) tail.push_back(dp_apply_oneshot_op(h, d));
+    else { tail.push_back(dp_reduce_op(d)); tail.push_back(dp_apply_op(h, d, none)); }
+    // multi-update calls on the device RNG: the same with the gather of the next update riding on K1 (plan_sac "prefetch")
+    std::vector<Op>* pf[3] = {one ? &h->ops_pfdp1_first : &h->ops_pfdp_first, one ? &h->ops_pfdp1_mid : &h->ops_pfdp_mid,
+                              one ? &h->ops_pfdp1_last : &h->ops_pfdp_last};
+    for (auto* v : pf) v->clear();
+    if (h->prefetch_ok) {
+      const std::vector<Op>* src[3] = {&h->ops_pf_first, &h->ops_pf_mid, &h->ops_pf_last};
+      for (int v = 0; v < 3; ++v) {
+        pf[v]->assign(src[v]->begin(), src[v]->end() - 1);
+        if (v == 2) pf[v]->push_back(dp_k1_op(h, h->red_all, d, h->loss_args, nullptr, 0, "reduce_publish"));
+        else pf[v]->push_back(dp_k1_op(h, h->red_all, d, h->pf_lk, &h->pf_g2, h->pf_gx, "reduce_publish"));
+        for (size_t k = 1; k < tail.size(); ++k) pf[v]->push_back(tail[k]);
+      }
+    }
   }
   // ---- the overlapped update (grl_allreduce_set_overlap): the staged plan (grl_compute_grads_staged) with both exchanges in
-  // the graph.  After heads_dfeat a SIDE LANE forms the dense layers' weight gradients, reduces them and exchanges them on
-  // channel 0 -- 90 % of the bytes -- while the main lane runs the backward through the convolutions and their weight
-  // gradients; the small convolution bucket follows on channel 1; Adam waits for both.  Same tiles, same sums: parameters
-  // are bit-identical to the plain update's.
+  // the graph.  After heads_dfeat a SIDE LANE forms the dense layers' weight gradients, reduces them (publishing) and
+  // exchanges them on channel 0 -- 90 % of the bytes -- while the main lane runs the backward through the convolutions and
+  // their weight gradients; the small convolution bucket follows on channel 1; Adam waits for both.  Same tiles, same
+  // sums: parameters are bit-identical to the plain update's.
   h->ops_dp_overlap.clear();
   if (h->staged_ok) {
     std::vector<std::pair<int64_t, int64_t>> dense, conv;
@@ -726,25 +763,30 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
     int cut = -1;
     for (size_t k = 0; k < h->ops_stage0.size(); ++k)
       if (h->ops_stage0[k].tag == "heads_dfeat") cut = (int)k;
+    ok = ok && h->ops_stage0.back().tag == "reduce_dense" && h->ops_stage1.back().tag == "reduce_conv";
     if (ok && cut >= 0) {
       DpArgs d0 = dp_channel(h, 0, dense, flags, data);
       const DpArgs d1 = dp_channel(h, 1, conv, flags, data);
-      d0.gathered = (float*)((char*)h->dp_buf + 2 * dp_arr_bytes(h->n_train));     // the side lane also pulls the dense sums
       std::vector<Op>& L = h->ops_dp_overlap;
       for (int k = 0; k <= cut; ++k) L.push_back(h->ops_stage0[k]);
       bool first = true;
       auto side = [&](Op o) { o.lane = 1; o.fork = first; o.join = false; first = false; L.push_back(o); };
-      const bool fp = fused_publish && h->ops_stage0.back().tag == "reduce_dense" && h->ops_stage1.back().tag == "reduce_conv";
-      for (size_t k = cut + 1; k + (fp ? 1 : 0) < h->ops_stage0.size(); ++k) side(h->ops_stage0[k]);     // wgrad_dense (, reduce_dense)
-      side(fp ? dp_reduce_publish_op(h, h->red_dense, d0, "reduce_dense_publish") : dp_publish_op(d0));
+      for (size_t k = cut + 1; k + 1 < h->ops_stage0.size(); ++k) side(h->ops_stage0[k]);     // wgrad_dense
+      side(dp_k1_op(h, h->red_dense, d0, h->loss_args, nullptr, 0, "reduce_dense_publish"));
       side(dp_reduce_op(d0));
+      d0.gathered = (float*)((char*)h->dp_buf + 2 * dp_arr_bytes(h->n_train));     // the side lane also pulls the dense sums
       side(dp_gather_op(d0));
-      for (size_t k = 0; k + (fp ? 1 : 0) < h->ops_stage1.size(); ++k) { Op o = h->ops_stage1[k]; o.join = false; L.push_back(o); }
-      L.push_back(fp ? dp_reduce_publish_op(h, h->red_conv, d1, "reduce_conv_publish") : dp_publish_op(d1));
+      for (size_t k = 0; k + 1 < h->ops_stage1.size(); ++k) { Op o = h->ops_stage1[k]; o.join = false; L.push_back(o); }
+      { Op o = dp_k1_op(h, h->red_conv, d1, h->loss_args, nullptr, 0, "reduce_conv_publish"); o.join = false; L.push_back(o); }
       L.push_back(dp_reduce_op(d1));
       L.push_back(dp_apply_op(h, d0, d1));       // (joins the side lane)
     }
   }
+  // ---- the running-statistics merge (grl_norm_update on a connected handle): channel 2, moment blocks behind the three arrays
+  memset(&h->dp_norm, 0, sizeof(h->dp_norm));
+  h->dp_norm.d = dp_channel(h, 2, {}, flags, data);
+  h->dp_norm.mom_stride = (int64_t)(dp_mom_bytes(h->n_elems) / 4);
+  for (int p = 0; p < h->dp.world; ++p) h->dp_norm.mom[p] = (float*)(data[p] + 3 * dp_arr_bytes(h->n_train));
   h->dp_on = true;
   return GRL_OK;
 }
@@ -757,28 +799,42 @@ int grl_allreduce_set_overlap(grl_handle h, int on) {
   return GRL_OK;
 }
 
+int grl_allreduce_set_mode(grl_handle h, int mode) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
+  if (mode < 0 || mode > 2) return fail(GRL_ERR_INVALID, "mode: 0 auto, 1 two-shot, 2 one-shot");
+  h->dp_mode = mode;
+  return GRL_OK;
+}
+
 int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps) {
   if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
+  if (*h->dp_err_host) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
+  // one-shot (every rank adds all contributions itself: one kernel and one flag round less, (W - 1) n bytes per rank
+  // instead of 2 (W - 1) / W n) pays for W <= 2
+  const bool one = !h->dp_overlap && (h->dp_mode == 2 || (h->dp_mode == 0 && h->dp.world <= 2));
   std::vector<Op> none;
   std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->dp_body;
-  std::vector<Op>* tail = h->dp_overlap ? &none : &h->ops_dp;
+  std::vector<Op>* tail = h->dp_overlap ? &none : (one ? &h->ops_dp1 : &h->ops_dp);
+  const std::string sfx = one ? "1" : "";
   const char* npf = getenv("GRL_NO_GATHER_PREFETCH");
-  if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !h->ops_pfdp_mid.empty() && !(npf && atoi(npf)) &&
-      h->ops_dp.size() == 3 && h->ops_dp[0].tag == "dp_publish") {
+  std::vector<Op>* pf[3] = {one ? &h->ops_pfdp1_first : &h->ops_pfdp_first, one ? &h->ops_pfdp1_mid : &h->ops_pfdp_mid,
+                            one ? &h->ops_pfdp1_last : &h->ops_pfdp_last};
+  if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !pf[1]->empty() && !(npf && atoi(npf))) {
     // plain exchange on the device RNG: the prefetching sequences (the gather of update t+1 rides on the reduction of update t)
-    if (int e = h->run_seq("dpp_first", {&h->ops_pfdp_first, &h->ops_dp})) return e;
+    if (int e = h->run_seq("dpp_first" + sfx, {pf[0]})) return e;
     if (n_steps > 2)
-      if (int e = h->run_repeated("dpp_mid", {&h->ops_pfdp_mid, &h->ops_dp}, n_steps - 2)) return e;
-    if (int e = h->run_seq("dpp_last", {&h->ops_pfdp_last, &h->ops_dp})) return e;
+      if (int e = h->run_repeated("dpp_mid" + sfx, {pf[1]}, n_steps - 2)) return e;
+    if (int e = h->run_seq("dpp_last" + sfx, {pf[2]})) return e;
   } else if (!idx) {      // device RNG: identical updates, several to a graph
-    if (int e = h->run_repeated(h->dp_overlap ? "dpo_rng" : "dp_rng", {&h->ops_rng, body, tail}, n_steps)) return e;
+    if (int e = h->run_repeated((h->dp_overlap ? "dpo_rng" : "dp_rng") + sfx, {&h->ops_rng, body, tail}, n_steps)) return e;
   } else {
     for (int s = 0; s < n_steps; ++s) {
       if (int e = stage_noise(h, idx, eps, s)) return e;
-      if (int e = h->run_seq(h->dp_overlap ? "dpo_explicit" : "dp_explicit", {&h->ops_gather, body, tail})) return e;
+      if (int e = h->run_seq((h->dp_overlap ? "dpo_explicit" : "dp_explicit") + sfx, {&h->ops_gather, body, tail})) return e;
     }
   }
   HIPCHK(hipGetLastError());
@@ -792,7 +848,8 @@ int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error) {
   for (int k = 0; k < DP_CHANNELS; ++k)
     HIPCHK(hipMemcpy(&c[k], (char*)h->dp_flags + k * dp_ctl_stride(), sizeof(DpCtl), hipMemcpyDeviceToHost));
   if (exchanges) *exchanges = c[0].epoch;          // (channel 0 takes part in every update, plain or overlapped)
-  const int err = (int)(c[0].error | c[1].error);
+  int err = h->dp_err_host ? (int)*h->dp_err_host : 0;
+  for (int k = 0; k < DP_CHANNELS; ++k) err |= (int)c[k].error;
   if (error) *error = err;
   if (err) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
   return GRL_OK;

@@ -1,48 +1,53 @@
 // dp_kernels.h -- the one exchange step of the data-parallel update (the gradient bucket of every rank
-// summed, the mean applied by every replica) as a hand-written two-shot all-reduce over peer-mapped memory, inside the
-// update's hipGraph -- no host round trip and no collective library call per update.  RCCL (grasp_rl/parallel.py)
-// stays as the baseline path.
+// summed, the mean applied by every replica) as hand-written all-reduces over peer-mapped memory, inside the update's
+// hipGraph -- no host round trip and no collective library call per update.  RCCL (grasp_rl/parallel.py) stays as the
+// baseline path.  Also here: the cross-rank merge of the VecNormalize running statistics kept on the device (8e: the
+// per-pixel (count, mean, var) of every rank's env-step batch, Chan-merged in rank order by every replica).
 //
-// Every rank owns TWO allocations (flags, data), both exported with hipIpcGetMemHandle and mapped by all peers (over xGMI between the
-// GPUs of a node; two processes on one GPU map each other's buffers the same way):
+// Every rank owns TWO allocations (flags, data), both exported with hipIpcGetMemHandle and mapped by all peers (over xGMI
+// between the GPUs of a node; several processes on one GPU map each other's buffers the same way):
 //
 //   flags (fine-grained, a few hundred bytes): per channel (DpCtl)
-//       ready[p]  written by rank p (remotely) once its gradients of exchange e sit in ITS src          -> e
-//       done[q]   written by rank q (remotely) once the sums of ITS chunk of exchange e sit in ITS red  -> e
-//       epoch (completed exchanges), error, block counters
-//   data: src[n] this rank's gradients as published, red[n] the sums of the chunk this rank owns, gathered[n] (overlapped
-//       update).  Stored write-through and loaded at system scope (below), so its caching policy does not matter to the
-//       kernels: fine-grained by default (the conservative choice between GPUs), ordinary device memory with
-//       GRL_DP_COARSE_DATA=1 -- 226 us per update either way on one MI355X.  (Round 3 first fenced every access instead:
-//       5.4 MB then took 53 us to publish, 31 us to reduce and 28 us to apply; it was the fences, not the memory type.)
+//       epoch     exchanges begun on this channel (advanced by the exchange's first kernel)
+//       ready[p]  written by rank p (remotely): its contribution to exchange e sits in ITS source array          -> e
+//       done[q]   written by rank q (remotely): the sums of ITS chunk of exchange e sit in ITS red array         -> e
+//       error     a bounded wait ran out, here or on a peer (sticky, poisons every rank)
+//   data: three bucket-shaped arrays per rank: src | red | gathered
 //
-//   publish   grads -> src (16-byte copies); the last block stores ready[me] = e into every rank's flags
-//   reduce    reduce-scatter: rank r owns chunk r = [r*c, (r+1)*c); it waits for ready[*] == e and adds the chunk of all
-//             ranks IN RANK ORDER (remote 16-byte loads; one rank forms each sum, so every replica receives the same bits,
-//             whatever the arrival order) into ITS red; its last block then stores done[r] = e everywhere
-//   apply     all-gather by PULL fused with Adam + Polyak: after done[*] == e every rank reads each sum from the red of the
-//             chunk's owner (grad_scale 1 / world) -- nothing is written remotely but flags; its last block advances epoch
+// Two-shot exchange (any world size; bytes per rank 2 (W-1)/W n):
+//   K1  the last launch of the gradient computation (the slab reduction that forms every gradient) stores each sum
+//       write-through into THIS rank's src as it forms it -- no copy kernel; one thread advances the epoch
+//   K2  reduce-scatter: announces ready[me] = e to every rank, waits for ready[*] >= e, adds chunk me of all ranks IN RANK
+//       ORDER (remote 16-byte loads; one rank forms each sum, so every replica receives the same bits) into ITS red
+//   K3  all-gather by PULL fused with Adam + Polyak: announces done[me] = e, waits for done[*] >= e, reads each sum from
+//       the red of the chunk's owner (grad_scale 1 / world) -- nothing is ever written remotely but flags
+// One-shot exchange (small worlds; bytes per rank (W-1) n, one flag round and one kernel less):
+//   K1  as above into source buffer e & 1 (src / red alternate: a rank overwrites the buffer of exchange e - 2 only after
+//       ready[*] >= e - 1, i.e. after every peer finished reading it -- no second flag round needed)
+//   K2' announces ready, waits, and every rank adds all W contributions of every element in rank order inside Adam
 //
-// A rank overwrites its src for exchange e+1 only after done[*] == e, i.e. after every owner finished reading it; an owner
-// overwrites its red only after ready[*] == e+1, i.e. after every rank's apply of e (stream order on that rank).
-// Visibility: exchanged data is stored write-through and loaded past the caches (see dp_st_sys / dp_ld_sys below).
-// Waits are BOUNDED (a peer that never arrives sets error, which the host reports -- the kernels never hang).
+// A flag is stored by the FIRST thread of the kernel that follows the data it announces: a kernel boundary on one stream
+// (or graph edge) completes and drains every write-through store of the kernel before it, so no block counts itself in,
+// no block drains or fences (round 3 ended every data kernel with drain + barrier + atomic per block and a last-block
+// election: 11 + 10.5 + 19 us for 5.4 MB).  Exchanged data is stored WRITE-THROUGH (buffer stores with sc0 | sc1) and
+// loaded past the caches (sc0 | sc1 loads): nothing stays dirty in an L2 and nothing stale is read from one
+// (cdna_hip_programming.md, Guideline 16, at SYSTEM scope because the other side may be another GPU).
+// Waits are BOUNDED by the 100 MHz wall clock (GRL_TUNE dp_timeout_ms, default 120 s -- like a collective library a rank
+// simply waits for a peer that is late, e.g. one running an evaluation callback); a rank that gives up raises `error`
+// on EVERY rank and in a host-visible mailbox, and stops announcing, so that no replica applies a partial exchange
+// silently: grl_train_step_allreduce / grl_allreduce_status fail on every rank.
 #pragma once
 #include "elem_kernels.h"
 
 namespace grl {
 
-enum { DP_MAX_WORLD = 16, DP_SPIN_LIMIT = 1 << 22, DP_MAX_RANGES = 6, DP_CHANNELS = 2 };
+enum { DP_MAX_WORLD = 16, DP_MAX_RANGES = 6, DP_CHANNELS = 3 };   // channel 2: running-statistics merge (dp_norm_*)
 
-// One CHANNEL = one independent exchange with its own flags (a buffer carries DP_CHANNELS of them).  The plain update uses
-// channel 0 over the whole bucket.  The overlapped update (engine.hip, grl_allreduce_set_overlap) exchanges the dense
-// layers' gradients on channel 0 from a side lane of the graph while the convolution backward runs, then the
-// convolution gradients on channel 1; the apply kernel waits for both.
 struct DpCtl {
-  uint32_t epoch;        // completed exchanges of this channel
-  uint32_t error;        // 1: a bounded wait ran out
-  uint32_t cnt_publish, cnt_reduce, cnt_apply;
-  uint32_t pad[3];
+  uint32_t epoch;        // exchanges begun on this channel
+  uint32_t error;        // 1: a bounded wait ran out (here, or on a peer that then poisoned this rank)
+  uint32_t next_buf;     // one-shot: source buffer of the NEXT exchange (written by K2', read by K1)
+  uint32_t pad[5];
   uint32_t ready[DP_MAX_WORLD];
   uint32_t done[DP_MAX_WORLD];
 };
@@ -50,25 +55,17 @@ struct DpCtl {
 // What a channel moves: up to DP_MAX_RANGES pieces of the flat bucket (offsets and lengths multiples of 4 floats), seen
 // as one VIRTUAL array of n floats that is cut into world chunks.  vstart[r] = virtual position of piece r (vstart[n_ranges] = n).
 struct DpArgs {
-  int rank, world, n_ranges, pad_;
+  int rank, world, n_ranges, oneshot;
   int64_t n, chunk;                 // virtual floats; virtual floats per rank chunk (multiple of 4)
   int64_t start[DP_MAX_RANGES], vstart[DP_MAX_RANGES + 1];
-  const float* grads;               // this rank's gradient bucket (caller's grads arena)
+  uint64_t timeout_ticks;           // bound of every wait, in ticks of the 100 MHz wall clock
+  uint32_t* host_err;               // page-locked mailbox of THIS rank's host: set when a wait ran out or a peer poisoned us
   DpCtl* ctl[DP_MAX_WORLD];         // this channel's flags in the exchange buffers of all ranks as mapped HERE ([rank] = own)
   float* src[DP_MAX_WORLD];         // bucket-shaped arrays of all ranks: gradients as published
-  float* red[DP_MAX_WORLD];         //                                    the sums of the chunk the rank owns
+  float* red[DP_MAX_WORLD];         //   two-shot: the sums of the chunk the rank owns; one-shot: the second source buffer
   float* gathered;                  // local bucket-shaped array holding every sum of this channel (dp_gather_kernel), or nullptr
 };
 
-// How data and flags travel (cdna_hip_programming.md, Guideline 16, "publish / consume"; here at SYSTEM scope because the
-// other side may be another GPU):
-//   * exchanged data is stored WRITE-THROUGH (buffer stores with sc0 | sc1): nothing stays dirty in an L2, so no block needs
-//     a release fence (an L2 write-back per block -- issued by every wave it cost 50 us per 5 MB kernel, by one thread per
-//     block still 13 us); every storing wave drains its stores (s_waitcnt vmcnt(0)), the block's barrier follows, ONE thread
-//     counts the block in with a relaxed device-scope atomic, and the last block of the grid stores the flags;
-//   * exchanged data is loaded with system-scope loads (sc0 | sc1: they are served from memory, never from a stale line), so
-//     no block needs an acquire fence (a cache invalidation per block) either;
-//   * flags are polled by ONE thread per block with relaxed loads.
 #ifdef GRL_HOSTEMU
 struct dp_f4 {     // (g++ has no ext_vector_type)
   float v[4];
@@ -78,12 +75,8 @@ static inline dp_f4 dp_ld_sys(const float* base, int64_t qd) { return ((const dp
 static inline void dp_st_sys(float* base, int64_t qd, const dp_f4& v) { ((dp_f4*)base)[qd] = v; }
 static inline uint32_t dp_load_flag(const uint32_t* p) { return *p; }
 static inline void dp_store_flag(uint32_t* p, uint32_t v) { *p = v; }
-static inline bool dp_block_done(uint32_t* counter) {
-  if (threadIdx.x != 0) return false;
-  if (++*counter != gridDim.x) return false;
-  *counter = 0u;
-  return true;
-}
+static inline uint64_t dp_clock() { static uint64_t t = 0; return t += 1000; }   // (every poll "takes" 10 us)
+static inline void dp_sleep() {}
 #else
 typedef float dp_f4 __attribute__((ext_vector_type(4)));
 enum { DP_SYS = 1 | 16 };     // buffer-instruction cache policy: sc0 | sc1 = system scope
@@ -105,30 +98,35 @@ __device__ __forceinline__ uint32_t dp_load_flag(const uint32_t* p) {
 __device__ __forceinline__ void dp_store_flag(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// End of a block's data phase.  Returns true in thread 0 of the last block of the grid (which then stores the flags).
-__device__ __forceinline__ bool dp_block_done(uint32_t* counter) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave: its write-through stores have reached memory
-  __syncthreads();
-  if (threadIdx.x != 0) return false;
-  const uint32_t old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old != gridDim.x - 1) return false;
-  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
+__device__ __forceinline__ uint64_t dp_clock() { return wall_clock64(); }
+__device__ __forceinline__ void dp_sleep() { __builtin_amdgcn_s_sleep(8); }
+#endif
+
+// this rank gives up: sticky error here, on every peer and in the host's mailbox
+__device__ __forceinline__ void dp_fail(const DpArgs& a) {
+  for (int p = 0; p < a.world; ++p) dp_store_flag(&a.ctl[p]->error, 1u);
+  if (a.host_err) dp_store_flag(a.host_err, 1u);
 }
-#endif
-// thread 0 of the block waits until flags[0 .. world) >= target; false on time-out (error flag set)
-__device__ __forceinline__ bool dp_wait_all(DpCtl* mine, const uint32_t* flags, int world, uint32_t target) {
-  bool ok = true;
-  for (int p = 0; p < world && ok; ++p) {
-    int spins = 0;
+// one thread: announce `mine[rank] = e` in every rank's flags -- unless this rank has already failed
+__device__ __forceinline__ void dp_announce(const DpArgs& a, bool ready, uint32_t e) {
+  if (dp_load_flag(&a.ctl[a.rank]->error)) { if (a.host_err) dp_store_flag(a.host_err, 1u); return; }
+  for (int p = 0; p < a.world; ++p) dp_store_flag(ready ? &a.ctl[p]->ready[a.rank] : &a.ctl[p]->done[a.rank], e);
+}
+// one thread: wait until flags[0 .. world) >= target; false when the wait ran out or the channel is poisoned
+__device__ __forceinline__ bool dp_wait_all(const DpArgs& a, const uint32_t* flags, uint32_t target) {
+  DpCtl* mine = a.ctl[a.rank];
+  const uint64_t t0 = dp_clock();
+  for (int p = 0; p < a.world; ++p) {
+    int polls = 0;
     while ((int32_t)(dp_load_flag(flags + p) - target) < 0) {
-      if (++spins > DP_SPIN_LIMIT) { mine->error = 1u; ok = false; break; }
-#ifndef GRL_HOSTEMU
-      __builtin_amdgcn_s_sleep(8);
-#endif
+      if ((++polls & 63) == 0) {
+        if (dp_load_flag(&mine->error)) { if (a.host_err) dp_store_flag(a.host_err, 1u); return false; }
+        if (dp_clock() - t0 > a.timeout_ticks) { dp_fail(a); return false; }
+      }
+      dp_sleep();
     }
   }
-  return ok;
+  return dp_load_flag(&mine->error) == 0u;
 }
 // virtual quad (4-float group) -> quad of the bucket
 __device__ __forceinline__ int64_t dp_quad(const DpArgs& a, int64_t vq) {
@@ -138,60 +136,62 @@ __device__ __forceinline__ int64_t dp_quad(const DpArgs& a, int64_t vq) {
   return (a.start[r] + (v - a.vstart[r])) >> 2;
 }
 
-__global__ __launch_bounds__(256) void dp_publish_kernel(DpArgs a) {
+// K1: the launch that ends a gradient computation (reduce_slabs_kernel: every trainable element = the sum of its
+// split-reduction slabs; the loss workgroup forms the entropy coefficient's gradient) publishing what it sums: each sum
+// also goes, write-through, into this rank's source array.  The pieces of the channel are exactly what the launch's
+// descriptors cover.  Optionally carries the replay gather of the next update like reduce_slabs_gather_kernel (gx > 0).
+// Block 0 advances the channel's epoch (no thread of this launch reads it).
+__global__ __launch_bounds__(256) void dp_reduce_slabs_kernel(const ReduceDesc* __restrict__ descs, const int2* __restrict__ tiles,
+                                                             int n_tiles, LossArgs la, int has_loss, AdamArgs aa, DpArgs a,
+                                                             GatherArgs ga, int gx) {
   DpCtl* mine = a.ctl[a.rank];
-  const uint32_t e = mine->epoch + 1u;
-  const int64_t n4 = a.n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const int64_t qd = dp_quad(a, i);
-    dp_st_sys(a.src[a.rank], qd, ((const dp_f4*)a.grads)[qd]);
+  float* out = (a.oneshot && (mine->next_buf & 1u)) ? a.red[a.rank] : a.src[a.rank];
+  const long nb = n_tiles + has_loss, total = (long)gridDim.x, x = (long)blockIdx.x;
+  const long before = x * nb / total, upto = (x + 1) * nb / total;     // (gx == 0: total == nb, every block reduces)
+  if (upto > before) {
+    reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, 0, (int)before, out);
+    if (has_loss && (int)before == n_tiles) {
+      __syncthreads();
+      if (threadIdx.x == 0) st_sys_f1(out + (la.g_log_ent_coef - aa.grads), la.g_log_ent_coef[0]);
+    }
+    if (before == 0 && threadIdx.x == 0) mine->epoch = mine->epoch + 1u;
+    return;
   }
-  if (dp_block_done(&mine->cnt_publish))
-    for (int p = 0; p < a.world; ++p) dp_store_flag(&a.ctl[p]->ready[a.rank], e);
+  const int r = (int)(x - before);
+  gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
 }
 
-// The last launch of the gradient computation (reduce_slabs_kernel: every trainable element = the sum of its split-reduction
-// slabs; the loss workgroup forms the entropy coefficient's gradient) publishing what it sums: each sum also goes, write-through,
-// into this rank's src -- no copy kernel.  The pieces of the channel are exactly what the launch's descriptors cover.
-__global__ __launch_bounds__(256) void dp_reduce_slabs_publish_kernel(const ReduceDesc* __restrict__ descs, const int2* __restrict__ tiles,
-                                                                     int n_tiles, LossArgs la, int has_loss, AdamArgs aa, DpArgs a) {
-  DpCtl* mine = a.ctl[a.rank];
-  const uint32_t e = mine->epoch + 1u;
-  reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, 0, (int)blockIdx.x, a.src[a.rank]);
-  if (has_loss && (int)blockIdx.x == n_tiles) {
-    __syncthreads();
-    if (threadIdx.x == 0) st_sys_f1(a.src[a.rank] + (la.g_log_ent_coef - aa.grads), la.g_log_ent_coef[0]);
-  }
-  if (dp_block_done(&mine->cnt_publish))
-    for (int p = 0; p < a.world; ++p) dp_store_flag(&a.ctl[p]->ready[a.rank], e);
-}
-
+// K2 (two-shot)
 __global__ __launch_bounds__(256) void dp_reduce_kernel(DpArgs a) {
   DpCtl* mine = a.ctl[a.rank];
-  const uint32_t e = mine->epoch + 1u;
+  const uint32_t e = mine->epoch;
   __shared__ int ok_s;
-  if (threadIdx.x == 0) ok_s = dp_wait_all(mine, mine->ready, a.world, e) ? 1 : 0;
-  __syncthreads();
-  const int64_t lo = (int64_t)a.rank * a.chunk, hi = min(a.n, lo + a.chunk);
-  if (ok_s) {
-    const int64_t q0 = lo >> 2, q1 = hi >> 2;      // (n, chunk and every piece are multiples of 4 floats)
-    for (int64_t i = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (int64_t)gridDim.x * 256) {
-      const int64_t qd = dp_quad(a, i);
-      dp_f4 s = dp_ld_sys(a.src[0], qd);
-      for (int p = 1; p < a.world; ++p) s += dp_ld_sys(a.src[p], qd);
-      dp_st_sys(a.red[a.rank], qd, s);
-    }
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) { dp_announce(a, true, e); mine->next_buf = (e + 1u) & 1u; }     // (next_buf: kept in step for a later one-shot exchange)
+    ok_s = dp_wait_all(a, mine->ready, e) ? 1 : 0;
   }
-  if (dp_block_done(&mine->cnt_reduce))
-    for (int q = 0; q < a.world; ++q) dp_store_flag(&a.ctl[q]->done[a.rank], e);
+  __syncthreads();
+  if (!ok_s) return;
+  const int64_t lo = (int64_t)a.rank * a.chunk, hi = min(a.n, lo + a.chunk);
+  const int64_t q0 = lo >> 2, q1 = hi >> 2;      // (n, chunk and every piece are multiples of 4 floats; an empty chunk: q0 >= q1)
+  for (int64_t i = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (int64_t)gridDim.x * 256) {
+    const int64_t qd = dp_quad(a, i);
+    dp_f4 s = dp_ld_sys(a.src[0], qd);
+    for (int p = 1; p < a.world; ++p) s += dp_ld_sys(a.src[p], qd);
+    dp_st_sys(a.red[a.rank], qd, s);
+  }
 }
 
 // All-gather half of a channel as a kernel of its own (the overlapped update runs it on the side lane, so that the pull over
 // xGMI is hidden as well): every sum from the red array of its chunk's owner into this rank's `gathered` array.
 __global__ __launch_bounds__(256) void dp_gather_kernel(DpArgs d) {
   DpCtl* mine = d.ctl[d.rank];
+  const uint32_t e = mine->epoch;
   __shared__ int ok_s;
-  if (threadIdx.x == 0) ok_s = dp_wait_all(mine, mine->done, d.world, mine->epoch + 1u) ? 1 : 0;
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) dp_announce(d, false, e);
+    ok_s = dp_wait_all(d, mine->done, e) ? 1 : 0;
+  }
   __syncthreads();
   if (!ok_s) return;
   const int64_t n4 = d.n >> 2, c4 = d.chunk >> 2;
@@ -202,63 +202,145 @@ __global__ __launch_bounds__(256) void dp_gather_kernel(DpArgs d) {
     }
 }
 
-// Adam + Polyak of adam_polyak_kernel on the sums, each read from the red array of its chunk's owner (grad_scale = 1 / world).
-// d: the channel whose counters pace the launch (0); d2: a second channel (overlapped update), or world = 0.  The pieces of
-// the two channels partition the trainable bucket.
+// Adam + Polyak of adam_polyak_kernel on one quad of sums
+__device__ __forceinline__ void dp_adam_quad(const AdamArgs& a, int64_t qd, const dp_f4& g4, float alpha) {
+  const int64_t e0 = qd << 2;
+  dp_f4 m4 = *(const dp_f4*)(a.m + e0), v4 = *(const dp_f4*)(a.v + e0), p4 = *(const dp_f4*)(a.params + e0);
+#ifdef GRL_HOSTEMU
+  const float* gp = g4.v; float* mp = m4.v; float* vp = v4.v; float* pp = p4.v;
+#else
+  const float gp[4] = {g4.x, g4.y, g4.z, g4.w};
+  float mp[4] = {m4.x, m4.y, m4.z, m4.w}, vp[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#endif
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    adam_elem(grad_scaled(gp[u], a.grad_scale), pp[u], mp[u], vp[u], alpha, a.eps);
+    const int64_t k = e0 + u - a.src_ofs;
+    if (k >= 0 && k < a.n_polyak) a.target[k] = polyak_elem(a.target[k], pp[u], a.tau);
+  }
+#ifndef GRL_HOSTEMU
+  m4 = dp_f4{mp[0], mp[1], mp[2], mp[3]}; v4 = dp_f4{vp[0], vp[1], vp[2], vp[3]}; p4 = dp_f4{pp[0], pp[1], pp[2], pp[3]};
+#endif
+  *(dp_f4*)(a.m + e0) = m4; *(dp_f4*)(a.v + e0) = v4; *(dp_f4*)(a.params + e0) = p4;
+}
+
+// the sums of one channel, each read from the red array of its chunk's owner (or from `gathered`), applied
 __device__ __forceinline__ void dp_apply_channel(const AdamArgs& a, const DpArgs& d, float alpha) {
   const int64_t n4 = d.n >> 2, c4 = d.chunk >> 2;
   for (int owner = 0; owner < d.world; ++owner)      // (one owner at a time: the array a wave loads from is wave-uniform)
-  for (int64_t i = owner * c4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < min(n4, (owner + 1) * c4); i += (int64_t)gridDim.x * 256) {
-    const int64_t qd = dp_quad(d, i);
-    const dp_f4 g4 = d.gathered ? ((const dp_f4*)d.gathered)[qd] : dp_ld_sys(d.red[owner], qd);
-    const int64_t e0 = qd << 2;
-    dp_f4 m4 = *(const dp_f4*)(a.m + e0), v4 = *(const dp_f4*)(a.v + e0), p4 = *(const dp_f4*)(a.params + e0);
-#ifdef GRL_HOSTEMU
-    float* gp = (float*)g4.v; float* mp = m4.v; float* vp = v4.v; float* pp = p4.v;
-#else
-    const float gp[4] = {g4.x, g4.y, g4.z, g4.w};
-    float mp[4] = {m4.x, m4.y, m4.z, m4.w}, vp[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
-#endif
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      adam_elem(grad_scaled(gp[u], a.grad_scale), pp[u], mp[u], vp[u], alpha, a.eps);
-      const int64_t k = e0 + u - a.src_ofs;
-      if (k >= 0 && k < a.n_polyak) a.target[k] = polyak_elem(a.target[k], pp[u], a.tau);
+    for (int64_t i = owner * c4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < min(n4, (owner + 1) * c4); i += (int64_t)gridDim.x * 256) {
+      const int64_t qd = dp_quad(d, i);
+      dp_adam_quad(a, qd, d.gathered ? ((const dp_f4*)d.gathered)[qd] : dp_ld_sys(d.red[owner], qd), alpha);
     }
-#ifndef GRL_HOSTEMU
-    m4 = dp_f4{mp[0], mp[1], mp[2], mp[3]}; v4 = dp_f4{vp[0], vp[1], vp[2], vp[3]}; p4 = dp_f4{pp[0], pp[1], pp[2], pp[3]};
-#endif
-    *(dp_f4*)(a.m + e0) = m4; *(dp_f4*)(a.v + e0) = v4; *(dp_f4*)(a.params + e0) = p4;
-  }
 }
 
+// K3 (two-shot).  d: a channel whose sums are pulled here (or, with d.gathered set, were pulled by dp_gather_kernel on the
+// side lane: nothing to wait for); d2: a second channel (overlapped update), or world = 0.  The pieces of the two channels
+// partition the trainable bucket.
 __global__ __launch_bounds__(256) void dp_apply_kernel(AdamArgs a, DpArgs d, DpArgs d2) {
-  DpCtl* mine = d.ctl[d.rank];
-  const uint32_t e = mine->epoch + 1u;
   __shared__ int ok_s;
   if (threadIdx.x == 0) {
-    bool ok = dp_wait_all(mine, mine->done, d.world, e);
-    if (ok && d2.world > 0) {
+    bool ok = true;
+    if (!d.gathered) {
+      DpCtl* m1 = d.ctl[d.rank];
+      if (blockIdx.x == 0) dp_announce(d, false, m1->epoch);
+      ok = dp_wait_all(d, m1->done, m1->epoch);
+    } else {
+      ok = dp_load_flag(&d.ctl[d.rank]->error) == 0u;
+    }
+    if (d2.world > 0) {
       DpCtl* m2 = d2.ctl[d2.rank];
-      ok = dp_wait_all(m2, m2->done, d2.world, m2->epoch + 1u);
+      if (blockIdx.x == 0) dp_announce(d2, false, m2->epoch);
+      ok = dp_wait_all(d2, m2->done, m2->epoch) && ok;
     }
     ok_s = ok ? 1 : 0;
   }
   __syncthreads();
-  if (ok_s) {
-    const float alpha = a.sc->adam_alpha;
-    dp_apply_channel(a, d, alpha);
-    if (d2.world > 0) dp_apply_channel(a, d2, alpha);
+  if (!ok_s) return;
+  const float alpha = a.sc->adam_alpha;
+  dp_apply_channel(a, d, alpha);
+  if (d2.world > 0) dp_apply_channel(a, d2, alpha);
+}
+
+// K2' (one-shot): every rank adds the W contributions of every element in rank order and applies the mean
+__global__ __launch_bounds__(256) void dp_apply_oneshot_kernel(AdamArgs a, DpArgs d) {
+  DpCtl* mine = d.ctl[d.rank];
+  const uint32_t e = mine->epoch;
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) { dp_announce(d, true, e); mine->next_buf = (e + 1u) & 1u; }
+    ok_s = dp_wait_all(d, mine->ready, e) ? 1 : 0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t old = atomicAdd(&mine->cnt_apply, 1u);
-    if (old == gridDim.x - 1) {
-      mine->cnt_apply = 0u;
-      mine->epoch = e;        // read again only by the next exchange's kernels (stream order)
-      if (d2.world > 0) { DpCtl* m2 = d2.ctl[d2.rank]; m2->epoch = m2->epoch + 1u; }
-    }
+  if (!ok_s) return;
+  const float alpha = a.sc->adam_alpha;
+  const bool odd = (e & 1u) != 0u;
+  const int64_t n4 = d.n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t qd = dp_quad(d, i);
+    dp_f4 s = dp_ld_sys(odd ? d.red[0] : d.src[0], qd);
+    for (int p = 1; p < d.world; ++p) s += dp_ld_sys(odd ? d.red[p] : d.src[p], qd);
+    dp_adam_quad(a, qd, s, alpha);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Running observation statistics of VecNormalize kept on the device, merged over the ranks: every rank's
+// env-step batch gives per-element float32 moments (np.mean / np.var over its n observations, exactly as
+// norm_update_kernel forms them); every replica then merges the W batches into its float64 running statistics IN RANK
+// ORDER with the Chan update -- the arithmetic of grasp_rl.parallel.share_running_stats on the host (moments widened to
+// float64 before they travel), so the replicas stay bit-identical to each other and to the host path.  Exchange memory: a
+// fourth region of the data allocation, two moment blocks [mean f32 x elems | var f32 x elems | n] alternating by epoch
+// (a block is overwritten two exchanges later, after ready[*] of the exchange in between: every peer has merged it).
+struct DpNormArgs {
+  DpArgs d;                  // channel 2: flags only (n, chunk, ranges unused)
+  NormUpdateArgs nu;         // the local update's arguments (obs staged, running statistics, derived arrays)
+  float* mom[DP_MAX_WORLD];  // every rank's pair of moment blocks as mapped here
+  int64_t mom_stride;        // floats between the two blocks
+};
+
+// N1: this rank's batch moments into its moment block (write-through); thread 0 advances the epoch
+__global__ __launch_bounds__(256) void dp_norm_moments_kernel(DpNormArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const NormUpdateArgs& u = a.nu;
+  DpCtl* mine = a.d.ctl[a.d.rank];
+  float* out = a.mom[a.d.rank] + (int64_t)(mine->next_buf & 1u) * a.mom_stride;
+  if (i < u.elems) {
+    float bm, bv;
+    norm_batch_moments(u, i, bm, bv);
+    st_sys_f1(out + i, bm);
+    st_sys_f1(out + u.elems + i, bv);
+  }
+  if (i == 0) {
+    st_sys_f1(out + 2 * (int64_t)u.elems, (float)u.n);
+    mine->epoch = mine->epoch + 1u;
+  }
+}
+// N2: wait for every rank's moments, merge them in rank order, refresh the derived arrays
+__global__ __launch_bounds__(256) void dp_norm_merge_kernel(DpNormArgs a) {
+  DpCtl* mine = a.d.ctl[a.d.rank];
+  const uint32_t e = mine->epoch;
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) { dp_announce(a.d, true, e); mine->next_buf = (e + 1u) & 1u; }
+    ok_s = dp_wait_all(a.d, mine->ready, e) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!ok_s) return;
+  const NormUpdateArgs& u = a.nu;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int64_t off = (int64_t)(e & 1u) * a.mom_stride;
+  double cnt = u.count[u.parity];
+  double mean = 0.0, var = 0.0;
+  if (i < u.elems) { mean = u.mean[i]; var = u.var[i]; }
+  for (int p = 0; p < a.d.world; ++p) {
+    const float* mp = a.mom[p] + off;
+    const int bn = (int)ld_sys_f1(mp + 2 * (int64_t)u.elems);
+    if (i < u.elems) norm_chan_merge(mean, var, cnt, ld_sys_f1(mp + i), ld_sys_f1(mp + u.elems + i), bn, false);
+    else cnt += (double)bn;
+  }
+  if (i < u.elems) norm_store(u, i, mean, var);
+  if (i == 0) u.count[u.parity ^ 1] = cnt;
 }
 
 }  // namespace grl

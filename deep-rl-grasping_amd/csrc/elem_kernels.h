@@ -373,40 +373,61 @@ struct NormUpdateArgs {
   int hw, c_obs, c_img, n_direct, vec;
   double* s_mean; double* s_std; double* s_dmean; double* s_dstd;
 };
-__global__ __launch_bounds__(256) void norm_update_kernel(NormUpdateArgs a) {
+// float32 batch moments of element e over the n staged observations, as np.mean / np.var(axis=0) form them
+__device__ __forceinline__ void norm_batch_moments(const NormUpdateArgs& a, int e, float& bm, float& bv) {
 #pragma clang fp contract(off)
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const double cnt = a.count[a.parity], bc = (double)a.n;
-  if (e < a.elems) {
-    float acc = a.obs[e];
-    for (int i = 1; i < a.n; ++i) acc += a.obs[(long)i * a.elems + e];
-    const float bm = acc / (float)a.n;
-    float d0 = a.obs[e] - bm;
-    float acc2 = d0 * d0;
-    for (int i = 1; i < a.n; ++i) {
-      const float d = a.obs[(long)i * a.elems + e] - bm;
-      acc2 += d * d;
-    }
-    const float bv = acc2 / (float)a.n;
-    const double mean = a.mean[e], var = a.var[e];
-    const double delta = (double)bm - mean;
-    const double tot = cnt + bc;
-    const double new_mean = mean + delta * bc / tot;
-    const double m_a = var * cnt;
-    const double m_b = (double)(bv * (float)a.n);
-    const double m2 = m_a + m_b + delta * delta * cnt * bc / (cnt + bc);
-    const double new_var = m2 / (cnt + bc);
-    a.mean[e] = new_mean;
-    a.var[e] = new_var;
-    const double sd = sqrt(new_var + a.eps);
-    if (a.vec) { a.s_mean[e] = new_mean; a.s_std[e] = sd; }
-    else {
-      const int px = e / a.c_obs, ch = e - px * a.c_obs;
-      if (ch < a.c_img) { a.s_mean[px * a.c_img + ch] = new_mean; a.s_std[px * a.c_img + ch] = sd; }
-      else if (ch == a.c_obs - 1 && px < a.n_direct) { a.s_dmean[px] = new_mean; a.s_dstd[px] = sd; }
-    }
+  float acc = a.obs[e];
+  for (int i = 1; i < a.n; ++i) acc += a.obs[(long)i * a.elems + e];
+  bm = acc / (float)a.n;
+  const float d0 = a.obs[e] - bm;
+  float acc2 = d0 * d0;
+  for (int i = 1; i < a.n; ++i) {
+    const float d = a.obs[(long)i * a.elems + e] - bm;
+    acc2 += d * d;
   }
-  if (e == 0) a.count[a.parity ^ 1] = cnt + bc;
+  bv = acc2 / (float)a.n;
+}
+// RunningMeanStd.update_from_moments on one element.  f32_product: `batch_var * batch_count` as NumPy evaluates it for a
+// float32 array and a Python int (the single-process path); data parallel, the moments were widened to float64 before
+// they travelled (grasp_rl.parallel.gather_moments) and the product is a float64 one.
+__device__ __forceinline__ void norm_chan_merge(double& mean, double& var, double& cnt, float bm, float bv, int n, bool f32_product) {
+#pragma clang fp contract(off)
+  const double bc = (double)n;
+  const double delta = (double)bm - mean;
+  const double tot = cnt + bc;
+  const double new_mean = mean + delta * bc / tot;
+  const double m_a = var * cnt;
+  const double m_b = f32_product ? (double)(bv * (float)n) : (double)bv * bc;
+  const double m2 = m_a + m_b + delta * delta * cnt * bc / (cnt + bc);
+  var = m2 / (cnt + bc);
+  mean = new_mean;
+  cnt = tot;
+}
+// running statistics of element e and the derived arrays the sampling / acting kernels read
+__device__ __forceinline__ void norm_store(const NormUpdateArgs& a, int e, double mean, double var) {
+  a.mean[e] = mean;
+  a.var[e] = var;
+  const double sd = sqrt(var + a.eps);
+  if (a.vec) { a.s_mean[e] = mean; a.s_std[e] = sd; }
+  else {
+    const int px = e / a.c_obs, ch = e - px * a.c_obs;
+    if (ch < a.c_img) { a.s_mean[px * a.c_img + ch] = mean; a.s_std[px * a.c_img + ch] = sd; }
+    else if (ch == a.c_obs - 1 && px < a.n_direct) { a.s_dmean[px] = mean; a.s_dstd[px] = sd; }
+  }
+}
+__global__ __launch_bounds__(256) void norm_update_kernel(NormUpdateArgs a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  double cnt = a.count[a.parity];
+  if (e < a.elems) {
+    float bm, bv;
+    norm_batch_moments(a, e, bm, bv);
+    double mean = a.mean[e], var = a.var[e];
+    norm_chan_merge(mean, var, cnt, bm, bv, a.n, true);
+    norm_store(a, e, mean, var);
+  } else {
+    cnt += (double)a.n;
+  }
+  if (e == 0) a.count[a.parity ^ 1] = cnt;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -958,6 +979,7 @@ struct ReduceDesc {
 struct sys_f4 { float v[4]; };
 static inline void st_sys_quad(float* base, int64_t quad, const float (&v)[4]) { for (int k = 0; k < 4; ++k) base[4 * quad + k] = v[k]; }
 static inline void st_sys_f1(float* p, float v) { *p = v; }
+static inline float ld_sys_f1(const float* p) { return *p; }
 #else
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_rsrc(const float* p) {
   const uint64_t a = (uint64_t)p;     // (made provably wave-uniform: no waterfall loop around the buffer instructions)
@@ -971,6 +993,7 @@ __device__ __forceinline__ void st_sys_quad(float* base, int64_t quad, const flo
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sys_u4, sys_f4{v[0], v[1], v[2], v[3]}), sys_rsrc(base), (int)(quad << 4), 0, SYS_SCOPE);
 }
 __device__ __forceinline__ void st_sys_f1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float ld_sys_f1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #endif
 
 // mirror (optional): a second, bucket-shaped array that receives every sum write-through (the exchange buffer of the

@@ -54,6 +54,33 @@ static int fail(int code, const std::string& msg) {
 
 static inline int64_t rup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// GRL_TUNE="key=value,key=value,...": the measurement / tuning knobs of scripts/ behind ONE variable (workgroup shape per
+// launch tag `i2cfg_<tag>`, `sk_wgs`, `wg_split` "a/b/c", `l0_split`, `graph_updates`, `dp_blocks` "a/b/c", `dp_coarse`,
+// `dp_timeout_ms`, `heads_stamps`).  Nothing here changes arithmetic.
+static bool tune_str(const char* key, std::string* out) {
+  const char* e = getenv("GRL_TUNE");
+  if (!e) return false;
+  const std::string s(e), k(key);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(',', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string item = s.substr(pos, end - pos);
+    const size_t eq = item.find('=');
+    if (eq != std::string::npos && item.substr(0, eq) == k) { *out = item.substr(eq + 1); return true; }
+    pos = end + 1;
+  }
+  return false;
+}
+static int tune_int(const char* key, int dflt) {
+  std::string v;
+  return tune_str(key, &v) ? atoi(v.c_str()) : dflt;
+}
+static int tune_int3(const char* key, int v[3]) {     // "a/b/c"
+  std::string t;
+  return tune_str(key, &t) ? sscanf(t.c_str(), "%d/%d/%d", &v[0], &v[1], &v[2]) : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Var {
   std::string name;
@@ -117,11 +144,8 @@ struct Launch {
   std::vector<IgemmProb> probs;
   IgemmProb* d_probs = nullptr;
   int4* d_tiles = nullptr;
-  int32_t* d_pre = nullptr;     // per-tile preambles (igemm2.h, I2F_PRE): the table entries a tile needs before its first load
-  std::vector<int4> h_tiles;    // host copy of the work list (chain_ops derives the tile dependencies from it)
   int n_tiles = 0;
   Launch* filler = nullptr;     // tiles of a second instantiation carried by the same launch (igemm2_pair_kernel)
-  unsigned dyn_lds = 0;         // extra LDS bytes requested per workgroup: caps the workgroups a CU holds at once
 };
 
 struct Op {
@@ -132,7 +156,6 @@ struct Op {
   int lane = 0;
   bool fork = false, join = false;
   std::function<void(hipStream_t)> run;
-  Launch* launch = nullptr;   // the igemm2 launch behind a plain (single-instantiation) op: what chain_ops merges
   double flops = 0;   // algorithmic FLOPs of one launch (2 * M * N * K over the taps / rows that exist)
   double flops_exec = 0;   // FLOPs the launch's MFMAs execute (>= flops: masked taps of the parity-class backward-data form)
   double bytes = 0;   // algorithmic HBM bytes of one launch
@@ -214,11 +237,10 @@ struct grl_ctx {
   HeadGrad gPI, gVF, gQF1, gQF2, gQF1PI;
   float *da_pi, *dmu, *dls;
   float *dfeat[2], *g3[2], *g2[2], *g1[2];
-  int ld1 = 32;   // pixel stride of a1 / g1 (64: the two trained networks side by side)
+  int ld1 = 64;   // pixel stride of a1 / g1: the two trained networks side by side
   float* act_p = nullptr;            // [B, Ap] row-padded copy of the minibatch actions (Ap = rup(A, 4))
   int Ap = 0, ld_d = 1, ld_dm = 0;   // strides of the packed output-gradient buffers (fused heads)
   bool fused_heads = false;          // heads_kernels.h path (row-local chains) instead of per-layer GEMMs
-  bool exact_tap = true;             // conv backward-data over exactly the taps that exist (conv_bwd_tabs_exact)
   bool heads_mfma = false;           // heads_mfma.h: forward + backward of all heads as ONE launch on 16x16x4 MFMAs
   float *u_l0[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // layer-0 feature partials: pi, vf, qf1, qf2, target
   int l0_split = 1;
@@ -238,7 +260,6 @@ struct grl_ctx {
   ReduceDesc* d_reduces = nullptr;
 
   std::vector<Op> ops_rng, ops_gather, ops_grads, ops_apply, ops_act, ops_act_det, ops_act_sto, ops_enc, wgrad_ops;   // ops_rng: gather with device RNG; ops_gather: gather of explicit indices
-  bool use_lanes = false;
   LossArgs loss_args;              // SAC: batch reductions appended to the reduce_slabs launch (fused heads)
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
   // SAC, calls of several updates on the device RNG: the next minibatch is gathered inside the last launch of an update
@@ -266,9 +287,16 @@ struct grl_ctx {
   struct ReducePlan { const int2* tiles = nullptr; int n = 0; int has_loss = 0; };
   ReducePlan red_all, red_dense, red_conv;
   AdamArgs adam_base;
-  std::vector<Op> ops_dp;                // reduce + publish | reduce-scatter | Adam + Polyak on the exchanged bucket (replaces the last op of ops_grads)
-  std::vector<Op> ops_pfdp_first, ops_pfdp_mid, ops_pfdp_last;   // prefetching sequences whose last launch sums without applying (plan_sac)
+  std::vector<Op> ops_dp;                // two-shot: reduce + publish | reduce-scatter | pull + Adam + Polyak (replaces the last op of ops_grads)
+  std::vector<Op> ops_dp1;               // one-shot: reduce + publish | sum of all ranks + Adam + Polyak
+  std::vector<Op> ops_pfdp_first, ops_pfdp_mid, ops_pfdp_last;      // prefetching sequences ending in the two-shot exchange (built at connect)
+  std::vector<Op> ops_pfdp1_first, ops_pfdp1_mid, ops_pfdp1_last;   // ... in the one-shot exchange
+  LossArgs pf_lk;                        // loss arguments / gather of the NEXT update as the prefetching reductions carry them (plan_sac)
+  GatherArgs pf_g2;
   std::vector<Op> dp_body;               // ops_grads without its final reduction (the exchange's first kernel forms the sums)
+  int dp_mode = 0;                       // 0 auto (one-shot for world <= 2), 1 two-shot, 2 one-shot
+  uint32_t* dp_err_host = nullptr;       // page-locked mailbox: a kernel that gave up waiting for a peer sets it
+  DpNormArgs dp_norm;                    // running-statistics merge over the ranks (grl_norm_update on a connected handle)
   std::vector<Op> ops_dp_overlap;        // the whole overlapped update: staged gradients, two exchanges (one on a side lane), Adam
   bool dp_overlap = false;
 
@@ -297,6 +325,7 @@ struct grl_ctx {
       if (dp_peer[p]) (void)hipIpcCloseMemHandle(dp_peer[p]);
     if (dp_buf) (void)hipFree(dp_buf);
     if (dp_flags) (void)hipFree(dp_flags);
+    if (dp_err_host) (void)hipHostFree(dp_err_host);
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
     for (auto e : lane_ev) hipEventDestroy(e);
@@ -327,11 +356,10 @@ struct grl_ctx {
   }
 
   // `count` identical updates (device RNG: nothing changes on the host between them): groups of up to GRL_GRAPH_UPDATES
-  // (default 16, powers of two) go out as ONE graph -- no graph boundary between the updates of a group (measured on
+  // (GRL_TUNE graph_updates; default 16, powers of two) go out as ONE graph -- no graph boundary between the updates of a group (measured on
   // MI355X, SAC depth B = 256: 5 090 -> 5 194 / 5 227 / 5 232 updates/s at 4 / 8 / 16 per graph)
   int run_repeated(const std::string& key, const std::vector<std::vector<Op>*>& one, int count) {
-    const char* ge = getenv("GRL_GRAPH_UPDATES");
-    const int max_group = ge ? std::max(1, std::min(64, atoi(ge))) : 16;
+    const int max_group = std::max(1, std::min(64, tune_int("graph_updates", 16)));
     while (count > 0) {
       int group = 1;
       while (2 * group <= max_group && 2 * group <= count) group *= 2;
@@ -349,11 +377,9 @@ struct grl_ctx {
   }
 
   // ---------------------------------------------------------------- helpers
-  std::map<const void*, std::vector<int32_t>> htab;   // host copies of the int32 addressing tables (plan time only: preambles)
   template <class T>
   T* upload_vec(Arena& a, const std::vector<T>& v) {
     T* d = (T*)a.take(std::max<size_t>(v.size(), 1) * sizeof(T));
-    if constexpr (std::is_same<T, int32_t>::value) htab[(const void*)d] = v;
     if (!dry && !v.empty()) {
       Upload u;
       u.dst = d;
@@ -771,10 +797,10 @@ struct grl_ctx {
     return true;
   }
   // workgroup shape of a v2 launch: narrow outputs -> 128x32; few 64x64 tiles -> 32x64 with the reduction
-  // split over wave pairs; otherwise 64x64 (shape 2, a 4-way split, stays selectable by GRL_I2CFG_<tag>)
+  // split over wave pairs; otherwise 64x64 (shape 2, a 4-way split, stays selectable by GRL_TUNE i2cfg_<tag>)
   static int v2_pick_cfg(const std::vector<IgemmProb>& probs, int variant, const std::string& tag) {
-    const std::string key = "GRL_I2CFG_" + tag;
-    if (const char* e = getenv(key.c_str())) return atoi(e);
+    const int forced = tune_int(("i2cfg_" + tag).c_str(), -1);
+    if (forced >= 0) return forced;
     int maxN = 0;
     long tiles64 = 0;
     bool ones = false, longk = true;
@@ -798,8 +824,7 @@ struct grl_ctx {
   static bool pair_ok(const Launch* a, const Launch* b) {
     if (!a->v2 || !b->v2 || a->sk || b->sk || v2_key(b) != 21001) return false;
     const int ka = v2_key(a);
-    return ka == 10030 || ka == 10000 || ka == 12130 || ka == 12110 || ka == 12100 || ka == 11130 || ka == 11110 || ka == 11100 ||
-           ka == 11134 || ka == 11114 || ka == 11104;
+    return ka == 11130;     // conv3_bwd (exact taps), 32x64 shape
   }
 
   // finish a launch: tile list (heaviest reductions first), upload, wrap as an Op.  `filler`: independent problems
@@ -824,9 +849,7 @@ struct grl_ctx {
       add_launch(tmp_a, tag, variant, probs);
       lpt_extra_tiles = 0; lpt_extra_w = 0;
       Launch* la = launches.back();
-      suppress_pre = true;                                          // (the pair kernel's filler side is one fixed instantiation)
       add_launch(tmp_b, ftag, fvariant, fprobs, "", 0, {}, 0);      // fillers keep the 64x64 shape of the merged launch
-      suppress_pre = false;
       Launch* lb = launches.back();
       if (tmp_a.size() == 1 && tmp_b.size() == 1 && pair_ok(la, lb)) {
         la->filler = lb;
@@ -839,28 +862,16 @@ struct grl_ctx {
         op.run = [la, lb, t2](hipStream_t s) {
           const dim3 grid(la->n_tiles + lb->n_tiles), block(256);
           const int ka = la->variant * 10000 + la->pm * 1000 + la->qm * 100 + la->cfg * 10 + la->flags;
-#define GRL_I2PF(PLv, QLv, PMv, QMv, CF, FLv)                                                                            \
-  hipLaunchKernelGGL((igemm2_pair_kernel<PLv, QLv, PMv, QMv, CF, FLv, I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES>), \
-                     grid, block, 0, s, la->d_probs, la->d_tiles, la->n_tiles, lb->d_probs, lb->d_tiles, (const int*)la->d_pre)
-#define GRL_I2P(PLv, QLv, PMv, QMv, CF) GRL_I2PF(PLv, QLv, PMv, QMv, CF, 0)
+#define GRL_I2P(PLv, QLv, PMv, QMv, CF)                                                                                  \
+  hipLaunchKernelGGL((igemm2_pair_kernel<PLv, QLv, PMv, QMv, CF, 0, I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES>), \
+                     grid, block, 0, s, la->d_probs, la->d_tiles, la->n_tiles, lb->d_probs, lb->d_tiles)
           switch (ka) {
-            case 10030: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3); break;
-            case 10000: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0); break;
-            case 12130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 3); break;
-            case 12110: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 1); break;
-            case 12100: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0); break;
             case 11130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 3); break;
-            case 11110: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 1); break;
-            case 11100: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0); break;
-            case 11134: GRL_I2PF(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 3, I2F_PRE); break;
-            case 11114: GRL_I2PF(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 1, I2F_PRE); break;
-            case 11104: GRL_I2PF(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0, I2F_PRE); break;
             default:
               fprintf(stderr, "grl: no igemm2 pair instantiation for launch '%s' (key %d)\n", t2.c_str(), ka);
               abort();
           }
 #undef GRL_I2P
-#undef GRL_I2PF
         };
         (void)self;
         if (getenv("GRL_PLAN_DUMP"))
@@ -911,8 +922,7 @@ struct grl_ctx {
           p.vflags |= VF_C_VEC;
     // short reductions with a narrow output (first convolution of the extractors): streaming kernel, igemm_sk.h
     {
-      const char* ns = getenv("GRL_NO_SK");
-      bool ok = l->v2 && variant == 0 && l->pm == PM_TABLE && l->qm == QM_AFFINE && l->flags == 0 && !(ns && ns[0] == '1');
+      bool ok = l->v2 && variant == 0 && l->pm == PM_TABLE && l->qm == QM_AFFINE && l->flags == 0;
       for (auto& p : l->probs)
         ok = ok && (p.K == 64 || p.K == 32) && p.K == l->probs[0].K && p.N <= 32 && (p.N % 4) == 0 && p.split == 1 &&
              (p.vflags & VF_P_TABS) && (p.vflags & VF_C_VEC) && !p.c_tab_i && !p.relu_mask && !p.accumulate &&
@@ -923,7 +933,7 @@ struct grl_ctx {
       long total = 0;
       for (auto& p : l->probs) total += (p.M + 127) / 128;
       long slots = 512;                                                // ~2 workgroups per CU, each streams `per` tiles
-      if (const char* e = getenv("GRL_SK_WGS")) slots = std::max(1, atoi(e));   // tuning aid
+      slots = std::max(1, tune_int("sk_wgs", (int)slots));
       const int per = (int)std::max<long>(1, (total + slots - 1) / slots);
       std::vector<int4> work;
       double flops = 0;
@@ -960,50 +970,7 @@ struct grl_ctx {
     std::vector<int4> tiles = tile_list(l->probs, l->v2, BMt, BNt);
     if (variant == 2) tiles = xcd_order(tiles, l->probs, BMt, BNt);
     if (variant == 1 && l->v2) tiles = lpt_order(tiles, l->probs, BMt, BNt, lpt_extra_tiles, lpt_extra_w, tag);
-    if (variant == 2 && l->v2) {
-      if (const char* e = getenv("GRL_WG_DYNLDS")) l->dyn_lds = (unsigned)atoi(e);
-    }
     l->n_tiles = (int)tiles.size();
-    {   // per-tile preambles (I2F_PRE): unmasked table addressing of the three convolution directions.  Opt-in
-        // (GRL_PREAMBLE=1): measured neutral on MI355X at B = 256 (5 102 against 5 092 updates/s on one box) -- the 2 - 4 us
-        // between a workgroup's start and its first barrier are the operand loads of 400 - 800 workgroups arriving at
-        // once, not the table hop in front of them.  Kept as a tested switch (bit-identical results).
-      const char* np = getenv("GRL_PREAMBLE");
-      bool ok = l->v2 && !suppress_pre && (np && atoi(np)) && l->pm == PM_TABLE &&
-                ((variant == 0 && l->qm == QM_AFFINE && l->flags == 0) || (variant == 1 && l->qm == QM_TABLE && l->flags == 0) ||
-                 (variant == 2 && l->qm == QM_AFFINE && l->flags == I2F_ONES && l->cfg <= 1));
-      for (auto& p : l->probs)
-        ok = ok && htab.count(p.p_tab_i) && htab.count(p.p_tab_r) && (!p.q_tab_r || htab.count(p.q_tab_r)) &&
-             (!p.c_tab_i || htab.count(p.c_tab_i));
-      if (ok) {
-        const int BKTt = 32 * (l->cfg == 2 ? 4 : (l->cfg == 3 ? 2 : 1));
-        const int ROWo = 0, PKo = BMt, QKo = BMt + 3 * BKTt, CTo = BMt + 6 * BKTt, STR = 2 * BMt + 6 * BKTt;
-        std::vector<int32_t> pre((size_t)tiles.size() * STR, 0);
-        for (size_t ti = 0; ti < tiles.size(); ++ti) {
-          const int4& t = tiles[ti];
-          const IgemmProb& p = l->probs[t.x];
-          const std::vector<int32_t>&hi = htab[p.p_tab_i], &hr = htab[p.p_tab_r];
-          const std::vector<int32_t>* hq = p.q_tab_r ? &htab[p.q_tab_r] : nullptr;
-          const std::vector<int32_t>* hc = p.c_tab_i ? &htab[p.c_tab_i] : nullptr;
-          const int Meff = p.p_ones_i >= 0 ? p.M - 1 : p.M;
-          const int i0 = t.z * BMt, r_begin = t.y * p.k_chunk, r_end = std::min(p.K, r_begin + p.k_chunk);
-          int32_t* o = pre.data() + ti * STR;
-          for (int x = 0; x < BMt; ++x) {
-            const int i = i0 + x;
-            o[ROWo + x] = hi[(size_t)(i < Meff ? i : i0)];
-            if (hc) o[CTo + x] = (*hc)[(size_t)(i < Meff ? i : 0)];
-          }
-          for (int k = 0; k < 3 * BKTt; ++k) {
-            const int r = r_begin + k, rc = r < r_end ? r : r_begin;
-            o[PKo + k] = hr[(size_t)rc];
-            if (hq) o[QKo + k] = (*hq)[(size_t)rc];
-          }
-        }
-        l->d_pre = upload_vec(wk, pre);
-        htab.erase((const void*)l->d_pre);          // (not an addressing table)
-        l->flags |= I2F_PRE;
-      }
-    }
     if (getenv("GRL_PLAN_DUMP"))
       fprintf(stderr, "grl plan: %-14s variant %d pm %d qm %d np %d  %s cfg %d flags %d  probs %zu  tiles %d\n", tag.c_str(),
               variant, l->pm, l->qm, l->np, l->v2 ? "v2" : "v1", l->cfg, l->flags, l->probs.size(), l->n_tiles);
@@ -1022,8 +989,6 @@ struct grl_ctx {
     launches.push_back(l);
     Op op;
     op.tag = tag;
-    op.launch = l;
-    l->h_tiles = tiles;
     op.flops = flops_alg;
     op.flops_exec = flops;
     op.run = [l, tag](hipStream_t s) {
@@ -1031,7 +996,7 @@ struct grl_ctx {
       if (l->v2) {
         const int key = l->variant * 10000 + l->pm * 1000 + l->qm * 100 + l->cfg * 10 + l->flags;
 #define GRL_I2(PLv, QLv, PMv, QMv, CF, FL) \
-  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, l->dyn_lds, s, l->d_probs, l->d_tiles, (const int*)l->d_pre)
+  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, 0, s, l->d_probs, l->d_tiles)
 #define GRL_I2_CFGS(base, PLv, QLv, PMv, QMv, FL)                           \
   case base + 0 + FL: GRL_I2(PLv, QLv, PMv, QMv, 0, FL); break;              \
   case base + 10 + FL: GRL_I2(PLv, QLv, PMv, QMv, 1, FL); break;             \
@@ -1045,10 +1010,6 @@ struct grl_ctx {
           GRL_I2_CFGS(10000, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0)        // dense backward-data
           GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data, masked taps
           GRL_I2_CFGS(11100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0)          // conv backward-data, exact taps
-          GRL_I2_CFGS(1000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, I2F_PRE)    // ... the same with per-tile preambles
-          GRL_I2_CFGS(11100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, I2F_PRE)
-          case 21005: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES | I2F_PRE); break;
-          case 21015: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 1, I2F_ONES | I2F_PRE); break;
           GRL_I2_CFGS(10100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 0)         // dense backward-data over several kernels
           case 20000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, 0); break;         // dense weight gradient
           case 20001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, I2F_ONES); break;  //   ... with bias row
@@ -1213,11 +1174,9 @@ struct grl_ctx {
   // (MI355X_MICROARCH.md, "Workgroup dispatch"; an observation, used for speed only): in list order those tiles land on
   // 8 different L2s and each fetches its operands from HBM -- 158 MB per launch where ~50 MB are distinct.  Here the
   // tiles are grouped by chunk, the groups dealt to 8 queues (least work first, heavy groups first) and the list is
-  // re-emitted so that position i comes from queue i % 8.  Same tiles, same arithmetic; GRL_NO_XCD_ORDER=1 keeps the
-  // list order (test / measurement switch).
+  // re-emitted so that position i comes from queue i % 8.  Same tiles, same arithmetic.
   static std::vector<int4> xcd_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt,
                                      double* model_max = nullptr) {
-    if (const char* e = getenv("GRL_NO_XCD_ORDER")) if (atoi(e) && !model_max) return tiles;   // (the split chooser still models the ordered list)
     constexpr int NX = 8;
     struct Grp { std::vector<int4> t; double w = 0; };
     std::vector<Grp> groups;
@@ -1304,10 +1263,9 @@ struct grl_ctx {
   // mod 256 share a CU, all of a launch's workgroups are resident at once and a CU works through the SUM of what it
   // holds.  Longest-processing-time-first over 256 bins (bin c owns positions c, c + 256, ...); `extra_tiles` filler
   // tiles of weight `extra_w` will follow at positions n.. (riders of igemm2_pair_kernel) and are counted into their
-  // bins beforehand.  Same tiles, same arithmetic; GRL_NO_LPT_ORDER=1 keeps the list order (measurement switch).
+  // bins beforehand.  Same tiles, same arithmetic.
   int lpt_extra_tiles = 0;
   double lpt_extra_w = 0;
-  bool suppress_pre = false;
   static std::vector<int4> lpt_order(const std::vector<int4>& tiles, const std::vector<IgemmProb>& probs, int BMt, int BNt,
                                      int extra_tiles, double extra_w, const std::string& tag) {
     const int n = (int)tiles.size();
@@ -1318,7 +1276,6 @@ struct grl_ctx {
     };
     bool uniform = true;
     for (const int4& t : tiles) uniform = uniform && w_of(t) == w_of(tiles[0]);
-    if (const char* e = getenv("GRL_NO_LPT_ORDER")) if (atoi(e)) uniform = true;
     if (uniform || n <= 256) return tiles;
     constexpr int NB = 256;
     std::vector<double> load(NB, 0.0);
@@ -1348,145 +1305,6 @@ struct grl_ctx {
     return out;
   }
 
-  // ---------------------------------------------------------------- dependent stages in one launch (igemm2_chain_kernel)
-  // Replaces runs of consecutive ops {tags[0], tags[1][, tags[2]]} of `list` by one op whose launch carries the tiles of
-  // all of them, later stages waiting per tile for the earlier tiles that write their operands.  Conditions: every op is a
-  // plain igemm2 launch of the 32x64 / 48 KB shape (three workgroups per CU), the total fits 3 x 256 workgroups -- i.e.
-  // the whole launch is resident at once -- and the instantiation triple is one the kernel is built for.  The
-  // dependencies come from the address ranges: a consumer tile reads rows [i0, i0 + 32) of its (affine, row-major) P
-  // operand; every producer tile whose output rows intersect that range must have finished.  Same tiles, same
-  // arithmetic: results are bit-identical to the separate launches.  A waiting tile cannot keep its producers from running
-  // whatever else shares the machine: workgroups are dispatched in index order, so every producer of a tile was dispatched
-  // before it.
-  // OPT-IN (GRL_CHAIN=1), MEASURED SLOWER on MI355X at B = 256: conv3_fwd+fc_fwd+heads_l0 72.1 us against 18.3 + 17.7 + 8.3,
-  // heads_dfeat+fc_bwd 30.3 against 8.3 + 12.8 (4168 against 5084 updates/s on one box).  The 8 XCDs have private L2s, so
-  // every hand-over is a device-scope release / acquire pair -- a write-back of the producer XCD's L2 and an invalidation
-  // of the consumer XCD's, 300+ times per launch -- and each invalidation throws away the dense-layer weights the other
-  // tiles of that XCD were sharing (with an acquire per POLL it was 198 us).  A launch boundary does the same flush once.
-  std::map<std::vector<Launch*>, Op> chain_cache;
-  bool chain_ops(std::vector<Op>& list, const std::vector<std::string>& tags) {
-    const char* nc = getenv("GRL_CHAIN");
-    if (!nc || !atoi(nc)) return false;
-    for (size_t k = 0; k + tags.size() <= list.size(); ++k) {
-      bool match = true;
-      for (size_t j = 0; j < tags.size(); ++j) match = match && list[k + j].tag == tags[j] && list[k + j].launch != nullptr;
-      if (!match) continue;
-      std::vector<Launch*> ls;
-      for (size_t j = 0; j < tags.size(); ++j) ls.push_back(list[k + j].launch);
-      auto it = chain_cache.find(ls);
-      if (it == chain_cache.end()) {
-        int total = 0, keys[3] = {-1, -1, -1};
-        bool ok = true;
-        for (size_t j = 0; j < ls.size(); ++j) {
-          Launch* l = ls[j];
-          ok = ok && l->v2 && !l->sk && !l->filler && l->cfg == 3 && (int)l->h_tiles.size() == l->n_tiles;
-          keys[j] = v2_key(l);
-          total += l->n_tiles;
-          if (j > 0)      // consumers: affine P along r (rows of a row-major tensor)
-            ok = ok && l->pm == PM_AFFINE && (l->variant == 0 || l->variant == 1);
-        }
-        const bool fwd3t = ls.size() == 3 && keys[0] == 1030 && keys[1] == 30 && keys[2] == 30 + I2F_KTAIL;
-        const bool fwd3 = fwd3t || (ls.size() == 3 && keys[0] == 1030 && keys[1] == 30 && keys[2] == 30);
-        const bool bwd2 = ls.size() == 2 && keys[0] == 10130 && keys[1] == 10030;
-        ok = ok && total <= 768 && (fwd3 || bwd2);
-        if (!ok) {
-          if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: %s ... not chained (keys %d %d %d, %d tiles)\n", tags[0].c_str(), keys[0], keys[1], keys[2], total);
-          return false;
-        }
-        // ---- counters: one per consumer row group (stage, operand tensor, first row); targets = intersecting producer tiles
-        struct Grp { int stage; const float* base; int i0; long lo, hi; int target; };
-        std::vector<Grp> grps;
-        std::vector<std::vector<int4>> dep(ls.size());
-        for (size_t j = 0; j < ls.size(); ++j) dep[j].assign(ls[j]->n_tiles, make_int4(-1, 0, -1, -1));
-        auto group_of = [&](int stage, const IgemmProb& p, int i0) {
-          for (size_t g = 0; g < grps.size(); ++g)
-            if (grps[g].stage == stage && grps[g].base == p.p_base[0] && grps[g].i0 == i0) return (int)g;
-          const int i1 = std::min(p.M, i0 + 32) - 1;
-          Grp g{stage, p.p_base[0], i0, (long)i0 * p.p_ld_i[0], (long)i1 * p.p_ld_i[0] + p.K, 0};
-          grps.push_back(g);
-          return (int)grps.size() - 1;
-        };
-        for (size_t j = 1; j < ls.size(); ++j)
-          for (int t = 0; t < ls[j]->n_tiles; ++t) {
-            const int4& tl = ls[j]->h_tiles[t];
-            dep[j][t].x = group_of((int)j, ls[j]->probs[tl.x], tl.z * 32);
-          }
-        for (size_t j = 0; j + 1 < ls.size(); ++j)
-          for (int t = 0; t < ls[j]->n_tiles; ++t) {
-            const int4& tl = ls[j]->h_tiles[t];
-            const IgemmProb& p = ls[j]->probs[tl.x];
-            if (p.c_tab_i || p.split != 1) { ok = false; break; }
-            const int r0 = tl.z * 32, r1 = std::min(p.M, r0 + 32) - 1, c0 = tl.w * 64, c1 = std::min(p.N, c0 + 64);
-            int n_sig = 0;
-            for (size_t g = 0; g < grps.size(); ++g) {
-              if (grps[g].stage != (int)j + 1) continue;
-              const long off = p.c - grps[g].base;                       // producer output relative to the consumer's operand
-              const long lo = off + (long)r0 * p.ldc + c0, hi = off + (long)r1 * p.ldc + c1;
-              if (hi <= grps[g].lo || lo >= grps[g].hi) continue;
-              grps[g].target += 1;
-              if (n_sig == 0) dep[j][t].z = (int)g;
-              else if (n_sig == 1) dep[j][t].w = (int)g;
-              else ok = false;
-              ++n_sig;
-            }
-          }
-        for (auto& g : grps) ok = ok && g.target > 0;
-        if (!ok) return false;
-        for (size_t j = 1; j < ls.size(); ++j)
-          for (auto& d : dep[j]) d.y = grps[d.x].target;
-        ChainArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        for (size_t j = 0; j < ls.size(); ++j) {
-          ca.p[j] = ls[j]->d_probs; ca.t[j] = ls[j]->d_tiles; ca.n[j] = ls[j]->n_tiles;
-          ca.dep[j] = upload_vec(wk, dep[j]);
-        }
-        ca.n_cnt = (int)grps.size();
-        ca.cnt = (int*)wk.take((size_t)(ca.n_cnt + 2) * 4);
-        zero_once.push_back({ca.cnt, (size_t)(ca.n_cnt + 2) * 4});
-        chain_err.push_back(ca.cnt + ca.n_cnt + 1);
-        Op op;
-        op.tag = tags[0];
-        for (size_t j = 1; j < tags.size(); ++j) op.tag += "+" + tags[j];
-        for (size_t j = 0; j < tags.size(); ++j) { op.flops += list[k + j].flops; op.flops_exec += list[k + j].flops_exec; }
-        const int n_all = total;
-        op.run = [ca, n_all, fwd3, fwd3t](hipStream_t s) {
-          if (fwd3 && !fwd3t)
-            hipLaunchKernelGGL((igemm2_chain_kernel<I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 3, 0,
-                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, 0,
-                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, 0>),
-                               dim3(n_all), dim3(256), 0, s, ca);
-          else if (fwd3)
-            hipLaunchKernelGGL((igemm2_chain_kernel<I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 3, 0,
-                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, 0,
-                                                     I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 3, I2F_KTAIL>),
-                               dim3(n_all), dim3(256), 0, s, ca);
-          else
-            hipLaunchKernelGGL((igemm2_chain_kernel<I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 3, 0,
-                                                     I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3, 0,
-                                                     I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 3, 0>),
-                               dim3(n_all), dim3(256), 0, s, ca);
-        };
-        if (getenv("GRL_PLAN_DUMP"))
-        {
-          fprintf(stderr, "grl plan: %-14s one launch of %d dependent tiles (%zu stages, %zu row-group counters; producers per group:", op.tag.c_str(),
-                  n_all, ls.size(), grps.size());
-          for (size_t j = 1; j < ls.size(); ++j) {
-            int lo = 1 << 30, hi = 0;
-            for (auto& g : grps) if (g.stage == (int)j) { lo = std::min(lo, g.target); hi = std::max(hi, g.target); }
-            fprintf(stderr, " stage %zu %d..%d", j, lo, hi);
-          }
-          fprintf(stderr, ")\n");
-        }
-        it = chain_cache.emplace(ls, op).first;
-      }
-      list.erase(list.begin() + k, list.begin() + k + tags.size());
-      list.insert(list.begin() + k, it->second);
-      return true;
-    }
-    return false;
-  }
-  std::vector<int*> chain_err;     // error flags of the chained launches (a bounded wait ran out): checked by grl_get_metrics
-
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
   // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors
   // whose geometry allows 16-byte accesses are marked (vec) and cut into tiles of 1024 outputs, the others of 256
@@ -1497,8 +1315,7 @@ struct grl_ctx {
 #ifdef GRL_HOSTEMU
       r.vec = 0;
 #else
-      const char* nv = getenv("GRL_NO_VEC_REDUCE");   // test switch: the one-output-per-thread form everywhere
-      r.vec = (!(nv && atoi(nv)) && r.n % 4 == 0 && r.slab_stride % 4 == 0 && r.row_len % 4 == 0 && r.src_ld % 4 == 0 &&
+      r.vec = (r.n % 4 == 0 && r.slab_stride % 4 == 0 && r.row_len % 4 == 0 && r.src_ld % 4 == 0 &&
                (((uintptr_t)r.dst | (uintptr_t)r.src) & 15) == 0) ? 1 : 0;
 #endif
       if (pick && !pick(r)) continue;

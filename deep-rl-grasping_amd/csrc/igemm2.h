@@ -29,7 +29,7 @@ namespace grl {
 
 enum { I2_P_ALONG_R = 0, I2_P_ALONG_I = 1 };
 enum { I2_Q_ALONG_R = 0, I2_Q_ALONG_J = 1 };
-enum { I2F_ONES = 1, I2F_KTAIL = 2, I2F_PRE = 4 };
+enum { I2F_ONES = 1, I2F_KTAIL = 2 };
 
 template <int CFG> struct I2Cfg;
 template <> struct I2Cfg<0> { static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, WK = 1, FM = 1, FN = 1; };
@@ -39,12 +39,6 @@ template <> struct I2Cfg<3> { static constexpr int BM = 32, BN = 64, WM = 1, WN 
 
 static inline int i2_bm(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 128 : 32); }   // cfg 2, 3: 32
 static inline int i2_bn(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 32 : 64); }
-
-// preamble of one tile, in ints: [BM row terms | 3*BKT P column terms | 3*BKT Q row terms | BM output offsets]
-template <int CFG> struct I2Pre {
-  static constexpr int BM = I2Cfg<CFG>::BM, BKT = 32 * I2Cfg<CFG>::WK;
-  static constexpr int ROW = 0, PK = BM, QK = BM + 3 * BKT, CT = BM + 6 * BKT, STRIDE = 2 * BM + 6 * BKT;
-};
 
 #ifdef GRL_HOSTEMU
 #include "igemm2_ref1.h"   // tests/hostemu: the emulation build only
@@ -71,12 +65,6 @@ __device__ __forceinline__ f32x4 i2_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) 
 
 // FLAGS: I2F_ONES  -- the problems carry a bias-gradient ones row (p_ones_i == M-1), Q along j, WK == 1
 //        I2F_KTAIL -- K % 4 != 0 (affine operands along r): elements past r_end are zeroed one by one
-//        I2F_PRE   -- table-addressed launches (no masks): the table entries a tile needs BEFORE its first operand load --
-//                     its BM row terms, the column / row terms of its first three reduction slabs, its BM output offsets --
-//                     come from a per-tile PREAMBLE indexed by blockIdx (a kernel argument), i.e. they are requested at
-//                     kernel start together with the descriptor instead of after it: one dependent memory round trip
-//                     less in front of the first MFMA.  Same values, same arithmetic.  MEASURED NEUTRAL (engine.hip,
-//                     add_launch): opt-in with GRL_PREAMBLE=1, covered by the bit-identity tests.
 // LDS floats one tile of an instantiation needs
 template <int PL, int QL, int CFG>
 struct I2Lds {
@@ -112,14 +100,10 @@ __device__ __forceinline__ void i2_trace_record(const IgemmProb* pb, const int4 
 // one tile; `lds` is the workgroup's staging area (I2Lds<...>::value floats, 16-byte aligned).  A function, not the
 // kernel, so that one launch can carry tiles of two instantiations (igemm2_pair_kernel).
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, const int4 tl, float* __restrict__ lds,
-                                            const int* __restrict__ pre_ = nullptr) {
+__device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, const int4 tl, float* __restrict__ lds) {
   using C = I2Cfg<CFG>;
   constexpr int BM = C::BM, BN = C::BN, WK = C::WK, FM = C::FM, FN = C::FN, WN = C::WN, WM = C::WM;
   constexpr bool ONES = (FLAGS & I2F_ONES) != 0, KTAIL = (FLAGS & I2F_KTAIL) != 0;
-  constexpr bool PRE = (FLAGS & I2F_PRE) != 0;
-  static_assert(!PRE || PM == PM_TABLE, "the preamble serves table-addressed, unmasked P operands");
-  const gci32 pre = (gci32)pre_;
   constexpr int BKT = 32 * WK;                 // reduction depth staged per barrier
   // Row strides of the two layouts of an operand.  K-contiguous rows (operand along r) are NOT padded: the 16-byte
   // chunks of a row are XOR-swizzled with row bits instead (i2_swz), which keeps the four ds_read_b128 per slab
@@ -185,14 +169,14 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
       const int i = i0 + p_l + e * PSTEP;
       p_fok[e] = i < M;
       const int ic = p_fok[e] ? i : i0;
-      p_fix[e] = PRE ? pre[I2Pre<CFG>::ROW + p_l + e * PSTEP] : (PM != PM_AFFINE ? pTi[ic] : ic * pLi);
+      p_fix[e] = PM != PM_AFFINE ? pTi[ic] : ic * pLi;
       p_vm[e] = PM == PM_TABLE_MASK ? pVm[ic] : ~0ull;
     }
   } else {
     const int i = i0 + 4 * p_q;
     p_fok[0] = i < M;
     const int ic = p_fok[0] ? i : i0;
-    p_fix[0] = PRE ? pre[I2Pre<CFG>::ROW + 4 * p_q] : (PM != PM_AFFINE ? pTi[ic] : ic);
+    p_fix[0] = PM != PM_AFFINE ? pTi[ic] : ic;
     p_vm[0] = ~0ull;
   }
   constexpr int QNQ = QL == I2_Q_ALONG_R ? BKT / 4 : BN / 4;
@@ -240,18 +224,6 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
         const int r = QL == I2_Q_ALONG_R ? r0 + 4 * q_q : r0 + q_l + e * QSTEP;
         tb.q[e] = qTr[r < r_end ? r : r_begin];
       }
-    }
-  };
-  // the same entries for slab k = 0, 1, 2 of this tile's reduction chunk from the preamble (filled by the host with the
-  // clamping of fetch_tabs applied)
-  auto fetch_tabs_pre = [&](int k, Tabs& tb) {
-#pragma unroll
-    for (int e = 0; e < NTP; ++e)
-      tb.p[e] = pre[I2Pre<CFG>::PK + k * BKT + (PL == I2_P_ALONG_R ? 4 * p_q : p_l + e * PSTEP)];
-    if (QM == QM_TABLE) {
-#pragma unroll
-      for (int e = 0; e < NTQ; ++e)
-        tb.q[e] = pre[I2Pre<CFG>::QK + k * BKT + (QL == I2_Q_ALONG_R ? 4 * q_q : q_l + e * QSTEP)];
     }
   };
   Tabs tbA, tbB;
@@ -371,7 +343,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
 #pragma unroll
     for (int e = 0; e < EP_NQ; ++e) {
       const int i = i0 + t / EP_NC4 + e * EP_RSTEP;
-      ct_pre[e] = PRE ? pre[I2Pre<CFG>::CT + t / EP_NC4 + e * EP_RSTEP] : cT[i < M ? i : 0];
+      ct_pre[e] = cT[i < M ? i : 0];
     }
   }
   I2_STAMP(1);
@@ -382,15 +354,9 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
     unsigned p_kb0 = 0xfu, q_kb0 = 0xfu;
     Tabs tb0;
     tb0.tap = 0;
-    if (PRE) {
-      fetch_tabs_pre(0, tb0);
-      fetch_tabs_pre(1, tbA);
-      fetch_tabs_pre(2, tbB);
-    } else {
-      fetch_tabs(r_begin, tb0);
-      fetch_tabs(r_begin + BKT, tbA);
-      fetch_tabs(r_begin + 2 * BKT, tbB);
-    }
+    fetch_tabs(r_begin, tb0);
+    fetch_tabs(r_begin + BKT, tbA);
+    fetch_tabs(r_begin + 2 * BKT, tbB);
 #pragma unroll
     for (int e = 0; e < NVP; ++e) load_p(r_begin, e, pv0, p_kb0, tb0);
 #pragma unroll
@@ -705,16 +671,14 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
 
 
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs,
-                                                    const int4* __restrict__ tiles, const int* __restrict__ pre) {
+__global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict__ probs, const int4* __restrict__ tiles) {
   __shared__ __attribute__((aligned(16))) float lds[I2Lds<PL, QL, CFG>::value];
 #ifdef GRL_TILE_TRACE
   const unsigned long long t0 = wall_clock64();
 #endif
   // `probs` holds one descriptor copy per workgroup (add_launch): the tile entry and the descriptor are fetched side
   // by side instead of one after the other -- one dependent memory round trip less before the first operand load
-  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds,
-                                          (FLAGS & I2F_PRE) ? pre + (size_t)blockIdx.x * I2Pre<CFG>::STRIDE : nullptr);
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], lds);
 #ifdef GRL_TILE_TRACE
   i2_trace_record(probs + blockIdx.x, tiles[blockIdx.x], t0, CFG);
 #endif
@@ -725,8 +689,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const IgemmProb* __restrict
 // already complete) that fills the SIMD time A's few tiles per CU leave idle and rides on A's launch ramp.
 template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
 __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __restrict__ pa, const int4* __restrict__ ta, int n_a,
-                                                         const IgemmProb* __restrict__ pb, const int4* __restrict__ tb,
-                                                         const int* __restrict__ pre_a) {
+                                                         const IgemmProb* __restrict__ pb, const int4* __restrict__ tb) {
   constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value;
   __shared__ __attribute__((aligned(16))) float lds[LA > LB ? LA : LB];
   const int b = (int)blockIdx.x;
@@ -735,7 +698,7 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
 #ifdef GRL_TILE_TRACE
   const unsigned long long t0 = wall_clock64();
 #endif
-  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], lds, (FLa & I2F_PRE) ? pre_a + (size_t)k * I2Pre<CFGa>::STRIDE : nullptr);
+  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], lds);
   else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + k, tb[k], lds);
 #ifdef GRL_TILE_TRACE
   i2_trace_record(is_a ? pa + k : pb + k, is_a ? ta[k] : tb[k], t0, is_a ? CFGa : CFGb);
@@ -743,94 +706,5 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
 }
 
 #endif  // GRL_HOSTEMU
-
-// Up to three DEPENDENT stages in one launch (engine.hip, chain_ops): blocks [0, n0) run stage 0, the next n1 stage 1,
-// the next n2 stage 2 -- each stage its own instantiation -- and a tile of stage s + 1 waits, before it touches its operands,
-// until the stage-s tiles that write them have finished (a counter per consumer row group: every producer tile adds 1 behind
-// a device-scope fence, the consumer's thread 0 polls with an acquire load).  ALL workgroups of the launch are resident at
-// once (the host only chains launches whose tiles fit: <= 3 x 256 workgroups of the 48 KB shape), so a waiting tile can never
-// keep its producers from running; the wait is bounded all the same (a time-out raises cnt[n_cnt + 1], read by the host).
-// What it was meant to buy over three launches: no boundary and no drained machine between the stages -- a consumer starts
-// the moment ITS producers are done.  What it costs on a chip of 8 XCDs with private L2s: every hand-over is a device-scope
-// release / acquire, i.e. an L2 write-back on the producer's XCD and an L2 invalidation on the consumer's, and the
-// invalidations evict the operands the neighbouring tiles share.  Measured slower than the launches it replaces (engine.hip,
-// chain_ops, has the numbers): OPT-IN, GRL_CHAIN=1.  The last workgroup to finish
-// zeroes the counters for the next launch (graph replay).
-struct ChainArgs {
-  const IgemmProb* p[3];
-  const int4* t[3];
-  const int4* dep[3];     // per tile {counter to wait on (-1: none), its target, counter to signal (-1: none), second counter to signal}
-  int n[3];
-  int* cnt;               // [n_cnt] dependency counters, [n_cnt] finished workgroups, [n_cnt + 1] error flag
-  int n_cnt;
-};
-enum { CHAIN_SPIN_LIMIT = 1 << 21 };
-
-#ifdef GRL_HOSTEMU
-// TEST-ONLY sequential form: blocks run in index order, producers first, so every wait is already satisfied
-template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb,
-          int PLc, int QLc, int PMc, int QMc, int CFGc, int FLc>
-void igemm2_chain_kernel(ChainArgs a) {
-  const int b = (int)blockIdx.x;
-  const int kind = b < a.n[0] ? 0 : (b < a.n[0] + a.n[1] ? 1 : 2);
-  const int k = b - (kind == 0 ? 0 : (kind == 1 ? a.n[0] : a.n[0] + a.n[1]));
-  const int4 d = a.dep[kind][k];
-  if (d.x >= 0 && a.cnt[d.x] < d.y) abort();
-  if (kind == 0) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(a.p[0] + k, a.t[0][k]);
-  else if (kind == 1) igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(a.p[1] + k, a.t[1][k]);
-  else igemm2_tile<PLc, QLc, PMc, QMc, CFGc, FLc>(a.p[2] + k, a.t[2][k]);
-  if (threadIdx.x != 255) return;            // (the emulated "threads" of a block run one after the other: signal after the last)
-  if (d.z >= 0) a.cnt[d.z] += 1;
-  if (d.w >= 0) a.cnt[d.w] += 1;
-  if (++a.cnt[a.n_cnt] == (int)gridDim.x)
-    for (int i = 0; i <= a.n_cnt; ++i) a.cnt[i] = 0;
-}
-#else
-template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb,
-          int PLc, int QLc, int PMc, int QMc, int CFGc, int FLc>
-__global__ __launch_bounds__(256) void igemm2_chain_kernel(ChainArgs a) {
-  constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value, LC = I2Lds<PLc, QLc, CFGc>::value;
-  __shared__ __attribute__((aligned(16))) float lds[(LA > LB ? LA : LB) > LC ? (LA > LB ? LA : LB) : LC];
-  const int b = (int)blockIdx.x;
-  const int kind = b < a.n[0] ? 0 : (b < a.n[0] + a.n[1] ? 1 : 2);
-  const int k = b - (kind == 0 ? 0 : (kind == 1 ? a.n[0] : a.n[0] + a.n[1]));
-  const int4 d = a.dep[kind][k];
-#ifdef GRL_TILE_TRACE
-  const unsigned long long t0 = wall_clock64();
-#endif
-  if (d.x >= 0) {
-    if (threadIdx.x == 0) {
-      // poll RELAXED (an acquire per poll would invalidate this XCD's L2 under the producers still running on it -- measured:
-      // 4x the time of the separate launches), then ONE acquire fence once the count is there
-      int spins = 0;
-      while (__hip_atomic_load(a.cnt + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.y) {
-        if (++spins > CHAIN_SPIN_LIMIT) { a.cnt[a.n_cnt + 1] = 1; break; }
-        __builtin_amdgcn_s_sleep(16);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the L1 of this CU and the L2 of this XCD drop their stale lines)
-    }
-    __syncthreads();
-  }
-  if (kind == 0) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(a.p[0] + k, a.t[0][k], lds);
-  else if (kind == 1) igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(a.p[1] + k, a.t[1][k], lds);
-  else igemm2_tile<PLc, QLc, PMc, QMc, CFGc, FLc>(a.p[2] + k, a.t[2][k], lds);
-#ifdef GRL_TILE_TRACE
-  i2_trace_record(a.p[kind] + k, a.t[kind][k], t0, kind == 0 ? CFGa : (kind == 1 ? CFGb : CFGc));
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave acknowledged by the L2 (the L1 writes through) ...
-  __syncthreads();                                    // ... and of every wave of the tile;
-  if (threadIdx.x == 0) {
-    if (d.z >= 0 || d.w >= 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE write-back of this XCD's L2 makes them visible device-wide
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (restated: the compiler drops the wait behind the write-back when its
-    }                                                      //  scoreboard shows nothing outstanding -- cdna_hip_programming.md, G16 pitfall 12)
-    if (d.z >= 0) __hip_atomic_fetch_add(a.cnt + d.z, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d.w >= 0) __hip_atomic_fetch_add(a.cnt + d.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int done = __hip_atomic_fetch_add(a.cnt + a.n_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (int)gridDim.x - 1)
-      for (int i = 0; i <= a.n_cnt; ++i) a.cnt[i] = 0;      // every workgroup has passed its wait: ready for the next launch
-  }
-}
-#endif
 
 }  // namespace grl

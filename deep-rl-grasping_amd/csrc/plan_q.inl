@@ -313,16 +313,6 @@ int grl_ctx::plan_q() {
       for (int l = 1; l < Lc; ++l) { h.w[l] = P + Pon.cw[l]; h.hid[l] = c.q_common[l]; h.z[l] = a.zc[l]; h.g[l] = gact.zc[l]; }
       qf.bwd_tr = upload_vec(wk, std::vector<HtHead>{h});
       qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
-      // GRL_Q_TRUNK_MERGE=1 (opt-in): the trunk's backward inside the tower launch, in the workgroup of the last tower of its
-      // row block to finish (q_kernels.h).  Bit-identical (the partials are added in tower order either way); MEASURED SLOWER
-      // on MI355X (BDQ B = 64: q_bwd 22.5 against 21.3 us, 12 515 against 12 757 updates/s): the device-scope release /
-      // acquire of the hand-off costs more than the boundary of the four-workgroup launch it replaces.
-      const char* nt = getenv("GRL_Q_TRUNK_MERGE");
-      if (nt && atoi(nt)) {
-        const size_t nblk = (size_t)(B + HT_RB - 1) / HT_RB;
-        qf.tw_done = (unsigned*)wk.take(nblk * 4);
-        zero_once.push_back({qf.tw_done, nblk * 4});
-      }
     }
     add_launch(ops_grads, "q_l0", 0, l0);
     Op op; op.tag = "q_fwd";
@@ -382,7 +372,7 @@ int grl_ctx::plan_q() {
       Op op; op.tag = "q_bwd";
       op.run = [fa](hipStream_t s) {
         hipLaunchKernelGGL(q_bwd_towers_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, fa.D + 1), dim3(256), 0, s, fa);
-        if (fa.bwd_tr && !fa.tw_done) hipLaunchKernelGGL(q_bwd_trunk_kernel, dim3((fa.B + HT_RB - 1) / HT_RB), dim3(256), 0, s, fa);
+        if (fa.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, dim3((fa.B + HT_RB - 1) / HT_RB), dim3(256), 0, s, fa);
       };
       ops_grads.push_back(op);
     } else {

@@ -70,14 +70,11 @@ int grl_ctx::plan_sac() {
     // pi in columns 0..31, values_fn in 32..63.  Both networks read the same observations, so conv1's weight
     // gradient becomes ONE product obs-patches^T x [dY_pi | dY_vf] (N = 64: full 64x64 tiles, the gathered patches
     // read once) instead of two half-empty ones.  The target network's buffer keeps the stride (columns 32..63 idle)
-    // so that one set of conv2 tables serves all three.  GRL_NO_CONV1_SIDE=1: separate dense buffers (test switch).
-    {
-      const char* ns = getenv("GRL_NO_CONV1_SIDE");
-      ld1 = (ns && atoi(ns)) ? 32 : 64;
-    }
-    float* a1_pair = ld1 == 64 ? wk.f32((int64_t)B * 225 * 64) : nullptr;
+    // so that one set of conv2 tables serves all three.
+    ld1 = 64;
+    float* a1_pair = wk.f32((int64_t)B * 225 * 64);
     for (int n = 0; n < 3; ++n) {
-      a1[n] = ld1 == 32 ? wk.f32((int64_t)B * 225 * 32) : (n < 2 ? a1_pair + 32 * n : wk.f32((int64_t)B * 225 * 64));
+      a1[n] = n < 2 ? a1_pair + 32 * n : wk.f32((int64_t)B * 225 * 64);
       a2[n] = wk.f32((int64_t)B * 36 * 64);
       a3[n] = wk.f32((int64_t)B * 16 * 64);
     }
@@ -107,8 +104,7 @@ int grl_ctx::plan_sac() {
   }
   if (fused_heads) {
     {
-      const char* e = getenv("GRL_L0_SPLIT");
-      l0_split = e ? std::max(1, atoi(e)) : 3;       // reduction of the layer-0 GEMM (K = 513) cut into partial sums
+      l0_split = std::max(1, tune_int("l0_split", 3));       // reduction of the layer-0 GEMM (K = 513) cut into partial sums
       IgemmProb probe = blank();
       probe.M = B; probe.N = hid[0]; probe.K = F;
       set_split(probe, l0_split);
@@ -131,12 +127,12 @@ int grl_ctx::plan_sac() {
     zero_once.push_back({dls, (size_t)B * ld_dm * 4});
   }
   if (cnn) {
-    float* g1_pair = ld1 == 64 ? wk.f32((int64_t)B * 225 * 64) : nullptr;
+    float* g1_pair = wk.f32((int64_t)B * 225 * 64);
     for (int n = 0; n < 2; ++n) {
       dfeat[n] = wk.f32((int64_t)B * ldf);
       g3[n] = wk.f32((int64_t)B * 16 * 64);
       g2[n] = wk.f32((int64_t)B * 36 * 64);
-      g1[n] = ld1 == 64 ? g1_pair + 32 * n : wk.f32((int64_t)B * 225 * 32);
+      g1[n] = g1_pair + 32 * n;
     }
   }
 
@@ -284,12 +280,10 @@ int grl_ctx::plan_sac() {
       ha.log_ent_coef = params + ent_off; ha.da_pi = da_pi; ha.dmu = dmu; ha.dls = dls; ha.ld_dm = ld_dm;
       ha.rew = rew; ha.done = done; ha.gamma = c.gamma;
       ha.d_out[1] = d_v; ha.d_out[2] = d_qf1; ha.d_out[3] = d_qf2; ha.d_out[4] = d_qf1pi; ha.ld_d = ld_d;
-      if (const char* e = getenv("GRL_HEADS_STAMPS")) {
-        if (e[0] == '1') {
-          ha.stamps = (unsigned long long*)wk.take(4 * 32 * 8);
-          zero_once.push_back({ha.stamps, 4 * 32 * 8});
-          dbg["heads_stamps"] = {(const float*)ha.stamps, 4 * 32 * 2};
-        }
+      if (tune_int("heads_stamps", 0)) {     // in-kernel phase stamps (scripts/heads_stamps.py)
+        ha.stamps = (unsigned long long*)wk.take(4 * 32 * 8);
+        zero_once.push_back({ha.stamps, 4 * 32 * 8});
+        dbg["heads_stamps"] = {(const float*)ha.stamps, 4 * 32 * 2};
       }
       // argument blocks: [0] the plain update, [1] / [2] updates of a prefetching multi-update call whose head launch
       // opens the update (Adam step size) and, from the second update on, advances the RNG counter
@@ -486,7 +480,7 @@ int grl_ctx::plan_sac() {
 
   }
   // =============================================================== backward through the two CNNs
-  bool fillers_on = false, only_vec_dense = false;
+  bool only_vec_dense = false;
   int rider_budget = 0;                            // empty slots of conv3_bwd's last dispatch round (see below)
   std::vector<Op> conv3_bwd_plain;                 // conv3_bwd without riders, for the staged data-parallel plan
   std::vector<IgemmProb> dense_affine, conv_all;   // dense / conv weight-gradient problems as first built (staged plan)
@@ -501,13 +495,11 @@ int grl_ctx::plan_sac() {
   //    conv2_bwd's tiles: they start when the first wave drains (18 us) and end at 36 us instead of 28: conv2_bwd
   //    31.8 -> 41.2 us, the weight-gradient launch 36.6 -> 28.2 us, reduction +2.5 us: 4 519 against 4 580.
   if (cnn) {
-    // backward-data with exact taps (conv_bwd_tabs_exact); GRL_NO_EXACT_TAP=1 keeps the masked parity-class form
-    // (bit-identical results, 1.8-2.25x the MACs: test / measurement switch)
-    const char* net = getenv("GRL_NO_EXACT_TAP");
-    exact_tap = !(net && atoi(net));
+    // backward-data with exact taps (conv_bwd_tabs_exact; the masked parity-class form of conv_bwd_tabs gives bit-identical
+    // sums with 1.8-2.25x the MACs -- the auto-encoder's padded convolutions still use it)
     std::vector<int32_t> untouched;
-    std::vector<ConvBwdClass> bc3 = exact_tap ? conv_bwd_tabs_exact(cg[2], B, nullptr) : conv_bwd_tabs(cg[2], B);
-    std::vector<ConvBwdClass> bc2 = exact_tap ? conv_bwd_tabs_exact(cg[1], B, &untouched) : conv_bwd_tabs(cg[1], B);
+    std::vector<ConvBwdClass> bc3 = conv_bwd_tabs_exact(cg[2], B, nullptr);
+    std::vector<ConvBwdClass> bc2 = conv_bwd_tabs_exact(cg[1], B, &untouched);
     if (!untouched.empty())   // input pixels of conv2 that no output window covers (row / column 14): their gradient is zero
       for (int n = 0; n < 2; ++n) zero_once.push_back({g1[n], (size_t)(((int64_t)B * 225 - 1) * ld1 + 32) * 4});
     for (int n = 0; n < 2; ++n)
@@ -521,21 +513,16 @@ int grl_ctx::plan_sac() {
     // 192 CUs hold two tiles, 64 hold three, and the launch lasts as long as those 64.  Dense-layer weight gradients
     // whose operands are complete by then (d feat, head gradients) and whose tiles are as long as conv3_bwd's (reduction
     // = the batch, 8 slabs) ride in the empty slots of that round -- list positions 576.. land exactly on the CUs that
-    // hold two -- and leave the merged weight-gradient launch.  GRL_NO_CONV3_RIDERS=1 switches it off.
+    // hold two -- and leave the merged weight-gradient launch.
     {
       int cfg3 = -1;
       const int t3 = planned_tiles(bwd_pr[1], 1, "conv3_bwd", &cfg3);
-      const char* nr = getenv("GRL_NO_CONV3_RIDERS");
-      const char* nfl0 = getenv("GRL_FILLERS");
-      const char* nm0 = getenv("GRL_NO_WGRAD_MERGE");
-      const char* le0 = getenv("GRL_LANES");
-      const bool off = (nr && atoi(nr)) || (nfl0 && nfl0[0] == '1') || (nm0 && nm0[0] == '1') || (le0 && le0[0] == '1');
-      rider_budget = (!off && cfg3 == 3) ? free_slots(t3, 3) : 0;
+      rider_budget = cfg3 == 3 ? free_slots(t3, 3) : 0;
     }
-    int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3 (GRL_WG_SPLIT=a,b,c overrides the model's choice)
-    pick_wgrad_splits(cg, ft, ld1 == 64 ? 2 : 1, wsplit, rider_budget);
-    if (const char* e = getenv("GRL_WG_SPLIT")) sscanf(e, "%d,%d,%d", &wsplit[0], &wsplit[1], &wsplit[2]);
-    if (ld1 == 64) {   // conv1 of both networks: one problem over the side-by-side gradient buffer, columns 32n.. -> net n
+    int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3 (GRL_TUNE wg_split=a/b/c overrides the model's choice)
+    pick_wgrad_splits(cg, ft, 2, wsplit, rider_budget);
+    tune_int3("wg_split", wsplit);
+    {   // conv1 of both networks: one problem over the side-by-side gradient buffer, columns 32n.. -> net n
       IgemmProb p = conv_wgrad(x_obs, ft[0], cg[0], g1[0], nullptr, wsplit[0], 2);
       p.c = wk.f32(p.slab_stride * p.split);
       wgc[0].push_back(p);
@@ -551,12 +538,6 @@ int grl_ctx::plan_sac() {
       }
     }
     for (int n = 0; n < 2; ++n) {
-      const float* xin = x_obs;
-      if (ld1 != 64) {
-        IgemmProb p = conv_wgrad(xin, ft[0], cg[0], g1[n], nullptr, wsplit[0]);
-        p.c = wk.f32(p.slab_stride * p.split);
-        add_wgrad(wgc[0], p, ex[n].w[0], 0, cg[0].K(), ex[n].b[0]);
-      }
       {
         IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, wsplit[1]);
         p.c = wk.f32(p.slab_stride * p.split);
@@ -622,8 +603,6 @@ int grl_ctx::plan_sac() {
       else if (p.p_ones_i >= 0) wg_ones.push_back(p);
       else wg_plain.push_back(p);
     }
-    const char* le = getenv("GRL_LANES");
-    use_lanes = le && le[0] == '1';   // ROCm's graph scheduler serialises most forked kernels: off by default
     wgrad_ops.clear();
     // One launch for all weight gradients: the dense problems (x^T read with affine addresses) are re-expressed
     // with the table addressing of the convolution ones and appended to that launch -- one kernel boundary
@@ -632,8 +611,7 @@ int grl_ctx::plan_sac() {
     for (int l = 2; l >= 0; --l) conv_all.insert(conv_all.end(), wgc[l].begin(), wgc[l].end());
     only_vec_dense = wg_plain.empty() && wg_rest.empty();
     std::vector<IgemmProb> wg_merged;
-    const char* nm = getenv("GRL_NO_WGRAD_MERGE");
-    if (cnn && !use_lanes && !(nm && nm[0] == '1') && wg_plain.empty() && !wgc[0].empty() && v2_prob_ok(wgc[0][0], 2)) {
+    if (cnn && wg_plain.empty() && !wgc[0].empty() && v2_prob_ok(wgc[0][0], 2)) {
       for (auto p : wg_ones) {
         std::vector<int32_t> ti(p.M), tr(p.K);
         for (int i = 0; i < p.M; ++i) ti[i] = i * p.p_ld_i[0];
@@ -645,57 +623,29 @@ int grl_ctx::plan_sac() {
       }
       wg_ones.clear();
     }
-    // Weight gradients as FILLERS of the backward-data launches (opt-in, GRL_FILLERS=1): each group only needs
-    // tensors that are complete when the stage it rides on starts (fc + head layers: d feat and the head gradients;
-    // conv3: g3 from fc_bwd; conv2: g2 from conv3_bwd), so its tiles share that stage's launch
-    // (igemm2_pair_kernel) and only conv1's (needs g1, the last backward-data result) remain a launch of their own.
-    // Same tiles, same workgroup shape, bit-identical results -- but MEASURED SLOWER on MI355X at B = 256
-    // (fc_bwd 10.9 -> 21.1, conv3_bwd 23.3 -> 30.3, conv2_bwd 29.8 -> 43.5 us, conv1's weight gradient alone 21.0
-    // against 38.5 us for the single merged launch: 116 vs 102.5 us, 3998 vs 4287 updates/s): the 10-us reduction
-    // chunks of the weight gradients lengthen every stage's tail by more than the launch they save, and the
-    // merged launch (747 tiles, heaviest first) was already the better packing.  Kept as a tested switch.
-    const char* nfl = getenv("GRL_FILLERS");
-    const bool fillers = cnn && !wg_merged.empty() && nfl && nfl[0] == '1';
-    fillers_on = fillers;
     if (cnn) {
-      if (fillers) {
-        add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0], "wgrad_dense", 2, wg_merged);
-        add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1], "wgrad_conv3", 2, wgc[2]);
-        add_launch(ops_grads, "conv2_bwd", 1, bwd_pr[2], "wgrad_conv2", 2, wgc[1]);
-        wg_merged.clear(); wgc[2].clear(); wgc[1].clear();
-      } else {
-        add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
-        std::vector<IgemmProb> riders = take_riders(wg_merged, rider_budget);
-        if (!riders.empty()) add_launch(conv3_bwd_plain, "conv3_bwd", 1, bwd_pr[1]);
-        add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1], "wgrad_dense", 2, riders);
-        add_launch(ops_grads, "conv2_bwd", 1, bwd_pr[2]);
-      }
+      add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
+      std::vector<IgemmProb> riders = take_riders(wg_merged, rider_budget);
+      if (!riders.empty()) add_launch(conv3_bwd_plain, "conv3_bwd", 1, bwd_pr[1]);
+      add_launch(ops_grads, "conv3_bwd", 1, bwd_pr[1], "wgrad_dense", 2, riders);
+      add_launch(ops_grads, "conv2_bwd", 1, bwd_pr[2]);
     }
     add_launch(wgrad_ops, "wgrad_dense", 2, wg_ones);
     add_launch(wgrad_ops, "wgrad_dense", 2, wg_plain);
     add_launch(wgrad_ops, "wgrad_small", 2, wg_rest);
-    if (use_lanes) {
-      add_launch(wgrad_ops, "wgrad_conv3", 2, wgc[2]);
-      add_launch(wgrad_ops, "wgrad_conv2", 2, wgc[1]);
-      add_launch(wgrad_ops, "wgrad_conv1", 2, wgc[0]);
-    } else {
+    {
       std::vector<IgemmProb> all;
       for (int l = 2; l >= 0; --l) all.insert(all.end(), wgc[l].begin(), wgc[l].end());
       all.insert(all.end(), wg_merged.begin(), wg_merged.end());
-      add_launch(wgrad_ops, "wgrad_conv", 2, all, "", 0, {}, fillers ? 0 : -1);   // (fillers: conv1 alone keeps the 64x64 shape)
+      add_launch(wgrad_ops, "wgrad_conv", 2, all);
     }
   }
-  // ---- schedule: weight gradients ride on the side lane next to the backward-data chain.  In list
-  // (= eager) order every op still follows its producers.
+  // ---- schedule: every weight-gradient launch directly behind the last producer of its operands
   {
     std::vector<Op> sched;
-    auto take = [&](const char* tag, bool side_lane) {
+    auto take = [&](const char* tag) {
       for (auto& o : wgrad_ops)
-        if (o.tag == tag) {
-          Op c = o;
-          if (side_lane && use_lanes) { c.lane = 1; c.fork = true; }
-          sched.push_back(c);
-        }
+        if (o.tag == tag) sched.push_back(o);
     };
     int dense_after = -1;   // the dense weight gradients need every head gradient and (CNN) d feat
     for (size_t k = 0; k < ops_grads.size(); ++k)
@@ -703,10 +653,8 @@ int grl_ctx::plan_sac() {
     for (size_t k = 0; k < ops_grads.size(); ++k) {
       const Op& o = ops_grads[k];
       sched.push_back(o);
-      if ((int)k == dense_after) { take("wgrad_dense", cnn); take("wgrad_small", cnn); }
-      if (o.tag == "fc_bwd") take("wgrad_conv3", true);
-      else if (o.tag == "conv3_bwd") take("wgrad_conv2", true);
-      else if (o.tag == "conv2_bwd") { take("wgrad_conv1", false); take("wgrad_conv", false); }
+      if ((int)k == dense_after) { take("wgrad_dense"); take("wgrad_small"); }
+      if (o.tag == "conv2_bwd") take("wgrad_conv");
     }
     ops_grads.swap(sched);
   }
@@ -716,7 +664,7 @@ int grl_ctx::plan_sac() {
     // get a launch of their own right after the feature gradients, so that their all-reduce can travel while the
     // convolution backward and the convolution weight gradients run (grasp_rl/parallel.py).  Costs two launches
     // more than the single-exchange plan; same tiles, same arithmetic.
-    staged_ok = cnn && fused_heads && only_vec_dense && !dense_affine.empty() && !conv_all.empty() && !fillers_on && !use_lanes;
+    staged_ok = cnn && fused_heads && only_vec_dense && !dense_affine.empty() && !conv_all.empty();
     if (staged_ok) {
       int cut = -1;
       for (size_t k = 0; k < ops_grads.size(); ++k)
@@ -802,7 +750,7 @@ int grl_ctx::plan_sac() {
       //   middle:                                              body, heads[tick, counter += 1] | reduce + Adam + gather(t+1)
       //   last  :                                              body, heads[tick, counter += 1] | reduce + Adam (counter += 1)
       const char* npf = getenv("GRL_NO_GATHER_PREFETCH");
-      if (heads_mfma && !(npf && atoi(npf)) && !use_lanes) {
+      if (heads_mfma && !(npf && atoi(npf))) {
         GatherArgs g1 = pf_ga;
         g1.use_rng = 1; g1.adam_tick = 0; g1.quiet = 0; g1.rng_ahead = 0;
         const int gx = pf_gx;
@@ -831,33 +779,10 @@ int grl_ctx::plan_sac() {
           }
           dst.push_back(v == 2 ? fo : ro);
         }
-        // the same three sequences for the data-parallel update (grl_train_step_allreduce): the final launch forms the sums
-        // WITHOUT applying them (the exchange follows, Adam runs in dp_apply_kernel) and still carries the next gather
-        Op rd; rd.tag = "reduce_slabs";
-        rd.join = true;
-        rd.bytes = ro.bytes;
-        rd.run = [dr, d_rt, ntiles, lk, has_loss, aa, g2, gx](hipStream_t s) {
-          hipLaunchKernelGGL(reduce_slabs_gather_kernel, dim3(ntiles + has_loss + gx * g2.B * 2), dim3(256), 0, s, dr, d_rt, ntiles, lk,
-                             has_loss, aa, 0, g2, gx);
-        };
-        for (int v = 0; v < 3; ++v) {
-          const std::vector<Op>& src = v == 0 ? ops_pf_first : (v == 1 ? ops_pf_mid : ops_pf_last);
-          std::vector<Op>& dst = v == 0 ? ops_pfdp_first : (v == 1 ? ops_pfdp_mid : ops_pfdp_last);
-          dst.assign(src.begin(), src.end() - 1);
-          dst.push_back(v == 2 ? ops_grads.back() : rd);
-        }
+        pf_lk = lk; pf_g2 = g2;     // (the data-parallel update builds its own final launches from these at connect)
         prefetch_ok = true;
       }
     }
-  }
-
-  // ---- dependent stages as one launch (igemm2_chain_kernel; opt-in GRL_CHAIN=1, measured slower -- engine.hip, chain_ops):
-  // conv3_fwd -> fc_fwd -> heads_l0 and heads_dfeat -> fc_bwd.  Applied to the lists of full updates (the staged
-  // data-parallel lists keep their launches).
-  for (std::vector<Op>* lst : {&ops_grads, &ops_grads_apply, &ops_pf_first, &ops_pf_mid, &ops_pf_last}) {
-    if (lst->empty()) continue;
-    chain_ops(*lst, {"conv3_fwd", "fc_fwd", "heads_l0"});
-    chain_ops(*lst, {"heads_dfeat", "fc_bwd"});
   }
 
   // =============================================================== apply

@@ -26,7 +26,6 @@ struct QFusedArgs {
   const float* d_adv; const float* d_v;   // loss gradients [B, D*nb], [B]
   float* dh_part;         // [D+1][B, Ht]: gradient w.r.t. the trunk output, one partial per tower
   float trunk_scale;
-  unsigned* tw_done;      // [B/16] towers finished per row block, or nullptr: q_bwd_trunk_kernel is a launch of its own
 };
 
 #ifdef GRL_HOSTEMU
@@ -51,28 +50,6 @@ __global__ __launch_bounds__(256) void q_bwd_towers_kernel(QFusedArgs a) {
   }
   __syncthreads();
   ht_bwd_head(h, row0, a.B, s, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht);
-  if (!a.tw_done || !a.bwd_tr) return;       // (uniform)
-  // ---- (opt-in, plan_q.inl: measured slower than the launch it replaces) the trunk of this row block runs in the workgroup
-  // of its LAST tower to finish: no second launch.  Hand-off as in
-  // cdna_hip_programming.md, Guideline 16 (counter form): every wave drains its stores, the barrier, ONE device-scope
-  // release + counter; the last arriver acquires once, then reads the partials with plain loads.  Correct wherever the
-  // towers of a row block ran (8 XCDs with private L2s); the counter is re-armed by the last arriver (graph replay).
-  __shared__ int last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned done = __hip_atomic_fetch_add(a.tw_done + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = done == (unsigned)a.D;
-    if (last) {
-      __hip_atomic_store(a.tw_done + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-  }
-  __syncthreads();
-  if (!last) return;
-  ht_bwd_head(*a.bwd_tr, row0, a.B, s, nullptr, 0, a.dh_part, a.D + 1, (long)a.B * a.Ht, a.trunk_scale);
 }
 
 __global__ __launch_bounds__(256) void q_bwd_trunk_kernel(QFusedArgs a) {

@@ -51,8 +51,8 @@ EXPORTS = [
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
     "grl_ae_train_step",
     "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate", "grl_compute_grads_staged", "grl_grad_ranges",
-    "grl_norm_update", "grl_set_obs_count", "grl_set_ret_var", "grl_get_obs_stats",
-    "grl_allreduce_init", "grl_allreduce_connect", "grl_train_step_allreduce", "grl_allreduce_status", "grl_allreduce_set_overlap",
+    "grl_norm_update", "grl_set_running_stats", "grl_set_ret_var", "grl_get_obs_stats",
+    "grl_allreduce_init", "grl_allreduce_connect", "grl_train_step_allreduce", "grl_allreduce_status", "grl_allreduce_set_overlap", "grl_allreduce_set_mode",
 ]
 
 
@@ -98,10 +98,11 @@ def load_library(path=None):
     lib.grl_allreduce_init.argtypes = [vp, i32, i32, vp]
     lib.grl_allreduce_connect.argtypes = [vp, vp]
     lib.grl_allreduce_set_overlap.argtypes = [vp, i32]
+    lib.grl_allreduce_set_mode.argtypes = [vp, i32]
     lib.grl_train_step_allreduce.argtypes = [vp, i32, vp, vp]
     lib.grl_allreduce_status.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
     lib.grl_norm_update.argtypes = [vp, f32p, i32]
-    lib.grl_set_obs_count.argtypes = [vp, C.c_double]
+    lib.grl_set_running_stats.argtypes = [vp, dp, dp, C.c_double]
     lib.grl_set_ret_var.argtypes = [vp, C.c_double]
     lib.grl_get_obs_stats.argtypes = [vp, dp, dp, C.POINTER(C.c_double)]
     lib.grl_ae_train_step.argtypes = [vp, vp, C.c_int]

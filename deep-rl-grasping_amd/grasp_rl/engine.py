@@ -195,6 +195,13 @@ class SacEngine:
         (include/grl.h: grl_allreduce_set_overlap).  Raises when the configuration has no staged plan."""
         check(self.lib, self.lib.grl_allreduce_set_overlap(self.h, 1 if on else 0))
 
+    MODES = {"auto": 0, "twoshot": 1, "oneshot": 2}
+
+    def allreduce_set_mode(self, mode="auto"):
+        """'auto' (one-shot for world <= 2), 'twoshot', 'oneshot' (include/grl.h: grl_allreduce_set_mode).  All ranks alike,
+        while no exchange is in flight."""
+        check(self.lib, self.lib.grl_allreduce_set_mode(self.h, self.MODES[mode]))
+
     def train_allreduce(self, n_steps=1, idx=None, eps=None):
         pi, pe, keep = self._noise(idx, eps, n_steps)
         check(self.lib, self.lib.grl_train_step_allreduce(self.h, n_steps, pi, pe))
@@ -211,8 +218,11 @@ class SacEngine:
         obs = np.ascontiguousarray(obs, dtype=np.float32)
         check(self.lib, self.lib.grl_norm_update(self.h, obs.ctypes.data, obs.shape[0]))
 
-    def set_obs_count(self, count):
-        check(self.lib, self.lib.grl_set_obs_count(self.h, float(count)))
+    def set_running_stats(self, mean, var, count):
+        """Starting point of the running statistics grl_norm_update continues from (env layout, float64)."""
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        var = np.ascontiguousarray(var, dtype=np.float64)
+        check(self.lib, self.lib.grl_set_running_stats(self.h, mean.ctypes.data, var.ctypes.data, float(count)))
 
     def set_ret_var(self, ret_var):
         check(self.lib, self.lib.grl_set_ret_var(self.h, float(ret_var)))

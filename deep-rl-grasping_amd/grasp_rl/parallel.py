@@ -125,13 +125,16 @@ class DataParallelSac:
 
 class DataParallelInGraph:
     """The exchange inside the library (include/grl.h: grl_allreduce_init / connect / grl_train_step_allreduce,
-    csrc/dp_kernels.h): a two-shot all-reduce over IPC-mapped exchange buffers, captured in the update's hipGraph --
+    csrc/dp_kernels.h): hand-written all-reduces over IPC-mapped exchange buffers, captured in the update's hipGraph --
     one C call per update, no collective library, no Python between compute and apply.  ``torch.distributed`` (any
     backend; gloo is enough) is used ONCE, to hand the 128-byte handle blobs around.  Needs
-    HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment (dmabuf IPC).  Every replica receives bit-identical sums: each
-    1/world chunk is added by its owner in rank order.  `train` raises if a peer did not arrive (bounded waits)."""
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment (dmabuf IPC).  Every replica receives bit-identical sums: every
+    element is added in rank order.  ``mode``: 'auto' (one-shot for world <= 2, else two-shot), 'oneshot', 'twoshot';
+    ``overlap``: the staged plan with the dense bucket's exchange under the convolution backward (two-shot).
+    A rank waits for a late peer (GRL_TUNE dp_timeout_ms, default 120 s); after a time-out `train` / `check` raise on
+    EVERY rank (the channel is poisoned: no replica applies a partial exchange silently)."""
 
-    def __init__(self, engine, group=None, overlap=False):
+    def __init__(self, engine, group=None, overlap=False, mode="auto"):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.eng, self.group = engine, group
@@ -141,9 +144,30 @@ class DataParallelInGraph:
         dist.all_gather_object(handles, mine, group=group)
         engine.allreduce_connect(handles)
         self.overlap = bool(overlap)
+        self.mode = mode
+        engine.allreduce_set_mode(mode)
         if self.overlap:                   # dense bucket exchanged on a side lane of the graph, under the conv backward
             engine.allreduce_set_overlap(True)
         dist.barrier(group=group)          # every rank has mapped every buffer before the first exchange starts
+
+    def set_mode(self, mode=None, overlap=None):
+        """Switch the exchange variant.  Collective: every rank drains its stream and meets at a barrier first, so no
+        exchange is in flight anywhere while the source buffers change roles."""
+        self.eng.synchronize()
+        dist.barrier(group=self.group)
+        err = None
+        try:
+            if overlap is not None:
+                self.eng.allreduce_set_overlap(bool(overlap))
+                self.overlap = bool(overlap)
+            if mode is not None:
+                self.eng.allreduce_set_mode(mode)
+                self.mode = mode
+        except Exception as e:       # noqa: BLE001  (raised after the closing barrier: the ranks stay in step)
+            err = e
+        dist.barrier(group=self.group)
+        if err is not None:
+            raise err
 
     def broadcast_parameters(self, src=0):
         P = [self.eng.get_parameters() if self.rank == src else None]
@@ -151,8 +175,93 @@ class DataParallelInGraph:
         self.eng.set_parameters(P[0])
 
     def train(self, n_steps=1, idx=None, eps=None):
-        self.eng.train_allreduce(n_steps, idx, eps)
+        self.eng.train_allreduce(n_steps, idx, eps)    # (raises once a previous exchange has timed out, on every rank)
 
     def check(self):
-        """Synchronises; raises if an exchange timed out.  Returns the number of completed exchanges."""
+        """Synchronises; raises if an exchange timed out.  Returns the number of exchanges begun."""
         return self.eng.allreduce_status()
+
+
+def launched_world():
+    """(rank, world, local_rank) of a process started by ``torch.distributed.run`` / torchrun (RANK, WORLD_SIZE,
+    LOCAL_RANK in the environment), or None for a plain single-process start."""
+    import os
+    try:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+    except ValueError:
+        return None
+    if world <= 1:
+        return None
+    return rank, world, int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+class DataParallelRuntime:
+    """What ``grasp_rl.sb.SAC(data_parallel=...)`` needs around the engine: the process group (initialised here when the
+    launcher has not: gloo -- the gradient exchange itself runs inside the update graph and needs no collective
+    library), a gloo CONTROL group for the few host-side exchanges of the learn loop (handle blobs, return statistics,
+    the stop flag), this rank's device and its share of the environments / of the global minibatch."""
+
+    def __init__(self):
+        import os
+        lw = launched_world()
+        if not dist.is_initialized():
+            if lw is None:
+                raise RuntimeError("data_parallel needs a torch.distributed launch (torchrun: RANK / WORLD_SIZE / MASTER_*)")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("gloo", rank=lw[0], world_size=lw[1])
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.local_rank = lw[2] if lw is not None else self.rank
+        # host-side traffic never touches a GPU stream
+        self.ctrl = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        same = os.environ.get("GRL_DP_SAME_DEVICE", "0") == "1"       # several ranks on one GPU (tests, dress rehearsals)
+        self.device = "cuda:%d" % (0 if same else self.local_rank)
+
+    def shard(self, total, what="environments"):
+        """This rank's share of `total` items dealt evenly over the ranks."""
+        if total % self.world:
+            raise ValueError("%d %s do not divide over %d ranks" % (total, what, self.world))
+        return total // self.world
+
+    def any(self, flag):
+        """True on every rank if `flag` is true on any (one small host all-reduce; also bounds the skew between ranks)."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.ctrl)
+        return bool(t.item())
+
+    def all(self, flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.ctrl)
+        return bool(t.item())
+
+    def barrier(self):
+        dist.barrier(group=self.ctrl)
+
+    def make_exchange(self, engine, prefer="ingraph", overlap=False, mode="auto"):
+        """The gradient exchange for `engine`: in-graph over IPC-mapped memory when every rank can set it up, else
+        (or with prefer="collective") compute -> all-reduce -> apply (``DataParallelSac``: RCCL, or gloo where the ranks
+        do not own a GPU each).  The decision is COLLECTIVE: a rank whose set-up fails still takes part in every
+        collective of the fallback."""
+        ok, dp = True, None
+        if prefer == "ingraph":
+            try:
+                dp = DataParallelInGraph(engine, group=self.ctrl, overlap=overlap, mode=mode)
+            except Exception as e:       # noqa: BLE001  (hipIpc unavailable, no staged plan for `overlap`, ...)
+                ok = False
+                self.ingraph_error = e
+            if self.all(ok):
+                return dp
+        # a collective library: RCCL with one GPU per rank, gloo otherwise (CPU tests, several ranks sharing a GPU)
+        if torch.cuda.is_available() and not os_same_device():
+            if dist.get_backend() == "nccl":
+                return DataParallelSac(engine, overlap=overlap)
+            if getattr(self, "_nccl", None) is None:
+                self._nccl = dist.new_group(backend="nccl")
+            return DataParallelSac(engine, group=self._nccl, overlap=overlap)
+        return DataParallelSac(engine, group=self.ctrl, overlap=overlap)
+
+
+def os_same_device():
+    import os
+    return os.environ.get("GRL_DP_SAME_DEVICE", "0") == "1"

@@ -10,6 +10,17 @@ Differences to stable-baselines, all opt-in: vectorised envs with ``num_envs > 1
 (stable-baselines 2 asserts a single env); ``ent_coef`` must be 'auto' / 'auto_<init>' and
 ``target_update_interval`` 1 (what the reference uses: zip JSON).
 
+Data parallelism (BASELINE configs[4]: global batch 1024, 64 envs, 8 GPUs).  ``data_parallel="auto"`` (or
+GRL_DATA_PARALLEL=auto in the environment, so that the reference's unmodified scripts pick it up) makes a model that was
+started by ``torch.distributed.run`` one replica of W: ``batch_size`` is the GLOBAL minibatch (each rank's engine takes
+batch_size / W rows from ITS replay shard, which holds the transitions of ITS environments), the gradients are exchanged
+inside the update's graph (``grasp_rl.parallel.DataParallelInGraph``; RCCL as fallback), parameters start from rank 0's,
+the VecNormalize statistics are merged over the ranks at every env step (host: ``share_running_stats``; with
+``device_norm`` on the device, grl_norm_update), ``num_timesteps`` / ``total_timesteps`` / ``learning_starts`` count the
+environment steps of ALL ranks, callbacks (evaluation, checkpoints, logging) run on rank 0 only and its stop request ends
+``learn`` on every rank.  ``python -m grasp_rl.dp_run <script> ...`` is the launcher-side helper for scripts that create
+directories (train_stable_baselines.py:27-29).
+
 Updates per env step.  stable-baselines runs ``gradient_steps`` updates every ``train_freq`` calls of ``env.step``
 and its env is a single environment, so its defaults (1, 1) mean ONE UPDATE PER ENVIRONMENT STEP.  With N
 sub-environments one ``env.step`` is N environment steps; ``gradient_steps=None`` (the default here) resolves to
@@ -46,7 +57,7 @@ class SAC:
                  gradient_steps=None, target_entropy="auto", action_noise=None, random_exploration=0.0, verbose=0,
                  tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False,
                  seed=None, n_cpu_tf_sess=None, device="cuda:0", overlap_env_step=None, replay_rgb_u8=False,
-                 device_norm=None):
+                 device_norm=None, data_parallel=None, dp_exchange="ingraph", dp_mode="auto", dp_overlap=False):
         if isinstance(policy, str):
             if policy not in _POLICY_NAMES:
                 raise ValueError("unknown policy %r" % policy)
@@ -78,6 +89,13 @@ class SAC:
         if device_norm is None:
             device_norm = os.environ.get("GRL_DEVICE_NORM", "0") == "1"
         self.device_norm = bool(device_norm)
+        # Opt-in: one replica of a data-parallel job (module docstring).  None / False: off; "auto": when this process was
+        # launched by torch.distributed.run with WORLD_SIZE > 1; True: required (raises without a launch).
+        if data_parallel is None:
+            data_parallel = os.environ.get("GRL_DATA_PARALLEL") or None
+        self.data_parallel = data_parallel
+        self.dp_exchange, self.dp_mode, self.dp_overlap = dp_exchange, dp_mode, bool(dp_overlap)
+        self._dp_rt = self._dp = None
         self.num_timesteps = 0
         self.n_updates = 0
         self.env = None
@@ -88,6 +106,8 @@ class SAC:
         self.engine = None
         self.episode_reward = None
         self._rng = np.random.default_rng(seed)
+        if self._dp_runtime() is not None:        # exploration noise differs per replica
+            self._rng = np.random.default_rng([0 if seed is None else int(seed), self._dp_rt.rank])
         if env is not None:
             self.set_env(env)
         if _init_setup_model and self.observation_space is not None:
@@ -114,6 +134,23 @@ class SAC:
     def get_vec_normalize_env(self):
         return self._vec_normalize_env
 
+    # ------------------------------------------------------------------ data parallel
+    def _dp_runtime(self):
+        if self._dp_rt is not None:
+            return self._dp_rt
+        mode = self.data_parallel
+        if mode in (None, False, "", "0", "off"):
+            return None
+        from ..parallel import DataParallelRuntime, launched_world
+        import torch.distributed as dist
+        if mode == "auto" and launched_world() is None and not dist.is_initialized():
+            return None
+        rt = DataParallelRuntime()
+        if rt.world == 1 and mode == "auto":
+            return None
+        self._dp_rt = rt
+        return rt
+
     # ------------------------------------------------------------------ model
     def _learning_rate_value(self):
         lr = self.learning_rate
@@ -136,11 +173,17 @@ class SAC:
         act_dim = int(np.prod(self.action_space.shape))
         if self.target_entropy == "auto":
             self.target_entropy = -np.prod(self.action_space.shape).astype(np.float32)
-        kw = dict(act_dim=act_dim, layers=layers, batch_size=self.batch_size, act_batch=max(1, self.n_envs),
+        rt = self._dp_runtime()
+        self._local_batch = self.batch_size if rt is None else rt.shard(self.batch_size, "minibatch rows")
+        engine_seed = 0 if self.seed is None else int(self.seed)
+        if rt is not None:
+            engine_seed = engine_seed + 7919 * rt.rank       # every replica draws its own replay indices / policy noise
+            self.device = rt.device
+        kw = dict(act_dim=act_dim, layers=layers, batch_size=self._local_batch, act_batch=max(1, self.n_envs),
                   replay_capacity=self.buffer_size,
                   normalize=0 if self._vec_normalize_env is None else _capi.norm_mode(self._vec_normalize_env),
                   gamma=self.gamma, lr=self._learning_rate_value(), tau=self.tau,
-                  target_entropy=float(self.target_entropy), seed=0 if self.seed is None else int(self.seed))
+                  target_entropy=float(self.target_entropy), seed=engine_seed)
         if self._vec_normalize_env is not None:
             vn = self._vec_normalize_env
             kw.update(clip_obs=vn.clip_obs, clip_reward=vn.clip_reward, norm_eps=vn.epsilon)
@@ -166,6 +209,9 @@ class SAC:
         params = init_parameters(self.engine.table, seed=0 if self.seed is None else int(self.seed))
         params["model/log_ent_coef:0"] = np.float32(np.log(self._ent_init)).reshape(())
         self.engine.set_parameters(params)
+        if rt is not None:
+            self._dp = rt.make_exchange(self.engine, prefer=self.dp_exchange, overlap=self.dp_overlap, mode=self.dp_mode)
+            self._dp.broadcast_parameters(src=0)
 
     def _sync_norm_stats(self):
         """VecNormalize statistics are updated on the env side every step and read at sample time
@@ -223,9 +269,15 @@ class SAC:
         total_timesteps = int(total_timesteps)
         if reset_num_timesteps:
             self.num_timesteps = 0
-        callback = as_callback(callback)
+        rt, dp = self._dp_rt, self._dp
+        W = 1 if rt is None else rt.world
+        lead = rt is None or rt.rank == 0
+        callback = as_callback(callback if lead else None)      # data parallel: evaluation / checkpoints / logging on rank 0 only
         callback.init_callback(self)
         eng, vn, N = self.engine, self._vec_normalize_env, self.n_envs
+        if rt is not None and vn is not None:       # running statistics merged over the ranks (ret_rms always on the host)
+            from ..parallel import share_running_stats
+            share_running_stats(vn, rt.ctrl)
         episode_rewards = [0.0]
         episode_successes = []
         ep_info_buf = deque(maxlen=100)
@@ -238,13 +290,30 @@ class SAC:
         if self.device_norm and vn is not None and vn.norm_obs and eng.cfg.normalize in (1, 2):
             vn.attach_device(eng)
             self._norm_stamp = None
-        raw_obs = vn is not None and vn.hands_out_raw_observations
+        try:
+            self._learn_loop(total_timesteps, callback, log_interval, writer, rt, dp, W, lead, eng, vn, N, episode_rewards,
+                             episode_successes, ep_info_buf, start)
+        finally:
+            if vn is not None and vn._dev is not None:     # whatever ended the loop: the wrapper carries the statistics again
+                vn.detach_device()
+                self._norm_stamp = None
+            if writer is not None:
+                writer.close()
+        if dp is not None and hasattr(dp, "check"):
+            dp.check()                  # raises if an exchange timed out (replicas out of step)
+        return self
+
+    def _learn_loop(self, total_timesteps, callback, log_interval, writer, rt, dp, W, lead, eng, vn, N, episode_rewards,
+                    episode_successes, ep_info_buf, start):
+        n_episodes = 0
+        infos_values = {}
         obs = self.env.reset()
         obs_ = vn.get_original_obs() if vn is not None else obs
         callback.on_training_start(locals(), globals())
         callback.on_rollout_start()
         step = 0
         while self.num_timesteps < total_timesteps:
+            raw_obs = vn is not None and vn.hands_out_raw_observations     # (a callback may toggle vn.training)
             if self.num_timesteps < self.learning_starts or self._rng.random() < self.random_exploration:
                 unscaled_action = np.stack([np.asarray(self.action_space.sample(), np.float32) for _ in range(N)])
                 action = self._scale(unscaled_action)
@@ -258,22 +327,28 @@ class SAC:
                 # precede it -- the same count in the strict and in the overlapped order
                 callback.on_rollout_end()
                 k = N if self.gradient_steps is None else int(self.gradient_steps)
-                done_steps = N * step_index
-                if k > 0 and eng.replay_size() >= self.batch_size and done_steps + N >= self.learning_starts:
+                done_steps = N * W * step_index
+                if k > 0 and eng.replay_size() >= self._local_batch and done_steps + N * W >= self.learning_starts:
                     self.n_updates += k
                     self._sync_norm_stats()
                     if callable(self.learning_rate):    # SB: frac = 1 - step / total (step = index of this env step)
                         eng.set_learning_rate(self.learning_rate(1.0 - done_steps / max(1, total_timesteps)))
-                    eng.train(k)
+                    if dp is not None:
+                        dp.train(k)      # k updates on the GLOBAL minibatch: gradients exchanged inside each update's graph
+                    else:
+                        eng.train(k)
                 callback.on_rollout_start()
 
             self.env.step_async(unscaled_action.reshape((N,) + tuple(self.action_space.shape)))
             if self.overlap_env_step and (step + 1) % self.train_freq == 0:
                 run_updates()          # GPU works while the simulator workers step
             new_obs, reward, done, info = self.env.step_wait()
-            self.num_timesteps += N
+            self.num_timesteps += N * W
             callback.update_locals(locals())
-            if callback.on_step() is False:
+            stop = callback.on_step() is False
+            if rt is not None:
+                stop = rt.any(stop)      # rank 0's callbacks decide for every replica (and no rank runs ahead of the others)
+            if stop:
                 break
             if vn is not None:
                 new_obs_, reward_ = vn.get_original_obs(), vn.get_original_reward()
@@ -305,7 +380,7 @@ class SAC:
                     self.action_noise.reset()
                 episode_rewards.append(0.0)
                 n_episodes += 1
-                if self.verbose >= 1 and log_interval is not None and n_episodes % log_interval == 0:
+                if lead and self.verbose >= 1 and log_interval is not None and n_episodes % log_interval == 0:
                     fps = int(self.num_timesteps / (time.time() - start + 1e-9))
                     logger.logkv("episodes", n_episodes)
                     logger.logkv("mean 100 episode reward", round(float(np.mean(episode_rewards[-101:-1])), 1))
@@ -323,12 +398,6 @@ class SAC:
                     logger.logkv("total timesteps", self.num_timesteps)
                     logger.dumpkvs()
         callback.on_training_end()
-        if raw_obs:
-            vn.detach_device()         # the wrapper carries the statistics again (and normalises on the host from here on)
-            self._norm_stamp = None
-        if writer is not None:
-            writer.close()
-        return self
 
     # ------------------------------------------------------------------ parameters / persistence
     def get_parameter_list(self):

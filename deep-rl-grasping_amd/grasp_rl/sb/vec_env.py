@@ -392,7 +392,7 @@ class VecNormalize(VecEnvWrapper):
         `pull_device_stats` -- automatically before pickling / `save` and in `sync_envs_normalization`."""
         self._dev = engine
         engine.set_obs_stats(self.obs_rms.mean, self.obs_rms.var, float(self.ret_rms.var))
-        engine.set_obs_count(self.obs_rms.count)
+        engine.set_running_stats(self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count)
 
     def detach_device(self):
         if self._dev is not None:

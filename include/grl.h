@@ -169,11 +169,15 @@ int grl_set_obs_stats(grl_handle h, const double* obs_mean, const double* obs_va
    batch moments of the n raw observations of one env step (HOST pointer, env layout [n, 64, 64, C+1] or [n, obs_dim],
    n <= max(act_batch, 64)) into the running mean / variance / count in device memory -- float32 batch moments like
    NumPy forms them from the float32 observations, float64 Chan merge -- and refreshes the sample-time statistics;
-   stream-ordered, no synchronisation.  grl_set_obs_stats loads a starting point (vecnormalize.pkl), grl_set_obs_count
-   its count (RunningMeanStd starts at 1e-4), grl_set_ret_var pushes the host-side return variance alone, and
-   grl_get_obs_stats (host, synchronises) copies mean / var [env layout] and count out for pickling. */
+   stream-ordered, no synchronisation.  grl_set_running_stats loads a starting point for them (the mean / var / count of a
+   vecnormalize.pkl; RunningMeanStd starts at 0 / 1 / 1e-4) -- grl_set_obs_stats only loads what sampling reads --
+   grl_set_ret_var pushes the host-side return variance alone, and grl_get_obs_stats (host, synchronises) copies
+   mean / var [env layout] and count out for pickling.
+   On a handle connected for data parallelism (grl_allreduce_connect) grl_norm_update merges the batch moments of ALL
+   ranks, in rank order, into every replica (csrc/dp_kernels.h) -- the arithmetic of
+   grasp_rl.parallel.share_running_stats on the host; all ranks must call it the same number of times. */
 int grl_norm_update(grl_handle h, const float* obs, int n);
-int grl_set_obs_count(grl_handle h, double count);
+int grl_set_running_stats(grl_handle h, const double* obs_mean, const double* obs_var, double count);
 int grl_set_ret_var(grl_handle h, double ret_var);
 int grl_get_obs_stats(grl_handle h, double* obs_mean, double* obs_var, double* count);
 
@@ -209,31 +213,39 @@ int grl_apply_grads(grl_handle h, float grad_scale);
    grl_compute_grads (stage 0 only).  Handles without a staged plan (vector observations, DQN / BDQ) do everything
    in stage 0 and report one range covering the whole bucket. */
 int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const float* eps);
-/* The exchange step inside the library (csrc/dp_kernels.h): a two-shot all-reduce written for this
-   path -- reduce-scatter by the owner of each 1/world chunk in rank order, all-gather by pull inside the Adam kernel --
-   over exchange buffers that every rank exports with hipIpcGetMemHandle and maps from its peers (xGMI between the GPUs of a node).
+/* The exchange step inside the library (csrc/dp_kernels.h): all-reduces written for this path over exchange
+   buffers that every rank exports with hipIpcGetMemHandle and maps from its peers (xGMI between the GPUs of a node).
+   The gradient computation's last launch publishes the sums it forms; then either TWO-SHOT -- reduce-scatter by the owner
+   of each 1/world chunk in rank order, all-gather by pull inside the Adam kernel -- or ONE-SHOT (small worlds) -- every
+   rank adds all contributions in rank order inside the Adam kernel.
      grl_allreduce_init     allocates this rank's exchange memory -- a few hundred bytes of flags and a
-                            buffer of three bucket-sized arrays, both fine-grained (the only device memory the library allocates
-                            itself: IPC export needs allocations of its own) -- and writes their two IPC handles,
-                            GRL_ALLREDUCE_HANDLE_BYTES = 128 bytes, to handle_out; the host exchanges the handles of all
-                            ranks out of band (any transport: files, MPI, torch.distributed.all_gather_object);
+                            buffer of three bucket-sized arrays + two moment blocks, both fine-grained (the only device
+                            memory the library allocates itself: IPC export needs allocations of its own) -- and writes
+                            their two IPC handles, GRL_ALLREDUCE_HANDLE_BYTES = 128 bytes, to handle_out; the host
+                            exchanges the handles of all ranks out of band (any transport: files, MPI,
+                            torch.distributed.all_gather_object);
      grl_allreduce_connect  handles = world x GRL_ALLREDUCE_HANDLE_BYTES in rank order; maps the peers' memory;
      grl_train_step_allreduce   n_steps data-parallel updates, each ONE graph: minibatch from this rank's replay shard,
                             gradients, exchange, Adam + Polyak with the mean gradient -- what grl_compute_grads ->
                             all-reduce -> grl_apply_grads(1 / world) does with a collective library in between.  Every
-                            replica receives bit-identical sums.  All ranks must call it the same number of times;
-     grl_allreduce_status   host: exchanges completed; error != 0 (and a negative return) if a bounded wait for a peer ran
-                            out -- the kernels never hang;
+                            replica receives bit-identical sums.  All ranks must call it the same number of times.  A rank
+                            WAITS for a peer that is late (GRL_TUNE dp_timeout_ms, default 120 s); when a wait runs out the
+                            rank poisons the channel on every rank: this and every later call fail with GRL_ERR_STATE on
+                            all of them (no replica keeps training on a partial exchange);
+     grl_allreduce_status   host (synchronises): exchanges begun; error != 0 (and a negative return) after a time-out;
+     grl_allreduce_set_mode 0 (default): one-shot for world <= 2, else two-shot; 1: two-shot; 2: one-shot.  All ranks must
+                            choose alike, while no exchange is in flight on any rank;
      grl_allreduce_set_overlap   on = 1: grl_train_step_allreduce runs the staged plan (grl_compute_grads_staged) with BOTH
                             exchanges in its graph -- bucket 0 (dense layers, ~90 % of the bytes) is reduced and exchanged on
                             a side lane of the graph while the backward through the convolutions runs, bucket 1 follows,
-                            Adam waits for both (SURVEY.md 8e "overlapped with the backward").  Same sums, bit-identical
-                            parameters.  All ranks must choose alike.  GRL_ERR_STATE when the handle has no staged plan
-                            (vector observations); off by default. */
+                            Adam waits for both (SURVEY.md 8e "overlapped with the backward"; two-shot).  Same sums,
+                            bit-identical parameters.  All ranks must choose alike.  GRL_ERR_STATE when the handle has no
+                            staged plan (vector observations); off by default. */
 #define GRL_ALLREDUCE_HANDLE_BYTES 128
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out);
 int grl_allreduce_connect(grl_handle h, const void* handles);
 int grl_allreduce_set_overlap(grl_handle h, int on);
+int grl_allreduce_set_mode(grl_handle h, int mode);
 int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
 int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error);
 /* contiguous ranges (float offsets into the grads arena) of bucket 0 / 1; returns their number (<= cap) or < 0 */

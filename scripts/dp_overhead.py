@@ -33,19 +33,25 @@ for name, fn in (("fused train_device(n)", lambda n: eng.train_device(n)),
 # the in-graph exchange with world = 1 (the rank exchanges with itself: every kernel of the N-rank update runs, nothing waits)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 eng.allreduce_connect([eng.allreduce_init(0, 1)])
-for name, ov in (("in-graph exchange, plain (world 1)", False), ("in-graph exchange, overlapped (world 1)", True)):
+VARIANTS = (("one-shot", "oneshot", False), ("two-shot", "twoshot", False), ("two-shot, overlapped", "twoshot", True))
+for name, mode, ov in VARIANTS:
+    eng.synchronize()
     eng.allreduce_set_overlap(ov)
+    eng.allreduce_set_mode(mode)
     eng.train_allreduce(50); eng.synchronize()
     t0 = time.perf_counter(); eng.train_allreduce(500); eng.synchronize()
     dt = time.perf_counter() - t0
-    print("%-40s %.1f us/update, %d exchanges, no time-out" % (name, 1e6 * dt / 500, eng.allreduce_status()))
+    print("in-graph exchange, %-22s (world 1) %.1f us/update, %d exchanges, no time-out" % (name, 1e6 * dt / 500, eng.allreduce_status()))
 
 # per-launch times of the exchange (eager pass, hipEvents)
 eng.profile(True)
-for ov in (False, True):
+for name, mode, ov in VARIANTS:
+    eng.synchronize()
     eng.allreduce_set_overlap(ov)
+    eng.allreduce_set_mode(mode)
     eng.train_allreduce(30)
     eng.synchronize()
     d = eng.profile_dump()
-    print("overlapped" if ov else "plain", " ".join("%s %.1f" % (k, 1e3 * v["avg_ms"]) for k, v in sorted(d.items()) if k.startswith(("dp_", "reduce", "wgrad"))))
+    print(name, " ".join("%s %.1f" % (k, 1e3 * v["avg_ms"]) for k, v in sorted(d.items()) if k.startswith(("dp_", "reduce", "wgrad"))))
+    eng.profile(True)       # (clears the accumulators)
 eng.profile(False)

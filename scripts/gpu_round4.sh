@@ -1,0 +1,44 @@
+#!/bin/bash
+# one gpurun call of round 4: stages run in order, everything lands in gpurun_out/round4.log
+#   STAGES="tests bench dp rehearsal" bash scripts/gpu_round4.sh      (any other word is run as a shell command)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+LOG=$R/gpurun_out/${LOGNAME_R4:-round4}.log
+: > $LOG
+STAGES=${STAGES-tests bench dp}
+for st in $STAGES; do
+  S0=$(date +%s)
+  case $st in
+    tests)
+      echo "== pytest ${PYTEST_ARGS-} ${PYTEST_K:+-k $PYTEST_K}" >> $LOG
+      timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q ${PYTEST_ARGS-} ${PYTEST_K:+-k "$PYTEST_K"} --timeout 600 --durations=15 -rA 2>&1 | grep -v "^PASSED\|^$" | tail -${PYTEST_TAIL:-80} >> $LOG
+      ;;
+    bench)
+      for W in ${WORKLOADS-sac_depth}; do
+        echo "== bench $W" >> $LOG
+        timeout 900 python bench.py --workload $W --steps ${BENCH_STEPS:-200} --warmup 20 ${BENCH_ARGS-} > $R/gpurun_out/bench_$W.json 2> $R/gpurun_out/bench_$W.err
+        echo "rc=$?" >> $LOG; tail -3 $R/gpurun_out/bench_$W.err >> $LOG; cut -c1-3500 $R/gpurun_out/bench_$W.json >> $LOG
+      done
+      ;;
+    dp)
+      echo "== data-parallel overhead at world 1 (scripts/dp_overhead.py)" >> $LOG
+      timeout 600 python scripts/dp_overhead.py >> $LOG 2>&1
+      ;;
+    rehearsal)
+      for N in ${REHEARSAL_N-2 4 8}; do
+        echo "== bench.py --gpus $N --dist-backend gloo --same-device (dress rehearsal of the driver's SCALE run)" >> $LOG
+        timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600 + N)) bench.py \
+          --gpus $N --steps 64 --warmup 16 --repeats 3 --dist-backend gloo --same-device --no-profile ${REHEARSAL_ARGS-} > $R/gpurun_out/rehearsal_$N.json 2> $R/gpurun_out/rehearsal_$N.err
+        echo "rc=$?" >> $LOG; grep -v "^W0\|^\[Gloo\]\|^$" $R/gpurun_out/rehearsal_$N.err | tail -8 >> $LOG; cut -c1-1500 $R/gpurun_out/rehearsal_$N.json >> $LOG
+      done
+      ;;
+    prof)
+      echo "== rocprofv3 kernel trace (graph replay)" >> $LOG
+      NAME=${PROF_NAME:-sac_depth} PMC=${PMC:-0} BENCH_ARGS="${PROF_BENCH_ARGS-}" bash scripts/profile_round.sh >> $LOG 2>&1
+      ;;
+    *) echo "== custom: $st" >> $LOG; bash -c "$st" >> $LOG 2>&1 ;;
+  esac
+  echo "-- stage $st took $(( $(date +%s) - S0 )) s" >> $LOG
+done
+tail -${TAIL:-260} $LOG

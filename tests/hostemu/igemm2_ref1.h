@@ -4,10 +4,9 @@
 // TEST-ONLY reference of the v2 tile semantics (see hostemu.h): tile = BM x BN of CFG; the ones row
 // (p_ones_i == M-1) is produced by row tile 0 and excluded from the row tiling.
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-void igemm2_tile(const IgemmProb* probs, const int4 tl, const int* pre = nullptr) {   // probs: THIS tile's descriptor copy; pre: its preamble (FLAGS & 4)
+void igemm2_tile(const IgemmProb* probs, const int4 tl) {   // probs: THIS tile's descriptor copy
   if (threadIdx.x != 0) return;
   if (((FLAGS & 1) != 0) != (probs[0].p_ones_i >= 0)) abort();
-  if ((FLAGS & 4) && (PM != PM_TABLE)) abort();   // the preamble (device build only) serves unmasked table addressing
   const int BM = i2_bm(CFG), BN = i2_bn(CFG);
   const IgemmProb& pb = probs[0];
   if ((PM != PM_AFFINE) != (pb.p_tab_i != nullptr && pb.p_tab_r != nullptr)) abort();
@@ -30,21 +29,14 @@ void igemm2_tile(const IgemmProb* probs, const int4 tl, const int* pre = nullptr
         else if (ok) {
           long rowterm = pb.p_tab_i ? pb.p_tab_i[i] : (long)i * pb.p_ld_i[0];
           long colterm = pb.p_tab_r ? pb.p_tab_r[r] : (long)r * pb.p_ld_r[0];
-          // the preamble holds the same entries for the tile's rows and its first three reduction slabs: read them from
-          // there where the device kernel does, so that the host's preamble builder is checked by the plan tests
-          if ((FLAGS & 4) && i != pb.p_ones_i) {
-            rowterm = pre[I2Pre<CFG>::ROW + (i - tl.z * BM)];
-            if (r - r_begin < 3 * I2Pre<CFG>::BKT) colterm = pre[I2Pre<CFG>::PK + (r - r_begin)];
-          }
           pv = pb.p_base[0][rowterm + colterm];
         }
         long qrow = pb.q_tab_r ? pb.q_tab_r[r] : (long)r * pb.q_ld_r[0];
-        if ((FLAGS & 4) && pb.q_tab_r && r - r_begin < 3 * I2Pre<CFG>::BKT) qrow = pre[I2Pre<CFG>::QK + (r - r_begin)];
         acc = fmaf(pv, pb.q_base[0][qrow + (long)j * pb.q_ld_j[0]], acc);
       }
       long off;
       if (pb.c_tab_i) {
-        const int ct = ((FLAGS & 4) && i != pb.p_ones_i) ? pre[I2Pre<CFG>::CT + (i - tl.z * BM)] : pb.c_tab_i[i];
+        const int ct = pb.c_tab_i[i];
         if (ct < 0) continue;
         off = (long)ct + j;
       } else off = (long)i * pb.ldc + j;
@@ -60,15 +52,15 @@ void igemm2_tile(const IgemmProb* probs, const int4 tl, const int* pre = nullptr
   if (pb.p_ones_i >= 0 && tl.z == 0) row(pb.p_ones_i);
 }
 template <int PL, int QL, int PM, int QM, int CFG, int FLAGS>
-void igemm2_kernel(const IgemmProb* probs, const int4* tiles, const int* pre) {
-  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x], (FLAGS & 4) ? pre + (size_t)blockIdx.x * I2Pre<CFG>::STRIDE : nullptr);
+void igemm2_kernel(const IgemmProb* probs, const int4* tiles) {
+  igemm2_tile<PL, QL, PM, QM, CFG, FLAGS>(probs + blockIdx.x, tiles[blockIdx.x]);
 }
 // two kinds of tiles in one launch: blocks [0, n_a) run kind A (the launch's own stage), the rest kind B (fillers)
 template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb>
-void igemm2_pair_kernel(const IgemmProb* pa, const int4* ta, int n_a, const IgemmProb* pb, const int4* tb, const int* pre_a) {
+void igemm2_pair_kernel(const IgemmProb* pa, const int4* ta, int n_a, const IgemmProb* pb, const int4* tb) {
   const int b = (int)blockIdx.x;
   const bool is_a = b < n_a;
   const int k = is_a ? b : b - n_a;
-  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k], (FLa & 4) ? pre_a + (size_t)k * I2Pre<CFGa>::STRIDE : nullptr);
+  if (is_a) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(pa + k, ta[k]);
   else igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(pb + k, tb[k]);
 }

@@ -7,7 +7,6 @@ inline void q_fwd_fused_kernel(QFusedArgs a) {
   for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row)
     ht_ref_fwd_head(h, row, nullptr);
 }
-inline void q_bwd_trunk_kernel(QFusedArgs a);
 inline void q_bwd_towers_kernel(QFusedArgs a) {
   if (threadIdx.x != 0) return;
   const int tw = blockIdx.y;
@@ -18,10 +17,6 @@ inline void q_bwd_towers_kernel(QFusedArgs a) {
       for (int o = 0; o < a.nb; ++o) dv[o] = a.d_adv[((long)row * a.D + tw) * a.nb + o];
     else dv[0] = a.d_v[row];
     ht_ref_bwd_head(h, row, dv, h.n_xa ? a.dh_part + ((long)tw * a.B + row) * a.Ht : nullptr);
-  }
-  if (a.tw_done && a.bwd_tr && ++a.tw_done[blockIdx.x] == (unsigned)(a.D + 1)) {   // last tower of the row block: its trunk
-    a.tw_done[blockIdx.x] = 0u;
-    q_bwd_trunk_kernel(a);
   }
 }
 inline void q_bwd_trunk_kernel(QFusedArgs a) {

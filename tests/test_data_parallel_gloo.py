@@ -134,3 +134,67 @@ def test_running_stats_are_merged_over_ranks(tmp_path):
 def test_scale_and_bucket_helpers():
     from grasp_rl.parallel import allreduce_mean_scale
     assert allreduce_mean_scale(8) == 0.125
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data parallelism through the drop-in API: SAC(data_parallel=...).learn (sb_helper.py:175-177 on an env built like
+# train_stable_baselines.py:52-54), two replicas over gloo with the emulation engine
+def _learn_worker(rank, world, port, lib, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from fake_env import FakeGraspEnv
+    from grasp_rl.engine import SacEngine
+    from grasp_rl.sb.callbacks import BaseCallback
+    from grasp_rl.sb.sac import SAC
+    from grasp_rl.sb.vec_env import DummyVecEnv, VecNormalize
+    from grasp_rl.sb import policies as pol
+    SAC._engine_factory = staticmethod(lambda cfg, device: SacEngine(cfg, backend=NumpyHostBackend(), lib_path=lib))
+
+    class StopAt(BaseCallback):
+        calls = 0
+
+        def _on_step(self):
+            StopAt.calls += 1
+            return self.num_timesteps < 40          # rank 0 decides; every replica must leave the loop in the same iteration
+
+    env = VecNormalize(DummyVecEnv([(lambda i=i: FakeGraspEnv("depth", seed=10 * rank + i)) for i in range(2)]),
+                       training=True, norm_obs=True, norm_reward=True, clip_obs=10.0)
+    model = SAC(pol.SacCnnPolicy, env, batch_size=8, buffer_size=64, learning_starts=8, seed=3, data_parallel=True,
+                dp_exchange="collective", policy_kwargs={"cnn_extractor": _augmented(1)})
+    assert model.engine.cfg.batch_size == 4                      # the global minibatch dealt over the ranks
+    cb = StopAt()
+    model.learn(10_000, callback=cb)
+    P = model.get_parameters()
+    np.savez(os.path.join(out_dir, "learn%d.npz" % rank), steps=model.num_timesteps, updates=model.n_updates, calls=StopAt.calls,
+             obs_mean=env.obs_rms.mean, obs_var=env.obs_rms.var, obs_count=env.obs_rms.count, ret_var=env.ret_rms.var,
+             replay=model.engine.replay_size(), **{k.replace("/", "|"): v for k, v in P.items()})
+    dist.destroy_process_group()
+
+
+def _augmented(n):
+    def augmented_nature_cnn(scaled_images, **kwargs):
+        raise AssertionError("the TF extractor must not be called")
+    def bound(scaled_images, **kwargs):
+        return augmented_nature_cnn(scaled_images, n=n, **kwargs)
+    bound.__name__ = "augmented_nature_cnn"
+    return bound
+
+
+def test_model_learn_as_one_replica_of_two(hostemu_lib, tmp_path):
+    """SAC(data_parallel=True).learn with two replicas: global minibatch split over the ranks, parameters from rank 0,
+    gradients exchanged every update, VecNormalize statistics (observations and returns) merged over the ranks at every
+    env step, timesteps counted over all ranks, callbacks on rank 0 only and its stop request ending both loops in the
+    same iteration -- the replicas end bit-identical."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_learn_worker, args=(2, port, hostemu_lib, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "learn0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "learn1.npz"))
+    assert int(r0["calls"]) > 0 and int(r1["calls"]) == 0
+    assert int(r0["steps"]) == int(r1["steps"]) == 40                  # 2 ranks x 2 envs per vectorised step
+    assert int(r0["updates"]) == int(r1["updates"]) > 0 and int(r0["replay"]) == int(r1["replay"]) == 18   # (the stopping step is not stored)
+    for k in r0.files:
+        if k != "calls":
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    assert float(r0["obs_count"]) == pytest.approx(1e-4 + 2 * 2 * 11)   # reset + 10 steps, both ranks' batches merged

@@ -134,68 +134,236 @@ def test_rccl_two_gpus_equal_single_engine(tmp_path):
     _check_against_single(tmp_path, 2, "rccl")
 
 
-def _ingraph_worker(rank, world, port, out_dir, overlap=False):
+# ---------------------------------------------------------------------------------------------------------------------
+# the exchange inside the update graph (csrc/dp_kernels.h), W processes sharing the box's one MI355X
+VARIANTS = (("oneshot", False), ("twoshot", False), ("twoshot", True))
+
+
+def _rank_ordered_reference(case, lo, hi, world, group_steps):
+    """The documented arithmetic of the exchange, formed on the host: every rank's gradient bucket (grl_compute_grads),
+    added IN RANK ORDER in float32, applied with grad_scale 1 / world (grl_apply_grads) -- for two ranks also what a
+    collective library's all-reduce gives (a + b), for more ranks its association differs."""
+    ref = pu.engine_setup(case)
+    for s in range(group_steps):
+        ref.compute_grads(case["idx"][s:s + 1, lo:hi], case["eps"][s:s + 1, lo:hi])
+        g = torch.from_numpy(ref.fetch("grads", (ref.n_trainable,)))
+        parts = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        total = parts[0].numpy().copy()
+        for p in parts[1:]:
+            total += p.numpy()
+        ref.store("grads", total)
+        ref.apply_grads(1.0 / world)
+    ref.synchronize()
+    P = ref.get_parameters()
+    ref.close()
+    return P
+
+
+def _ingraph_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GRL_TUNE"] = "dp_timeout_ms=20000"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
+    cases = {"cnn": _case()}
+    if world >= 8:
+        # the smallest SAC there is: a bucket of 84 floats -- not a multiple of 4 * world, rank 6's chunk short, rank 7's EMPTY
+        # (capi.inl: chunk = rup(ceil(n / world), 4))
+        cases["tiny"] = pu.make_case(extractor="mlp", obs_dim=1, act_dim=1, layers=(4,), B=B, n_replay=48, n_steps=STEPS)
+    for cname, case in cases.items():
+        cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+        cfg.batch_size = B // world
+        case["cfg"] = cfg
+        lo, hi = rank * (B // world), (rank + 1) * (B // world)
+        Pref = _rank_ordered_reference(case, lo, hi, world, STEPS)
+        if world == 2:      # ... and the same two ranks exchanging through gloo (single bucket: compute -> all_reduce -> apply)
+            g = pu.engine_setup(case)
+            DataParallelSac(g, overlap=False).train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+            g.synchronize()
+            Pg = g.get_parameters()
+            g.close()
+            for k in Pg:
+                assert np.array_equal(Pg[k], Pref[k]), "rank-ordered sum differs from the gloo exchange: " + k
+        finals = []
+        for mode, overlap in VARIANTS:
+            if overlap and cname == "tiny":
+                continue                              # (vector observations have no staged plan)
+            eng = pu.engine_setup(case)
+            dp = DataParallelInGraph(eng, overlap=overlap, mode=mode)
+            if cname == "tiny":
+                assert eng.n_trainable == 84
+            dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+            assert dp.check() == STEPS
+            P = eng.get_parameters()
+            for k in P:
+                assert np.array_equal(P[k], Pref[k]), "%s / %s%s: differs from the rank-ordered sum: %s" % (cname, mode, "+overlap" if overlap else "", k)
+            # and on the device RNG, several updates per call (the same seed and replay contents on every rank, so even
+            # these must leave identical replicas), then a switch of the variant on the idle handle
+            dp.train(5)
+            dp.train(1)
+            assert dp.check() == STEPS + 6
+            dp.set_mode("oneshot" if mode == "twoshot" else "twoshot", False)
+            dp.train(3)
+            assert dp.check() == STEPS + 9
+            finals.append(eng.get_parameters())
+            eng.close()
+        for P in finals[1:]:
+            for k in P:
+                assert np.array_equal(P[k], finals[0][k]), "variants differ after the device-RNG updates: " + k
+        np.savez(os.path.join(out_dir, "ig_%s_%d.npz" % (cname, rank)), **{k.replace("/", "|"): v for k, v in finals[0].items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
+    """W processes on the box's one MI355X map each other's exchange buffers (hipIpc) and run the data-parallel update with
+    the hand-written all-reduces inside the graph -- one-shot, two-shot, two-shot with the dense bucket overlapped: each
+    bit-identical to the rank-ordered float32 sum formed on the host (for W = 2 also to the gloo exchange), the replicas
+    bit-identical to each other (also after updates on the device RNG and a switch of the variant).  W = 8 adds the
+    smallest bucket there is: ragged chunks, the last one empty."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ingraph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for cname in ("cnn", "tiny") if world >= 8 else ("cnn",):
+        parts = [np.load(os.path.join(str(tmp_path), "ig_%s_%d.npz" % (cname, r))) for r in range(world)]
+        for p in parts[1:]:
+            for k in parts[0].files:
+                assert np.array_equal(parts[0][k], p[k]), "replicas diverged (%s): %s" % (cname, k)
+
+
+def _timeout_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GRL_TUNE"] = "dp_timeout_ms=1500"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grasp_rl._capi import GrlError
+    from grasp_rl.parallel import DataParallelInGraph
     case = _case()
     cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
     cfg.batch_size = B // world
     case["cfg"] = cfg
-    lo, hi = rank * (B // world), (rank + 1) * (B // world)
-    # reference: the same two ranks exchanging through gloo (single bucket: compute -> all_reduce -> apply)
-    ref = pu.engine_setup(case)
-    dpr = DataParallelSac(ref, overlap=False)
-    dpr.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
-    ref.synchronize()
-    Pref = ref.get_parameters()
-    ref.close()
-    # the in-graph exchange over IPC-mapped buffers
     eng = pu.engine_setup(case)
-    dp = DataParallelInGraph(eng, overlap=overlap)
-    dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
-    assert dp.check() == STEPS
-    P = eng.get_parameters()
-    for k in P:
-        assert np.array_equal(P[k], Pref[k]), "in-graph exchange differs from the gloo exchange: " + k
-    # and on the device RNG, several updates per call
-    dp.train(5)
-    assert dp.check() == STEPS + 5
-    P = eng.get_parameters()
-    np.savez(os.path.join(out_dir, "ig%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
+    dp = DataParallelInGraph(eng, mode="twoshot")
+    dp.train(2)
+    assert dp.check() == 2
+    before = eng.get_parameters()
+    dist.barrier()
+    raised = False
+    if rank == 0:
+        dp.train(1)                   # the peer never arrives: the wait runs out, the channel is poisoned on EVERY rank
+        try:
+            dp.check()
+        except GrlError:
+            raised = True
+        dist.barrier()
+    else:
+        dist.barrier()                # (rank 0 has given up by now)
+        try:
+            dp.train(1)               # refused: the host mailbox / the poisoned flags say the replicas are out of step
+            dp.check()
+        except GrlError:
+            raised = True
+    assert raised, "rank %d did not see the time-out" % rank
+    try:
+        dp.train(1)
+        later = False
+    except GrlError:
+        later = True
+    assert later, "a poisoned channel must refuse further updates"
+    after = eng.get_parameters()
+    for k in before:                  # nobody applied a partial exchange
+        assert np.array_equal(before[k], after[k]), k
     eng.close()
     dist.destroy_process_group()
 
 
-def test_overlapped_in_graph_exchange_two_processes_on_one_gpu(tmp_path):
-    """grl_allreduce_set_overlap: the staged plan with the dense bucket's exchange on a side lane of the graph (channel 0)
-    and the convolution bucket's after it (channel 1).  Same sums: bit-identical to the gloo exchange and between the
-    replicas, explicit minibatches and device RNG."""
+def test_a_missing_peer_poisons_the_exchange_on_every_rank(tmp_path):
+    """Bounded waits (GRL_TUNE dp_timeout_ms): a rank whose peer does not arrive gives up, raises `error` on every rank and in
+    its host mailbox, and announces nothing further -- both ranks' next calls fail, no replica has applied a stale sum."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_ingraph_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
-    r0 = np.load(os.path.join(str(tmp_path), "ig0.npz"))
-    r1 = np.load(os.path.join(str(tmp_path), "ig1.npz"))
-    for k in r0.files:
-        assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    mp.spawn(_timeout_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
 
 
-def test_in_graph_exchange_two_processes_on_one_gpu(tmp_path):
-    """Two processes on the box's one MI355X map each other's exchange buffer (hipIpc) and run the data-parallel update
-    with the hand-written two-shot all-reduce inside the graph: bit-identical to the same two ranks exchanging through
-    gloo, replicas bit-identical to each other (also after five more updates on the device RNG)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# data parallelism through the drop-in API: SAC(data_parallel=True).learn (sb_helper.py:175-177), two replicas on one GPU
+def _learn_worker(rank, world, port, out_dir, device_norm):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GRL_DP_SAME_DEVICE="1", GRL_TUNE="dp_timeout_ms=20000")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from fake_env import FakeGraspEnv
+    from grasp_rl.engine import SacEngine
+    from grasp_rl.parallel import DataParallelInGraph
+    from grasp_rl.sb import policies as pol
+    from grasp_rl.sb.sac import SAC
+    from grasp_rl.sb.vec_env import DummyVecEnv, VecNormalize
+    from test_data_parallel_gloo import _augmented
+
+    env = VecNormalize(DummyVecEnv([(lambda i=i: FakeGraspEnv("depth", seed=10 * rank + i)) for i in range(2)]),
+                       training=True, norm_obs=True, norm_reward=True, clip_obs=10.0)
+    model = SAC(pol.SacCnnPolicy, env, batch_size=16, buffer_size=64, learning_starts=8, seed=3, data_parallel=True,
+                device_norm=device_norm, policy_kwargs={"cnn_extractor": _augmented(1)})
+    assert isinstance(model._dp, DataParallelInGraph) and model.engine.cfg.batch_size == 8
+    eng = model.engine
+    P0 = eng.get_parameters()
+    # record what learn() hands to the engine / the exchange: the same schedule is replayed below through the wrapper alone
+    log = []
+    for name in ("replay_add", "set_obs_stats", "set_ret_var", "norm_update", "set_running_stats"):
+        def rec(*a, _f=getattr(eng, name), _n=name):
+            log.append((_n, tuple(np.array(x, copy=True) if isinstance(x, np.ndarray) else x for x in a)))
+            return _f(*a)
+        setattr(eng, name, rec)
+    train = model._dp.train
+    model._dp.train = lambda k: (log.append(("train", (k,))), train(k))[1]
+    model.learn(48)
+    assert model.num_timesteps == 48 and model.n_updates > 0
+    P = model.get_parameters()
+    mean, var, count = env.obs_rms.mean.copy(), env.obs_rms.var.copy(), env.obs_rms.count
+    assert count == pytest.approx(1e-4 + 2 * 2 * 13)           # reset + 12 steps, both ranks' batches merged (host or device)
+    # ---- the bench-style path: an engine of the same configuration driven by the wrapper alone
+    eng2 = SacEngine(eng.cfg, device="cuda:0")
+    eng2.set_parameters(P0)
+    dp2 = DataParallelInGraph(eng2, group=model._dp_rt.ctrl)
+    for name, a in log:
+        if name == "train":
+            dp2.train(*a)
+        else:
+            getattr(eng2, name)(*a)
+    dp2.check()
+    P2 = eng2.get_parameters()
+    for k in P:
+        assert np.array_equal(P[k], P2[k]), "model.learn and the wrapper-driven engine differ: " + k
+    np.savez(os.path.join(out_dir, "learn%d.npz" % rank), obs_mean=mean, obs_var=var, obs_count=count, ret_var=env.ret_rms.var,
+             **{k.replace("/", "|"): v for k, v in P.items()})
+    eng2.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_norm", [False, True])
+def test_model_learn_two_replicas_on_one_gpu(tmp_path, device_norm):
+    """SAC(data_parallel=True).learn, two processes: the in-graph exchange behind `model.learn`, running statistics merged
+    over the ranks on the host (share_running_stats) or on the device (grl_norm_update on a connected handle).  Each
+    replica reaches exactly the parameters of an engine driven by the DataParallelInGraph wrapper alone on the recorded
+    schedule (what bench.py does), and the replicas -- parameters and statistics -- are bit-identical."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_ingraph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = np.load(os.path.join(str(tmp_path), "ig0.npz"))
-    r1 = np.load(os.path.join(str(tmp_path), "ig1.npz"))
-    for k in r0.files:
-        if not k.startswith("model|pi|") and not k.startswith("model|values_fn") and not k.startswith("target"):
-            continue
-    # the ranks sample DIFFERENT shards on the device RNG (seeds differ by rank in bench.py; here the same seed and the
-    # same replay contents, so even the device-RNG updates must leave identical replicas)
+    mp.spawn(_learn_worker, args=(2, port, str(tmp_path), device_norm), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "learn0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "learn1.npz"))
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    np.savez(os.path.join(str(tmp_path), "..", "dp_learn_stats_%d.npz" % int(device_norm)), mean=r0["obs_mean"], var=r0["obs_var"])
+
+
+def test_device_and_host_statistics_agree_under_data_parallelism(tmp_path):
+    """The running statistics two replicas end with are the same bits whether the host merged the moments
+    (share_running_stats) or the device did (dp_norm_*_kernel): both restate RunningMeanStd over the gathered batches."""
+    files = [os.path.join(str(tmp_path), "..", "dp_learn_stats_%d.npz" % k) for k in (0, 1)]
+    if not all(os.path.exists(f) for f in files):
+        pytest.skip("runs after test_model_learn_two_replicas_on_one_gpu (both parametrisations)")
+    a, b = np.load(files[0]), np.load(files[1])
+    assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["var"], b["var"])

@@ -25,25 +25,6 @@ def test_q_update_three_launch_apply(name, monkeypatch):
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 
-@pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
-def test_trunk_backward_inside_the_tower_launch_is_bit_identical(name, monkeypatch):
-    """The trunk's backward runs in the workgroup of the last tower of its row block to finish (q_kernels.h; device-scope
-    release / acquire hand-off of the per-tower partials; opt-in GRL_Q_TRUNK_MERGE=1, measured slower) instead of a launch
-    of its own: the partials are added in tower order either way -- parameters after 40 updates on the device RNG are
-    bit-identical, and both match the oracle on explicit minibatches."""
-    import numpy as np
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("GRL_Q_TRUNK_MERGE", flag)
-        qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
-        eng = qu.q_engine_setup(qu.make_q_case(**qu.CASES[name]))
-        eng.train(40)
-        outs.append(eng.get_parameters())
-        eng.close()
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
-
-
 def test_q_update_with_vecnormalize():
     qu.run_and_compare(qu.make_q_case(normalize=True, **qu.CASES["bdq"]))
 

@@ -147,12 +147,10 @@ def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_
     assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
 
 
-@pytest.mark.parametrize("fused_publish", ["0", "1"])
-def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib, monkeypatch, fused_publish):
+def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
     """grl_allreduce_set_overlap with world = 1: the staged plan, the dense pieces of the bucket exchanged on channel 0 and
     the convolution pieces on channel 1 (several disjoint ranges each), Adam waiting for both -- exactly the parameters of
     compute_grads + apply_grads(1.0), also over a wrap of the per-rank chunking (ragged piece sizes)."""
-    monkeypatch.setenv("GRL_DP_FUSED_PUBLISH", fused_publish)     # (1: the reductions publish their sums themselves; opt-in)
     case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=3)
     a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
@@ -180,7 +178,8 @@ def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(host
     c.close()
 
 
-def test_in_graph_exchange_on_the_device_rng_prefetches_like_the_fused_update(hostemu_lib):
+@pytest.mark.parametrize("mode", ["oneshot", "twoshot"])
+def test_in_graph_exchange_on_the_device_rng_prefetches_like_the_fused_update(hostemu_lib, mode):
     """Several data-parallel updates per call on the device RNG: the gather of update t+1 rides on the (unfused) reduction of
     update t, the exchange and Adam follow -- with one rank exactly the parameters, moments and RNG position of
     grl_train_step(n) on a second handle, call after call."""
@@ -188,6 +187,7 @@ def test_in_graph_exchange_on_the_device_rng_prefetches_like_the_fused_update(ho
     a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     a.allreduce_connect([a.allreduce_init(0, 1)])
+    a.allreduce_set_mode(mode)
     for n in (5, 1, 2):
         a.train_allreduce(n)
         b.train_device(n)
@@ -199,50 +199,30 @@ def test_in_graph_exchange_on_the_device_rng_prefetches_like_the_fused_update(ho
     a.close(); b.close()
 
 
-def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
+@pytest.mark.parametrize("mode", ["auto", "oneshot", "twoshot"])
+def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib, mode):
     """grl_allreduce_init / connect / grl_train_step_allreduce with world = 1 (the peer is the rank itself): the
-    publish -> reduce + push -> apply chain must leave exactly the parameters of compute_grads + apply_grads(1.0).
-    (Two ranks in two processes run on the GPU box: tests/test_gpu_data_parallel.py.)"""
+    reduce + publish -> (reduce-scatter ->) apply chain must leave exactly the parameters of compute_grads +
+    apply_grads(1.0), one-shot (source buffers alternating) and two-shot, also after switching between them.
+    (Several ranks in several processes run on the GPU box: tests/test_gpu_data_parallel.py.)"""
     case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=3)
     a = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     b = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
     h = a.allreduce_init(0, 1)
     assert len(h) == 128
     a.allreduce_connect([h])
+    a.allreduce_set_mode(mode)
     for s in range(3):
         a.train_allreduce(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
         b.compute_grads(case["idx"][s:s + 1], case["eps"][s:s + 1])
         b.apply_grads(1.0)
     assert a.allreduce_status() == 3
+    a.allreduce_set_mode("twoshot" if mode != "twoshot" else "oneshot")     # (idle handle: the modes may alternate)
+    for s in range(2):
+        a.train_allreduce(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
+        b.compute_grads(case["idx"][s:s + 1], case["eps"][s:s + 1])
+        b.apply_grads(1.0)
+    assert a.allreduce_status() == 5
     Pa, Pb = a.get_parameters(), b.get_parameters()
     assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
     a.close(); b.close()
-
-
-def test_per_tile_preambles_carry_the_table_entries(hostemu_lib, monkeypatch):
-    """GRL_PREAMBLE=1: the convolution launches take their rows' and first slabs' table entries from per-tile preambles
-    built on the host; the emulation kernels read them where the device kernels do -- same results as the table path."""
-    case = pu.make_case(extractor="augmented", kind="depth", B=5, n_replay=20, n_steps=2)
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("GRL_PREAMBLE", flag)
-        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
-        eng.train(2, case["idx"], case["eps"])
-        outs.append(eng.get_parameters())
-        eng.close()
-    assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
-
-
-def test_dependent_stage_launches_cover_their_producers(hostemu_lib, monkeypatch):
-    """conv3_fwd -> fc_fwd -> heads_l0 and heads_dfeat -> fc_bwd as one launch each (engine.hip: chain_ops): the emulated
-    kernel runs the tiles in index order and aborts if a tile starts before the count of producer tiles the host derived for
-    its operand rows -- and the host derivation must name every producer, or results would differ from separate launches."""
-    case = pu.make_case(extractor="augmented", kind="depth", B=70, n_replay=200, n_steps=2)
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("GRL_CHAIN", flag)
-        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
-        eng.train(2, case["idx"], case["eps"])
-        outs.append(eng.get_parameters())
-        eng.close()
-    assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])

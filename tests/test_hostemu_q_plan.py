@@ -21,14 +21,6 @@ def test_q_plan_per_layer_gemm_fallback(hostemu_lib, name, monkeypatch):
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
 
 
-@pytest.mark.parametrize("name", ["dqn", "bdq_5_branches"])
-def test_q_plan_trunk_backward_inside_the_tower_launch(hostemu_lib, name, monkeypatch):
-    """GRL_Q_TRUNK_MERGE=1 (opt-in): the last tower of a row block runs the trunk's backward; counters re-armed per launch."""
-    monkeypatch.setenv("GRL_Q_TRUNK_MERGE", "1")
-    case = qu.make_q_case(**qu.CASES[name])
-    qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
-
-
 def test_q_plan_with_vecnormalize(hostemu_lib):
     case = qu.make_q_case(normalize=True, **qu.CASES["bdq"])
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)

@@ -390,7 +390,7 @@ def test_running_statistics_on_the_device_equal_the_host_wrapper(hostemu_lib, em
         assert np.array_equal(a_host, a_dev)
         # a loaded pickle's statistics continue on the device
         eng.set_obs_stats(rms.mean * 0.5, rms.var * 2.0, 3.0)
-        eng.set_obs_count(123.0)
+        eng.set_running_stats(rms.mean * 0.5, rms.var * 2.0, 123.0)
         rms.mean, rms.var, rms.count = rms.mean * 0.5, rms.var * 2.0, 123.0
         x = rng.normal(0.2, 0.5, (3,) + obs_shape).astype(np.float32)
         rms.update(x)
