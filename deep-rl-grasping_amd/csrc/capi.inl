@@ -848,6 +848,14 @@ int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error) {
   for (int k = 0; k < DP_CHANNELS; ++k)
     HIPCHK(hipMemcpy(&c[k], (char*)h->dp_flags + k * dp_ctl_stride(), sizeof(DpCtl), hipMemcpyDeviceToHost));
   if (exchanges) *exchanges = c[0].epoch;          // (channel 0 takes part in every update, plain or overlapped)
+  if (getenv("GRL_PLAN_DUMP"))
+    for (int k = 0; k < DP_CHANNELS; ++k) {
+      fprintf(stderr, "grl dp: rank %d channel %d epoch %u error %u next_buf %u ready", h->dp.rank, k, c[k].epoch, c[k].error, c[k].next_buf);
+      for (int p = 0; p < h->dp.world; ++p) fprintf(stderr, " %u", c[k].ready[p]);
+      fprintf(stderr, " done");
+      for (int p = 0; p < h->dp.world; ++p) fprintf(stderr, " %u", c[k].done[p]);
+      fprintf(stderr, " mailbox %u\n", h->dp_err_host ? *h->dp_err_host : 0u);
+    }
   int err = h->dp_err_host ? (int)*h->dp_err_host : 0;
   for (int k = 0; k < DP_CHANNELS; ++k) err |= (int)c[k].error;
   if (error) *error = err;

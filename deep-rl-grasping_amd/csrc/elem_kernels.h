@@ -29,9 +29,11 @@ struct DevScalars {
 };
 
 // one float written in stream order (grl_set_learning_rate: the step size read by captured graphs)
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ void set_f32_kernel(float* p, float v) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // device RNG (Philox4x32-10): replay indices uniform in [0, size) and standard normals
@@ -269,9 +271,11 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
     if (a.adam_tick) adam_tick_device(a.sc);
   }
 }
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   gather_norm_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // replay ingest: env-layout observation [n, HW, Cobs] (or [n, D]) -> image block [HW*Cimg] + direct
@@ -284,6 +288,7 @@ struct IngestArgs {
   int rgb_u8;   // RGB-D ring with byte colours (grl_config.replay_rgb_u8)
 };
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
   const int k = blockIdx.y;
   const int which = blockIdx.z;
@@ -319,6 +324,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
     if (threadIdx.x == 65) a.rp_done[dst] = a.done[k];
   }
 }
+#endif
 
 // observation of grl_act: already VecNormalize-d by the env wrapper; only split + /255
 struct ActIngestArgs {
@@ -332,6 +338,7 @@ struct ActIngestArgs {
   const double* mean; const double* stdv; const double* dmean; const double* dstd;
 };
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void act_ingest_kernel(ActIngestArgs a) {
   const int k = blockIdx.y;
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(256) void act_ingest_kernel(ActIngestArgs a) {
     a.d[(long)k * a.ldd + q] = a.normalize ? norm_elem(x, a.dmean[q], a.dstd[q], 1, a.clip_obs, a.scale_div) : x / a.scale_div;
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // VecNormalize running statistics on the device (stable-baselines RunningMeanStd.update + update_from_moments, reached
@@ -415,6 +423,7 @@ __device__ __forceinline__ void norm_store(const NormUpdateArgs& a, int e, doubl
     else if (ch == a.c_obs - 1 && px < a.n_direct) { a.s_dmean[px] = mean; a.s_dstd[px] = sd; }
   }
 }
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void norm_update_kernel(NormUpdateArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   double cnt = a.count[a.parity];
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(256) void norm_update_kernel(NormUpdateArgs a) {
   }
   if (e == 0) a.count[a.parity ^ 1] = cnt;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // squashed Gaussian policy head (A.3).  mu/ls_raw are the `dense` / `dense_1` outputs.
@@ -444,6 +454,7 @@ struct SampleArgs {
   float* entropy;  // [B]
 };
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   a.logp[b] = logp;
   a.entropy[b] = ent;
 }
+#endif
 
 // backward of policy_loss = mean(ent_coef*logp - qf1_pi) through the squashing / sampling.
 struct SampleBwdArgs {
@@ -475,6 +487,7 @@ struct SampleBwdArgs {
   float* dmu; float* dls;      // [B,A]
 };
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void sample_bwd_kernel(SampleBwdArgs a) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
@@ -498,6 +511,7 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(SampleBwdArgs a) {
     a.dls[b * a.A + j] = dls;
   }
 }
+#endif
 
 // one element of TF-1.x Adam (A.5; epsilon outside the bias correction, which lives in alpha)
 // The fused multiply-adds are spelled out and contraction is off inside: the scalar, the 4-wide and the stand-alone
@@ -608,7 +622,9 @@ __device__ __forceinline__ void sac_loss_body(const LossArgs& a, int fuse_adam =
     if (sc->rng_used && !a.keep_rng) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch came from the device RNG
   }
 }
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }
+#endif
 
 #endif  // GRL_HOSTEMU
 
@@ -728,6 +744,7 @@ __device__ __forceinline__ void q_loss_finish(const QLossArgs& a, float loss, fl
 #include "elem_kernels_ref2.h"   // tests/hostemu: the emulation build only
 #else
 // fallback for more than 64 bins per branch: one thread per row
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void q_loss_rows_kernel(QLossArgs a) {
   __shared__ float red[3][256];
   const int t = threadIdx.x;
@@ -745,6 +762,7 @@ __global__ __launch_bounds__(256) void q_loss_rows_kernel(QLossArgs a) {
     else q_loss_finish(a, red[0][0], red[1][0], red[2][0]);
   }
 }
+#endif
 
 // One wavefront per minibatch row, lane = bin (n <= 64): the bin loops of q_loss_row become wave reductions
 // (fixed butterfly order), the D branches stay a loop.  Row partial sums go to a.row_part; the last
@@ -754,6 +772,7 @@ __device__ __forceinline__ float q_wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int D = a.D, n = a.n;
@@ -911,6 +930,7 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
   }
 }
 #endif
+#endif
 
 // tf.clip_by_norm per variable: g <- g * clip / max(||g||, clip); one workgroup per variable
 struct VarSeg { int64_t off; int64_t n; };
@@ -918,6 +938,7 @@ struct VarSeg { int64_t off; int64_t n; };
 #ifdef GRL_HOSTEMU
 #include "elem_kernels_ref3.h"   // tests/hostemu: the emulation build only
 #else
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void clip_by_norm_kernel(float* grads, const VarSeg* segs, float clip) {
   __shared__ float red[256];
   const VarSeg sg = segs[blockIdx.x];
@@ -934,8 +955,10 @@ __global__ __launch_bounds__(256) void clip_by_norm_kernel(float* grads, const V
   for (int64_t i = t; i < sg.n; i += 256) grads[sg.off + i] *= sc;
 }
 #endif
+#endif
 
 // Q-values of the act path: q[b, d, k] = v[b] + adv[b, d, k] - mean_k adv[b, d, :]
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void dueling_kernel(const float* adv, const float* v, int rows, int D, int n,
                                                      float* q) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -947,6 +970,7 @@ __global__ __launch_bounds__(256) void dueling_kernel(const float* adv, const fl
   m /= (float)n;
   for (int k = 0; k < n; ++k) q[(long)i * n + k] = v[b] + a[k] - m;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // sum split slabs of weight gradients into the flat gradient bucket
@@ -1090,15 +1114,18 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
     }
   }
 }
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __restrict__ descs,
                                                           const int2* __restrict__ tiles, int n_tiles,
                                                           LossArgs la, int has_loss, AdamArgs aa, int fuse_adam) {
   reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)blockIdx.x);
 }
+#endif
 // The same launch carrying, behind its own workgroups, the replay gather of the NEXT update (grid gx x B x 2 of
 // gather_norm_kernel, linearised): inside a multi-update call nothing is added to the replay between updates, every
 // reader of the minibatch tensors of update t has finished when this last launch of update t starts, and both halves
 // are memory / latency bound -- they overlap instead of paying two launches (engine.hip, "prefetch").
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDesc* __restrict__ descs,
                                                                  const int2* __restrict__ tiles, int n_tiles,
                                                                  LossArgs la, int has_loss, AdamArgs aa, int fuse_adam,
@@ -1111,10 +1138,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDe
   const int r = (int)(x - before);
   gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // TF-1.x Adam (A.5) over the flat trainable block, fused with the Polyak target update (A.4):
 // target <- (1-tau)*target + tau*source for the leading `n_polyak` floats of model/values_fn.
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
   const float alpha = a.sc->adam_alpha;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_train;
@@ -1129,6 +1158,7 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(AdamArgs a) {
     if (k >= 0 && k < a.n_polyak) a.target[k] = polyak_elem(a.target[k], p, a.tau);
   }
 }
+#endif
 
 struct RngArgs {
   DevScalars* sc; uint64_t seed; int B, A;
@@ -1136,6 +1166,7 @@ struct RngArgs {
   float* ones; int mark;     // optional: ones[b] = 1 (uniform importance weights); mark: set rng_used instead of a separate tick launch
 };
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void rng_kernel(RngArgs a) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   const uint64_t step = a.sc->rng_step;
@@ -1160,15 +1191,21 @@ __global__ __launch_bounds__(256) void rng_kernel(RngArgs a) {
   }
   if (a.mark && b == 0) a.sc->rng_used = 1u;
 }
+#endif
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ void rng_tick_kernel(DevScalars* sc) { sc->rng_step += 1; }
+#endif
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = v;
 }
+#endif
 
 // final tanh of the act path: a = deterministic ? tanh(mu) : tanh(mu + exp(clip(ls)) * eps)
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void act_out_kernel(const float* mu, const float* ls_raw,
                                                      const float* eps, int n, int A,
                                                      int deterministic, float* out) {
@@ -1181,5 +1218,6 @@ __global__ __launch_bounds__(256) void act_out_kernel(const float* mu, const flo
   }
   out[i] = tanhf(u);
 }
+#endif
 
 }  // namespace grl

@@ -2,6 +2,8 @@
 // graph machinery); the launch plans and the C ABI of include/grl.h are included parts of this translation unit:
 //   plan_sac.inl (SAC update, act, encoder forward)   plan_q.inl (DQN / BDQ, prioritised replay)
 //   plan_ae.inl  (auto-encoder training)              capi.inl  (extern "C" entry points)
+// The element-wise, replay, prioritised-sampling and exchange kernels are compiled here; the GEMM and head kernels in
+// gemm_fwd.hip / gemm_bwd.hip / gemm_wgrad.hip / heads.hip behind the launchers of launch.h.
 //
 // What is built here is the stable-baselines SAC update the reference drives through
 // manipulation_main/training/sb_helper.py:104-128 (policy / extractor selection :85-96, extractor
@@ -26,16 +28,14 @@
 #include <vector>
 
 #include "../../include/grl.h"
+// the GEMM and head kernels are instantiated in their own translation units (launch.h): descriptors / argument blocks only here
+#define GRL_GEMM_TYPES_ONLY
+#define GRL_HEADS_TYPES_ONLY
+#include "launch.h"
 #include "elem_kernels.h"
-#include "igemm.h"
-#include "igemm2.h"
-#include "heads_kernels.h"
-#include "heads_mfma.h"
 #include "per_kernels.h"
 #include "ae_kernels.h"
-#include "q_kernels.h"
 #include "q_apply_kernels.h"
-#include "igemm_sk.h"
 #include "dp_kernels.h"
 
 namespace grl {
@@ -860,18 +860,7 @@ struct grl_ctx {
         grl_ctx* self = this;
         const std::string t2 = tag;
         op.run = [la, lb, t2](hipStream_t s) {
-          const dim3 grid(la->n_tiles + lb->n_tiles), block(256);
-          const int ka = la->variant * 10000 + la->pm * 1000 + la->qm * 100 + la->cfg * 10 + la->flags;
-#define GRL_I2P(PLv, QLv, PMv, QMv, CF)                                                                                  \
-  hipLaunchKernelGGL((igemm2_pair_kernel<PLv, QLv, PMv, QMv, CF, 0, I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES>), \
-                     grid, block, 0, s, la->d_probs, la->d_tiles, la->n_tiles, lb->d_probs, lb->d_tiles)
-          switch (ka) {
-            case 11130: GRL_I2P(I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 3); break;
-            default:
-              fprintf(stderr, "grl: no igemm2 pair instantiation for launch '%s' (key %d)\n", t2.c_str(), ka);
-              abort();
-          }
-#undef GRL_I2P
+          launch_igemm2_pair(v2_key(la), la->n_tiles, lb->n_tiles, s, la->d_probs, la->d_tiles, lb->d_probs, lb->d_tiles, t2.c_str());
         };
         (void)self;
         if (getenv("GRL_PLAN_DUMP"))
@@ -953,10 +942,7 @@ struct grl_ctx {
       Op op;
       op.tag = tag;
       op.flops = op.flops_exec = flops;
-      op.run = [l](hipStream_t s) {
-        if (l->sk == 64) hipLaunchKernelGGL((igemm_sk_kernel<64>), dim3(l->n_tiles), dim3(256), 0, s, l->d_probs, l->d_tiles);
-        else hipLaunchKernelGGL((igemm_sk_kernel<32>), dim3(l->n_tiles), dim3(256), 0, s, l->d_probs, l->d_tiles);
-      };
+      op.run = [l](hipStream_t s) { launch_igemm_sk(l->sk, l->n_tiles, s, l->d_probs, l->d_tiles); };
       ops.push_back(op);
       return;
     }
@@ -992,62 +978,14 @@ struct grl_ctx {
     op.flops = flops_alg;
     op.flops_exec = flops;
     op.run = [l, tag](hipStream_t s) {
-      dim3 grid(l->n_tiles), block(256);
       if (l->v2) {
-        const int key = l->variant * 10000 + l->pm * 1000 + l->qm * 100 + l->cfg * 10 + l->flags;
-#define GRL_I2(PLv, QLv, PMv, QMv, CF, FL) \
-  hipLaunchKernelGGL((igemm2_kernel<PLv, QLv, PMv, QMv, CF, FL>), grid, block, 0, s, l->d_probs, l->d_tiles)
-#define GRL_I2_CFGS(base, PLv, QLv, PMv, QMv, FL)                           \
-  case base + 0 + FL: GRL_I2(PLv, QLv, PMv, QMv, 0, FL); break;              \
-  case base + 10 + FL: GRL_I2(PLv, QLv, PMv, QMv, 1, FL); break;             \
-  case base + 20 + FL: GRL_I2(PLv, QLv, PMv, QMv, 2, FL); break;             \
-  case base + 30 + FL: GRL_I2(PLv, QLv, PMv, QMv, 3, FL); break;
-        switch (key) {
-          GRL_I2_CFGS(0, I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0)            // dense forward
-          GRL_I2_CFGS(0, I2_P_ALONG_R, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, I2F_KTAIL)    //   ... K % 4 != 0
-          GRL_I2_CFGS(1000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0)          // VALID conv forward
-          GRL_I2_CFGS(2000, I2_P_ALONG_R, I2_Q_ALONG_J, PM_TABLE_MASK, QM_AFFINE, 0)     // padded conv forward
-          GRL_I2_CFGS(10000, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_AFFINE, 0)        // dense backward-data
-          GRL_I2_CFGS(12100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE_MASK, QM_TABLE, 0)     // conv backward-data, masked taps
-          GRL_I2_CFGS(11100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_TABLE, QM_TABLE, 0)          // conv backward-data, exact taps
-          GRL_I2_CFGS(10100, I2_P_ALONG_R, I2_Q_ALONG_R, PM_AFFINE, QM_TABLE, 0)         // dense backward-data over several kernels
-          case 20000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, 0); break;         // dense weight gradient
-          case 20001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 0, I2F_ONES); break;  //   ... with bias row
-          case 20010: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 1, 0); break;
-          case 20011: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_AFFINE, QM_AFFINE, 1, I2F_ONES); break;
-          case 21000: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, 0); break;          // conv weight gradient
-          case 21001: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 0, I2F_ONES); break;
-          case 21010: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 1, 0); break;
-          case 21011: GRL_I2(I2_P_ALONG_I, I2_Q_ALONG_J, PM_TABLE, QM_AFFINE, 1, I2F_ONES); break;
-          default:
-            fprintf(stderr, "grl: no igemm2 instantiation for launch '%s' (key %d)\n", tag.c_str(), key);
-            abort();
-        }
-#undef GRL_I2_CFGS
-#undef GRL_I2
+        const int key = v2_key(l);
+        if (l->variant == 0) launch_igemm2_fwd(key, l->n_tiles, s, l->d_probs, l->d_tiles, tag.c_str());
+        else if (l->variant == 1) launch_igemm2_bwd(key, l->n_tiles, s, l->d_probs, l->d_tiles, tag.c_str());
+        else launch_igemm2_wgrad(key, l->n_tiles, s, l->d_probs, l->d_tiles, tag.c_str());
         return;
       }
-      const int key = l->np * 1000 + l->pm * 100 + l->qm * 10 + l->variant;
-#define GRL_IGEMM(PMv, QMv, PR, QJ, NPv) \
-  hipLaunchKernelGGL((igemm_kernel<PMv, QMv, PR, QJ, NPv>), grid, block, 0, s, l->d_probs, l->d_tiles)
-      switch (key) {
-        case 1000: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, true, 1); break;        // dense forward
-        case 3000: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, true, 3); break;        //   ... concatenated input
-        case 1100: GRL_IGEMM(PM_TABLE, QM_AFFINE, true, true, 1); break;         // VALID conv forward
-        case 1200: GRL_IGEMM(PM_TABLE_MASK, QM_AFFINE, true, true, 1); break;    // padded conv forward
-        case 1001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 1); break;       // dense backward-data
-        case 3001: GRL_IGEMM(PM_AFFINE, QM_AFFINE, true, false, 3); break;       //   ... summed over heads
-        case 1211: GRL_IGEMM(PM_TABLE_MASK, QM_TABLE, true, false, 1); break;    // conv backward-data
-        case 1111: GRL_IGEMM(PM_TABLE, QM_TABLE, true, false, 1); break;         //   ... over exact taps
-        case 1011: GRL_IGEMM(PM_AFFINE, QM_TABLE, true, false, 1); break;        // dense backward-data over several kernels
-        case 1002: GRL_IGEMM(PM_AFFINE, QM_AFFINE, false, true, 1); break;       // dense weight gradient
-        case 1102: GRL_IGEMM(PM_TABLE, QM_AFFINE, false, true, 1); break;        // conv weight gradient
-        case 1202: GRL_IGEMM(PM_TABLE_MASK, QM_AFFINE, false, true, 1); break;   //   ... of a padded conv
-        default:
-          fprintf(stderr, "grl: no igemm instantiation for launch '%s' (key %d)\n", tag.c_str(), key);
-          abort();
-      }
-#undef GRL_IGEMM
+      launch_igemm(l->np * 1000 + l->pm * 100 + l->qm * 10 + l->variant, l->n_tiles, s, l->d_probs, l->d_tiles, tag.c_str());
     };
     ops.push_back(std::move(op));
   }

@@ -1,0 +1,43 @@
+// heads.hip -- the row-local chains: every MLP head of the SAC update forward + backward on the 16x16x4 matrix cores
+// (heads_mfma.h), the two-launch VALU chains other widths fall back to (heads_kernels.h), and the DQN / BDQ towers
+// (q_kernels.h).  Launchers declared in launch.h.
+#ifdef GRL_HOSTEMU
+#include "hostemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <cstdio>
+#include <cstdlib>
+#define GRL_ELEM_TYPES_ONLY     // (the element-wise kernels are compiled in engine.hip)
+#include "launch.h"
+
+namespace grl {
+
+void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args) {
+  if (shape == HEADS_FAST_128) hipLaunchKernelGGL((heads_fused_kernel<128, true>), dim3(nblk, 4), dim3(256), 0, s, args);
+  else if (shape == HEADS_FAST_64) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, args);
+  else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, args);
+}
+size_t heads_fused_lds_bytes(int shape) {
+#ifdef GRL_HOSTEMU
+  (void)shape;
+  return 0;
+#else
+  return shape == HEADS_FAST_128 ? sizeof(HmLds<128>) : sizeof(HmLds<64>);
+#endif
+}
+void launch_heads_fwd(const HeadsFwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3((a.B + HT_RB - 1) / HT_RB, 6), dim3(256), 0, s, a);
+}
+void launch_heads_bwd(const HeadsBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3((a.B + HT_RB - 1) / HT_RB, 4), dim3(256), 0, s, a);
+}
+void launch_q_fwd(const QFusedArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(q_fwd_fused_kernel, dim3((a.B + HT_RB - 1) / HT_RB, 3, a.D + 1), dim3(256), 0, s, a);
+}
+void launch_q_bwd(const QFusedArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(q_bwd_towers_kernel, dim3((a.B + HT_RB - 1) / HT_RB, a.D + 1), dim3(256), 0, s, a);
+  if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, dim3((a.B + HT_RB - 1) / HT_RB), dim3(256), 0, s, a);
+}
+
+}  // namespace grl

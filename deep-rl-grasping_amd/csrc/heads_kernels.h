@@ -152,6 +152,7 @@ __device__ __forceinline__ void ht_sample_bwd_row(const float* ls_raw, const flo
   }
 }
 
+#ifndef GRL_HEADS_TYPES_ONLY    // (engine.hip needs the argument blocks only: the kernels live in heads.hip)
 #ifdef GRL_HOSTEMU
 #include "heads_kernels_ref1.h"   // tests/hostemu: the emulation build only
 #else  // ------------------------------------------------------------------------------------ device
@@ -577,5 +578,6 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs a) {
 }
 
 #endif  // GRL_HOSTEMU
+#endif  // GRL_HEADS_TYPES_ONLY
 
 }  // namespace grl

@@ -53,6 +53,7 @@ struct HeadsFusedArgs {
   int rng_advance;   // rng_step += 1: this update's minibatch was drawn a launch chain ago with rng_step + 1
 };
 
+#ifndef GRL_HEADS_TYPES_ONLY
 #ifdef GRL_HOSTEMU
 #include "heads_mfma_ref1.h"   // tests/hostemu: the emulation build only
 #else  // ------------------------------------------------------------------------------------ device
@@ -747,5 +748,6 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
 }
 
 #endif  // GRL_HOSTEMU
+#endif  // GRL_HEADS_TYPES_ONLY
 
 }  // namespace grl

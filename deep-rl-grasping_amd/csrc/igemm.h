@@ -86,6 +86,7 @@ typedef const GRL_GLOBAL uint8_t* gcu8;
 enum { PM_AFFINE = 0, PM_TABLE = 1, PM_TABLE_MASK = 2 };
 enum { QM_AFFINE = 0, QM_TABLE = 1 };
 
+#ifndef GRL_GEMM_TYPES_ONLY     // (engine.hip needs the descriptors only: the kernels live in gemm_*.hip)
 #ifdef GRL_HOSTEMU
 #include "igemm_ref1.h"   // tests/hostemu: the emulation build only
 #else
@@ -361,5 +362,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
 }
 
 #endif  // GRL_HOSTEMU
+#endif  // GRL_GEMM_TYPES_ONLY
 
 }  // namespace grl

@@ -40,6 +40,7 @@ template <> struct I2Cfg<3> { static constexpr int BM = 32, BN = 64, WM = 1, WN 
 static inline int i2_bm(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 128 : 32); }   // cfg 2, 3: 32
 static inline int i2_bn(int cfg) { return cfg == 0 ? 64 : (cfg == 1 ? 32 : 64); }
 
+#ifndef GRL_GEMM_TYPES_ONLY
 #ifdef GRL_HOSTEMU
 #include "igemm2_ref1.h"   // tests/hostemu: the emulation build only
 #else
@@ -706,5 +707,6 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
 }
 
 #endif  // GRL_HOSTEMU
+#endif  // GRL_GEMM_TYPES_ONLY
 
 }  // namespace grl

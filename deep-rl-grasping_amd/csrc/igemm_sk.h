@@ -17,6 +17,7 @@
 
 namespace grl {
 
+#ifndef GRL_GEMM_TYPES_ONLY
 #ifdef GRL_HOSTEMU
 #include "igemm_sk_ref1.h"   // tests/hostemu: the emulation build only
 #else
@@ -167,5 +168,6 @@ __global__ __launch_bounds__(256) void igemm_sk_kernel(const IgemmProb* __restri
   if (tt < wk.z) body(tt, fixB, fixA);
 }
 #endif
+#endif  // GRL_GEMM_TYPES_ONLY
 
 }  // namespace grl

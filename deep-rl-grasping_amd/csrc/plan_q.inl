@@ -317,9 +317,7 @@ int grl_ctx::plan_q() {
     add_launch(ops_grads, "q_l0", 0, l0);
     Op op; op.tag = "q_fwd";
     const QFusedArgs fa = qf;
-    op.run = [fa](hipStream_t s) {
-      hipLaunchKernelGGL(q_fwd_fused_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 3, fa.D + 1), dim3(256), 0, s, fa);
-    };
+    op.run = [fa](hipStream_t s) { launch_q_fwd(fa, s); };
     ops_grads.push_back(op);
   } else {
     std::vector<std::vector<IgemmProb>> sc_[3], sh_[3];
@@ -370,10 +368,7 @@ int grl_ctx::plan_q() {
     if (fused_q) {
       const QFusedArgs fa = qf;
       Op op; op.tag = "q_bwd";
-      op.run = [fa](hipStream_t s) {
-        hipLaunchKernelGGL(q_bwd_towers_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, fa.D + 1), dim3(256), 0, s, fa);
-        if (fa.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, dim3((fa.B + HT_RB - 1) / HT_RB), dim3(256), 0, s, fa);
-      };
+      op.run = [fa](hipStream_t s) { launch_q_bwd(fa, s); };
       ops_grads.push_back(op);
     } else {
       std::vector<IgemmProb> pr;      // output layers -> last hidden

@@ -259,7 +259,7 @@ int grl_ctx::plan_sac() {
       if (!narrow && wide_ok) {   // the 128-wide kernel keeps 75 KB of static LDS per workgroup: fits gfx950's 160 KB; a device that offers less keeps the VALU chains
         int dev = 0, lds = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
-            lds < (int)sizeof(HmLds<128>))
+            lds < (int)heads_fused_lds_bytes(HEADS_FAST_128))
           wide_ok = false;
       }
 #endif
@@ -300,19 +300,14 @@ int grl_ctx::plan_sac() {
       for (int v = 0; v < 3; ++v) {
         Op op; op.tag = "heads";
         const HeadsFusedArgs* dv = d_ha + v;
-        op.run = [dv, nblk, fast, wide](hipStream_t s) {
-          if (wide) hipLaunchKernelGGL((heads_fused_kernel<128, true>), dim3(nblk, 4), dim3(256), 0, s, dv);
-          else if (fast) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, dv);
-          else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, dv);
-        };
+        const int shape = wide ? HEADS_FAST_128 : (fast ? HEADS_FAST_64 : HEADS_GENERAL_64);
+        op.run = [dv, nblk, shape](hipStream_t s) { launch_heads_fused(shape, nblk, s, dv); };
         if (v == 0) ops_grads.push_back(op);
         else pf_heads[v - 1] = op;
       }
     } else {
     Op op; op.tag = "heads_fwd";
-    op.run = [fa](hipStream_t s) {
-      hipLaunchKernelGGL(heads_fwd_kernel, dim3((fa.B + HT_RB - 1) / HT_RB, 6), dim3(256), 0, s, fa);
-    };
+    op.run = [fa](hipStream_t s) { launch_heads_fwd(fa, s); };
     ops_grads.push_back(op);
     }
   } else {
@@ -396,9 +391,7 @@ int grl_ctx::plan_sac() {
     ba.log_ent_coef = params + ent_off; ba.da_pi = da_pi; ba.dmu = dmu; ba.dls = dls;
     if (!heads_mfma) {
     Op op; op.tag = "heads_bwd";
-    op.run = [ba](hipStream_t s) {
-      hipLaunchKernelGGL(heads_bwd_kernel, dim3((ba.B + HT_RB - 1) / HT_RB, 4), dim3(256), 0, s, ba);
-    };
+    op.run = [ba](hipStream_t s) { launch_heads_bwd(ba, s); };
     ops_grads.push_back(op);
     }
     if (cnn) {

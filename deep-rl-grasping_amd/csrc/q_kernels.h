@@ -28,6 +28,7 @@ struct QFusedArgs {
   float trunk_scale;
 };
 
+#ifndef GRL_HEADS_TYPES_ONLY
 #ifdef GRL_HOSTEMU
 #include "q_kernels_ref1.h"   // tests/hostemu: the emulation build only
 #else
@@ -57,5 +58,6 @@ __global__ __launch_bounds__(256) void q_bwd_trunk_kernel(QFusedArgs a) {
   ht_bwd_head(*a.bwd_tr, blockIdx.x * HT_RB, a.B, s, nullptr, 0, a.dh_part, a.D + 1, (long)a.B * a.Ht, a.trunk_scale);
 }
 #endif
+#endif  // GRL_HEADS_TYPES_ONLY
 
 }  // namespace grl

@@ -181,6 +181,12 @@ class DataParallelInGraph:
         """Synchronises; raises if an exchange timed out.  Returns the number of exchanges begun."""
         return self.eng.allreduce_status()
 
+    def close(self):
+        """Collective: every rank drains its stream and meets the others BEFORE any of them releases its engine -- a peer's
+        kernels read this rank's exchange memory until their last exchange has completed."""
+        self.eng.synchronize()
+        dist.barrier(group=self.group)
+
 
 def launched_world():
     """(rank, world, local_rank) of a process started by ``torch.distributed.run`` / torchrun (RANK, WORLD_SIZE,

@@ -6,5 +6,12 @@
 set -e
 cd "$(dirname "$0")/.."
 sfx="$1"; shift || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -DGRL_TILE_TRACE "$@" \
-  deep-rl-grasping_amd/csrc/engine.hip -o deep-rl-grasping_amd/grasp_rl/libgrl_trace${sfx}.so
+objs=""
+for u in deep-rl-grasping_amd/csrc/*.hip; do
+  o=build/obj/$(basename ${u%.hip}).trace${sfx}.o
+  mkdir -p build/obj
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -DGRL_TILE_TRACE "$@" -c $u -o $o &
+  objs="$objs $o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o deep-rl-grasping_amd/grasp_rl/libgrl_trace${sfx}.so

@@ -34,16 +34,20 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def hostemu_lib():
-    """TEST-ONLY g++ build of engine.hip with the HIP runtime stubbed (tests/hostemu/hostemu.h + the reference
-    loops tests/hostemu/*_ref*.h that the kernel headers include only under -DGRL_HOSTEMU): validates the
+    """TEST-ONLY g++ build of the library's translation units (csrc/*.hip) with the HIP runtime stubbed (tests/hostemu/hostemu.h
+    + the reference loops tests/hostemu/*_ref*.h that the kernel headers include only under -DGRL_HOSTEMU): validates the
     host-side launch plan against the oracle without a GPU.  Never used by the product."""
     out = os.path.join(ROOT, "tests", "_build", "libgrl_hostemu.so")
-    src = os.path.join(PKG, "csrc", "engine.hip")
     csrc = os.path.join(PKG, "csrc")
     emu = os.path.join(ROOT, "tests", "hostemu")
     deps = [os.path.join(d, f) for d in (csrc, emu) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".inl"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DGRL_HOSTEMU", "-I", emu, "-x", "c++", src,
-                               "-o", out])
+        units = [f[:-4] for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+        objs = [os.path.join(ROOT, "tests", "_build", u + ".emu.o") for u in units]
+        procs = [subprocess.Popen(["g++", "-O2", "-std=c++17", "-fPIC", "-DGRL_HOSTEMU", "-I", emu, "-x", "c++", "-c",
+                                   os.path.join(csrc, u + ".hip"), "-o", o]) for u, o in zip(units, objs)]
+        if any(p.wait() != 0 for p in procs):
+            raise RuntimeError("g++ emulation build failed")
+        subprocess.check_call(["g++", "-shared", "-fPIC"] + objs + ["-o", out])
     return out

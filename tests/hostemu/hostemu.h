@@ -30,7 +30,9 @@ struct int4 { int x, y, z, w; };
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
-static thread_local dim3 threadIdx, blockIdx, gridDim, blockDim;
+// ONE instance for the whole library (C++17 inline variables): the kernel templates are instantiated in several translation
+// units and the linker keeps one copy of each -- which must read the indices the launcher of ANY unit set
+inline thread_local dim3 threadIdx, blockIdx, gridDim, blockDim;
 static inline void __syncthreads() {}
 static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 using std::max;

@@ -207,6 +207,7 @@ def _ingraph_worker(rank, world, port, out_dir):
             dp.train(3)
             assert dp.check() == STEPS + 9
             finals.append(eng.get_parameters())
+            dp.close()            # (collective: no rank frees its exchange memory while a peer may still read it)
             eng.close()
         for P in finals[1:]:
             for k in P:
@@ -275,6 +276,7 @@ def _timeout_worker(rank, world, port, out_dir):
     after = eng.get_parameters()
     for k in before:                  # nobody applied a partial exchange
         assert np.array_equal(before[k], after[k]), k
+    dp.close()
     eng.close()
     dist.destroy_process_group()
 
@@ -338,7 +340,10 @@ def _learn_worker(rank, world, port, out_dir, device_norm):
         assert np.array_equal(P[k], P2[k]), "model.learn and the wrapper-driven engine differ: " + k
     np.savez(os.path.join(out_dir, "learn%d.npz" % rank), obs_mean=mean, obs_var=var, obs_count=count, ret_var=env.ret_rms.var,
              **{k.replace("/", "|"): v for k, v in P.items()})
+    dp2.close()
+    model._dp.close()
     eng2.close()
+    model.engine.close()
     dist.destroy_process_group()
 
 
