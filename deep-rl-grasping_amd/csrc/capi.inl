@@ -247,6 +247,7 @@ int grl_norm_update(grl_handle h, const float* obs, int n) {
     DpNormArgs na = h->dp_norm;
     na.nu = a;
     hipLaunchKernelGGL(dp_norm_moments_kernel, grid, dim3(256), 0, h->stream, na);
+    hipLaunchKernelGGL(dp_wait_kernel, dim3(1), dim3(64), 0, h->stream, na.d, 0);
     hipLaunchKernelGGL(dp_norm_merge_kernel, grid, dim3(256), 0, h->stream, na);
   } else {
     hipLaunchKernelGGL(norm_update_kernel, grid, dim3(256), 0, h->stream, a);
@@ -523,6 +524,11 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
   out->policy_loss = s.policy_loss; out->qf1_loss = s.qf1_loss; out->qf2_loss = s.qf2_loss;
   out->value_loss = s.value_loss; out->ent_coef_loss = s.ent_loss; out->ent_coef = s.ent_coef;
   out->entropy = s.entropy; out->mean_qf1 = s.mean_qf1; out->mean_v = s.mean_v;
+  for (int* e : h->chain_err) {     // a bounded wait of a dependent-stage launch ran out (igemm2_chain_kernel): results are not valid
+    int v = 0;
+    HIPCHK(hipMemcpy(&v, e, sizeof(v), hipMemcpyDeviceToHost));
+    if (v) return fail(GRL_ERR_STATE, "a dependent-stage launch timed out waiting for its producers");
+  }
   return GRL_OK;
 }
 
@@ -654,6 +660,12 @@ static Op dp_k1_op(grl_ctx* self, const grl_ctx::ReducePlan& rp, const DpArgs& d
   };
   return op;
 }
+// W: one wave announces (`which` 0: ready, 1: done) and waits for every rank (the only kernel of the exchange that waits)
+static Op dp_wait_op(const DpArgs& da, int which) {
+  Op op; op.tag = which == 0 ? "dp_wait_ready" : "dp_wait_done";
+  op.run = [da, which](hipStream_t s) { hipLaunchKernelGGL(dp_wait_kernel, dim3(1), dim3(64), 0, s, da, which); };
+  return op;
+}
 static Op dp_reduce_op(const DpArgs& da) {
   Op op; op.tag = "dp_reduce"; op.bytes = 4.0 * (double)da.chunk * (da.world + 1);
   const int blocks = dp_blocks(0, da.chunk / 4);
@@ -727,8 +739,9 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
     std::vector<Op>& tail = one ? h->ops_dp1 : h->ops_dp;
     tail.clear();
     tail.push_back(dp_k1_op(h, h->red_all, d, h->loss_args, nullptr, 0, "reduce_publish"));
+    tail.push_back(dp_wait_op(d, 0));
     if (one) tail.push_back(dp_apply_oneshot_op(h, d));
-    else { tail.push_back(dp_reduce_op(d)); tail.push_back(dp_apply_op(h, d, none)); }
+    else { tail.push_back(dp_reduce_op(d)); tail.push_back(dp_wait_op(d, 1)); tail.push_back(dp_apply_op(h, d, none)); }
     // multi-update calls on the device RNG: the same with the gather of the next update riding on K1 (plan_sac "prefetch")
     std::vector<Op>* pf[3] = {one ? &h->ops_pfdp1_first : &h->ops_pfdp_first, one ? &h->ops_pfdp1_mid : &h->ops_pfdp_mid,
                               one ? &h->ops_pfdp1_last : &h->ops_pfdp_last};
@@ -773,12 +786,16 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
       auto side = [&](Op o) { o.lane = 1; o.fork = first; o.join = false; first = false; L.push_back(o); };
       for (size_t k = cut + 1; k + 1 < h->ops_stage0.size(); ++k) side(h->ops_stage0[k]);     // wgrad_dense
       side(dp_k1_op(h, h->red_dense, d0, h->loss_args, nullptr, 0, "reduce_dense_publish"));
+      side(dp_wait_op(d0, 0));
       side(dp_reduce_op(d0));
+      side(dp_wait_op(d0, 1));
       d0.gathered = (float*)((char*)h->dp_buf + 2 * dp_arr_bytes(h->n_train));     // the side lane also pulls the dense sums
       side(dp_gather_op(d0));
       for (size_t k = 0; k + 1 < h->ops_stage1.size(); ++k) { Op o = h->ops_stage1[k]; o.join = false; L.push_back(o); }
       { Op o = dp_k1_op(h, h->red_conv, d1, h->loss_args, nullptr, 0, "reduce_conv_publish"); o.join = false; L.push_back(o); }
+      L.push_back(dp_wait_op(d1, 0));
       L.push_back(dp_reduce_op(d1));
+      L.push_back(dp_wait_op(d1, 1));
       L.push_back(dp_apply_op(h, d0, d1));       // (joins the side lane)
     }
   }

@@ -17,19 +17,25 @@
 // Two-shot exchange (any world size; bytes per rank 2 (W-1)/W n):
 //   K1  the last launch of the gradient computation (the slab reduction that forms every gradient) stores each sum
 //       write-through into THIS rank's src as it forms it -- no copy kernel; one thread advances the epoch
-//   K2  reduce-scatter: announces ready[me] = e to every rank, waits for ready[*] >= e, adds chunk me of all ranks IN RANK
-//       ORDER (remote 16-byte loads; one rank forms each sum, so every replica receives the same bits) into ITS red
-//   K3  all-gather by PULL fused with Adam + Polyak: announces done[me] = e, waits for done[*] >= e, reads each sum from
-//       the red of the chunk's owner (grad_scale 1 / world) -- nothing is ever written remotely but flags
+//   W   announces ready[me] = e to every rank, waits for ready[*] >= e
+//   K2  reduce-scatter: adds chunk me of all ranks IN RANK ORDER (remote 16-byte loads; one rank forms each sum, so every
+//       replica receives the same bits) into ITS red
+//   W   announces done[me] = e, waits for done[*] >= e
+//   K3  all-gather by PULL fused with Adam + Polyak: reads each sum from the red of the chunk's owner (grad_scale
+//       1 / world) -- nothing is ever written remotely but flags
 // One-shot exchange (small worlds; bytes per rank (W-1) n, one flag round and one kernel less):
 //   K1  as above into source buffer e & 1 (src / red alternate: a rank overwrites the buffer of exchange e - 2 only after
 //       ready[*] >= e - 1, i.e. after every peer finished reading it -- no second flag round needed)
-//   K2' announces ready, waits, and every rank adds all W contributions of every element in rank order inside Adam
+//   W   announces ready, waits
+//   K2' every rank adds all W contributions of every element in rank order inside Adam
 //
-// A flag is stored by the FIRST thread of the kernel that follows the data it announces: a kernel boundary on one stream
-// (or graph edge) completes and drains every write-through store of the kernel before it, so no block counts itself in,
-// no block drains or fences (round 3 ended every data kernel with drain + barrier + atomic per block and a last-block
-// election: 11 + 10.5 + 19 us for 5.4 MB).  Exchanged data is stored WRITE-THROUGH (buffer stores with sc0 | sc1) and
+// Announcing and waiting is the job of ONE wave: dp_wait_kernel (one 64-thread block) sits between the kernel that wrote
+// the data and the kernel that reads the peers' -- a kernel boundary on one stream (or graph edge) completes and drains
+// every write-through store of the kernel before it, so the data kernels neither count themselves in nor drain nor fence
+// (round 3 ended every data kernel with drain + barrier + atomic per block and a last-block election: 11 + 10.5 + 19 us
+// for 5.4 MB), and they never SPIN: a full grid of polling blocks fills the machine's wave slots, and when the peer it
+// waits for is another process on the same GPU (or this process's own later kernels) nothing else can be dispatched --
+// measured: 4 processes on one MI355X dead-locked until the wait ran out, 2 processes lost 7 s on their first exchange.  Exchanged data is stored WRITE-THROUGH (buffer stores with sc0 | sc1) and
 // loaded past the caches (sc0 | sc1 loads): nothing stays dirty in an L2 and nothing stale is read from one
 // (cdna_hip_programming.md, Guideline 16, at SYSTEM scope because the other side may be another GPU).
 // Waits are BOUNDED by the 100 MHz wall clock (GRL_TUNE dp_timeout_ms, default 120 s -- like a collective library a rank
@@ -161,17 +167,27 @@ __global__ __launch_bounds__(256) void dp_reduce_slabs_kernel(const ReduceDesc* 
   gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
 }
 
-// K2 (two-shot)
-__global__ __launch_bounds__(256) void dp_reduce_kernel(DpArgs a) {
+// W: the only kernel that waits.  One wave: announce `ready` (which = 0) or `done` (which = 1) for the current exchange in
+// every rank's flags, wait for every rank's.  It also keeps next_buf in step (the source buffer of the NEXT exchange).
+__global__ __launch_bounds__(64) void dp_wait_kernel(DpArgs a, int which) {
+  if (threadIdx.x != 0) return;
   DpCtl* mine = a.ctl[a.rank];
   const uint32_t e = mine->epoch;
+  dp_announce(a, which == 0, e);
+  if (which == 0) mine->next_buf = (e + 1u) & 1u;
+  (void)dp_wait_all(a, which == 0 ? mine->ready : mine->done, e);
+}
+// a data kernel's entry check: the channel is healthy (the wait in front of it succeeded)
+__device__ __forceinline__ bool dp_healthy(const DpArgs& a) {
   __shared__ int ok_s;
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) { dp_announce(a, true, e); mine->next_buf = (e + 1u) & 1u; }     // (next_buf: kept in step for a later one-shot exchange)
-    ok_s = dp_wait_all(a, mine->ready, e) ? 1 : 0;
-  }
+  if (threadIdx.x == 0) ok_s = dp_load_flag(&a.ctl[a.rank]->error) == 0u ? 1 : 0;
   __syncthreads();
-  if (!ok_s) return;
+  return ok_s != 0;
+}
+
+// K2 (two-shot)
+__global__ __launch_bounds__(256) void dp_reduce_kernel(DpArgs a) {
+  if (!dp_healthy(a)) return;
   const int64_t lo = (int64_t)a.rank * a.chunk, hi = min(a.n, lo + a.chunk);
   const int64_t q0 = lo >> 2, q1 = hi >> 2;      // (n, chunk and every piece are multiples of 4 floats; an empty chunk: q0 >= q1)
   for (int64_t i = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < q1; i += (int64_t)gridDim.x * 256) {
@@ -185,15 +201,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(DpArgs a) {
 // All-gather half of a channel as a kernel of its own (the overlapped update runs it on the side lane, so that the pull over
 // xGMI is hidden as well): every sum from the red array of its chunk's owner into this rank's `gathered` array.
 __global__ __launch_bounds__(256) void dp_gather_kernel(DpArgs d) {
-  DpCtl* mine = d.ctl[d.rank];
-  const uint32_t e = mine->epoch;
-  __shared__ int ok_s;
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) dp_announce(d, false, e);
-    ok_s = dp_wait_all(d, mine->done, e) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!ok_s) return;
+  if (!dp_healthy(d)) return;
   const int64_t n4 = d.n >> 2, c4 = d.chunk >> 2;
   for (int owner = 0; owner < d.world; ++owner)
     for (int64_t i = owner * c4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < min(n4, (owner + 1) * c4); i += (int64_t)gridDim.x * 256) {
@@ -235,26 +243,12 @@ __device__ __forceinline__ void dp_apply_channel(const AdamArgs& a, const DpArgs
 }
 
 // K3 (two-shot).  d: a channel whose sums are pulled here (or, with d.gathered set, were pulled by dp_gather_kernel on the
-// side lane: nothing to wait for); d2: a second channel (overlapped update), or world = 0.  The pieces of the two channels
-// partition the trainable bucket.
+// side lane); d2: a second channel (overlapped update), or world = 0.  The pieces of the two channels partition the
+// trainable bucket.  Nothing is applied unless BOTH channels are healthy.
 __global__ __launch_bounds__(256) void dp_apply_kernel(AdamArgs a, DpArgs d, DpArgs d2) {
   __shared__ int ok_s;
-  if (threadIdx.x == 0) {
-    bool ok = true;
-    if (!d.gathered) {
-      DpCtl* m1 = d.ctl[d.rank];
-      if (blockIdx.x == 0) dp_announce(d, false, m1->epoch);
-      ok = dp_wait_all(d, m1->done, m1->epoch);
-    } else {
-      ok = dp_load_flag(&d.ctl[d.rank]->error) == 0u;
-    }
-    if (d2.world > 0) {
-      DpCtl* m2 = d2.ctl[d2.rank];
-      if (blockIdx.x == 0) dp_announce(d2, false, m2->epoch);
-      ok = dp_wait_all(d2, m2->done, m2->epoch) && ok;
-    }
-    ok_s = ok ? 1 : 0;
-  }
+  if (threadIdx.x == 0)
+    ok_s = (dp_load_flag(&d.ctl[d.rank]->error) == 0u && (d2.world == 0 || dp_load_flag(&d2.ctl[d2.rank]->error) == 0u)) ? 1 : 0;
   __syncthreads();
   if (!ok_s) return;
   const float alpha = a.sc->adam_alpha;
@@ -264,17 +258,9 @@ __global__ __launch_bounds__(256) void dp_apply_kernel(AdamArgs a, DpArgs d, DpA
 
 // K2' (one-shot): every rank adds the W contributions of every element in rank order and applies the mean
 __global__ __launch_bounds__(256) void dp_apply_oneshot_kernel(AdamArgs a, DpArgs d) {
-  DpCtl* mine = d.ctl[d.rank];
-  const uint32_t e = mine->epoch;
-  __shared__ int ok_s;
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) { dp_announce(d, true, e); mine->next_buf = (e + 1u) & 1u; }
-    ok_s = dp_wait_all(d, mine->ready, e) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!ok_s) return;
+  if (!dp_healthy(d)) return;
   const float alpha = a.sc->adam_alpha;
-  const bool odd = (e & 1u) != 0u;
+  const bool odd = (d.ctl[d.rank]->epoch & 1u) != 0u;
   const int64_t n4 = d.n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int64_t qd = dp_quad(d, i);
@@ -316,17 +302,10 @@ __global__ __launch_bounds__(256) void dp_norm_moments_kernel(DpNormArgs a) {
     mine->epoch = mine->epoch + 1u;
   }
 }
-// N2: wait for every rank's moments, merge them in rank order, refresh the derived arrays
+// N2 (behind dp_wait_kernel on channel 2): merge every rank's moments in rank order, refresh the derived arrays
 __global__ __launch_bounds__(256) void dp_norm_merge_kernel(DpNormArgs a) {
-  DpCtl* mine = a.d.ctl[a.d.rank];
-  const uint32_t e = mine->epoch;
-  __shared__ int ok_s;
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) { dp_announce(a.d, true, e); mine->next_buf = (e + 1u) & 1u; }
-    ok_s = dp_wait_all(a.d, mine->ready, e) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!ok_s) return;
+  if (!dp_healthy(a.d)) return;
+  const uint32_t e = a.d.ctl[a.d.rank]->epoch;
   const NormUpdateArgs& u = a.nu;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int64_t off = (int64_t)(e & 1u) * a.mom_stride;

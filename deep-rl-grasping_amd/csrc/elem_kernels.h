@@ -1065,8 +1065,9 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
         for (int u = 0; u < 8; ++u) s += vv[u];
       }
       for (; k < d.splits; ++k) s += *(const rs_f4*)(src + (long)k * d.slab_stride);
-      *(rs_f4*)(d.dst + i) = s;
+      // (data parallel: the sums go to the exchange buffer ONLY -- nothing reads this rank's own bucket before the exchange)
       if (mirror) { const float sv[4] = {s.x, s.y, s.z, s.w}; st_sys_quad(mirror, ((d.dst + i) - aa.grads) >> 2, sv); }
+      else *(rs_f4*)(d.dst + i) = s;
       if (fuse_adam) {
         const float alpha = aa.sc->adam_alpha;
         float pe[4] = {p.x, p.y, p.z, p.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
@@ -1105,8 +1106,8 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
       for (int u = 0; u < 8; ++u) s += vv[u];
     }
     for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
-    d.dst[i] = s;
     if (mirror) st_sys_f1(mirror + ((d.dst + i) - aa.grads), s);
+    else d.dst[i] = s;
     if (fuse_adam) {   // the update every trainable tensor gets from adam_polyak_kernel, element by element
       adam_elem(grad_scaled(s, aa.grad_scale), p, m, v, aa.sc->adam_alpha, aa.eps);
       aa.params[e] = p; aa.m[e] = m; aa.v[e] = v;

@@ -16,6 +16,10 @@ CASES = {
     # BASELINE configs[2] exactly: gripper_grasp.yaml:104-118 (layers [[64,64],[32],[32]], num_actions_pad 33,
     # batch 64) on the 101-d auto-encoder observation (100 features + gripper width), 5 action dimensions
     "bdq_baseline_config3": dict(algo="bdq", obs_dim=101, D=5, bins=33, common=(64, 64), branch=(32,), value=(32,), B=64, lr=1e-4),
+    # ... and as gripper_grasp.yaml:104-118 actually selects it: `prioritized_replay: False` (:106) -- uniform replay, every
+    # importance weight 1
+    "bdq_baseline_config3_uniform": dict(algo="bdq", obs_dim=101, D=5, bins=33, common=(64, 64), branch=(32,), value=(32,), B=64,
+                                         lr=1e-4, uniform=True),
     # the alternative readings of the unavailable bdq_sb fork (oracle/dqn.py switches): TD loss summed over the
     # branches; no 1/(D+1) rescaling of the trunk gradient
     "bdq_loss_sum": dict(algo="bdq", obs_dim=20, D=3, bins=5, common=(16, 16), branch=(8,), value=(8,), B=8, loss_sum=True),
@@ -25,7 +29,7 @@ CASES = {
 
 
 def make_q_case(algo, obs_dim, D, bins, common, branch, value, B, n_replay=40, n_steps=3, seed=0, lr=1e-3,
-                normalize=False, loss_sum=False, trunk_rescale=True):
+                normalize=False, loss_sum=False, trunk_rescale=True, uniform=False):
     rng = np.random.default_rng(seed)
     spec = od.QSpec(algo=algo, obs_dim=obs_dim, n_branches=D, n_bins=bins, common=list(common),
                     branch_hidden=list(branch), value_hidden=list(value), gamma=0.97, lr=lr,
@@ -41,6 +45,8 @@ def make_q_case(algo, obs_dim, D, bins, common, branch, value, B, n_replay=40, n
           "done": (rng.random(n_replay) < 0.2).astype(np.float32)}
     idx = rng.integers(0, n_replay, (n_steps, B), dtype=np.int64)
     weights = rng.uniform(0.3, 1.0, (n_steps, B)).astype(np.float32)
+    if uniform:                   # uniform replay (prioritized_replay False): stable-baselines feeds weights of one
+        weights = np.ones((n_steps, B), np.float32)
     return dict(spec=spec, cfg=cfg, tr=tr, idx=idx, weights=weights, params=od.init_params(spec, seed), B=B,
                 n_steps=n_steps, stats={"mean": mean, "var": var, "ret_var": 9.0}, normalize=normalize)
 

@@ -166,7 +166,9 @@ def _ingraph_worker(rank, world, port, out_dir):
     os.environ["GRL_TUNE"] = "dp_timeout_ms=20000"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
-    cases = {"cnn": _case()}
+    B = max(16, 4 * world)      # (a per-rank minibatch of at least 4 rows: below that the dense weight gradients leave the
+    #                              vectorised kernel and the plan has no staged form to overlap)
+    cases = {"cnn": pu.make_case(extractor="augmented", kind="depth", B=B, n_replay=48, n_steps=STEPS)}
     if world >= 8:
         # the smallest SAC there is: a bucket of 84 floats -- not a multiple of 4 * world, rank 6's chunk short, rank 7's EMPTY
         # (capi.inl: chunk = rup(ceil(n / world), 4))

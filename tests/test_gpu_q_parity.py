@@ -25,6 +25,24 @@ def test_q_update_three_launch_apply(name, monkeypatch):
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 
+def test_bdq_uniform_replay_on_the_device_rng():
+    """configs[2] as the YAML selects it (gripper_grasp.yaml:104-118: 101-d observations, 5 x 33 bins, batch 64,
+    prioritized_replay False): next to the oracle comparison of `bdq_baseline_config3_uniform` above, the production form --
+    indices drawn on the device, every importance weight exactly 1, all indices inside the stored range, deterministic."""
+    import numpy as np
+    outs = []
+    for _ in range(2):
+        case = qu.make_q_case(**qu.CASES["bdq_baseline_config3_uniform"])
+        eng = qu.q_engine_setup(case)
+        eng.train(7)                                   # device RNG: idx / weights NULL
+        idx, w = eng.sampled_indices(), eng.importance_weights()
+        assert np.all(w == 1.0) and idx.min() >= 0 and idx.max() < eng.replay_size() and len(np.unique(idx)) > 8
+        outs.append(eng.get_parameters())
+        eng.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 def test_q_update_with_vecnormalize():
     qu.run_and_compare(qu.make_q_case(normalize=True, **qu.CASES["bdq"]))
 
