@@ -641,7 +641,8 @@ struct QLossArgs {
   const float* adv2; const float* v2;     // target(s')
   const float* act;                       // [B, D] bin indices stored as floats
   const float* rew; const float* done; const float* weights;   // [B]
-  float* d_adv0; float* d_v0;             // gradients [B, D*n], [B]
+  float* d_adv0; float* d_v0;             // gradients [B, D*nbp] (nbp >= n: a branch's bins start 16-byte aligned), [B] with stride ld_dv
+  int nbp, ld_dv;                         //   -- the weight-gradient GEMM fetches them 16 bytes at a time (padding stays zero)
   float* td; float* priority;             // [B, D], [B]
   DevScalars* sc;
   float* row_part; unsigned* counter;     // [3 B] per-row partial sums, completion counter (zero between launches)
@@ -693,10 +694,10 @@ __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3)
     lossb += err;
     const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
     dv += g;
-    float* ga = a.d_adv0 + ((long)b * D + d) * n;
+    float* ga = a.d_adv0 + ((long)b * D + d) * a.nbp;
     for (int k = 0; k < n; ++k) ga[k] = g * ((k == ai ? 1.f : 0.f) - invn);
   }
-  a.d_v0[b] = dv;
+  a.d_v0[(long)b * a.ld_dv] = dv;
   a.priority[b] = prio;
   s3[0] += w * lossb * (a.loss_sum ? 1.f : invD);
   s3[1] += qs * invD;
@@ -836,12 +837,12 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
         lossb += err;
         const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
         dv += g;
-        if (on) a.d_adv0[o] = g * ((lane == ai ? 1.f : 0.f) - invn);
+        if (on) a.d_adv0[((long)b * D + d) * a.nbp + lane] = g * ((lane == ai ? 1.f : 0.f) - invn);
         if (lane == 0) a.td[b * D + d] = tdv;
       }
     }
     if (lane == 0) {
-      a.d_v0[b] = dv;
+      a.d_v0[(long)b * a.ld_dv] = dv;
       a.priority[b] = prio;
       a.row_part[3 * b] = w * lossb * (a.loss_sum ? 1.f : invD);
       a.row_part[3 * b + 1] = qs * invD;
@@ -890,11 +891,11 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
       lossb += err;
       const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
       dv += g;
-      if (on) a.d_adv0[o] = g * ((lane == ai ? 1.f : 0.f) - invn);
+      if (on) a.d_adv0[((long)b * D + d) * a.nbp + lane] = g * ((lane == ai ? 1.f : 0.f) - invn);
       if (lane == 0) a.td[b * D + d] = tdv;
     }
     if (lane == 0) {
-      a.d_v0[b] = dv;
+      a.d_v0[(long)b * a.ld_dv] = dv;
       a.priority[b] = prio;
       a.row_part[3 * b] = w * lossb * (a.loss_sum ? 1.f : invD);
       a.row_part[3 * b + 1] = qs * invD;

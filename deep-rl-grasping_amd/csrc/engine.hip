@@ -76,7 +76,6 @@ static int tune_int(const char* key, int dflt) {
   std::string v;
   return tune_str(key, &v) ? atoi(v.c_str()) : dflt;
 }
-enum { GRL_CHAIN_DEFAULT = 0 };     // dependent stages merged into one launch (chain_ops): off until measured faster
 static int tune_int3(const char* key, int v[3]) {     // "a/b/c"
   std::string t;
   return tune_str(key, &t) ? sscanf(t.c_str(), "%d/%d/%d", &v[0], &v[1], &v[2]) : 0;
@@ -147,7 +146,6 @@ struct Launch {
   int4* d_tiles = nullptr;
   int n_tiles = 0;
   Launch* filler = nullptr;     // tiles of a second instantiation carried by the same launch (igemm2_pair_kernel)
-  std::vector<int4> h_tiles;    // host copy of the work list (chain_ops derives the tile dependencies from it)
 };
 
 struct Op {
@@ -158,7 +156,6 @@ struct Op {
   int lane = 0;
   bool fork = false, join = false;
   std::function<void(hipStream_t)> run;
-  Launch* launch = nullptr;   // the igemm2 launch behind a plain (single-instantiation) op: what chain_ops merges
   double flops = 0;   // algorithmic FLOPs of one launch (2 * M * N * K over the taps / rows that exist)
   double flops_exec = 0;   // FLOPs the launch's MFMAs execute (>= flops: masked taps of the parity-class backward-data form)
   double bytes = 0;   // algorithmic HBM bytes of one launch
@@ -978,8 +975,6 @@ struct grl_ctx {
     launches.push_back(l);
     Op op;
     op.tag = tag;
-    op.launch = l;
-    l->h_tiles = tiles;
     op.flops = flops_alg;
     op.flops_exec = flops;
     op.run = [l, tag](hipStream_t s) {
@@ -1018,10 +1013,7 @@ struct grl_ctx {
   // every extra split adds a slab the reduction pass has to write and read back (~4 TB/s effective).  The dense
   // problems of the same launch enter with their shapes only.  Measured at the headline shape: hand-tuned 72/12/6
   // (fullest CU 56 slabs) 4 560 updates/s, model's choice (49 slabs) 4 590.
-  // wsplit[layer][net]: the two networks may take DIFFERENT splits of the same layer (tune knob per_net_splits, default
-  // on) -- same shapes, but two tile lengths per layer let the placement fill the CUs more evenly (fullest CU 43 -> 40 slabs
-  // at the headline shape); conv1 of both networks is one problem (side-by-side gradient buffer) and has one split.
-  void pick_wgrad_splits(const ConvGeom* cg, const ConvFwdTabs* ft, int n_side, int wsplit[3][2], int rider_budget) {
+  void pick_wgrad_splits(const ConvGeom* cg, const ConvFwdTabs* ft, int n_side, int wsplit[3], int rider_budget) {
     auto shape = [](int M, int N, int K, int split) {
       IgemmProb p = blank();
       p.M = M; p.N = N; p.K = K; p.p_ones_i = M - 1;
@@ -1049,43 +1041,30 @@ struct grl_ctx {
       }
       return v;
     };
-    // (measured on MI355X at the headline shape, one box: 5 217 / 5 213 updates/s with per-network splits against 5 236 / 5 233
-    //  without -- the model's 43 -> 40 slabs on the fullest CU do not show up in the launch, 32.5 against 32.0 us: off)
-    const bool per_net = tune_int("per_net_splits", 0) != 0;
-    const std::vector<int> c1 = cands(rows[0]), c2 = cands(rows[1]), c3 = cands(rows[2]);
-    for (int s1 : c1)
-      for (int s2a : c2)
-        for (int s2b : c2) {
-          if (s2b > s2a || (!per_net && s2b != s2a)) continue;
-          for (int s3a : c3)
-            for (int s3b : c3) {
-              if (s3b > s3a || (!per_net && s3b != s3a)) continue;
-              std::vector<IgemmProb> pr;
-              double slab_bytes = 0;
-              const int sp[3][2] = {{s1, s1}, {s2a, s2b}, {s3a, s3b}};
-              for (int l = 2; l >= 0; --l) {
-                const int reps = (l == 0 && n_side > 1) ? 1 : 2;
-                const int N = (l == 0 && n_side > 1) ? n_side * cg[l].Cout : cg[l].Cout;
-                for (int n = 0; n < reps; ++n) {
-                  pr.push_back(shape(cg[l].K() + 1, N, ft[l].M, sp[l][n]));
-                  slab_bytes += 4.0 * pr.back().M * N * pr.back().split;
-                }
-              }
-              pr.insert(pr.end(), light.begin(), light.end());
-              double mx = 0;
-              xcd_order(tile_list(pr, true, 64, 64), pr, 64, 64, &mx);
-              // us: the fullest CU's slabs + the reduction pass: slab bytes written and read back, and its per-thread chain of
-              // load batches, which grows with the largest split (measured 13.5 / 15.0 / 19.3 us at 57 / 86-113 / 225 splits)
-              const double cost = 0.48 * mx + 2.0 * slab_bytes / 4e6 + 0.02 * std::max(s1, std::max(s2a, s3a));
-              if (cost < best) {
-                best = cost;
-                for (int l = 0; l < 3; ++l) for (int n = 0; n < 2; ++n) wsplit[l][n] = sp[l][n];
-              }
+    for (int s1 : cands(rows[0]))
+      for (int s2 : cands(rows[1]))
+        for (int s3 : cands(rows[2])) {
+          std::vector<IgemmProb> pr;
+          double slab_bytes = 0;
+          const int sp[3] = {s1, s2, s3};
+          for (int l = 2; l >= 0; --l) {
+            const int reps = (l == 0 && n_side > 1) ? 1 : 2;
+            const int N = (l == 0 && n_side > 1) ? n_side * cg[l].Cout : cg[l].Cout;
+            for (int n = 0; n < reps; ++n) {
+              pr.push_back(shape(cg[l].K() + 1, N, ft[l].M, sp[l]));
+              slab_bytes += 4.0 * pr.back().M * N * pr.back().split;
             }
+          }
+          pr.insert(pr.end(), light.begin(), light.end());
+          double mx = 0;
+          xcd_order(tile_list(pr, true, 64, 64), pr, 64, 64, &mx);
+          // us: the fullest CU's slabs + the reduction pass: slab bytes written and read back, and its per-thread chain of
+          // load batches, which grows with the largest split (measured 13.5 / 15.0 / 19.3 us at 57 / 86-113 / 225 splits)
+          const double cost = 0.48 * mx + 2.0 * slab_bytes / 4e6 + 0.02 * std::max(s1, std::max(s2, s3));
+          if (cost < best) { best = cost; wsplit[0] = s1; wsplit[1] = s2; wsplit[2] = s3; }
         }
     if (getenv("GRL_PLAN_DUMP"))
-      fprintf(stderr, "grl plan: weight-gradient reduction splits %d / %d,%d / %d,%d (model cost %.1f us)\n", wsplit[0][0], wsplit[1][0],
-              wsplit[1][1], wsplit[2][0], wsplit[2][1], best);
+      fprintf(stderr, "grl plan: weight-gradient reduction splits %d / %d / %d (model cost %.1f us)\n", wsplit[0], wsplit[1], wsplit[2], best);
   }
 
   // tiles a launch of these problems will have, and its workgroup shape (mirrors add_launch; -1: not on igemm2_kernel)
@@ -1263,129 +1242,6 @@ struct grl_ctx {
     }
     return out;
   }
-
-  // ---------------------------------------------------------------- dependent stages in one launch (igemm2_chain_kernel)
-  // Replaces runs of consecutive ops {tags[0], tags[1][, tags[2]]} of `list` by one op whose launch carries the tiles of
-  // all of them, later stages waiting per tile for the earlier tiles that write their operands.  Conditions: every op is a
-  // plain igemm2 launch of the 32x64 / 48 KB shape (three workgroups per CU), the total fits 3 x 256 workgroups -- i.e.
-  // the whole launch is resident at once -- and the instantiation triple is one the kernel is built for.  The
-  // dependencies come from the address ranges: a consumer tile reads rows [i0, i0 + 32) of its (affine, row-major) P
-  // operand; every producer tile whose output rows intersect that range must have finished.  Same tiles, same
-  // arithmetic: results are bit-identical to the separate launches.  A waiting tile cannot keep its producers from running
-  // whatever else shares the machine: workgroups are dispatched in index order, so every producer of a tile was dispatched
-  // before it.
-  // Hand-overs cost no fences: write-through output stores, system-scope operand loads, relaxed counters (igemm2.h,
-  // igemm2_chain_kernel; gate measurement scripts/xcd_handoff_bench.hip: 2.65 us per stage against 6.7 us behind a kernel
-  // boundary).  Round 3 built the same dataflow with agent-scope release / acquire fences and measured it SLOWER (72.1 us
-  // against 18.3 + 17.7 + 8.3 for the forward chain: an L2 write-back + invalidation per hand-over, 11.5 us per stage in
-  // the gate measurement).  GRL_TUNE chain=0 keeps the separate launches.
-  std::map<std::vector<Launch*>, Op> chain_cache;
-  bool chain_ops(std::vector<Op>& list, const std::vector<std::string>& tags) {
-    if (!tune_int("chain", GRL_CHAIN_DEFAULT)) return false;
-    for (size_t k = 0; k + tags.size() <= list.size(); ++k) {
-      bool match = true;
-      for (size_t j = 0; j < tags.size(); ++j) match = match && list[k + j].tag == tags[j] && list[k + j].launch != nullptr;
-      if (!match) continue;
-      std::vector<Launch*> ls;
-      for (size_t j = 0; j < tags.size(); ++j) ls.push_back(list[k + j].launch);
-      auto it = chain_cache.find(ls);
-      if (it == chain_cache.end()) {
-        int total = 0, keys[3] = {-1, -1, -1};
-        bool ok = true;
-        for (size_t j = 0; j < ls.size(); ++j) {
-          Launch* l = ls[j];
-          ok = ok && l->v2 && !l->sk && !l->filler && l->cfg == 3 && (int)l->h_tiles.size() == l->n_tiles;
-          keys[j] = v2_key(l);
-          total += l->n_tiles;
-          if (j > 0)      // consumers: affine P along r (rows of a row-major tensor)
-            ok = ok && l->pm == PM_AFFINE && (l->variant == 0 || l->variant == 1);
-        }
-        const bool fwd3t = ls.size() == 3 && keys[0] == 1030 && keys[1] == 30 && keys[2] == 30 + I2F_KTAIL;
-        const bool fwd3 = fwd3t || (ls.size() == 3 && keys[0] == 1030 && keys[1] == 30 && keys[2] == 30);
-        const bool bwd2 = ls.size() == 2 && keys[0] == 10130 && keys[1] == 10030;
-        ok = ok && total <= 768 && (fwd3 || bwd2);
-        if (!ok) {
-          if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: %s ... not chained (keys %d %d %d, %d tiles)\n", tags[0].c_str(), keys[0], keys[1], keys[2], total);
-          return false;
-        }
-        // ---- counters: one per consumer row group (stage, operand tensor, first row); targets = intersecting producer tiles
-        struct Grp { int stage; const float* base; int i0; long lo, hi; int target; };
-        std::vector<Grp> grps;
-        std::vector<std::vector<int4>> dep(ls.size());
-        for (size_t j = 0; j < ls.size(); ++j) dep[j].assign(ls[j]->n_tiles, make_int4(-1, 0, -1, -1));
-        auto group_of = [&](int stage, const IgemmProb& p, int i0) {
-          for (size_t g = 0; g < grps.size(); ++g)
-            if (grps[g].stage == stage && grps[g].base == p.p_base[0] && grps[g].i0 == i0) return (int)g;
-          const int i1 = std::min(p.M, i0 + 32) - 1;
-          Grp g{stage, p.p_base[0], i0, (long)i0 * p.p_ld_i[0], (long)i1 * p.p_ld_i[0] + p.K, 0};
-          grps.push_back(g);
-          return (int)grps.size() - 1;
-        };
-        for (size_t j = 1; j < ls.size(); ++j)
-          for (int t = 0; t < ls[j]->n_tiles; ++t) {
-            const int4& tl = ls[j]->h_tiles[t];
-            dep[j][t].x = group_of((int)j, ls[j]->probs[tl.x], tl.z * 32);
-          }
-        for (size_t j = 0; j + 1 < ls.size(); ++j)
-          for (int t = 0; t < ls[j]->n_tiles; ++t) {
-            const int4& tl = ls[j]->h_tiles[t];
-            const IgemmProb& p = ls[j]->probs[tl.x];
-            if (p.c_tab_i || p.split != 1 || !(p.vflags & VF_C_VEC)) { ok = false; break; }     // (write-through stores: wide epilogue only)
-            const int r0 = tl.z * 32, r1 = std::min(p.M, r0 + 32) - 1, c0 = tl.w * 64, c1 = std::min(p.N, c0 + 64);
-            int n_sig = 0;
-            for (size_t g = 0; g < grps.size(); ++g) {
-              if (grps[g].stage != (int)j + 1) continue;
-              const long off = p.c - grps[g].base;                       // producer output relative to the consumer's operand
-              const long lo = off + (long)r0 * p.ldc + c0, hi = off + (long)r1 * p.ldc + c1;
-              if (hi <= grps[g].lo || lo >= grps[g].hi) continue;
-              grps[g].target += 1;
-              if (n_sig == 0) dep[j][t].z = (int)g;
-              else if (n_sig == 1) dep[j][t].w = (int)g;
-              else ok = false;
-              ++n_sig;
-            }
-          }
-        for (auto& g : grps) ok = ok && g.target > 0;
-        if (!ok) return false;
-        for (size_t j = 1; j < ls.size(); ++j)
-          for (auto& d : dep[j]) d.y = grps[d.x].target;
-        ChainArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        for (size_t j = 0; j < ls.size(); ++j) {
-          ca.p[j] = ls[j]->d_probs; ca.t[j] = ls[j]->d_tiles; ca.n[j] = ls[j]->n_tiles;
-          ca.dep[j] = upload_vec(wk, dep[j]);
-        }
-        ca.n_cnt = (int)grps.size();
-        ca.cnt = (int*)wk.take((size_t)(ca.n_cnt + 2) * 4);
-        zero_once.push_back({ca.cnt, (size_t)(ca.n_cnt + 2) * 4});
-        chain_err.push_back(ca.cnt + ca.n_cnt + 1);
-        Op op;
-        op.tag = tags[0];
-        for (size_t j = 1; j < tags.size(); ++j) op.tag += "+" + tags[j];
-        for (size_t j = 0; j < tags.size(); ++j) { op.flops += list[k + j].flops; op.flops_exec += list[k + j].flops_exec; }
-        const int n_all = total;
-        const int kind = fwd3 ? (fwd3t ? CHAIN_FWD3_KTAIL : CHAIN_FWD3) : CHAIN_BWD2;
-        op.run = [ca, n_all, kind](hipStream_t s) { launch_igemm2_chain(kind, ca, n_all, s); };
-        if (getenv("GRL_PLAN_DUMP"))
-        {
-          fprintf(stderr, "grl plan: %-14s one launch of %d dependent tiles (%zu stages, %zu row-group counters; producers per group:", op.tag.c_str(),
-                  n_all, ls.size(), grps.size());
-          for (size_t j = 1; j < ls.size(); ++j) {
-            int lo = 1 << 30, hi = 0;
-            for (auto& g : grps) if (g.stage == (int)j) { lo = std::min(lo, g.target); hi = std::max(hi, g.target); }
-            fprintf(stderr, " stage %zu %d..%d", j, lo, hi);
-          }
-          fprintf(stderr, ")\n");
-        }
-        it = chain_cache.emplace(ls, op).first;
-      }
-      list.erase(list.begin() + k, list.begin() + k + tags.size());
-      list.insert(list.begin() + k, it->second);
-      return true;
-    }
-    return false;
-  }
-  std::vector<int*> chain_err;     // error flags of the chained launches (a bounded wait ran out): checked by grl_get_metrics
 
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
   // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors

@@ -29,7 +29,7 @@ namespace grl {
 
 enum { I2_P_ALONG_R = 0, I2_P_ALONG_I = 1 };
 enum { I2_Q_ALONG_R = 0, I2_Q_ALONG_J = 1 };
-enum { I2F_ONES = 1, I2F_KTAIL = 2, I2F_WT = 4, I2F_PSYS = 8 };
+enum { I2F_ONES = 1, I2F_KTAIL = 2 };
 
 template <int CFG> struct I2Cfg;
 template <> struct I2Cfg<0> { static constexpr int BM = 64, BN = 64, WM = 2, WN = 2, WK = 1, FM = 1, FN = 1; };
@@ -63,21 +63,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t i2_rsrc(const float* p) {
 __device__ __forceinline__ f32x4 i2_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
 }
-// system-scope forms (sc0 | sc1): a load served from memory, never from a stale cache line; a store that is written
-// through -- what a tile uses for an operand another workgroup of the SAME launch produces / consumes (igemm2_chain_kernel)
-enum { I2_SYS = 1 | 16 };
-__device__ __forceinline__ f32x4 i2_ld_sys(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, I2_SYS));
-}
-__device__ __forceinline__ void i2_st_sys(__amdgpu_buffer_rsrc_t rs, int byte_off, f32x4 v) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, byte_off, 0, I2_SYS);
-}
 
 // FLAGS: I2F_ONES  -- the problems carry a bias-gradient ones row (p_ones_i == M-1), Q along j, WK == 1
 //        I2F_KTAIL -- K % 4 != 0 (affine operands along r): elements past r_end are zeroed one by one
-//        I2F_WT    -- the output tile leaves as write-through stores (wide epilogue only): consumed by tiles of the same launch
-//        I2F_PSYS  -- the P operand is loaded at system scope: produced by tiles of the same launch
 // LDS floats one tile of an instantiation needs
 template <int PL, int QL, int CFG>
 struct I2Lds {
@@ -117,7 +105,6 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   using C = I2Cfg<CFG>;
   constexpr int BM = C::BM, BN = C::BN, WK = C::WK, FM = C::FM, FN = C::FN, WN = C::WN, WM = C::WM;
   constexpr bool ONES = (FLAGS & I2F_ONES) != 0, KTAIL = (FLAGS & I2F_KTAIL) != 0;
-  constexpr bool WT = (FLAGS & I2F_WT) != 0, PSYS = (FLAGS & I2F_PSYS) != 0;
   constexpr int BKT = 32 * WK;                 // reduction depth staged per barrier
   // Row strides of the two layouts of an operand.  K-contiguous rows (operand along r) are NOT padded: the 16-byte
   // chunks of a row are XOR-swizzled with row bits instead (i2_swz), which keeps the four ds_read_b128 per slab
@@ -256,13 +243,13 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
       bool ok = r < r_end && p_fok[e];
       if (PM == PM_TABLE_MASK) ok = ok && ((p_vm[e] >> tb.tap) & 1ull);
       const int colterm = PM != PM_AFFINE ? tb.p[0] : r;
-      pv[e] = PSYS ? i2_ld_sys(rsP, ok ? (p_fix[e] + colterm) * 4 : I2_OOB) : i2_ld(rsP, ok ? (p_fix[e] + colterm) * 4 : I2_OOB);
+      pv[e] = i2_ld(rsP, ok ? (p_fix[e] + colterm) * 4 : I2_OOB);
       if (KTAIL && e == 0) p_kb = r + 4 <= r_end ? 0xfu : (0xfu >> min(4, max(0, r + 4 - r_end)));
     } else {
       const int r = r0 + p_l + e * PSTEP;
       const bool ok = r < r_end && p_fok[0];
       const int colterm = PM != PM_AFFINE ? tb.p[e] : r * pLr;
-      pv[e] = PSYS ? i2_ld_sys(rsP, ok ? (p_fix[0] + colterm) * 4 : I2_OOB) : i2_ld(rsP, ok ? (p_fix[0] + colterm) * 4 : I2_OOB);
+      pv[e] = i2_ld(rsP, ok ? (p_fix[0] + colterm) * 4 : I2_OOB);
     }
   };
   auto load_q = [&](int r0, int e, f32x4 (&qv)[NVQ], unsigned& q_kb, const Tabs& tb) {
@@ -579,10 +566,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
       }
       v.x = mk[e].x > 0.f ? v.x : alpha * v.x; v.y = mk[e].y > 0.f ? v.y : alpha * v.y;
       v.z = mk[e].z > 0.f ? v.z : alpha * v.z; v.w = mk[e].w > 0.f ? v.w : alpha * v.w;
-      if (ok[e]) {
-        if (WT) i2_st_sys(i2_rsrc((const float*)cbase), (int)(off[e] << 2), v);
-        else *(GRL_GLOBAL f32x4*)(cbase + off[e]) = v;
-      }
+      if (ok[e]) *(GRL_GLOBAL f32x4*)(cbase + off[e]) = v;
     }
   };
 
@@ -723,92 +707,6 @@ __global__ __launch_bounds__(256) void igemm2_pair_kernel(const IgemmProb* __res
 }
 
 #endif  // GRL_HOSTEMU
-#endif  // GRL_GEMM_TYPES_ONLY
-
-// ------------------------------------------------------------------------------------------------------------------
-// Up to three DEPENDENT stages in one launch (engine.hip, chain_ops): blocks [0, n0) run stage 0, the next n1 stage 1,
-// the next n2 stage 2 -- each stage its own instantiation -- and a tile of stage s + 1 waits, before it touches its
-// operands, until the stage-s tiles that write them have finished (a counter per consumer row group).  ALL workgroups of
-// the launch are resident at once (the host only chains launches whose tiles fit: <= 3 x 256 workgroups of the 48 KB
-// shape) and workgroups are dispatched in index order, so a waiting tile can never keep its producers from running; the
-// wait is bounded all the same (a time-out raises cnt[n_cnt + 1], read by the host).
-// Hand-over (round 4; scripts/xcd_handoff_bench.hip is the gate measurement): the producer's output tile leaves as
-// WRITE-THROUGH stores (I2F_WT), every wave drains them (s_waitcnt vmcnt(0)), the block's barrier, one relaxed counter
-// increment; the consumer polls the counter with relaxed loads from one lane and reads the operand at SYSTEM scope
-// (I2F_PSYS) -- no release / acquire fence anywhere.  Measured per hand-over of a 32 KB tile with all 256 CUs doing it:
-// 2.65 us per stage of work + hand-over against 6.7 us for the same work behind a kernel boundary of a hipGraph, and
-// 11.5 us with agent-scope fences (an L2 write-back + invalidation per hand-over: the form round 3 built and rejected).
-// The last workgroup to finish zeroes the counters for the next launch (graph replay).
-struct ChainArgs {
-  const IgemmProb* p[3];
-  const int4* t[3];
-  const int4* dep[3];     // per tile {counter to wait on (-1: none), its target, counter to signal (-1: none), second counter to signal}
-  int n[3];
-  int* cnt;               // [n_cnt] dependency counters, [n_cnt] finished workgroups, [n_cnt + 1] error flag
-  int n_cnt;
-};
-enum { CHAIN_SPIN_LIMIT = 1 << 21 };
-
-#ifndef GRL_GEMM_TYPES_ONLY
-#ifdef GRL_HOSTEMU
-// TEST-ONLY sequential form: blocks run in index order, producers first, so every wait is already satisfied
-template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb,
-          int PLc, int QLc, int PMc, int QMc, int CFGc, int FLc>
-void igemm2_chain_kernel(ChainArgs a) {
-  const int b = (int)blockIdx.x;
-  const int kind = b < a.n[0] ? 0 : (b < a.n[0] + a.n[1] ? 1 : 2);
-  const int k = b - (kind == 0 ? 0 : (kind == 1 ? a.n[0] : a.n[0] + a.n[1]));
-  const int4 d = a.dep[kind][k];
-  if (d.x >= 0 && a.cnt[d.x] < d.y) abort();
-  if (kind == 0) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa & 3>(a.p[0] + k, a.t[0][k]);
-  else if (kind == 1) igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb & 3>(a.p[1] + k, a.t[1][k]);
-  else igemm2_tile<PLc, QLc, PMc, QMc, CFGc, FLc & 3>(a.p[2] + k, a.t[2][k]);
-  if (threadIdx.x != 255) return;            // (the emulated "threads" of a block run one after the other: signal after the last)
-  if (d.z >= 0) a.cnt[d.z] += 1;
-  if (d.w >= 0) a.cnt[d.w] += 1;
-  if (++a.cnt[a.n_cnt] == (int)gridDim.x)
-    for (int i = 0; i <= a.n_cnt; ++i) a.cnt[i] = 0;
-}
-#else
-template <int PLa, int QLa, int PMa, int QMa, int CFGa, int FLa, int PLb, int QLb, int PMb, int QMb, int CFGb, int FLb,
-          int PLc, int QLc, int PMc, int QMc, int CFGc, int FLc>
-__global__ __launch_bounds__(256) void igemm2_chain_kernel(ChainArgs a) {
-  constexpr int LA = I2Lds<PLa, QLa, CFGa>::value, LB = I2Lds<PLb, QLb, CFGb>::value, LC = I2Lds<PLc, QLc, CFGc>::value;
-  __shared__ __attribute__((aligned(16))) float lds[(LA > LB ? LA : LB) > LC ? (LA > LB ? LA : LB) : LC];
-  const int b = (int)blockIdx.x;
-  const int kind = b < a.n[0] ? 0 : (b < a.n[0] + a.n[1] ? 1 : 2);
-  const int k = b - (kind == 0 ? 0 : (kind == 1 ? a.n[0] : a.n[0] + a.n[1]));
-  const int4 d = a.dep[kind][k];
-#ifdef GRL_TILE_TRACE
-  const unsigned long long t0 = wall_clock64();
-#endif
-  if (d.x >= 0) {
-    if (threadIdx.x == 0) {      // one lane polls, relaxed; the operand loads that follow bypass the caches (I2F_PSYS)
-      int spins = 0;
-      while (__hip_atomic_load(a.cnt + d.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.y) {
-        if (++spins > CHAIN_SPIN_LIMIT) { a.cnt[a.n_cnt + 1] = 1; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
-    __syncthreads();
-  }
-  if (kind == 0) igemm2_tile<PLa, QLa, PMa, QMa, CFGa, FLa>(a.p[0] + k, a.t[0][k], lds);
-  else if (kind == 1) igemm2_tile<PLb, QLb, PMb, QMb, CFGb, FLb>(a.p[1] + k, a.t[1][k], lds);
-  else igemm2_tile<PLc, QLc, PMc, QMc, CFGc, FLc>(a.p[2] + k, a.t[2][k], lds);
-#ifdef GRL_TILE_TRACE
-  i2_trace_record(a.p[kind] + k, a.t[kind][k], t0, kind == 0 ? CFGa : (kind == 1 ? CFGb : CFGc));
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have reached memory ...
-  __syncthreads();                                    // ... and those of every wave of the tile
-  if (threadIdx.x == 0) {
-    if (d.z >= 0) __hip_atomic_fetch_add(a.cnt + d.z, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d.w >= 0) __hip_atomic_fetch_add(a.cnt + d.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int done = __hip_atomic_fetch_add(a.cnt + a.n_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (int)gridDim.x - 1)
-      for (int i = 0; i <= a.n_cnt; ++i) __hip_atomic_store(a.cnt + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every workgroup has passed its wait
-  }
-}
-#endif
 #endif  // GRL_GEMM_TYPES_ONLY
 
 }  // namespace grl

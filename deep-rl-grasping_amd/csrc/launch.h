@@ -4,7 +4,6 @@
 //   gemm_fwd.hip    igemm2_kernel with P along the reduction, Q along the output columns (forward products), igemm_sk_kernel
 //   gemm_bwd.hip    igemm2_kernel with both operands along the reduction (backward-data), igemm2_pair_kernel
 //   gemm_wgrad.hip  igemm2_kernel with P along the output rows (weight gradients), the scalar-gather igemm_kernel
-//   gemm_chain.hip  igemm2_chain_kernel: dependent stages in one launch
 //   heads.hip       heads_fused_kernel (MFMA), the VALU head chains, the DQN / BDQ tower chains
 // so that the four compile side by side (the single translation unit of round 3 took 62 s).
 #pragma once
@@ -23,10 +22,6 @@ void launch_igemm2_wgrad(int key, int n_tiles, hipStream_t s, const IgemmProb* p
 // a backward-data stage (key ka, n_a tiles) carrying n_b weight-gradient tiles (key 21001) behind its own
 void launch_igemm2_pair(int ka, int n_a, int n_b, hipStream_t s, const IgemmProb* pa, const int4* ta, const IgemmProb* pb, const int4* tb,
                         const char* tag);
-// up to three dependent stages in one launch (igemm2_chain_kernel; engine.hip chain_ops): conv3_fwd -> fc_fwd -> heads_l0
-// (the last with or without a reduction tail) and heads_dfeat -> fc_bwd
-enum { CHAIN_FWD3 = 0, CHAIN_FWD3_KTAIL = 1, CHAIN_BWD2 = 2 };
-void launch_igemm2_chain(int kind, const ChainArgs& ca, int n_blocks, hipStream_t s);
 // scalar-gather fallback: key = np * 1000 + pm * 100 + qm * 10 + variant
 void launch_igemm(int key, int n_tiles, hipStream_t s, const IgemmProb* probs, const int4* tiles, const char* tag);
 void launch_igemm_sk(int K, int n_tiles, hipStream_t s, const IgemmProb* probs, const int4* work);

@@ -109,7 +109,15 @@ int grl_ctx::plan_q() {
   };
   QNetAct net[3], gact, aact;           // online(s), online(s'), target(s'); gradients; act path
   for (int n = 0; n < 3; ++n) alloc_net(net[n], B);
-  alloc_net(gact, B);                   // same shapes: gradient w.r.t. each pre-activation
+  alloc_net(gact, B);                   // same shapes: gradient w.r.t. each pre-activation ...
+  // ... except the output gradients, which the weight-gradient GEMM fetches 16 bytes at a time: every branch's bins start
+  // 16-byte aligned (nbp floats apart), the value gradient has a row stride of 4; the padding stays zero
+  const int nbp = (int)rup(nb, 4), ld_dv = 4;
+  gact.adv = wk.f32((int64_t)B * D * nbp);
+  gact.v = wk.f32((int64_t)B * ld_dv);
+  zero_once.push_back({gact.adv, (size_t)B * D * nbp * 4});
+  zero_once.push_back({gact.v, (size_t)B * ld_dv * 4});
+  for (int n = 0; n < 3; ++n) zero_once.push_back({feat[n], (size_t)B * ldf * 4});   // (row padding [F, ldf) is read by 16-byte loads)
   q_td = wk.f32((int64_t)B * D); q_prio = wk.f32(B);
   const float* P = params;
   const int hdim = Lc > 0 ? c.q_common[Lc - 1] : c.obs_dim;
@@ -305,7 +313,7 @@ int grl_ctx::plan_q() {
     qf.fwd = upload_vec(wk, hf);
     qf.bwd_tw = upload_vec(wk, hb);
     qf.B = B; qf.D = D; qf.nb = nb; qf.Ht = Lc > 0 ? c.q_common[Lc - 1] : 0;
-    qf.d_adv = gact.adv; qf.d_v = gact.v; qf.trunk_scale = c.q_trunk_scale;
+    qf.d_adv = gact.adv; qf.d_v = gact.v; qf.nbp = nbp; qf.ld_dv = ld_dv; qf.trunk_scale = c.q_trunk_scale;
     if (Lc > 0) {
       HtHead h;
       memset(&h, 0, sizeof(h));
@@ -337,7 +345,7 @@ int grl_ctx::plan_q() {
     qa.B = B; qa.D = D; qa.n = nb; qa.gamma = c.gamma; qa.lr = c.lr; qa.huber = c.q_huber; qa.double_q = c.q_double;
     qa.adv0 = net[0].adv; qa.v0 = net[0].v; qa.adv1 = net[1].adv; qa.adv2 = net[2].adv; qa.v2 = net[2].v;
     qa.act = act; qa.rew = rew; qa.done = done; qa.weights = eps_buf;
-    qa.d_adv0 = gact.adv; qa.d_v0 = gact.v; qa.td = q_td; qa.priority = q_prio; qa.sc = sc;
+    qa.d_adv0 = gact.adv; qa.d_v0 = gact.v; qa.nbp = nbp; qa.ld_dv = ld_dv; qa.td = q_td; qa.priority = q_prio; qa.sc = sc;
     qa.row_part = wk.f32(3 * (int64_t)B);
     qa.counter = (unsigned*)wk.take(16);
     qa.defer_finish = 0;
@@ -373,9 +381,9 @@ int grl_ctx::plan_q() {
     } else {
       std::vector<IgemmProb> pr;      // output layers -> last hidden
       for (int br = 0; br < D; ++br)
-        pr.push_back(dense_bwd({{gact.adv + br * nb, D * nb, nb, P + Pon.bw[br][Lb]}}, B, 0, c.q_branch[Lb - 1],
+        pr.push_back(dense_bwd({{gact.adv + br * nbp, D * nbp, nb, P + Pon.bw[br][Lb]}}, B, 0, c.q_branch[Lb - 1],
                                gact.zb[br][Lb - 1], c.q_branch[Lb - 1], a.zb[br][Lb - 1]));
-      pr.push_back(dense_bwd({{gact.v, 1, 1, P + Pon.vw[Lv]}}, B, 0, c.q_value[Lv - 1], gact.zv[Lv - 1], c.q_value[Lv - 1],
+      pr.push_back(dense_bwd({{gact.v, ld_dv, 1, P + Pon.vw[Lv]}}, B, 0, c.q_value[Lv - 1], gact.zv[Lv - 1], c.q_value[Lv - 1],
                              a.zv[Lv - 1]));
       add_launch(ops_grads, "q_bwd", 1, pr);
       for (int l = std::max(Lb, Lv) - 1; l >= 1; --l) {
@@ -409,8 +417,10 @@ int grl_ctx::plan_q() {
     }
     // weight gradients
     std::vector<IgemmProb> wg;
+    // (inputs whose rows are padded to a multiple of 4 floats -- the observations, ldf -- carry the padding columns along:
+    //  every problem then fits the vectorised weight-gradient kernel; their slab rows are never reduced)
     auto wgrad = [&](const float* x, int ldx, int kin, const float* g, int ldg, int n, int64_t woff, int64_t boff) {
-      IgemmProb p = dense_wgrad(x, ldx, kin, true, g, ldg, n, B, nullptr, 1);
+      IgemmProb p = dense_wgrad(x, ldx, kin, true, g, ldg, n, B, nullptr, 1, ldx >= (int)rup(kin, 4) ? (int)rup(kin, 4) : kin);
       p.c = wk.f32(p.slab_stride * p.split);
       add_wgrad(wg, p, woff, 0, kin, boff);
     };
@@ -425,14 +435,14 @@ int grl_ctx::plan_q() {
         wgrad(z, ldz, kz, gact.zb[br][l], c.q_branch[l], c.q_branch[l], Pon.bw[br][l], Pon.bb[br][l]);
         z = a.zb[br][l]; ldz = kz = c.q_branch[l];
       }
-      wgrad(z, ldz, kz, gact.adv + br * nb, D * nb, nb, Pon.bw[br][Lb], Pon.bb[br][Lb]);
+      wgrad(z, ldz, kz, gact.adv + br * nbp, D * nbp, nb, Pon.bw[br][Lb], Pon.bb[br][Lb]);
     }
     const float* z = in; int ldz = ldin, kz = kin;
     for (int l = 0; l < Lv; ++l) {
       wgrad(z, ldz, kz, gact.zv[l], c.q_value[l], c.q_value[l], Pon.vw[l], Pon.vb[l]);
       z = a.zv[l]; ldz = kz = c.q_value[l];
     }
-    wgrad(z, ldz, kz, gact.v, 1, 1, Pon.vw[Lv], Pon.vb[Lv]);
+    wgrad(z, ldz, kz, gact.v, ld_dv, 1, Pon.vw[Lv], Pon.vb[Lv]);
     add_launch(ops_grads, "q_wgrad", 2, wg);
   }
   {

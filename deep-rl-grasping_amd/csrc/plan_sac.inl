@@ -512,15 +512,11 @@ int grl_ctx::plan_sac() {
       const int t3 = planned_tiles(bwd_pr[1], 1, "conv3_bwd", &cfg3);
       rider_budget = cfg3 == 3 ? free_slots(t3, 3) : 0;
     }
-    int wsplit[3][2] = {{72, 72}, {12, 12}, {6, 6}};   // reduction splits of conv1..3 per network (GRL_TUNE wg_split=a/b/c overrides the model's choice)
+    int wsplit[3] = {72, 12, 6};   // reduction splits of conv1..3 (GRL_TUNE wg_split=a/b/c overrides the model's choice)
     pick_wgrad_splits(cg, ft, 2, wsplit, rider_budget);
-    {
-      int forced[3] = {0, 0, 0};
-      if (tune_int3("wg_split", forced) == 3)
-        for (int l = 0; l < 3; ++l) wsplit[l][0] = wsplit[l][1] = forced[l];
-    }
+    tune_int3("wg_split", wsplit);
     {   // conv1 of both networks: one problem over the side-by-side gradient buffer, columns 32n.. -> net n
-      IgemmProb p = conv_wgrad(x_obs, ft[0], cg[0], g1[0], nullptr, wsplit[0][0], 2);
+      IgemmProb p = conv_wgrad(x_obs, ft[0], cg[0], g1[0], nullptr, wsplit[0], 2);
       p.c = wk.f32(p.slab_stride * p.split);
       wgc[0].push_back(p);
       for (int n = 0; n < 2; ++n) {
@@ -536,12 +532,12 @@ int grl_ctx::plan_sac() {
     }
     for (int n = 0; n < 2; ++n) {
       {
-        IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, wsplit[1][n]);
+        IgemmProb p = conv_wgrad(a1[n], ft[1], cg[1], g2[n], nullptr, wsplit[1]);
         p.c = wk.f32(p.slab_stride * p.split);
         add_wgrad(wgc[1], p, ex[n].w[1], 0, cg[1].K(), ex[n].b[1]);
       }
       {
-        IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, wsplit[2][n]);
+        IgemmProb p = conv_wgrad(a2[n], ft[2], cg[2], g3[n], nullptr, wsplit[2]);
         p.c = wk.f32(p.slab_stride * p.split);
         add_wgrad(wgc[2], p, ex[n].w[2], 0, cg[2].K(), ex[n].b[2]);
       }
@@ -780,14 +776,6 @@ int grl_ctx::plan_sac() {
         prefetch_ok = true;
       }
     }
-  }
-
-  // ---- dependent stages as one launch (igemm2_chain_kernel, engine.hip chain_ops): conv3_fwd -> fc_fwd -> heads_l0 and
-  // heads_dfeat -> fc_bwd.  Applied to the lists of full updates (the staged data-parallel lists keep their launches).
-  for (std::vector<Op>* lst : {&ops_grads, &ops_grads_apply, &ops_pf_first, &ops_pf_mid, &ops_pf_last}) {
-    if (lst->empty()) continue;
-    chain_ops(*lst, {"conv3_fwd", "fc_fwd", "heads_l0"});
-    chain_ops(*lst, {"heads_dfeat", "fc_bwd"});
   }
 
   // =============================================================== apply

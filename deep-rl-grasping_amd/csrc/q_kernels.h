@@ -23,7 +23,8 @@ struct QFusedArgs {
   const HtHead* bwd_tw;   // [D+1]: towers of online(s); with a trunk its output is the head's `xa` input
   const HtHead* bwd_tr;   // trunk of online(s), or nullptr
   int B, D, nb, Ht;       // rows, branches, bins per branch, trunk output width (0: no trunk)
-  const float* d_adv; const float* d_v;   // loss gradients [B, D*nb], [B]
+  const float* d_adv; const float* d_v;   // loss gradients [B, D*nbp], [B] with stride ld_dv (QLossArgs)
+  int nbp, ld_dv;
   float* dh_part;         // [D+1][B, Ht]: gradient w.r.t. the trunk output, one partial per tower
   float trunk_scale;
 };
@@ -45,9 +46,9 @@ __global__ __launch_bounds__(256) void q_bwd_towers_kernel(QFusedArgs a) {
   const int r = t & (HT_RB - 1), row = row0 + r;
   if (tw < a.D) {
     for (int o = t / HT_RB; o < a.nb; o += 256 / HT_RB)
-      s.oT[o][r] = row < a.B ? a.d_adv[((long)row * a.D + tw) * a.nb + o] : 0.f;
+      s.oT[o][r] = row < a.B ? a.d_adv[((long)row * a.D + tw) * a.nbp + o] : 0.f;
   } else if (t < HT_RB) {
-    s.oT[0][r] = row < a.B ? a.d_v[row] : 0.f;
+    s.oT[0][r] = row < a.B ? a.d_v[(long)row * a.ld_dv] : 0.f;
   }
   __syncthreads();
   ht_bwd_head(h, row0, a.B, s, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht);

@@ -7,10 +7,12 @@ for p in (ROOT, os.path.join(ROOT, "deep-rl-grasping_amd")):
 
 def main():
     from grasp_rl import synthetic
-    synthetic.learn_loop_rate(16, 50, 20, overlap=True, device="cuda:0")   # warm
+    overlap = "--strict" not in sys.argv
+    dn = "--device-norm" in sys.argv
+    synthetic.learn_loop_rate(16, 50, 20, overlap=overlap, device="cuda:0", device_norm=dn)   # warm
     pr = cProfile.Profile()
     pr.enable()
-    r = synthetic.learn_loop_rate(16, 300, 20, overlap=True, device="cuda:0")
+    r = synthetic.learn_loop_rate(16, 300, 20, overlap=overlap, device="cuda:0", device_norm=dn)
     pr.disable()
     print(r)
     s = io.StringIO()

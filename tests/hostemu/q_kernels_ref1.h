@@ -14,8 +14,8 @@ inline void q_bwd_towers_kernel(QFusedArgs a) {
   for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row) {
     float dv[2 * HT_MAXA];
     if (tw < a.D)
-      for (int o = 0; o < a.nb; ++o) dv[o] = a.d_adv[((long)row * a.D + tw) * a.nb + o];
-    else dv[0] = a.d_v[row];
+      for (int o = 0; o < a.nb; ++o) dv[o] = a.d_adv[((long)row * a.D + tw) * a.nbp + o];
+    else dv[0] = a.d_v[(long)row * a.ld_dv];
     ht_ref_bwd_head(h, row, dv, h.n_xa ? a.dh_part + ((long)tw * a.B + row) * a.Ht : nullptr);
   }
 }

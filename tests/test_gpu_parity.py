@@ -155,26 +155,6 @@ def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
         assert np.array_equal(outs[0][n], outs[1][n]), n
 
 
-def test_dependent_stage_launches_are_bit_identical_at_full_batch(monkeypatch):
-    """conv3_fwd -> fc_fwd -> heads_l0 and heads_dfeat -> fc_bwd as single launches whose tiles wait for their producers
-    (igemm2.h: igemm2_chain_kernel -- write-through hand-overs, no fences; 696 and 384 workgroups on all 8 XCDs at B = 256):
-    40 updates in 2-update calls (graph replay, counters re-armed by the kernel) leave bit-identical parameters, and no
-    wait timed out."""
-    case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=600, n_steps=40)
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("GRL_TUNE", "chain=" + flag)
-        eng = pu.engine_setup(case)
-        for s in range(0, 40, 2):
-            eng.train(2, case["idx"][s:s + 2], case["eps"][s:s + 2])
-        eng.train_device(34)
-        eng.metrics()          # raises if a bounded wait ran out
-        outs.append(eng.get_parameters())
-        eng.close()
-    for n in outs[0]:
-        assert np.array_equal(outs[0][n], outs[1][n]), n
-
-
 @pytest.mark.parametrize("kind", ["sac_cnn", "sac_mlp"])
 def test_updates_grouped_into_one_graph_are_bit_identical(monkeypatch, kind):
     """Calls of several updates on the device RNG send their identical updates out in groups of up to 16 per hipGraph

@@ -226,19 +226,3 @@ def test_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib, mo
     Pa, Pb = a.get_parameters(), b.get_parameters()
     assert all(np.array_equal(Pa[k], Pb[k]) for k in Pa)
     a.close(); b.close()
-
-
-def test_dependent_stage_launches_cover_their_producers(hostemu_lib, monkeypatch):
-    """conv3_fwd -> fc_fwd -> heads_l0 and heads_dfeat -> fc_bwd as one launch each (engine.hip: chain_ops; GRL_TUNE chain=1):
-    the emulated kernel runs the tiles in index order and aborts if a tile starts before the count of producer tiles the host
-    derived for its operand rows -- and the host derivation must name every producer, or results would differ from separate
-    launches."""
-    case = pu.make_case(extractor="augmented", kind="depth", B=70, n_replay=200, n_steps=2)
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("GRL_TUNE", "chain=" + flag)
-        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
-        eng.train(2, case["idx"], case["eps"])
-        outs.append(eng.get_parameters())
-        eng.close()
-    assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
