@@ -178,8 +178,10 @@ def roofline_of(prof, n, dt_step, workload):
         tr = pmc_traffic(dom, workload)
         if tr:
             roof["traffic"], roof["traffic_unit"], roof["traffic_source"] = tr[0], "bytes/launch", tr[1]
-        gr = graph_trace_avg(dom, workload)
-        if gr:
+        gr = graph_trace_avg(dom, workload, live_value=1.0 / dt_step if dt_step else None)
+        if gr[0] is None and gr[1]:
+            roof["graph_source_refused"] = gr[1]
+        if gr[0] is not None:
             roof["graph_avg_launch_ms"] = round(gr[0], 5)
             roof["frac_graph"] = round(d["flops"] / (gr[0] * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)
             roof["graph_source"] = gr[1]
@@ -210,23 +212,29 @@ def roofline_of(prof, n, dt_step, workload):
     return roof
 
 
-def graph_trace_avg(tag, workload="sac_depth"):
+def graph_trace_avg(tag, workload="sac_depth", live_value=None):
     """Average duration (ms) of launch `tag` under hipGraph replay, from the newest committed rocprofv3 kernel-trace
     summary of this workload (`profiles/rNN_rocprofv3_summary_<workload>.txt`, written by scripts/profile_round.sh
-    from `rocprofv3 --kernel-trace --stats -- python bench.py ...`; lines `launch <tag> calls <n> avg <us> us`)."""
+    from `rocprofv3 --kernel-trace --stats -- python bench.py ...`; lines `launch <tag> calls <n> avg <us> us`).
+    A summary goes stale silently when a kernel changes: the file carries the bench line of its own (profiled) run, and a
+    file whose recorded `value` is more than 5 % away from THIS run's is refused (returns (None, reason))."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary_%s.txt" % workload)))
     for f in reversed(files):
         try:
-            with open(f) as fh:
-                for line in fh:
-                    m = re.match(r"launch\s+(\S+)\s+calls\s+(\d+)\s+avg\s+([0-9.]+)\s+us", line)
-                    if m and m.group(1) == tag:
-                        return float(m.group(3)) * 1e-3, "profiles/" + os.path.basename(f)
+            text = open(f).read()
         except OSError:
             continue
-    return None
+        rec = re.search(r'"value":\s*([0-9.]+)', text)
+        if live_value and rec and abs(float(rec.group(1)) - live_value) > 0.05 * live_value:
+            return None, "profiles/%s refused: recorded value %.1f is more than 5 %% from this run's %.1f" % (
+                os.path.basename(f), float(rec.group(1)), live_value)
+        for line in text.splitlines():
+            m = re.match(r"launch\s+(\S+)\s+calls\s+(\d+)\s+avg\s+([0-9.]+)\s+us", line)
+            if m and m.group(1) == tag:
+                return float(m.group(3)) * 1e-3, "profiles/" + os.path.basename(f)
+    return None, None
 
 
 def pmc_traffic(tag, workload="sac_depth"):

@@ -35,6 +35,27 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 DATA = os.path.join(ROOT, "deep-rl-grasping_amd", "grasp_rl", "data")
 
 
+def ent_coef_log_pin():
+    """B.7: the first rows of trained_models/SAC_depth_1mbuffer/logs.csv (the training log of the reference's own depth-SAC run:
+    total_timesteps, ent_coef, current_lr, entropy, ...).  SAC starts updating after learning_starts = 100 env steps with
+    one update per step; the entropy coefficient is exp(log_ent_coef), log_ent_coef starts at 0 and takes one Adam step per
+    update -- while the gradient keeps its sign (entropy far above the target) every step is ~lr, so the logged value at
+    step T is exp(-lr (T - 100)): a relationship that holds only for THIS parametrisation, sign and update schedule."""
+    import csv
+    rows = []
+    with open(REF + "/trained_models/SAC_depth_1mbuffer/logs.csv") as f:
+        for k, r in enumerate(csv.DictReader(f)):
+            rows.append({"total_timesteps": int(float(r["total_timesteps"])), "ent_coef": float(r["ent_coef"]),
+                         "current_lr": float(r["current_lr"]), "entropy": float(r["entropy"]), "ent_coef_loss": float(r["ent_coef_loss"])})
+            if k >= 3:
+                break
+    import yaml
+    cfg = yaml.safe_load(open(REF + "/trained_models/SAC_depth_1mbuffer/config.yaml"))
+    return {"source": "trained_models/SAC_depth_1mbuffer/logs.csv (first rows) + config.yaml", "rows": rows,
+            "learning_rate": float(cfg["SAC"]["learning_rate"]) if "learning_rate" in cfg.get("SAC", {}) else rows[0]["current_lr"],
+            "learning_starts": 100, "action_dim": 5}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(DATA, exist_ok=True)
@@ -200,6 +221,8 @@ def main():
     bm = np.asarray(qv).mean(axis=2)
     assert np.allclose(bm, bm[:, :1], atol=1e-4), bm
     pins["bdq_real_obs"]["branch_means_of_Q"] = bm.tolist()
+
+    pins["b7_ent_coef_log"] = ent_coef_log_pin()
 
     with open(GOLD + "/oracle_pins.json", "w") as f:
         json.dump(pins, f, indent=1, sort_keys=True)

@@ -149,6 +149,17 @@ def test_200_update_trajectory_follows_the_oracle():
     print("worst device deviation over 200 updates:", {k: round(v, 5) for k, v in worst.items()})
 
 
+def test_50_update_trajectory_at_the_headline_batch():
+    """The same twin-oracle yardstick at BASELINE configs[1]'s batch (B = 256): 50 updates on identical index / noise streams."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=1024, n_steps=50, seed=6)
+    eng = pu.engine_setup(case)
+    try:
+        worst, table = trajectory_check(case, eng, 50, every=10)
+    finally:
+        eng.close()
+    print("worst device deviation over 50 updates at B = 256:", {k: round(v, 5) for k, v in worst.items()})
+
+
 def test_20000_update_soak_on_the_device_rng():
     """20 000 updates with device-drawn indices and noise: every metric finite, the entropy coefficient and the
     Polyak target alive, and the replay indices the device draws uniform over the ring (chi-square)."""

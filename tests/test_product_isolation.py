@@ -59,3 +59,22 @@ def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
     for n in top:
         mod = n.module if isinstance(n, ast.ImportFrom) else n.names[0].name
         assert (mod or "").split(".")[0] != "oracle"
+
+
+def test_bench_refuses_a_profile_summary_of_a_different_kernel_generation(tmp_path, monkeypatch):
+    """`frac_graph` quotes a COMMITTED rocprofv3 summary; one recorded at a throughput more than 5 % from the live run's
+    describes other kernels and must not be quoted."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r09_rocprofv3_summary_sac_depth.txt").write_text(
+        '{"metric": "m", "value": 5000.0, "unit": "grad-steps/s"}\n'
+        "launch wgrad_conv       calls   110 avg    30.00 us  min   28.84  total    3300.0 us\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    ms, src = bench.graph_trace_avg("wgrad_conv", "sac_depth", live_value=5100.0)
+    assert abs(ms - 0.030) < 1e-9 and src.endswith("r09_rocprofv3_summary_sac_depth.txt")
+    ms, why = bench.graph_trace_avg("wgrad_conv", "sac_depth", live_value=5600.0)
+    assert ms is None and "refused" in why
+    assert bench.graph_trace_avg("wgrad_conv", "no_such_workload", live_value=5000.0) == (None, None)
