@@ -229,15 +229,12 @@ int grl_set_running_stats(grl_handle h, const double* mean, const double* var, d
   return GRL_OK;
 }
 
-int grl_norm_update(grl_handle h, const float* obs, int n) {
-  if (!h || !obs || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
-  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
-  if (n > h->stg_n) return fail(GRL_ERR_INVALID, "more observations than one env step of act_batch environments");
+// RunningMeanStd.update over `n` raw observations that are already on the device
+static int norm_update_from(grl_handle h, const float* dev_obs, int n) {
   const grl_config& c = h->cfg;
-  HIPCHK(hipMemcpyAsync(h->n_stage, obs, (size_t)n * h->n_elems * 4, hipMemcpyHostToDevice, h->stream));
   NormUpdateArgs a;
   memset(&a, 0, sizeof(a));
-  a.obs = h->n_stage; a.n = n; a.elems = (int)h->n_elems;
+  a.obs = dev_obs; a.n = n; a.elems = (int)h->n_elems;
   a.mean = h->n_mean; a.var = h->n_var; a.count = h->n_count; a.parity = h->n_parity; a.eps = c.norm_eps;
   a.hw = h->hw * h->hw; a.c_obs = c.obs_channels; a.c_img = h->C_img; a.n_direct = h->cnn ? h->F - 512 : 0; a.vec = h->cnn ? 0 : 1;
   a.s_mean = h->s_mean; a.s_std = h->s_std; a.s_dmean = h->s_dmean; a.s_dstd = h->s_dstd;
@@ -257,6 +254,14 @@ int grl_norm_update(grl_handle h, const float* obs, int n) {
   return GRL_OK;
 }
 
+int grl_norm_update(grl_handle h, const float* obs, int n) {
+  if (!h || !obs || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  if (n > h->stg_n) return fail(GRL_ERR_INVALID, "more observations than one env step of act_batch environments");
+  HIPCHK(hipMemcpyAsync(h->n_stage, obs, (size_t)n * h->n_elems * 4, hipMemcpyHostToDevice, h->stream));
+  return norm_update_from(h, h->n_stage, n);
+}
+
 int grl_get_obs_stats(grl_handle h, double* mean, double* var, double* count) {
   if (!h || !mean || !var || !count) return fail(GRL_ERR_INVALID, "null argument");
   if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
@@ -268,7 +273,7 @@ int grl_get_obs_stats(grl_handle h, double* mean, double* var, double* count) {
 }
 
 static int replay_add_dev(grl_handle h, const float* obs, const float* act, const float* rew, const float* nxt,
-                          const float* done, int n) {
+                          const float* done, int n, const int* next_row = nullptr, const float* next_alt = nullptr) {
   const grl_config& c = h->cfg;
   IngestArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -279,14 +284,16 @@ static int replay_add_dev(grl_handle h, const float* obs, const float* act, cons
   ia.rp_obs = h->rp_obs; ia.rp_next = h->rp_next; ia.rp_dobs = h->rp_dobs; ia.rp_dnext = h->rp_dnext;
   ia.rp_act = h->rp_act; ia.rp_rew = h->rp_rew; ia.rp_done = h->rp_done;
   ia.rgb_u8 = (c.algo == GRL_ALGO_SAC) ? c.replay_rgb_u8 : 0;
+  ia.next_row = next_row; ia.next_alt = next_alt;
   const int elems = h->cnn ? (ia.rgb_u8 ? h->hw * h->hw : h->img_elems) : c.obs_dim;
+  ia.size_out = &h->sc->replay_size;
+  ia.new_size = std::min<int64_t>(c.replay_capacity, h->rp_size + n);
   hipLaunchKernelGGL(ingest_kernel, dim3((elems + 255) / 256, n, 2), dim3(256), 0, h->stream, ia);
   if (h->per_on)   // new transitions enter with max_priority ** alpha
     hipLaunchKernelGGL(per_add_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->per, h->rp_pos, n,
                        (int64_t)c.replay_capacity);
   h->rp_pos = (h->rp_pos + n) % c.replay_capacity;
-  h->rp_size = std::min<int64_t>(c.replay_capacity, h->rp_size + n);
-  HIPCHK(hipMemcpyAsync(&h->sc->replay_size, &h->rp_size, 8, hipMemcpyHostToDevice, h->stream));
+  h->rp_size = ia.new_size;
   HIPCHK(hipGetLastError());
   return GRL_OK;
 }
@@ -329,10 +336,95 @@ int grl_replay_add(grl_handle h, const float* obs, const float* act, const float
     HIPCHK(hipMemcpyAsync(h->stg_act, act + (int64_t)k0 * h->A, (size_t)m * h->A * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->stg_rew, rew + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->stg_done, done + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    // (no wait between chunks: the copies are stream-ordered behind the ingest launch that reads the staging buffers, and
+    // hipMemcpyAsync has taken its copy of a pageable source by the time it returns)
     if (int e = replay_add_dev(h, h->stg_obs, h->stg_act, h->stg_rew, h->stg_next, h->stg_done, m)) return e;
-    HIPCHK(hipStreamSynchronize(h->stream));   // staging buffers are reused by the next chunk
   }
   return GRL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- observations uploaded once
+// One env step's observations serve three consumers -- the running statistics, the next action and two replay rows
+// (next_obs of this step, obs of the next).  grl_observe uploads them ONCE; grl_act (GRL_ACT_OBSERVED) and
+// grl_replay_add_observed read the device copy.  Page-locked staging, two buffers used in turn, each guarded by an event.
+static int ob_stage_acquire(grl_handle h, float** pin) {
+  const size_t need = (size_t)h->stg_n * (size_t)(h->ob_elems + h->A + 4);
+  if (h->pin_ob_n < need) {
+    for (int k = 0; k < 2; ++k) {
+      if (h->pin_ob[k]) { HIPCHK(hipStreamSynchronize(h->stream)); hipHostFree(h->pin_ob[k]); h->pin_ob[k] = nullptr; }
+      HIPCHK(hipHostMalloc((void**)&h->pin_ob[k], need * 4, 0));
+      if (!h->pin_ob_ev[k]) HIPCHK(hipEventCreateWithFlags(&h->pin_ob_ev[k], hipEventDisableTiming));
+      h->pin_ob_used[k] = false;
+    }
+    h->pin_ob_n = need;
+  }
+  const int k = h->pin_ob_next;
+  if (h->pin_ob_used[k]) HIPCHK(hipEventSynchronize(h->pin_ob_ev[k]));   // the copies that read it two calls ago
+  *pin = h->pin_ob[k];
+  return GRL_OK;
+}
+static int ob_stage_release(grl_handle h) {
+  const int k = h->pin_ob_next;
+  HIPCHK(hipEventRecord(h->pin_ob_ev[k], h->stream));
+  h->pin_ob_used[k] = true;
+  h->pin_ob_next = k ^ 1;
+  return GRL_OK;
+}
+
+int grl_observe(grl_handle h, const float* obs, int n, int flags) {
+  if (!h || !obs || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->ob_latest) return fail(GRL_ERR_STATE, "this handle keeps no observed observations (SAC handles do)");
+  if (n > h->stg_n) return fail(GRL_ERR_INVALID, "more observations than one env step of act_batch environments");
+  if (flags & ~GRL_OBSERVE_UPDATE_STATS) return fail(GRL_ERR_INVALID, "unknown flag bits");
+  if ((flags & GRL_OBSERVE_UPDATE_STATS) && !h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
+  const size_t bytes = (size_t)n * h->ob_elems * 4;
+  if (h->ob_n > 0)   // the previous step's observations become the `obs` side of the next replay rows
+    HIPCHK(hipMemcpyAsync(h->ob_prev, h->ob_latest, (size_t)h->ob_n * h->ob_elems * 4, hipMemcpyDeviceToDevice, h->stream));
+  h->ob_n_prev = h->ob_n;
+  static const int pinned = tune_int("observe_pinned", 1);   // 0: hand the caller's (pageable) buffer to hipMemcpyAsync
+  if (pinned) {
+    float* pin = nullptr;
+    if (int e = ob_stage_acquire(h, &pin)) return e;
+    memcpy(pin, obs, bytes);
+    HIPCHK(hipMemcpyAsync(h->ob_latest, pin, bytes, hipMemcpyHostToDevice, h->stream));
+    if (int e = ob_stage_release(h)) return e;
+  } else {
+    HIPCHK(hipMemcpyAsync(h->ob_latest, obs, bytes, hipMemcpyHostToDevice, h->stream));   // (staged before it returns)
+  }
+  h->ob_n = n;
+  if (flags & GRL_OBSERVE_UPDATE_STATS) return norm_update_from(h, h->ob_latest, n);
+  return GRL_OK;
+}
+
+int grl_replay_add_observed(grl_handle h, const float* act, const float* rew, const float* done, int n,
+                            const int32_t* term_rows, const float* term_obs, int n_term) {
+  if (!h || !act || !rew || !done || n < 1 || n_term < 0 || n_term > n) return fail(GRL_ERR_INVALID, "bad argument");
+  if (n_term > 0 && (!term_rows || !term_obs)) return fail(GRL_ERR_INVALID, "terminal rows without their observations");
+  if (!h->ob_latest) return fail(GRL_ERR_STATE, "this handle keeps no observed observations (SAC handles do)");
+  if (h->ob_n != n || h->ob_n_prev != n)
+    return fail(GRL_ERR_STATE, "grl_replay_add_observed needs two consecutive grl_observe calls of n observations each");
+  float* pin = nullptr;
+  if (int e = ob_stage_acquire(h, &pin)) return e;
+  const int A = h->A;
+  memcpy(pin, act, (size_t)n * A * 4);
+  memcpy(pin + (size_t)n * A, rew, (size_t)n * 4);
+  memcpy(pin + (size_t)n * (A + 1), done, (size_t)n * 4);
+  int32_t* rowmap = (int32_t*)(pin + (size_t)n * (A + 2));
+  for (int k = 0; k < n; ++k) rowmap[k] = -1;
+  for (int j = 0; j < n_term; ++j) {
+    if (term_rows[j] < 0 || term_rows[j] >= n) { (void)ob_stage_release(h); return fail(GRL_ERR_INVALID, "terminal row out of range"); }
+    rowmap[term_rows[j]] = j;
+  }
+  // (the ingest launch reads actions / rewards / done flags / row map straight from the page-locked buffer: 0.5 KB)
+  const size_t small = (size_t)n * (A + 3);
+  if (n_term > 0) {
+    memcpy(pin + small, term_obs, (size_t)n_term * h->ob_elems * 4);
+    HIPCHK(hipMemcpyAsync(h->ob_term, pin + small, (size_t)n_term * h->ob_elems * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  const int e = replay_add_dev(h, h->ob_prev, pin, pin + (size_t)n * A, h->ob_latest, pin + (size_t)n * (A + 1), n,
+                               n_term > 0 ? (const int*)(pin + (size_t)n * (A + 2)) : nullptr, h->ob_term);
+  if (int e2 = ob_stage_release(h)) return e2;    // (the event follows the launch that reads the buffer)
+  return e;
 }
 
 int64_t grl_replay_size(grl_handle h) { return h ? h->rp_size : -1; }
@@ -528,33 +620,38 @@ int grl_get_metrics(grl_handle h, grl_metrics* out) {
 }
 
 int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, float* out) {
-  if (!h || !obs || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
-  const int deterministic = flags & 1;
-  const bool raw = (flags & 2) != 0;      // raw observations: VecNormalize applied on the device (grl_norm_update statistics)
-  if (raw && h->ops_act_norm.empty()) return fail(GRL_ERR_STATE, "this handle has no normalising act path");
-  if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
+  if (!h || !out || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
+  if (flags & ~(GRL_ACT_DETERMINISTIC | GRL_ACT_RAW_OBS | GRL_ACT_OBSERVED)) return fail(GRL_ERR_INVALID, "unknown flag bits");
+  const int deterministic = flags & GRL_ACT_DETERMINISTIC;
+  const bool raw = (flags & GRL_ACT_RAW_OBS) != 0;        // raw observations: VecNormalize applied on the device (grl_norm_update statistics)
+  const bool observed = (flags & GRL_ACT_OBSERVED) != 0;  // act on what grl_observe uploaded: no second upload
   const bool q = h->cfg.algo != GRL_ALGO_SAC;   // DQN / BDQ: Q-values [n, D*bins]
+  if (!observed && !obs) return fail(GRL_ERR_INVALID, "bad argument");
+  if (q && (raw || observed)) return fail(GRL_ERR_STATE, "the Q handles take normalised observations handed to grl_act");
+  if (raw && !h->n_mean) return fail(GRL_ERR_STATE, "this handle has no normalising act path");
+  if (observed && h->ob_n != n) return fail(GRL_ERR_STATE, "n differs from the number of observations grl_observe holds");
+  if (n > h->NA) return fail(GRL_ERR_INVALID, "n exceeds act_batch");
   if (!q && !deterministic && !eps) return fail(GRL_ERR_INVALID, "stochastic action needs eps");
   const int64_t oe = (!q && h->cnn) ? (int64_t)h->hw * h->hw * h->cfg.obs_channels : h->cfg.obs_dim;
-  const size_t n_in = (size_t)n * oe, n_eps = (!q && !deterministic) ? (size_t)n * h->A : 0;
+  const size_t n_in = observed ? 0 : (size_t)n * oe, n_eps = (!q && !deterministic) ? (size_t)n * h->A : 0;
   const size_t n_out = q ? (size_t)n * h->qD * h->qN : (size_t)n * h->A;
-  if (int e = pin_reserve(h, n_in + n_eps, n_out)) return e;
-  memcpy(h->pin_in, obs, n_in * 4);
-  if (n_eps) memcpy(h->pin_in + n_in, eps, n_eps * 4);
-  HIPCHK(hipMemcpyAsync(h->stg_obs, h->pin_in, n_in * 4, hipMemcpyHostToDevice, h->stream));
-  if (n_eps) HIPCHK(hipMemcpyAsync(h->a_eps, h->pin_in + n_in, n_eps * 4, hipMemcpyHostToDevice, h->stream));
+  if (int e = pin_reserve(h, n_in, q ? n_out : 0)) return e;
+  if (n_in) memcpy(h->pin_in, obs, n_in * 4);
+  if (n_eps) memcpy(h->a_eps, eps, n_eps * 4);      // (SAC: a_eps / a_out are host memory the launches read and write; the
+  if (n_in) HIPCHK(hipMemcpyAsync(h->stg_obs, h->pin_in, n_in * 4, hipMemcpyHostToDevice, h->stream));   // previous call synchronised)
   if (q) {
     if (int e = h->run_seq("act", {&h->ops_act})) return e;
   } else {
     // the launches cover act_batch rows whatever n is (rows beyond n hold stale observations: computed, not returned)
-    if (int e = h->run_seq(std::string(deterministic ? "act_det" : "act_sto") + (raw ? "_n" : ""),
-                           {raw ? &h->ops_act_norm : &h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
+    const int v = (observed ? 2 : 0) | (raw ? 1 : 0);
+    if (int e = h->run_seq(std::string(deterministic ? "act_det" : "act_sto") + char('0' + v),
+                           {&h->ops_act_in[v], &h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
       return e;
   }
-  HIPCHK(hipMemcpyAsync(h->pin_out, q ? h->q_aout : h->a_out, n_out * 4, hipMemcpyDeviceToHost, h->stream));
+  if (q) HIPCHK(hipMemcpyAsync(h->pin_out, h->q_aout, n_out * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
-  memcpy(out, h->pin_out, n_out * 4);
+  memcpy(out, q ? h->pin_out : h->a_out, n_out * 4);
   return GRL_OK;
 }
 

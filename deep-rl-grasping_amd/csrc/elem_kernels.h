@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+#include "../../include/grl.h"   // GRL_MAX_LAYERS
 
 namespace grl {
 
@@ -286,6 +287,10 @@ struct IngestArgs {
   float* rp_obs; float* rp_next; float* rp_dobs; float* rp_dnext; float* rp_act; float* rp_rew;
   float* rp_done;
   int rgb_u8;   // RGB-D ring with byte colours (grl_config.replay_rgb_u8)
+  // grl_replay_add_observed: transition k's next observation is row next_row[k] of next_alt when next_row[k] >= 0 (the
+  // terminal observation of an episode that ended: the observed row already holds the first one of the next episode)
+  const int* next_row; const float* next_alt;
+  int64_t* size_out; int64_t new_size;   // the ring's fill level after this call (DevScalars.replay_size), written here
 };
 
 #ifndef GRL_ELEM_TYPES_ONLY
@@ -293,7 +298,10 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
   const int k = blockIdx.y;
   const int which = blockIdx.z;
   const int64_t dst = (a.pos + k) % a.cap;
-  const float* src = (which ? a.next_obs : a.obs);
+  const long row_elems = a.vec_dim > 0 ? a.vec_dim : (long)a.hw * a.c_obs;
+  const int alt = (which && a.next_row) ? a.next_row[k] : -1;
+  // (rebased so that row k below addresses the chosen row)
+  const float* src = alt >= 0 ? a.next_alt + ((long)alt - k) * row_elems : (which ? a.next_obs : a.obs);
   float* img = which ? a.rp_next : a.rp_obs;
   float* dir = which ? a.rp_dnext : a.rp_dobs;
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -322,6 +330,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
     if (threadIdx.x < a.act_dim) a.rp_act[dst * a.act_dim + threadIdx.x] = a.act[(long)k * a.act_dim + threadIdx.x];
     if (threadIdx.x == 64) a.rp_rew[dst] = a.rew[k];
     if (threadIdx.x == 65) a.rp_done[dst] = a.done[k];
+    if (threadIdx.x == 66 && k == 0) *a.size_out = a.new_size;
   }
 }
 #endif
@@ -1220,6 +1229,73 @@ __global__ __launch_bounds__(256) void act_out_kernel(const float* mu, const flo
   }
   out[i] = tanhf(u);
 }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// The policy head of the ACT path as one launch: L hidden layers (ReLU), the mu / log_std output layers and the final
+// tanh (+ sampling), one workgroup per observation row (16 environments: 16 workgroups; each layer is a few thousand
+// multiply-adds per row -- four dense launches and an output launch cost four kernel boundaries instead).
+// Weights [K, N] row-major as everywhere; thread t owns output t % Np over the input slice t / Np, partial sums meet in LDS.
+struct ActHeadsArgs {
+  const float* x; int ldx, K0;
+  const float* w[GRL_MAX_LAYERS]; const float* b[GRL_MAX_LAYERS]; int hid[GRL_MAX_LAYERS]; int L;
+  const float* ow[2]; const float* ob[2]; int A;
+  const float* eps; float* mu; float* ls; float* out; int rows; int deterministic;
+};
+enum { ACT_HEADS_MAX_IN = 2048, ACT_HEADS_MAX_HID = 256 };
+
+#ifndef GRL_ELEM_TYPES_ONLY
+#ifdef GRL_HOSTEMU
+#include "act_heads_ref1.h"   // tests/hostemu: the emulation build only
+#else
+__device__ inline void act_heads_layer(const float* in, int K, const float* w, const float* b, int N, int relu, float* part,
+                                       float* outv) {
+  int Np = 1;
+  while (Np < N) Np <<= 1;
+  const int S = 256 / Np, t = threadIdx.x, o = t % Np, q = t / Np;
+  float acc = 0.f;
+  if (o < N)
+    for (int i = q; i < K; i += S) acc = fmaf(in[i], w[(long)i * N + o], acc);
+  part[t] = acc;
+  __syncthreads();
+  if (t < N) {
+    float v = b[t];
+    for (int j = 0; j < S; ++j) v += part[j * Np + t];
+    outv[t] = relu ? fmaxf(v, 0.f) : v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void act_heads_kernel(ActHeadsArgs a) {
+  __shared__ float xs[ACT_HEADS_MAX_IN];
+  __shared__ float hs[2][ACT_HEADS_MAX_HID];
+  __shared__ float part[256];
+  __shared__ float o2[2][64];
+  const int r = blockIdx.x;
+  if (r >= a.rows) return;
+  for (int i = threadIdx.x; i < a.K0; i += 256) xs[i] = a.x[(long)r * a.ldx + i];
+  __syncthreads();
+  const float* in = xs;
+  int K = a.K0;
+  for (int l = 0; l < a.L; ++l) {
+    act_heads_layer(in, K, a.w[l], a.b[l], a.hid[l], 1, part, hs[l & 1]);
+    in = hs[l & 1];
+    K = a.hid[l];
+  }
+  for (int k = 0; k < 2; ++k) act_heads_layer(in, K, a.ow[k], a.ob[k], a.A, 0, part, o2[k]);
+  if (threadIdx.x < a.A) {
+    const int i = r * a.A + threadIdx.x;
+    float u = o2[0][threadIdx.x];
+    a.mu[i] = u;
+    a.ls[i] = o2[1][threadIdx.x];
+    if (!a.deterministic) {
+      const float ls = fminf(fmaxf(o2[1][threadIdx.x], GRL_LOG_STD_MIN), GRL_LOG_STD_MAX);
+      u += expf(ls) * a.eps[i];
+    }
+    a.out[i] = tanhf(u);
+  }
+}
+#endif  // GRL_HOSTEMU
 #endif
 
 }  // namespace grl

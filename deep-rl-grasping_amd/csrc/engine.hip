@@ -217,7 +217,16 @@ struct grl_ctx {
   float* n_stage = nullptr;
   int64_t n_elems = 0;
   int n_parity = 0;
-  std::vector<Op> ops_act_norm;   // the act path with VecNormalize applied to raw observations by the ingest launch
+  std::vector<Op> ops_act_in[4];  // entry launch of the SAC act path: [(observed by grl_observe) << 1 | (raw: VecNormalize applied on the device)]
+  // observations uploaded once per env step (grl_observe): newest, the one before, terminal rows, [act | rew | done | next_row]
+  float *ob_latest = nullptr, *ob_prev = nullptr, *ob_term = nullptr;
+  int64_t ob_elems = 0;
+  int ob_n = 0, ob_n_prev = 0;     // rows held by ob_latest / ob_prev (0 = nothing observed yet)
+  float* pin_ob[2] = {nullptr, nullptr};            // page-locked staging of grl_observe / grl_replay_add_observed, alternating
+  hipEvent_t pin_ob_ev[2] = {nullptr, nullptr};
+  bool pin_ob_used[2] = {false, false};
+  size_t pin_ob_n = 0;
+  int pin_ob_next = 0;
   // replay
   float *rp_obs, *rp_next, *rp_dobs, *rp_dnext, *rp_act, *rp_rew, *rp_done;
   int64_t rp_pos = 0, rp_size = 0;
@@ -247,6 +256,7 @@ struct grl_ctx {
   float* g0cat = nullptr;            // [B, 3*H0]: layer-0 gradients of vf | qf1 | qf2
   // act path
   float *ax, *aa1, *aa2, *aa3, *afeat, *a_eps, *a_out;
+  float* act_io_host = nullptr;   // SAC: a_eps | a_out live in page-locked host memory (plan_sac.inl)
   HeadAct ahPI;
   // encoder path
   float *enc_w[8];
@@ -317,6 +327,11 @@ struct grl_ctx {
   ~grl_ctx() {
     if (pin_in) hipHostFree(pin_in);
     if (pin_out) hipHostFree(pin_out);
+    if (act_io_host) hipHostFree(act_io_host);
+    for (int k = 0; k < 2; ++k) {
+      if (pin_ob[k]) hipHostFree(pin_ob[k]);
+      if (pin_ob_ev[k]) hipEventDestroy(pin_ob_ev[k]);
+    }
     for (int k = 0; k < 2; ++k) {
       if (pin_stats[k]) hipHostFree(pin_stats[k]);
       if (pin_stats_ev[k]) hipEventDestroy(pin_stats_ev[k]);

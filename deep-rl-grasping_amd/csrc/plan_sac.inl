@@ -55,6 +55,12 @@ int grl_ctx::plan_sac() {
   stg_rew = wk.f32(stg_n);
   stg_done = wk.f32(stg_n);
   n_stage = wk.f32(stg_n * obs_elems);
+  // observed observations (grl_observe): the newest env step's and the one before it, uploaded once each; terminal rows
+  // and the small per-step arrays of grl_replay_add_observed
+  ob_latest = wk.f32(stg_n * obs_elems);
+  ob_prev = wk.f32(stg_n * obs_elems);
+  ob_term = wk.f32(stg_n * obs_elems);
+  ob_elems = obs_elems;
 
   // ---------------- training workspace
   idx_buf = (int64_t*)wk.take((size_t)B * 8);
@@ -798,8 +804,14 @@ int grl_ctx::plan_sac() {
   {
     ax = cnn ? wk.f32((int64_t)NA * img_elems) : nullptr;
     afeat = wk.f32((int64_t)NA * ldf);
-    a_eps = wk.f32((int64_t)NA * A);
-    a_out = wk.f32((int64_t)NA * A);
+    // noise in, actions out: page-locked HOST memory that the last launch of the act path reads and writes itself -- 320 bytes
+    // each way for 16 environments, for which a copy-engine transfer in the stream costs more than the whole policy head
+    if (!dry) {    // (grl_query_sizes plans without a device)
+      if (hipHostMalloc((void**)&act_io_host, (size_t)2 * NA * A * 4, 0) != hipSuccess) return fail(GRL_ERR_HIP, "hipHostMalloc failed");
+      memset(act_io_host, 0, (size_t)2 * NA * A * 4);
+    }
+    a_eps = act_io_host;
+    a_out = act_io_host + (size_t)NA * A;
     alloc_head(ahPI, NA, 2, A);
     ActIngestArgs ia;
     memset(&ia, 0, sizeof(ia));
@@ -809,15 +821,16 @@ int grl_ctx::plan_sac() {
     ActIngestArgs ian = ia;
     ian.normalize = 1; ian.clip_obs = c.clip_obs;
     ian.mean = s_mean; ian.stdv = s_std; ian.dmean = s_dmean; ian.dstd = s_dstd;
-    {
+    {   // entry launch: [observed by grl_observe | handed to grl_act] x [raw: VecNormalize applied here | already normalised]
       const int elems = cnn ? img_elems : c.obs_dim;
-      for (int v = 0; v < 2; ++v) {
-        const ActIngestArgs iv = v ? ian : ia;
+      for (int v = 0; v < 4; ++v) {
+        ActIngestArgs iv = (v & 1) ? ian : ia;
+        if (v & 2) iv.obs = ob_latest;
         Op op; op.tag = "act_ingest";
         op.run = [iv, elems](hipStream_t s) {
           hipLaunchKernelGGL(act_ingest_kernel, dim3((elems + 255) / 256, iv.n), dim3(256), 0, s, iv);
         };
-        (v ? ops_act_norm : ops_act).push_back(op);
+        ops_act_in[v].push_back(op);
       }
     }
     if (cnn) {
@@ -833,19 +846,34 @@ int grl_ctx::plan_sac() {
       add_launch(ops_act, "act_fc", 0,
                  {dense_fwd(aa3, 1024, 1024, nullptr, 0, 0, NA, P + ex[0].fw, 512, P + ex[0].fb, afeat, ldf, ACT_RELU)});
     }
-    for (int l = 0; l < L; ++l)
-      add_launch(ops_act, "act_head", 0, {head_layer(m_pi, P, ahPI, l, afeat, ldf, F, nullptr, 0, 0, NA)});
-    add_launch(ops_act, "act_head", 0, {head_out(m_pi, P, ahPI, 0, NA), head_out(m_pi, P, ahPI, 1, NA)});
-    for (size_t k = 1; k < ops_act.size(); ++k) ops_act_norm.push_back(ops_act[k]);
-    // final tanh (+ sampling): two variants so that each is a static graph
+    // the policy head: one launch (act_heads_kernel) for layer widths it covers, else a launch per layer + the output launch.
+    // Two variants (deterministic / sampled) so that each is a static graph.
+    bool one_launch = F <= ACT_HEADS_MAX_IN && A <= 64;
+    for (int l = 0; l < L; ++l) one_launch = one_launch && hid[l] <= ACT_HEADS_MAX_HID;
     for (int det = 0; det < 2; ++det) {
+      std::vector<Op>& tail = det ? ops_act_det : ops_act_sto;
+      if (one_launch) {
+        ActHeadsArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.x = afeat; ha.ldx = ldf; ha.K0 = F; ha.L = L;
+        for (int l = 0; l < L; ++l) { ha.w[l] = P + m_pi.w[l]; ha.b[l] = P + m_pi.b[l]; ha.hid[l] = hid[l]; }
+        for (int k = 0; k < 2; ++k) { ha.ow[k] = P + m_pi.ow[k]; ha.ob[k] = P + m_pi.ob[k]; }
+        ha.A = A; ha.eps = a_eps; ha.mu = ahPI.out[0]; ha.ls = ahPI.out[1]; ha.out = a_out; ha.rows = NA; ha.deterministic = det;
+        Op op; op.tag = "act_heads";
+        op.run = [ha](hipStream_t s) { hipLaunchKernelGGL(act_heads_kernel, dim3(ha.rows), dim3(256), 0, s, ha); };
+        tail.push_back(op);
+        continue;
+      }
+      for (int l = 0; l < L; ++l)
+        add_launch(tail, "act_head", 0, {head_layer(m_pi, P, ahPI, l, afeat, ldf, F, nullptr, 0, 0, NA)});
+      add_launch(tail, "act_head", 0, {head_out(m_pi, P, ahPI, 0, NA), head_out(m_pi, P, ahPI, 1, NA)});
       const float* mu = ahPI.out[0]; const float* ls = ahPI.out[1]; const float* ep = a_eps; float* ao = a_out;
       const int rows = NA, Ad = A;
       Op op; op.tag = "act_out";
       op.run = [mu, ls, ep, ao, rows, Ad, det](hipStream_t s) {
         hipLaunchKernelGGL(act_out_kernel, dim3((rows * Ad + 255) / 256), dim3(256), 0, s, mu, ls, ep, rows, Ad, det, ao);
       };
-      (det ? ops_act_det : ops_act_sto).push_back(op);
+      tail.push_back(op);
     }
   }
 
@@ -897,6 +925,9 @@ int grl_ctx::plan_sac() {
   dbg["grads"] = {grads, n_train};
   dbg["adam_m"] = {adam_m, n_train};
   dbg["adam_v"] = {adam_v, n_train};
+  dbg["rp_obs"] = {rp_obs, cap * obs_store}; dbg["rp_next"] = {rp_next, cap * obs_store};
+  dbg["rp_dobs"] = {rp_dobs, cap * std::max(nd, 1)}; dbg["rp_dnext"] = {rp_dnext, cap * std::max(nd, 1)};
+  dbg["rp_act"] = {rp_act, cap * A}; dbg["rp_rew"] = {rp_rew, cap}; dbg["rp_done"] = {rp_done, cap};
   dbg["idx_raw"] = {(const float*)idx_buf, (int64_t)2 * B};     // replay indices of the last minibatch: int64 viewed as float pairs
   return GRL_OK;
 }

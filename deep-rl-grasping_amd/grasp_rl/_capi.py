@@ -51,6 +51,7 @@ EXPORTS = [
     "grl_profile_enable", "grl_profile_query", "grl_profile_dump", "grl_q_update_target", "grl_train_step_per",
     "grl_ae_train_step",
     "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate", "grl_compute_grads_staged", "grl_grad_ranges",
+    "grl_observe", "grl_replay_add_observed",
     "grl_norm_update", "grl_set_running_stats", "grl_set_ret_var", "grl_get_obs_stats",
     "grl_allreduce_init", "grl_allreduce_connect", "grl_train_step_allreduce", "grl_allreduce_status", "grl_allreduce_set_overlap", "grl_allreduce_set_mode",
 ]
@@ -102,6 +103,8 @@ def load_library(path=None):
     lib.grl_train_step_allreduce.argtypes = [vp, i32, vp, vp]
     lib.grl_allreduce_status.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
     lib.grl_norm_update.argtypes = [vp, f32p, i32]
+    lib.grl_observe.argtypes = [vp, f32p, i32, i32]
+    lib.grl_replay_add_observed.argtypes = [vp, f32p, f32p, f32p, i32, vp, f32p, i32]
     lib.grl_set_running_stats.argtypes = [vp, dp, dp, C.c_double]
     lib.grl_set_ret_var.argtypes = [vp, C.c_double]
     lib.grl_get_obs_stats.argtypes = [vp, dp, dp, C.POINTER(C.c_double)]

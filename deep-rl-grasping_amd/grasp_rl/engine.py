@@ -111,6 +111,7 @@ class SacEngine:
         self.table = _capi.param_table(self.lib, self.h)
         self.n_trainable = sizes.n_trainable
         self.B, self.A = cfg.batch_size, cfg.act_dim
+        self.observe_rows = int(cfg.act_batch)      # one env step that `observe` + `act(observed=True)` cover in one call
         self._keep = []
 
     def close(self):
@@ -218,6 +219,30 @@ class SacEngine:
         obs = np.ascontiguousarray(obs, dtype=np.float32)
         check(self.lib, self.lib.grl_norm_update(self.h, obs.ctypes.data, obs.shape[0]))
 
+    def observe(self, obs, update_stats=False):
+        """Upload one env step's raw observations [n, ...] ONCE (grl_observe): `act(observed=True)` and
+        `replay_add_observed` read the device copy; update_stats folds them into the running statistics as `norm_update`
+        does.  Returns the serial number of this call (consecutive calls: consecutive numbers)."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        check(self.lib, self.lib.grl_observe(self.h, obs.ctypes.data, obs.shape[0], 1 if update_stats else 0))
+        self._observe_serial = getattr(self, "_observe_serial", 0) + 1
+        return self._observe_serial
+
+    def replay_add_observed(self, act, rew, done, term_rows=None, term_obs=None):
+        """The transitions between the last two `observe` calls.  term_rows / term_obs: rows whose episode ended and the
+        terminal observations stored as their next observation."""
+        rew = np.ascontiguousarray(rew, dtype=np.float32).reshape(-1)
+        n = rew.shape[0]
+        act = np.ascontiguousarray(act, dtype=np.float32).reshape(n, self.A)
+        done = np.ascontiguousarray(done, dtype=np.float32).reshape(n)
+        pr = po = None
+        n_term = 0
+        if term_rows is not None and len(term_rows):
+            tr = np.ascontiguousarray(term_rows, dtype=np.int32)
+            to = np.ascontiguousarray(term_obs, dtype=np.float32)
+            n_term, pr, po = tr.shape[0], tr.ctypes.data, to.ctypes.data
+        check(self.lib, self.lib.grl_replay_add_observed(self.h, act.ctypes.data, rew.ctypes.data, done.ctypes.data, n, pr, po, n_term))
+
     def set_running_stats(self, mean, var, count):
         """Starting point of the running statistics grl_norm_update continues from (env layout, float64)."""
         mean = np.ascontiguousarray(mean, dtype=np.float64)
@@ -307,17 +332,21 @@ class SacEngine:
         self.be.synchronize()
 
     # ------------------------------------------------------------------ inference
-    def act(self, obs, deterministic=True, eps=None, raw=False):
-        """raw=True: `obs` are un-normalised observations, VecNormalize is applied on the device (norm_update statistics)."""
-        obs = np.ascontiguousarray(obs, dtype=np.float32)
-        n = obs.shape[0]
+    def act(self, obs, deterministic=True, eps=None, raw=False, observed=False):
+        """raw=True: `obs` are un-normalised observations, VecNormalize is applied on the device (norm_update statistics).
+        observed=True: act on the observations the last `observe` uploaded (`obs` is then only looked at for its length)."""
+        if observed:
+            n, po = int(obs if np.isscalar(obs) else len(obs)), None
+        else:
+            obs = np.ascontiguousarray(obs, dtype=np.float32)
+            n, po = obs.shape[0], obs.ctypes.data
         out = np.empty((n, self.A), np.float32)
         pe = None
         if not deterministic:
             eps = np.ascontiguousarray(eps, dtype=np.float32).reshape(n, self.A)
             pe = eps.ctypes.data
-        flags = (1 if deterministic else 0) | (2 if raw else 0)
-        check(self.lib, self.lib.grl_act(self.h, obs.ctypes.data, n, flags, pe, out.ctypes.data))
+        flags = (1 if deterministic else 0) | (2 if raw else 0) | (4 if observed else 0)
+        check(self.lib, self.lib.grl_act(self.h, po, n, flags, pe, out.ctypes.data))
         return out
 
     def load_encoder(self, weights):

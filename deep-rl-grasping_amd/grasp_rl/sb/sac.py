@@ -234,9 +234,12 @@ class SAC:
         self.engine.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))   # asynchronous, stream-ordered
 
     # ------------------------------------------------------------------ acting
-    def _act(self, obs, deterministic, raw=False):
+    def _act(self, obs, deterministic, raw=False, observed=False):
+        n = len(obs)
+        if observed:      # the env wrapper uploaded these observations already (engine.observe): only noise and actions move
+            eps = None if deterministic else self._rng.standard_normal((n, int(np.prod(self.action_space.shape)))).astype(np.float32)
+            return self.engine.act(n, deterministic, eps, raw=raw, observed=True)
         obs = np.asarray(obs, np.float32)
-        n = obs.shape[0]
         out = np.empty((n, int(np.prod(self.action_space.shape))), np.float32)
         cap = self.engine.cfg.act_batch
         for k0 in range(0, n, cap):
@@ -309,6 +312,7 @@ class SAC:
         infos_values = {}
         obs = self.env.reset()
         obs_ = vn.get_original_obs() if vn is not None else obs
+        serial = vn.observed_serial if vn is not None else None     # engine.observe ticket of `obs` (device-side statistics)
         callback.on_training_start(locals(), globals())
         callback.on_rollout_start()
         step = 0
@@ -318,7 +322,7 @@ class SAC:
                 unscaled_action = np.stack([np.asarray(self.action_space.sample(), np.float32) for _ in range(N)])
                 action = self._scale(unscaled_action)
             else:
-                action = self._act(obs, deterministic=False, raw=raw_obs)
+                action = self._act(obs, deterministic=False, raw=raw_obs, observed=raw_obs and serial is not None)
                 if self.action_noise is not None:
                     action = np.clip(action + self.action_noise(), -1, 1)
                 unscaled_action = self._unscale(action)
@@ -350,17 +354,25 @@ class SAC:
                 stop = rt.any(stop)      # rank 0's callbacks decide for every replica (and no rank runs ahead of the others)
             if stop:
                 break
-            if vn is not None:
-                new_obs_, reward_ = vn.get_original_obs(), vn.get_original_reward()
+            new_serial = vn.observed_serial if vn is not None else None
+            # an auto-reset env returns the first observation of the next episode: the replay row keeps the terminal one
+            ended = [i for i in range(N) if done[i] and isinstance(info[i], dict) and "terminal_observation" in info[i]]
+            if serial is not None and new_serial == serial + 1:
+                # both sides of the transitions are on the device already (uploaded once each by the wrapper)
+                new_obs_, reward_ = vn.old_obs, vn.old_rews
+                eng.replay_add_observed(action.reshape(N, -1), reward_, done, ended,
+                                        np.stack([info[i]["terminal_observation"] for i in ended]) if ended else None)
             else:
-                new_obs_, reward_ = new_obs, reward
-            next_store = np.array(new_obs_, np.float32, copy=True)
-            for i in range(N):                            # an auto-reset env returns the first obs of the next
-                if done[i] and isinstance(info[i], dict) and "terminal_observation" in info[i]:   # episode
+                if vn is not None:
+                    new_obs_, reward_ = vn.get_original_obs(), vn.get_original_reward()
+                else:
+                    new_obs_, reward_ = new_obs, reward
+                next_store = np.array(new_obs_, np.float32, copy=True)
+                for i in ended:
                     next_store[i] = info[i]["terminal_observation"]
-            eng.replay_add(np.asarray(obs_, np.float32), action.reshape(N, -1), np.asarray(reward_, np.float32),
-                           next_store, np.asarray(done, np.float32))
-            obs, obs_ = new_obs, new_obs_
+                eng.replay_add(np.asarray(obs_, np.float32), action.reshape(N, -1), np.asarray(reward_, np.float32),
+                               next_store, np.asarray(done, np.float32))
+            obs, obs_, serial = new_obs, new_obs_, new_serial
             for i in range(N):
                 maybe = info[i].get("episode") if isinstance(info[i], dict) else None
                 if maybe is not None:

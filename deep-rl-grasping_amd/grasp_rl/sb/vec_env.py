@@ -106,7 +106,7 @@ def _subproc_worker(remote, parent_remote, env_fns_pickled):
     64x64x5 float32 observation is 80 KB: pickling it through a pipe costs more than the rest of the exchange)."""
     parent_remote.close()
     envs = [fn() for fn in pickle.loads(env_fns_pickled)]
-    shm, slots = None, None
+    shm, slots, fast = None, None, None
 
     def out(k, obs):
         if slots is None:
@@ -115,7 +115,26 @@ def _subproc_worker(remote, parent_remote, env_fns_pickled):
         return None
     try:
         while True:
-            cmd, data = remote.recv()
+            msg = remote.recv_bytes()
+            if msg == b"s":       # the per-step exchange: actions, rewards and done flags through the shared block as well
+                acts, rews, dones = fast
+                infos, plain = [], True
+                for k, env in enumerate(envs):
+                    obs, rew, done, info = env.step(acts[k].copy() if acts[k].ndim else acts[k][()])
+                    if done:
+                        info = dict(info)
+                        info["terminal_observation"] = np.array(obs, copy=True)
+                        obs = env.reset()
+                    slots[k][...] = obs
+                    rews[k], dones[k] = rew, done
+                    plain = plain and not info
+                    infos.append(info)
+                if plain:
+                    remote.send_bytes(b"\0")            # nothing to report: one byte instead of a pickled list
+                else:
+                    remote.send(infos)
+                continue
+            cmd, data = pickle.loads(msg)
             if cmd == "step":
                 res = []
                 for k, (env, action) in enumerate(zip(envs, data)):
@@ -130,10 +149,16 @@ def _subproc_worker(remote, parent_remote, env_fns_pickled):
                 remote.send([out(k, env.reset()) for k, env in enumerate(envs)])
             elif cmd == "shm":
                 from multiprocessing import shared_memory
-                name, first, shape, dtype = data
+                name, first, shape, dtype, extra = data
                 shm = shared_memory.SharedMemory(name=name)
                 item = int(np.prod(shape)) * np.dtype(dtype).itemsize
                 slots = [np.ndarray(shape, dtype=dtype, buffer=shm.buf, offset=(first + k) * item) for k in range(len(envs))]
+                if extra is not None:
+                    n_all, a_off, a_shape, a_dtype, r_off, d_off = extra
+                    a_all = np.ndarray((n_all,) + tuple(a_shape), dtype=a_dtype, buffer=shm.buf, offset=a_off)
+                    r_all = np.ndarray((n_all,), dtype=np.float64, buffer=shm.buf, offset=r_off)
+                    d_all = np.ndarray((n_all,), dtype=np.uint8, buffer=shm.buf, offset=d_off)
+                    fast = (a_all[first:first + len(envs)], r_all[first:first + len(envs)], d_all[first:first + len(envs)])
                 remote.send(True)
             elif cmd == "seed":
                 remote.send([env.seed(sd) if hasattr(env, "seed") else None for env, sd in zip(envs, data)])
@@ -153,7 +178,7 @@ def _subproc_worker(remote, parent_remote, env_fns_pickled):
                 for env in envs:
                     if hasattr(env, "close"):
                         env.close()
-                slots = None
+                slots = fast = None
                 if shm is not None:
                     shm.close()
                 remote.close()
@@ -203,14 +228,33 @@ class SubprocVecEnv(VecEnv):
         self.buf_infos = [{} for _ in range(self.num_envs)]
         # observations through shared memory (array observation spaces): one block, one slot per environment
         self._shm, self._shm_arr = None, None
+        self._act_arr = self._rew_arr = self._done_arr = None
         shape = tuple(getattr(obs_space, "shape", ()) or ())
         if shared_memory and shape:
             from multiprocessing import shared_memory as _sm
             dtype = np.dtype(getattr(obs_space, "dtype", np.float32))
-            self._shm = _sm.SharedMemory(create=True, size=max(1, self.num_envs * int(np.prod(shape)) * dtype.itemsize))
-            self._shm_arr = np.ndarray((self.num_envs,) + shape, dtype=dtype, buffer=self._shm.buf)
+            n = self.num_envs
+            obs_bytes = n * int(np.prod(shape)) * dtype.itemsize
+            # actions, rewards and done flags travel through the same block when the action space is an array type
+            # (Box / Discrete): the pipes then carry one byte each way per step instead of pickled tuples
+            a_shape, a_dtype = getattr(act_space, "shape", None), getattr(act_space, "dtype", None)
+            extra = None
+            size = obs_bytes
+            if a_shape is not None and a_dtype is not None:
+                a_dtype = np.dtype(a_dtype)
+                a_off = (obs_bytes + 63) // 64 * 64
+                r_off = (a_off + n * int(np.prod(a_shape, dtype=np.int64)) * a_dtype.itemsize + 63) // 64 * 64
+                d_off = r_off + n * 8
+                size = d_off + n
+                extra = (n, a_off, tuple(a_shape), a_dtype.str, r_off, d_off)
+            self._shm = _sm.SharedMemory(create=True, size=max(1, size))
+            self._shm_arr = np.ndarray((n,) + shape, dtype=dtype, buffer=self._shm.buf)
+            if extra is not None:
+                self._act_arr = np.ndarray((n,) + tuple(a_shape), dtype=a_dtype, buffer=self._shm.buf, offset=a_off)
+                self._rew_arr = np.ndarray((n,), dtype=np.float64, buffer=self._shm.buf, offset=r_off)
+                self._done_arr = np.ndarray((n,), dtype=np.uint8, buffer=self._shm.buf, offset=d_off)
             for remote, g in zip(self.remotes, groups):
-                remote.send(("shm", (self._shm.name, g[0], shape, dtype.str)))
+                remote.send(("shm", (self._shm.name, g[0], shape, dtype.str, extra)))
             for remote in self.remotes:
                 remote.recv()
 
@@ -221,11 +265,24 @@ class SubprocVecEnv(VecEnv):
         return np.stack(obs).astype(dtype)
 
     def step_async(self, actions):
-        for remote, g in zip(self.remotes, self._groups):
-            remote.send(("step", [actions[e] for e in g]))
+        if self._act_arr is not None:
+            self._act_arr[...] = np.asarray(actions).reshape(self._act_arr.shape)
+            for remote in self.remotes:
+                remote.send_bytes(b"s")
+        else:
+            for remote, g in zip(self.remotes, self._groups):
+                remote.send(("step", [actions[e] for e in g]))
         self.waiting = True
 
     def step_wait(self):
+        if self._act_arr is not None:
+            infos = []
+            for remote, g in zip(self.remotes, self._groups):
+                m = remote.recv_bytes()
+                infos.extend([{} for _ in g] if m == b"\0" else pickle.loads(m))
+            self.waiting = False
+            self.buf_infos = infos
+            return (self._stack_obs(None), self._rew_arr.astype(np.float32), self._done_arr.astype(bool), infos)
         results = [r for remote in self.remotes for r in remote.recv()]
         self.waiting = False
         obs, rews, dones, infos = zip(*results)
@@ -248,13 +305,13 @@ class SubprocVecEnv(VecEnv):
             return
         if self.waiting:
             for remote in self.remotes:
-                remote.recv()
+                remote.recv_bytes()
         for remote in self.remotes:
             remote.send(("close", None))
         for proc in self.processes:
             proc.join()
         if self._shm is not None:
-            self._shm_arr = None
+            self._shm_arr = self._act_arr = self._rew_arr = self._done_arr = None
             self._shm.close()
             self._shm.unlink()
             self._shm = None
@@ -383,6 +440,7 @@ class VecNormalize(VecEnvWrapper):
         self.old_obs = np.array([])
         self.old_rews = np.array([])
         self._dev = None
+        self.observed_serial = None      # engine.observe serial of the observations last handed out (None: not on the device)
 
     # -- observation statistics on the device (opt-in, grasp_rl.sb.SAC(device_norm=True)) -------------------------
     def attach_device(self, engine):
@@ -393,6 +451,14 @@ class VecNormalize(VecEnvWrapper):
         self._dev = engine
         engine.set_obs_stats(self.obs_rms.mean, self.obs_rms.var, float(self.ret_rms.var))
         engine.set_running_stats(self.obs_rms.mean, self.obs_rms.var, self.obs_rms.count)
+
+    def _observe(self, obs):
+        """One upload per env step: the statistics are updated from the device copy, and `observed_serial` tells the learn
+        loop that the action and the replay rows can come from it too (engine.observe)."""
+        if hasattr(self._dev, "observe") and obs.shape[0] <= getattr(self._dev, "observe_rows", 0):
+            self.observed_serial = self._dev.observe(obs, update_stats=True)
+        else:
+            self._dev.norm_update(obs)
 
     def detach_device(self):
         if self._dev is not None:
@@ -411,7 +477,7 @@ class VecNormalize(VecEnvWrapper):
     def __getstate__(self):
         self.pull_device_stats()
         state = self.__dict__.copy()
-        for k in ("venv", "class_attributes", "ret", "_dev"):
+        for k in ("venv", "class_attributes", "ret", "_dev", "observed_serial"):
             state.pop(k, None)
         return state
 
@@ -419,6 +485,7 @@ class VecNormalize(VecEnvWrapper):
         self.__dict__.update(state)
         self.venv = None
         self._dev = None
+        self.observed_serial = None
 
     def set_venv(self, venv):
         if self.venv is not None:
@@ -432,9 +499,12 @@ class VecNormalize(VecEnvWrapper):
     def step_wait(self):
         obs, rews, dones, infos = self.venv.step_wait()
         self.old_obs, self.old_rews = obs, rews
+        self.observed_serial = None
         if self.hands_out_raw_observations:
-            self._dev.norm_update(obs)                 # statistics on the device; the consumer normalises there too
+            self._observe(obs)                         # statistics on the device; the consumer normalises there too
         else:
+            if self._dev is not None:                  # attached but frozen (a callback cleared `training`): the host
+                self.pull_device_stats()               # arithmetic below needs the statistics the device holds
             if self.training:
                 self.obs_rms.update(obs)               # batch moments in the observations' own dtype (float32), as NumPy forms them
             obs = self.normalize_obs(obs)
@@ -449,9 +519,12 @@ class VecNormalize(VecEnvWrapper):
         obs = self.venv.reset()
         self.old_obs = obs
         self.ret = np.zeros(self.num_envs)
+        self.observed_serial = None
         if self.hands_out_raw_observations:
-            self._dev.norm_update(obs)
+            self._observe(obs)
             return obs
+        if self._dev is not None:
+            self.pull_device_stats()
         if self.training:
             self.obs_rms.update(obs)
         return self.normalize_obs(obs)

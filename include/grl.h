@@ -253,13 +253,37 @@ int grl_grad_ranges(grl_handle h, int bucket, int cap, int64_t* offsets, int64_t
 /* host: metrics of the most recent update (synchronises the stream) */
 int grl_get_metrics(grl_handle h, grl_metrics* out);
 
-/* host: actor forward for n <= act_batch observations (env layout, host ptr); flags bit 0: deterministic action,
-   bit 1 (SAC handles): the observations are RAW and VecNormalize.normalize_obs is applied on the device with the
-   statistics grl_norm_update maintains (otherwise they are already normalised, as VecNormalize hands them out);
+/* host: actor forward for n <= act_batch observations (env layout, host ptr); `flags` is a mask of the bits below
+   (any other bit: GRL_ERR_INVALID).
+     GRL_ACT_DETERMINISTIC  tanh(mu) instead of a sample;
+     GRL_ACT_RAW_OBS        (SAC handles) the observations are RAW and VecNormalize.normalize_obs is applied on the device
+                            with the statistics grl_norm_update / grl_observe maintain (otherwise they are already
+                            normalised, as VecNormalize hands them out);
+     GRL_ACT_OBSERVED       (SAC handles) act on the n observations the last grl_observe uploaded; `obs` is ignored
+                            (may be NULL) and nothing but eps and the actions crosses the bus.
    eps_or_null: [n,act_dim] noise for stochastic actions (host).  Synchronises the stream.
    DQN / BDQ handles: out receives the dueling Q-values [n, q_branches*q_bins]. */
+#define GRL_ACT_DETERMINISTIC 1
+#define GRL_ACT_RAW_OBS 2
+#define GRL_ACT_OBSERVED 4
 int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps_or_null,
             float* out_actions);
+
+/* One env step's observations uploaded ONCE (SAC handles).  In SAC.learn the observations an env step returns are used
+   three times -- RunningMeanStd.update (VecNormalize.step_wait), the next model.predict-style action, and two
+   replay_buffer.add rows (new_obs of this step, obs of the next; stable-baselines' learn loop entered at
+   sb_helper.py:175-177).  grl_observe copies obs [n, env layout] (host ptr, n <= max(act_batch, 64); copied before the
+   call returns) to the device, keeps the previous call's observations beside them and, with GRL_OBSERVE_UPDATE_STATS,
+   folds them into the running statistics exactly as grl_norm_update does.  grl_act(GRL_ACT_OBSERVED) then acts on them;
+   grl_replay_add_observed appends the n transitions (previous observations, act, rew, newest observations, done) --
+   GRL_ERR_STATE unless the last two grl_observe calls both held n observations.  Rows whose episode ended store the
+   terminal observation instead: term_rows [n_term] names them, term_obs [n_term, env layout] holds their observations
+   (the auto-resetting VecEnv has already put the next episode's first observation in the observed row).
+   All stream-ordered; nothing synchronises. */
+#define GRL_OBSERVE_UPDATE_STATS 1
+int grl_observe(grl_handle h, const float* obs, int n, int flags);
+int grl_replay_add_observed(grl_handle h, const float* act, const float* rew, const float* done, int n,
+                            const int32_t* term_rows, const float* term_obs, int n_term);
 
 /* GRL_ALGO_AE handles: n_steps minibatch updates of the depth auto-encoder (forward, mean-squared
    reconstruction error, backward, Keras-Adam; encoders.py:40-50,127-136).  imgs: DEVICE pointer to

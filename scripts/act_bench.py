@@ -32,6 +32,38 @@ for n in (1, 16, 64):
         eng.replay_add(obs, a, r, obs, r)
     dt = (time.perf_counter() - t0) / 200
     print("replay_add n=%2d: %.1f us per call" % (n, 1e6 * dt))
+    # the same three consumers fed by ONE upload per env step (grl_observe): statistics, action, replay rows
+    eps = np.zeros((n, 5), np.float32)
+    def once():
+        eng.observe(obs, update_stats=True)
+        eng.replay_add_observed(a, r, r)
+        return eng.act(n, False, eps, raw=True, observed=True)
+    def separate():
+        eng.norm_update(obs)
+        eng.replay_add(obs, a, r, obs, r)
+        return eng.act(obs, False, eps, raw=True)
+    eng.observe(obs)
+    for name, fn in (("uploaded once", once), ("separate uploads", separate)):
+        for _ in range(20):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fn()
+        dt = (time.perf_counter() - t0) / 200
+        print("env step n=%2d, %s (statistics + replay rows + stochastic action): %.1f us" % (n, name, 1e6 * dt))
+    for _ in range(20):
+        eng.act(n, True, raw=True, observed=True)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.act(n, True, raw=True, observed=True)
+    dt = (time.perf_counter() - t0) / 200
+    print("act   n=%2d on observed observations: %.1f us per call" % (n, 1e6 * dt))
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.observe(obs, update_stats=True)
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / 200
+    print("observe n=%2d (+ statistics): %.1f us per call" % (n, 1e6 * dt))
     eng.close()
 W = np.load(os.path.join(ROOT, "tests", "golden", "ae_new_gripper_encoder.npz"))
 order = ["encoder/conv2d_1/kernel", "encoder/conv2d_1/bias", "encoder/conv2d_2/kernel", "encoder/conv2d_2/bias",

@@ -33,6 +33,18 @@ for st in $STAGES; do
         echo "rc=$?" >> $LOG; grep -v "^W0\|^\[Gloo\]\|^$" $R/gpurun_out/rehearsal_$N.err | tail -8 >> $LOG; cut -c1-1500 $R/gpurun_out/rehearsal_$N.json >> $LOG
       done
       ;;
+    act)
+      echo "== scripts/act_bench.py (grl_act / grl_replay_add / grl_observe latencies)" >> $LOG
+      timeout 300 python scripts/act_bench.py 2>&1 | grep -v amdgpu.ids >> $LOG
+      echo "== the same with GRL_TUNE=observe_pinned=0 (pageable source handed to hipMemcpyAsync)" >> $LOG
+      GRL_TUNE=observe_pinned=0 timeout 300 python scripts/act_bench.py 2>&1 | grep "env step\|observe" >> $LOG
+      ;;
+    loop)
+      echo "== scripts/profile_learn_loop.py --strict --device-norm" >> $LOG
+      timeout 300 python scripts/profile_learn_loop.py --strict --device-norm 2>&1 | grep -v amdgpu.ids | head -45 >> $LOG
+      echo "== scripts/profile_learn_loop.py --strict" >> $LOG
+      timeout 300 python scripts/profile_learn_loop.py --strict 2>&1 | grep -v amdgpu.ids | head -12 >> $LOG
+      ;;
     prof)
       echo "== rocprofv3 kernel trace (graph replay)" >> $LOG
       NAME=${PROF_NAME:-sac_depth} PMC=${PMC:-0} BENCH_ARGS="${PROF_BENCH_ARGS-}" bash scripts/profile_round.sh >> $LOG 2>&1

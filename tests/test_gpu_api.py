@@ -70,3 +70,37 @@ def test_subproc_envs_overlap_gpu():
         assert a.shape == (4, 5) and np.all(np.isfinite(a))
     finally:
         venv.close()
+
+
+@pytest.mark.parametrize("extractor,channels,rgb_u8", [("augmented", 2, False), ("augmented", 5, True), ("mlp", 0, False)])
+def test_observations_uploaded_once_gpu(extractor, channels, rgb_u8):
+    """grl_observe / grl_act(GRL_ACT_OBSERVED) / grl_replay_add_observed leave the replay ring, the running statistics and
+    the actions bit-identical to the separate uploads (tests/observed_util.py; the CPU suite runs it on the emulation build)."""
+    import observed_util
+    from grasp_rl.engine import SacEngine
+    observed_util.check_observed_path(lambda cfg: SacEngine(cfg, device="cuda:0"), extractor, channels, rgb_u8=rgb_u8)
+
+
+def test_learning_on_observations_uploaded_once_equals_the_separate_uploads_gpu(tmp_path):
+    """SAC(device_norm=True) -- one upload per env step -- against the default host-statistics path: parameters after
+    learn() and the saved statistics, bit for bit (same body as the emulation test in test_sb_api_host.py)."""
+    import numpy as np
+    import stable_baselines as sb
+    from stable_baselines.common.vec_env import DummyVecEnv, VecNormalize
+    outs = []
+    for dev in (False, True):
+        env = DummyVecEnv([(lambda s=s: FakeGraspEnv("depth", seed=s)) for s in range(3)])
+        env = VecNormalize(env, norm_obs=True, norm_reward=True, clip_obs=10.)
+        m = sb.SAC(sacCnn, env, policy_kwargs={"layers": [64, 64], "cnn_extractor": host.create_augmented_nature_cnn(1)},
+                   buffer_size=64, batch_size=4, learning_starts=6, seed=5, device_norm=dev)
+        m.learn(total_timesteps=45)
+        outs.append((m.get_parameters(), env.obs_rms.mean.copy(), env.obs_rms.var.copy(), env.obs_rms.count,
+                     m.engine.fetch("rp_obs"), m.engine.fetch("rp_next"), m.engine.fetch("rp_done")))
+        m.engine.close()
+    (p0, m0, v0, c0, *r0), (p1, m1, v1, c1, *r1) = outs
+    assert c0 == c1 and np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    for x, y in zip(r0, r1):
+        assert np.array_equal(x, y)
+    assert r0[2].sum() > 0          # episodes ended: terminal rows went through the row map
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
