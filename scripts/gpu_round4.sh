@@ -36,8 +36,6 @@ for st in $STAGES; do
     act)
       echo "== scripts/act_bench.py (grl_act / grl_replay_add / grl_observe latencies)" >> $LOG
       timeout 300 python scripts/act_bench.py 2>&1 | grep -v amdgpu.ids >> $LOG
-      echo "== the same with GRL_TUNE=observe_pinned=0 (pageable source handed to hipMemcpyAsync)" >> $LOG
-      GRL_TUNE=observe_pinned=0 timeout 300 python scripts/act_bench.py 2>&1 | grep "env step\|observe" >> $LOG
       ;;
     loop)
       echo "== scripts/profile_learn_loop.py --strict --device-norm" >> $LOG
