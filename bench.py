@@ -553,6 +553,8 @@ def run_sac(args, wl_name, world, rank, device):
                 "strict_order": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False, device=str(device)),
                 "strict_order_device_norm": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False,
                                                                       device=str(device), device_norm=True),
+                "overlap_env_step_device_norm": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
+                                                                          device=str(device), device_norm=True),
                 "one_update_per_iteration": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
                                                                       device=str(device), gradient_steps=1),
                 "one_update_per_iteration_device_norm": synthetic.learn_loop_rate(

@@ -924,10 +924,9 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->dp_body;
   std::vector<Op>* tail = h->dp_overlap ? &none : (one ? &h->ops_dp1 : &h->ops_dp);
   const std::string sfx = one ? "1" : "";
-  const char* npf = getenv("GRL_NO_GATHER_PREFETCH");
   std::vector<Op>* pf[3] = {one ? &h->ops_pfdp1_first : &h->ops_pfdp_first, one ? &h->ops_pfdp1_mid : &h->ops_pfdp_mid,
                             one ? &h->ops_pfdp1_last : &h->ops_pfdp_last};
-  if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !pf[1]->empty() && !(npf && atoi(npf))) {
+  if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !pf[1]->empty() && tune_int("gather_prefetch", 1)) {
     // plain exchange on the device RNG: the prefetching sequences (the gather of update t+1 rides on the reduction of update t)
     if (int e = h->run_seq("dpp_first" + sfx, {pf[0]})) return e;
     if (n_steps > 2)

@@ -56,7 +56,8 @@ static inline int64_t rup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // GRL_TUNE="key=value,key=value,...": the measurement / tuning knobs of scripts/ behind ONE variable (workgroup shape per
 // launch tag `i2cfg_<tag>`, `sk_wgs`, `wg_split` "a/b/c", `l0_split`, `graph_updates`, `dp_blocks` "a/b/c", `dp_coarse`,
-// `dp_timeout_ms`, `heads_stamps`).  Nothing here changes arithmetic.
+// `dp_timeout_ms`, `heads_stamps`) and the switches that select a tested alternative launch list (`fused_adam=0`,
+// `gather_prefetch=0`, `fused_q=0`, `fused_qapply=0`).  Nothing here changes arithmetic.
 static bool tune_str(const char* key, std::string* out) {
   const char* e = getenv("GRL_TUNE");
   if (!e) return false;

@@ -233,8 +233,7 @@ int grl_ctx::plan_q() {
   // ---- row-local chains (q_kernels.h) when every width fits the head primitives; else one GEMM launch per layer
   bool fused_q = false;
   {
-    const char* nf = getenv("GRL_NO_FUSED_Q");
-    bool ok = !(nf && nf[0] == '1') && nb <= 64 && Lc + std::max(Lb, Lv) <= GRL_MAX_LAYERS;
+    bool ok = tune_int("fused_q", 1) && nb <= 64 && Lc + std::max(Lb, Lv) <= GRL_MAX_LAYERS;
     for (int k = 0; k < Lc; ++k) ok = ok && c.q_common[k] <= HT_MAXW;
     for (int l = 0; l < Lb; ++l) ok = ok && c.q_branch[l] <= HT_MAXW;
     for (int l = 0; l < Lv; ++l) ok = ok && c.q_value[l] <= HT_MAXW;
@@ -487,9 +486,8 @@ int grl_ctx::plan_q() {
   }
   {
     // Full updates: reduction + clip + Adam as one launch (q_reduce_clip_adam_kernel) when every trainable variable is
-    // exactly one reduction descriptor and fits the kernel's LDS buffer.  GRL_NO_FUSED_QAPPLY=1 keeps the three launches.
-    const char* nf = getenv("GRL_NO_FUSED_QAPPLY");
-    bool ok = !(nf && atoi(nf)) && !ops_grads.empty() && ops_grads.back().tag == "reduce_slabs";
+    // exactly one reduction descriptor and fits the kernel's LDS buffer.  GRL_TUNE fused_qapply=0 keeps the three launches.
+    bool ok = tune_int("fused_qapply", 1) && !ops_grads.empty() && ops_grads.back().tag == "reduce_slabs";
     size_t n_tr = 0;
     for (auto& v : vars) {
       if (!v.trainable) continue;

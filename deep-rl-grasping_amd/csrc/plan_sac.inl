@@ -730,8 +730,7 @@ int grl_ctx::plan_sac() {
     // Full updates (no gradient exchange in between): every trainable element is the sum of one slab
     // column, so Adam + Polyak are applied where the sum is formed -- one launch and one pass over the
     // gradient bucket less.  log_ent_coef, whose gradient comes from the loss workgroup, is applied there.
-    const char* nf = getenv("GRL_NO_FUSED_ADAM");
-    if (has_loss && !(nf && nf[0] == '1')) {
+    if (has_loss && tune_int("fused_adam", 1)) {
       ops_grads_apply.assign(ops_grads.begin(), ops_grads.end() - 1);
       Op fo; fo.tag = "reduce_adam";
       fo.join = true;
@@ -748,8 +747,7 @@ int grl_ctx::plan_sac() {
       //   first : gather (does not touch the Adam step size) | body, heads[tick] | reduce + Adam + gather(t+1, counter + 1)
       //   middle:                                              body, heads[tick, counter += 1] | reduce + Adam + gather(t+1)
       //   last  :                                              body, heads[tick, counter += 1] | reduce + Adam (counter += 1)
-      const char* npf = getenv("GRL_NO_GATHER_PREFETCH");
-      if (heads_mfma && !(npf && atoi(npf))) {
+      if (heads_mfma && tune_int("gather_prefetch", 1)) {
         GatherArgs g1 = pf_ga;
         g1.use_rng = 1; g1.adam_tick = 0; g1.quiet = 0; g1.rng_ahead = 0;
         const int gx = pf_gx;

@@ -8,7 +8,7 @@ SAC losses are batch means, so the mean of per-shard gradients equals the gradie
 
 Two schedules:
   * one bucket: compute_grads -> all_reduce(whole bucket) on the engine stream -> apply_grads;
-  * two buckets, overlapped (opt-in: ``overlap=True`` / GRL_DP_OVERLAP=1): stage 0 of the gradient
+  * two buckets, overlapped (opt-in: ``overlap=True``): stage 0 of the gradient
     computation ends with the fully-connected + head gradients (90 % of the bytes) final; their all-reduce is
     issued on a second stream and travels over xGMI while stage 1 (convolution backward + convolution weight
     gradients, ~40 % of the update) runs on the engine stream; the small convolution bucket follows, then
@@ -84,9 +84,7 @@ class DataParallelSac:
         full = engine.be.as_torch(engine.grads)
         ranges = [engine.grad_ranges(b) for b in (0, 1)]
         self.staged = len(ranges[1]) > 0
-        if overlap is None:     # opt-in (GRL_DP_OVERLAP=1): the staged plan costs +16 % on-GPU and has no multi-GPU measurement yet
-            import os
-            overlap = os.environ.get("GRL_DP_OVERLAP", "0") == "1"
+        # (opt-in: the staged plan costs +16 % on-GPU and has no multi-GPU measurement yet)
         self.overlap = bool(overlap) and self.staged
         self.views = [[full[o:o + n] for o, n in r] for r in ranges]     # [bucket][range] views of the grads arena
 

@@ -37,6 +37,10 @@ for st in $STAGES; do
       echo "== scripts/act_bench.py (grl_act / grl_replay_add / grl_observe latencies)" >> $LOG
       timeout 300 python scripts/act_bench.py 2>&1 | grep -v amdgpu.ids >> $LOG
       ;;
+    phases)
+      echo "== scripts/learn_loop_phases.py" >> $LOG
+      timeout 300 python scripts/learn_loop_phases.py 2>&1 | grep -v amdgpu.ids >> $LOG
+      ;;
     loop)
       echo "== scripts/profile_learn_loop.py --strict --device-norm" >> $LOG
       timeout 300 python scripts/profile_learn_loop.py --strict --device-norm 2>&1 | grep -v amdgpu.ids | head -45 >> $LOG

@@ -315,13 +315,13 @@ def _learn_worker(rank, world, port, out_dir, device_norm):
     P0 = eng.get_parameters()
     # record what learn() hands to the engine / the exchange: the same schedule is replayed below through the wrapper alone
     log = []
-    for name in ("replay_add", "set_obs_stats", "set_ret_var", "norm_update", "set_running_stats"):
-        def rec(*a, _f=getattr(eng, name), _n=name):
-            log.append((_n, tuple(np.array(x, copy=True) if isinstance(x, np.ndarray) else x for x in a)))
-            return _f(*a)
+    for name in ("replay_add", "set_obs_stats", "set_ret_var", "norm_update", "set_running_stats", "observe", "replay_add_observed"):
+        def rec(*a, _f=getattr(eng, name), _n=name, **kw):
+            log.append((_n, tuple(np.array(x, copy=True) if isinstance(x, np.ndarray) else x for x in a), dict(kw)))
+            return _f(*a, **kw)
         setattr(eng, name, rec)
     train = model._dp.train
-    model._dp.train = lambda k: (log.append(("train", (k,))), train(k))[1]
+    model._dp.train = lambda k: (log.append(("train", (k,), {})), train(k))[1]
     model.learn(48)
     assert model.num_timesteps == 48 and model.n_updates > 0
     P = model.get_parameters()
@@ -331,11 +331,13 @@ def _learn_worker(rank, world, port, out_dir, device_norm):
     eng2 = SacEngine(eng.cfg, device="cuda:0")
     eng2.set_parameters(P0)
     dp2 = DataParallelInGraph(eng2, group=model._dp_rt.ctrl)
-    for name, a in log:
+    for name, a, kw in log:
         if name == "train":
             dp2.train(*a)
         else:
-            getattr(eng2, name)(*a)
+            getattr(eng2, name)(*a, **kw)
+    if device_norm:
+        assert any(name == "replay_add_observed" for name, _, _ in log)      # one upload per env step behind model.learn
     dp2.check()
     P2 = eng2.get_parameters()
     for k in P:

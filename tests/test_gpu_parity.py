@@ -45,11 +45,11 @@ def test_update_matches_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS", "GRL_NO_HEADS_MFMA", "GRL_NO_V2", "GRL_NO_FUSED_ADAM"])
+@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS=1", "GRL_NO_HEADS_MFMA=1", "GRL_NO_V2=1", "GRL_TUNE=fused_adam=0"])
 def test_fallback_paths_match_oracle(monkeypatch, var):
     """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel and the
     separate Adam launch -- the kernels other shapes fall back to -- stay correct."""
-    monkeypatch.setenv(var, "1")
+    monkeypatch.setenv(*var.split("=", 1))
     case = pu.make_case(n_steps=2, extractor="augmented", kind="depth", B=16, n_replay=48)
     ref, orc = pu.oracle_run(case)
     eng = pu.engine_setup(case)
@@ -136,15 +136,15 @@ def test_graph_replay_equals_eager(monkeypatch):
         assert np.array_equal(engs[0][n], engs[1][n]), n
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_FUSED_ADAM", "GRL_NO_GATHER_PREFETCH"])
+@pytest.mark.parametrize("var", ["fused_adam", "gather_prefetch"])
 def test_launch_plan_switches_do_not_touch_arithmetic(monkeypatch, var):
     """Adam fused into the slab reduction or as a launch of its own, the next minibatch gathered by the update's last
     launch or by one of its own: the switches only regroup work -- parameters after three updates (explicit minibatches)
     and after further calls of several updates on the device RNG are bit-identical."""
     case = pu.make_case(extractor="augmented", kind="depth", B=32, n_replay=96, n_steps=3)
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv(var, flag)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GRL_TUNE", "%s=%s" % (var, flag))
         eng = pu.engine_setup(case)
         eng.train(3, case["idx"], case["eps"])
         eng.train_device(5)
@@ -286,11 +286,11 @@ def test_error_paths():
 
 def test_multi_update_call_prefetch_is_bit_identical_b256(monkeypatch):
     """Headline shape, device RNG: one call of 6 updates (the gather of update t+1 rides on the last launch of update t,
-    the head launch opens each update) == 6 calls of one update == the same with GRL_NO_GATHER_PREFETCH=1: parameters,
+    the head launch opens each update) == 6 calls of one update == the same with GRL_TUNE gather_prefetch=0: parameters,
     Adam moments and the last drawn indices bit for bit."""
     def run(split, off=False):
         if off:
-            monkeypatch.setenv("GRL_NO_GATHER_PREFETCH", "1")
+            monkeypatch.setenv("GRL_TUNE", "gather_prefetch=0")
         case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=512, n_steps=1)
         eng = pu.engine_setup(case)
         for n in split:
@@ -299,7 +299,7 @@ def test_multi_update_call_prefetch_is_bit_identical_b256(monkeypatch):
                eng.metrics())
         eng.close()
         if off:
-            monkeypatch.delenv("GRL_NO_GATHER_PREFETCH")
+            monkeypatch.delenv("GRL_TUNE")
         return out
     ref = run([1] * 6)
     for got in (run([6]), run([2, 4]), run([6], off=True)):

@@ -13,15 +13,15 @@ def test_q_update_matches_oracle(name):
 
 @pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
 def test_q_update_per_layer_gemm_fallback(name, monkeypatch):
-    """GRL_NO_FUSED_Q=1: the per-layer GEMM launches stay correct next to the row-local chains."""
-    monkeypatch.setenv("GRL_NO_FUSED_Q", "1")
+    """GRL_TUNE fused_q=0: the per-layer GEMM launches stay correct next to the row-local chains."""
+    monkeypatch.setenv("GRL_TUNE", "fused_q=0")
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 
 @pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
 def test_q_update_three_launch_apply(name, monkeypatch):
-    """GRL_NO_FUSED_QAPPLY=1: slab reduction, clip_by_norm and Adam as three launches instead of the fused one."""
-    monkeypatch.setenv("GRL_NO_FUSED_QAPPLY", "1")
+    """GRL_TUNE fused_qapply=0: slab reduction, clip_by_norm and Adam as three launches instead of the fused one."""
+    monkeypatch.setenv("GRL_TUNE", "fused_qapply=0")
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 

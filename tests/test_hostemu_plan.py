@@ -110,7 +110,7 @@ def test_60_update_trajectory_follows_the_oracle(hostemu_lib):
 def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_lib, monkeypatch):
     """A call of n updates on the device RNG gathers minibatch t+1 inside the last launch of update t
     (reduce_slabs_gather_kernel) and opens each update in the head launch: parameters, Adam state and the RNG counter
-    must equal n single-update calls bit for bit (and the switch GRL_NO_GATHER_PREFETCH=1 must change nothing)."""
+    must equal n single-update calls bit for bit (and the switch GRL_TUNE gather_prefetch=0 must change nothing)."""
     def run(split, env=None):
         if env:
             monkeypatch.setenv(*env)
@@ -133,7 +133,7 @@ def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_
         for a, b in zip(xa, xb):
             assert np.array_equal(a, b), split
         assert ma == mb
-    Pc, xc, _ = run([5], env=("GRL_NO_GATHER_PREFETCH", "1"))
+    Pc, xc, _ = run([5], env=("GRL_TUNE", "gather_prefetch=0"))
     assert all(np.array_equal(Pa[n], Pc[n]) for n in Pa) and all(np.array_equal(a, b) for a, b in zip(xa, xc))
     # the CNN plan too (one shape)
     case = pu.make_case(extractor="augmented", kind="depth", B=4, n_replay=16, n_steps=1)

@@ -15,8 +15,8 @@ def test_q_plan_matches_oracle(hostemu_lib, name):
 
 @pytest.mark.parametrize("name", ["dqn", "bdq_5_branches"])
 def test_q_plan_per_layer_gemm_fallback(hostemu_lib, name, monkeypatch):
-    """GRL_NO_FUSED_Q=1: one GEMM launch per layer instead of the row-local chains of q_kernels.h."""
-    monkeypatch.setenv("GRL_NO_FUSED_Q", "1")
+    """GRL_TUNE fused_q=0: one GEMM launch per layer instead of the row-local chains of q_kernels.h."""
+    monkeypatch.setenv("GRL_TUNE", "fused_q=0")
     case = qu.make_q_case(**qu.CASES[name])
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
 
