@@ -229,6 +229,7 @@ class SubprocVecEnv(VecEnv):
         # observations through shared memory (array observation spaces): one block, one slot per environment
         self._shm, self._shm_arr = None, None
         self._act_arr = self._rew_arr = self._done_arr = None
+        self._fds = [r.fileno() for r in self.remotes]
         shape = tuple(getattr(obs_space, "shape", ()) or ())
         if shared_memory and shape:
             from multiprocessing import shared_memory as _sm
@@ -264,11 +265,29 @@ class SubprocVecEnv(VecEnv):
             return np.array(self._shm_arr, dtype=dtype, copy=True)     # the next step overwrites the slots
         return np.stack(obs).astype(dtype)
 
+    _STEP_MSG = b"\x00\x00\x00\x01s"      # multiprocessing.Connection framing of send_bytes(b"s"): length, payload
+
+    def _recv_framed(self, fd):
+        """One Connection message read straight from the pipe: the workers' replies are a few hundred bytes, written with
+        one write(), so one read() normally returns header and payload together."""
+        buf = os.read(fd, 65536)
+        while len(buf) < 4:
+            buf += os.read(fd, 65536)
+        n = int.from_bytes(buf[:4], "big", signed=True)
+        if n < 0:                    # (the 8-byte length form of messages over 2 GB: not something a step reply is)
+            raise RuntimeError("unexpected message framing from an environment worker")
+        while len(buf) < 4 + n:
+            chunk = os.read(fd, 4 + n - len(buf))
+            if not chunk:
+                raise EOFError("environment worker closed its pipe")
+            buf += chunk
+        return buf[4:4 + n]
+
     def step_async(self, actions):
         if self._act_arr is not None:
             self._act_arr[...] = np.asarray(actions).reshape(self._act_arr.shape)
-            for remote in self.remotes:
-                remote.send_bytes(b"s")
+            for fd in self._fds:
+                os.write(fd, self._STEP_MSG)
         else:
             for remote, g in zip(self.remotes, self._groups):
                 remote.send(("step", [actions[e] for e in g]))
@@ -277,8 +296,8 @@ class SubprocVecEnv(VecEnv):
     def step_wait(self):
         if self._act_arr is not None:
             infos = []
-            for remote, g in zip(self.remotes, self._groups):
-                m = remote.recv_bytes()
+            for fd, g in zip(self._fds, self._groups):
+                m = self._recv_framed(fd)
                 infos.extend([{} for _ in g] if m == b"\0" else pickle.loads(m))
             self.waiting = False
             self.buf_infos = infos
@@ -306,6 +325,7 @@ class SubprocVecEnv(VecEnv):
         if self.waiting:
             for remote in self.remotes:
                 remote.recv_bytes()
+            self.waiting = False
         for remote in self.remotes:
             remote.send(("close", None))
         for proc in self.processes:

@@ -191,6 +191,8 @@ def _ingraph_worker(rank, world, port, out_dir):
         for mode, overlap in VARIANTS:
             if overlap and cname == "tiny":
                 continue                              # (vector observations have no staged plan)
+            if world >= 8 and cname == "cnn" and (mode, overlap) != ("twoshot", False):
+                continue                              # (W = 4 runs every variant on this shape; eight time-sliced processes are slow)
             eng = pu.engine_setup(case)
             dp = DataParallelInGraph(eng, overlap=overlap, mode=mode)
             if cname == "tiny":
@@ -224,7 +226,7 @@ def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
     the hand-written all-reduces inside the graph -- one-shot, two-shot, two-shot with the dense bucket overlapped: each
     bit-identical to the rank-ordered float32 sum formed on the host (for W = 2 also to the gloo exchange), the replicas
     bit-identical to each other (also after updates on the device RNG and a switch of the variant).  W = 8 adds the
-    smallest bucket there is: ragged chunks, the last one empty."""
+    smallest bucket there is: ragged chunks, the last one empty (and keeps only the two-shot variant on the CNN shape)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
