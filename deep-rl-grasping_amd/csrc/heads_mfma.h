@@ -44,7 +44,7 @@ struct HeadsFusedArgs {
   const float* rew; const float* done; float gamma;
   float* d_out[5];        // [B] (stride ld_d): 1 d_v, 2 d_qf1, 3 d_qf2, 4 d_qf1_pi
   int ld_d;
-  unsigned long long* stamps;   // development aid (GRL_HEADS_STAMPS=1): [4 types][32] wall-clock stamps of row block 0
+  unsigned long long* stamps;   // development aid (GRL_TUNE=heads_stamps=1): [4 types][32] wall-clock stamps of row block 0
   // multi-update calls that prefetch the next minibatch (engine.hip "prefetch"): this launch sits between the last
   // launch of the previous update (which read the Adam step size and drew the indices of THIS update with counter
   // rng_step + 1) and the last launch of this one, so one thread opens the update here instead of in the gather
@@ -123,7 +123,7 @@ template <int W> struct HmLds {
   HeadsFusedArgs args;               // the argument block, copied once: field reads are LDS reads, not scalar-cache misses
 };
 
-// Latency rules this kernel is built on (measured with the wall-clock stamps of GRL_HEADS_STAMPS=1, MI355X):
+// Latency rules this kernel is built on (measured with the wall-clock stamps of GRL_TUNE=heads_stamps=1, MI355X):
 // every dependent global access costs ~1.2 us here, an MFMA stage ~0.3 us.  So (1) the argument block is copied to
 // LDS in one coalesced read, (2) the per-row inputs and the layer-0 partial sums of every head of the chain are
 // requested in one burst of few, wide loads, (3) the register operands of ALL stages of a head are requested one

@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Development aid: wall-clock stamps (100 MHz) of the phases of heads_fused_kernel's row block 0, per chain type.
-GRL_HEADS_STAMPS=1 python scripts/heads_stamps.py"""
+python scripts/heads_stamps.py   (sets GRL_TUNE=heads_stamps=1)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "deep-rl-grasping_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
-os.environ["GRL_HEADS_STAMPS"] = "1"
+os.environ["GRL_TUNE"] = "heads_stamps=1"
 import numpy as np
 import parity_util as pu
 
