@@ -216,8 +216,10 @@ def graph_trace_avg(tag, workload="sac_depth", live_value=None):
     """Average duration (ms) of launch `tag` under hipGraph replay, from the newest committed rocprofv3 kernel-trace
     summary of this workload (`profiles/rNN_rocprofv3_summary_<workload>.txt`, written by scripts/profile_round.sh
     from `rocprofv3 --kernel-trace --stats -- python bench.py ...`; lines `launch <tag> calls <n> avg <us> us`).
-    A summary goes stale silently when a kernel changes: the file carries the bench line of its own (profiled) run, and a
-    file whose recorded `value` is more than 5 % away from THIS run's is refused (returns (None, reason))."""
+    A summary goes stale silently when a kernel changes: the file carries the bench line of its own (profiled) run and, since
+    round 4, a line `unprofiled_value: <updates/s>` of the same build on the same box without the profiler (launch-bound
+    workloads run up to 20 % slower under rocprofv3).  A file whose recorded value -- the unprofiled one when present -- is
+    more than 5 % away from THIS run's is refused (returns (None, reason))."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_summary_%s.txt" % workload)))
@@ -226,7 +228,7 @@ def graph_trace_avg(tag, workload="sac_depth", live_value=None):
             text = open(f).read()
         except OSError:
             continue
-        rec = re.search(r'"value":\s*([0-9.]+)', text)
+        rec = re.search(r'unprofiled_value:\s*([0-9.]+)', text) or re.search(r'"value":\s*([0-9.]+)', text)
         if live_value and rec and abs(float(rec.group(1)) - live_value) > 0.05 * live_value:
             return None, "profiles/%s refused: recorded value %.1f is more than 5 %% from this run's %.1f" % (
                 os.path.basename(f), float(rec.group(1)), live_value)

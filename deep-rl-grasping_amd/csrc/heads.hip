@@ -33,11 +33,23 @@ void launch_heads_bwd(const HeadsBwdArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(heads_bwd_kernel, dim3((a.B + HT_RB - 1) / HT_RB, 4), dim3(256), 0, s, a);
 }
 void launch_q_fwd(const QFusedArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(q_fwd_fused_kernel, dim3((a.B + HT_RB - 1) / HT_RB, 3, a.D + 1), dim3(256), 0, s, a);
+  const dim3 grid((a.B + HT_RB - 1) / HT_RB, 3, a.D + 1);
+#ifndef GRL_HOSTEMU
+  if (a.mfma) { hipLaunchKernelGGL(q_fwd_mfma_kernel, grid, dim3(256), 0, s, a); return; }
+#endif
+  hipLaunchKernelGGL(q_fwd_fused_kernel, grid, dim3(256), 0, s, a);
 }
 void launch_q_bwd(const QFusedArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(q_bwd_towers_kernel, dim3((a.B + HT_RB - 1) / HT_RB, a.D + 1), dim3(256), 0, s, a);
-  if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, dim3((a.B + HT_RB - 1) / HT_RB), dim3(256), 0, s, a);
+  const dim3 towers((a.B + HT_RB - 1) / HT_RB, a.D + 1), trunk((a.B + HT_RB - 1) / HT_RB);
+#ifndef GRL_HOSTEMU
+  if (a.mfma) {
+    hipLaunchKernelGGL(q_bwd_towers_mfma_kernel, towers, dim3(256), 0, s, a);
+    if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_mfma_kernel, trunk, dim3(256), 0, s, a);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(q_bwd_towers_kernel, towers, dim3(256), 0, s, a);
+  if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, trunk, dim3(256), 0, s, a);
 }
 
 }  // namespace grl

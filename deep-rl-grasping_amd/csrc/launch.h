@@ -4,7 +4,7 @@
 //   gemm_fwd.hip    igemm2_kernel with P along the reduction, Q along the output columns (forward products), igemm_sk_kernel
 //   gemm_bwd.hip    igemm2_kernel with both operands along the reduction (backward-data), igemm2_pair_kernel
 //   gemm_wgrad.hip  igemm2_kernel with P along the output rows (weight gradients), the scalar-gather igemm_kernel
-//   heads.hip       heads_fused_kernel (MFMA), the VALU head chains, the DQN / BDQ tower chains
+//   heads.hip       heads_fused_kernel (MFMA), the VALU head chains, the DQN / BDQ tower chains (q_mfma.h on the matrix cores, q_kernels.h VALU)
 // so that the four compile side by side (the single translation unit of round 3 took 62 s).
 #pragma once
 #include "igemm.h"
@@ -12,6 +12,7 @@
 #include "heads_kernels.h"
 #include "heads_mfma.h"
 #include "q_kernels.h"
+#include "q_mfma.h"
 
 namespace grl {
 

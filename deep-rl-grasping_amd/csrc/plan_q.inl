@@ -313,14 +313,24 @@ int grl_ctx::plan_q() {
     qf.bwd_tw = upload_vec(wk, hb);
     qf.B = B; qf.D = D; qf.nb = nb; qf.Ht = Lc > 0 ? c.q_common[Lc - 1] : 0;
     qf.d_adv = gact.adv; qf.d_v = gact.v; qf.nbp = nbp; qf.ld_dv = ld_dv; qf.trunk_scale = c.q_trunk_scale;
+    bool trunk_mfma_ok = true;
     if (Lc > 0) {
       HtHead h;
       memset(&h, 0, sizeof(h));
       h.H0 = c.q_common[0]; h.L = Lc; h.z0 = a.zc[0]; h.g0 = gact.zc[0]; h.ldg0 = h.H0; h.hid[0] = h.H0;
       for (int l = 1; l < Lc; ++l) { h.w[l] = P + Pon.cw[l]; h.hid[l] = c.q_common[l]; h.z[l] = a.zc[l]; h.g[l] = gact.zc[l]; }
       qf.bwd_tr = upload_vec(wk, std::vector<HtHead>{h});
+      trunk_mfma_ok = qm_head_ok(h, false);
       qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
     }
+    // matrix-core stages (q_mfma.h) when every chain fits their 64-wide shape; GRL_TUNE q_mfma=0 keeps the VALU chains
+    qf.mfma = tune_int("q_mfma", 1) && trunk_mfma_ok;
+    for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h);
+    for (auto& h : hb) qf.mfma = qf.mfma && qm_head_ok(h);
+#ifdef GRL_HOSTEMU
+    qf.mfma = 0;
+#endif
+    if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: q chains       %s\n", qf.mfma ? "matrix-core stages (q_mfma.h)" : "VALU stages (q_kernels.h)");
     add_launch(ops_grads, "q_l0", 0, l0);
     Op op; op.tag = "q_fwd";
     const QFusedArgs fa = qf;

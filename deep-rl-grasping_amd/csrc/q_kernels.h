@@ -27,6 +27,7 @@ struct QFusedArgs {
   int nbp, ld_dv;
   float* dh_part;         // [D+1][B, Ht]: gradient w.r.t. the trunk output, one partial per tower
   float trunk_scale;
+  int mfma;               // every chain fits q_mfma.h's 64-wide MFMA stages: the launchers take those kernels
 };
 
 #ifndef GRL_HEADS_TYPES_ONLY

@@ -17,7 +17,7 @@ for n in (1, 16, 64):
     eng = SacEngine(cfg)
     eng.set_parameters(init_parameters(eng.table, seed=0))
     obs = np.random.default_rng(0).normal(size=(n, 64, 64, 2)).astype(np.float32)
-    for _ in range(2000 if n == 1 else 20):       # (the first engine of the process also wakes the GPU's clocks up)
+    for _ in range(2000 if n == 1 else 200):      # (the first engine of the process also wakes the GPU's clocks up)
         eng.act(obs, True)
     t0 = time.perf_counter()
     for _ in range(200):

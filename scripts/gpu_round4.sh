@@ -49,7 +49,15 @@ for st in $STAGES; do
       ;;
     prof)
       echo "== rocprofv3 kernel trace (graph replay)" >> $LOG
-      NAME=${PROF_NAME:-sac_depth} PMC=${PMC:-0} BENCH_ARGS="${PROF_BENCH_ARGS-}" bash scripts/profile_round.sh >> $LOG 2>&1
+      for W in ${PROF_WORKLOADS-sac_depth}; do
+        A="${PROF_BENCH_ARGS-}"; [ "$W" != "sac_depth" ] && A="$A --workload $W"
+        P=${PMC:-0}; [ "$W" != "sac_depth" ] && P=0          # counters for the headline workload only
+        NAME=$W PMC=$P BENCH_ARGS="$A" bash scripts/profile_round.sh >> $LOG 2>&1
+        # the same build on the same box WITHOUT the profiler (bench stage of this call): what bench.py's staleness check compares with
+        [ -f $R/gpurun_out/bench_$W.json ] && python3 -c "
+import json,sys
+d=json.loads(open('$R/gpurun_out/bench_$W.json').read().strip().splitlines()[-1]); print('unprofiled_value: %.2f  (ms_per_step %.4f, same box, same build, no profiler)' % (d['value'], d['ms_per_step']))" >> $R/gpurun_out/prof_$W/kernel_summary.txt
+      done
       ;;
     *) echo "== custom: $st" >> $LOG; bash -c "$st" >> $LOG 2>&1 ;;
   esac

@@ -18,6 +18,18 @@ def test_q_update_per_layer_gemm_fallback(name, monkeypatch):
     qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
 
 
+@pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape", "bdq_baseline_config3"])
+def test_q_update_valu_chains(name, monkeypatch, capfd):
+    """GRL_TUNE q_mfma=0: the VALU stage chains of q_kernels.h (what networks wider than 64 units run on) stay correct next
+    to the matrix-core stages of q_mfma.h -- and the default plan does take the matrix-core kernels for these shapes."""
+    monkeypatch.setenv("GRL_PLAN_DUMP", "1")
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+    assert "matrix-core stages" in capfd.readouterr().err
+    monkeypatch.setenv("GRL_TUNE", "q_mfma=0")
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+    assert "VALU stages" in capfd.readouterr().err
+
+
 @pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
 def test_q_update_three_launch_apply(name, monkeypatch):
     """GRL_TUNE fused_qapply=0: slab reduction, clip_by_norm and Adam as three launches instead of the fused one."""
