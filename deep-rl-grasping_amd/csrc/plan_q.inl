@@ -324,7 +324,7 @@ int grl_ctx::plan_q() {
       qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
     }
     // matrix-core stages (q_mfma.h) when every chain fits their 64-wide shape; GRL_TUNE q_mfma=0 keeps the VALU chains
-    qf.mfma = tune_int("q_mfma", 1) && trunk_mfma_ok;
+    qf.mfma = tune_int("q_mfma", 1) && trunk_mfma_ok && D + 1 <= QM_MAXP;
     for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h);
     for (auto& h : hb) qf.mfma = qf.mfma && qm_head_ok(h);
 #ifdef GRL_HOSTEMU

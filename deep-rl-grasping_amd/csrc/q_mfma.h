@@ -20,7 +20,7 @@
 
 namespace grl {
 
-enum { QM_W = 64, QM_LD = QM_W + 4, QM_KS = QM_W / 4 };
+enum { QM_W = 64, QM_LD = QM_W + 4, QM_KS = QM_W / 4, QM_MAXP = 8 };   // QM_MAXP: towers whose trunk gradients one launch adds up
 
 // host: can this chain run here?  (layer widths and outputs within one 64-wide stage; one output layer)
 static inline bool qm_head_ok(const HtHead& h, bool has_out = true) {
@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
 //   dz_parts == nullptr: s.o holds the output gradients [row][o]; g_{L-1} = mask * (d_out . ow^T)
 //   dz_parts != nullptr: g_{L-1} = mask * (sum of n_parts partial gradients w.r.t. the last hidden activation) * scale
 // then g_{l-1} = mask * (g_l . w_l^T) down to layer 0, and optionally d xa = g_0 . w0a^T.  Writes every g.
+// `stage_in()` runs after every operand of the chain has been requested: it clears the LDS block, brings the output
+// gradients in (its own loads travel with the operands') and ends with a barrier.
+template <class StageIn>
 __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, QmLds& s, float* da, int ld_da,
-                                            const float* dz_parts, int n_parts, long part_stride, float dz_scale) {
+                                            const float* dz_parts, int n_parts, long part_stride, float dz_scale, StageIn&& stage_in) {
   const int t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4;
   const int n = 16 * w + c, L = h.L;
   // ---- operands of every stage: [0] output layer (transposed), [l] hidden layer l (transposed), bwa: layer-0 action rows
@@ -184,15 +187,29 @@ __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, Qm
       }
     }
   };
+  // the trunk's partial gradients: all requested at once (a loop over a run-time count would wait for each in turn), added
+  // in tower order
+  float part[QM_MAXP][4];
+  if (dz_parts) {
+    const __amdgpu_buffer_rsrc_t rp = i2_rsrc(dz_parts);
+#pragma unroll
+    for (int p = 0; p < QM_MAXP; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 4 * q + i;
+        const bool ok = p < n_parts && row < B && n < HL;
+        part[p][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ok ? (int)((p * part_stride + (long)row * HL + n) * 4) : I2_OOB, 0, 0));
+      }
+  }
+  stage_in();
   // ---- g_{L-1}
   qm_f4 top = {0.f, 0.f, 0.f, 0.f};
   if (dz_parts) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = row0 + 4 * q + i;
       float sum = 0.f;
-      if (row < B && n < HL)
-        for (int p = 0; p < n_parts; ++p) sum += dz_parts[p * part_stride + (long)row * HL + n];
+#pragma unroll
+      for (int p = 0; p < QM_MAXP; ++p) sum += part[p][i];      // (zeros beyond n_parts: x + 0 is exact)
       top[i] = sum * dz_scale;
     }
   } else {
@@ -226,27 +243,34 @@ __global__ __launch_bounds__(256) void q_bwd_towers_mfma_kernel(QFusedArgs a) {
   __shared__ QmLds s;
   const int row0 = blockIdx.x * HT_RB, tw = blockIdx.y, t = threadIdx.x;
   const HtHead& h = a.bwd_tw[tw];
-  qm_zero(s);
-  __syncthreads();
-  {
-    const int r = t >> 4, row = row0 + r;              // 16 threads per row
-    if (tw < a.D) {
-      for (int o = t & 15; o < a.nb; o += 16)
-        s.o[r][o] = row < a.B ? a.d_adv[((long)row * a.D + tw) * a.nbp + o] : 0.f;
-    } else if ((t & 15) == 0) {
-      s.o[r][0] = row < a.B ? a.d_v[(long)row * a.ld_dv] : 0.f;
+  // output gradients of the rows: 16 threads per row, up to 64 bins -> 4 per thread, requested before the chain's operands
+  const int r = t >> 4, row = row0 + r, o0 = t & 15;
+  float dv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tw < a.D) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = o0 + 16 * j;
+      if (row < a.B && o < a.nb) dv[j] = a.d_adv[((long)row * a.D + tw) * a.nbp + o];
     }
+  } else if (o0 == 0 && row < a.B) {
+    dv[0] = a.d_v[(long)row * a.ld_dv];
   }
-  __syncthreads();
-  qm_bwd_head(h, row0, a.B, s, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht, nullptr, 0, 0, 1.f);
+  qm_bwd_head(h, row0, a.B, s, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht, nullptr, 0, 0, 1.f, [&]() {
+    qm_zero(s);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.o[r][o0 + 16 * j] = dv[j];
+    __syncthreads();
+  });
 }
 
 // grid (B/16): trunk -- partials added in tower order, scaled, masked, propagated down to layer 0
 __global__ __launch_bounds__(256) void q_bwd_trunk_mfma_kernel(QFusedArgs a) {
   __shared__ QmLds s;
-  qm_zero(s);
-  __syncthreads();
-  qm_bwd_head(*a.bwd_tr, blockIdx.x * HT_RB, a.B, s, nullptr, 0, a.dh_part, a.D + 1, (long)a.B * a.Ht, a.trunk_scale);
+  qm_bwd_head(*a.bwd_tr, blockIdx.x * HT_RB, a.B, s, nullptr, 0, a.dh_part, a.D + 1, (long)a.B * a.Ht, a.trunk_scale, [&]() {
+    qm_zero(s);
+    __syncthreads();
+  });
 }
 
 #endif  // GRL_HOSTEMU
