@@ -251,11 +251,21 @@ int grl_ctx::plan_q() {
     auto tower_z = [&](const QNetAct& a, int tw, int l) { return tw < D ? a.zb[tw][l] : a.zv[l]; };
     std::vector<HtHead> hf, hb;
     std::vector<IgemmProb> l0;
+    // matrix-core stages (q_mfma.h) when every width fits their 64-wide shape (GRL_TUNE q_mfma=0 keeps the VALU chains); they
+    // also take layer 0 (K = obs_dim <= 128) into the chain: no GEMM launch in front of it (GRL_TUNE q_l0_chain=0 keeps it)
+    bool want_mfma = tune_int("q_mfma", 1) != 0 && nb <= QM_W && D + 1 <= QM_MAXP;
+    for (int k = 0; k < Lc; ++k) want_mfma = want_mfma && c.q_common[k] <= QM_W;
+    for (int l = 0; l < Lb; ++l) want_mfma = want_mfma && c.q_branch[l] <= QM_W;
+    for (int l = 0; l < Lv; ++l) want_mfma = want_mfma && c.q_value[l] <= QM_W;
+#ifdef GRL_HOSTEMU
+    want_mfma = false;
+#endif
+    const bool l0_chain = want_mfma && c.obs_dim <= 2 * QM_W && tune_int("q_l0_chain", 1) != 0;
     for (int n = 0; n < 3; ++n) {
       const QNetP& W = *Wn[n];
       const QNetAct& a = net[n];
       float* u_trunk = nullptr;
-      if (Lc > 0) {   // layer 0 of the trunk: one GEMM (K = obs_dim), no bias / activation (applied by the chain)
+      if (Lc > 0 && !l0_chain) {   // layer 0 of the trunk: one GEMM (K = obs_dim), no bias / activation (applied by the chain)
         u_trunk = wk.f32((int64_t)B * c.q_common[0]);
         l0.push_back(dense_fwd(xin[n], ldf, c.obs_dim, nullptr, 0, 0, B, P + W.cw[0], c.q_common[0], nullptr, u_trunk,
                                c.q_common[0], ACT_NONE));
@@ -267,6 +277,7 @@ int grl_ctx::plan_q() {
         int li = 0;
         if (Lc > 0) {
           h.u = u_trunk; h.ldu = c.q_common[0]; h.b0 = P + W.cb[0]; h.H0 = c.q_common[0];
+          if (l0_chain) { h.xa = xin[n]; h.ld_xa = ldf; h.n_xa = c.obs_dim; h.w0a = P + W.cw[0]; }
           h.z0 = tw == 0 ? a.zc[0] : nullptr;             // the trunk is recomputed per tower, stored once
           h.hid[0] = c.q_common[0];
           for (li = 1; li < Lc; ++li) {
@@ -277,9 +288,13 @@ int grl_ctx::plan_q() {
             h.w[li] = tower_w(W, tw, l); h.b[li] = tower_b(W, tw, l); h.hid[li] = tower_hid(tw, l); h.z[li] = tower_z(a, tw, l);
           }
         } else {      // no trunk: layer 0 of every tower from the GEMM launch
-          float* u = wk.f32((int64_t)B * tower_hid(tw, 0));
-          l0.push_back(dense_fwd(xin[n], ldf, c.obs_dim, nullptr, 0, 0, B, tower_w(W, tw, 0), tower_hid(tw, 0), nullptr, u,
-                                 tower_hid(tw, 0), ACT_NONE));
+          float* u = nullptr;
+          if (l0_chain) { h.xa = xin[n]; h.ld_xa = ldf; h.n_xa = c.obs_dim; h.w0a = tower_w(W, tw, 0); }
+          else {
+            u = wk.f32((int64_t)B * tower_hid(tw, 0));
+            l0.push_back(dense_fwd(xin[n], ldf, c.obs_dim, nullptr, 0, 0, B, tower_w(W, tw, 0), tower_hid(tw, 0), nullptr, u,
+                                   tower_hid(tw, 0), ACT_NONE));
+          }
           h.u = u; h.ldu = tower_hid(tw, 0); h.b0 = tower_b(W, tw, 0); h.H0 = tower_hid(tw, 0);
           h.z0 = tower_z(a, tw, 0); h.hid[0] = h.H0;
           for (li = 1; li < Lt; ++li) {
@@ -324,14 +339,12 @@ int grl_ctx::plan_q() {
       qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
     }
     // matrix-core stages (q_mfma.h) when every chain fits their 64-wide shape; GRL_TUNE q_mfma=0 keeps the VALU chains
-    qf.mfma = tune_int("q_mfma", 1) && trunk_mfma_ok && D + 1 <= QM_MAXP;
-    for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h);
+    qf.mfma = want_mfma && trunk_mfma_ok;
+    for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h, true, true);
     for (auto& h : hb) qf.mfma = qf.mfma && qm_head_ok(h);
-#ifdef GRL_HOSTEMU
-    qf.mfma = 0;
-#endif
+    if (want_mfma && !qf.mfma) return fail(GRL_ERR_INVALID, "internal: the Q chains were planned for the matrix-core stages and do not fit them");
     if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: q chains       %s\n", qf.mfma ? "matrix-core stages (q_mfma.h)" : "VALU stages (q_kernels.h)");
-    add_launch(ops_grads, "q_l0", 0, l0);
+    if (!l0.empty()) add_launch(ops_grads, "q_l0", 0, l0);
     Op op; op.tag = "q_fwd";
     const QFusedArgs fa = qf;
     op.run = [fa](hipStream_t s) { launch_q_fwd(fa, s); };

@@ -23,8 +23,10 @@ namespace grl {
 enum { QM_W = 64, QM_LD = QM_W + 4, QM_KS = QM_W / 4, QM_MAXP = 8 };   // QM_MAXP: towers whose trunk gradients one launch adds up
 
 // host: can this chain run here?  (layer widths and outputs within one 64-wide stage; one output layer)
-static inline bool qm_head_ok(const HtHead& h, bool has_out = true) {
-  bool ok = h.L >= 1 && h.L <= GRL_MAX_LAYERS && h.n_xa <= QM_W && (!has_out || (h.n_out == 1 && h.out_dim >= 1 && h.out_dim <= QM_W));
+// (forward heads may carry the rows' INPUT as their action part: layer 0 is then computed in the chain, K = n_xa <= 128)
+static inline bool qm_head_ok(const HtHead& h, bool has_out = true, bool fwd = false) {
+  bool ok = h.L >= 1 && h.L <= GRL_MAX_LAYERS && h.n_xa <= (fwd ? 2 * QM_W : QM_W) &&
+            (!has_out || (h.n_out == 1 && h.out_dim >= 1 && h.out_dim <= QM_W));
   for (int l = 0; l < h.L; ++l) ok = ok && h.hid[l] >= 1 && h.hid[l] <= QM_W;
   return ok;
 }
@@ -49,15 +51,15 @@ __device__ __forceinline__ void qm_load_b(float (&bw)[QM_KS], const float* W, in
     bw[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (base + s * sk) * 4 : I2_OOB, 0, 0));
   }
 }
-// out(rows 4q .. 4q+3, column of this lane) = sum_k zin[row][k] * B(k, col)
-__device__ __forceinline__ qm_f4 qm_mma(const float (*zin)[QM_LD], const float (&bw)[QM_KS], int c, int q) {
+// out(rows 4q .. 4q+3, column of this lane) = acc + sum_k zin[row][k] * B(k, col)
+__device__ __forceinline__ qm_f4 qm_mma(const float (*zin)[QM_LD], const float (&bw)[QM_KS], int c, int q,
+                                        qm_f4 acc = qm_f4{0.f, 0.f, 0.f, 0.f}) {
   float av[QM_KS];
 #pragma unroll
   for (int j = 0; j < QM_KS / 4; ++j) {
     const qm_f4 v = *(const qm_f4*)(&zin[c][QM_KS * q + 4 * j]);
     av[4 * j] = v.x; av[4 * j + 1] = v.y; av[4 * j + 2] = v.z; av[4 * j + 3] = v.w;
   }
-  qm_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < QM_KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bw[s], acc, 0, 0, 0);
   return acc;
@@ -83,11 +85,26 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
     }
   qm_load_b(bw[0], h.ow[0], h.hid[L - 1], h.out_dim, h.out_dim, 1, n, q);
   bias[0] = n < h.out_dim ? h.ob[0][n] : 0.f;
-  // layer 0: z0 = relu(u (+ further partial sums, in order) + b0); thread -> (column t & 63, rows 4 (t >> 6) ..)
+  // layer 0 inside the chain (n_xa > 0: `xa` holds the rows' inputs, `w0a` the layer-0 kernel [n_xa, H0], n_xa <= 128):
+  // two 64-deep stages over the inputs staged in z[0] | z[1] -- no GEMM launch in front of the chain
+  const int nx = h.n_xa;
+  float bx[2][QM_KS], xv[8], bx0 = 0.f;
+  if (nx > 0) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) qm_load_b(bx[kc], h.w0a + (long)kc * QM_W * h.H0, nx - kc * QM_W, h.H0, h.H0, 1, n, q);
+    bx0 = n < h.H0 ? h.b0[n] : 0.f;
+    const int r = t >> 4, row = row0 + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = (t & 15) + 16 * j;
+      xv[j] = (row < B && col < nx) ? h.xa[(long)row * h.ld_xa + col] : 0.f;
+    }
+  }
+  // layer 0 from the GEMM launch: z0 = relu(u (+ further partial sums, in order) + b0); thread -> (column t & 63, rows 4 (t >> 6) ..)
   const int n0 = t & 63, rg = t >> 6;
   float u0[4] = {0.f, 0.f, 0.f, 0.f};
   float b0 = 0.f;
-  if (n0 < h.H0) {
+  if (nx == 0 && n0 < h.H0) {
     b0 = h.b0[n0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -103,7 +120,21 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
   }
   qm_zero(s);
   __syncthreads();
-  if (n0 < h.H0) {
+  if (nx > 0) {
+    const int r = t >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.z[j >> 2][r][(t & 15) + 16 * (j & 3)] = xv[j];
+    __syncthreads();
+    const qm_f4 acc = qm_mma(s.z[1], bx[1], c, q, qm_mma(s.z[0], bx[0], c, q));
+    __syncthreads();                      // every wave has read the inputs: z[0] now receives the layer's output
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r2 = 4 * q + i, row = row0 + r2;
+      const float v = n < h.H0 ? fmaxf(acc[i] + bx0, 0.f) : 0.f;
+      s.z[0][r2][n] = v;
+      if (row < B && n < h.H0 && h.z0) h.z0[(long)row * h.H0 + n] = v;
+    }
+  } else if (n0 < h.H0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + 4 * rg + i;
