@@ -552,7 +552,12 @@ int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u) 
   if (h->rp_size < 2) return fail(GRL_ERR_STATE, "prioritised sampling needs at least two stored transitions (sum(0, len - 1))");
   HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 8, hipMemcpyHostToDevice, h->stream));
   if (!u) {        // device Philox: identical updates, several to a graph
-    if (!h->ops_grads_apply_per.empty()) {
+    if (n_steps >= 2 && !h->ops_grads_apply_per_r.empty() && !h->prof) {
+      // nothing but the updates themselves touches the leaves inside one call: the first update sums every block of the
+      // ring, each apply launch refreshes the blocks its write-back touched, the later samplers start from those
+      if (int e = h->run_seq("per_rng_first", {&h->ops_per_rng_g, &h->ops_grads_apply_per_r})) return e;
+      if (int e = h->run_repeated("per_rng_inc", {&h->ops_per_rng_g_inc, &h->ops_grads_apply_per_r}, n_steps - 1)) return e;
+    } else if (!h->ops_grads_apply_per.empty()) {
       if (int e = h->run_repeated("per_rng", {&h->ops_per_rng_g, &h->ops_grads_apply_per}, n_steps)) return e;
     } else if (!h->ops_grads_apply.empty()) {
       if (int e = h->run_repeated("per_rng", {&h->ops_per_rng, &h->ops_gather, &h->ops_grads_apply, &h->ops_per_update}, n_steps)) return e;

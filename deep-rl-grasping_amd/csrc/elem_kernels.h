@@ -782,6 +782,45 @@ __device__ __forceinline__ float q_wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+// The same reductions without the LDS crossbar: __shfl_xor is a ds_bpermute, ~120 cycles of dependent latency each, and a
+// row of the loss chains 18 of them per branch (the kernel was 10 us of which 7 were these).  DPP moves cost a few cycles:
+// four steps (lane ^ 1, lane ^ 2, mirror inside 8, mirror inside 16) leave the sum of each 16-lane row in all of its lanes,
+// the four row values are read back through SGPRs and added in row order.  Deterministic, every lane gets the same value.
+template <int CTRL> __device__ __forceinline__ float q_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int q_dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+enum { Q_DPP_XOR1 = 0xB1, Q_DPP_XOR2 = 0x4E, Q_DPP_HALF_MIRROR = 0x141, Q_DPP_MIRROR = 0x140 };
+__device__ __forceinline__ float q_lane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float q_wave_sum_dpp(float v) {
+  v += q_dpp<Q_DPP_XOR1>(v);
+  v += q_dpp<Q_DPP_XOR2>(v);
+  v += q_dpp<Q_DPP_HALF_MIRROR>(v);
+  v += q_dpp<Q_DPP_MIRROR>(v);
+  return (q_lane_f(v, 0) + q_lane_f(v, 16)) + (q_lane_f(v, 32) + q_lane_f(v, 48));
+}
+// arg max over the wave, ties -> lowest lane (the sequential scan keeps the first maximum); returns the winning lane
+__device__ __forceinline__ int q_wave_argmax_dpp(float sv, int si) {
+#define Q_AM_STEP(CTRL)                                                     \
+  {                                                                         \
+    const float ov = q_dpp<CTRL>(sv);                                       \
+    const int oi = q_dpp_i<CTRL>(si);                                       \
+    if (ov > sv || (ov == sv && oi < si)) { sv = ov; si = oi; }             \
+  }
+  Q_AM_STEP(Q_DPP_XOR1) Q_AM_STEP(Q_DPP_XOR2) Q_AM_STEP(Q_DPP_HALF_MIRROR) Q_AM_STEP(Q_DPP_MIRROR)
+#undef Q_AM_STEP
+  float bv = q_lane_f(sv, 0);
+  int bi = __builtin_amdgcn_readlane(si, 0);
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+    const float ov = q_lane_f(sv, 16 * r);
+    const int oi = __builtin_amdgcn_readlane(si, 16 * r);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  return __builtin_amdgcn_readfirstlane(bi);
+}
 #ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -807,17 +846,10 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
 #pragma unroll
     for (int d = 0; d < DM; ++d) {
       if (d < D) {
-        float sv = xs[d];
         const float tg = xt[d];
-        int si = lane;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {      // arg max, ties -> lowest bin (the sequential scan keeps the first maximum)
-          const float ov = __shfl_xor(sv, m, 64);
-          const int oi = __shfl_xor(si, m, 64);
-          if (ov > sv || (ov == sv && oi < si)) { sv = ov; si = oi; }
-        }
-        const float mean2 = q_wave_sum(tg);
-        qbest += v2b + __shfl(tg, si, 64) - mean2 * invn;
+        const int si = q_wave_argmax_dpp(xs[d], lane);      // (wave-uniform)
+        const float mean2 = q_wave_sum_dpp(tg);
+        qbest += v2b + q_lane_f(tg, si) - mean2 * invn;
       }
     }
     qbest *= invD;
@@ -828,9 +860,9 @@ __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
       if (d < D) {
         const long o = ((long)b * D + d) * n + lane;
         const float ad = x0[d];
-        const float mean0 = q_wave_sum(ad) * invn;
+        const float mean0 = q_wave_sum_dpp(ad) * invn;
         const int ai = ais[d];
-        const float q_sel = v0b + __shfl(ad, ai, 64) - mean0;
+        const float q_sel = v0b + q_lane_f(ad, __builtin_amdgcn_readfirstlane(ai)) - mean0;
         const float tdv = q_sel - y;
         prio += fabsf(tdv);
         qs += q_sel;

@@ -1331,6 +1331,8 @@ struct grl_ctx {
   double* per_u = nullptr;
   std::vector<Op> ops_per_rng, ops_per_u, ops_per_update;
   std::vector<Op> ops_per_rng_g, ops_per_u_g;   // ... the sampler launches that also gather their rows (fully fused PER update)
+  std::vector<Op> ops_per_rng_g_inc;            // ... without the block-sum pass over the ring, and the update whose apply launch keeps the
+  std::vector<Op> ops_grads_apply_per_r;        //     block sums current instead (updates 2 .. n of one call)
   int qD = 0, qN = 0;
   float *q_td = nullptr, *q_prio = nullptr, *q_aout = nullptr;
   // pinned host staging of the per-env-step calls (grl_act / grl_encode): pageable copies cost more than the kernels

@@ -222,6 +222,70 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
 }
 #endif
 
+// Block sums kept current by the launch that writes the priorities back (multi-update calls: between two updates of one
+// call nothing else touches the leaves, so the block-sum pass over the WHOLE ring in front of every sampler is only
+// needed for the first update of a call).  Workgroup of sample k -- if k is the first sample that falls into its
+// 1024-leaf block -- rebuilds that block's tree from the stored leaves with the new values of every sampled leaf of the
+// block put in (the write-back workgroup of the same launch stores the same values: whichever this one reads is
+// overridden here), in the association order of per_blocksum_kernel.  Called by 256 threads (the caller retires the other
+// waves of a larger workgroup first); `tr`: 2 * PER_BLK doubles, `sm`: 256 doubles, `sidx`: B int64 of LDS.
+__device__ __forceinline__ void per_refresh_body(const PerArgs& a, const int64_t* idx_g, int k, double* tr, double* sm, int64_t* sidx) {
+  const int t = threadIdx.x;
+  for (int j = t; j < a.B; j += 256) sidx[j] = idx_g[j];      // (one round trip: a scan over global memory waits for every entry)
+  __syncthreads();
+  const int64_t* idx = sidx;
+  const int64_t blk = idx[k] / PER_BLK;
+  for (int j = 0; j < k; ++j)
+    if (idx[j] / PER_BLK == blk) return;           // (uniform) an earlier sample's workgroup rebuilds this block
+  const int64_t size = a.sc->replay_size, b0 = blk * PER_BLK;
+  if (t < 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = b0 + 4 * t + e;
+      tr[PER_BLK + 4 * t + e] = i < size ? a.p[i] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (t < 256)
+    for (int j = t; j < a.B; j += 256) {
+      const int64_t me = idx[j];
+      if (me / PER_BLK != blk) continue;
+      bool later = false;
+      for (int j2 = j + 1; j2 < a.B; ++j2) later = later || idx[j2] == me;
+      if (!later) tr[PER_BLK + (int)(me - b0)] = (double)per_powf(a.prio_in[j] + a.eps, a.alpha);
+    }
+  __syncthreads();
+  // the two lowest levels of the tree from registers (node = left + right, as per_tree_build forms them), the levels above
+  // together with the minimum: 8 barriers instead of 18
+  {
+    const double l0 = tr[PER_BLK + 4 * t], l1 = tr[PER_BLK + 4 * t + 1], l2 = tr[PER_BLK + 4 * t + 2], l3 = tr[PER_BLK + 4 * t + 3];
+    double m = INFINITY;
+    if (b0 + 4 * t < size) m = fmin(m, l0);
+    if (b0 + 4 * t + 1 < size) m = fmin(m, l1);
+    if (b0 + 4 * t + 2 < size) m = fmin(m, l2);
+    if (b0 + 4 * t + 3 < size) m = fmin(m, l3);
+    const double s01 = l0 + l1, s23 = l2 + l3;
+    tr[PER_BLK / 2 + 2 * t] = s01;
+    tr[PER_BLK / 2 + 2 * t + 1] = s23;
+    tr[PER_BLK / 4 + t] = s01 + s23;
+    sm[t] = m;
+  }
+  __syncthreads();
+  for (int n = PER_BLK / 8; n >= 1; n >>= 1) {
+    if (t < n) {
+      tr[n + t] = tr[2 * (n + t)] + tr[2 * (n + t) + 1];
+      sm[t] = fmin(sm[t], sm[t + n]);
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    a.bsum[blk] = tr[1];
+    a.bmin[blk] = sm[0];
+    const int64_t e = size - 2;
+    if (e >= 0 && e / PER_BLK == blk) a.st->tail_w = per_prefix_reduce(tr, e % PER_BLK, 1, [] { return 0.0; });
+  }
+}
+
 // priorities of the minibatch just trained on.  A transition drawn twice keeps the value of its LAST
 // occurrence (what NumPy's fancy assignment leaves behind): every sample writes unless a later sample
 // names the same index.  One workgroup; B <= 1024.

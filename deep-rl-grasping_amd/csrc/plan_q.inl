@@ -175,15 +175,23 @@ int grl_ctx::plan_q() {
       grl_ctx* self = this;
       for (int with_gather = 0; with_gather < 2; ++with_gather) {
         Op op; op.tag = "per_sample";
-        op.run = [self, pa, nb, mode, with_gather, q_ga, q_defer](hipStream_t s) {
-          PerArgs q = pa;
-          q.prio_in = self->q_prio;
-          GatherArgs g = *q_ga;
-          g.adam_tick = *q_defer;
-          hipLaunchKernelGGL(per_blocksum_kernel, dim3(nb), dim3(256), 0, s, q);
-          hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb, g, with_gather);   // RNG mode: marks rng_used, q_loss ticks
+        auto sampler = [self, pa, nb, with_gather, q_ga, q_defer](bool block_sums) {
+          return [self, pa, nb, with_gather, q_ga, q_defer, block_sums](hipStream_t s) {
+            PerArgs q = pa;
+            q.prio_in = self->q_prio;
+            GatherArgs g = *q_ga;
+            g.adam_tick = *q_defer;
+            if (block_sums) hipLaunchKernelGGL(per_blocksum_kernel, dim3(nb), dim3(256), 0, s, q);
+            hipLaunchKernelGGL(per_sample_kernel, dim3(q.B), dim3(256), 0, s, q, nb, g, with_gather);   // RNG mode: marks rng_used, q_loss ticks
+          };
         };
+        op.run = sampler(true);
         (with_gather ? (mode ? ops_per_u_g : ops_per_rng_g) : (mode ? ops_per_u : ops_per_rng)).push_back(op);
+        if (with_gather && !mode) {     // later updates of a multi-update call: the apply launch of the update before kept the block sums current
+          Op oi = op;
+          oi.run = sampler(false);
+          ops_per_rng_g_inc.push_back(oi);
+        }
       }
     }
     {
@@ -538,8 +546,8 @@ int grl_ctx::plan_q() {
       const int nd = (int)reduces.size();
       const float clip = c.q_grad_clip;
       const float* rp = q_row_part; const int rows = B, fin = q_finish;
-      auto apply_op = [self, dr, nd, clip, rp, rows, fin](bool with_per) {
-        return [self, dr, nd, clip, rp, rows, fin, with_per](hipStream_t s) {
+      auto apply_op = [self, dr, nd, clip, rp, rows, fin](bool with_per, bool refresh = false) {
+        return [self, dr, nd, clip, rp, rows, fin, with_per, refresh](hipStream_t s) {
           AdamArgs aa;
           aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
           aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
@@ -547,8 +555,9 @@ int grl_ctx::plan_q() {
           PerArgs q = self->per;
           q.prio_in = self->q_prio;
           // prioritised replay: one more workgroup writes the new priorities back (per_update_kernel's work)
-          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + (with_per ? 2 : 1)), dim3(1024), 0, s, dr, nd, clip, aa, rp, rows, fin,
-                             q, (const int64_t*)self->idx_buf);
+          // (refresh: one more workgroup per sample rebuilds the block sums its new priority touches, per_refresh_body)
+          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + (with_per ? 2 : 1) + (refresh ? rows : 0)), dim3(1024), 0, s, dr, nd, clip,
+                             aa, rp, rows, fin, q, (const int64_t*)self->idx_buf);
         };
       };
       op.run = apply_op(false);
@@ -559,6 +568,12 @@ int grl_ctx::plan_q() {
         Op po; po.tag = "q_apply";
         po.run = apply_op(true);
         ops_grads_apply_per.push_back(po);
+#ifndef GRL_HOSTEMU
+        if (tune_int("per_inc", 1) && !ops_per_rng_g_inc.empty()) {      // multi-update calls on the device RNG (capi: grl_train_step_per)
+          ops_grads_apply_per_r = ops_grads_apply_per;
+          ops_grads_apply_per_r.back().run = apply_op(true, true);
+        }
+#endif
       }
       *q_defer = 1;
       if (fin) {     // split compute / apply path of this plan: the batch means as a launch of their own, behind the reduction

@@ -31,6 +31,12 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
     per_update_body(per, per_idx, (int64_t*)gsum, red);
     return;
   }
+  if ((int)blockIdx.x > n_desc + 1) {   // one more per sample (multi-update calls): the block sums the NEXT sampler reads
+    if (t >= 256) return;               // (whole waves retire: the barriers below are among the remaining four)
+    per_refresh_body(per, per_idx, (int)blockIdx.x - n_desc - 2, (double*)gsum, (double*)gsum + 2 * PER_BLK,
+                     (int64_t*)((double*)gsum + 2 * PER_BLK + 256));
+    return;
+  }
   const ReduceDesc d = descs[blockIdx.x];
   constexpr int U = 8;                  // elements per thread in flight: the loops below are chains of load batches
   float ss = 0.f;
