@@ -57,7 +57,8 @@ static inline int64_t rup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 // GRL_TUNE="key=value,key=value,...": the measurement / tuning knobs of scripts/ behind ONE variable (workgroup shape per
 // launch tag `i2cfg_<tag>`, `sk_wgs`, `wg_split` "a/b/c", `l0_split`, `graph_updates`, `dp_blocks` "a/b/c", `dp_coarse`,
 // `dp_timeout_ms`, `heads_stamps`) and the switches that select a tested alternative launch list (`fused_adam=0`,
-// `gather_prefetch=0`, `fused_q=0`, `fused_qapply=0`).  Nothing here changes arithmetic.
+// `gather_prefetch=0`, `fused_q=0`, `fused_qapply=0`, `q_mfma=0`, `q_l0_chain=0`, `per_inc=0`).  None of them changes what is
+// computed; `q_mfma` / `fused_q` pick stage kernels with a different summation order (each checked against the oracle).
 static bool tune_str(const char* key, std::string* out) {
   const char* e = getenv("GRL_TUNE");
   if (!e) return false;
