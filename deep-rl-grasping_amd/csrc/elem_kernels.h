@@ -1273,6 +1273,9 @@ struct ActHeadsArgs {
   const float* w[GRL_MAX_LAYERS]; const float* b[GRL_MAX_LAYERS]; int hid[GRL_MAX_LAYERS]; int L;
   const float* ow[2]; const float* ob[2]; int A;
   const float* eps; float* mu; float* ls; float* out; int rows; int deterministic;
+  // act_mfma.h only: columns [0, n_sum) of the input are ReLU(sum of n_parts partial sums [rows, ld_parts] + x_bias) -- the
+  // extractor's dense layer run as a split-K GEMM; n_parts == 0: every column comes from x
+  const float* x_parts; const float* x_bias; int n_parts, n_sum, ld_parts; long part_stride;
 };
 enum { ACT_HEADS_MAX_IN = 2048, ACT_HEADS_MAX_HID = 256 };
 

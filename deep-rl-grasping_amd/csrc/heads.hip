@@ -32,6 +32,13 @@ void launch_heads_fwd(const HeadsFwdArgs& a, hipStream_t s) {
 void launch_heads_bwd(const HeadsBwdArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(heads_bwd_kernel, dim3((a.B + HT_RB - 1) / HT_RB, 4), dim3(256), 0, s, a);
 }
+void launch_act_heads_mfma(const ActHeadsArgs& a, hipStream_t s) {
+#ifndef GRL_HOSTEMU
+  hipLaunchKernelGGL(act_heads_mfma_kernel, dim3((a.rows + HT_RB - 1) / HT_RB), dim3(256), 0, s, a);
+#else
+  (void)a; (void)s;
+#endif
+}
 void launch_q_fwd(const QFusedArgs& a, hipStream_t s) {
   const dim3 grid((a.B + HT_RB - 1) / HT_RB, 3, a.D + 1);
 #ifndef GRL_HOSTEMU

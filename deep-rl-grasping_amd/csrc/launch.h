@@ -13,6 +13,7 @@
 #include "heads_mfma.h"
 #include "q_kernels.h"
 #include "q_mfma.h"
+#include "act_mfma.h"
 
 namespace grl {
 
@@ -32,6 +33,7 @@ void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs
 size_t heads_fused_lds_bytes(int shape);
 void launch_heads_fwd(const HeadsFwdArgs& a, hipStream_t s);
 void launch_heads_bwd(const HeadsBwdArgs& a, hipStream_t s);
+void launch_act_heads_mfma(const ActHeadsArgs& a, hipStream_t s);     // one workgroup per 16 observations (act_mfma.h)
 void launch_q_fwd(const QFusedArgs& a, hipStream_t s);
 void launch_q_bwd(const QFusedArgs& a, hipStream_t s);     // towers, then the trunk (when there is one)
 

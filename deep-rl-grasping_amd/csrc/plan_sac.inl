@@ -831,6 +831,14 @@ int grl_ctx::plan_sac() {
         ops_act_in[v].push_back(op);
       }
     }
+    // the policy head on the matrix cores (act_mfma.h) for the shapes it covers (GRL_TUNE act_mfma=0: the VALU kernel): the
+    // extractor's dense layer then runs as a split-K GEMM whose partial sums the head kernel adds up while it stages its input
+    bool mfma_heads = am_shape_ok(F, L, hid, A) && tune_int("act_mfma", 1) != 0;
+#ifdef GRL_HOSTEMU
+    mfma_heads = false;
+#endif
+    float* fc_parts = nullptr;
+    int fc_split = 0;
     if (cnn) {
       aa1 = wk.f32((int64_t)NA * 225 * 32); aa2 = wk.f32((int64_t)NA * 36 * 64); aa3 = wk.f32((int64_t)NA * 16 * 64);
       float* io[4] = {ax, aa1, aa2, aa3};
@@ -841,8 +849,17 @@ int grl_ctx::plan_sac() {
         add_launch(ops_act, "act_conv", 0,
                    {conv_fwd(io[l], t, ag, P + ex[0].w[l], P + ex[0].b[l], io[l + 1], ACT_RELU, 0.f)});
       }
-      add_launch(ops_act, "act_fc", 0,
-                 {dense_fwd(aa3, 1024, 1024, nullptr, 0, 0, NA, P + ex[0].fw, 512, P + ex[0].fb, afeat, ldf, ACT_RELU)});
+      if (mfma_heads) {
+        IgemmProb p = dense_fwd(aa3, 1024, 1024, nullptr, 0, 0, NA, P + ex[0].fw, 512, nullptr, nullptr, 512, ACT_NONE);
+        set_split(p, AM_MAXP);       // one tile walking 32 slabs (13.6 us for 16 rows) -> 4 x the tiles, 8 slabs each
+        fc_split = p.split;
+        fc_parts = wk.f32((int64_t)NA * 512 * p.split);
+        p.c = fc_parts;
+        add_launch(ops_act, "act_fc", 0, {p});
+      } else {
+        add_launch(ops_act, "act_fc", 0,
+                   {dense_fwd(aa3, 1024, 1024, nullptr, 0, 0, NA, P + ex[0].fw, 512, P + ex[0].fb, afeat, ldf, ACT_RELU)});
+      }
     }
     // the policy head: one launch (act_heads_kernel) for layer widths it covers, else a launch per layer + the output launch.
     // Two variants (deterministic / sampled) so that each is a static graph.
@@ -858,7 +875,15 @@ int grl_ctx::plan_sac() {
         for (int k = 0; k < 2; ++k) { ha.ow[k] = P + m_pi.ow[k]; ha.ob[k] = P + m_pi.ob[k]; }
         ha.A = A; ha.eps = a_eps; ha.mu = ahPI.out[0]; ha.ls = ahPI.out[1]; ha.out = a_out; ha.rows = NA; ha.deterministic = det;
         Op op; op.tag = "act_heads";
-        op.run = [ha](hipStream_t s) { hipLaunchKernelGGL(act_heads_kernel, dim3(ha.rows), dim3(256), 0, s, ha); };
+        if (mfma_heads) {
+          if (fc_split > 0) {
+            ha.x_parts = fc_parts; ha.n_parts = fc_split; ha.part_stride = (long)NA * 512; ha.ld_parts = 512;
+            ha.x_bias = P + ex[0].fb; ha.n_sum = 512;
+          }
+          op.run = [ha](hipStream_t s) { launch_act_heads_mfma(ha, s); };
+        } else {
+          op.run = [ha](hipStream_t s) { hipLaunchKernelGGL(act_heads_kernel, dim3(ha.rows), dim3(256), 0, s, ha); };
+        }
         tail.push_back(op);
         continue;
       }

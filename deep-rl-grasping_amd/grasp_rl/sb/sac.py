@@ -356,7 +356,8 @@ class SAC:
                 break
             new_serial = vn.observed_serial if vn is not None else None
             # an auto-reset env returns the first observation of the next episode: the replay row keeps the terminal one
-            ended = [i for i in range(N) if done[i] and isinstance(info[i], dict) and "terminal_observation" in info[i]]
+            ended = ([i for i in range(N) if done[i] and isinstance(info[i], dict) and "terminal_observation" in info[i]]
+                     if np.any(done) else [])
             if serial is not None and new_serial == serial + 1:
                 # both sides of the transitions are on the device already (uploaded once each by the wrapper)
                 new_obs_, reward_ = vn.old_obs, vn.old_rews
@@ -373,6 +374,9 @@ class SAC:
                 eng.replay_add(np.asarray(obs_, np.float32), action.reshape(N, -1), np.asarray(reward_, np.float32),
                                next_store, np.asarray(done, np.float32))
             obs, obs_, serial = new_obs, new_obs_, new_serial
+            step += 1
+            if step % self.train_freq == 0 and not self.overlap_env_step:
+                run_updates()          # strict order: the GPU idles from the action to this point -- bookkeeping comes after it
             for i in range(N):
                 maybe = info[i].get("episode") if isinstance(info[i], dict) else None
                 if maybe is not None:
@@ -380,12 +384,8 @@ class SAC:
                 if isinstance(info[i], dict) and info[i].get("is_success") is not None and done[i]:
                     episode_successes.append(float(info[i]["is_success"]))
             self.episode_reward += np.asarray(reward_, np.float64).reshape(N)
-            step += 1
-            if step % self.train_freq == 0:
-                if not self.overlap_env_step:
-                    run_updates()
-                if self.n_updates > 0 and (step // self.train_freq) % 50 == 0:
-                    infos_values = eng.metrics()
+            if step % self.train_freq == 0 and self.n_updates > 0 and (step // self.train_freq) % 50 == 0:
+                infos_values = eng.metrics()
             episode_rewards[-1] += float(np.asarray(reward_).reshape(N)[0])
             if done[0]:
                 if self.action_noise is not None:
