@@ -271,8 +271,13 @@ class SubprocVecEnv(VecEnv):
         """One Connection message read straight from the pipe: the workers' replies are a few hundred bytes, written with
         one write(), so one read() normally returns header and payload together."""
         buf = os.read(fd, 65536)
+        if not buf:
+            raise EOFError("environment worker closed its pipe")
         while len(buf) < 4:
-            buf += os.read(fd, 65536)
+            chunk = os.read(fd, 65536)
+            if not chunk:
+                raise EOFError("environment worker closed its pipe")
+            buf += chunk
         n = int.from_bytes(buf[:4], "big", signed=True)
         if n < 0:                    # (the 8-byte length form of messages over 2 GB: not something a step reply is)
             raise RuntimeError("unexpected message framing from an environment worker")
@@ -322,12 +327,19 @@ class SubprocVecEnv(VecEnv):
     def close(self):
         if self.closed:
             return
-        if self.waiting:
+        gone = (EOFError, BrokenPipeError, ConnectionResetError, OSError)      # a worker that died must not keep close() from
+        if self.waiting:                                                        # releasing the others and the shared block
             for remote in self.remotes:
-                remote.recv_bytes()
+                try:
+                    remote.recv_bytes()
+                except gone:
+                    pass
             self.waiting = False
         for remote in self.remotes:
-            remote.send(("close", None))
+            try:
+                remote.send(("close", None))
+            except gone:
+                pass
         for proc in self.processes:
             proc.join()
         if self._shm is not None:

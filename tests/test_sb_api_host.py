@@ -430,7 +430,7 @@ def test_learning_with_device_statistics_equals_the_host_path(tmp_path, emulated
 @pytest.mark.parametrize("extractor,channels,rgb_u8", [("augmented", 2, False), ("augmented", 5, True), ("mlp", 0, False)])
 def test_observations_uploaded_once_leave_the_engine_in_the_same_state(hostemu_lib, extractor, channels, rgb_u8):
     """grl_observe + grl_act(GRL_ACT_OBSERVED) + grl_replay_add_observed against the separate uploads (emulation build;
-    tests/test_gpu_sb_api.py runs the same body on the MI355X)."""
+    tests/test_gpu_api.py runs the same body on the MI355X)."""
     import observed_util
     observed_util.check_observed_path(lambda cfg: SacEngine(cfg, backend=NumpyHostBackend(), lib_path=hostemu_lib),
                                       extractor, channels, rgb_u8=rgb_u8)

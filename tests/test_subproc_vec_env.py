@@ -72,3 +72,23 @@ def test_several_envs_per_worker_behave_like_one_each():
     finally:
         sub.close()
         ref.close()
+
+
+def test_a_dead_worker_raises_instead_of_hanging_and_close_still_releases_the_rest():
+    """The per-step exchange reads the workers' pipes directly (one byte each way): a worker that died must surface as an
+    exception in step_async / step_wait, not as a read that never returns, and close() must still join the others."""
+    import pytest
+    sub = SubprocVecEnv([functools.partial(_make, s) for s in range(3)])
+    try:
+        sub.reset()
+        sub.step(np.zeros((3, 3), np.float32))
+        sub.processes[1].terminate()
+        sub.processes[1].join()
+        with pytest.raises((EOFError, BrokenPipeError, ConnectionResetError)):
+            for _ in range(3):          # (the first write after the death may still land in the pipe's buffer)
+                sub.step_async(np.zeros((3, 3), np.float32))
+                sub.step_wait()
+    finally:
+        sub.waiting = False
+        sub.close()
+    assert sub.closed
