@@ -372,8 +372,8 @@ struct grl_ctx {
     return GRL_OK;
   }
 
-  // `count` identical updates (device RNG: nothing changes on the host between them): groups of up to GRL_GRAPH_UPDATES
-  // (GRL_TUNE graph_updates; default 16, powers of two) go out as ONE graph -- no graph boundary between the updates of a group (measured on
+  // `count` identical updates (device RNG: nothing changes on the host between them): groups of up to `graph_updates`
+  // (GRL_TUNE; default 16, powers of two) go out as ONE graph -- no graph boundary between the updates of a group (measured on
   // MI355X, SAC depth B = 256: 5 090 -> 5 194 / 5 227 / 5 232 updates/s at 4 / 8 / 16 per graph)
   int run_repeated(const std::string& key, const std::vector<std::vector<Op>*>& one, int count) {
     const int max_group = std::max(1, std::min(64, tune_int("graph_updates", 16)));
