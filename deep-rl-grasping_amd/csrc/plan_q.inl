@@ -568,12 +568,10 @@ int grl_ctx::plan_q() {
         Op po; po.tag = "q_apply";
         po.run = apply_op(true);
         ops_grads_apply_per.push_back(po);
-#ifndef GRL_HOSTEMU
         if (tune_int("per_inc", 1) && !ops_per_rng_g_inc.empty()) {      // multi-update calls on the device RNG (capi: grl_train_step_per)
           ops_grads_apply_per_r = ops_grads_apply_per;
           ops_grads_apply_per_r.back().run = apply_op(true, true);
         }
-#endif
       }
       *q_defer = 1;
       if (fin) {     // split compute / apply path of this plan: the batch means as a launch of their own, behind the reduction

@@ -15,6 +15,10 @@ inline void q_reduce_clip_adam_kernel(const ReduceDesc* descs, int n_desc, float
     if (threadIdx.x == 0) per_update_ref(per, per_idx);
     return;
   }
+  if ((int)blockIdx.x > n_desc + 1) {    // block sums of the sum tree refreshed by the apply launch (multi-update calls)
+    if (threadIdx.x == 0) per_refresh_ref(per, per_idx, (int)blockIdx.x - n_desc - 2);
+    return;
+  }
   if (threadIdx.x != 0) return;
   if ((int)blockIdx.x == n_desc) {
     if (finish) q_finish_ref(const_cast<DevScalars*>(aa.sc), row_part, rows);

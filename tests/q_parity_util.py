@@ -185,3 +185,35 @@ def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps
     tot = float(orc._it_sum.sum())
     eng.close()
     return tot
+
+
+def per_multi_update_check(monkeypatch, name, cap, n_store, backend=None, lib_path=None, n=9):
+    """Prioritised replay on the device RNG: ONE call of n updates (the first sums every block of the ring, every apply
+    launch rebuilds the blocks its priority write-back touched, the later samplers start from those -- per_refresh_body) ==
+    n calls of one update (a block-sum pass over the whole ring in front of every sampler) == the same with GRL_TUNE
+    per_inc=0: drawn indices, float64 leaves and parameters bit for bit.  (Several samples per 1024-leaf block, repeated
+    indices, the block that holds leaf size - 2.)"""
+    def run(split, env=None):
+        if env:
+            monkeypatch.setenv("GRL_TUNE", env)
+        case = make_q_case(n_replay=n_store, n_steps=1, **dict(CASES[name]))
+        case["cfg"].replay_capacity = cap
+        case["cfg"].q_per, case["cfg"].q_per_alpha, case["cfg"].q_per_eps = 1, 0.6, 1e-6
+        case["cfg"].q_per_alpha64 = 0.6
+        eng = q_engine_setup(case, backend, lib_path)
+        idx = []
+        for k in split:
+            eng.train_per(k, 0.7)
+            idx.append(eng.sampled_indices())
+        out = (eng.get_parameters(), eng.stored_priorities(), idx[-1], eng.metrics())
+        eng.close()
+        if env:
+            monkeypatch.delenv("GRL_TUNE")
+        return out
+    ref = run([1] * n)
+    assert np.count_nonzero(ref[1] != ref[1][0]) > min(100, n * 4)            # the priorities moved
+    splits = ([n], [2, n - 2], [n - 4, 1, 3])
+    for got in [run(list(sp)) for sp in splits] + [run([n], env="per_inc=0")]:
+        for k in ref[0]:
+            assert np.array_equal(ref[0][k], got[0][k]), k
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2]) and ref[3] == got[3]

@@ -110,34 +110,6 @@ def test_shipped_bdq_weights_on_real_observations():
 
 @pytest.mark.parametrize("name,cap,n_store", [("bdq_reference_shape", 3000, 2500), ("dqn_reference_shape", 5000, 5000)])
 def test_per_multi_update_call_keeps_the_block_sums_current(name, cap, n_store, monkeypatch):
-    """Prioritised replay on the device RNG: ONE call of n updates (the first sums every block of the ring, every apply
-    launch rebuilds the blocks its priority write-back touched, the later samplers start from those -- per_refresh_body) ==
-    n calls of one update (a block-sum pass over the whole ring in front of every sampler) == the same with GRL_TUNE
-    per_inc=0: drawn indices, float64 leaves and parameters bit for bit.  (Several samples per 1024-leaf block, repeated
-    indices, the block that holds leaf size - 2.)"""
-    import numpy as np
-
-    def run(split, env=None):
-        if env:
-            monkeypatch.setenv("GRL_TUNE", env)
-        c = dict(qu.CASES[name])
-        case = qu.make_q_case(n_replay=n_store, n_steps=1, **c)
-        case["cfg"].replay_capacity = cap
-        case["cfg"].q_per, case["cfg"].q_per_alpha, case["cfg"].q_per_eps = 1, 0.6, 1e-6
-        case["cfg"].q_per_alpha64 = 0.6
-        eng = qu.q_engine_setup(case)
-        idx = []
-        for n in split:
-            eng.train_per(n, 0.7)
-            idx.append(eng.sampled_indices())
-        out = (eng.get_parameters(), eng.stored_priorities(), idx[-1], eng.metrics())
-        eng.close()
-        if env:
-            monkeypatch.delenv("GRL_TUNE")
-        return out
-    ref = run([1] * 9)
-    assert np.count_nonzero(ref[1] != ref[1][0]) > 100            # the priorities moved
-    for got in (run([9]), run([2, 7]), run([5, 1, 3]), run([9], env="per_inc=0")):
-        for k in ref[0]:
-            assert np.array_equal(ref[0][k], got[0][k]), k
-        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2]) and ref[3] == got[3]
+    """Prioritised replay on the device RNG: ONE call of n updates == n calls of one update, bit for bit
+    (q_parity_util.per_multi_update_check; the CPU suite runs it on the emulation build)."""
+    qu.per_multi_update_check(monkeypatch, name, cap, n_store)

@@ -48,3 +48,10 @@ def test_prioritised_replay_plan(hostemu_lib):
     qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=2500, n_store=2100, B=64, n_steps=5, seed=5,
                  case_name="bdq_baseline_config3")
     qu.per_check(backend=NumpyHostBackend(), lib_path=hostemu_lib, cap=1024, n_store=1023, B=8, n_steps=5, seed=2)   # leaf size - 2 ends a block
+
+
+def test_multi_update_per_call_keeps_the_block_sums_current(hostemu_lib, monkeypatch):
+    """One grl_train_step_per call of n updates (block sums refreshed by the apply launch) == n single-update calls, on the
+    emulation build: the launch sequences of capi.inl / plan_q.inl and the refresh's ownership rule, bit for bit."""
+    from hostemu_backend import NumpyHostBackend
+    qu.per_multi_update_check(monkeypatch, "bdq", 2100, 2050, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=6)
