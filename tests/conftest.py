@@ -13,6 +13,13 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle is small PyTorch-CPU work (batch 8 .. 256 convolutions): on a 256-core GPU box the default of one intra-op
+    # thread per core made the 200-update trajectory test take 88 s instead of 6.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:
+        pass
 
 
 def _gpu_available():

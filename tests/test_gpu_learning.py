@@ -111,13 +111,20 @@ def trajectory_check(case, eng, n_steps, every, floors=None, envelope=ENVELOPE):
     twin = _noisy_oracle(spec, case["params"], TWIN_NOISE)
     floors = dict(FLOORS, **(floors or {}))
     worst, table, twin_max = {}, [], {}
-    for s in range(n_steps):
+    import os
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # (B = 32 convolutions: a hundred host threads only get in each other's way)
+    pool = ThreadPoolExecutor(2)       # the oracle and its twin are independent CPU learners: stepped side by side (PyTorch
+    for s in range(n_steps):           # releases the GIL), which halves what this test costs -- all of it host time
         ii = case["idx"][s]
         raw = {k: tr[k][ii] for k in ("obs", "act", "rew", "next_obs", "done")}
         batch = osac.prepare_batch(spec, raw, case["stats"])
+        f_twin = pool.submit(twin.step, batch, case["eps"][s])
+        eng.train(1, case["idx"][s:s + 1], case["eps"][s:s + 1])      # (asynchronous: the device update runs meanwhile too)
         d = orc.step(batch, case["eps"][s])
-        dt = twin.step(batch, case["eps"][s])
-        eng.train(1, case["idx"][s:s + 1], case["eps"][s:s + 1])
+        dt = f_twin.result()
         if (s + 1) % every == 0 or s == n_steps - 1:
             m, ref, tw = eng.metrics(), _metrics_of(d), _metrics_of(dt)
             row = {}
@@ -133,6 +140,8 @@ def trajectory_check(case, eng, n_steps, every, floors=None, envelope=ENVELOPE):
                 assert dev <= lim, "update %d: %s device %.6g oracle %.6g twin %.6g (%.2f %% > %.2f %%)" % (
                     s + 1, k, a, b, tw[k], 100 * dev, 100 * lim)
             table.append((s + 1, row))
+    pool.shutdown()
+    torch.set_num_threads(threads)
     return worst, table
 
 
