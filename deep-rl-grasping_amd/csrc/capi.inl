@@ -211,6 +211,31 @@ int grl_set_obs_stats(grl_handle h, const double* mean, const double* var, doubl
   return GRL_OK;
 }
 
+// Host-to-device copy of a CALLER-owned buffer that the caller may reuse the moment the entry point returns (include/grl.h:
+// "copied before the call returns").  For PAGEABLE memory (NumPy arrays, malloc) hipMemcpyAsync stages the source before it
+// returns -- the documented behaviour of the asynchronous copies for pageable host memory -- so nothing more is needed.  A
+// page-locked or registered source is read by the DMA engine LATER, in stream order: wait for that copy.  GRL_TUNE
+// host_copy_wait=1 waits in every case (a runtime whose pageable path cannot be trusted); tests/test_gpu_api.py mutates
+// the source right after each of these calls.
+static int copy_from_caller(grl_handle h, void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  static const int always = tune_int("host_copy_wait", 0);
+  bool wait = always != 0;
+#ifndef GRL_HOSTEMU
+  if (!wait) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess) wait = at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged;
+    else (void)hipGetLastError();      // unknown to the runtime: pageable
+  }
+#endif
+  if (wait) {
+    if (!h->copy_ev) HIPCHK(hipEventCreateWithFlags(&h->copy_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->copy_ev, h->stream));
+    HIPCHK(hipEventSynchronize(h->copy_ev));
+  }
+  return GRL_OK;
+}
+
 int grl_set_ret_var(grl_handle h, double ret_var) {
   if (!h) return fail(GRL_ERR_INVALID, "null handle");
   const double sd = std::sqrt(ret_var + (double)h->cfg.norm_eps);
@@ -222,8 +247,8 @@ int grl_set_running_stats(grl_handle h, const double* mean, const double* var, d
   if (!h || !mean || !var) return fail(GRL_ERR_INVALID, "null argument");
   if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
   // (rare: once per attach / load; pageable sources are staged before hipMemcpyAsync returns)
-  HIPCHK(hipMemcpyAsync(h->n_mean, mean, (size_t)h->n_elems * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->n_var, var, (size_t)h->n_elems * 8, hipMemcpyHostToDevice, h->stream));
+  if (int e = copy_from_caller(h, h->n_mean, mean, (size_t)h->n_elems * 8)) return e;
+  if (int e = copy_from_caller(h, h->n_var, var, (size_t)h->n_elems * 8)) return e;
   const double c2[2] = {count, count};
   HIPCHK(hipMemcpyAsync(h->n_count, c2, 16, hipMemcpyHostToDevice, h->stream));
   return GRL_OK;
@@ -258,7 +283,7 @@ int grl_norm_update(grl_handle h, const float* obs, int n) {
   if (!h || !obs || n < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (!h->n_mean) return fail(GRL_ERR_STATE, "this handle keeps no running statistics");
   if (n > h->stg_n) return fail(GRL_ERR_INVALID, "more observations than one env step of act_batch environments");
-  HIPCHK(hipMemcpyAsync(h->n_stage, obs, (size_t)n * h->n_elems * 4, hipMemcpyHostToDevice, h->stream));
+  if (int e = copy_from_caller(h, h->n_stage, obs, (size_t)n * h->n_elems * 4)) return e;
   return norm_update_from(h, h->n_stage, n);
 }
 
@@ -331,13 +356,13 @@ int grl_replay_add(grl_handle h, const float* obs, const float* act, const float
   // more than it saves: 77 -> 90 us for 16 transitions, 150 -> 214 us for 64; measured with scripts/act_bench.py)
   for (int k0 = 0; k0 < n; k0 += h->stg_n) {
     const int m = std::min(h->stg_n, n - k0);
-    HIPCHK(hipMemcpyAsync(h->stg_obs, obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->stg_next, next_obs + k0 * oe, (size_t)m * oe * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->stg_act, act + (int64_t)k0 * h->A, (size_t)m * h->A * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->stg_rew, rew + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->stg_done, done + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
-    // (no wait between chunks: the copies are stream-ordered behind the ingest launch that reads the staging buffers, and
-    // hipMemcpyAsync has taken its copy of a pageable source by the time it returns)
+    if (int e = copy_from_caller(h, h->stg_obs, obs + k0 * oe, (size_t)m * oe * 4)) return e;
+    if (int e = copy_from_caller(h, h->stg_next, next_obs + k0 * oe, (size_t)m * oe * 4)) return e;
+    if (int e = copy_from_caller(h, h->stg_act, act + (int64_t)k0 * h->A, (size_t)m * h->A * 4)) return e;
+    if (int e = copy_from_caller(h, h->stg_rew, rew + k0, (size_t)m * 4)) return e;
+    if (int e = copy_from_caller(h, h->stg_done, done + k0, (size_t)m * 4)) return e;
+    // (no wait between chunks for pageable sources: the copies are stream-ordered behind the ingest launch that reads the
+    // staging buffers, and the runtime has taken its copy of the source by the time copy_from_caller returns)
     if (int e = replay_add_dev(h, h->stg_obs, h->stg_act, h->stg_rew, h->stg_next, h->stg_done, m)) return e;
   }
   return GRL_OK;
@@ -383,9 +408,9 @@ int grl_observe(grl_handle h, const float* obs, int n, int flags) {
   if (h->ob_n > 0)   // the previous step's observations become the `obs` side of the next replay rows
     HIPCHK(hipMemcpyAsync(h->ob_prev, h->ob_latest, (size_t)h->ob_n * h->ob_elems * 4, hipMemcpyDeviceToDevice, h->stream));
   h->ob_n_prev = h->ob_n;
-  // (the caller's pageable buffer goes to hipMemcpyAsync as it is -- the runtime has taken its copy when the call returns;
-  //  a bounce through page-locked staging of our own measured slower: 140 vs 126 us per env step of 16 observations, round 4)
-  HIPCHK(hipMemcpyAsync(h->ob_latest, obs, bytes, hipMemcpyHostToDevice, h->stream));
+  // (the caller's buffer goes to hipMemcpyAsync as it is, copy_from_caller; a bounce through page-locked staging of our own
+  //  measured slower: 140 vs 126 us per env step of 16 observations, round 4)
+  if (int e = copy_from_caller(h, h->ob_latest, obs, bytes)) return e;
   h->ob_n = n;
   if (flags & GRL_OBSERVE_UPDATE_STATS) return norm_update_from(h, h->ob_latest, n);
   return GRL_OK;
@@ -897,6 +922,28 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
   h->dp_norm.mom_stride = (int64_t)(dp_mom_bytes(h->n_elems) / 4);
   for (int p = 0; p < h->dp.world; ++p) h->dp_norm.mom[p] = (float*)(data[p] + 3 * dp_arr_bytes(h->n_train));
   h->dp_on = true;
+  return GRL_OK;
+}
+
+int grl_allreduce_disconnect(grl_handle h) {
+  if (!h) return fail(GRL_ERR_INVALID, "null handle");
+  if (!h->dp_buf && !h->dp_flags) return GRL_OK;          // never initialised (or already released): nothing to do
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->drop_graphs();                                        // captured sequences hold the peers' addresses
+  h->dp_on = false;
+  h->dp_overlap = false;
+  h->dp_mode = 0;
+  for (auto* v : {&h->ops_dp, &h->ops_dp1, &h->ops_pfdp_first, &h->ops_pfdp_mid, &h->ops_pfdp_last, &h->ops_pfdp1_first,
+                  &h->ops_pfdp1_mid, &h->ops_pfdp1_last, &h->dp_body, &h->ops_dp_overlap})
+    v->clear();
+  for (int p = 0; p < 2 * DP_MAX_WORLD; ++p)
+    if (h->dp_peer[p]) { (void)hipIpcCloseMemHandle(h->dp_peer[p]); h->dp_peer[p] = nullptr; }
+  if (h->dp_buf) (void)hipFree(h->dp_buf);
+  if (h->dp_flags) (void)hipFree(h->dp_flags);
+  h->dp_buf = h->dp_flags = nullptr;
+  memset(&h->dp, 0, sizeof(h->dp));
+  memset(&h->dp_norm, 0, sizeof(h->dp_norm));
+  if (h->dp_err_host) *h->dp_err_host = 0u;
   return GRL_OK;
 }
 

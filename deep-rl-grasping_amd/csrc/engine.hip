@@ -307,6 +307,7 @@ struct grl_ctx {
   GatherArgs pf_g2;
   std::vector<Op> dp_body;               // ops_grads without its final reduction (the exchange's first kernel forms the sums)
   int dp_mode = 0;                       // 0 auto (one-shot for world <= 2), 1 two-shot, 2 one-shot
+  hipEvent_t copy_ev = nullptr;          // copy_from_caller: completion of a copy whose source is page-locked caller memory
   uint32_t* dp_err_host = nullptr;       // page-locked mailbox: a kernel that gave up waiting for a peer sets it
   DpNormArgs dp_norm;                    // running-statistics merge over the ranks (grl_norm_update on a connected handle)
   std::vector<Op> ops_dp_overlap;        // the whole overlapped update: staged gradients, two exchanges (one on a side lane), Adam
@@ -343,6 +344,7 @@ struct grl_ctx {
     if (dp_buf) (void)hipFree(dp_buf);
     if (dp_flags) (void)hipFree(dp_flags);
     if (dp_err_host) (void)hipHostFree(dp_err_host);
+    if (copy_ev) (void)hipEventDestroy(copy_ev);
     for (auto* l : launches) delete l;
     for (auto e : ev) hipEventDestroy(e);
     for (auto e : lane_ev) hipEventDestroy(e);

@@ -54,6 +54,7 @@ EXPORTS = [
     "grl_observe", "grl_replay_add_observed",
     "grl_norm_update", "grl_set_running_stats", "grl_set_ret_var", "grl_get_obs_stats",
     "grl_allreduce_init", "grl_allreduce_connect", "grl_train_step_allreduce", "grl_allreduce_status", "grl_allreduce_set_overlap", "grl_allreduce_set_mode",
+    "grl_allreduce_disconnect",
 ]
 
 
@@ -98,6 +99,7 @@ def load_library(path=None):
     lib.grl_train_step_per.argtypes = [vp, C.c_int, C.c_double, vp]
     lib.grl_allreduce_init.argtypes = [vp, i32, i32, vp]
     lib.grl_allreduce_connect.argtypes = [vp, vp]
+    lib.grl_allreduce_disconnect.argtypes = [vp]
     lib.grl_allreduce_set_overlap.argtypes = [vp, i32]
     lib.grl_allreduce_set_mode.argtypes = [vp, i32]
     lib.grl_train_step_allreduce.argtypes = [vp, i32, vp, vp]

@@ -191,6 +191,11 @@ class SacEngine:
         blob = b"".join(handles)
         check(self.lib, self.lib.grl_allreduce_connect(self.h, C.c_char_p(blob)))
 
+    def allreduce_disconnect(self):
+        """Back to a single-process handle: peers unmapped, exchange memory freed (grl_allreduce_disconnect).  The caller
+        makes sure no exchange is in flight on any rank (DataParallelInGraph.close)."""
+        check(self.lib, self.lib.grl_allreduce_disconnect(self.h))
+
     def allreduce_set_overlap(self, on=True):
         """Exchange the dense bucket on a side lane of the update's graph while the convolution backward runs
         (include/grl.h: grl_allreduce_set_overlap).  Raises when the configuration has no staged plan."""

@@ -121,6 +121,18 @@ class DataParallelSac:
                 step(idx[s:s + 1], eps[s:s + 1])
 
 
+class ExchangeSetupError(RuntimeError):
+    """Raised by every rank of the group when any of them could not set up the in-graph exchange."""
+
+
+def vote_all(flag, group=None):
+    """True on every rank iff `flag` is true on all of them (one MIN all-reduce; device tensor under RCCL)."""
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
+
+
 class DataParallelInGraph:
     """The exchange inside the library (include/grl.h: grl_allreduce_init / connect / grl_train_step_allreduce,
     csrc/dp_kernels.h): hand-written all-reduces over IPC-mapped exchange buffers, captured in the update's hipGraph --
@@ -133,19 +145,42 @@ class DataParallelInGraph:
     EVERY rank (the channel is poisoned: no replica applies a partial exchange silently)."""
 
     def __init__(self, engine, group=None, overlap=False, mode="auto"):
+        """COLLECTIVE, and fail-safe as a collective: set-up is three local phases (allocate + export, map the peers,
+        configure), each followed by a vote over the group, so every rank executes the same sequence of collectives
+        whatever failed where.  If any rank fails a phase, EVERY rank releases what it had set up
+        (grl_allreduce_disconnect: the handle is a plain single-process handle again, `grl_norm_update` no longer waits
+        for peers) and raises ``ExchangeSetupError`` from the same place -- callers can fall back together."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.eng, self.group = engine, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        mine = engine.allreduce_init(self.rank, self.world)
+        self.overlap, self.mode = bool(overlap), mode
+        err = [None]
+
+        def phase(fn):
+            try:
+                out = fn()
+            except Exception as e:       # noqa: BLE001  (hipIpc unavailable, a peer's handle that does not map, no staged plan ...)
+                err[0], out = e, None
+            if vote_all(err[0] is None, group):
+                return out
+            try:
+                engine.allreduce_disconnect()
+            except Exception:            # noqa: BLE001
+                pass
+            raise ExchangeSetupError("in-graph exchange set-up failed on %s" % (
+                "this rank (%d): %s" % (self.rank, err[0]) if err[0] is not None else "a peer rank")) from err[0]
+
+        mine = phase(lambda: engine.allreduce_init(self.rank, self.world))
         handles = [None] * self.world
         dist.all_gather_object(handles, mine, group=group)
-        engine.allreduce_connect(handles)
-        self.overlap = bool(overlap)
-        self.mode = mode
-        engine.allreduce_set_mode(mode)
-        if self.overlap:                   # dense bucket exchanged on a side lane of the graph, under the conv backward
-            engine.allreduce_set_overlap(True)
+
+        def connect():
+            engine.allreduce_connect(handles)
+            engine.allreduce_set_mode(mode)
+            if self.overlap:               # dense bucket exchanged on a side lane of the graph, under the conv backward
+                engine.allreduce_set_overlap(True)
+        phase(connect)
         dist.barrier(group=group)          # every rank has mapped every buffer before the first exchange starts
 
     def set_mode(self, mode=None, overlap=None):
@@ -179,11 +214,15 @@ class DataParallelInGraph:
         """Synchronises; raises if an exchange timed out.  Returns the number of exchanges begun."""
         return self.eng.allreduce_status()
 
-    def close(self):
+    def close(self, disconnect=False):
         """Collective: every rank drains its stream and meets the others BEFORE any of them releases its engine -- a peer's
-        kernels read this rank's exchange memory until their last exchange has completed."""
+        kernels read this rank's exchange memory until their last exchange has completed.  ``disconnect``: also unmap the
+        peers and free the exchange memory (after a second barrier: nobody unmaps what a peer is still closing)."""
         self.eng.synchronize()
         dist.barrier(group=self.group)
+        if disconnect:
+            self.eng.allreduce_disconnect()
+            dist.barrier(group=self.group)
 
 
 def launched_world():
@@ -245,17 +284,14 @@ class DataParallelRuntime:
     def make_exchange(self, engine, prefer="ingraph", overlap=False, mode="auto"):
         """The gradient exchange for `engine`: in-graph over IPC-mapped memory when every rank can set it up, else
         (or with prefer="collective") compute -> all-reduce -> apply (``DataParallelSac``: RCCL, or gloo where the ranks
-        do not own a GPU each).  The decision is COLLECTIVE: a rank whose set-up fails still takes part in every
-        collective of the fallback."""
-        ok, dp = True, None
+        do not own a GPU each).  The decision is COLLECTIVE: ``DataParallelInGraph`` votes after each of its set-up
+        phases and raises on every rank or on none (``self.ingraph_error`` keeps the reason)."""
+        self.ingraph_error = None
         if prefer == "ingraph":
             try:
-                dp = DataParallelInGraph(engine, group=self.ctrl, overlap=overlap, mode=mode)
-            except Exception as e:       # noqa: BLE001  (hipIpc unavailable, no staged plan for `overlap`, ...)
-                ok = False
+                return DataParallelInGraph(engine, group=self.ctrl, overlap=overlap, mode=mode)
+            except ExchangeSetupError as e:       # raised on EVERY rank after the same collectives: all of them fall back
                 self.ingraph_error = e
-            if self.all(ok):
-                return dp
         # a collective library: RCCL with one GPU per rank, gloo otherwise (CPU tests, several ranks sharing a GPU)
         if torch.cuda.is_available() and not os_same_device():
             if dist.get_backend() == "nccl":

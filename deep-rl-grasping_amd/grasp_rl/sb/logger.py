@@ -69,6 +69,11 @@ def info(*args):
 warn = error = debug = log = info
 
 
+def warn(*args):
+    import sys
+    print("WARNING:", *args, file=sys.stderr)
+
+
 class SummaryWriter:
     """Stand-in for the ``tf.summary.FileWriter`` stable-baselines hands to callbacks as ``locals['writer']``
     when ``tensorboard_log`` is set (the reference's TensorboardCallback calls

@@ -7,6 +7,10 @@ import json
 import os
 import time
 
+# number of the environment being constructed in this process (set by grasp_rl.sb.vec_env._RankedEnvFn around the factory
+# call inside a fan-out worker; 0 everywhere else): environment k > 0 logs to <filename>.env<k>.monitor.csv
+ENV_RANK = 0
+
 
 class Monitor:
     EXT = "monitor.csv"
@@ -18,6 +22,11 @@ class Monitor:
         self.t_start = time.time()
         self.file_handler, self.logger = None, None
         if filename is not None:
+            if ENV_RANK > 0 and not os.path.isdir(filename):
+                stem = filename[:-len(Monitor.EXT) - 1] if filename.endswith("." + Monitor.EXT) else filename
+                filename = "%s.env%d" % (stem, ENV_RANK)
+            elif ENV_RANK > 0:
+                filename = os.path.join(filename, "env%d" % ENV_RANK)
             if not filename.endswith(Monitor.EXT):
                 filename = os.path.join(filename, Monitor.EXT) if os.path.isdir(filename) else filename + "." + Monitor.EXT
             self.file_handler = open(filename, "wt")

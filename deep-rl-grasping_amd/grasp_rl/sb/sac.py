@@ -42,7 +42,7 @@ from . import policies as pol
 from . import save_util
 from . import spaces as sp
 from .callbacks import as_callback
-from .vec_env import DummyVecEnv, VecEnv, unwrap_vec_normalize
+from .vec_env import DummyVecEnv, VecEnv, expand_training_env, unwrap_vec_normalize
 
 _POLICY_NAMES = {"MlpPolicy": pol.SacMlpPolicy, "CnnPolicy": pol.SacCnnPolicy, "LnMlpPolicy": pol.SacLnMlpPolicy,
                  "LnCnnPolicy": pol.SacLnCnnPolicy}
@@ -118,6 +118,10 @@ class SAC:
         if env is not None and not isinstance(env, VecEnv) and not hasattr(env, "num_envs"):
             env = DummyVecEnv([lambda: env])
         if env is not None:
+            # GRL_NUM_ENVS: the env a model is handed is its TRAINING env -- the one the reference's script wraps as
+            # DummyVecEnv([one factory]) (train_stable_baselines.py:52-54) fans out to worker processes here (row J3)
+            rt = self._dp_runtime()
+            env = expand_training_env(env, rank=0 if rt is None else rt.rank, world=1 if rt is None else rt.world)
             if self.observation_space is not None and tuple(env.observation_space.shape) != tuple(self.observation_space.shape):
                 raise ValueError("observation space of the new env does not match the model")
             self.observation_space, self.action_space = env.observation_space, env.action_space
@@ -278,6 +282,13 @@ class SAC:
         callback = as_callback(callback if lead else None)      # data parallel: evaluation / checkpoints / logging on rank 0 only
         callback.init_callback(self)
         eng, vn, N = self.engine, self._vec_normalize_env, self.n_envs
+        device_norm = self.device_norm
+        if rt is not None and device_norm and not hasattr(dp, "check"):
+            # the device-side merge of the statistics rides on the in-graph exchange's channel; with the collective
+            # fallback (RCCL / gloo) the handle is not connected and every replica would keep its own observation
+            # statistics: take the host path, whose moments are gathered over the ranks below
+            logger.warn("device_norm needs the in-graph exchange; this job fell back to a collective library -> host statistics")
+            device_norm = False
         if rt is not None and vn is not None:       # running statistics merged over the ranks (ret_rms always on the host)
             from ..parallel import share_running_stats
             share_running_stats(vn, rt.ctrl)
@@ -290,20 +301,29 @@ class SAC:
         start = time.time()
         # stable-baselines hands callbacks a FileWriter when tensorboard_log is set, None otherwise
         writer = logger.SummaryWriter(self.tensorboard_log, tb_log_name) if self.tensorboard_log else None
-        if self.device_norm and vn is not None and vn.norm_obs and eng.cfg.normalize in (1, 2):
+        if device_norm and vn is not None and vn.norm_obs and eng.cfg.normalize in (1, 2):
             vn.attach_device(eng)
             self._norm_stamp = None
+        finished = False
         try:
             self._learn_loop(total_timesteps, callback, log_interval, writer, rt, dp, W, lead, eng, vn, N, episode_rewards,
                              episode_successes, ep_info_buf, start)
+            finished = True
         finally:
             if vn is not None and vn._dev is not None:     # whatever ended the loop: the wrapper carries the statistics again
                 vn.detach_device()
                 self._norm_stamp = None
+            if rt is not None and vn is not None:          # the collective hook must not outlive the collective loop: a later
+                for rms in (vn.obs_rms, vn.ret_rms):       # step of this env on ONE rank (the script's own evaluation run on
+                    rms.__dict__.pop("gather", None)       # rank 0) would wait in all_gather for peers that have left
             if writer is not None:
                 writer.close()
         if dp is not None and hasattr(dp, "check"):
             dp.check()                  # raises if an exchange timed out (replicas out of step)
+        if dp is not None and finished and hasattr(dp, "close"):
+            # collective (every rank left the loop in the same iteration): drain + barrier, so that no rank goes on to
+            # release its engine -- and with it the exchange memory its peers' last kernels pull from -- early
+            dp.close()
         return self
 
     def _learn_loop(self, total_timesteps, callback, log_interval, writer, rt, dp, W, lead, eng, vn, N, episode_rewards,
@@ -330,7 +350,9 @@ class SAC:
                 # the updates that follow vectorised env step `step_index` (0-based): N * step_index environment steps
                 # precede it -- the same count in the strict and in the overlapped order
                 callback.on_rollout_end()
-                k = N if self.gradient_steps is None else int(self.gradient_steps)
+                # None: one update per ENVIRONMENT step of the JOB -- N * W of them happen per vectorised step, and under data
+                # parallelism every update consumes the global minibatch on all ranks at once
+                k = N * W if self.gradient_steps is None else int(self.gradient_steps)
                 done_steps = N * W * step_index
                 if k > 0 and eng.replay_size() >= self._local_batch and done_steps + N * W >= self.learning_starts:
                     self.n_updates += k

@@ -35,26 +35,96 @@ class VecEnv:
         return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
 
 
+class _RankedEnvFn:
+    """``fn`` called with the number of the environment it builds announced to ``grasp_rl.sb.monitor`` first, so that the
+    ``Monitor(env, filename)`` inside an opaque factory (train_stable_baselines.py:54: one lambda, one file name) writes
+    ``<filename>.env<k>.monitor.csv`` for k > 0 instead of N workers truncating one file (``load_results`` globs
+    ``*monitor.csv``; environment 0 keeps the name a single-env run uses)."""
+
+    def __init__(self, fn, rank):
+        self.fn, self.rank = fn, int(rank)
+
+    def __call__(self):
+        from . import monitor
+        monitor.ENV_RANK = self.rank
+        try:
+            return self.fn()
+        finally:
+            monitor.ENV_RANK = 0
+
+
 class DummyVecEnv(VecEnv):
     """Steps its environments sequentially in this process; resets an env automatically when its
-    episode ends (the terminal observation is kept in info['terminal_observation'])."""
+    episode ends (the terminal observation is kept in info['terminal_observation']).
+
+    ``fan_out(n)`` (row J3: "vectorised PyBullet envs fan out across host cores", reached from the reference's unmodified
+    ``DummyVecEnv([lambda: Monitor(gym.make(...), ...)])``, train_stable_baselines.py:52-54): the ONE factory this object
+    was built from is called in n worker processes (``SubprocVecEnv``) and every VecEnv call is forwarded there; the
+    instance built in this process stays in ``.envs`` as a template for the static questions the reference asks before it
+    constructs the model (``env.envs[0].is_simplified()`` / ``.depth_obs`` / ``.full_obs``, sb_helper.py:86-91) and is
+    closed -- the simulators that are stepped live in the workers (``get_attr('history')`` etc., sb_helper.py:42-45, go
+    there).  ``grasp_rl.sb.SAC`` calls it on its TRAINING env when GRL_NUM_ENVS > 1 (`expand_training_env`); evaluation
+    envs are never handed to a model constructor and stay single."""
 
     def __init__(self, env_fns):
-        self.envs = [fn() for fn in env_fns]
+        self._env_fns = list(env_fns)
+        self._fan = None
+        self.envs = [fn() for fn in self._env_fns]
         env = self.envs[0]
         super().__init__(len(self.envs), env.observation_space, env.action_space)
+        self._alloc()
+        self.actions = None
+
+    def _alloc(self):
         shape = tuple(self.observation_space.shape)
         dtype = getattr(self.observation_space, "dtype", np.float32)
         self.buf_obs = np.zeros((self.num_envs,) + shape, dtype=dtype)
         self.buf_dones = np.zeros((self.num_envs,), dtype=bool)
         self.buf_rews = np.zeros((self.num_envs,), dtype=np.float32)
         self.buf_infos = [{} for _ in range(self.num_envs)]
-        self.actions = None
+
+    # -- fan-out ----------------------------------------------------------------------------------------------------
+    @property
+    def fanned_out(self):
+        return self._fan is not None
+
+    def fan_out(self, n, envs_per_worker=1, start_method=None, first_rank=0, seed=None):
+        """Replace the single in-process environment by n worker processes built from the same factory.  `first_rank`:
+        number of this object's first environment within the job (data parallel: rank * n), used for Monitor file names
+        and seeds.  Idempotent for the same n."""
+        n = int(n)
+        if self._fan is not None:
+            if n != self.num_envs:
+                raise ValueError("this DummyVecEnv already fans out to %d environments" % self.num_envs)
+            return self
+        if len(self._env_fns) != 1:
+            raise ValueError("fan_out multiplies ONE environment factory; this DummyVecEnv was built from %d" % len(self._env_fns))
+        if n < 1:
+            raise ValueError("fan_out needs n >= 1")
+        for env in self.envs:                    # the template's Monitor file / simulator: environment 0 of the workers owns them now
+            if hasattr(env, "close"):
+                try:
+                    env.close()
+                except Exception:                # noqa: BLE001  (a simulator that cannot close twice must not stop training)
+                    pass
+        fns = [_RankedEnvFn(self._env_fns[0], first_rank + k) for k in range(n)]
+        self._fan = SubprocVecEnv(fns, start_method=start_method, envs_per_worker=envs_per_worker)
+        self.num_envs = n
+        self._alloc()
+        if seed is not None:
+            self._fan.seed(int(seed) + first_rank)
+        return self
 
     def step_async(self, actions):
+        if self._fan is not None:
+            return self._fan.step_async(actions)
         self.actions = actions
 
     def step_wait(self):
+        if self._fan is not None:
+            out = self._fan.step_wait()
+            self.buf_infos = self._fan.buf_infos
+            return out
         for i, env in enumerate(self.envs):
             obs, self.buf_rews[i], self.buf_dones[i], self.buf_infos[i] = env.step(self.actions[i])
             if self.buf_dones[i]:
@@ -65,19 +135,27 @@ class DummyVecEnv(VecEnv):
         return self.buf_obs.copy(), self.buf_rews.copy(), self.buf_dones.copy(), list(self.buf_infos)
 
     def reset(self):
+        if self._fan is not None:
+            return self._fan.reset()
         for i, env in enumerate(self.envs):
             self.buf_obs[i] = env.reset()
         return self.buf_obs.copy()
 
     def close(self):
+        if self._fan is not None:
+            return self._fan.close()             # (the template was closed when the workers took over)
         for env in self.envs:
             if hasattr(env, "close"):
                 env.close()
 
     def render(self, *a, **k):
+        if self._fan is not None:
+            return self._fan.render(*a, **k)
         return self.envs[0].render(*a, **k)
 
     def seed(self, seed=None):
+        if self._fan is not None:
+            return self._fan.seed(seed)
         return [env.seed(None if seed is None else seed + i) if hasattr(env, "seed") else None
                 for i, env in enumerate(self.envs)]
 
@@ -89,13 +167,19 @@ class DummyVecEnv(VecEnv):
         return [self.envs[i] for i in indices]
 
     def get_attr(self, name, indices=None):
+        if self._fan is not None:
+            return self._fan.get_attr(name, indices)
         return [getattr(e, name) for e in self._targets(indices)]
 
     def set_attr(self, name, value, indices=None):
+        if self._fan is not None:
+            return self._fan.set_attr(name, value, indices)
         for e in self._targets(indices):
             setattr(e, name, value)
 
     def env_method(self, name, *args, indices=None, **kwargs):
+        if self._fan is not None:
+            return self._fan.env_method(name, *args, indices=indices, **kwargs)
         return [getattr(e, name)(*args, **kwargs) for e in self._targets(indices)]
 
 
@@ -677,3 +761,48 @@ def sync_envs_normalization(env, eval_env):
             b.obs_rms = copy.deepcopy(a.obs_rms)
             b.ret_rms = copy.deepcopy(a.ret_rms)
         a, b = a.venv, b.venv
+
+
+def requested_num_envs(world=1):
+    """GRL_NUM_ENVS: how many environments the JOB trains on (the knob the reference's CLI does not have: its script
+    wraps one env, train_stable_baselines.py:52-54; BASELINE configs[1] = 16, configs[4] = 64 over 8 ranks).  Returns this
+    process's share, or None when the variable is not set."""
+    raw = os.environ.get("GRL_NUM_ENVS", "").strip()
+    if not raw:
+        return None
+    n = int(raw)
+    if n < 1:
+        raise ValueError("GRL_NUM_ENVS must be a positive integer, got %r" % raw)
+    if n % max(1, world):
+        raise ValueError("GRL_NUM_ENVS=%d environments do not divide over %d ranks" % (n, world))
+    return n // max(1, world)
+
+
+def expand_training_env(env, n=None, rank=0, world=1):
+    """The training env a model was handed, fanned out to this process's share of GRL_NUM_ENVS worker environments when
+    it is (a wrapper chain around) a single-factory ``DummyVecEnv``; anything else -- no request, a request of 1, an env
+    that already is vectorised by its maker -- is returned as it is.  Wrappers built around the single env before the
+    model existed (sb_helper.py:117-119 wraps VecNormalize first) get their per-env state re-sized.
+    GRL_ENVS_PER_WORKER (default 1), GRL_ENV_START_METHOD (forkserver | spawn | fork; fork only before HIP is
+    initialised) and GRL_ENV_SEED (env k of the job is seeded GRL_ENV_SEED + k) tune the workers."""
+    if n is None:
+        n = requested_num_envs(world)
+    if n is None or env is None:
+        return env
+    chain, inner = [], env
+    while isinstance(inner, VecEnvWrapper):
+        chain.append(inner)
+        inner = inner.venv
+    if not isinstance(inner, DummyVecEnv):
+        return env
+    if inner.fanned_out or (n > 1 and len(getattr(inner, "_env_fns", ())) == 1):
+        seed = os.environ.get("GRL_ENV_SEED")
+        inner.fan_out(n, envs_per_worker=int(os.environ.get("GRL_ENVS_PER_WORKER", "1")),
+                      start_method=os.environ.get("GRL_ENV_START_METHOD") or None, first_rank=rank * n,
+                      seed=None if seed in (None, "") else int(seed))
+    for w in chain:
+        if w.num_envs != inner.num_envs:
+            w.num_envs = inner.num_envs
+            if isinstance(w, VecNormalize):
+                w.ret = np.zeros(w.num_envs)
+    return env

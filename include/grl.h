@@ -225,6 +225,12 @@ int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const 
                             exchanges the handles of all ranks out of band (any transport: files, MPI,
                             torch.distributed.all_gather_object);
      grl_allreduce_connect  handles = world x GRL_ALLREDUCE_HANDLE_BYTES in rank order; maps the peers' memory;
+     grl_allreduce_disconnect   host (synchronises this handle's stream): unmaps the peers, frees the exchange memory, and
+                            the handle is a single-process handle again (grl_norm_update / grl_observe no longer merge over
+                            ranks; grl_allreduce_init may be called anew).  For a set-up that failed on SOME rank -- every
+                            rank then releases what it had and the job falls back together -- and for an orderly end of
+                            training.  The caller guarantees that no exchange is in flight on any rank (drain, barrier).
+                            No-op on a handle that was never initialised;
      grl_train_step_allreduce   n_steps data-parallel updates, each ONE graph: minibatch from this rank's replay shard,
                             gradients, exchange, Adam + Polyak with the mean gradient -- what grl_compute_grads ->
                             all-reduce -> grl_apply_grads(1 / world) does with a collective library in between.  Every
@@ -244,6 +250,7 @@ int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const 
 #define GRL_ALLREDUCE_HANDLE_BYTES 128
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out);
 int grl_allreduce_connect(grl_handle h, const void* handles);
+int grl_allreduce_disconnect(grl_handle h);
 int grl_allreduce_set_overlap(grl_handle h, int on);
 int grl_allreduce_set_mode(grl_handle h, int mode);
 int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps);

@@ -13,7 +13,7 @@ class _Curriculum:
 
 class FakeGraspEnv:
     def __init__(self, kind="depth", episode_len=7, seed=0, vector_dim=None, discrete_actions=None, act_dim=5):
-        self._rng = np.random.default_rng(seed)
+        self._rng = np.random.default_rng(seed)       # seed=None: OS entropy (fan-out workers built from ONE factory)
         self.vector_dim = vector_dim
         if vector_dim:
             self.observation_space = Box(-1.0, 1.0, shape=(vector_dim,), dtype=np.float32)

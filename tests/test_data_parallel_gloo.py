@@ -193,8 +193,67 @@ def test_model_learn_as_one_replica_of_two(hostemu_lib, tmp_path):
     r1 = np.load(os.path.join(str(tmp_path), "learn1.npz"))
     assert int(r0["calls"]) > 0 and int(r1["calls"]) == 0
     assert int(r0["steps"]) == int(r1["steps"]) == 40                  # 2 ranks x 2 envs per vectorised step
-    assert int(r0["updates"]) == int(r1["updates"]) > 0 and int(r0["replay"]) == int(r1["replay"]) == 18   # (the stopping step is not stored)
+    assert int(r0["replay"]) == int(r1["replay"]) == 18                # (the stopping step is not stored)
+    # gradient_steps=None = one update per ENVIRONMENT step of the job: 2 ranks x 2 envs = 4 updates (each on the global
+    # minibatch) per vectorised step, from the step that reaches learning_starts = 8 to the one before the stop
+    assert int(r0["updates"]) == int(r1["updates"]) == 4 * 8
     for k in r0.files:
         if k != "calls":
             assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
     assert float(r0["obs_count"]) == pytest.approx(1e-4 + 2 * 2 * 11)   # reset + 10 steps, both ranks' batches merged
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# set-up of the in-graph exchange is collective and fail-safe: whatever fails on whichever rank, every rank executes the
+# same collectives, releases what it had set up and takes the fallback together (ADVICE r4 / VERDICT r4 "Next 1b")
+def _fallback_worker(rank, world, port, lib, out_dir, fail_phase, fail_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from grasp_rl.parallel import DataParallelInGraph, DataParallelRuntime, ExchangeSetupError
+    rt = DataParallelRuntime()                     # initialises gloo from the launcher variables
+    case = _case()
+    case["cfg"] = _shard_cfg(case["cfg"], B // world)
+    eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=lib)
+    calls = []
+    if rank == fail_rank:
+        real = getattr(eng, fail_phase)
+
+        def broken(*a, **k):
+            calls.append(fail_phase)
+            if fail_phase == "allreduce_connect":
+                real(*a, **k)                      # the mapping itself worked; what follows it does not
+            raise RuntimeError("injected: %s fails on rank %d" % (fail_phase, rank))
+        setattr(eng, fail_phase, broken)
+    # the constructor raises on EVERY rank, from the same place
+    with pytest.raises(ExchangeSetupError) as ei:
+        DataParallelInGraph(eng, group=rt.ctrl)
+    assert ("this rank" in str(ei.value)) == (rank == fail_rank)
+    # ... and left a plain handle behind on every rank: a fresh initialisation is accepted, device statistics do not wait for peers
+    if rank == fail_rank:
+        setattr(eng, fail_phase, real)
+    eng.allreduce_init(rank, world)
+    eng.allreduce_disconnect()
+    eng.allreduce_disconnect()                     # idempotent
+    # make_exchange: everyone lands on the collective fallback and trains in step
+    if rank == fail_rank:
+        setattr(eng, fail_phase, broken)
+    dp = rt.make_exchange(eng, prefer="ingraph")
+    assert isinstance(dp, DataParallelSac) and isinstance(rt.ingraph_error, ExchangeSetupError)
+    dp.broadcast_parameters(src=0)
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    dp.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+    P = eng.get_parameters()
+    np.savez(os.path.join(out_dir, "fb%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_phase,fail_rank", [("allreduce_init", 1), ("allreduce_connect", 0)])
+def test_exchange_setup_failure_on_one_rank_falls_back_on_all(hostemu_lib, tmp_path, fail_phase, fail_rank):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_fallback_worker, args=(2, port, hostemu_lib, str(tmp_path), fail_phase, fail_rank), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "fb0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "fb1.npz"))
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k

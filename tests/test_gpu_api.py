@@ -104,3 +104,91 @@ def test_learning_on_observations_uploaded_once_equals_the_separate_uploads_gpu(
     assert r0[2].sum() > 0          # episodes ended: terminal rows went through the row map
     for k in p0:
         assert np.array_equal(p0[k], p1[k]), k
+
+
+def test_caller_buffers_are_copied_before_the_call_returns_gpu():
+    """include/grl.h promises that host buffers handed to grl_replay_add / grl_observe / grl_norm_update /
+    grl_set_running_stats are copied before the call returns (capi.inl: copy_from_caller -- pageable sources are staged by
+    the runtime, page-locked ones are waited for).  ADVICE r4: the Python wrappers free their temporaries right after the
+    call, so the source is overwritten HERE the moment each call returns, while the stream is still busy with 64 queued
+    updates; the ring and the statistics must hold the original values.  Pageable (NumPy) and page-locked (pinned torch
+    tensor) sources."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from grasp_rl import _capi
+    from grasp_rl._capi import check
+    from grasp_rl.engine import SacEngine
+    from grasp_rl.init import init_parameters
+    n = 8
+    cfg = _capi.make_config("augmented", obs_channels=2, n_direct=1, act_dim=5, layers=(64, 64), batch_size=32, replay_capacity=64,
+                            normalize=True, act_batch=n)
+    eng = SacEngine(cfg, device="cuda:0")
+    try:
+        eng.set_parameters(init_parameters(eng.table, seed=1))
+        rng = np.random.default_rng(0)
+
+        def fresh(pinned, *shape):
+            x = rng.uniform(0.1, 1.0, shape).astype(np.float32)
+            if pinned:
+                t = torch.from_numpy(x).pin_memory()
+                return t.numpy(), x.copy(), t
+            return x, x.copy(), None
+        for pinned in (False, True):
+            keep = []
+            obs, obs0, k1 = fresh(pinned, n, 64, 64, 2)
+            nxt, nxt0, k2 = fresh(pinned, n, 64, 64, 2)
+            act, act0, k3 = fresh(pinned, n, 5)
+            rew, rew0, k4 = fresh(pinned, n)
+            done = np.zeros(n, np.float32)
+            keep += [k1, k2, k3, k4]
+            if eng.replay_size() >= 32:
+                eng.train(64)                                    # the stream is busy for ~10 ms from here on
+            first = eng.replay_size() % 64
+            check(eng.lib, eng.lib.grl_replay_add(eng.h, obs.ctypes.data, act.ctypes.data, rew.ctypes.data, nxt.ctypes.data,
+                                                  done.ctypes.data, n))
+            obs[...] = -7.0; nxt[...] = -7.0; act[...] = -7.0; rew[...] = -7.0      # noqa: E702
+            ring_obs = eng.fetch("rp_obs").reshape(64, 4096)
+            ring_next = eng.fetch("rp_next").reshape(64, 4096)
+            rows = [(first + k) % 64 for k in range(n)]
+            assert np.array_equal(ring_obs[rows], obs0[..., 0].reshape(n, 4096)), "pinned=%s" % pinned
+            assert np.array_equal(ring_next[rows], nxt0[..., 0].reshape(n, 4096))
+            assert np.array_equal(eng.fetch("rp_act").reshape(64, -1)[rows][:, :5], act0)
+            assert np.array_equal(eng.fetch("rp_rew")[rows], rew0)
+            # the statistics entry points
+            for _ in range(4):                                   # fill the ring so that updates can run
+                eng.replay_add(obs0, act0, rew0, nxt0, done)
+            mean = rng.uniform(0, 1, (64, 64, 2))
+            var = rng.uniform(0.5, 1.5, (64, 64, 2))
+            m, m0, k5 = (mean, mean.copy(), None)
+            v, v0, k6 = (var, var.copy(), None)
+            eng.train(64)
+            check(eng.lib, eng.lib.grl_set_running_stats(eng.h, m.ctypes.data, v.ctypes.data, 100.0))
+            m[...] = -1.0; v[...] = -1.0                          # noqa: E702
+            gm, gv, gc = eng.get_obs_stats((64, 64, 2))
+            assert np.array_equal(gm, m0) and np.array_equal(gv, v0) and gc == 100.0
+            o2, o20, k7 = fresh(pinned, n, 64, 64, 2)
+            ref_m, ref_v, ref_c = _chan(m0, v0, 100.0, o20)
+            eng.train(64)
+            check(eng.lib, eng.lib.grl_observe(eng.h, o2.ctypes.data, n, 1))
+            o2[...] = 55.0
+            gm, gv, gc = eng.get_obs_stats((64, 64, 2))
+            assert gc == ref_c and np.array_equal(gm, ref_m) and np.array_equal(gv, ref_v), "grl_observe, pinned=%s" % pinned
+            o3, o30, k8 = fresh(pinned, n, 64, 64, 2)
+            ref_m, ref_v, ref_c = _chan(ref_m, ref_v, ref_c, o30)
+            eng.train(64)
+            check(eng.lib, eng.lib.grl_norm_update(eng.h, o3.ctypes.data, n))
+            o3[...] = 55.0
+            gm, gv, gc = eng.get_obs_stats((64, 64, 2))
+            assert gc == ref_c and np.array_equal(gm, ref_m) and np.array_equal(gv, ref_v), "grl_norm_update, pinned=%s" % pinned
+            del keep
+    finally:
+        eng.close()
+
+
+def _chan(mean, var, count, batch):
+    from grasp_rl.sb.running_mean_std import RunningMeanStd
+    r = RunningMeanStd(shape=mean.shape)
+    r.mean, r.var, r.count = mean.copy(), var.copy(), count
+    r.update(batch)
+    return r.mean, r.var, r.count

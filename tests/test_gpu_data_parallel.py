@@ -169,8 +169,11 @@ def _ingraph_worker(rank, world, port, out_dir):
     B = max(16, 4 * world)      # (a per-rank minibatch of at least 4 rows: below that the dense weight gradients leave the
     #                              vectorised kernel and the plan has no staged form to overlap)
     cases = {}
-    if world < 8:       # (W = 2 and 4 run every variant on the CNN shape; eight time-sliced processes take two minutes for it)
-        cases["cnn"] = pu.make_case(extractor="augmented", kind="depth", B=B, n_replay=48, n_steps=STEPS)
+    # W = 2 and 4 run every variant on the CNN shape with the device-RNG / variant-switch extras; eight time-sliced processes
+    # took two minutes for that, so W = 8 runs the CNN bucket (1 342 992 floats, 8 chunks of 167 874 -> rup 4) LIGHT: one-shot
+    # and two-shot against the rank-ordered sum on the explicit minibatches only
+    cases["cnn"] = pu.make_case(extractor="augmented", kind="depth", B=B, n_replay=48, n_steps=STEPS)
+    light = world >= 8
     if world >= 8:
         # the smallest SAC there is: a bucket of 84 floats -- not a multiple of 4 * world, rank 6's chunk short, rank 7's EMPTY
         # (capi.inl: chunk = rup(ceil(n / world), 4))
@@ -191,7 +194,7 @@ def _ingraph_worker(rank, world, port, out_dir):
                 assert np.array_equal(Pg[k], Pref[k]), "rank-ordered sum differs from the gloo exchange: " + k
         finals = []
         for mode, overlap in VARIANTS:
-            if overlap and cname == "tiny":
+            if overlap and (cname == "tiny" or light):
                 continue                              # (vector observations have no staged plan)
             eng = pu.engine_setup(case)
             dp = DataParallelInGraph(eng, overlap=overlap, mode=mode)
@@ -202,6 +205,11 @@ def _ingraph_worker(rank, world, port, out_dir):
             P = eng.get_parameters()
             for k in P:
                 assert np.array_equal(P[k], Pref[k]), "%s / %s%s: differs from the rank-ordered sum: %s" % (cname, mode, "+overlap" if overlap else "", k)
+            if light and cname == "cnn":
+                finals.append(P)
+                dp.close()
+                eng.close()
+                continue
             # and on the device RNG, several updates per call (the same seed and replay contents on every rank, so even
             # these must leave identical replicas), then a switch of the variant on the idle handle
             dp.train(5)
@@ -226,12 +234,13 @@ def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
     the hand-written all-reduces inside the graph -- one-shot, two-shot, two-shot with the dense bucket overlapped: each
     bit-identical to the rank-ordered float32 sum formed on the host (for W = 2 also to the gloo exchange), the replicas
     bit-identical to each other (also after updates on the device RNG and a switch of the variant).  W = 8 adds the
-    smallest bucket there is: ragged chunks, the last one empty (W = 8 runs only that one: one-shot and two-shot)."""
+    smallest bucket there is: ragged chunks, the last one empty; its CNN-bucket pass is the light one (one-shot and two-shot
+    on the explicit minibatches)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_ingraph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    for cname in ("tiny",) if world >= 8 else ("cnn",):
+    for cname in ("cnn", "tiny") if world >= 8 else ("cnn",):
         parts = [np.load(os.path.join(str(tmp_path), "ig_%s_%d.npz" % (cname, r))) for r in range(world)]
         for p in parts[1:]:
             for k in parts[0].files:
@@ -353,28 +362,141 @@ def _learn_worker(rank, world, port, out_dir, device_norm):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("device_norm", [False, True])
-def test_model_learn_two_replicas_on_one_gpu(tmp_path, device_norm):
+def test_model_learn_two_replicas_on_one_gpu(tmp_path):
     """SAC(data_parallel=True).learn, two processes: the in-graph exchange behind `model.learn`, running statistics merged
     over the ranks on the host (share_running_stats) or on the device (grl_norm_update on a connected handle).  Each
     replica reaches exactly the parameters of an engine driven by the DataParallelInGraph wrapper alone on the recorded
-    schedule (what bench.py does), and the replicas -- parameters and statistics -- are bit-identical."""
+    schedule (what bench.py does), and the replicas -- parameters and statistics -- are bit-identical.  The statistics the
+    two paths end with are the same bits: both restate RunningMeanStd over the gathered batches."""
+    stats = {}
+    for device_norm in (False, True):
+        out = tmp_path / ("dev" if device_norm else "host")
+        out.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_learn_worker, args=(2, port, str(out), device_norm), nprocs=2, join=True)
+        r0 = np.load(os.path.join(str(out), "learn0.npz"))
+        r1 = np.load(os.path.join(str(out), "learn1.npz"))
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged (device_norm=%s): %s" % (device_norm, k)
+        stats[device_norm] = (r0["obs_mean"], r0["obs_var"], float(r0["obs_count"]))
+    assert np.array_equal(stats[False][0], stats[True][0]) and np.array_equal(stats[False][1], stats[True][1])
+    assert stats[False][2] == stats[True][2]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the shape of `python -m grasp_rl.dp_run train_stable_baselines.py ...` with GRL_NUM_ENVS: W = 4 replicas, the job's 8
+# environments = 2 worker processes per rank, each rank's env built as the reference's script builds it (ONE factory)
+def _fanout_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GRL_DP_SAME_DEVICE="1", GRL_TUNE="dp_timeout_ms=60000", GRL_NUM_ENVS="8", GRL_DATA_PARALLEL="auto")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import functools
+    from fake_env import FakeGraspEnv
+    from grasp_rl.parallel import DataParallelInGraph
+    from grasp_rl.sb import policies as pol
+    from grasp_rl.sb.monitor import Monitor
+    from grasp_rl.sb.sac import SAC
+    from grasp_rl.sb.vec_env import DummyVecEnv, VecNormalize
+    from test_data_parallel_gloo import _augmented
+    log_dir = os.path.join(out_dir, "rank%d" % rank)
+    os.makedirs(log_dir)
+    env = DummyVecEnv([functools.partial(_monitored_env, os.path.join(log_dir, "log_file"))])     # train_stable_baselines.py:54
+    assert env.num_envs == 1 and env.envs[0].depth_obs                                            # sb_helper.py:86
+    env = VecNormalize(env, norm_obs=True, norm_reward=True, clip_obs=10.0)                       # sb_helper.py:117-119
+    model = SAC(pol.SacCnnPolicy, env, batch_size=16, buffer_size=128, learning_starts=16, seed=5,
+                policy_kwargs={"cnn_extractor": _augmented(1)})                                   # data_parallel from the environment
+    assert isinstance(model._dp, DataParallelInGraph) and model.engine.cfg.batch_size == 4
+    assert env.num_envs == model.n_envs == model.engine.cfg.act_batch == 2 and env.ret.shape == (2,)
+    model.learn(96)
+    assert model.num_timesteps == 96                               # 12 vectorised steps x 2 envs x 4 ranks
+    assert model.n_updates == 8 * (12 - 1)                         # one update per environment step of the job once 16 steps exist
+    files = sorted(f for f in os.listdir(log_dir) if f.endswith("monitor.csv"))
+    first = 2 * rank                                               # environment numbers are the job's: rank r owns 2r, 2r + 1
+    assert files == sorted(["log_file.env%d.monitor.csv" % k if k else "log_file.monitor.csv" for k in (first, first + 1)])
+    P = model.get_parameters()
+    np.savez(os.path.join(out_dir, "fan%d.npz" % rank), obs_mean=env.obs_rms.mean, obs_count=env.obs_rms.count,
+             **{k.replace("/", "|"): v for k, v in P.items()})
+    env.close()
+    model.engine.close()
+    dist.destroy_process_group()
+
+
+def _monitored_env(path):
+    from fake_env import FakeGraspEnv
+    from grasp_rl.sb.monitor import Monitor
+    return Monitor(FakeGraspEnv("depth", seed=None, episode_len=4), path)
+
+
+def test_model_learn_four_replicas_with_fanned_out_envs(tmp_path):
+    """Row J3 under data parallelism (`dp_run` + GRL_NUM_ENVS, BASELINE configs[4] in small): four replicas on one MI355X,
+    each fanning the single env it was handed out to 2 worker processes, global minibatch 16 = 4 rows per rank, gradients
+    exchanged inside the update graph (two-shot at W = 4), one update per environment step of the job; replicas identical."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_learn_worker, args=(2, port, str(tmp_path), device_norm), nprocs=2, join=True)
-    r0 = np.load(os.path.join(str(tmp_path), "learn0.npz"))
-    r1 = np.load(os.path.join(str(tmp_path), "learn1.npz"))
+    mp.spawn(_fanout_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "fan%d.npz" % r)) for r in range(4)]
+    for p in parts[1:]:
+        for k in parts[0].files:
+            assert np.array_equal(parts[0][k], p[k]), "replicas diverged: " + k
+    assert float(parts[0]["obs_count"]) == pytest.approx(1e-4 + 8 * 13)      # reset + 12 steps of all 8 environments
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _setup_failure_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GRL_DP_SAME_DEVICE="1", GRL_TUNE="dp_timeout_ms=20000")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from grasp_rl.parallel import DataParallelInGraph, DataParallelRuntime, DataParallelSac, ExchangeSetupError
+    rt = DataParallelRuntime()
+    case = _case()
+    cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+    cfg.batch_size = B // world
+    case["cfg"] = cfg
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    eng = pu.engine_setup(case)
+    real = eng.allreduce_connect
+    if rank == 1:                     # the peers' memory maps, then the set-up fails on this rank only
+        def broken(handles):
+            real(handles)
+            raise RuntimeError("injected failure after hipIpcOpenMemHandle")
+        eng.allreduce_connect = broken
+    with pytest.raises(ExchangeSetupError):
+        DataParallelInGraph(eng, group=rt.ctrl)
+    # every rank released its mappings and its exchange memory; the handle trains alone again ...
+    eng.train(1, case["idx"][:1, lo:hi], case["eps"][:1, lo:hi])
+    eng.synchronize()
+    # ... can be connected anew (the real set-up this time) ...
+    eng.allreduce_connect = real
+    dp = DataParallelInGraph(eng, group=rt.ctrl, mode="twoshot")
+    dp.train(2)
+    assert dp.check() == 2
+    dp.close(disconnect=True)
+    # ... and make_exchange lands every rank on the collective fallback together when the failure persists
+    if rank == 1:
+        eng.allreduce_connect = broken
+    fb = rt.make_exchange(eng, prefer="ingraph")
+    assert isinstance(fb, DataParallelSac) and isinstance(rt.ingraph_error, ExchangeSetupError)
+    fb.broadcast_parameters(src=0)
+    fb.train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
+    eng.synchronize()
+    P = eng.get_parameters()
+    np.savez(os.path.join(out_dir, "sf%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_exchange_setup_failure_releases_every_rank_and_falls_back_together(tmp_path):
+    """a rank whose set-up fails AFTER the collectives of the set-up began (here: after mapping its peers)
+    no longer leaves the others in `all_gather_object` / `barrier` -- every phase is voted on, every rank disconnects
+    (grl_allreduce_disconnect), the handle works alone, can be connected again, and `make_exchange` falls back on all ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_setup_failure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "sf0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "sf1.npz"))
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
-    np.savez(os.path.join(str(tmp_path), "..", "dp_learn_stats_%d.npz" % int(device_norm)), mean=r0["obs_mean"], var=r0["obs_var"])
-
-
-def test_device_and_host_statistics_agree_under_data_parallelism(tmp_path):
-    """The running statistics two replicas end with are the same bits whether the host merged the moments
-    (share_running_stats) or the device did (dp_norm_*_kernel): both restate RunningMeanStd over the gathered batches."""
-    files = [os.path.join(str(tmp_path), "..", "dp_learn_stats_%d.npz" % k) for k in (0, 1)]
-    if not all(os.path.exists(f) for f in files):
-        pytest.skip("runs after test_model_learn_two_replicas_on_one_gpu (both parametrisations)")
-    a, b = np.load(files[0]), np.load(files[1])
-    assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["var"], b["var"])

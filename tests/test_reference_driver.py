@@ -250,6 +250,93 @@ def test_reference_train_script_train_then_run(reference_sb_helper, tmp_path, mo
     sys.modules.pop("train_stable_baselines", None)
 
 
+def test_reference_train_script_fans_out_with_grl_num_envs(reference_sb_helper, tmp_path, monkeypatch):
+    """Row J3: the reference's OWN `train(args)` with GRL_NUM_ENVS=4 in the environment.  Its
+    `DummyVecEnv([lambda: Monitor(gym.make(...), model_dir/log_file)])` (train_stable_baselines.py:52-54) is answered as it
+    always was (`env.envs[0].is_simplified()`, sb_helper.py:86) and, when sb_helper hands it to `sb.SAC(...)` as the training
+    env, becomes 4 worker processes each calling that same lambda: 4 monitor files, `get_attr('history')` (sb_helper.py:42-45,
+    the reference's TensorboardCallback) served by the workers, one update per environment step, evaluation env single."""
+    import enum
+    import importlib.util
+    import yaml
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    robot = types.ModuleType("manipulation_main.gripperEnv.robot")
+    robot.RobotEnv = type("RobotEnv", (), {"Status": enum.IntEnum("Status", {"RUNNING": 0, "SUCCESS": 1})})
+    wrapper = types.ModuleType("manipulation_main.training.wrapper")
+    wrapper.TimeFeatureWrapper = lambda env: env
+    pkgs = {n: types.ModuleType(n) for n in ("manipulation_main", "manipulation_main.gripperEnv", "manipulation_main.training",
+                                             "manipulation_main.common")}
+    for m in pkgs.values():
+        m.__path__ = []
+    pkgs.update({"manipulation_main.gripperEnv.robot": robot, "manipulation_main.training.wrapper": wrapper})
+    for n, m in pkgs.items():
+        monkeypatch.setitem(sys.modules, n, m)
+    real_yaml_load = yaml.load
+    monkeypatch.setattr(yaml, "load", lambda f, Loader=None: real_yaml_load(f, Loader=Loader or yaml.FullLoader))
+    io_utils = load("manipulation_main.common.io_utils", "/root/reference/manipulation_main/common/io_utils.py")
+    monkeypatch.setitem(sys.modules, "manipulation_main.common.io_utils", io_utils)
+    pkgs["manipulation_main.common"].io_utils = io_utils
+    utils = load("manipulation_main.utils", "/root/reference/manipulation_main/utils.py")
+    monkeypatch.setitem(sys.modules, "manipulation_main.utils", utils)
+    made = []
+
+    def make(name, config=None, **kw):
+        made.append(os.getpid())
+        return FakeGraspEnv("depth", seed=len(made) + 17 * (os.getpid() % 1000), episode_len=5)
+    sys.modules["gym"].make = make
+    monkeypatch.delitem(sys.modules, "train_stable_baselines", raising=False)
+    script = importlib.import_module("train_stable_baselines")
+    assert os.path.realpath(script.__file__).startswith("/root/reference/")
+    with open("/root/reference/config/gripper_grasp.yaml") as f:
+        cfg = yaml.safe_load(f)
+    cfg["SAC"]["buffer_size"], cfg["SAC"]["batch_size"] = 256, 4
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("trained")
+    with open("cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    # the workers are forked here: the lambda's globals (the stub `gym`, FakeGraspEnv) exist only in this test process, and the
+    # emulation engine has no HIP context a fork could damage (the product default is forkserver)
+    monkeypatch.setenv("GRL_NUM_ENVS", "4")
+    monkeypatch.setenv("GRL_ENV_START_METHOD", "fork")
+    seen = {}
+    real_learn = SAC.learn
+
+    def spy(self, total_timesteps, callback=None, **kw):
+        env = self.env
+        seen["n_envs"], seen["num_envs"] = self.n_envs, env.num_envs
+        seen["history"] = env.get_attr("history")
+        seen["act_batch"] = self.engine.cfg.act_batch
+        out = real_learn(self, total_timesteps, callback=callback, **kw)
+        seen["updates"], seen["steps"] = self.n_updates, self.num_timesteps
+        seen["ret_shape"] = self.get_vec_normalize_env().ret.shape
+        seen["sr"] = env.get_attr("sr_mean")
+        return out
+    monkeypatch.setattr(SAC, "learn", spy)
+    args = types.SimpleNamespace(config="cfg.yaml", model_dir="trained/fan", algo="SAC", load_dir=None, timestep="120",
+                                 simple=False, shaped=False, visualize=False, timefeature=False)
+    script.train(args)
+    assert seen["n_envs"] == seen["num_envs"] == seen["act_batch"] == 4 and seen["ret_shape"] == (4,)
+    assert seen["history"] == [[], [], [], []] and seen["sr"] == [1.0] * 4          # live attributes of the WORKERS' envs
+    assert seen["steps"] == 120 and seen["updates"] == 120 - 100 + 4                # one update per environment step after learning_starts
+    files = sorted(f for f in os.listdir("trained/fan") if f.endswith("monitor.csv"))
+    assert files == ["log_file.env1.monitor.csv", "log_file.env2.monitor.csv", "log_file.env3.monitor.csv", "log_file.monitor.csv"]
+    rows = [open(os.path.join("trained/fan", f)).read().strip().splitlines() for f in files]
+    assert all(len(r) == 2 + 6 for r in rows)                                      # header, column names, 30 steps / 5 per episode
+    from stable_baselines.results_plotter import load_results
+    assert len(load_results("trained/fan")) == 24
+    assert os.path.isfile("trained/fan/fan.zip") and os.path.isfile("trained/fan/vecnormalize.pkl")
+    # train env template + evaluation env were built in THIS process, the four training envs in four others
+    here = os.getpid()
+    assert made.count(here) == 2
+    sys.modules.pop("train_stable_baselines", None)
+
+
 def test_reference_train_encoder_script(hostemu_lib, tmp_path, monkeypatch):
     """`manipulation_main/training/train_encoder.py`: its `train(args)` (:30-49) and `test(args)` (:52-64) on the
     reference's `config/encoder.yaml` (epochs / batch size reduced, `data_path` pointing at a synthetic pickle of
