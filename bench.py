@@ -548,7 +548,8 @@ def run_sac(args, wl_name, world, rank, device):
         from grasp_rl import synthetic
         try:
             out["learn_loop"] = {
-                "what": "SAC.learn with 16 SubprocVecEnv workers of a free synthetic env + VecNormalize (host loop cost: "
+                "what": "SAC.learn on an env built as the reference's script builds it -- DummyVecEnv([one factory]) + VecNormalize -- "
+                        "fanned out to 16 worker processes by GRL_NUM_ENVS=16 (free synthetic env; host loop cost: "
                         "pipes, running statistics, staging, act); default = one update per environment step, i.e. 16 "
                         "updates per loop iteration (stable-baselines' ratio on its single env); not part of `value`",
                 "overlap_env_step": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True, device=str(device)),

@@ -285,6 +285,7 @@ struct grl_ctx {
   // bucket, stage 1 is the convolution backward + its weight gradients + the loss reductions
   std::vector<Op> ops_stage0, ops_stage1;
   bool staged_ok = false;
+  bool conv_stack = false;                // conv1 -> conv2 -> conv3 as one sample-local launch (conv_stack.h)
   bool loss_in_reduce = false;
   float grad_scale = 1.f;   // read by the apply op
 

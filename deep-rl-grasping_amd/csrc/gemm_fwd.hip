@@ -37,6 +37,18 @@ void launch_igemm2_fwd(int key, int n_tiles, hipStream_t s, const IgemmProb* pro
 #undef GRL_I2
 }
 
+bool conv_stack_ok(int C) { return C == 1 || C == 2 || C == 4; }
+void launch_conv_stack_fwd(int C, const ConvStackArgs& a, hipStream_t s) {
+  const dim3 grid(a.B * a.n_nets), block(256);
+  if (C == 1) hipLaunchKernelGGL((conv_stack_fwd_kernel<1>), grid, block, 0, s, a);
+  else if (C == 2) hipLaunchKernelGGL((conv_stack_fwd_kernel<2>), grid, block, 0, s, a);
+  else if (C == 4) hipLaunchKernelGGL((conv_stack_fwd_kernel<4>), grid, block, 0, s, a);
+  else {
+    fprintf(stderr, "grl: no conv-stack instantiation for %d image channels\n", C);
+    abort();
+  }
+}
+
 void launch_igemm_sk(int K, int n_tiles, hipStream_t s, const IgemmProb* probs, const int4* work) {
   if (K == 64) hipLaunchKernelGGL((igemm_sk_kernel<64>), dim3(n_tiles), dim3(256), 0, s, probs, work);
   else hipLaunchKernelGGL((igemm_sk_kernel<32>), dim3(n_tiles), dim3(256), 0, s, probs, work);

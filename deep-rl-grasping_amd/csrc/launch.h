@@ -14,6 +14,7 @@
 #include "q_kernels.h"
 #include "q_mfma.h"
 #include "act_mfma.h"
+#include "conv_stack.h"
 
 namespace grl {
 
@@ -27,6 +28,9 @@ void launch_igemm2_pair(int ka, int n_a, int n_b, hipStream_t s, const IgemmProb
 // scalar-gather fallback: key = np * 1000 + pm * 100 + qm * 10 + variant
 void launch_igemm(int key, int n_tiles, hipStream_t s, const IgemmProb* probs, const int4* tiles, const char* tag);
 void launch_igemm_sk(int K, int n_tiles, hipStream_t s, const IgemmProb* probs, const int4* work);
+// the three convolutions of the extractor as one sample-local launch (conv_stack.h); C = image channels, 1 / 2 / 4
+bool conv_stack_ok(int C);
+void launch_conv_stack_fwd(int C, const ConvStackArgs& a, hipStream_t s);
 
 enum { HEADS_GENERAL_64 = 0, HEADS_FAST_64 = 1, HEADS_FAST_128 = 2 };
 void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args);

@@ -195,6 +195,30 @@ int grl_ctx::plan_sac() {
       ft[l] = conv_fwd_tabs(cg[l], B);
     }
     const float* xin[3] = {x_obs, x_obs, x_next};
+    // conv1 -> conv2 -> conv3 of the three networks: ONE sample-local launch (conv_stack.h; a workgroup owns a sample of a
+    // network and keeps the activation chain in LDS) for 1 / 2 / 4 image channels; GRL_TUNE conv_stack=0 or any other channel
+    // count: one implicit-GEMM launch per layer.  The target network's layer-1 / layer-2 activations are not stored.
+    {
+      const char* nv2 = getenv("GRL_NO_V2");      // (the scalar-gather fallback test runs the per-layer launches on igemm_kernel)
+      conv_stack = conv_stack_ok(C_img) && hw == 64 && tune_int("conv_stack", 1) != 0 && !(nv2 && nv2[0] == '1');
+    }
+    if (conv_stack) {
+      std::vector<ConvStackNet> nets(3);
+      for (int n = 0; n < 3; ++n) {
+        ConvStackNet& cn = nets[n];
+        memset(&cn, 0, sizeof(cn));
+        cn.x = xin[n];
+        for (int l = 0; l < 3; ++l) { cn.w[l] = P + ex[n].w[l]; cn.b[l] = P + ex[n].b[l]; }
+        cn.a1 = n < 2 ? a1[n] : nullptr; cn.a2 = n < 2 ? a2[n] : nullptr; cn.a3 = a3[n]; cn.ld1 = ld1;
+      }
+      ConvStackArgs ca;
+      ca.nets = upload_vec(wk, nets); ca.B = B; ca.n_nets = 3;
+      const int Ci = C_img;
+      Op op; op.tag = "conv_stack_fwd";
+      op.flops = op.flops_exec = 2.0 * B * 3 * (225.0 * 32 * 64 * Ci + 36.0 * 64 * 512 + 16.0 * 64 * 576);
+      op.run = [ca, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, ca, s); };
+      ops_grads.push_back(op);
+    } else {
     const char* tags[3] = {"conv1_fwd", "conv2_fwd", "conv3_fwd"};
     for (int l = 0; l < 3; ++l) {
       std::vector<IgemmProb> pr;
@@ -204,6 +228,7 @@ int grl_ctx::plan_sac() {
         pr.push_back(conv_fwd(in, ft[l], cg[l], P + ex[n].w[l], P + ex[n].b[l], out, ACT_RELU, 0.f));
       }
       add_launch(ops_grads, tags[l], 0, pr);
+    }
     }
     std::vector<IgemmProb> pr;
     for (int n = 0; n < 3; ++n)
@@ -842,6 +867,19 @@ int grl_ctx::plan_sac() {
     if (cnn) {
       aa1 = wk.f32((int64_t)NA * 225 * 32); aa2 = wk.f32((int64_t)NA * 36 * 64); aa3 = wk.f32((int64_t)NA * 16 * 64);
       float* io[4] = {ax, aa1, aa2, aa3};
+      if (conv_stack) {     // one workgroup per observation walks conv1 -> conv2 -> conv3 (round 4: three launches, 4.9 + 9.2 + 9.2 us)
+        std::vector<ConvStackNet> nets(1);
+        memset(&nets[0], 0, sizeof(ConvStackNet));
+        nets[0].x = ax;
+        for (int l = 0; l < 3; ++l) { nets[0].w[l] = P + ex[0].w[l]; nets[0].b[l] = P + ex[0].b[l]; }
+        nets[0].a3 = aa3;
+        ConvStackArgs ca;
+        ca.nets = upload_vec(wk, nets); ca.B = NA; ca.n_nets = 1;
+        const int Ci = C_img;
+        Op op; op.tag = "act_conv";
+        op.run = [ca, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, ca, s); };
+        ops_act.push_back(op);
+      } else
       for (int l = 0; l < 3; ++l) {
         ConvGeom ag = cg[l];
         ag.ldx = ag.ldy = 0;                      // the acting pass keeps dense buffers of its own

@@ -53,6 +53,24 @@ class _RankedEnvFn:
             monitor.ENV_RANK = 0
 
 
+def _drop_empty_monitor_file(env):
+    """Remove the monitor CSV of a (closed) template environment when it holds no episode row."""
+    seen = 0
+    while env is not None and seen < 16:
+        fh = getattr(env, "__dict__", {}).get("file_handler")
+        name = getattr(fh, "name", None)
+        if isinstance(name, str) and name.endswith("monitor.csv") and os.path.isfile(name):
+            try:
+                with open(name) as f:
+                    if len(f.read().strip().splitlines()) <= 2:
+                        os.remove(name)
+            except OSError:
+                pass
+            return
+        env = getattr(env, "__dict__", {}).get("env")
+        seen += 1
+
+
 class DummyVecEnv(VecEnv):
     """Steps its environments sequentially in this process; resets an env automatically when its
     episode ends (the terminal observation is kept in info['terminal_observation']).
@@ -107,6 +125,8 @@ class DummyVecEnv(VecEnv):
                     env.close()
                 except Exception:                # noqa: BLE001  (a simulator that cannot close twice must not stop training)
                     pass
+            if first_rank > 0:                   # ... and where this process owns no environment 0 (data parallel, ranks > 0)
+                _drop_empty_monitor_file(env)    # the template's header-only log_file.monitor.csv is nobody's log
         fns = [_RankedEnvFn(self._env_fns[0], first_rank + k) for k in range(n)]
         self._fan = SubprocVecEnv(fns, start_method=start_method, envs_per_worker=envs_per_worker)
         self.num_envs = n

@@ -212,10 +212,13 @@ class ReachGraspEnv:
 
 
 def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0",
-                    gradient_steps=None, device_norm=False, envs_per_worker=1):
+                    gradient_steps=None, device_norm=False, envs_per_worker=1, via="cli"):
     """Env-steps / second and updates / second of ``SAC.learn`` with `n_envs` SyntheticGraspEnv worker processes behind
     SubprocVecEnv + VecNormalize -- BASELINE configs[1]: "16 vectorised PyBullet envs feed a single GPU", with the
-    simulator replaced by a free one.  gradient_steps None = one update per ENVIRONMENT step (stable-baselines' ratio
+    simulator replaced by a free one.  via="cli" (default): the env is built the way the reference's unmodified script
+    builds it -- ``DummyVecEnv([ONE factory])`` (train_stable_baselines.py:52-54) wrapped in VecNormalize
+    (sb_helper.py:117-119) -- and reaches its `n_envs` workers through GRL_NUM_ENVS when the model is constructed;
+    via="subproc": a ``SubprocVecEnv`` built by hand.  gradient_steps None = one update per ENVIRONMENT step (stable-baselines' ratio
     with train_freq 1 / gradient_steps 1 on its single env, sb_helper.py:120-128: n_envs updates per loop iteration);
     1 = one update per loop iteration.  Returns a dict."""
     import functools
@@ -223,7 +226,7 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
     from .sb.callbacks import BaseCallback
     from .sb.policies import AugmentedNatureCnn, SacCnnPolicy
     from .sb.sac import SAC
-    from .sb.vec_env import SubprocVecEnv, VecNormalize
+    from .sb.vec_env import DummyVecEnv, SubprocVecEnv, VecNormalize
 
     class Clock(BaseCallback):
         def __init__(self, warm):
@@ -236,13 +239,20 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
                 self.t0, self.u0 = time.perf_counter(), self.model.n_updates
             return True
 
-    venv = SubprocVecEnv([functools.partial(SyntheticGraspEnv, "depth", 15, s) for s in range(n_envs)],
-                         envs_per_worker=envs_per_worker)
+    saved = {k: os.environ.get(k) for k in ("GRL_NUM_ENVS", "GRL_ENVS_PER_WORKER")}
+    if via == "cli":
+        venv = DummyVecEnv([functools.partial(SyntheticGraspEnv, "depth", 15, None)])     # seed None: every worker draws its own
+        os.environ["GRL_NUM_ENVS"], os.environ["GRL_ENVS_PER_WORKER"] = str(n_envs), str(envs_per_worker)
+    else:
+        venv = SubprocVecEnv([functools.partial(SyntheticGraspEnv, "depth", 15, s) for s in range(n_envs)],
+                             envs_per_worker=envs_per_worker)
+        os.environ.pop("GRL_NUM_ENVS", None)
     try:
         env = VecNormalize(venv, norm_obs=True, norm_reward=True, clip_obs=10.0)
         model = SAC(SacCnnPolicy, env, policy_kwargs={"layers": [64, 64], "cnn_extractor": AugmentedNatureCnn(1)},
                     buffer_size=buffer_size, batch_size=batch_size, learning_starts=max(batch_size, n_envs),
                     overlap_env_step=overlap, device=device, gradient_steps=gradient_steps, device_norm=device_norm)
+        assert model.n_envs == n_envs and env.num_envs == n_envs
         clock = Clock(warm)
         model.learn(total_timesteps=n_envs * (warm + iterations), callback=clock)
         model.engine.synchronize()
@@ -250,11 +260,17 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
         return {"n_envs": n_envs, "iterations": iterations, "overlap_env_step": bool(overlap),
                 "gradient_steps": n_envs if gradient_steps is None else gradient_steps, "device_norm": bool(device_norm),
                 "worker_processes": (n_envs + envs_per_worker - 1) // envs_per_worker,
+                "env_built_as": "DummyVecEnv([fn]) + GRL_NUM_ENVS" if via == "cli" else "SubprocVecEnv",
                 "env_steps_per_s": round(n_envs * iterations / dt, 1),
                 "updates_per_s": round((model.n_updates - clock.u0) / dt, 1),
                 "ms_per_iteration": round(1e3 * dt / iterations, 3)}
     finally:
         venv.close()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 # ------------------------------------------------------------------------------------------------ learning evidence

@@ -45,10 +45,12 @@ def test_update_matches_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS=1", "GRL_NO_HEADS_MFMA=1", "GRL_NO_V2=1", "GRL_TUNE=fused_adam=0"])
+@pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS=1", "GRL_NO_HEADS_MFMA=1", "GRL_NO_V2=1", "GRL_TUNE=fused_adam=0",
+                                 "GRL_TUNE=conv_stack=0"])
 def test_fallback_paths_match_oracle(monkeypatch, var):
-    """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel and the
-    separate Adam launch -- the kernels other shapes fall back to -- stay correct."""
+    """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel, the
+    separate Adam launch and one implicit-GEMM launch per convolution instead of the sample-local stack (conv_stack.h) --
+    the kernels other shapes fall back to -- stay correct."""
     monkeypatch.setenv(*var.split("=", 1))
     case = pu.make_case(n_steps=2, extractor="augmented", kind="depth", B=16, n_replay=48)
     ref, orc = pu.oracle_run(case)

@@ -71,9 +71,11 @@ def test_optimiser_step_is_tf_adam_on_identical_inputs(hostemu_lib, name):
     pu.check_optimiser_steps(case, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=3)
 
 
-def test_two_launch_head_chains_still_match(hostemu_lib, monkeypatch):
-    """GRL_NO_HEADS_MFMA=1: the plan with heads_fwd + heads_bwd (heads_kernels.h) instead of the fused launch."""
-    monkeypatch.setenv("GRL_NO_HEADS_MFMA", "1")
+@pytest.mark.parametrize("var", ["GRL_NO_HEADS_MFMA=1", "GRL_TUNE=conv_stack=0"])
+def test_two_launch_head_chains_still_match(hostemu_lib, monkeypatch, var):
+    """GRL_NO_HEADS_MFMA=1: the plan with heads_fwd + heads_bwd (heads_kernels.h) instead of the fused launch;
+    GRL_TUNE conv_stack=0: one implicit-GEMM launch per convolution instead of the sample-local stack (conv_stack.h)."""
+    monkeypatch.setenv(*var.split("=", 1))
     case = pu.make_case(n_steps=2, **CASES["depth_augmented"])
     ref, orc = pu.oracle_run(case)
     eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
