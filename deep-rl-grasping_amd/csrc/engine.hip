@@ -286,6 +286,7 @@ struct grl_ctx {
   std::vector<Op> ops_stage0, ops_stage1;
   bool staged_ok = false;
   bool conv_stack = false;                // conv1 -> conv2 -> conv3 as one sample-local launch (conv_stack.h)
+  bool conv_stack_bwd = false;            // ... and the backward-data of conv3 -> conv2
   bool loss_in_reduce = false;
   float grad_scale = 1.f;   // read by the apply op
 

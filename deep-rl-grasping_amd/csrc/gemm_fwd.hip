@@ -49,6 +49,10 @@ void launch_conv_stack_fwd(int C, const ConvStackArgs& a, hipStream_t s) {
   }
 }
 
+void launch_conv_stack_bwd(const ConvStackBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((conv_stack_bwd_kernel<0>), dim3(a.B * a.n_nets), dim3(256), 0, s, a);
+}
+
 void launch_igemm_sk(int K, int n_tiles, hipStream_t s, const IgemmProb* probs, const int4* work) {
   if (K == 64) hipLaunchKernelGGL((igemm_sk_kernel<64>), dim3(n_tiles), dim3(256), 0, s, probs, work);
   else hipLaunchKernelGGL((igemm_sk_kernel<32>), dim3(n_tiles), dim3(256), 0, s, probs, work);

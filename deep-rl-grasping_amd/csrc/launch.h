@@ -31,6 +31,7 @@ void launch_igemm_sk(int K, int n_tiles, hipStream_t s, const IgemmProb* probs, 
 // the three convolutions of the extractor as one sample-local launch (conv_stack.h); C = image channels, 1 / 2 / 4
 bool conv_stack_ok(int C);
 void launch_conv_stack_fwd(int C, const ConvStackArgs& a, hipStream_t s);
+void launch_conv_stack_bwd(const ConvStackBwdArgs& a, hipStream_t s);
 
 enum { HEADS_GENERAL_64 = 0, HEADS_FAST_64 = 1, HEADS_FAST_128 = 2 };
 void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args);

@@ -203,16 +203,15 @@ int grl_ctx::plan_sac() {
       conv_stack = conv_stack_ok(C_img) && hw == 64 && tune_int("conv_stack", 1) != 0 && !(nv2 && nv2[0] == '1');
     }
     if (conv_stack) {
-      std::vector<ConvStackNet> nets(3);
+      ConvStackArgs ca;
+      memset(&ca, 0, sizeof(ca));
       for (int n = 0; n < 3; ++n) {
-        ConvStackNet& cn = nets[n];
-        memset(&cn, 0, sizeof(cn));
+        ConvStackNet& cn = ca.nets[n];
         cn.x = xin[n];
         for (int l = 0; l < 3; ++l) { cn.w[l] = P + ex[n].w[l]; cn.b[l] = P + ex[n].b[l]; }
         cn.a1 = n < 2 ? a1[n] : nullptr; cn.a2 = n < 2 ? a2[n] : nullptr; cn.a3 = a3[n]; cn.ld1 = ld1;
       }
-      ConvStackArgs ca;
-      ca.nets = upload_vec(wk, nets); ca.B = B; ca.n_nets = 3;
+      ca.B = B; ca.n_nets = 3;
       const int Ci = C_img;
       Op op; op.tag = "conv_stack_fwd";
       op.flops = op.flops_exec = 2.0 * B * 3 * (225.0 * 32 * 64 * Ci + 36.0 * 64 * 512 + 16.0 * 64 * 576);
@@ -538,7 +537,12 @@ int grl_ctx::plan_sac() {
     // whose operands are complete by then (d feat, head gradients) and whose tiles are as long as conv3_bwd's (reduction
     // = the batch, 8 slabs) ride in the empty slots of that round -- list positions 576.. land exactly on the CUs that
     // hold two -- and leave the merged weight-gradient launch.
-    {
+    // backward-data of conv3 and conv2 as ONE sample-local launch (conv_stack.h: conv_stack_bwd_kernel, scatter form with the
+    // forward's MACs) -- OPT-IN, GRL_TUNE conv_stack_bwd=1: measured on the MI355X at B = 256 it takes 34.3 us against 17.0 + 20.3
+    // for the two exact-tap implicit-GEMM launches, but those carry the dense weight gradients as riders, which then go back
+    // into the weight-gradient launch (30.1 -> 34.8 us): 5 660 against 5 689 updates/s (profiles/r05_conv_stack_gate.txt)
+    conv_stack_bwd = conv_stack && tune_int("conv_stack_bwd", 0) != 0;
+    if (!conv_stack_bwd) {
       int cfg3 = -1;
       const int t3 = planned_tiles(bwd_pr[1], 1, "conv3_bwd", &cfg3);
       rider_budget = cfg3 == 3 ? free_slots(t3, 3) : 0;
@@ -647,7 +651,22 @@ int grl_ctx::plan_sac() {
       }
       wg_ones.clear();
     }
-    if (cnn) {
+    if (cnn && conv_stack_bwd) {
+      add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
+      std::vector<ConvStackBwdNet> nets(2);
+      for (int n = 0; n < 2; ++n) {
+        ConvStackBwdNet& bn = nets[n];
+        memset(&bn, 0, sizeof(bn));
+        bn.g3 = g3[n]; bn.a2 = a2[n]; bn.a1 = a1[n]; bn.w2 = P + ex[n].w[1]; bn.w3 = P + ex[n].w[2];
+        bn.g2 = g2[n]; bn.g1 = g1[n]; bn.ld1 = ld1;
+      }
+      ConvStackBwdArgs ba;
+      ba.nets = upload_vec(wk, nets); ba.B = B; ba.n_nets = 2;
+      Op op; op.tag = "conv_stack_bwd";
+      op.flops = op.flops_exec = 2.0 * B * 2 * (36.0 * 64 * 512 + 16.0 * 64 * 576);
+      op.run = [ba](hipStream_t s) { launch_conv_stack_bwd(ba, s); };
+      ops_grads.push_back(op);
+    } else if (cnn) {
       add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
       std::vector<IgemmProb> riders = take_riders(wg_merged, rider_budget);
       if (!riders.empty()) add_launch(conv3_bwd_plain, "conv3_bwd", 1, bwd_pr[1]);
@@ -678,7 +697,7 @@ int grl_ctx::plan_sac() {
       const Op& o = ops_grads[k];
       sched.push_back(o);
       if ((int)k == dense_after) { take("wgrad_dense"); take("wgrad_small"); }
-      if (o.tag == "conv2_bwd") take("wgrad_conv");
+      if (o.tag == "conv2_bwd" || o.tag == "conv_stack_bwd") take("wgrad_conv");
     }
     ops_grads.swap(sched);
   }
@@ -868,13 +887,12 @@ int grl_ctx::plan_sac() {
       aa1 = wk.f32((int64_t)NA * 225 * 32); aa2 = wk.f32((int64_t)NA * 36 * 64); aa3 = wk.f32((int64_t)NA * 16 * 64);
       float* io[4] = {ax, aa1, aa2, aa3};
       if (conv_stack) {     // one workgroup per observation walks conv1 -> conv2 -> conv3 (round 4: three launches, 4.9 + 9.2 + 9.2 us)
-        std::vector<ConvStackNet> nets(1);
-        memset(&nets[0], 0, sizeof(ConvStackNet));
-        nets[0].x = ax;
-        for (int l = 0; l < 3; ++l) { nets[0].w[l] = P + ex[0].w[l]; nets[0].b[l] = P + ex[0].b[l]; }
-        nets[0].a3 = aa3;
         ConvStackArgs ca;
-        ca.nets = upload_vec(wk, nets); ca.B = NA; ca.n_nets = 1;
+        memset(&ca, 0, sizeof(ca));
+        ca.nets[0].x = ax;
+        for (int l = 0; l < 3; ++l) { ca.nets[0].w[l] = P + ex[0].w[l]; ca.nets[0].b[l] = P + ex[0].b[l]; }
+        ca.nets[0].a3 = aa3;
+        ca.B = NA; ca.n_nets = 1;
         const int Ci = C_img;
         Op op; op.tag = "act_conv";
         op.run = [ca, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, ca, s); };
@@ -968,6 +986,9 @@ int grl_ctx::plan_sac() {
     dbg["a1_pi"] = {a1[0], (int64_t)B * 225 * 32};   // (side-by-side layout: the first half of the pair buffer, stride 64)
     dbg["a2_pi"] = {a2[0], (int64_t)B * 36 * 64};
     dbg["a3_pi"] = {a3[0], (int64_t)B * 1024};
+    dbg["a1_pair"] = {a1[0], (int64_t)B * 225 * 64};   // [B * 225][pi 0..31 | values_fn 32..63]
+    dbg["a2_vf"] = {a2[1], (int64_t)B * 36 * 64};
+    dbg["a3_vf"] = {a3[1], (int64_t)B * 1024};
     dbg["g1_vf"] = {g1[1], (int64_t)B * 225 * 32};
     dbg["g2_vf"] = {g2[1], (int64_t)B * 36 * 64};
     dbg["g3_vf"] = {g3[1], (int64_t)B * 1024};

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #include "../deep-rl-grasping_amd/csrc/conv_stack.h"
@@ -39,6 +40,23 @@ static void conv_ref(const float* x, int H, int W, int Ci, const float* w, const
 }
 
 static int g_dynlds = 0;     // extra (unused) dynamic LDS per workgroup: limits how many workgroups share a CU (measurement)
+// the same convolution as a float32 chain of fmaf in increasing k = (kh, kw, ci): what the kernel must reproduce BIT FOR BIT
+static void conv_ref_f32(const float* x, int H, int W, int Ci, const float* w, const float* b, int KH, int S, int Co, std::vector<float>& y) {
+  const int OH = (H - KH) / S + 1, OW = (W - KH) / S + 1;
+  y.assign((size_t)OH * OW * Co, 0.f);
+  for (int oh = 0; oh < OH; ++oh)
+    for (int ow = 0; ow < OW; ++ow)
+      for (int co = 0; co < Co; ++co) {
+        float acc = 0.f;
+        for (int kh = 0; kh < KH; ++kh)
+          for (int kw = 0; kw < KH; ++kw)
+            for (int ci = 0; ci < Ci; ++ci)
+              acc = fmaf(x[((oh * S + kh) * W + ow * S + kw) * Ci + ci], w[((kh * KH + kw) * Ci + ci) * Co + co], acc);
+        const float v = acc + b[co];
+        y[((size_t)oh * OW + ow) * Co + co] = v > 0.f ? v : 0.f;
+      }
+}
+
 template <int C> static int run(int B, int reps) {
   const int NN = 3;
   std::vector<ConvStackNet> nets(NN);
@@ -63,9 +81,10 @@ template <int C> static int run(int B, int reps) {
     nets[n].a1 = nullptr; nets[n].a2 = nullptr;
 #endif
   }
-  ConvStackNet* dn = up(nets);
   ConvStackArgs args;
-  args.nets = dn; args.B = B; args.n_nets = NN;
+  memset(&args, 0, sizeof(args));
+  for (int n = 0; n < NN; ++n) args.nets[n] = nets[n];
+  args.B = B; args.n_nets = NN;
 #ifdef CS_STAMPS
   CK(hipMalloc(&args.stamps, (size_t)B * NN * 16 * 8));
   CK(hipMemset(args.stamps, 0, (size_t)B * NN * 16 * 8));
@@ -75,6 +94,7 @@ template <int C> static int run(int B, int reps) {
   CK(hipDeviceSynchronize());
   // ---- check a few samples of every network against the tap loops
   int bad = 0;
+  long bits_bad = 0;
   double worst = 0;
   std::vector<float> g1((size_t)B * 225 * 64), g2((size_t)B * 36 * 64), g3((size_t)B * 16 * 64);
   for (int n = 0; n < NN; ++n) {
@@ -94,6 +114,18 @@ template <int C> static int run(int B, int reps) {
         if (d > tol && bad++ < 10) printf("MISMATCH net %d sample %d %s[%d]: got %g ref %g\n", n, s, what, idx, got, ref);
       };
       for (int i = 0; i < 16 * 64; ++i) cmp(g3[(size_t)s * 1024 + i], y3[i], "a3", i);
+      {   // bit identity with the sequential fmaf chain (layer by layer on the chain's own activations)
+        std::vector<float> z1, z2, z3;
+        conv_ref_f32(hx[n == 2 ? 1 : 0].data() + (size_t)s * 4096 * C, 64, 64, C, hw[0][n].data(), hb[0][n].data(), 8, 4, 32, z1);
+        conv_ref_f32(z1.data(), 15, 15, 32, hw[1][n].data(), hb[1][n].data(), 4, 2, 64, z2);
+        conv_ref_f32(z2.data(), 6, 6, 64, hw[2][n].data(), hb[2][n].data(), 3, 1, 64, z3);
+        for (int i = 0; i < 16 * 64; ++i) bits_bad += g3[(size_t)s * 1024 + i] != z3[i];
+        if (n < 2 && nets[n].a1) {
+          for (int p = 0; p < 225; ++p)
+            for (int ch = 0; ch < 32; ++ch) bits_bad += g1[((size_t)s * 225 + p) * 64 + 32 * n + ch] != z1[p * 32 + ch];
+          for (int i = 0; i < 36 * 64; ++i) bits_bad += g2[(size_t)s * 2304 + i] != z2[i];
+        }
+      }
       if (n < 2 && nets[n].a1) {
         for (int p = 0; p < 225; ++p)
           for (int ch = 0; ch < 32; ++ch) cmp(g1[((size_t)s * 225 + p) * 64 + 32 * n + ch], y1[p * 32 + ch], "a1", p * 32 + ch);
@@ -101,7 +133,8 @@ template <int C> static int run(int B, int reps) {
       }
     }
   }
-  printf("C=%d B=%d: check %s (worst error / tolerance %.3f)\n", C, B, bad ? "FAILED" : "ok", worst);
+  printf("C=%d B=%d: check %s (worst error / tolerance %.3f); bit-identical to the sequential fmaf chain: %s (%ld elements differ)\n", C, B,
+         bad ? "FAILED" : "ok", worst, bits_bad ? "NO" : "yes", bits_bad);
 #ifdef CS_STAMPS
   {   // phase stamps of the LAST warm launch: per boundary the mean / min / max over workgroups, relative to the first start
     for (int i = 0; i < 5; ++i) launch();

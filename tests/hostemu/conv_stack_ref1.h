@@ -30,3 +30,42 @@ void conv_stack_fwd_kernel(ConvStackArgs a) {
     for (int i = 0; i < 36 * 64; ++i) net.a2[(long)smp * 36 * 64 + i] = y2[i];
   for (int i = 0; i < 16 * 64; ++i) net.a3[(long)smp * 16 * 64 + i] = y3[i];
 }
+
+// TEST-ONLY reference of conv_stack_bwd_kernel: the transposed convolutions as scatter loops over the forward taps
+template <int DUMMY>
+void conv_stack_bwd_kernel(ConvStackBwdArgs a) {
+  if (threadIdx.x != 0) return;
+  const int net_i = blockIdx.x / a.B, smp = blockIdx.x % a.B;
+  const ConvStackBwdNet& net = a.nets[net_i];
+  static thread_local float g2[36 * 64], g1[225 * 32];
+  for (int i = 0; i < 36 * 64; ++i) g2[i] = 0.f;
+  for (int i = 0; i < 225 * 32; ++i) g1[i] = 0.f;
+  const float* g3 = net.g3 + (long)smp * 16 * 64;
+  for (int kh = 0; kh < 3; ++kh)
+    for (int kw = 0; kw < 3; ++kw)
+      for (int oh = 0; oh < 4; ++oh)
+        for (int ow = 0; ow < 4; ++ow)
+          for (int ci = 0; ci < 64; ++ci) {
+            float acc = 0.f;
+            for (int co = 0; co < 64; ++co) acc = fmaf(g3[(oh * 4 + ow) * 64 + co], net.w3[((kh * 3 + kw) * 64 + ci) * 64 + co], acc);
+            g2[((oh + kh) * 6 + ow + kw) * 64 + ci] += acc;
+          }
+  for (int i = 0; i < 36 * 64; ++i) {
+    if (!(net.a2[(long)smp * 36 * 64 + i] > 0.f)) g2[i] = 0.f;
+    net.g2[(long)smp * 36 * 64 + i] = g2[i];
+  }
+  for (int kh = 0; kh < 4; ++kh)
+    for (int kw = 0; kw < 4; ++kw)
+      for (int oh = 0; oh < 6; ++oh)
+        for (int ow = 0; ow < 6; ++ow)
+          for (int ci = 0; ci < 32; ++ci) {
+            float acc = 0.f;
+            for (int co = 0; co < 64; ++co) acc = fmaf(g2[(oh * 6 + ow) * 64 + co], net.w2[((kh * 4 + kw) * 32 + ci) * 64 + co], acc);
+            g1[((2 * oh + kh) * 15 + 2 * ow + kw) * 32 + ci] += acc;
+          }
+  for (int p = 0; p < 225; ++p)
+    for (int ci = 0; ci < 32; ++ci) {
+      const long at = ((long)smp * 225 + p) * net.ld1 + ci;
+      net.g1[at] = net.a1[at] > 0.f ? g1[p * 32 + ci] : 0.f;
+    }
+}

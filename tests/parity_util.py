@@ -90,8 +90,9 @@ def close_rel_max(a, ref, rel=GRAD_REL, what="", floor=1e-12):
     assert d <= rel * scale + 1e-9, "%s: max |d| %.3e vs %.1e * max|ref| %.3e" % (what, d, rel, scale)
 
 
-def compare_first_step(eng, case, d0):
-    """After exactly one engine update: forward tensors, losses and gradients vs the oracle."""
+def compare_first_step(eng, case, d0, step_index=0):
+    """After exactly one engine update: forward tensors, losses and gradients vs the oracle (`step_index`: which minibatch
+    of the case that update consumed -- None when the caller cannot say: no second look at sign-ambiguous ReLU units)."""
     spec, B, A = case["spec"], case["B"], case["spec"].act_dim
     batch = d0["batch"]
     ldf = (spec.feat_dim + 3) // 4 * 4
@@ -121,8 +122,30 @@ def compare_first_step(eng, case, d0):
         ref = float(d0[k_o])
         assert abs(m[k_e] - ref) <= 1e-4 * abs(ref) + 1e-6, (k_e, m[k_e], ref)
     G = eng.get_gradients()
-    for n, g in d0["grads"].items():
-        close_rel_max(G[n], g, what="grad " + n)
+    try:
+        for n, g in d0["grads"].items():
+            close_rel_max(G[n], g, what="grad " + n)
+    except AssertionError:
+        if spec.extractor == "mlp" or step_index is None:
+            raise
+        # A ReLU unit whose pre-activation is within rounding of zero has no defined derivative in float32: the engine's
+        # summation order and the oracle's may take different sides (scripts/conv_stack_flips.py: a conv1 output of 2.5e-10
+        # among activations of 1e-2).  The oracle is re-run with the ENGINE's side for units with |pre-activation| <=
+        # osac.AMBIG_TOL -- and only those -- and the gradients must then agree to the same tolerance.
+        p1 = eng.fetch("a1_pair", (B, 15, 15, 64))
+        hints = {("model/pi", 1): p1[..., :32] > 0, ("model/values_fn", 1): p1[..., 32:] > 0,
+                 ("model/pi", 2): eng.fetch("a2_pi", (B, 6, 6, 64)) > 0, ("model/values_fn", 2): eng.fetch("a2_vf", (B, 6, 6, 64)) > 0,
+                 ("model/pi", 3): eng.fetch("a3_pi", (B, 4, 4, 64)) > 0, ("model/values_fn", 3): eng.fetch("a3_vf", (B, 4, 4, 64)) > 0}
+        osac.RELU_HINTS, osac.RELU_ALIGNED[:] = hints, []
+        try:
+            d1 = osac.SacOracle(spec, case["params"]).step(batch, case["eps"][step_index])
+        finally:
+            osac.RELU_HINTS = None
+        aligned = list(osac.RELU_ALIGNED)
+        assert 0 < len(aligned) <= 16, "gradients differ and %d sign-ambiguous ReLU units explain nothing" % len(aligned)
+        print("sign-ambiguous ReLU units taken the engine's way:", aligned)
+        for n, g in d1["grads"].items():
+            close_rel_max(G[n], g, what="grad (ambiguous ReLU units aligned) " + n)
 
 
 def adam_state(eng):

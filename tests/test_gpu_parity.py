@@ -46,7 +46,7 @@ def test_update_matches_oracle(name):
 
 
 @pytest.mark.parametrize("var", ["GRL_NO_FUSED_HEADS=1", "GRL_NO_HEADS_MFMA=1", "GRL_NO_V2=1", "GRL_TUNE=fused_adam=0",
-                                 "GRL_TUNE=conv_stack=0"])
+                                 "GRL_TUNE=conv_stack=0", "GRL_TUNE=conv_stack_bwd=1"])
 def test_fallback_paths_match_oracle(monkeypatch, var):
     """The per-layer GEMM heads, the two-launch VALU head chains (heads_kernels.h), the scalar-gather igemm_kernel, the
     separate Adam launch and one implicit-GEMM launch per convolution instead of the sample-local stack (conv_stack.h) --

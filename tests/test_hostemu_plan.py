@@ -71,10 +71,11 @@ def test_optimiser_step_is_tf_adam_on_identical_inputs(hostemu_lib, name):
     pu.check_optimiser_steps(case, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=3)
 
 
-@pytest.mark.parametrize("var", ["GRL_NO_HEADS_MFMA=1", "GRL_TUNE=conv_stack=0"])
+@pytest.mark.parametrize("var", ["GRL_NO_HEADS_MFMA=1", "GRL_TUNE=conv_stack=0", "GRL_TUNE=conv_stack_bwd=1"])
 def test_two_launch_head_chains_still_match(hostemu_lib, monkeypatch, var):
     """GRL_NO_HEADS_MFMA=1: the plan with heads_fwd + heads_bwd (heads_kernels.h) instead of the fused launch;
-    GRL_TUNE conv_stack=0: one implicit-GEMM launch per convolution instead of the sample-local stack (conv_stack.h)."""
+    GRL_TUNE conv_stack=0: one implicit-GEMM launch per convolution instead of the sample-local stack (conv_stack.h);
+    GRL_TUNE conv_stack_bwd=1: the opt-in sample-local backward-data launch."""
     monkeypatch.setenv(*var.split("=", 1))
     case = pu.make_case(n_steps=2, **CASES["depth_augmented"])
     ref, orc = pu.oracle_run(case)

@@ -322,3 +322,34 @@ def test_segment_tree_prefix_reduce_is_right_nested():
     # reduce over [0, 6]: node(0..3) + (node(4..5) + leaf 6)
     assert t.sum(0, 7) == v[4] + (v[10] + v[16 + 6])
     assert t.sum() == v[1]
+
+
+def test_relu_hints_move_only_sign_ambiguous_units(monkeypatch):
+    """oracle/sac.py RELU_HINTS (used by parity_util.compare_first_step when a gradient deviates): a hint decides the sign of
+    a ReLU unit ONLY where the pre-activation is within AMBIG_TOL of zero; everywhere else the oracle keeps its own sign."""
+    import parity_util as pu
+    from oracle import sac as osac
+    case = pu.make_case(extractor="augmented", kind="depth", B=2, n_replay=6, n_steps=1)
+    ref, _ = pu.oracle_run(case)
+    batch, eps = ref[0]["batch"], case["eps"][0]
+    keep = {}
+    T = osac.SacOracle(case["spec"], case["params"]).tensors()
+    osac.critic_fwd(case["spec"], T, "model/values_fn", batch["obs"], batch["act"], None, keep)
+    l1 = keep["l1"].numpy()
+    # all-False hints with the real tolerance: nothing is ambiguous in this tiny case -> identical gradients
+    hints = {("model/values_fn", 1): np.zeros(l1.shape, bool), ("model/pi", 1): np.zeros(l1.shape, bool)}
+    monkeypatch.setattr(osac, "RELU_HINTS", hints)
+    osac.RELU_ALIGNED[:] = []
+    d1 = osac.SacOracle(case["spec"], case["params"]).step(batch, eps)
+    assert osac.RELU_ALIGNED == []
+    for n, g in ref[0]["grads"].items():
+        assert np.array_equal(g, d1["grads"][n]), n
+    # a tolerance wide enough to catch the smallest positive unit: exactly the units below it follow the hint
+    pos = l1[l1 > 0]
+    tol = float(np.sort(pos)[2])
+    monkeypatch.setattr(osac, "AMBIG_TOL", tol)
+    osac.RELU_ALIGNED[:] = []
+    d2 = osac.SacOracle(case["spec"], case["params"]).step(batch, eps)
+    moved = [a for a in osac.RELU_ALIGNED if a[0] == "model/values_fn" and a[1] == 1]
+    assert len(moved) == 3 and all(0 < a[3] <= tol for a in moved)
+    assert any(not np.array_equal(ref[0]["grads"][n], d2["grads"][n]) for n in d2["grads"] if "values_fn/cnn1" in n or "values_fn/c1" in n)
