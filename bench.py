@@ -552,19 +552,20 @@ def run_sac(args, wl_name, world, rank, device):
                         "fanned out to 16 worker processes by GRL_NUM_ENVS=16 (free synthetic env; host loop cost: "
                         "pipes, running statistics, staging, act); default = one update per environment step, i.e. 16 "
                         "updates per loop iteration (stable-baselines' ratio on its single env); not part of `value`",
-                "overlap_env_step": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True, device=str(device)),
+                # default SAC(...) arguments: strict step -> store -> update order; VecNormalize statistics on the device
+                # because no callback reads the observations (device_norm="auto")
                 "strict_order": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False, device=str(device)),
-                "strict_order_device_norm": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False,
-                                                                      device=str(device), device_norm=True),
-                "overlap_env_step_device_norm": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
-                                                                          device=str(device), device_norm=True),
+                "strict_order_host_statistics": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=False,
+                                                                          device=str(device), device_norm=False),
+                "overlap_env_step": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True, device=str(device)),
+                "overlap_env_step_host_statistics": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
+                                                                              device=str(device), device_norm=False),
                 "one_update_per_iteration": synthetic.learn_loop_rate(16, args.learn_iters, 60, overlap=True,
                                                                       device=str(device), gradient_steps=1),
-                "one_update_per_iteration_device_norm": synthetic.learn_loop_rate(
-                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=True),
-                "one_update_per_iteration_device_norm_4_workers": synthetic.learn_loop_rate(
-                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=True,
-                    envs_per_worker=4)}
+                "one_update_per_iteration_host_statistics": synthetic.learn_loop_rate(
+                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, device_norm=False),
+                "one_update_per_iteration_4_workers": synthetic.learn_loop_rate(
+                    16, args.learn_iters, 60, overlap=True, device=str(device), gradient_steps=1, envs_per_worker=4)}
             out["learn_loop_updates_per_s"] = out["learn_loop"]["strict_order"]["updates_per_s"]
             out["learn_loop_steps_per_s"] = out["learn_loop"]["overlap_env_step"]["env_steps_per_s"]
         except Exception as e:      # the headline number must not depend on process spawning

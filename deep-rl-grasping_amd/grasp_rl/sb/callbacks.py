@@ -143,6 +143,33 @@ class ConvertCallback(BaseCallback):
         return True if r is None else bool(r)
 
 
+# Callbacks of the reference that are known not to look at the observations in `locals` (sb_helper.py:25-54,
+# base_callbacks.py:16-245: they read attributes of the envs, evaluate on their own env, save files, keep time)
+_REFERENCE_CALLBACKS = {"EvalCallback", "SaveVecNormalizeCallback", "TrainingTimeCallback", "TensorboardCallback", "CheckpointCallback"}
+_REFERENCE_MODULES = {"base_callbacks", "sb_helper", "manipulation_main.training.base_callbacks", "manipulation_main.training.sb_helper"}
+
+
+def may_read_observations(callback):
+    """False when every callback in the tree is known not to read `locals['new_obs']` / `locals['obs']`: this module's
+    classes, the reference's own (by class and module name), or a class that declares ``reads_observations = False``.
+    ``SAC(device_norm='auto')`` keeps the VecNormalize statistics on the device only then -- with them there the learn loop
+    sees RAW observations (the engine normalises where it consumes them), which a callback that looks at them would notice."""
+    if callback is None:
+        return False
+    kids = []
+    if isinstance(callback, CallbackList):
+        kids = list(callback.callbacks)
+    elif isinstance(callback, EventCallback) and callback.callback is not None:
+        kids = [callback.callback]
+    cls = type(callback)
+    declared = getattr(cls, "reads_observations", None)
+    own = cls.__module__ == __name__ and cls is not ConvertCallback
+    ref = cls.__name__ in _REFERENCE_CALLBACKS and cls.__module__ in _REFERENCE_MODULES
+    if declared is True or (declared is None and not own and not ref):
+        return True
+    return any(may_read_observations(k) for k in kids)
+
+
 def as_callback(callback):
     if callback is None:
         return BaseCallback()

@@ -41,7 +41,7 @@ from . import logger
 from . import policies as pol
 from . import save_util
 from . import spaces as sp
-from .callbacks import as_callback
+from .callbacks import as_callback, may_read_observations
 from .vec_env import DummyVecEnv, VecEnv, expand_training_env, unwrap_vec_normalize
 
 _POLICY_NAMES = {"MlpPolicy": pol.SacMlpPolicy, "CnnPolicy": pol.SacCnnPolicy, "LnMlpPolicy": pol.SacLnMlpPolicy,
@@ -82,13 +82,17 @@ class SAC:
         # Opt-in: RGB-D observations whose colour channels are integers in [0, 255] (the reference's camera: uint8,
         # sensor.py:126-145) are stored with byte colours -- half the HBM per transition (grl_config.replay_rgb_u8).
         self.replay_rgb_u8 = bool(replay_rgb_u8)
-        # Opt-in: keep the VecNormalize observation statistics on the device (grl_norm_update) while learning.  The
-        # wrapper then hands RAW observations to this loop (callbacks see them as `new_obs`); actions and minibatches
-        # are normalised where the engine consumes them, with the same arithmetic.  The wrapper's host copy is
-        # refreshed whenever it is pickled / saved / synchronised into an evaluation env, and when learn() returns.
+        # The VecNormalize observation statistics on the device (grl_norm_update / grl_observe) while learning: the wrapper
+        # then hands RAW observations to this loop (callbacks would see them as `new_obs`); actions and minibatches are
+        # normalised where the engine consumes them, with the same arithmetic -- parameters and the pickled statistics are
+        # bit-identical to the host path (tests/test_sb_api_host.py), one upload per env step instead of three, no float64
+        # pass over the observations on the host (learn loop 80 % -> 94 % of the engine-only rate in strict order).  The
+        # wrapper's host copy is refreshed whenever it is pickled / saved / synchronised into an evaluation env and when
+        # learn() returns.  True / False, or "auto" (default; GRL_DEVICE_NORM=0 / 1 / auto): on unless a callback may look at
+        # the observations (callbacks.may_read_observations: everything but this package's and the reference's own callbacks).
         if device_norm is None:
-            device_norm = os.environ.get("GRL_DEVICE_NORM", "0") == "1"
-        self.device_norm = bool(device_norm)
+            device_norm = {"0": False, "1": True}.get(os.environ.get("GRL_DEVICE_NORM", "auto"), "auto")
+        self.device_norm = device_norm if device_norm == "auto" else bool(device_norm)
         # Opt-in: one replica of a data-parallel job (module docstring).  None / False: off; "auto": when this process was
         # launched by torch.distributed.run with WORLD_SIZE > 1; True: required (raises without a launch).
         if data_parallel is None:
@@ -283,6 +287,8 @@ class SAC:
         callback.init_callback(self)
         eng, vn, N = self.engine, self._vec_normalize_env, self.n_envs
         device_norm = self.device_norm
+        if device_norm == "auto":
+            device_norm = not may_read_observations(callback)
         if rt is not None and device_norm and not hasattr(dp, "check"):
             # the device-side merge of the statistics rides on the in-graph exchange's channel; with the collective
             # fallback (RCCL / gloo) the handle is not connected and every replica would keep its own observation

@@ -212,7 +212,7 @@ class ReachGraspEnv:
 
 
 def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_size=20000, overlap=True, device="cuda:0",
-                    gradient_steps=None, device_norm=False, envs_per_worker=1, via="cli"):
+                    gradient_steps=None, device_norm=None, envs_per_worker=1, via="cli"):
     """Env-steps / second and updates / second of ``SAC.learn`` with `n_envs` SyntheticGraspEnv worker processes behind
     SubprocVecEnv + VecNormalize -- BASELINE configs[1]: "16 vectorised PyBullet envs feed a single GPU", with the
     simulator replaced by a free one.  via="cli" (default): the env is built the way the reference's unmodified script
@@ -229,6 +229,8 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
     from .sb.vec_env import DummyVecEnv, SubprocVecEnv, VecNormalize
 
     class Clock(BaseCallback):
+        reads_observations = False
+
         def __init__(self, warm):
             super().__init__()
             self.warm, self.t0, self.u0 = warm, None, 0
@@ -258,7 +260,7 @@ def learn_loop_rate(n_envs=16, iterations=300, warm=60, batch_size=256, buffer_s
         model.engine.synchronize()
         dt = time.perf_counter() - clock.t0
         return {"n_envs": n_envs, "iterations": iterations, "overlap_env_step": bool(overlap),
-                "gradient_steps": n_envs if gradient_steps is None else gradient_steps, "device_norm": bool(device_norm),
+                "gradient_steps": n_envs if gradient_steps is None else gradient_steps, "device_norm": "auto (on: no callback reads the observations)" if device_norm is None else bool(device_norm),
                 "worker_processes": (n_envs + envs_per_worker - 1) // envs_per_worker,
                 "env_built_as": "DummyVecEnv([fn]) + GRL_NUM_ENVS" if via == "cli" else "SubprocVecEnv",
                 "env_steps_per_s": round(n_envs * iterations / dt, 1),
