@@ -221,13 +221,11 @@ static int copy_from_caller(grl_handle h, void* dst, const void* src, size_t byt
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
   static const int always = tune_int("host_copy_wait", 0);
   bool wait = always != 0;
-#ifndef GRL_HOSTEMU
   if (!wait) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, src) == hipSuccess) wait = at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged;
     else (void)hipGetLastError();      // unknown to the runtime: pageable
   }
-#endif
   if (wait) {
     if (!h->copy_ev) HIPCHK(hipEventCreateWithFlags(&h->copy_ev, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->copy_ev, h->stream));

@@ -1333,4 +1333,34 @@ __global__ __launch_bounds__(256) void act_heads_kernel(ActHeadsArgs a) {
 #endif  // GRL_HOSTEMU
 #endif
 
+#ifndef GRL_ELEM_TYPES_ONLY
+// ---- what THIS build offers, answered at the kernel boundary (launch.h: the plans carry no build switches of their own)
+// The TD-loss launch: the emulation's reference form walks all rows in one call and always finishes the batch sums itself; the
+// device uses four rows per workgroup up to 64 bins, one workgroup beyond
+static inline bool q_loss_finishes_itself(int n_bins) {
+#ifdef GRL_HOSTEMU
+  (void)n_bins;
+  return true;
+#else
+  return n_bins <= 64;
+#endif
+}
+static inline void launch_q_loss(const QLossArgs& a, hipStream_t s) {
+#ifdef GRL_HOSTEMU
+  hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, a);
+#else
+  if (a.n <= 64) hipLaunchKernelGGL(q_loss_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(q_loss_rows_kernel, dim3(1), dim3(256), 0, s, a);
+#endif
+}
+// 16-byte forms of the element-wise kernels (gather_norm's vec4 rows, the reduction's quads): device build only
+static inline bool elem_vec4_built() {
+#ifdef GRL_HOSTEMU
+  return false;
+#else
+  return true;
+#endif
+}
+#endif
+
 }  // namespace grl

@@ -1271,12 +1271,8 @@ struct grl_ctx {
     std::vector<int2> rt;
     for (size_t k = 0; k < reduces.size(); ++k) {
       ReduceDesc& r = reduces[k];
-#ifdef GRL_HOSTEMU
-      r.vec = 0;
-#else
-      r.vec = (r.n % 4 == 0 && r.slab_stride % 4 == 0 && r.row_len % 4 == 0 && r.src_ld % 4 == 0 &&
+      r.vec = (elem_vec4_built() && r.n % 4 == 0 && r.slab_stride % 4 == 0 && r.row_len % 4 == 0 && r.src_ld % 4 == 0 &&
                (((uintptr_t)r.dst | (uintptr_t)r.src) & 15) == 0) ? 1 : 0;
-#endif
       if (pick && !pick(r)) continue;
       const int step = r.vec ? 1024 : 256;
       for (int st0 = 0; st0 < r.n; st0 += step) rt.push_back(make_int2((int)k, st0));

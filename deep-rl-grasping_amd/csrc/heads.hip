@@ -18,6 +18,23 @@ void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs
   else if (shape == HEADS_FAST_64) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, args);
   else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, args);
 }
+bool q_mfma_built() {
+#ifdef GRL_HOSTEMU
+  return false;
+#else
+  return true;
+#endif
+}
+bool act_mfma_built() { return q_mfma_built(); }
+int device_lds_bytes() {
+#ifdef GRL_HOSTEMU
+  return 1 << 30;
+#else
+  int dev = 0, lds = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+  return lds;
+#endif
+}
 size_t heads_fused_lds_bytes(int shape) {
 #ifdef GRL_HOSTEMU
   (void)shape;

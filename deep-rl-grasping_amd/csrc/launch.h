@@ -33,6 +33,12 @@ bool conv_stack_ok(int C);
 void launch_conv_stack_fwd(int C, const ConvStackArgs& a, hipStream_t s);
 void launch_conv_stack_bwd(const ConvStackBwdArgs& a, hipStream_t s);
 
+// What THIS build of the kernels offers -- answered where the kernels are instantiated, so that the launch plans (plan_*.inl)
+// carry no build switches of their own: the g++ emulation build (tests only) has sequential reference forms for the VALU chains
+// and the scalar element-wise kernels, but none for the matrix-core chains or the 16-byte element-wise variants.
+bool q_mfma_built();                 // q_mfma.h: tower / trunk chains on 16x16x4 MFMA stages
+bool act_mfma_built();               // act_mfma.h: policy head of grl_act on MFMA stages
+int device_lds_bytes();              // shared memory a workgroup may declare on the current device (emulation: no limit)
 enum { HEADS_GENERAL_64 = 0, HEADS_FAST_64 = 1, HEADS_FAST_128 = 2 };
 void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args);
 size_t heads_fused_lds_bytes(int shape);

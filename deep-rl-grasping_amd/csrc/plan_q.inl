@@ -261,13 +261,10 @@ int grl_ctx::plan_q() {
     std::vector<IgemmProb> l0;
     // matrix-core stages (q_mfma.h) when every width fits their 64-wide shape (GRL_TUNE q_mfma=0 keeps the VALU chains); they
     // also take layer 0 (K = obs_dim <= 128) into the chain: no GEMM launch in front of it (GRL_TUNE q_l0_chain=0 keeps it)
-    bool want_mfma = tune_int("q_mfma", 1) != 0 && nb <= QM_W && D + 1 <= QM_MAXP;
+    bool want_mfma = q_mfma_built() && tune_int("q_mfma", 1) != 0 && nb <= QM_W && D + 1 <= QM_MAXP;
     for (int k = 0; k < Lc; ++k) want_mfma = want_mfma && c.q_common[k] <= QM_W;
     for (int l = 0; l < Lb; ++l) want_mfma = want_mfma && c.q_branch[l] <= QM_W;
     for (int l = 0; l < Lv; ++l) want_mfma = want_mfma && c.q_value[l] <= QM_W;
-#ifdef GRL_HOSTEMU
-    want_mfma = false;
-#endif
     const bool l0_chain = want_mfma && c.obs_dim <= 2 * QM_W && tune_int("q_l0_chain", 1) != 0;
     for (int n = 0; n < 3; ++n) {
       const QNetP& W = *Wn[n];
@@ -382,21 +379,12 @@ int grl_ctx::plan_q() {
     qa.loss_sum = (c.algo == GRL_ALGO_BDQ && c.q_loss_sum_branches) ? 1 : 0;
     zero_once.push_back({qa.counter, 16});
     q_row_part = qa.row_part;
-#ifdef GRL_HOSTEMU
-    q_finish = 1;
-#else
-    q_finish = qa.n <= 64 ? 1 : 0;     // (the one-workgroup fallback for > 64 bins forms its sums itself)
-#endif
+    q_finish = q_loss_finishes_itself(qa.n) ? 1 : 0;     // (the one-workgroup fallback for > 64 bins forms its sums itself)
     Op op; op.tag = "q_loss";
     op.run = [qa, q_defer](hipStream_t s) {
       QLossArgs q2 = qa;
       q2.defer_finish = *q_defer;
-#ifdef GRL_HOSTEMU
-      hipLaunchKernelGGL(q_loss_kernel, dim3(1), dim3(256), 0, s, q2);
-#else
-      if (q2.n <= 64) hipLaunchKernelGGL(q_loss_kernel, dim3((q2.B + 3) / 4), dim3(256), 0, s, q2);
-      else hipLaunchKernelGGL(q_loss_rows_kernel, dim3(1), dim3(256), 0, s, q2);
-#endif
+      launch_q_loss(q2, s);
     };
     ops_grads.push_back(op);
   }
@@ -529,14 +517,8 @@ int grl_ctx::plan_q() {
     }
     ok = ok && n_tr == reduces.size();
     for (auto& r : reduces) ok = ok && r.row_len == 0;     // the kernel reads plain (non-strided) slabs
-#ifndef GRL_HOSTEMU
-    if (ok) {   // ~71 KB of static LDS per workgroup: fits gfx950's 160 KB; any device that offers less keeps the three launches
-      int dev = 0, lds = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
-          lds < (int)(GRL_QAPPLY_MAX * 4 + 1024 * 4 + 3 * 256 * 4))
-        ok = false;
-    }
-#endif
+    // ~71 KB of static LDS per workgroup: fits gfx950's 160 KB; any device that offers less keeps the three launches
+    if (ok && device_lds_bytes() < (int)(GRL_QAPPLY_MAX * 4 + 1024 * 4 + 3 * 256 * 4)) ok = false;
     if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: q_apply       reduction + clip + Adam in one launch: %s (%zu variables)\n", ok ? "yes" : "no", n_tr);
     if (ok) {
       ops_grads_apply.assign(ops_grads.begin(), ops_grads.end() - 1);

@@ -168,9 +168,7 @@ int grl_ctx::plan_sac() {
     ga.rgb_u8 = c.replay_rgb_u8;
     ga.sc = sc; ga.seed = c.seed; ga.idx_w = idx_buf; ga.eps_w = eps_buf; ga.n_eps = A;
     ga.adam_tick = fused_heads ? 1 : 0;   // otherwise sac_loss_kernel fixes the step size
-#ifndef GRL_HOSTEMU
-    ga.vec4 = (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
-#endif
+    ga.vec4 = elem_vec4_built() && (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
     const int per_block = ga.vec4 ? 1024 : 256;
     pf_ga = ga;
     pf_gx = (ga.img_elems + per_block - 1) / per_block;
@@ -285,14 +283,8 @@ int grl_ctx::plan_sac() {
       bool narrow = true;
       for (int l = 0; l < L; ++l) narrow = narrow && hid[l] <= 64;
       bool wide_ok = L == 2 && hid[0] == 128 && hid[1] == 128 && A <= 8 && B % HT_RB == 0;
-#ifndef GRL_HOSTEMU
-      if (!narrow && wide_ok) {   // the 128-wide kernel keeps 75 KB of static LDS per workgroup: fits gfx950's 160 KB; a device that offers less keeps the VALU chains
-        int dev = 0, lds = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
-            lds < (int)heads_fused_lds_bytes(HEADS_FAST_128))
-          wide_ok = false;
-      }
-#endif
+      // the 128-wide kernel keeps 75 KB of static LDS per workgroup: fits gfx950's 160 KB; a device that offers less keeps the VALU chains
+      if (!narrow && wide_ok && device_lds_bytes() < (int)heads_fused_lds_bytes(HEADS_FAST_128)) wide_ok = false;
       heads_mfma = heads_mfma && (narrow || wide_ok);
     }
     if (heads_mfma) {
@@ -877,10 +869,7 @@ int grl_ctx::plan_sac() {
     }
     // the policy head on the matrix cores (act_mfma.h) for the shapes it covers (GRL_TUNE act_mfma=0: the VALU kernel): the
     // extractor's dense layer then runs as a split-K GEMM whose partial sums the head kernel adds up while it stages its input
-    bool mfma_heads = am_shape_ok(F, L, hid, A) && tune_int("act_mfma", 1) != 0;
-#ifdef GRL_HOSTEMU
-    mfma_heads = false;
-#endif
+    const bool mfma_heads = act_mfma_built() && am_shape_ok(F, L, hid, A) && tune_int("act_mfma", 1) != 0;
     float* fc_parts = nullptr;
     int fc_split = 0;
     if (cnn) {

@@ -55,6 +55,9 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n); return *p ? 0 : 1; }
 static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
+struct hipPointerAttribute_t { int type; };
+enum { hipMemoryTypeHost = 1, hipMemoryTypeManaged = 3 };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t*, const void*) { return 1; }   // every pointer is pageable host memory here
 static inline hipError_t hipEventCreate(hipEvent_t*) { return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
