@@ -369,6 +369,7 @@ def cpu_baseline_ae(seconds=8.0):
             "sample": "%d oracle auto-encoder training steps at batch 128 (PyTorch-CPU fp32), %.1f s" % (n, dt)}
 
 
+OVERLAP_WORTH_MS = 0.040      # the overlapped plan costs ~0.05 ms more than two-shot at world 1 (profiles/r04_dp_overhead.txt)
 IN_GRAPH_VARIANTS = {      # --dp -> [(mode, overlap)] tried in this order
     "auto": [("oneshot", False), ("twoshot", False), ("twoshot", True)],
     "ingraph": [("auto", False)], "ingraph-oneshot": [("oneshot", False)], "ingraph-twoshot": [("twoshot", False)],
@@ -400,12 +401,36 @@ def make_data_parallel(eng, kind, world, rank, device, init):
 
     if kind in IN_GRAPH_VARIANTS:
         box = {}
+        # this rank's update WITHOUT an exchange (max over ranks): what every variant's time is read against -- the exchange
+        # costs (variant - plain) per update, and the overlapped plan (two more launches, +27 % at world 1) can only win when
+        # that cost exceeds what its side lane hides
+        def plain():
+            eng.train_device(16)
+            eng.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            eng.train_device(48)
+            eng.synchronize()
+            box["plain"] = time.perf_counter() - t0
+        plain_ok = agreed(attempt(plain, "plain update (no exchange)"))
+        plain_ms = None
+        if plain_ok:
+            t = torch.tensor([box["plain"]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            plain_ms = 1e3 * float(t) / 48
+        eng.set_parameters(init)
+        eng.reset_optimizer()
+        # (DataParallelInGraph votes after each of its set-up phases: it raises on every rank or on none)
         ok = agreed(attempt(lambda: box.setdefault("dp", DataParallelInGraph(eng, mode="twoshot")), "set-up"))
-        good, ms = [], {}
+        good, ms, skipped = [], {}, []
         if ok:
             dp = box["dp"]
             for mode, overlap in IN_GRAPH_VARIANTS[kind]:
                 name = mode + ("+overlap" if overlap else "")
+                if overlap and kind == "auto" and plain_ms is not None and ms and min(ms.values()) - plain_ms < OVERLAP_WORTH_MS:
+                    skipped.append("%s not tried: the cheapest plain exchange costs %.3f ms per update over the %.4f ms update, below the "
+                                   "%.3f ms the overlapped plan adds on its own" % (name, min(ms.values()) - plain_ms, plain_ms, OVERLAP_WORTH_MS))
+                    continue
                 # (switching is itself collective: drain, barrier, switch, barrier; a configuration without a staged plan
                 # refuses `overlap` on every rank alike)
                 if not agreed(attempt(lambda: dp.set_mode(mode, overlap), name)):
@@ -443,7 +468,11 @@ def make_data_parallel(eng, kind, world, rank, device, init):
             dp.set_mode(mode, overlap)
             note = ""
             if ms:
-                note = "; chosen by timing (ms per update): " + ", ".join("%s%s %.4f" % (m, "+overlap" if o else "", ms[(m, o)]) for m, o in good)
+                note = "; chosen by timing (ms per update, max over ranks): " + ", ".join("%s%s %.4f" % (m, "+overlap" if o else "", ms[(m, o)]) for m, o in good)
+            if plain_ms is not None:
+                note += "; update without an exchange %.4f ms" % plain_ms
+            if skipped:
+                note += "; " + "; ".join(skipped)
             resolved = mode if mode != "auto" else ("oneshot" if world <= 2 else "twoshot")
             return dp, "dp%d, %s all-reduce over IPC-mapped buffers inside the update graph%s%s" % (
                 world, {"oneshot": "one-shot", "twoshot": "two-shot"}[resolved],

@@ -70,6 +70,9 @@ struct ConvStackBwdArgs {
 // channel: 4096 floats, staged with 16-byte loads) and the layer-2 tile [36][CS_P2] afterwards
 enum { CS_P1 = 36, CS_P2 = 68, CS_R2 = 64 * 64, CS_LDS_FLOATS = 225 * CS_P1 + CS_R2 };
 static_assert(CS_R2 >= 36 * CS_P2, "the layer-2 tile lives where the image was");
+// (two image channels: 8192 floats staged, 65 KB per workgroup, two per CU; four channels are not staged -- 64 KB of image per
+//  sample -- and the launch plans keep one implicit-GEMM launch per layer for them: conv_stack_ok)
+constexpr int cs_lds_floats(int C) { return 225 * CS_P1 + (C <= 2 ? CS_R2 * C : 36 * CS_P2); }
 
 #ifdef GRL_HOSTEMU
 #include "conv_stack_ref1.h"   // tests/hostemu: the emulation build only
@@ -148,11 +151,11 @@ __device__ __forceinline__ void cs_unit(int B, int n_nets, int& net, int& smp) {
 #endif
 
 template <int C>
-__global__ __launch_bounds__(256, CS_WG_PER_CU) void conv_stack_fwd_kernel(ConvStackArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CS_LDS_FLOATS];
+__global__ __launch_bounds__(256, (C == 1 ? CS_WG_PER_CU : 2)) void conv_stack_fwd_kernel(ConvStackArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[cs_lds_floats(C)];
   float* const act1 = lds;
   float* const act2 = lds + 225 * CS_P1;
-  float* const ximg = lds + 225 * CS_P1;      // (C = 1) the sample's image, dead once conv1 is done
+  float* const ximg = lds + 225 * CS_P1;      // (C <= 2) the sample's image, dead once conv1 is done
   int net_i, smp;
   cs_unit(a.B, a.n_nets, net_i, smp);
   // the descriptor of this workgroup's network, selected field by field from the kernel arguments (scalar selects: indexing the
@@ -183,12 +186,12 @@ __global__ __launch_bounds__(256, CS_WG_PER_CU) void conv_stack_fwd_kernel(ConvS
     auto a_koff = [](int j, int i) -> int {
       return C == 1 ? (2 * j + (i >> 1)) * 64 + 4 * (i & 1) : (C == 2 ? (j * 64 + 2 * i) * 2 : (((4 * j + i) >> 3) * 64 + ((4 * j + i) & 7)) * 4);
     };
-    // C = 1: the image is staged in LDS once (four 16-byte loads per thread) and the patches are read from there -- four
-    // 4-byte global loads per chunk and row tile cost the first layer 6 k cycles (scripts/conv_stack_bench.hip stamps)
-    constexpr bool STAGE = C == 1;
+    // C <= 2: the image is staged in LDS once (four 16-byte loads per thread and channel) and the patches are read from there --
+    // four 4-byte global loads per chunk and row tile cost the first layer 6 k cycles (scripts/conv_stack_bench.hip stamps)
+    constexpr bool STAGE = C <= 2;
     if (STAGE) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *(cs_f4*)(ximg + 4 * (t + 256 * r)) = *(const cs_f4*)(x + 4 * (t + 256 * r));
+      for (int r = 0; r < 4 * C; ++r) *(cs_f4*)(ximg + 4 * (t + 256 * r)) = *(const cs_f4*)(x + 4 * (t + 256 * r));
     }
     auto a_load = [&](cs_f4& v, int base, int j) {
 #pragma unroll

@@ -255,11 +255,6 @@ def _subproc_worker(remote, parent_remote, env_fns_pickled):
                 from multiprocessing import shared_memory
                 name, first, shape, dtype, extra = data
                 shm = shared_memory.SharedMemory(name=name)
-                try:      # Python < 3.13 registers an ATTACHED block with the resource tracker as if this process owned it:
-                    from multiprocessing import resource_tracker      # the tracker would unlink it when a worker goes away
-                    resource_tracker.unregister(shm._name, "shared_memory")
-                except Exception:       # noqa: BLE001
-                    pass
                 item = int(np.prod(shape)) * np.dtype(dtype).itemsize
                 slots = [np.ndarray(shape, dtype=dtype, buffer=shm.buf, offset=(first + k) * item) for k in range(len(envs))]
                 if extra is not None:
