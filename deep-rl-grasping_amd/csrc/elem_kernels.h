@@ -1026,10 +1026,14 @@ struct AdamArgs {
   float* target;               // target block
 };
 
+#ifndef GRL_RS_QUADS
+#define GRL_RS_QUADS 1     // (measurement builds: scripts/ab_build.sh build "-DGRL_RS_QUADS=2" engine)
+#endif
+enum { RS_QUADS = GRL_RS_QUADS };     // quads (4 consecutive outputs) per thread of the 16-byte reduction path: a tile is 1024 * RS_QUADS outputs
 struct ReduceDesc {
   float* dst; const float* src; int32_t n; int32_t splits; int64_t slab_stride;
-  int32_t vec;   // 1: n, slab_stride multiples of 4 and dst / src 16-byte aligned -- a thread sums 4 consecutive outputs
-                 //    (tile = 1024 outputs instead of 256); set by the host (reduce_tiles)
+  int32_t vec;   // 1: n, slab_stride multiples of 4 and dst / src 16-byte aligned -- a thread sums RS_QUADS x 4 consecutive outputs
+                 //    (tile = 1024 * RS_QUADS outputs instead of 256); set by the host (reduce_tiles)
   int32_t row_len, src_ld;   // row_len > 0: output i comes from src[(i / row_len) * src_ld + i % row_len] -- a column
                              // block of a slab whose rows hold several variables side by side (conv1 of both nets)
 };
@@ -1075,54 +1079,84 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
   const ReduceDesc d = descs[tl.x];
 #ifndef GRL_HOSTEMU
   if (d.vec) {
-    // four consecutive outputs per thread, 16-byte accesses throughout (the pass is HBM-bound: a quarter of the
-    // memory instructions for the same bytes).  Per element the arithmetic is the scalar path's, in the same order.
+    // four consecutive outputs per thread and quad, RS_QUADS quads per thread (1024 outputs apart), 16-byte accesses
+    // throughout.  The pass is latency-bound: a workgroup lives for three dependent memory round trips (descriptor, loads,
+    // stores).  RS_QUADS = 2 (half the workgroups, twice the bytes in flight per thread) measured SLOWER on the MI355X:
+    // 17.2 against 14.2 us for the reduction + Adam launch, 5 628 against 5 732 updates/s (round 5, scripts/ab_build.sh) --
+    // many thin workgroups beat few fat ones here; the default stays 1.  Per element the arithmetic is the scalar path's, in
+    // the same order.
     typedef float rs_f4 __attribute__((ext_vector_type(4)));
-    const int i = tl.y + 4 * threadIdx.x;
-    if (i < d.n) {
-      const int64_t e = fuse_adam ? (d.dst + i) - aa.grads : 0;
-      const int64_t kp = e - aa.src_ofs;
-      const bool pol = fuse_adam && kp >= 0 && kp < aa.n_polyak;     // variables are padded to quads: no straddling
-      rs_f4 p = {0.f, 0.f, 0.f, 0.f}, m = p, v = p, tg = p;
-      if (fuse_adam) {
-        p = *(const rs_f4*)(aa.params + e); m = *(const rs_f4*)(aa.m + e); v = *(const rs_f4*)(aa.v + e);
-        if (pol) tg = *(const rs_f4*)(aa.target + kp);
+    constexpr int NQ = RS_QUADS;
+    const rs_f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    int ii[NQ];
+    bool on[NQ], pol[NQ];
+    int64_t e[NQ], kp[NQ];
+    rs_f4 p[NQ], m[NQ], v[NQ], tg[NQ], s[NQ];
+    const float* __restrict__ src[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      ii[u] = tl.y + 4 * threadIdx.x + 1024 * u;
+      on[u] = ii[u] < d.n;
+      e[u] = fuse_adam ? (d.dst + ii[u]) - aa.grads : 0;
+      kp[u] = e[u] - aa.src_ofs;
+      pol[u] = on[u] && fuse_adam && kp[u] >= 0 && kp[u] < aa.n_polyak;     // variables are padded to quads: no straddling
+      p[u] = m[u] = v[u] = tg[u] = s[u] = z4;
+      if (on[u] && fuse_adam) {
+        p[u] = *(const rs_f4*)(aa.params + e[u]); m[u] = *(const rs_f4*)(aa.m + e[u]); v[u] = *(const rs_f4*)(aa.v + e[u]);
+        if (pol[u]) tg[u] = *(const rs_f4*)(aa.target + kp[u]);
       }
-      const float* __restrict__ src = d.src + (d.row_len > 0 ? (long)(i / d.row_len) * d.src_ld + i % d.row_len : i);
-      rs_f4 s = {0.f, 0.f, 0.f, 0.f};
-      int k = 0;
-      // the pass is a chain of load batches per thread (~1 us each): 16 slabs in flight, summed in slab order
-      for (; k + 16 <= d.splits; k += 16) {
-        rs_f4 vv[16];
+      const int i = on[u] ? ii[u] : 0;
+      src[u] = d.src + (d.row_len > 0 ? (long)(i / d.row_len) * d.src_ld + i % d.row_len : i);
+    }
+    int k = 0;
+    // slab loads in batches of RS_BATCH per quad (2 x RS_BATCH in flight per thread), summed in slab order
+#ifndef GRL_RS_BATCH
+#define GRL_RS_BATCH 6
+#endif
+    constexpr int RS_BATCH = GRL_RS_BATCH;
+    for (; k + RS_BATCH <= d.splits; k += RS_BATCH) {
+      rs_f4 vv[NQ][RS_BATCH];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) vv[u] = *(const rs_f4*)(src + (long)(k + u) * d.slab_stride);
+      for (int u = 0; u < NQ; ++u)
+        if (on[u]) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += vv[u];
-      }
-      for (; k + 8 <= d.splits; k += 8) {
-        rs_f4 vv[8];
+          for (int j = 0; j < RS_BATCH; ++j) vv[u][j] = *(const rs_f4*)(src[u] + (long)(k + j) * d.slab_stride);
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vv[u] = *(const rs_f4*)(src + (long)(k + u) * d.slab_stride);
+      for (int u = 0; u < NQ; ++u)
+        if (on[u]) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += vv[u];
-      }
-      for (; k < d.splits; ++k) s += *(const rs_f4*)(src + (long)k * d.slab_stride);
+          for (int j = 0; j < RS_BATCH; ++j) s[u] += vv[u][j];
+        }
+    }
+    for (; k < d.splits; ++k) {
+      rs_f4 vv[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u)
+        if (on[u]) vv[u] = *(const rs_f4*)(src[u] + (long)k * d.slab_stride);
+#pragma unroll
+      for (int u = 0; u < NQ; ++u)
+        if (on[u]) s[u] += vv[u];
+    }
+    const float alpha = fuse_adam ? aa.sc->adam_alpha : 0.f;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      if (!on[u]) continue;
       // (data parallel: the sums go to the exchange buffer ONLY -- nothing reads this rank's own bucket before the exchange)
-      if (mirror) { const float sv[4] = {s.x, s.y, s.z, s.w}; st_sys_quad(mirror, ((d.dst + i) - aa.grads) >> 2, sv); }
-      else *(rs_f4*)(d.dst + i) = s;
+      if (mirror) { const float sv[4] = {s[u].x, s[u].y, s[u].z, s[u].w}; st_sys_quad(mirror, ((d.dst + ii[u]) - aa.grads) >> 2, sv); }
+      else *(rs_f4*)(d.dst + ii[u]) = s[u];
       if (fuse_adam) {
-        const float alpha = aa.sc->adam_alpha;
-        float pe[4] = {p.x, p.y, p.z, p.w}, me[4] = {m.x, m.y, m.z, m.w}, ve[4] = {v.x, v.y, v.z, v.w};
-        const float ge[4] = {s.x, s.y, s.z, s.w};
+        float pe[4] = {p[u].x, p[u].y, p[u].z, p[u].w}, me[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, ve[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const float ge[4] = {s[u].x, s[u].y, s[u].z, s[u].w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) adam_elem(grad_scaled(ge[u], aa.grad_scale), pe[u], me[u], ve[u], alpha, aa.eps);
-        p = rs_f4{pe[0], pe[1], pe[2], pe[3]}; m = rs_f4{me[0], me[1], me[2], me[3]}; v = rs_f4{ve[0], ve[1], ve[2], ve[3]};
-        *(rs_f4*)(aa.params + e) = p; *(rs_f4*)(aa.m + e) = m; *(rs_f4*)(aa.v + e) = v;
-        if (pol) {
+        for (int w = 0; w < 4; ++w) adam_elem(grad_scaled(ge[w], aa.grad_scale), pe[w], me[w], ve[w], alpha, aa.eps);
+        const rs_f4 p2 = {pe[0], pe[1], pe[2], pe[3]}, m2 = {me[0], me[1], me[2], me[3]}, v2 = {ve[0], ve[1], ve[2], ve[3]};
+        *(rs_f4*)(aa.params + e[u]) = p2; *(rs_f4*)(aa.m + e[u]) = m2; *(rs_f4*)(aa.v + e[u]) = v2;
+        if (pol[u]) {
           rs_f4 t2;
-          t2.x = polyak_elem(tg.x, p.x, aa.tau); t2.y = polyak_elem(tg.y, p.y, aa.tau);
-          t2.z = polyak_elem(tg.z, p.z, aa.tau); t2.w = polyak_elem(tg.w, p.w, aa.tau);
-          *(rs_f4*)(aa.target + kp) = t2;
+          t2.x = polyak_elem(tg[u].x, p2.x, aa.tau); t2.y = polyak_elem(tg[u].y, p2.y, aa.tau);
+          t2.z = polyak_elem(tg[u].z, p2.z, aa.tau); t2.w = polyak_elem(tg[u].w, p2.w, aa.tau);
+          *(rs_f4*)(aa.target + kp[u]) = t2;
         }
       }
     }

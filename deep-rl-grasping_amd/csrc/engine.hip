@@ -1266,7 +1266,7 @@ struct grl_ctx {
 
   // weight-gradient problem + the reductions that land its slab in the flat gradient bucket
   // work list of reduce_slabs_kernel over the descriptors `pick` selects: {descriptor, first output}; descriptors
-  // whose geometry allows 16-byte accesses are marked (vec) and cut into tiles of 1024 outputs, the others of 256
+  // whose geometry allows 16-byte accesses are marked (vec) and cut into tiles of 1024 * RS_QUADS outputs, the others of 256
   std::vector<int2> reduce_tiles(std::function<bool(const ReduceDesc&)> pick = nullptr) {
     std::vector<int2> rt;
     for (size_t k = 0; k < reduces.size(); ++k) {
@@ -1274,7 +1274,7 @@ struct grl_ctx {
       r.vec = (elem_vec4_built() && r.n % 4 == 0 && r.slab_stride % 4 == 0 && r.row_len % 4 == 0 && r.src_ld % 4 == 0 &&
                (((uintptr_t)r.dst | (uintptr_t)r.src) & 15) == 0) ? 1 : 0;
       if (pick && !pick(r)) continue;
-      const int step = r.vec ? 1024 : 256;
+      const int step = r.vec ? 1024 * RS_QUADS : 256;
       for (int st0 = 0; st0 < r.n; st0 += step) rt.push_back(make_int2((int)k, st0));
     }
     return rt;
