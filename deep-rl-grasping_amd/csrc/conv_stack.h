@@ -61,7 +61,7 @@ struct ConvStackBwdNet {
 };
 
 struct ConvStackBwdArgs {
-  const ConvStackBwdNet* nets;
+  ConvStackBwdNet nets[2];   // by value, like ConvStackArgs
   int B;
   int n_nets;
 };
@@ -381,26 +381,42 @@ __global__ __launch_bounds__(256, (C == 1 ? CS_WG_PER_CU : 2)) void conv_stack_f
 // Every LDS cell has ONE writer and the additions happen in program order: sums are deterministic.  The ReLU masks are applied
 // where the results leave for memory (g2 also stays in LDS as conv2's operand).
 // (two trained networks x B samples = 2 workgroups per CU at B = 256: the register budget of two waves per SIMD)
+// Latency measures, as in the forward kernel: descriptors in the kernel arguments; the ReLU masks (a2 rows, the a1 rows of the
+// wave's own parity class) are requested long before they are needed; every wave finishes ITS share of g1 alone -- no barrier
+// and no burst of all 225 rows at the end; the two workgroups of a CU belong to the same network; issue priority falls with
+// progress.
 template <int DUMMY>
 __global__ __launch_bounds__(256, 2) void conv_stack_bwd_kernel(ConvStackBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[CS_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[225 * CS_P1 + 36 * CS_P2];
   float* const g1acc = lds;
   float* const g2acc = lds + 225 * CS_P1;
-  const int net_i = blockIdx.x / a.B, smp = blockIdx.x - net_i * a.B;
-  const ConvStackBwdNet& net = a.nets[net_i];
+  int net_i, smp;
+  cs_unit(a.B, a.n_nets, net_i, smp);
+  ConvStackBwdNet net = a.nets[0];
+  if (net_i == 1) net = a.nets[1];
   const int t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4;
   const cs_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  CS_SETPRIO(2);
 
-  // ---- operands of the first stage, requested before anything else; accumulators cleared meanwhile
+  // ---- operands of the first stage and the layer-2 mask, requested before anything else; accumulators cleared meanwhile
   const float* g3 = net.g3 + ((int64_t)smp * 16 + c) * 64 + 4 * q;
   cs_f4 a3[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) a3[j] = *(const cs_f4*)(g3 + 16 * j);
   const float* w3 = net.w3 + (16 * w + c) * 64 + 4 * q;         // + tap * 4096 + 16 j
-  cs_f4 bn[4];
+  cs_f4 bn[2][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bn[j] = *(const cs_f4*)(w3 + 16 * j);
-  for (int e = t; e < CS_LDS_FLOATS / 4; e += 256) *(cs_f4*)(lds + 4 * e) = zero4;
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bn[d][j] = *(const cs_f4*)(w3 + d * 4096 + 16 * j);
+  const float* a2 = net.a2 + (int64_t)smp * 36 * 64;
+  cs_f4 m2[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int e = t + 256 * r;
+    m2[r] = e < 36 * 16 ? *(const cs_f4*)(a2 + 4 * e) : zero4;
+  }
+  for (int e = t; e < (225 * CS_P1 + 36 * CS_P2) / 4; e += 256) *(cs_f4*)(lds + 4 * e) = zero4;
   __syncthreads();
 
   // =========================================================================== conv3, 3x3 stride 1: g3 [16, 64] -> g2 [36, 64]
@@ -408,10 +424,10 @@ __global__ __launch_bounds__(256, 2) void conv_stack_bwd_kernel(ConvStackBwdArgs
   for (int tap = 0; tap < 9; ++tap) {
     cs_f4 bw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bw[j] = bn[j];
-    if (tap + 1 < 9) {
+    for (int j = 0; j < 4; ++j) bw[j] = bn[tap & 1][j];
+    if (tap + 2 < 9) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bn[j] = *(const cs_f4*)(w3 + (tap + 1) * 4096 + 16 * j);
+      for (int j = 0; j < 4; ++j) bn[tap & 1][j] = *(const cs_f4*)(w3 + (tap + 2) * 4096 + 16 * j);
     }
     cs_f4 acc[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
@@ -420,11 +436,16 @@ __global__ __launch_bounds__(256, 2) void conv_stack_bwd_kernel(ConvStackBwdArgs
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[j][i], bw[j][i], acc[j], 0, 0, 0);
     const int kh = tap / 3, kw = tap - 3 * kh;
     float* dst = g2acc + ((q + kh) * 6 + kw) * CS_P2 + 16 * w + c;      // output pixel (q, v) -> input pixel (q + kh, v + kw)
+    // (the four cells of a tap are distinct: all reads, then all writes -- one LDS round trip per tap instead of four)
+    float old[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) dst[v * CS_P2] += (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
+    for (int v = 0; v < 4; ++v) old[v] = dst[v * CS_P2];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dst[v * CS_P2] = old[v] + ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]));
   }
-  // the first kernel tap of conv2 (this wave's parity class) travels across the barrier
-  const int ph = w >> 1, pw = w & 1;
+  // ---- across the barrier travel: the first kernel tap of conv2 (this wave's parity class) and the layer-1 mask rows of the
+  // class (pixel (2 a + ph, 2 b + pw), a < na, b < nb: 64 / 56 / 56 / 49 pixels of 32 channels = up to 8 x 16 bytes per lane)
+  const int ph = w >> 1, pw = w & 1, na = 8 - ph, nb = 8 - pw, n4 = na * nb * 8;
   const float* w2 = net.w2 + c * 64 + 4 * q;                       // + tap * 2048 + nt * 1024 + 16 j
   cs_f4 b2n[2][4];
   {
@@ -434,19 +455,32 @@ __global__ __launch_bounds__(256, 2) void conv_stack_bwd_kernel(ConvStackBwdArgs
 #pragma unroll
       for (int j = 0; j < 4; ++j) b2n[nt][j] = *(const cs_f4*)(w2 + tap0 * 2048 + nt * 1024 + 16 * j);
   }
+  const float* a1 = net.a1 + (int64_t)smp * 225 * net.ld1;
+  float* g1 = net.g1 + (int64_t)smp * 225 * net.ld1;
+  cs_f4 m1[8];
+  int pix1[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int e = l + 64 * r, px = e >> 3, pa = px / nb, pb = px - pa * nb;
+    pix1[r] = e < n4 ? (2 * pa + ph) * 15 + 2 * pb + pw : -1;
+    m1[r] = pix1[r] >= 0 ? *(const cs_f4*)(a1 + (int64_t)pix1[r] * net.ld1 + 4 * (l & 7)) : zero4;
+  }
+  CS_SETPRIO(1);
   __syncthreads();
   // ---- g2 = sums x (a2 > 0): back into LDS (conv2's operand) and out to memory (conv2's weight gradient reads it)
   {
-    const float* a2 = net.a2 + (int64_t)smp * 36 * 64;
     float* g2 = net.g2 + (int64_t)smp * 36 * 64;
-    for (int e = t; e < 36 * 16; e += 256) {
-      const int row = e >> 4, ch = e & 15;
-      const cs_f4 m = *(const cs_f4*)(a2 + row * 64 + 4 * ch);
-      cs_f4 v = *(const cs_f4*)(g2acc + row * CS_P2 + 4 * ch);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
-      *(cs_f4*)(g2acc + row * CS_P2 + 4 * ch) = v;
-      *(cs_f4*)(g2 + row * 64 + 4 * ch) = v;
+    for (int r = 0; r < 3; ++r) {
+      const int e = t + 256 * r;
+      if (e < 36 * 16) {
+        const int row = e >> 4, ch = e & 15;
+        cs_f4 v = *(const cs_f4*)(g2acc + row * CS_P2 + 4 * ch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = m2[r][i] > 0.f ? v[i] : 0.f;
+        *(cs_f4*)(g2acc + row * CS_P2 + 4 * ch) = v;
+        *(cs_f4*)(g2 + 4 * e) = v;
+      }
     }
   }
   __syncthreads();
@@ -475,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_stack_bwd_kernel(ConvStackBwdArgs
 #pragma unroll
           for (int j = 0; j < 4; ++j) b2n[nt][j] = *(const cs_f4*)(w2 + tapn * 2048 + nt * 1024 + 16 * j);
       }
+      if (d == 2) CS_SETPRIO(0);
       cs_f4 acc[3][2] = {{zero4, zero4}, {zero4, zero4}, {zero4, zero4}};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -485,35 +520,42 @@ __global__ __launch_bounds__(256, 2) void conv_stack_bwd_kernel(ConvStackBwdArgs
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[mt][j][i], bw[nt][j][i], acc[mt][nt], 0, 0, 0);
-      // output pixel (oh, ow) of row 16 mt + 4 q + v -> input pixel (2 oh + kh, 2 ow + kw)
+      // output pixel (oh, ow) of row 16 mt + 4 q + v -> input pixel (2 oh + kh, 2 ow + kw).  The cells of one tap are distinct:
+      // all reads, then all writes (one LDS round trip per tap instead of twelve dependent ones)
+      int cell[3][4];
+      float old[3][4][2];
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int row = 16 * mt + 4 * q + v;
-          if (row < 36) {
-            const int oh = row / 6, ow = row - 6 * oh;
-            float* dst = g1acc + ((2 * oh + kh) * 15 + 2 * ow + kw) * CS_P1 + c;
-            dst[0] += acc[mt][0][v];
-            dst[16] += acc[mt][1][v];
-          }
+          const int oh = row / 6, ow = row - 6 * oh;
+          cell[mt][v] = row < 36 ? ((2 * oh + kh) * 15 + 2 * ow + kw) * CS_P1 + c : -1;
+          if (cell[mt][v] >= 0) { old[mt][v][0] = g1acc[cell[mt][v]]; old[mt][v][1] = g1acc[cell[mt][v] + 16]; }
         }
-    }
-  }
-  __syncthreads();
-  // ---- g1 = sums x (a1 > 0), 225 rows of 128 bytes
-  {
-    const float* a1 = net.a1 + (int64_t)smp * 225 * net.ld1;
-    float* g1 = net.g1 + (int64_t)smp * 225 * net.ld1;
-    for (int e = t; e < 225 * 8; e += 256) {
-      const int row = e >> 3, ch = e & 7;
-      const cs_f4 m = *(const cs_f4*)(a1 + (int64_t)row * net.ld1 + 4 * ch);
-      cs_f4 v = *(const cs_f4*)(g1acc + row * CS_P1 + 4 * ch);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
-      *(cs_f4*)(g1 + (int64_t)row * net.ld1 + 4 * ch) = v;
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (cell[mt][v] >= 0) {
+            g1acc[cell[mt][v]] = old[mt][v][0] + acc[mt][0][v];
+            g1acc[cell[mt][v] + 16] = old[mt][v][1] + acc[mt][1][v];
+          }
     }
   }
+  // ---- g1 of this wave's parity class = sums x (a1 > 0): nobody else wrote these pixels, nobody else stores them (LDS
+  // operations of one wave execute in order: the fence only keeps the compiler from moving the reads up)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (pix1[r] >= 0) {
+      cs_f4 v = *(const cs_f4*)(g1acc + pix1[r] * CS_P1 + 4 * (l & 7));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = m1[r][i] > 0.f ? v[i] : 0.f;
+      *(cs_f4*)(g1 + (int64_t)pix1[r] * net.ld1 + 4 * (l & 7)) = v;
+    }
 }
 
 #endif  // GRL_HOSTEMU

@@ -530,9 +530,12 @@ int grl_ctx::plan_sac() {
     // = the batch, 8 slabs) ride in the empty slots of that round -- list positions 576.. land exactly on the CUs that
     // hold two -- and leave the merged weight-gradient launch.
     // backward-data of conv3 and conv2 as ONE sample-local launch (conv_stack.h: conv_stack_bwd_kernel, scatter form with the
-    // forward's MACs) -- OPT-IN, GRL_TUNE conv_stack_bwd=1: measured on the MI355X at B = 256 it takes 34.3 us against 17.0 + 20.3
-    // for the two exact-tap implicit-GEMM launches, but those carry the dense weight gradients as riders, which then go back
-    // into the weight-gradient launch (30.1 -> 34.8 us): 5 660 against 5 689 updates/s (profiles/r05_conv_stack_gate.txt)
+    // forward's MACs) -- OPT-IN, GRL_TUNE conv_stack_bwd=1.  Measured on the MI355X at B = 256 (same box, scripts/ab_env.sh):
+    // first cut 5 660 against 5 689 updates/s; with the masks prefetched, wave-local epilogues, batched LDS read-modify-writes
+    // and falling issue priority 5 741 - 5 762 against 5 755 - 5 757: NEUTRAL.  The launch itself (33 - 35 us) replaces 17.0 +
+    // 20.3 us, but the dense weight gradients that ride in conv3_bwd's empty slots go back into the weight-gradient launch
+    // (30.5 -> 35 us), and the conv3 half is bound by its kernel stream: 16 output pixels per sample reuse every 4 KB of
+    // kernel for 16 MFMAs, where the batched exact-tap launch reuses it over 128 rows (profiles/r05_ab_conv_stack_bwd.txt)
     conv_stack_bwd = conv_stack && tune_int("conv_stack_bwd", 0) != 0;
     if (!conv_stack_bwd) {
       int cfg3 = -1;
@@ -645,15 +648,14 @@ int grl_ctx::plan_sac() {
     }
     if (cnn && conv_stack_bwd) {
       add_launch(ops_grads, "fc_bwd", 1, bwd_pr[0]);
-      std::vector<ConvStackBwdNet> nets(2);
+      ConvStackBwdArgs ba;
+      memset(&ba, 0, sizeof(ba));
       for (int n = 0; n < 2; ++n) {
-        ConvStackBwdNet& bn = nets[n];
-        memset(&bn, 0, sizeof(bn));
+        ConvStackBwdNet& bn = ba.nets[n];
         bn.g3 = g3[n]; bn.a2 = a2[n]; bn.a1 = a1[n]; bn.w2 = P + ex[n].w[1]; bn.w3 = P + ex[n].w[2];
         bn.g2 = g2[n]; bn.g1 = g1[n]; bn.ld1 = ld1;
       }
-      ConvStackBwdArgs ba;
-      ba.nets = upload_vec(wk, nets); ba.B = B; ba.n_nets = 2;
+      ba.B = B; ba.n_nets = 2;
       Op op; op.tag = "conv_stack_bwd";
       op.flops = op.flops_exec = 2.0 * B * 2 * (36.0 * 64 * 512 + 16.0 * 64 * 576);
       op.run = [ba](hipStream_t s) { launch_conv_stack_bwd(ba, s); };
