@@ -135,6 +135,24 @@ __global__ __launch_bounds__(256) void ae_out_kernel_flip(const float* __restric
   Wp[e] = j == 0 ? 0.f : W[(kh * 7 + (7 - j)) * C + c];
 }
 
+// Both re-ordered kernels of a training step in ONE launch at its start (the weights do not change inside a step): the flipped
+// output kernel above, and the FIRST encoder convolution's 7x7x1 kernel with every kernel row padded to 8 taps (tap 7 = 0):
+// K = 49 is no multiple of 4, so its forward ran on the scalar-gather igemm_kernel (28 us per step, rounds 3 - 4); with K = 56 --
+// the eighth tap of a row reads one more pixel of the zero-bordered image and multiplies it by 0.0 -- it is an igemm2 problem
+// whose quads of taps are 4 neighbouring pixels.  Adding x * 0.0 to a running fmaf sum leaves it bit for bit.
+__global__ __launch_bounds__(256) void ae_kernel_prep(const float* __restrict__ W6, float* __restrict__ W6p, int C6,
+                                                     const float* __restrict__ W1, float* __restrict__ W1p, int C1) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < 7 * 8 * C6) {
+    const int c = e % C6, j = (e / C6) % 8, kh = e / (8 * C6);
+    W6p[e] = j == 0 ? 0.f : W6[(kh * 7 + (7 - j)) * C6 + c];
+  }
+  if (e < 7 * 8 * C1) {
+    const int c = e % C1, j = (e / C1) % 8, kh = e / (8 * C1);
+    W1p[e] = j == 7 ? 0.f : W1[(kh * 7 + j) * C1 + c];
+  }
+}
+
 // loss value + Keras-Adam step size lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); advances the beta powers
 __global__ void ae_finish_kernel(const float* partial, const float* partial_g, int n_partial, long n_total, float lr,
                                  DevScalars* sc, float* g_out_bias) {

@@ -101,7 +101,11 @@ __device__ __forceinline__ constexpr int cs_pos(int ch) { return (ch & ~15) | ((
 // the four reduction steps k = 16 j + 4 i + q (i = 0 .. 3) of column n of a [K][ldw] kernel matrix; voff = (q * ldw + n) * 4
 __device__ __forceinline__ void cs_load_b(float (&bw)[4], __amdgpu_buffer_rsrc_t rs, int voff, int j, int ldw) {
 #pragma unroll
+#ifdef CS_FAKE_B      // measurement only (WRONG results): every chunk reads chunk 0 -- what would perfect kernel caching buy?
+  for (int i = 0; i < 4; ++i) bw[i] = cs_ld(rs, voff + i * 4 * ldw * 4, 0 * j);
+#else
   for (int i = 0; i < 4; ++i) bw[i] = cs_ld(rs, voff + i * 4 * ldw * 4, j * 16 * ldw * 4);
+#endif
 }
 // 16 bytes of channels 4 m .. 4 m + 3 of an activation row in LDS (un-transposed: what memory and the backward pass see)
 __device__ __forceinline__ cs_f4 cs_row4(const float* row, int m) {

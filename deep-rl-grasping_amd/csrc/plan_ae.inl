@@ -96,11 +96,32 @@ int grl_ctx::plan_ae() {
     });
   };
   // =============================================================== forward
+  float* W6p = wk.f32(56 * 32);       // output kernel flipped + padded (backward-data of the output convolution, below)
+  float* W1p = wk.f32(56 * 32);       // first encoder kernel, rows padded to 8 taps (its forward, here)
+  {
+    const float *W6 = P + dw[2], *W1 = P + ew[0];
+    elem("ae_kernel_prep", [=](hipStream_t s) {
+      hipLaunchKernelGGL(ae_kernel_prep, dim3((56 * 32 + 255) / 256), dim3(256), 0, s, W6, W6p, 32, W1, W1p, 32);
+    });
+  }
   {
     const float* in[3] = {x_p, e1_p, e2_p};
     float* o[3] = {e1, e2, e3};
     padcp(ae_x, x_p, 64, 1, 2, 3);
     for (int l = 0; l < 3; ++l) {
+      if (l == 0) {
+        // 7 x 8 taps over the bordered 69 x 69 image (see ae_kernel_prep): the reduction index is (kh, j), j = 0 .. 7
+        std::vector<int32_t> tr(57, 0);
+        for (int kh = 0; kh < 7; ++kh)
+          for (int j = 0; j < 8; ++j) tr[kh * 8 + j] = kh * 69 + j;
+        IgemmProb p = conv_fwd(in[0], fte[0], gev[0], W1p, P + eb[0], o[0], ACT_LEAKY, LA);
+        p.K = 56;
+        p.p_tab_r = upload_vec(wk, tr);
+        p.vflags |= VF_P_TABS;      // 4-runs along the taps at dword-aligned offsets (16-byte buffer loads take them on gfx950)
+        add_launch(ops_ae, "ae_enc_conv", 0, {p});
+        padcp(e1, e1_p, 32, 32, 1, 2);
+        continue;
+      }
       add_launch(ops_ae, "ae_enc_conv", 0, {conv_fwd(in[l], fte[l], gev[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA)});
       if (l == 0) padcp(e1, e1_p, 32, 32, 1, 2);
       if (l == 1) padcp(e2, e2_p, 16, 32, 0, 1);
@@ -193,11 +214,7 @@ int grl_ctx::plan_ae() {
     // backward-data of the output conv: g_u6[p, c] = sum_{kh,kw} g_pad[p - shift(kh,kw)] W[kh,kw,c], a GEMM with
     // M = pixels, N = 32, K = 7 x 8 taps (each kernel row flipped and padded to 8: ae_kernels.h) on the
     // vectorised kernel -- the taps of a quad are 4 neighbouring gradient pixels
-    float* Wp = wk.f32(56 * 32);
-    const float* W6 = P + dw[2];
-    elem("ae_out_kernel_flip", [=](hipStream_t s) {
-      hipLaunchKernelGGL(ae_out_kernel_flip, dim3((56 * 32 + 255) / 256), dim3(256), 0, s, W6, Wp, 32);
-    });
+    float* Wp = W6p;                  // (written by ae_kernel_prep at the start of the step)
     std::vector<int32_t> ti((size_t)B * 4096), tr(56);
     for (int n = 0; n < B; ++n)
       for (int ih = 0; ih < 64; ++ih)

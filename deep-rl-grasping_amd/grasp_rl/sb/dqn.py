@@ -76,6 +76,10 @@ class _QModel:
         if env is not None:
             if env.num_envs != 1:
                 raise ValueError("%s trains on a single environment (as stable-baselines does)" % type(self).__name__)
+            import os
+            if os.environ.get("GRL_NUM_ENVS", "1").strip() not in ("", "1"):
+                logger.warn("GRL_NUM_ENVS is ignored by %s: it trains on the single environment it is given, like "
+                            "stable-baselines' (the fan-out is SAC's)" % type(self).__name__)
             self.observation_space, self.action_space = env.observation_space, env.action_space
             self._vec_normalize_env = unwrap_vec_normalize(env)
         self.env = env
