@@ -6,19 +6,20 @@
 // N <= 64 output channels, so ONE workgroup can own a whole sample of one network and keep the chain in its LDS: the
 // hand-overs between the layers are __syncthreads(), not launches, and conv2 / conv3 never read their input from memory
 // (round 4 wrote 22 MB of layer-1 activations per update and read them straight back).  Networks whose activations the
-// backward pass needs (model/pi, model/values_fn) still store them -- as 16-byte rows from LDS while the next layer
-// computes; the target network stores only its last layer.
+// backward pass needs (model/pi, model/values_fn) still store them -- whole 128-byte rows from LDS, each wave its own tile as
+// soon as it is done; the target network stores only its last layer.
 //
 // Work decomposition (f32 matrix cores, v_mfma_f32_16x16x4_f32, exact fp32):
-//   * grid = networks x batch samples, 256 threads.  42 KB of LDS per workgroup: three workgroups share a CU and hide each
-//     other's load / barrier latencies (3 x B = 768 workgroups at B = 256 = exactly three per CU);
+//   * grid = networks x batch samples, 256 threads.  48.8 KB of LDS per workgroup (one image channel; two: 65 KB): three
+//     workgroups share a CU (3 x B = 768 workgroups at B = 256 = exactly three per CU, those of a CU from ONE network);
 //   * the GEMM rows are the output pixels of THIS sample (225 / 36 / 16: 15 / 3 / 1 row tiles of 16), the columns the output
 //     channels (two / four / four column tiles of 16);
-//   * A operand (patches): conv1 straight from the minibatch tensor (four 4-byte loads per chunk of 16: the k-order below rules
-//     out one 16-byte load); conv2 / conv3 from the activation tile in LDS (pixel stride padded to 36 / 68 floats: 16-byte
-//     reads, at most 2-way bank conflicts);
+//   * A operand (patches): conv1 from the sample's image, staged in LDS once with 16-byte loads (four 4-byte LDS reads per
+//     chunk of 16: the k-order below rules out one 16-byte read); conv2 / conv3 from the activation tile in LDS (pixel stride
+//     padded to 36 / 68 floats: 16-byte reads, at most 2-way bank conflicts);
 //   * B operand (kernels, TF's HWIO layout untouched): global memory -> registers, prefetched two reduction chunks ahead;
-//     every workgroup of a network reads the same 283 KB, which stay in L2 (and, for the three workgroups of a CU, in L1);
+//     every workgroup of a network reads the same 283 KB from L2 (perfectly cached kernels would buy 3 of the 40 us: measured
+//     with -DCS_FAKE_B);
 //   * reduction order: increasing k, one fmaf per step -- bit-identical to the per-layer implicit-GEMM launches and to a scalar
 //     fmaf loop (see "Reduction order" below; scripts/conv_stack_bench.hip checks the bits against such a loop).
 #pragma once
