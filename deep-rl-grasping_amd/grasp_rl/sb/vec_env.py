@@ -203,12 +203,33 @@ class DummyVecEnv(VecEnv):
         return [getattr(e, name)(*args, **kwargs) for e in self._targets(indices)]
 
 
-def _subproc_worker(remote, parent_remote, env_fns_pickled):
+def _main_module_imports():
+    """Names of the modules the running script imported at its top level.  The reference's environment factory --
+    ``lambda: gym.make('gripper-env-v0', ...)`` -- relies on a side effect of the script's imports (``import manipulation_main``
+    registers the env, train_stable_baselines.py:10).  Worker processes of the forkserver / spawn start methods normally get
+    that by re-importing the parent's ``__main__`` from its file (also under ``runpy.run_path``, i.e. ``python -m
+    grasp_rl.dp_run script.py``: tests/test_subproc_vec_env.py); where ``__main__`` has no file to re-import (``python -c``, an
+    interactive session, an embedding application) they import the same top-level modules themselves, best effort, before
+    they unpickle the factories."""
+    import sys
+    import types
+    main = sys.modules.get("__main__")
+    names = {v.__name__ for v in vars(main).values() if isinstance(v, types.ModuleType)} if main is not None else set()
+    return sorted(n for n in names if n not in ("__main__", "__mp_main__"))
+
+
+def _subproc_worker(remote, parent_remote, env_fns_pickled, preimport=()):
     """Worker loop of SubprocVecEnv: owns ONE OR MORE environments (`envs_per_worker`), answers commands over a pipe;
     every command carries / returns one entry per owned environment.  After an "shm" command the observations are
     written into this worker's slots of a shared-memory block and the pipe only carries `None` in their place (a
     64x64x5 float32 observation is 80 KB: pickling it through a pipe costs more than the rest of the exchange)."""
     parent_remote.close()
+    import importlib
+    for name in preimport:
+        try:
+            importlib.import_module(name)
+        except Exception:       # noqa: BLE001  (best effort: a module that cannot be imported here is the factory's problem)
+            pass
     envs = [fn() for fn in pickle.loads(env_fns_pickled)]
     shm, slots, fast = None, None, None
 
@@ -321,8 +342,9 @@ class SubprocVecEnv(VecEnv):
             import cloudpickle as _pk
         except ImportError:      # plain pickle: env_fns must be importable callables
             _pk = pickle
+        pre = _main_module_imports()
         for work_remote, remote, g in zip(self.work_remotes, self.remotes, groups):
-            proc = ctx.Process(target=_subproc_worker, args=(work_remote, remote, _pk.dumps([env_fns[e] for e in g])), daemon=True)
+            proc = ctx.Process(target=_subproc_worker, args=(work_remote, remote, _pk.dumps([env_fns[e] for e in g]), pre), daemon=True)
             proc.start()
             self.processes.append(proc)
             work_remote.close()

@@ -92,3 +92,43 @@ def test_a_dead_worker_raises_instead_of_hanging_and_close_still_releases_the_re
         sub.waiting = False
         sub.close()
     assert sub.closed
+
+
+def test_workers_import_what_the_script_imported_when_it_runs_under_runpy(tmp_path):
+    """`python -m grasp_rl.dp_run train_stable_baselines.py ...` executes the script with runpy.  Its factory -- `lambda:
+    gym.make('gripper-env-v0', ...)` -- needs the registration that `import manipulation_main` performs at the script's top
+    (train_stable_baselines.py:10) in every forkserver worker: the workers re-import the script (multiprocessing, from its file)
+    and, belt and braces, the script's top-level modules (vec_env._main_module_imports).  The whole flow -- one factory,
+    `fan_out(3)`, forkserver, runpy -- in a child interpreter."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    (tmp_path / "regmod.py").write_text("import fakegym\nfakegym.REGISTERED.add('gripper-env-v0')\n")
+    (tmp_path / "fakegym.py").write_text(textwrap.dedent("""
+        REGISTERED = set()
+        def make(name):
+            if name not in REGISTERED:
+                raise KeyError("no registered env with id: " + name)
+            from fake_env import FakeGraspEnv
+            return FakeGraspEnv(seed=None, vector_dim=6, act_dim=2, episode_len=3)
+        """))
+    (tmp_path / "script.py").write_text(textwrap.dedent("""
+        import numpy as np
+        import fakegym
+        import regmod                      # side effect: registers the env (like `import manipulation_main`)
+        from stable_baselines.common.vec_env import DummyVecEnv
+        if __name__ == "__main__":
+            env = DummyVecEnv([lambda: fakegym.make('gripper-env-v0')])
+            env.fan_out(3, start_method="forkserver")
+            obs = env.reset()
+            obs, rew, done, info = env.step(np.zeros((3, 2), np.float32))
+            env.close()
+            open("ok.txt", "w").write("%d %s" % (env.num_envs, obs.shape))
+        """))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(repo, "deep-rl-grasping_amd"), os.path.join(repo, "tests")]))
+    runner = "import runpy, sys; sys.argv = ['script.py']; runpy.run_path('script.py', run_name='__main__')"
+    r = subprocess.run([sys.executable, "-c", runner], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "ok.txt").read_text() == "3 (3, 6)"
