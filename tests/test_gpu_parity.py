@@ -308,3 +308,28 @@ def test_multi_update_call_prefetch_is_bit_identical_b256(monkeypatch):
         assert all(np.array_equal(ref[0][n], got[0][n]) for n in ref[0])
         assert all(np.array_equal(a, b) for a, b in zip(ref[1:4], got[1:4]))
         assert ref[4] == got[4]
+
+
+def test_conv_stack_is_bit_identical_to_the_per_layer_launches_where_the_order_is_the_same(monkeypatch):
+    """csrc/conv_stack.h sums every output in increasing k, one fmaf per step -- the order of the per-layer implicit-GEMM
+    launches whose reduction stays in one wave (conv1, conv2; conv3's per-layer launch adds the partial sums of wave pairs).
+    Layer-1 and layer-2 activations of both trained networks must therefore be the SAME BITS with and without the stack at
+    the headline shape, layer 3 and everything downstream equal to rounding -- and no ReLU unit may change sides
+    (scripts/conv_stack_flips.py tells the story of the k-permuted first cut)."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=256, n_replay=600, n_steps=1)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRL_TUNE", "conv_stack=" + mode)
+        eng = pu.engine_setup(case)
+        eng.train(1, case["idx"][:1], case["eps"][:1])
+        out[mode] = {k: eng.fetch(k) for k in ("a1_pair", "a2_pi", "a2_vf", "a3_pi", "a3_vf", "feat_pi", "feat_vf", "feat_tgt")}
+        out[mode]["G"] = eng.get_gradients()
+        eng.close()
+    s, l = out["1"], out["0"]
+    for k in ("a1_pair", "a2_pi", "a2_vf"):
+        assert np.array_equal(s[k], l[k]), k
+    for k in ("a3_pi", "a3_vf", "feat_pi", "feat_vf", "feat_tgt"):
+        assert np.array_equal(s[k] > 0, l[k] > 0), "a ReLU unit changed sides: " + k
+        assert np.abs(s[k] - l[k]).max() <= 1e-7, k
+    for n, g in l["G"].items():
+        pu.close_rel_max(s["G"][n], g, rel=1e-5, what="stack vs per-layer grad " + n)
