@@ -821,74 +821,94 @@ __device__ __forceinline__ int q_wave_argmax_dpp(float sv, int si) {
   }
   return __builtin_amdgcn_readfirstlane(bi);
 }
+// One minibatch row of the loss on one wavefront, lane = bin (n <= 64, D <= Q_DM), in two steps: the operands of the row --
+// requested in one burst (one memory round trip instead of 2 D) -- and the arithmetic.  emit_g(d, g, ai, td) receives the
+// loss gradient scale, the stored bin and the TD error of branch d (wave-uniform values, every lane calls it), emit_row(dv,
+// priority, weighted loss, mean selected Q) the row's results.  Shared by q_loss_kernel and the backward chains of
+// q_chain.h, which form the loss of their own rows themselves.
+enum { Q_DM = 8 };
+struct QRowIn { float xs[Q_DM], xt[Q_DM], x0[Q_DM]; int ais[Q_DM]; float v2b, v0b, rewb, doneb, w; };
+__device__ __forceinline__ void q_row_load(const QLossArgs& a, int b, int lane, QRowIn& in) {
+  const int D = a.D, n = a.n;
+  const bool on = lane < n;
+  const float* sel = a.double_q ? a.adv1 : a.adv2;
+#pragma unroll
+  for (int d = 0; d < Q_DM; ++d) {
+    in.xs[d] = -INFINITY; in.xt[d] = 0.f; in.x0[d] = 0.f; in.ais[d] = 0;
+    if (d < D) {
+      const long o = ((long)b * D + d) * n + lane;
+      if (on) { in.xs[d] = sel[o]; in.xt[d] = a.adv2[o]; in.x0[d] = a.adv0[o]; }
+      in.ais[d] = (int)a.act[b * D + d];
+    }
+  }
+  in.v2b = a.v2[b]; in.v0b = a.v0[b]; in.rewb = a.rew[b]; in.doneb = a.done[b]; in.w = a.weights[b];
+}
+template <class EmitG, class EmitRow>
+__device__ __forceinline__ void q_row_loss(const QLossArgs& a, const QRowIn& in, int lane, EmitG&& emit_g, EmitRow&& emit_row) {
+  const int D = a.D, n = a.n;
+  const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
+  float qbest = 0.f;
+#pragma unroll
+  for (int d = 0; d < Q_DM; ++d) {
+    if (d < D) {
+      const float tg = in.xt[d];
+      const int si = q_wave_argmax_dpp(in.xs[d], lane);      // (wave-uniform)
+      const float mean2 = q_wave_sum_dpp(tg);
+      qbest += in.v2b + q_lane_f(tg, si) - mean2 * invn;
+    }
+  }
+  qbest *= invD;
+  const float y = in.rewb + a.gamma * (1.f - in.doneb) * qbest;
+  float dv = 0.f, prio = 0.f, lossb = 0.f, qs = 0.f;
+#pragma unroll
+  for (int d = 0; d < Q_DM; ++d) {
+    if (d < D) {
+      const float ad = in.x0[d];
+      const float mean0 = q_wave_sum_dpp(ad) * invn;
+      const int ai = in.ais[d];
+      const float q_sel = in.v0b + q_lane_f(ad, __builtin_amdgcn_readfirstlane(ai)) - mean0;
+      const float tdv = q_sel - y;
+      prio += fabsf(tdv);
+      qs += q_sel;
+      float err, dfd;
+      if (a.huber) {
+        const float at = fabsf(tdv);
+        err = at < 1.f ? 0.5f * tdv * tdv : at - 0.5f;
+        dfd = fminf(fmaxf(tdv, -1.f), 1.f);
+      } else {
+        err = tdv * tdv;
+        dfd = 2.f * tdv;
+      }
+      lossb += err;
+      const float g = in.w * invB * (a.loss_sum ? 1.f : invD) * dfd;
+      dv += g;
+      emit_g(d, g, ai, tdv);
+    }
+  }
+  emit_row(dv, prio, in.w * lossb * (a.loss_sum ? 1.f : invD), qs * invD);
+}
 #ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void q_loss_kernel(QLossArgs a) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int D = a.D, n = a.n;
-  constexpr int DM = 8;      // branches whose operands are requested up front (one memory round trip instead of 2 D)
-  if (b < a.B && D <= DM) {
-    const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
-    const bool on = lane < n;
-    float xs[DM], xt[DM], x0[DM];
-    int ais[DM];
-    const float* sel = a.double_q ? a.adv1 : a.adv2;
-#pragma unroll
-    for (int d = 0; d < DM; ++d) {
-      xs[d] = -INFINITY; xt[d] = 0.f; x0[d] = 0.f; ais[d] = 0;
-      if (d < D) {
-        const long o = ((long)b * D + d) * n + lane;
-        if (on) { xs[d] = sel[o]; xt[d] = a.adv2[o]; x0[d] = a.adv0[o]; }
-        ais[d] = (int)a.act[b * D + d];
-      }
-    }
-    const float v2b = a.v2[b], v0b = a.v0[b], rewb = a.rew[b], doneb = a.done[b], w = a.weights[b];
-    float qbest = 0.f;
-#pragma unroll
-    for (int d = 0; d < DM; ++d) {
-      if (d < D) {
-        const float tg = xt[d];
-        const int si = q_wave_argmax_dpp(xs[d], lane);      // (wave-uniform)
-        const float mean2 = q_wave_sum_dpp(tg);
-        qbest += v2b + q_lane_f(tg, si) - mean2 * invn;
-      }
-    }
-    qbest *= invD;
-    const float y = rewb + a.gamma * (1.f - doneb) * qbest;
-    float dv = 0.f, prio = 0.f, lossb = 0.f, qs = 0.f;
-#pragma unroll
-    for (int d = 0; d < DM; ++d) {
-      if (d < D) {
-        const long o = ((long)b * D + d) * n + lane;
-        const float ad = x0[d];
-        const float mean0 = q_wave_sum_dpp(ad) * invn;
-        const int ai = ais[d];
-        const float q_sel = v0b + q_lane_f(ad, __builtin_amdgcn_readfirstlane(ai)) - mean0;
-        const float tdv = q_sel - y;
-        prio += fabsf(tdv);
-        qs += q_sel;
-        float err, dfd;
-        if (a.huber) {
-          const float at = fabsf(tdv);
-          err = at < 1.f ? 0.5f * tdv * tdv : at - 0.5f;
-          dfd = fminf(fmaxf(tdv, -1.f), 1.f);
-        } else {
-          err = tdv * tdv;
-          dfd = 2.f * tdv;
-        }
-        lossb += err;
-        const float g = w * invB * (a.loss_sum ? 1.f : invD) * dfd;
-        dv += g;
-        if (on) a.d_adv0[((long)b * D + d) * a.nbp + lane] = g * ((lane == ai ? 1.f : 0.f) - invn);
-        if (lane == 0) a.td[b * D + d] = tdv;
-      }
-    }
-    if (lane == 0) {
-      a.d_v0[(long)b * a.ld_dv] = dv;
-      a.priority[b] = prio;
-      a.row_part[3 * b] = w * lossb * (a.loss_sum ? 1.f : invD);
-      a.row_part[3 * b + 1] = qs * invD;
-      a.row_part[3 * b + 2] = prio * invD;
-    }
+  if (b < a.B && D <= Q_DM) {
+    QRowIn in;
+    q_row_load(a, b, lane, in);
+    const float invD = 1.f / (float)D, invn = 1.f / (float)n;
+    q_row_loss(a, in, lane,
+               [&](int d, float g, int ai, float tdv) {
+                 if (lane < n) a.d_adv0[((long)b * D + d) * a.nbp + lane] = g * ((lane == ai ? 1.f : 0.f) - invn);
+                 if (lane == 0) a.td[b * D + d] = tdv;
+               },
+               [&](float dv, float prio, float wloss, float qsel) {
+                 if (lane == 0) {
+                   a.d_v0[(long)b * a.ld_dv] = dv;
+                   a.priority[b] = prio;
+                   a.row_part[3 * b] = wloss;
+                   a.row_part[3 * b + 1] = qsel;
+                   a.row_part[3 * b + 2] = prio * invD;
+                 }
+               });
   } else if (b < a.B) {
     const float invB = 1.f / (float)a.B, invD = 1.f / (float)D, invn = 1.f / (float)n;
     const bool on = lane < n;

@@ -25,6 +25,7 @@ bool q_mfma_built() {
   return true;
 #endif
 }
+bool q_chain_built() { return q_mfma_built(); }
 bool act_mfma_built() { return q_mfma_built(); }
 int device_lds_bytes() {
 #ifdef GRL_HOSTEMU
@@ -74,6 +75,17 @@ void launch_q_bwd(const QFusedArgs& a, hipStream_t s) {
 #endif
   hipLaunchKernelGGL(q_bwd_towers_kernel, towers, dim3(256), 0, s, a);
   if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, trunk, dim3(256), 0, s, a);
+}
+void launch_q_bwd_chain(const QChainArgs& a, hipStream_t s) {
+#ifdef GRL_HOSTEMU
+  (void)a; (void)s;
+  fprintf(stderr, "grl: the chained Q backward has no emulation form (q_chain_built() is false there)\n");
+  abort();
+#else
+  const dim3 towers((a.f.B + HT_RB - 1) / HT_RB, a.f.D + 1), trunk((a.f.B + HT_RB - 1) / HT_RB);
+  hipLaunchKernelGGL(q_bwd_towers_chain_kernel, towers, dim3(256), 0, s, a);
+  if (a.f.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_chain_kernel, trunk, dim3(256), 0, s, a);
+#endif
 }
 
 }  // namespace grl

@@ -13,6 +13,7 @@
 #include "heads_mfma.h"
 #include "q_kernels.h"
 #include "q_mfma.h"
+#include "q_chain.h"
 #include "act_mfma.h"
 #include "conv_stack.h"
 
@@ -37,6 +38,7 @@ void launch_conv_stack_bwd(const ConvStackBwdArgs& a, hipStream_t s);
 // carry no build switches of their own: the g++ emulation build (tests only) has sequential reference forms for the VALU chains
 // and the scalar element-wise kernels, but none for the matrix-core chains or the 16-byte element-wise variants.
 bool q_mfma_built();                 // q_mfma.h: tower / trunk chains on 16x16x4 MFMA stages
+bool q_chain_built();                // q_chain.h: backward chains that form the loss and the weight gradients of their rows
 bool act_mfma_built();               // act_mfma.h: policy head of grl_act on MFMA stages
 int device_lds_bytes();              // shared memory a workgroup may declare on the current device (emulation: no limit)
 enum { HEADS_GENERAL_64 = 0, HEADS_FAST_64 = 1, HEADS_FAST_128 = 2 };
@@ -47,5 +49,6 @@ void launch_heads_bwd(const HeadsBwdArgs& a, hipStream_t s);
 void launch_act_heads_mfma(const ActHeadsArgs& a, hipStream_t s);     // one workgroup per 16 observations (act_mfma.h)
 void launch_q_fwd(const QFusedArgs& a, hipStream_t s);
 void launch_q_bwd(const QFusedArgs& a, hipStream_t s);     // towers, then the trunk (when there is one)
+void launch_q_bwd_chain(const QChainArgs& a, hipStream_t s);     // the same with loss + weight gradients inside (q_chain.h)
 
 }  // namespace grl

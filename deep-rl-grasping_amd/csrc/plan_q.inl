@@ -250,6 +250,10 @@ int grl_ctx::plan_q() {
   }
   QFusedArgs qf;
   memset(&qf, 0, sizeof(qf));
+  // backward chains that form the loss and the weight gradients of their own rows (q_chain.h): five launches per update instead
+  // of seven.  Needs the matrix-core chains and the fused reduction + clip + Adam launch (which sums the row-block slabs and
+  // the loss's row sums); GRL_TUNE q_chain=0 keeps the loss and weight-gradient launches.
+  bool q_chain = false;
   if (fused_q) {
     const QNetP* Wn[3] = {&Pon, &Pon, &Ptg};
     const float* xin[3] = {feat[0], feat[2], feat[2]};
@@ -329,17 +333,16 @@ int grl_ctx::plan_q() {
       h.n_out = 1; h.out_dim = tw < D ? nb : 1; h.ow[0] = tower_w(Pon, tw, Lt);
       hb.push_back(h);
     }
-    qf.fwd = upload_vec(wk, hf);
-    qf.bwd_tw = upload_vec(wk, hb);
     qf.B = B; qf.D = D; qf.nb = nb; qf.Ht = Lc > 0 ? c.q_common[Lc - 1] : 0;
     qf.d_adv = gact.adv; qf.d_v = gact.v; qf.nbp = nbp; qf.ld_dv = ld_dv; qf.trunk_scale = c.q_trunk_scale;
     bool trunk_mfma_ok = true;
+    std::vector<HtHead> htr;
     if (Lc > 0) {
       HtHead h;
       memset(&h, 0, sizeof(h));
       h.H0 = c.q_common[0]; h.L = Lc; h.z0 = a.zc[0]; h.g0 = gact.zc[0]; h.ldg0 = h.H0; h.hid[0] = h.H0;
       for (int l = 1; l < Lc; ++l) { h.w[l] = P + Pon.cw[l]; h.hid[l] = c.q_common[l]; h.z[l] = a.zc[l]; h.g[l] = gact.zc[l]; }
-      qf.bwd_tr = upload_vec(wk, std::vector<HtHead>{h});
+      htr.push_back(h);
       trunk_mfma_ok = qm_head_ok(h, false);
       qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
     }
@@ -348,7 +351,17 @@ int grl_ctx::plan_q() {
     for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h, true, true);
     for (auto& h : hb) qf.mfma = qf.mfma && qm_head_ok(h);
     if (want_mfma && !qf.mfma) return fail(GRL_ERR_INVALID, "internal: the Q chains were planned for the matrix-core stages and do not fit them");
-    if (getenv("GRL_PLAN_DUMP")) fprintf(stderr, "grl plan: q chains       %s\n", qf.mfma ? "matrix-core stages (q_mfma.h)" : "VALU stages (q_kernels.h)");
+    q_chain = qf.mfma && q_chain_built() && tune_int("q_chain", 1) != 0 && tune_int("fused_qapply", 1) != 0 && qc_shape_ok(nb, D, c.obs_dim);
+    if (q_chain) {      // nothing reads the pre-activation gradients from memory any more: the chains keep them in LDS
+      for (auto& h : hb) { h.g0 = nullptr; for (int l = 0; l < GRL_MAX_LAYERS; ++l) h.g[l] = nullptr; }
+      for (auto& h : htr) { h.g0 = nullptr; for (int l = 0; l < GRL_MAX_LAYERS; ++l) h.g[l] = nullptr; }
+    }
+    qf.fwd = upload_vec(wk, hf);
+    qf.bwd_tw = upload_vec(wk, hb);
+    if (!htr.empty()) qf.bwd_tr = upload_vec(wk, htr);
+    if (getenv("GRL_PLAN_DUMP"))
+      fprintf(stderr, "grl plan: q chains       %s%s\n", qf.mfma ? "matrix-core stages (q_mfma.h)" : "VALU stages (q_kernels.h)",
+              q_chain ? ", loss + weight gradients inside the backward chains (q_chain.h)" : "");
     if (!l0.empty()) add_launch(ops_grads, "q_l0", 0, l0);
     Op op; op.tag = "q_fwd";
     const QFusedArgs fa = qf;
@@ -367,6 +380,8 @@ int grl_ctx::plan_q() {
     for (size_t l = 0; l < sh_[0].size(); ++l) add_launch(ops_grads, "q_fwd", 0, merged(sh_[0][l], sh_[1][l], sh_[2][l]));
     add_launch(ops_grads, "q_fwd", 0, merged(so_[0], so_[1], so_[2]));
   }
+  QLossArgs q_loss_args;
+  memset(&q_loss_args, 0, sizeof(q_loss_args));
   {
     QLossArgs qa;
     qa.B = B; qa.D = D; qa.n = nb; qa.gamma = c.gamma; qa.lr = c.lr; qa.huber = c.q_huber; qa.double_q = c.q_double;
@@ -380,18 +395,68 @@ int grl_ctx::plan_q() {
     zero_once.push_back({qa.counter, 16});
     q_row_part = qa.row_part;
     q_finish = q_loss_finishes_itself(qa.n) ? 1 : 0;     // (the one-workgroup fallback for > 64 bins forms its sums itself)
-    Op op; op.tag = "q_loss";
-    op.run = [qa, q_defer](hipStream_t s) {
-      QLossArgs q2 = qa;
-      q2.defer_finish = *q_defer;
-      launch_q_loss(q2, s);
-    };
-    ops_grads.push_back(op);
+    q_loss_args = qa;
+    if (!q_chain) {
+      Op op; op.tag = "q_loss";
+      op.run = [qa, q_defer](hipStream_t s) {
+        QLossArgs q2 = qa;
+        q2.defer_finish = *q_defer;
+        launch_q_loss(q2, s);
+      };
+      ops_grads.push_back(op);
+    }
   }
   // =============================================================== backward (online net on s)
   {
     const QNetAct& a = net[0];
-    if (fused_q) {
+    if (q_chain) {
+      // one slab per row block and variable; the apply launch sums them in row-block order
+      const int n_rb = (B + HT_RB - 1) / HT_RB;
+      auto layer = [&](int K, int N, int64_t woff, int64_t boff) {
+        QcLayer y;
+        y.K = K; y.N = N;
+        y.dw = wk.f32((int64_t)n_rb * K * N); y.db = wk.f32((int64_t)n_rb * N);
+        ReduceDesc r;
+        memset(&r, 0, sizeof(r));
+        r.src = y.dw; r.splits = n_rb; r.slab_stride = (int64_t)K * N; r.dst = grads + woff; r.n = K * N;
+        reduces.push_back(r);
+        r.src = y.db; r.slab_stride = N; r.dst = grads + boff; r.n = N;
+        reduces.push_back(r);
+        return y;
+      };
+      std::vector<QcHead> ytw;
+      for (int tw = 0; tw <= D; ++tw) {
+        const int Lt = tw < D ? Lb : Lv;
+        const std::vector<int64_t>& W = tw < D ? Pon.bw[tw] : Pon.vw;
+        const std::vector<int64_t>& Bv = tw < D ? Pon.bb[tw] : Pon.vb;
+        QcHead y;
+        memset(&y, 0, sizeof(y));
+        y.xin = Lc > 0 ? a.zc[Lc - 1] : feat[0]; y.ld_xin = Lc > 0 ? hdim : ldf;
+        int kin = hdim;
+        for (int l = 0; l < Lt; ++l) {
+          const int n = tw < D ? c.q_branch[l] : c.q_value[l];
+          y.lay[l] = layer(kin, n, W[l], Bv[l]);
+          kin = n;
+        }
+        y.lay[Lt] = layer(kin, tw < D ? nb : 1, W[Lt], Bv[Lt]);
+        ytw.push_back(y);
+      }
+      QChainArgs ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.f = qf; ca.l = q_loss_args; ca.l.defer_finish = 1;
+      ca.tw = upload_vec(wk, ytw);
+      if (Lc > 0) {
+        QcHead y;
+        memset(&y, 0, sizeof(y));
+        y.xin = feat[0]; y.ld_xin = ldf;
+        int kin = c.obs_dim;
+        for (int k = 0; k < Lc; ++k) { y.lay[k] = layer(kin, c.q_common[k], Pon.cw[k], Pon.cb[k]); kin = c.q_common[k]; }
+        ca.tr = upload_vec(wk, std::vector<QcHead>{y});
+      }
+      Op op; op.tag = "q_bwd";
+      op.run = [ca](hipStream_t s) { launch_q_bwd_chain(ca, s); };
+      ops_grads.push_back(op);
+    } else if (fused_q) {
       const QFusedArgs fa = qf;
       Op op; op.tag = "q_bwd";
       op.run = [fa](hipStream_t s) { launch_q_bwd(fa, s); };
@@ -433,7 +498,8 @@ int grl_ctx::plan_q() {
                                 gact.zc[k - 1], c.q_common[k - 1], a.zc[k - 1])});
       }
     }
-    // weight gradients
+    // weight gradients (not here when the chained backward has formed them)
+    if (!q_chain) {
     std::vector<IgemmProb> wg;
     // (inputs whose rows are padded to a multiple of 4 floats -- the observations, ldf -- carry the padding columns along:
     //  every problem then fits the vectorised weight-gradient kernel; their slab rows are never reduced)
@@ -462,6 +528,7 @@ int grl_ctx::plan_q() {
     }
     wgrad(z, ldz, kz, gact.v, ld_dv, 1, Pon.vw[Lv], Pon.vb[Lv]);
     add_launch(ops_grads, "q_wgrad", 2, wg);
+    }
   }
   {
     std::vector<int2> rt = reduce_tiles();
@@ -564,6 +631,8 @@ int grl_ctx::plan_q() {
       }
     }
   }
+  if (q_chain && (!*q_defer || !q_finish))
+    return fail(GRL_ERR_INVALID, "internal: the chained Q backward was planned without the fused apply launch that sums its slabs and row sums");
   // =============================================================== act path: Q-values of n observations
   {
     afeat = wk.f32((int64_t)NA * ldf);

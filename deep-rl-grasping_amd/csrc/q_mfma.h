@@ -35,6 +35,14 @@ static inline bool qm_head_ok(const HtHead& h, bool has_out = true, bool fwd = f
 #ifndef GRL_HOSTEMU
 
 typedef float qm_f4 __attribute__((ext_vector_type(4)));
+// Pointers read from a descriptor are generic to the compiler and become FLAT accesses, which count on the LDS counter as
+// well: the wait in front of every stage barrier then also waited for the acknowledgement of the activations / gradients
+// the stage before had just stored (a memory round trip per stage).  Typed as global (address space 1) they are
+// global_load / global_store and the barriers order LDS traffic only.
+typedef __attribute__((address_space(1))) float* qm_gp;
+typedef __attribute__((address_space(1))) const float* qm_gcp;
+#define QM_GW(p) ((qm_gp)(p))
+#define QM_G(p) ((qm_gcp)(p))
 struct __attribute__((aligned(16))) QmLds {
   float z[2][HT_RB][QM_LD];   // activations (forward) / gradients (backward) entering the next stage
   float o[HT_RB][QM_LD];      // backward: output gradients of the rows
@@ -81,10 +89,10 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
   for (int li = 1; li < GRL_MAX_LAYERS; ++li)
     if (li < L) {
       qm_load_b(bw[li], h.w[li], h.hid[li - 1], h.hid[li], h.hid[li], 1, n, q);
-      bias[li] = n < h.hid[li] ? h.b[li][n] : 0.f;
+      bias[li] = n < h.hid[li] ? QM_G(h.b[li])[n] : 0.f;
     }
   qm_load_b(bw[0], h.ow[0], h.hid[L - 1], h.out_dim, h.out_dim, 1, n, q);
-  bias[0] = n < h.out_dim ? h.ob[0][n] : 0.f;
+  bias[0] = n < h.out_dim ? QM_G(h.ob[0])[n] : 0.f;
   // layer 0 inside the chain (n_xa > 0: `xa` holds the rows' inputs, `w0a` the layer-0 kernel [n_xa, H0], n_xa <= 128):
   // two 64-deep stages over the inputs staged in z[0] | z[1] -- no GEMM launch in front of the chain
   const int nx = h.n_xa;
@@ -92,12 +100,12 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
   if (nx > 0) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) qm_load_b(bx[kc], h.w0a + (long)kc * QM_W * h.H0, nx - kc * QM_W, h.H0, h.H0, 1, n, q);
-    bx0 = n < h.H0 ? h.b0[n] : 0.f;
+    bx0 = n < h.H0 ? QM_G(h.b0)[n] : 0.f;
     const int r = t >> 4, row = row0 + r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int col = (t & 15) + 16 * j;
-      xv[j] = (row < B && col < nx) ? h.xa[(long)row * h.ld_xa + col] : 0.f;
+      xv[j] = (row < B && col < nx) ? QM_G(h.xa)[(long)row * h.ld_xa + col] : 0.f;
     }
   }
   // layer 0 from the GEMM launch: z0 = relu(u (+ further partial sums, in order) + b0); thread -> (column t & 63, rows 4 (t >> 6) ..)
@@ -105,17 +113,17 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
   float u0[4] = {0.f, 0.f, 0.f, 0.f};
   float b0 = 0.f;
   if (nx == 0 && n0 < h.H0) {
-    b0 = h.b0[n0];
+    b0 = QM_G(h.b0)[n0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + 4 * rg + i;
-      u0[i] = row < B ? h.u[(long)row * h.ldu + n0] : 0.f;
+      u0[i] = row < B ? QM_G(h.u)[(long)row * h.ldu + n0] : 0.f;
     }
     for (int sp = 1; sp < h.u_split; ++sp)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * rg + i;
-        u0[i] += row < B ? h.u[sp * h.u_stride + (long)row * h.ldu + n0] : 0.f;
+        u0[i] += row < B ? QM_G(h.u)[sp * h.u_stride + (long)row * h.ldu + n0] : 0.f;
       }
   }
   qm_zero(s);
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
       const int r2 = 4 * q + i, row = row0 + r2;
       const float v = n < h.H0 ? fmaxf(acc[i] + bx0, 0.f) : 0.f;
       s.z[0][r2][n] = v;
-      if (row < B && n < h.H0 && h.z0) h.z0[(long)row * h.H0 + n] = v;
+      if (row < B && n < h.H0 && h.z0) QM_GW(h.z0)[(long)row * h.H0 + n] = v;
     }
   } else if (n0 < h.H0) {
 #pragma unroll
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
       const int row = row0 + 4 * rg + i;
       const float v = fmaxf(u0[i] + b0, 0.f);
       s.z[0][4 * rg + i][n0] = v;
-      if (row < B && h.z0) h.z0[(long)row * h.H0 + n0] = v;
+      if (row < B && h.z0) QM_GW(h.z0)[(long)row * h.H0 + n0] = v;
     }
   }
   __syncthreads();
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
         const int r = 4 * q + i, row = row0 + r;
         const float v = n < Hout ? fmaxf(acc[i] + bias[li], 0.f) : 0.f;
         s.z[li & 1][r][n] = v;
-        if (row < B && n < Hout && h.z[li]) h.z[li][(long)row * Hout + n] = v;
+        if (row < B && n < Hout && h.z[li]) QM_GW(h.z[li])[(long)row * Hout + n] = v;
       }
       __syncthreads();
     }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + 4 * q + i;
-      if (row < B && n < h.out_dim) h.out[0][(long)row * ld + n] = acc[i] + bias[0];
+      if (row < B && n < h.out_dim) QM_GW(h.out[0])[(long)row * ld + n] = acc[i] + bias[0];
     }
   }
 }
@@ -176,11 +184,15 @@ __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
 //   dz_parts == nullptr: s.o holds the output gradients [row][o]; g_{L-1} = mask * (d_out . ow^T)
 //   dz_parts != nullptr: g_{L-1} = mask * (sum of n_parts partial gradients w.r.t. the last hidden activation) * scale
 // then g_{l-1} = mask * (g_l . w_l^T) down to layer 0, and optionally d xa = g_0 . w0a^T.  Writes every g.
-// `stage_in()` runs after every operand of the chain has been requested: it clears the LDS block, brings the output
-// gradients in (its own loads travel with the operands') and ends with a barrier.
-template <class StageIn>
+// `stage_in(zm)` runs after every operand of the chain has been requested: it clears the LDS block, brings the output
+// gradients in (its own loads travel with the operands') and ends with a barrier; zm[l][i] are the forward activations of
+// this lane's (rows 4q + i, column n) per layer.  `after(li)` runs behind the barrier that follows g_li's arrival in
+// s.z[li & 1] (q_chain.h forms the layer's weight gradient there; the kernels of this file pass a no-op).
+struct QmNoAfter { __device__ __forceinline__ void operator()(int) const {} };
+template <class StageIn, class After = QmNoAfter>
 __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, QmLds& s, float* da, int ld_da,
-                                            const float* dz_parts, int n_parts, long part_stride, float dz_scale, StageIn&& stage_in) {
+                                            const float* dz_parts, int n_parts, long part_stride, float dz_scale, StageIn&& stage_in,
+                                            After&& after = After()) {
   const int t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4;
   const int n = 16 * w + c, L = h.L;
   // ---- operands of every stage: [0] output layer (transposed), [l] hidden layer l (transposed), bwa: layer-0 action rows
@@ -200,7 +212,7 @@ __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, Qm
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = row0 + 4 * q + i;
-        zm[li][i] = (row < B && n < H) ? zp[(long)row * H + n] : 0.f;
+        zm[li][i] = (row < B && n < H) ? QM_G(zp)[(long)row * H + n] : 0.f;
       }
     }
   // g_li of this lane's (rows 4q.., column n): mask, keep in LDS for the next stage, store.  (Called with compile-time li
@@ -213,8 +225,8 @@ __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, Qm
       const float v = mask[i] > 0.f ? acc[i] : 0.f;
       s.z[li & 1][r][n] = v;
       if (row < B && n < H) {
-        if (li == 0) h.g0[(long)row * h.ldg0 + n] = v;
-        else h.g[li][(long)row * H + n] = v;
+        float* gp = li == 0 ? h.g0 : h.g[li];          // (nullptr: nothing reads this gradient from memory -- q_chain.h)
+        if (gp) QM_GW(gp)[(long)row * (li == 0 ? h.ldg0 : H) + n] = v;
       }
     }
   };
@@ -232,7 +244,7 @@ __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, Qm
         part[p][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, ok ? (int)((p * part_stride + (long)row * HL + n) * 4) : I2_OOB, 0, 0));
       }
   }
-  stage_in();
+  stage_in(zm);
   // ---- g_{L-1}
   qm_f4 top = {0.f, 0.f, 0.f, 0.f};
   if (dz_parts) {
@@ -250,12 +262,16 @@ __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, Qm
   for (int li = 0; li < GRL_MAX_LAYERS; ++li)
     if (li == L - 1) put(li, zm[li], top);
   __syncthreads();
+#pragma unroll
+  for (int li = 0; li < GRL_MAX_LAYERS; ++li)
+    if (li == L - 1) after(li);
   // ---- hidden layers
 #pragma unroll
   for (int li = GRL_MAX_LAYERS - 1; li >= 1; --li)
     if (li < L) {
       put(li - 1, zm[li - 1], qm_mma(s.z[li & 1], bw[li], c, q));
       __syncthreads();
+      after(li - 1);
     }
   // ---- d xa
   if (da) {
@@ -263,7 +279,7 @@ __device__ __forceinline__ void qm_bwd_head(const HtHead& h, int row0, int B, Qm
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + 4 * q + i;
-      if (row < B && n < h.n_xa) da[(long)row * ld_da + n] = acc[i];
+      if (row < B && n < h.n_xa) QM_GW(da)[(long)row * ld_da + n] = acc[i];
     }
   }
 }
@@ -281,12 +297,12 @@ __global__ __launch_bounds__(256) void q_bwd_towers_mfma_kernel(QFusedArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int o = o0 + 16 * j;
-      if (row < a.B && o < a.nb) dv[j] = a.d_adv[((long)row * a.D + tw) * a.nbp + o];
+      if (row < a.B && o < a.nb) dv[j] = QM_G(a.d_adv)[((long)row * a.D + tw) * a.nbp + o];
     }
   } else if (o0 == 0 && row < a.B) {
-    dv[0] = a.d_v[(long)row * a.ld_dv];
+    dv[0] = QM_G(a.d_v)[(long)row * a.ld_dv];
   }
-  qm_bwd_head(h, row0, a.B, s, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht, nullptr, 0, 0, 1.f, [&]() {
+  qm_bwd_head(h, row0, a.B, s, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht, nullptr, 0, 0, 1.f, [&](const auto&) {
     qm_zero(s);
     __syncthreads();
 #pragma unroll
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(256) void q_bwd_towers_mfma_kernel(QFusedArgs a) {
 // grid (B/16): trunk -- partials added in tower order, scaled, masked, propagated down to layer 0
 __global__ __launch_bounds__(256) void q_bwd_trunk_mfma_kernel(QFusedArgs a) {
   __shared__ QmLds s;
-  qm_bwd_head(*a.bwd_tr, blockIdx.x * HT_RB, a.B, s, nullptr, 0, a.dh_part, a.D + 1, (long)a.B * a.Ht, a.trunk_scale, [&]() {
+  qm_bwd_head(*a.bwd_tr, blockIdx.x * HT_RB, a.B, s, nullptr, 0, a.dh_part, a.D + 1, (long)a.B * a.Ht, a.trunk_scale, [&](const auto&) {
     qm_zero(s);
     __syncthreads();
   });

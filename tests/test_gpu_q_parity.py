@@ -30,6 +30,34 @@ def test_q_update_valu_chains(name, monkeypatch, capfd):
     assert "VALU stages" in capfd.readouterr().err
 
 
+@pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape", "bdq_baseline_config3", "bdq_5_branches"])
+def test_q_update_separate_loss_and_weight_gradient_launches(name, monkeypatch, capfd):
+    """The default plan forms the loss and the weight gradients inside the backward chains (q_chain.h: five launches per
+    update); GRL_TUNE q_chain=0 keeps the loss and weight-gradient launches of their own (seven).  Both against the oracle --
+    and the TD errors, priorities and parameters of the two agree: the loss arithmetic is the same instruction for
+    instruction, only the summation order of the weight gradients differs."""
+    import numpy as np
+    monkeypatch.setenv("GRL_PLAN_DUMP", "1")
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+    assert "inside the backward chains" in capfd.readouterr().err
+    monkeypatch.setenv("GRL_TUNE", "q_chain=0")
+    qu.run_and_compare(qu.make_q_case(**qu.CASES[name]))
+    assert "inside the backward chains" not in capfd.readouterr().err
+    outs = []
+    for tune in ("q_chain=1", "q_chain=0"):
+        monkeypatch.setenv("GRL_TUNE", tune)
+        case = qu.make_q_case(**qu.CASES[name])
+        eng = qu.q_engine_setup(case)
+        eng.train(1, case["idx"][:1], case["weights"][:1])
+        outs.append((eng.td_errors(), eng.priorities(), eng.get_gradients(), eng.get_parameters()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for k, g1 in outs[1][2].items():
+        assert np.max(np.abs(outs[0][2][k] - g1)) <= 1e-5 * max(1e-6, float(np.max(np.abs(g1)))), k
+    for k in outs[0][3]:
+        np.testing.assert_allclose(outs[0][3][k], outs[1][3][k], rtol=0, atol=2e-6, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
 def test_q_update_three_launch_apply(name, monkeypatch):
     """GRL_TUNE fused_qapply=0: slab reduction, clip_by_norm and Adam as three launches instead of the fused one."""
