@@ -1106,6 +1106,9 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
     // many thin workgroups beat few fat ones here; the default stays 1.  Per element the arithmetic is the scalar path's, in
     // the same order.
     typedef float rs_f4 __attribute__((ext_vector_type(4)));
+    // (descriptor pointers are generic to the compiler -> FLAT loads; typed as global they are global_load_dwordx4)
+    typedef const __attribute__((address_space(1))) rs_f4* rs_gq;
+    typedef __attribute__((address_space(1))) rs_f4* rs_gqw;
     constexpr int NQ = RS_QUADS;
     const rs_f4 z4 = {0.f, 0.f, 0.f, 0.f};
     int ii[NQ];
@@ -1140,7 +1143,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
       for (int u = 0; u < NQ; ++u)
         if (on[u]) {
 #pragma unroll
-          for (int j = 0; j < RS_BATCH; ++j) vv[u][j] = *(const rs_f4*)(src[u] + (long)(k + j) * d.slab_stride);
+          for (int j = 0; j < RS_BATCH; ++j) vv[u][j] = *(rs_gq)(src[u] + (long)(k + j) * d.slab_stride);
         }
 #pragma unroll
       for (int u = 0; u < NQ; ++u)
@@ -1153,7 +1156,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
       rs_f4 vv[NQ];
 #pragma unroll
       for (int u = 0; u < NQ; ++u)
-        if (on[u]) vv[u] = *(const rs_f4*)(src[u] + (long)k * d.slab_stride);
+        if (on[u]) vv[u] = *(rs_gq)(src[u] + (long)k * d.slab_stride);
 #pragma unroll
       for (int u = 0; u < NQ; ++u)
         if (on[u]) s[u] += vv[u];
@@ -1164,7 +1167,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
       if (!on[u]) continue;
       // (data parallel: the sums go to the exchange buffer ONLY -- nothing reads this rank's own bucket before the exchange)
       if (mirror) { const float sv[4] = {s[u].x, s[u].y, s[u].z, s[u].w}; st_sys_quad(mirror, ((d.dst + ii[u]) - aa.grads) >> 2, sv); }
-      else *(rs_f4*)(d.dst + ii[u]) = s[u];
+      else *(rs_gqw)(d.dst + ii[u]) = s[u];
       if (fuse_adam) {
         float pe[4] = {p[u].x, p[u].y, p[u].z, p[u].w}, me[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, ve[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
         const float ge[4] = {s[u].x, s[u].y, s[u].z, s[u].w};

@@ -42,12 +42,12 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
   float ss = 0.f;
   for (int base = 0; base < d.n; base += NT * U) {
     float acc[U];
-    const float* sp[U];
+    const __attribute__((address_space(1))) float* sp[U];     // (global, not generic: no FLAT loads on the LDS counter)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = base + u * NT + t;
       const int ic = i < d.n ? i : 0;
-      sp[u] = d.src + (d.row_len > 0 ? (long)(ic / d.row_len) * d.src_ld + ic % d.row_len : ic);
+      sp[u] = (const __attribute__((address_space(1))) float*)d.src + (d.row_len > 0 ? (long)(ic / d.row_len) * d.src_ld + ic % d.row_len : ic);
       acc[u] = 0.f;
     }
     for (int k = 0; k < d.splits; ++k) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
       if (i < d.n) {
         float g = gsum[i];
         if (clip > 0.f) g *= sc;
-        d.dst[i] = g;
+        ((__attribute__((address_space(1))) float*)d.dst)[i] = g;
         adam_elem(grad_scaled(g, aa.grad_scale), p[u], m[u], v[u], alpha, aa.eps);
         aa.params[e0 + i] = p[u]; aa.m[e0 + i] = m[u]; aa.v[e0 + i] = v[u];
       }
