@@ -67,10 +67,20 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
   if (clip > 0.f) {
     red[t] = ss;
     __syncthreads();
-    for (int off = NT / 2; off > 0; off >>= 1) {
+    for (int off = NT / 2; off >= 64; off >>= 1) {
       if (t < off) red[t] += red[t + off];
       __syncthreads();
     }
+    if (t < 64) {       // the last six levels live in wave 0 alone: same tree, a wave-level fence instead of a barrier of 16 waves
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (t < off) red[t] += red[t + off];
+      }
+    }
+    __syncthreads();
     sc = clip / fmaxf(sqrtf(red[0]), clip);
   }
   const float alpha = aa.sc->adam_alpha;
