@@ -686,7 +686,7 @@ static size_t dp_mom_bytes(int64_t elems) { return (size_t)rup((2 * elems + 4) *
 
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
   if (!h || !handle_out) return fail(GRL_ERR_INVALID, "null argument");
-  if (h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "the exchange step is defined for SAC handles");
+  if (h->cfg.algo == GRL_ALGO_AE) return fail(GRL_ERR_STATE, "the exchange step is defined for SAC / DQN / BDQ handles");
   if (world < 1 || world > DP_MAX_WORLD || rank < 0 || rank >= world) return fail(GRL_ERR_INVALID, "bad rank / world size");
   if (h->dp_buf) return fail(GRL_ERR_STATE, "grl_allreduce_init was already called on this handle");
   if (h->n_train % 4 || h->n_train * 4 >= (int64_t)1 << 31) return fail(GRL_ERR_STATE, "the gradient bucket is not a whole number of 16-byte groups below 2 GB");
@@ -822,7 +822,11 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
   if (!h || !handles) return fail(GRL_ERR_INVALID, "null argument");
   if (!h->dp_buf) return fail(GRL_ERR_STATE, "call grl_allreduce_init first");
   if (h->dp_on) return fail(GRL_ERR_STATE, "already connected");
-  if (h->ops_grads.empty() || h->ops_grads.back().tag != "reduce_slabs" || !h->red_all.tiles)
+  const bool qh = h->cfg.algo != GRL_ALGO_SAC;
+  // (DQN / BDQ: the batch means of the loss launch follow the reduction as a launch of their own in the split plan)
+  size_t n_body = h->ops_grads.size();
+  while (n_body > 0 && h->ops_grads[n_body - 1].tag == "q_finish") --n_body;
+  if (n_body == 0 || h->ops_grads[n_body - 1].tag != "reduce_slabs" || !h->red_all.tiles)
     return fail(GRL_ERR_STATE, "this plan does not end in the slab reduction the exchange publishes from");
   char* flags[DP_MAX_WORLD];
   char* data[DP_MAX_WORLD];
@@ -848,8 +852,26 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
   h->dp = dp_channel(h, 0, {{0, h->n_train}}, flags, data);
   DpArgs d1s = h->dp;
   d1s.oneshot = 1;
-  h->dp_body.assign(h->ops_grads.begin(), h->ops_grads.end() - 1);
-  for (int one = 0; one < 2; ++one) {
+  h->dp_body.assign(h->ops_grads.begin(), h->ops_grads.begin() + (n_body - 1));
+  if (qh) {
+    // DQN / BDQ: per-variable clip_by_norm sits between the all-reduce and Adam, so the sums are pulled into the gradient
+    // bucket (two-shot + gather) and the plan's own apply launches follow with grad_scale = 1 / W (clip threshold W c on the
+    // sum, plan_q.inl).  One form only: grl_allreduce_set_mode accepts "auto" / two-shot on these handles.
+    DpArgs d = h->dp;
+    d.gathered = h->grads;
+    std::vector<Op>& tail = h->ops_dp;
+    tail.clear();
+    tail.push_back(dp_k1_op(h, h->red_all, d, h->loss_args, nullptr, 0, "reduce_publish"));
+    tail.push_back(dp_wait_op(d, 0));
+    tail.push_back(dp_reduce_op(d));
+    tail.push_back(dp_wait_op(d, 1));
+    tail.push_back(dp_gather_op(d));
+    for (size_t k = n_body; k < h->ops_grads.size(); ++k) tail.push_back(h->ops_grads[k]);      // q_finish
+    for (auto& o : h->ops_apply) tail.push_back(o);
+    h->ops_dp1.clear();
+    for (auto* v : {&h->ops_pfdp_first, &h->ops_pfdp_mid, &h->ops_pfdp_last, &h->ops_pfdp1_first, &h->ops_pfdp1_mid, &h->ops_pfdp1_last}) v->clear();
+  }
+  for (int one = 0; one < 2 && !qh; ++one) {
     const DpArgs& d = one ? d1s : h->dp;
     std::vector<Op>& tail = one ? h->ops_dp1 : h->ops_dp;
     tail.clear();
@@ -957,6 +979,7 @@ int grl_allreduce_set_mode(grl_handle h, int mode) {
   if (!h) return fail(GRL_ERR_INVALID, "null handle");
   if (!h->dp_on) return fail(GRL_ERR_STATE, "call grl_allreduce_init / grl_allreduce_connect first");
   if (mode < 0 || mode > 2) return fail(GRL_ERR_INVALID, "mode: 0 auto, 1 two-shot, 2 one-shot");
+  if (mode == 2 && h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "DQN / BDQ handles exchange two-shot (the clipped apply reads the gathered sums)");
   h->dp_mode = mode;
   return GRL_OK;
 }
@@ -969,7 +992,10 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   if (*h->dp_err_host) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
   // one-shot (every rank adds all contributions itself: one kernel and one flag round less, (W - 1) n bytes per rank
   // instead of 2 (W - 1) / W n) pays for W <= 2
-  const bool one = !h->dp_overlap && (h->dp_mode == 2 || (h->dp_mode == 0 && h->dp.world <= 2));
+  const bool qh = h->cfg.algo != GRL_ALGO_SAC;
+  if (qh && h->per_on) return fail(GRL_ERR_STATE, "the exchange step draws uniform minibatches: prioritised handles train with grl_train_step_per");
+  if (qh) h->grad_scale = 1.f / (float)h->dp.world;       // (baked into the captured apply launches: constant per connection)
+  const bool one = !qh && !h->dp_overlap && (h->dp_mode == 2 || (h->dp_mode == 0 && h->dp.world <= 2));
   std::vector<Op> none;
   std::vector<Op>* body = h->dp_overlap ? &h->ops_dp_overlap : &h->dp_body;
   std::vector<Op>* tail = h->dp_overlap ? &none : (one ? &h->ops_dp1 : &h->ops_dp);

@@ -543,6 +543,12 @@ int grl_ctx::plan_q() {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0, AdamArgs{}, 0);
     };
     ops_grads.push_back(op);
+    // (the in-graph exchange publishes from this reduction: capi.inl, grl_allreduce_connect)
+    red_all.tiles = d_rt; red_all.n = ntiles; red_all.has_loss = 0;
+    memset(&adam_base, 0, sizeof(adam_base));
+    adam_base.params = params; adam_base.grads = grads; adam_base.m = adam_m; adam_base.v = adam_v; adam_base.n_train = n_train; adam_base.sc = sc;
+    adam_base.grad_scale = 1.f; adam_base.eps = 1e-8f; adam_base.target = params + tgt_off;
+    memset(&loss_args, 0, sizeof(loss_args));
   }
   if (c.q_grad_clip > 0.f) {   // per-variable tf.clip_by_norm, after the data-parallel all-reduce point
     std::vector<VarSeg> segs;
@@ -552,8 +558,11 @@ int grl_ctx::plan_q() {
     const int nseg = (int)segs.size();
     float* g = grads; const float clip = c.q_grad_clip;
     Op op; op.tag = "clip_by_norm";
-    op.run = [g, d_segs, nseg, clip](hipStream_t s) {
-      hipLaunchKernelGGL(clip_by_norm_kernel, dim3(nseg), dim3(256), 0, s, g, d_segs, clip);
+    grl_ctx* self = this;
+    // data parallel (grl_apply_grads(1 / W) on the all-reduced SUM of W replicas): clip(mean, c) * W == clip(sum, W c), so the
+    // sum is clipped at clip / grad_scale and Adam's 1 / W brings it back -- the mean of the replicas clipped as one gradient
+    op.run = [self, g, d_segs, nseg, clip](hipStream_t s) {
+      hipLaunchKernelGGL(clip_by_norm_kernel, dim3(nseg), dim3(256), 0, s, g, d_segs, clip / self->grad_scale);
     };
     ops_apply.push_back(op);
   }

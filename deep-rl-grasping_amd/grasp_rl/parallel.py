@@ -239,6 +239,19 @@ def launched_world():
     return rank, world, int(os.environ.get("LOCAL_RANK", str(rank)))
 
 
+def runtime_for(mode):
+    """The ``DataParallelRuntime`` of a model constructed with ``data_parallel=mode``: None for None / False / "off";
+    "auto" only under a torch.distributed launch of more than one process; anything else insists."""
+    if mode in (None, False, "", "0", "off"):
+        return None
+    if mode == "auto" and launched_world() is None and not dist.is_initialized():
+        return None
+    rt = DataParallelRuntime()
+    if rt.world == 1 and mode == "auto":
+        return None
+    return rt
+
+
 class DataParallelRuntime:
     """What ``grasp_rl.sb.SAC(data_parallel=...)`` needs around the engine: the process group (initialised here when the
     launcher has not: gloo -- the gradient exchange itself runs inside the update graph and needs no collective

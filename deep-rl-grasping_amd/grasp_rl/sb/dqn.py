@@ -11,6 +11,16 @@ epsilon-greedy exploration, replay bookkeeping and -- when ``prioritized_replay=
 proportional prioritised sampler (sum-tree on the host, as stable-baselines does; a device-side tree
 is SURVEY.md 8f row 4).  DQN follows stock stable-baselines 2.10.1; BDQ follows the decisions
 documented in SURVEY.md A.6 / oracle/dqn.py (the fork's source is unavailable: parity unpinned).
+
+Data parallelism (BASELINE north_star: "SAC / BDQ / DQN update ... optionally sharded"):
+``data_parallel="auto"`` (or GRL_DATA_PARALLEL=auto) under a torchrun launch trains one replica per rank, as ``sb.SAC``
+does -- every rank steps its OWN environment and fills its own replay ring, the global minibatch is split evenly over
+the ranks, the gradient SUM is exchanged inside the update's graph (``grasp_rl.parallel.DataParallelInGraph``; a
+collective library as fallback), clipped per variable as the mean of the replicas and applied identically everywhere.
+Counters (``num_timesteps``, exploration and beta schedules, ``learning_starts``, ``train_freq``,
+``target_network_update_freq``) count environment steps of the JOB: W per loop iteration.  Callbacks, logging and
+the stop decision are rank 0's.  Uniform replay only: prioritised replay keeps per-rank trees and is not combined with
+the exchange (raises).
 """
 import time
 
@@ -45,9 +55,15 @@ class _QModel:
                  learning_starts=1000, target_network_update_freq=500, prioritized_replay=False,
                  prioritized_replay_alpha=0.6, prioritized_replay_beta0=0.4, prioritized_replay_beta_iters=None,
                  prioritized_replay_eps=1e-6, param_noise=False, n_cpu_tf_sess=None, verbose=0, tensorboard_log=None,
-                 _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False, seed=None, device="cuda:0"):
+                 _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False, seed=None, device="cuda:0",
+                 data_parallel=None, dp_exchange="ingraph"):
         if param_noise:
             raise NotImplementedError("param_noise is not implemented")
+        import os
+        if data_parallel is None:
+            data_parallel = os.environ.get("GRL_DATA_PARALLEL") or None
+        self.data_parallel, self.dp_exchange = data_parallel, dp_exchange
+        self._dp_rt = self._dp = None
         self.policy, self.policy_kwargs = policy, ({} if policy_kwargs is None else dict(policy_kwargs))
         self.gamma, self.learning_rate, self.buffer_size = gamma, learning_rate, int(buffer_size)
         self.exploration_fraction, self.exploration_final_eps = exploration_fraction, exploration_final_eps
@@ -63,6 +79,8 @@ class _QModel:
         self.env = self.observation_space = self.action_space = None
         self.n_envs, self._vec_normalize_env, self.engine = 1, None, None
         self._rng = np.random.default_rng(seed)
+        if self._dp_runtime() is not None:        # exploration differs per replica
+            self._rng = np.random.default_rng([0 if seed is None else int(seed), self._dp_rt.rank])
         self.exploration = None
         if env is not None:
             self.set_env(env)
@@ -90,6 +108,16 @@ class _QModel:
     def get_vec_normalize_env(self):
         return self._vec_normalize_env
 
+    # ------------------------------------------------------------------ data parallel
+    def _dp_runtime(self):
+        if self._dp_rt is not None:
+            return self._dp_rt
+        if self.data_parallel in (None, False, "", "0", "off"):
+            return None
+        from ..parallel import runtime_for
+        self._dp_rt = runtime_for(self.data_parallel)
+        return self._dp_rt
+
     # ------------------------------------------------------------------ model
     def _towers(self):
         raise NotImplementedError
@@ -109,14 +137,26 @@ class _QModel:
         if vn is not None:
             kw = dict(clip_obs=vn.clip_obs, clip_reward=vn.clip_reward, norm_eps=vn.epsilon)
         lr = float(self.learning_rate(1.0)) if callable(self.learning_rate) else float(self.learning_rate)
-        cfg = _capi.make_q_config(self.algo, obs_shape[0], D, bins, common, branch, value, batch_size=self.batch_size,
+        rt = self._dp_runtime()
+        if rt is not None and self.prioritized_replay:
+            raise NotImplementedError("prioritized_replay under data parallelism: the per-rank priority trees are not combined "
+                                      "with the gradient exchange (use uniform replay, as gripper_grasp.yaml:106 selects)")
+        self._local_batch = self.batch_size if rt is None else rt.shard(self.batch_size, "minibatch rows")
+        engine_seed = 0 if self.seed is None else int(self.seed)
+        if rt is not None:
+            engine_seed += 7919 * rt.rank             # every replica draws its own replay indices
+            self.device = rt.device
+        cfg = _capi.make_q_config(self.algo, obs_shape[0], D, bins, common, branch, value, batch_size=self._local_batch,
                                   act_batch=1, replay_capacity=self.buffer_size, normalize=0 if vn is None else _capi.norm_mode(vn), gamma=self.gamma,
-                                  lr=lr, double_q=self.double_q, seed=0 if self.seed is None else int(self.seed),
+                                  lr=lr, double_q=self.double_q, seed=engine_seed,
                                   prioritized=bool(self.prioritized_replay), per_alpha=self.prioritized_replay_alpha,
                                   per_eps=self.prioritized_replay_eps, **kw)
         self.engine = self._engine_factory(cfg, self.device)
         self.D, self.bins = D, bins
         self._init_weights()
+        if rt is not None:
+            self._dp = rt.make_exchange(self.engine, prefer=self.dp_exchange)
+            self._dp.broadcast_parameters(src=0)
         # prioritised replay lives on the device (csrc/per_kernels.h): sampling, importance weights and the
         # priority write-back never leave HBM
         self._max_priority = 1.0
@@ -172,9 +212,15 @@ class _QModel:
         total_timesteps = int(total_timesteps)
         if reset_num_timesteps:
             self.num_timesteps = 0
-        callback = as_callback(callback)
+        rt, dp = self._dp_rt, self._dp
+        W = 1 if rt is None else rt.world
+        lead = rt is None or rt.rank == 0
+        callback = as_callback(callback if lead else None)      # data parallel: evaluation / checkpoints / logging on rank 0 only
         callback.init_callback(self)
         eng, vn = self.engine, self._vec_normalize_env
+        if rt is not None and vn is not None:       # running statistics merged over the ranks
+            from ..parallel import share_running_stats
+            share_running_stats(vn, rt.ctrl)
         self.exploration = LinearSchedule(self.exploration_fraction * total_timesteps, self.exploration_final_eps,
                                           self.exploration_initial_eps)
         beta_iters = self.prioritized_replay_beta_iters or total_timesteps
@@ -184,11 +230,32 @@ class _QModel:
             if getattr(self, "tensorboard_log", None) else None
         obs = self.env.reset()
         obs_ = vn.get_original_obs() if vn is not None else obs
-        ring_pos = eng.replay_size() % self.buffer_size
         start = time.time()
         callback.on_training_start(locals(), globals())
         callback.on_rollout_start()
-        for _ in range(total_timesteps):
+        finished = False
+        try:
+            self._learn_loop(total_timesteps, callback, log_interval, rt, dp, W, lead, eng, vn, obs, obs_, beta_schedule,
+                             episode_rewards, episode_successes, start)
+            finished = True
+        finally:
+            if rt is not None and vn is not None:          # the collective hook must not outlive the collective loop
+                for rms in (vn.obs_rms, vn.ret_rms):
+                    rms.__dict__.pop("gather", None)
+        if dp is not None and hasattr(dp, "check"):
+            dp.check()                  # raises if an exchange timed out (replicas out of step)
+        if dp is not None and finished and hasattr(dp, "close"):
+            dp.close()                  # collective drain: no rank releases its exchange memory while a peer still pulls from it
+        P = {self._eps_name(): np.float32(self.exploration.value(self.num_timesteps)).reshape(())}
+        eng.set_parameters(P, exact_match=False)        # stable-baselines stores the last epsilon with the model
+        callback.on_training_end()
+        if writer is not None:
+            writer.close()
+        return self
+
+    def _learn_loop(self, total_timesteps, callback, log_interval, rt, dp, W, lead, eng, vn, obs, obs_, beta_schedule,
+                    episode_rewards, episode_successes, start):
+        while self.num_timesteps < total_timesteps:
             eps = self.exploration.value(self.num_timesteps)
             if self._rng.random() < eps:
                 bins = self._rng.integers(0, self.bins, self.D)
@@ -196,37 +263,44 @@ class _QModel:
                 bins = self._greedy_bins(obs[0])
             env_action = self._bins_to_env_action(bins)
             new_obs, rew, done, info = self.env.step(np.asarray([env_action]))
-            self.num_timesteps += 1
+            before = self.num_timesteps
+            self.num_timesteps += W                 # environment steps of the job
             callback.update_locals(locals())
-            if callback.on_step() is False:
+            stop = callback.on_step() is False
+            if rt is not None:
+                stop = rt.any(stop)                 # rank 0's callbacks decide for every replica; no rank runs ahead
+            if stop:
                 break
             new_obs_, rew_ = (vn.get_original_obs(), vn.get_original_reward()) if vn is not None else (new_obs, rew)
             eng.replay_add(np.asarray(obs_, np.float32), bins.astype(np.float32).reshape(1, -1),
                            np.asarray(rew_, np.float32), np.asarray(new_obs_, np.float32), np.asarray(done, np.float32))
-            ring_pos = (ring_pos + 1) % self.buffer_size
             obs, obs_ = new_obs, new_obs_
             episode_rewards[-1] += float(np.asarray(rew_).reshape(-1)[0])
             if done[0]:
                 if isinstance(info[0], dict) and info[0].get("is_success") is not None:
                     episode_successes.append(float(info[0]["is_success"]))
                 episode_rewards.append(0.0)
-            can_sample = eng.replay_size() >= self.batch_size
-            if can_sample and self.num_timesteps > self.learning_starts and self.num_timesteps % self.train_freq == 0:
+            can_sample = eng.replay_size() >= self._local_batch
+            # one update per train_freq environment steps of the job: W of them happened in this iteration
+            crossed = lambda every: self.num_timesteps // max(1, int(every)) - before // max(1, int(every))
+            n_upd = crossed(self.train_freq) if (can_sample and self.num_timesteps > self.learning_starts) else 0
+            if n_upd > 0:
                 callback.on_rollout_end()
                 if vn is not None and eng.cfg.normalize:
                     eng.set_obs_stats(vn.obs_rms.mean, vn.obs_rms.var, float(vn.ret_rms.var))
                 if callable(self.learning_rate):    # stable-baselines evaluates the schedule per update: lr(1 - step / total)
                     eng.set_learning_rate(self.learning_rate(1.0 - (self.num_timesteps - 1) / max(1, total_timesteps)))
                 if self.prioritized_replay:
-                    eng.train_per(1, beta_schedule.value(self.num_timesteps))
+                    eng.train_per(n_upd, beta_schedule.value(self.num_timesteps))
+                elif dp is not None:
+                    dp.train(n_upd)                # the global minibatch: gradients exchanged inside each update's graph
                 else:
-                    eng.train(1)                   # uniform indices from the device RNG, importance weights 1
-                self.n_updates += 1
+                    eng.train(n_upd)               # uniform indices from the device RNG, importance weights 1
+                self.n_updates += n_upd
                 callback.on_rollout_start()
-            if can_sample and self.num_timesteps > self.learning_starts and \
-                    self.num_timesteps % self.target_network_update_freq == 0:
+            if can_sample and self.num_timesteps > self.learning_starts and crossed(self.target_network_update_freq) > 0:
                 eng.update_target()
-            if self.verbose >= 1 and done[0] and log_interval is not None and len(episode_rewards) % log_interval == 0:
+            if self.verbose >= 1 and lead and done[0] and log_interval is not None and len(episode_rewards) % log_interval == 0:
                 logger.logkv("steps", self.num_timesteps)
                 logger.logkv("episodes", len(episode_rewards))
                 logger.logkv("mean 100 episode reward", round(float(np.mean(episode_rewards[-101:-1])), 1))
@@ -235,12 +309,6 @@ class _QModel:
                     logger.logkv("success rate", float(np.mean(episode_successes[-100:])))
                 logger.logkv("fps", int(self.num_timesteps / (time.time() - start + 1e-9)))
                 logger.dumpkvs()
-        P = {self._eps_name(): np.float32(self.exploration.value(self.num_timesteps)).reshape(())}
-        eng.set_parameters(P, exact_match=False)        # stable-baselines stores the last epsilon with the model
-        callback.on_training_end()
-        if writer is not None:
-            writer.close()
-        return self
 
     # ------------------------------------------------------------------ persistence
     def get_parameter_list(self):

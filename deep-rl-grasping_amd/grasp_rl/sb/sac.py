@@ -146,18 +146,11 @@ class SAC:
     def _dp_runtime(self):
         if self._dp_rt is not None:
             return self._dp_rt
-        mode = self.data_parallel
-        if mode in (None, False, "", "0", "off"):
+        if self.data_parallel in (None, False, "", "0", "off"):
             return None
-        from ..parallel import DataParallelRuntime, launched_world
-        import torch.distributed as dist
-        if mode == "auto" and launched_world() is None and not dist.is_initialized():
-            return None
-        rt = DataParallelRuntime()
-        if rt.world == 1 and mode == "auto":
-            return None
-        self._dp_rt = rt
-        return rt
+        from ..parallel import runtime_for
+        self._dp_rt = runtime_for(self.data_parallel)
+        return self._dp_rt
 
     # ------------------------------------------------------------------ model
     def _learning_rate_value(self):

@@ -246,7 +246,12 @@ int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const 
                             a side lane of the graph while the backward through the convolutions runs, bucket 1 follows,
                             Adam waits for both (SURVEY.md 8e "overlapped with the backward"; two-shot).  Same sums,
                             bit-identical parameters.  All ranks must choose alike.  GRL_ERR_STATE when the handle has no
-                            staged plan (vector observations); off by default. */
+                            staged plan (vector observations); off by default.
+   DQN / BDQ handles (uniform replay) take part the same way: tf.clip_by_norm per variable sits between the all-reduce and
+   Adam there, so their exchange is two-shot + a pull of every sum into the gradient bucket, followed by the plan's own clip +
+   Adam with grad_scale 1 / world -- the SUM is clipped at world x clip, i.e. the MEAN of the replicas is clipped as one
+   gradient (the same holds for grl_compute_grads -> all-reduce -> grl_apply_grads(1 / world)).  Mode 2 and the overlapped
+   form are GRL_ERR_STATE on them; prioritised handles keep per-rank trees and train with grl_train_step_per only. */
 #define GRL_ALLREDUCE_HANDLE_BYTES 128
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out);
 int grl_allreduce_connect(grl_handle h, const void* handles);

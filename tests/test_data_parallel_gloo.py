@@ -257,3 +257,118 @@ def test_exchange_setup_failure_on_one_rank_falls_back_on_all(hostemu_lib, tmp_p
     r1 = np.load(os.path.join(str(tmp_path), "fb1.npz"))
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DQN / BDQ handles under data parallelism (north_star: "SAC / BDQ / DQN update ... optionally sharded").  The TD loss is a batch
+# mean, so the mean of the shard gradients is the global gradient; clip_by_norm acts on that mean -- the all-reduced SUM is
+# clipped at W * clip and Adam's 1 / W brings it back (csrc/plan_q.inl) -- with a threshold the gradients really exceed here.
+Q_B, Q_STEPS, Q_CLIP = 8, 3, 0.05
+
+
+def _q_case(batch, clip=Q_CLIP):
+    import q_parity_util as qu
+    case = qu.make_q_case(**dict(qu.CASES["bdq_5_branches"], B=Q_B), n_steps=Q_STEPS, lr=1e-2)
+    cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+    cfg.batch_size, cfg.q_grad_clip = batch, clip
+    case["cfg"] = cfg
+    return case
+
+
+def _q_worker(rank, world, port, lib, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import q_parity_util as qu
+    case = _q_case(Q_B // world)
+    eng = qu.q_engine_setup(case, backend=NumpyHostBackend(), lib_path=lib)
+    dp = DataParallelSac(eng)
+    assert not dp.staged
+    dp.broadcast_parameters(src=0)
+    lo, hi = rank * (Q_B // world), (rank + 1) * (Q_B // world)
+    dp.train(Q_STEPS, case["idx"][:, lo:hi], case["weights"][:, lo:hi])
+    P = eng.get_parameters()
+    np.savez(os.path.join(out_dir, "q%d.npz" % rank), **{k.replace("/", "|"): v for k, v in P.items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_bdq_update_with_clipping_equals_single_engine(hostemu_lib, tmp_path):
+    import q_parity_util as qu
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_q_worker, args=(2, port, hostemu_lib, str(tmp_path)), nprocs=2, join=True)
+    case = _q_case(Q_B)
+    single = qu.q_engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    single.compute_grads(case["idx"][:1], case["weights"][:1])
+    G = single.get_gradients()
+    assert max(float(np.sqrt((g.astype(np.float64) ** 2).sum())) for g in G.values()) > 2 * Q_CLIP     # the clip is active
+    single.apply_grads(1.0)
+    single.train(Q_STEPS - 1, case["idx"][1:], case["weights"][1:])
+    ref = single.get_parameters()
+    # ... and it matters: without it the parameters move visibly further
+    unclipped = qu.q_engine_setup(_q_case(Q_B, clip=0.0), backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    unclipped.train(Q_STEPS, case["idx"], case["weights"])
+    Pu = unclipped.get_parameters()
+    r0 = np.load(os.path.join(str(tmp_path), "q0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "q1.npz"))
+    lr = 1e-2
+    moved = 0
+    for k, v in ref.items():
+        a, b = r0[k.replace("/", "|")], r1[k.replace("/", "|")]
+        assert np.array_equal(a, b), "replicas diverged: " + k
+        d = np.abs(a.astype(np.float64) - v)
+        assert d.max() <= 0.3 * lr * Q_STEPS + 1e-7 and d.mean() <= 0.02 * lr * Q_STEPS + 1e-9, (k, d.max(), d.mean())
+        moved = max(moved, float(np.abs(Pu[k].astype(np.float64) - v).max()))
+    assert moved > 0
+
+
+def _q_learn_worker(rank, world, port, lib, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from fake_env import FakeGraspEnv
+    from grasp_rl.engine import QEngine
+    from grasp_rl.sb.callbacks import BaseCallback
+    from grasp_rl.sb.dqn import BDQ
+    from grasp_rl.sb.vec_env import DummyVecEnv
+    BDQ._engine_factory = staticmethod(lambda cfg, device: QEngine(cfg, backend=NumpyHostBackend(), lib_path=lib))
+
+    class StopAt(BaseCallback):
+        calls = 0
+
+        def _on_step(self):
+            StopAt.calls += 1
+            return self.num_timesteps < 60
+
+    from grasp_rl.sb.policies import BdqMlpActPolicy as MlpActPolicy
+    env = DummyVecEnv([lambda: FakeGraspEnv(vector_dim=12, act_dim=3, seed=5 + rank)])
+    model = BDQ(MlpActPolicy, env, batch_size=8, buffer_size=64, learning_starts=16, target_network_update_freq=20, seed=3, num_actions_pad=5,
+                policy_kwargs={"layers": [[16, 16], [8], [8]]}, data_parallel=True, dp_exchange="collective")
+    assert model.engine.cfg.batch_size == 4
+    model.learn(10_000, callback=StopAt())
+    P = model.get_parameters()
+    np.savez(os.path.join(out_dir, "ql%d.npz" % rank), steps=model.num_timesteps, updates=model.n_updates, calls=StopAt.calls,
+             replay=model.engine.replay_size(), **{k.replace("/", "|"): v for k, v in P.items()})
+    dist.destroy_process_group()
+
+
+def test_bdq_learn_as_one_replica_of_two(hostemu_lib, tmp_path):
+    """BDQ(data_parallel=True).learn with two replicas over gloo: every rank steps its own environment, counters count the
+    job's environment steps (2 per iteration), one update on the global minibatch per step of the job, hard target copies in
+    step, rank 0's callback stops both loops in the same iteration; the replicas end bit-identical, targets included."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_q_learn_worker, args=(2, port, hostemu_lib, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "ql0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "ql1.npz"))
+    assert int(r0["calls"]) > 0 and int(r1["calls"]) == 0
+    assert int(r0["steps"]) == int(r1["steps"]) == 60
+    assert int(r0["replay"]) == int(r1["replay"]) == 29                 # (the stopping step is not stored)
+    # steps 18, 20, ..., 58 of the job (> learning_starts, before the stop): two updates each
+    assert int(r0["updates"]) == int(r1["updates"]) == 2 * 21
+    for k in r0.files:
+        if k != "calls":
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    moved = [k for k in r0.files if "target_q_func" in k and "weights" in k]
+    assert moved

@@ -229,6 +229,76 @@ def _ingraph_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# DQN / BDQ handles in the exchange (north_star: "SAC / BDQ / DQN update ... optionally sharded"): two-shot + gather, the
+# plan's own clip_by_norm + Adam behind it with grad_scale 1 / W (the sum clipped at W * clip: csrc/plan_q.inl)
+def _q_ingraph_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GRL_TUNE"] = "dp_timeout_ms=20000"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import q_parity_util as qu
+    from grasp_rl.engine import GrlError
+    from grasp_rl.parallel import DataParallelInGraph
+    Bq = 16 * world
+    for name, clip in (("bdq_baseline_config3_uniform", 0.005), ("dqn_reference_shape", 10.0)):
+        case = qu.make_q_case(**dict(qu.CASES[name], B=Bq), n_replay=3 * Bq, n_steps=STEPS)
+        cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+        cfg.batch_size, cfg.q_grad_clip = Bq // world, clip
+        case["cfg"] = cfg
+        lo, hi = rank * (Bq // world), (rank + 1) * (Bq // world)
+        # reference: every rank's bucket added in rank order on the host, applied with grad_scale 1 / W
+        ref = qu.q_engine_setup(case)
+        for s in range(STEPS):
+            ref.compute_grads(case["idx"][s:s + 1, lo:hi], case["weights"][s:s + 1, lo:hi])
+            g = torch.from_numpy(ref.fetch("grads", (ref.n_trainable,)))
+            parts = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(parts, g)
+            total = parts[0].numpy().copy()
+            for p in parts[1:]:
+                total += p.numpy()
+            if s == 0 and clip < 1.0:         # the clip is active on the MEAN gradient of at least one variable
+                n_vars = len(ref.param_names(trainable_only=True))    # (sum of squared variable norms > n c^2: one exceeds c)
+                assert float(np.sqrt((total.astype(np.float64) ** 2).sum())) / world > clip * np.sqrt(n_vars)
+            ref.store("grads", total)
+            ref.apply_grads(1.0 / world)
+        ref.synchronize()
+        Pref = ref.get_parameters()
+        ref.close()
+        eng = qu.q_engine_setup(case)
+        dp = DataParallelInGraph(eng, mode="auto")
+        dp.train(STEPS, case["idx"][:, lo:hi], case["weights"][:, lo:hi])
+        assert dp.check() == STEPS
+        P = eng.get_parameters()
+        for k in P:
+            assert np.array_equal(P[k], Pref[k]), "%s: differs from the rank-ordered sum: %s" % (name, k)
+        with pytest.raises(GrlError):
+            eng.allreduce_set_mode("oneshot")          # (the clipped apply reads the gathered sums: two-shot only)
+        dp.train(4)                                     # device RNG: same seed and replay contents on every rank
+        dp.train(1)
+        assert dp.check() == STEPS + 5
+        np.savez(os.path.join(out_dir, "qig_%s_%d.npz" % (name, rank)), **{k.replace("/", "|"): v for k, v in eng.get_parameters().items()})
+        dp.close()
+        eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_in_graph_exchange_on_dqn_and_bdq_handles(tmp_path, world):
+    """configs[2]'s BDQ (uniform replay, as gripper_grasp.yaml:106 selects) and the reference-shape DQN with W processes on the
+    one MI355X: gradient sums exchanged inside the update graph, clipped per variable as the mean of the replicas, bit-identical
+    to the rank-ordered host sum + grl_apply_grads(1 / W); replicas identical also after device-RNG updates."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_q_ingraph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for name in ("bdq_baseline_config3_uniform", "dqn_reference_shape"):
+        parts = [np.load(os.path.join(str(tmp_path), "qig_%s_%d.npz" % (name, r))) for r in range(world)]
+        for p in parts[1:]:
+            for k in parts[0].files:
+                assert np.array_equal(parts[0][k], p[k]), "replicas diverged (%s): %s" % (name, k)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
     """W processes on the box's one MI355X map each other's exchange buffers (hipIpc) and run the data-parallel update with
