@@ -135,13 +135,16 @@ template <int W> struct HmLds {
 // SAC_real_2m_buffer_128/config.yaml `layers: [128, 128]`) and a batch that is a multiple of 16.  The kernel is bound
 // by instruction issue, and with the widths, the layer count and the row predicate known at compile time most of its
 // address / predicate arithmetic folds away.
-template <int W, bool FAST>
-__global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* __restrict__ ap) {
+// TG: the chain types this copy of the body serves -- -1: all four, told apart at run time (the 64-wide kernels: one body);
+// 0 / 1: that type; 2: types 2 and 3.  The 128-wide kernel is three copies behind a branch on blockIdx.y: as ONE body it
+// needed more than the 512 registers a lane has (20 spilled), although no single chain needs more than ~340 -- the operand
+// sets of all chains were live across the type branches.
+template <int W, bool FAST, int TG>
+__device__ __forceinline__ void heads_fused_body(const HeadsFusedArgs* __restrict__ ap, HmLds<W>& s) {
   static_assert(W == 64 || W == 128, "layer widths above 128 run on heads_kernels.h");
   typedef HmDim<W, FAST> D;
   constexpr int NB = D::NB, K4 = D::K4, LD = D::LD, KA = HM_KA, ALD = HM_ALD, NK = D::NK;
   constexpr bool KSPLIT = D::KSPLIT;
-  __shared__ __attribute__((aligned(16))) HmLds<W> s;
   const int t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4;
   // columns owned by this lane in a stage output (result layout: rows 4q .. 4q+3).  The NB column blocks of a wave are
   // INTERLEAVED (block b = columns NB c + b of the wave's 16 NB): the lane's columns are neighbours in memory, so a
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     if (a.rng_advance) a.sc->rng_step += 1;
     if (a.tick) adam_tick_device(a.sc);
   }
-  const int row0 = blockIdx.x * HT_RB, type = blockIdx.y, B = a.B, A = a.A;
+  const int row0 = blockIdx.x * HT_RB, type = TG < 0 ? (int)blockIdx.y : TG < 2 ? TG : (int)(blockIdx.y | 2u), B = a.B, A = a.A;
   const float invB = 1.f / (float)B;
   auto LY = [](int v) { return FAST ? 2 : v; };          // hidden layers of a head
   auto WD = [](int v) { return FAST ? (int)W : v; };      // a hidden width
@@ -661,8 +664,8 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     fwd_head(a.h[5], fB, uB, zsB); stamp();     // qf1(s, pi): s.o[r][0]
     if (t < HT_RB) { s.sv[0][t] = s.o[t][0]; s.sv[5][t] = ROW(t) ? -invB : 0.f; }
     HM_SYNC();
-    float gq[GRL_MAX_LAYERS][NB][4] = {};       // gradients of qf1's own weights are not wanted here (policy loss)
-    bwd_head(a.h[5], gA, zsB, gq, true, true); stamp();
+    // (gradients of qf1's own weights are not wanted here -- policy loss: they land in `gs`, which the pi backward overwrites)
+    bwd_head(a.h[5], gA, zsB, gs, true, true); stamp();
     prefetch_bwd(a.h[0], gA, false, false);
     // sample backward; s.o becomes the A operand [dmu | dls] of the pi backward (zero beyond 2A)
     {
@@ -745,6 +748,18 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* 
     store_rows(a.d_out[type], a.ld_d, s.sv[5]);
   }
   stamp();
+}
+
+template <int W, bool FAST>
+__global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* __restrict__ ap) {
+  __shared__ __attribute__((aligned(16))) HmLds<W> s;
+  if constexpr (W == 128) {      // (the same split of the 64-wide fast kernel measured neutral: 5 780 / 5 758 against 5 776 / 5 759)
+    if (blockIdx.y == 0) heads_fused_body<W, FAST, 0>(ap, s);
+    else if (blockIdx.y == 1) heads_fused_body<W, FAST, 1>(ap, s);
+    else heads_fused_body<W, FAST, 2>(ap, s);
+  } else {
+    heads_fused_body<W, FAST, -1>(ap, s);
+  }
 }
 
 #endif  // GRL_HOSTEMU
