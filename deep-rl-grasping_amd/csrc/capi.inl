@@ -672,7 +672,19 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
       return e;
   }
   if (q) HIPCHK(hipMemcpyAsync(h->pin_out, h->q_aout, n_out * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  bool seen = false;
+  if (!q && h->act_done_wgs && !h->prof) {
+    // the last launch counts its workgroups into coherent host memory once their actions are out (act_mfma.h): poll that
+    // instead of the stream's completion signal; bounded -- after 2 ms (or on any doubt) the stream is synchronised as before
+    h->act_done_seen += h->act_done_wgs;
+    const unsigned want = h->act_done_seen;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+      if (__atomic_load_n(h->act_done_host, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  if (!seen) HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   memcpy(out, q ? h->pin_out : h->a_out, n_out * 4);
   return GRL_OK;

@@ -1333,6 +1333,9 @@ struct ActHeadsArgs {
   // act_mfma.h only: columns [0, n_sum) of the input are ReLU(sum of n_parts partial sums [rows, ld_parts] + x_bias) -- the
   // extractor's dense layer run as a split-K GEMM; n_parts == 0: every column comes from x
   const float* x_parts; const float* x_bias; int n_parts, n_sum, ld_parts; long part_stride;
+  // act_mfma.h only: completion counter in page-locked host memory (one increment per workgroup), or nullptr -- grl_act polls it
+  // instead of synchronising the stream
+  unsigned* done;
 };
 enum { ACT_HEADS_MAX_IN = 2048, ACT_HEADS_MAX_HID = 256 };
 

@@ -845,6 +845,9 @@ int grl_ctx::plan_sac() {
     if (!dry) {    // (grl_query_sizes plans without a device)
       if (hipHostMalloc((void**)&act_io_host, (size_t)2 * NA * A * 4, 0) != hipSuccess) return fail(GRL_ERR_HIP, "hipHostMalloc failed");
       memset(act_io_host, 0, (size_t)2 * NA * A * 4);
+      // (GRL_TUNE act_poll=0 keeps the stream synchronisation at the end of grl_act)
+      if (tune_int("act_poll", 1) != 0 && hipHostMalloc((void**)&act_done_host, 64, hipHostMallocCoherent) == hipSuccess) *act_done_host = 0u;
+      else act_done_host = nullptr;
     }
     a_eps = act_io_host;
     a_out = act_io_host + (size_t)NA * A;
@@ -927,6 +930,8 @@ int grl_ctx::plan_sac() {
             ha.x_parts = fc_parts; ha.n_parts = fc_split; ha.part_stride = (long)NA * 512; ha.ld_parts = 512;
             ha.x_bias = P + ex[0].fb; ha.n_sum = 512;
           }
+          ha.done = act_done_host;
+          act_done_wgs = act_done_host ? (unsigned)((NA + HT_RB - 1) / HT_RB) : 0u;
           op.run = [ha](hipStream_t s) { launch_act_heads_mfma(ha, s); };
         } else {
           op.run = [ha](hipStream_t s) { hipLaunchKernelGGL(act_heads_kernel, dim3(ha.rows), dim3(256), 0, s, ha); };

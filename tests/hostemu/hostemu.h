@@ -52,6 +52,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+enum { hipHostMallocCoherent = 0x40000000 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n); return *p ? 0 : 1; }
 static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
