@@ -156,9 +156,23 @@ __global__ __launch_bounds__(256) void ae_kernel_prep(const float* __restrict__ 
 // loss value + Keras-Adam step size lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); advances the beta powers
 __global__ void ae_finish_kernel(const float* partial, const float* partial_g, int n_partial, long n_total, float lr,
                                  DevScalars* sc, float* g_out_bias) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // (the partial sums arrive in ONE batch of loads and are added from LDS in the same order k = 0, 1, ... as before: one thread
+  //  walking global memory was 12 us of dependent round trips)
+  if (blockIdx.x != 0) return;
   float s = 0.f, sg = 0.f;
+#ifndef GRL_HOSTEMU
+  __shared__ float sp[2][256];
+  for (int k = threadIdx.x; k < n_partial && k < 256; k += blockDim.x) { sp[0][k] = partial[k]; sp[1][k] = partial_g[k]; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < n_partial; ++k) {
+    s += k < 256 ? sp[0][k] : partial[k];
+    sg += k < 256 ? sp[1][k] : partial_g[k];
+  }
+#else      // (the emulation runs the threads of a workgroup one after the other: no staging through shared memory)
+  if (threadIdx.x != 0) return;
   for (int k = 0; k < n_partial; ++k) { s += partial[k]; sg += partial_g[k]; }
+#endif
   if (g_out_bias) g_out_bias[0] = sg;             // d loss / d bias of the output convolution
   sc->policy_loss = s / (float)n_total;          // reported as the reconstruction loss
   sc->adam_alpha = lr * sqrtf(1.f - sc->beta2_power) / (1.f - sc->beta1_power);
