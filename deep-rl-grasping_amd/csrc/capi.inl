@@ -570,10 +570,27 @@ int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u) 
   if (!h || n_steps < 1) return fail(GRL_ERR_INVALID, "bad argument");
   if (!h->per_on) return fail(GRL_ERR_STATE, "prioritised replay is not enabled (grl_config.q_per)");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
-  h->grad_scale = 1.f;
   if (!(beta > 0.0)) return fail(GRL_ERR_INVALID, "beta must be positive (PrioritizedReplayBuffer.sample asserts beta > 0)");
   if (h->rp_size < 2) return fail(GRL_ERR_STATE, "prioritised sampling needs at least two stored transitions (sum(0, len - 1))");
   HIPCHK(hipMemcpyAsync(&h->per.st->beta, &beta, 8, hipMemcpyHostToDevice, h->stream));
+  h->grad_scale = 1.f;
+  if (h->dp_on) {
+    // connected handle (grl_allreduce_connect): every rank draws from ITS priority tree (importance weights against its own
+    // total and minimum), the gradient sums are exchanged inside the graph, the plan's clip + Adam apply the mean, every rank
+    // writes the priorities of its own rows back.  All ranks must call alike, as with grl_train_step_allreduce.
+    if (*h->dp_err_host) return fail(GRL_ERR_STATE, "an exchange timed out waiting for a peer (the replicas are no longer in step)");
+    h->grad_scale = 1.f / (float)h->dp.world;
+    if (!u) {
+      if (int e = h->run_repeated("dp_per_rng", {&h->ops_per_rng_g, &h->dp_body_per, &h->ops_dp, &h->ops_per_update}, n_steps)) return e;
+    } else {
+      for (int s = 0; s < n_steps; ++s) {
+        HIPCHK(hipMemcpyAsync(h->per_u, u + (int64_t)s * h->B, (size_t)h->B * 8, hipMemcpyDeviceToDevice, h->stream));
+        if (int e = h->run_seq("dp_per_u", {&h->ops_per_u_g, &h->dp_body_per, &h->ops_dp, &h->ops_per_update})) return e;
+      }
+    }
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
   if (!u) {        // device Philox: identical updates, several to a graph
     if (n_steps >= 2 && !h->ops_grads_apply_per_r.empty() && !h->prof) {
       // nothing but the updates themselves touches the leaves inside one call: the first update sums every block of the
@@ -880,6 +897,9 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
     tail.push_back(dp_gather_op(d));
     for (size_t k = n_body; k < h->ops_grads.size(); ++k) tail.push_back(h->ops_grads[k]);      // q_finish
     for (auto& o : h->ops_apply) tail.push_back(o);
+    h->dp_body_per.clear();
+    for (auto& o : h->dp_body)
+      if (o.tag != "gather_norm") h->dp_body_per.push_back(o);
     h->ops_dp1.clear();
     for (auto* v : {&h->ops_pfdp_first, &h->ops_pfdp_mid, &h->ops_pfdp_last, &h->ops_pfdp1_first, &h->ops_pfdp1_mid, &h->ops_pfdp1_last}) v->clear();
   }
@@ -966,7 +986,7 @@ int grl_allreduce_disconnect(grl_handle h) {
   h->dp_overlap = false;
   h->dp_mode = 0;
   for (auto* v : {&h->ops_dp, &h->ops_dp1, &h->ops_pfdp_first, &h->ops_pfdp_mid, &h->ops_pfdp_last, &h->ops_pfdp1_first,
-                  &h->ops_pfdp1_mid, &h->ops_pfdp1_last, &h->dp_body, &h->ops_dp_overlap})
+                  &h->ops_pfdp1_mid, &h->ops_pfdp1_last, &h->dp_body, &h->dp_body_per, &h->ops_dp_overlap})
     v->clear();
   for (int p = 0; p < 2 * DP_MAX_WORLD; ++p)
     if (h->dp_peer[p]) { (void)hipIpcCloseMemHandle(h->dp_peer[p]); h->dp_peer[p] = nullptr; }

@@ -311,6 +311,7 @@ struct grl_ctx {
   LossArgs pf_lk;                        // loss arguments / gather of the NEXT update as the prefetching reductions carry them (plan_sac)
   GatherArgs pf_g2;
   std::vector<Op> dp_body;               // ops_grads without its final reduction (the exchange's first kernel forms the sums)
+  std::vector<Op> dp_body_per;           // DQN / BDQ with prioritised replay: the same without the gather (the sampler gathers its rows)
   int dp_mode = 0;                       // 0 auto (one-shot for world <= 2), 1 two-shot, 2 one-shot
   hipEvent_t copy_ev = nullptr;          // copy_from_caller: completion of a copy whose source is page-locked caller memory
   uint32_t* dp_err_host = nullptr;       // page-locked mailbox: a kernel that gave up waiting for a peer sets it

@@ -210,6 +210,10 @@ class DataParallelInGraph:
     def train(self, n_steps=1, idx=None, eps=None):
         self.eng.train_allreduce(n_steps, idx, eps)    # (raises once a previous exchange has timed out, on every rank)
 
+    def train_per(self, n_steps=1, beta=1.0, u=None):
+        """DQN / BDQ with prioritised replay: every rank draws from its own priority tree, the exchange is the same."""
+        self.eng.train_per(n_steps, beta, u)
+
     def check(self):
         """Synchronises; raises if an exchange timed out.  Returns the number of exchanges begun."""
         return self.eng.allreduce_status()

@@ -19,8 +19,8 @@ the ranks, the gradient SUM is exchanged inside the update's graph (``grasp_rl.p
 collective library as fallback), clipped per variable as the mean of the replicas and applied identically everywhere.
 Counters (``num_timesteps``, exploration and beta schedules, ``learning_starts``, ``train_freq``,
 ``target_network_update_freq``) count environment steps of the JOB: W per loop iteration.  Callbacks, logging and
-the stop decision are rank 0's.  Uniform replay only: prioritised replay keeps per-rank trees and is not combined with
-the exchange (raises).
+the stop decision are rank 0's.  Prioritised replay keeps one priority tree per rank (importance weights against the
+rank's own total and minimum) and needs the in-graph exchange.
 """
 import time
 
@@ -138,9 +138,6 @@ class _QModel:
             kw = dict(clip_obs=vn.clip_obs, clip_reward=vn.clip_reward, norm_eps=vn.epsilon)
         lr = float(self.learning_rate(1.0)) if callable(self.learning_rate) else float(self.learning_rate)
         rt = self._dp_runtime()
-        if rt is not None and self.prioritized_replay:
-            raise NotImplementedError("prioritized_replay under data parallelism: the per-rank priority trees are not combined "
-                                      "with the gradient exchange (use uniform replay, as gripper_grasp.yaml:106 selects)")
         self._local_batch = self.batch_size if rt is None else rt.shard(self.batch_size, "minibatch rows")
         engine_seed = 0 if self.seed is None else int(self.seed)
         if rt is not None:
@@ -156,6 +153,9 @@ class _QModel:
         self._init_weights()
         if rt is not None:
             self._dp = rt.make_exchange(self.engine, prefer=self.dp_exchange)
+            if self.prioritized_replay and not hasattr(self._dp, "train_per"):
+                raise NotImplementedError("prioritized_replay under data parallelism needs the in-graph exchange (every rank draws "
+                                          "from its own priority tree inside the update's graph); this job fell back to a collective library")
             self._dp.broadcast_parameters(src=0)
         # prioritised replay lives on the device (csrc/per_kernels.h): sampling, importance weights and the
         # priority write-back never leave HBM
@@ -291,7 +291,7 @@ class _QModel:
                 if callable(self.learning_rate):    # stable-baselines evaluates the schedule per update: lr(1 - step / total)
                     eng.set_learning_rate(self.learning_rate(1.0 - (self.num_timesteps - 1) / max(1, total_timesteps)))
                 if self.prioritized_replay:
-                    eng.train_per(n_upd, beta_schedule.value(self.num_timesteps))
+                    (eng if dp is None else dp).train_per(n_upd, beta_schedule.value(self.num_timesteps))
                 elif dp is not None:
                     dp.train(n_upd)                # the global minibatch: gradients exchanged inside each update's graph
                 else:

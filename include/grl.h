@@ -251,7 +251,10 @@ int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const 
    Adam there, so their exchange is two-shot + a pull of every sum into the gradient bucket, followed by the plan's own clip +
    Adam with grad_scale 1 / world -- the SUM is clipped at world x clip, i.e. the MEAN of the replicas is clipped as one
    gradient (the same holds for grl_compute_grads -> all-reduce -> grl_apply_grads(1 / world)).  Mode 2 and the overlapped
-   form are GRL_ERR_STATE on them; prioritised handles keep per-rank trees and train with grl_train_step_per only. */
+   form are GRL_ERR_STATE on them.  Prioritised handles keep per-rank priority trees: on a connected handle
+   grl_train_step_per draws from this rank's tree (importance weights against its own total and minimum), exchanges the
+   gradient sums the same way and writes the priorities of its own rows back; grl_train_step_allreduce (uniform draws) is
+   GRL_ERR_STATE on them.  All ranks call alike. */
 #define GRL_ALLREDUCE_HANDLE_BYTES 128
 int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out);
 int grl_allreduce_connect(grl_handle h, const void* handles);

@@ -280,6 +280,50 @@ def _q_ingraph_worker(rank, world, port, out_dir):
         np.savez(os.path.join(out_dir, "qig_%s_%d.npz" % (name, rank)), **{k.replace("/", "|"): v for k, v in eng.get_parameters().items()})
         dp.close()
         eng.close()
+    # ---- prioritised replay on a connected handle: every rank draws from ITS priority tree (different uniforms per rank),
+    # the exchange is the same; reference = the drawn rows and weights replayed on a plain handle, rank-ordered sum, apply
+    from oracle.per import PerOracle
+    case = qu.make_q_case(**dict(qu.CASES["bdq_baseline_config3"], B=Bq), n_replay=3 * Bq, n_steps=STEPS)
+    cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
+    cfg.batch_size, cfg.q_grad_clip = Bq // world, 0.005
+    plain = _capi.GrlConfig.from_buffer_copy(cfg)
+    cfg.q_per, cfg.q_per_alpha, cfg.q_per_eps, cfg.q_per_alpha64 = 1, 0.6, 1e-6, 0.6
+    eng = qu.q_engine_setup(dict(case, cfg=cfg))
+    ref = qu.q_engine_setup(dict(case, cfg=plain))
+    dp = DataParallelInGraph(eng, mode="auto")
+    orc = PerOracle(int(cfg.replay_capacity), 0.6, 1e-6)
+    orc.add(3 * Bq)
+    rng = np.random.default_rng(50 + rank)
+    for s in range(STEPS):
+        u = rng.random(Bq // world)
+        dp.train_per(1, 0.5, u[None])
+        idx, w = eng.sampled_indices(), eng.importance_weights()
+        ref_idx, ref_w = orc.sample(u, 0.5)               # this rank's tree, walked by the restated segment trees
+        assert np.array_equal(idx, ref_idx)
+        assert np.allclose(w, ref_w.astype(np.float32), rtol=1e-6, atol=0)
+        orc.update(idx, eng.priorities())
+        assert np.array_equal(eng.stored_priorities(), orc.leaves), "leaves after update %d" % s
+        ref.compute_grads(idx[None], w[None])
+        g = torch.from_numpy(ref.fetch("grads", (ref.n_trainable,)))
+        parts = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        total = parts[0].numpy().copy()
+        for p in parts[1:]:
+            total += p.numpy()
+        ref.store("grads", total)
+        ref.apply_grads(1.0 / world)
+        ref.synchronize()
+        P, Pr = eng.get_parameters(), ref.get_parameters()
+        for k in P:
+            assert np.array_equal(P[k], Pr[k]), "prioritised: differs from the rank-ordered sum at update %d: %s" % (s, k)
+    with pytest.raises(GrlError):
+        eng.train_allreduce(1)                             # (uniform draws are refused on a prioritised handle)
+    dp.train_per(3, 0.7)                                   # device RNG: per-rank draws, same exchange
+    assert dp.check() == STEPS + 3
+    np.savez(os.path.join(out_dir, "qig_per_%d.npz" % rank), **{k.replace("/", "|"): v for k, v in eng.get_parameters().items()})
+    dp.close()
+    eng.close()
+    ref.close()
     dist.destroy_process_group()
 
 
@@ -287,12 +331,14 @@ def _q_ingraph_worker(rank, world, port, out_dir):
 def test_in_graph_exchange_on_dqn_and_bdq_handles(tmp_path, world):
     """configs[2]'s BDQ (uniform replay, as gripper_grasp.yaml:106 selects) and the reference-shape DQN with W processes on the
     one MI355X: gradient sums exchanged inside the update graph, clipped per variable as the mean of the replicas, bit-identical
-    to the rank-ordered host sum + grl_apply_grads(1 / W); replicas identical also after device-RNG updates."""
+    to the rank-ordered host sum + grl_apply_grads(1 / W); replicas identical also after device-RNG updates.  Then configs[2]
+    WITH prioritised replay: every rank draws from its own tree (indices and float64 leaves equal to the restated segment
+    trees), same exchange, same bits as the rank-ordered sum of the drawn rows' gradients."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_q_ingraph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    for name in ("bdq_baseline_config3_uniform", "dqn_reference_shape"):
+    for name in ("bdq_baseline_config3_uniform", "dqn_reference_shape", "per"):
         parts = [np.load(os.path.join(str(tmp_path), "qig_%s_%d.npz" % (name, r))) for r in range(world)]
         for p in parts[1:]:
             for k in parts[0].files:
