@@ -352,8 +352,11 @@ int grl_ctx::plan_q() {
     for (auto& h : hb) qf.mfma = qf.mfma && qm_head_ok(h);
     if (want_mfma && !qf.mfma) return fail(GRL_ERR_INVALID, "internal: the Q chains were planned for the matrix-core stages and do not fit them");
     q_chain = qf.mfma && q_chain_built() && tune_int("q_chain", 1) != 0 && tune_int("fused_qapply", 1) != 0 && qc_shape_ok(nb, D, c.obs_dim);
-    if (q_chain) {      // nothing reads the pre-activation gradients from memory any more: the chains keep them in LDS
-      for (auto& h : hb) { h.g0 = nullptr; for (int l = 0; l < GRL_MAX_LAYERS; ++l) h.g[l] = nullptr; }
+    if (q_chain) {      // nothing reads the trunk's pre-activation gradients from memory any more: its chain keeps them in LDS;
+      // the towers' are read back by the weight-gradient workgroups of the trunk launch when there is one (GRL_TUNE q_chain_late=0:
+      // every tower chain forms its slabs itself, at its end)
+      const bool late = Lc > 0 && tune_int("q_chain_late", 1) != 0;
+      if (!late) for (auto& h : hb) { h.g0 = nullptr; for (int l = 0; l < GRL_MAX_LAYERS; ++l) h.g[l] = nullptr; }
       for (auto& h : htr) { h.g0 = nullptr; for (int l = 0; l < GRL_MAX_LAYERS; ++l) h.g[l] = nullptr; }
     }
     qf.fwd = upload_vec(wk, hf);
@@ -444,6 +447,7 @@ int grl_ctx::plan_q() {
       QChainArgs ca;
       memset(&ca, 0, sizeof(ca));
       ca.f = qf; ca.l = q_loss_args; ca.l.defer_finish = 1;
+      ca.late = (Lc > 0 && tune_int("q_chain_late", 1) != 0) ? 1 : 0;
       ca.tw = upload_vec(wk, ytw);
       if (Lc > 0) {
         QcHead y;

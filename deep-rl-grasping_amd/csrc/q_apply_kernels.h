@@ -39,6 +39,16 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
   }
   const ReduceDesc d = descs[blockIdx.x];
   constexpr int U = 8;                  // elements per thread in flight: the loops below are chains of load batches
+  // the Adam state of the first batch of elements (all of them for every variable of the reference networks) is requested
+  // together with the slabs: one memory round trip per workgroup instead of two
+  const int64_t e0 = d.dst - aa.grads;
+  float p0[U], m0[U], v0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = u * NT + t;
+    const int64_t e = e0 + (i < d.n ? i : 0);
+    p0[u] = aa.params[e]; m0[u] = aa.m[e]; v0[u] = aa.v[e];
+  }
   float ss = 0.f;
   for (int base = 0; base < d.n; base += NT * U) {
     float acc[U];
@@ -84,14 +94,14 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
     sc = clip / fmaxf(sqrtf(red[0]), clip);
   }
   const float alpha = aa.sc->adam_alpha;
-  const int64_t e0 = d.dst - aa.grads;
   for (int base = 0; base < d.n; base += NT * U) {
     float p[U], m[U], v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = base + u * NT + t;
       const int64_t e = e0 + (i < d.n ? i : 0);
-      p[u] = aa.params[e]; m[u] = aa.m[e]; v[u] = aa.v[e];
+      if (base == 0) { p[u] = p0[u]; m[u] = m0[u]; v[u] = v0[u]; }
+      else { p[u] = aa.params[e]; m[u] = aa.m[e]; v[u] = aa.v[e]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

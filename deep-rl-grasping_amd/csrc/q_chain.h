@@ -14,6 +14,8 @@
 //     partial product of ITS rows and stores it as one slab per row block; the launch that applies the update sums the
 //     B / 16 slabs in row-block order (ReduceDesc.splits = B / 16), exactly as it sums split-K slabs of the GEMM launches.
 // Five launches per update instead of seven: sampler / gather, forward, tower chains, trunk chain, reduce + clip + Adam.
+// With a trunk (BDQ) the towers' weight gradients leave the critical path as well: the tower chains store their gradient
+// rows as before and (D + 1) extra workgroups per row block of the TRUNK launch form the slabs while the trunk chain runs.
 //
 // Summation order of a weight gradient: rows 4 s + q of a row block in MFMA order (quarter q, step s), row blocks in order --
 // the GEMM launch it replaces sums the batch in its own tile order; both are checked against the oracle with the same
@@ -37,6 +39,8 @@ struct QChainArgs {
   QLossArgs l;
   const QcHead* tw;       // [D+1]
   const QcHead* tr;       // trunk, or nullptr
+  int late;               // 1 (networks with a trunk): the towers' weight gradients are formed by workgroups of their own in the
+                          // TRUNK launch, in the shadow of the trunk chain, from the gradient rows the tower chains stored
 };
 enum { QC_XW = 2 * QM_W, QC_XLD = QC_XW + 4 };
 
@@ -294,15 +298,16 @@ __global__ __launch_bounds__(256) void q_bwd_towers_chain_kernel(QChainArgs ca) 
                      : (k >= 8 && k - 8 < D) ? la.act + (long)b * D + (k - 8) : nullptr;
     if (b < a.B && p) rsv = *QM_G(p);
   }
-  float xv[8];
-  qc_xin_load(ca.tw[tw], row0, a.B, xv);
-  qc_head_to_lds(s, ca.tw + tw);
+  float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (!ca.late) {         // (the rows the weight gradients need: formed elsewhere in the late form)
+    qc_xin_load(ca.tw[tw], row0, a.B, xv);
+    qc_head_to_lds(s, ca.tw + tw);
+  }
   qm_bwd_head(
       h, row0, a.B, s.m, h.n_xa ? a.dh_part + (long)tw * a.B * a.Ht : nullptr, a.Ht, nullptr, 0, 0, 1.f,
       [&](const auto& zm) {
         qm_zero(s.m);
-        qc_park_z(s, zm, h.L);
-        qc_xin_store(s, xv);
+        if (!ca.late) { qc_park_z(s, zm, h.L); qc_xin_store(s, xv); }
 #pragma unroll
         for (int k3 = 0; k3 < 3; ++k3)
 #pragma unroll
@@ -327,19 +332,25 @@ __global__ __launch_bounds__(256) void q_bwd_towers_chain_kernel(QChainArgs ca) 
                   QM_GW(la.row_part)[3 * b + 1] = qsel;
                   QM_GW(la.row_part)[3 * b + 2] = prio * invD;
                   s.m.o[r][0] = dv;
+                  if (ca.late) QM_GW(la.d_v0)[(long)b * la.ld_dv] = dv;
                 }
               });
-        // the tower's own output gradients (nothing else reads them: the weight gradients are formed right here)
+        // the tower's own output gradients (to memory as well when the weight gradients are formed in the trunk launch)
         if (tw < D && live) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int k = 16 * j + i;
-            if (k < nbins) s.m.o[r][k] = g_own * ((k == ai_own ? 1.f : 0.f) - invn);
+            const float ga = g_own * ((k == ai_own ? 1.f : 0.f) - invn);
+            if (k < nbins) {
+              s.m.o[r][k] = ga;
+              if (ca.late) QM_GW(la.d_adv0)[((long)b * D + tw) * la.nbp + k] = ga;
+            }
           }
         }
         __syncthreads();
       },
-      [&](int li) { qc_park_g(s, li); });
+      [&](int li) { if (!ca.late) qc_park_g(s, li); });
+  if (ca.late) return;
   __syncthreads();
   qc_wgrad_all(s, rb, h.L, true);
 }
@@ -349,6 +360,54 @@ __global__ __launch_bounds__(256) void q_bwd_trunk_chain_kernel(QChainArgs ca) {
   __shared__ QcLds s;
   const QFusedArgs& a = ca.f;
   const int rb = blockIdx.x, row0 = rb * HT_RB;
+  if (blockIdx.y > 0) {
+    // ---- grid row 1 + tw: the weight gradients of tower tw for this row block, from what the tower chains left in memory
+    // (activations, gradient rows, output gradients): one batch of loads, the rows parked in LDS, qc_wgrad_all
+    const int tw = blockIdx.y - 1, t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4, n = 16 * w + c;
+    const HtHead& h = a.bwd_tw[tw];
+    const int L = h.L;
+    float xv[8], zm[GRL_MAX_LAYERS][4], gm[GRL_MAX_LAYERS][4], dv[4] = {0.f, 0.f, 0.f, 0.f};
+    qc_xin_load(ca.tw[tw], row0, a.B, xv);
+    qc_head_to_lds(s, ca.tw + tw);
+#pragma unroll
+    for (int li = 0; li < GRL_MAX_LAYERS; ++li)
+      if (li < L) {
+        const int H = h.hid[li];
+        const float* zp = li == 0 ? h.z0 : h.z[li];
+        const float* gp = li == 0 ? h.g0 : h.g[li];
+        const int ldg = li == 0 ? h.ldg0 : H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + 4 * q + i;
+          const bool ok = row < a.B && n < H;
+          zm[li][i] = ok ? QM_G(zp)[(long)row * H + n] : 0.f;
+          gm[li][i] = ok ? QM_G(gp)[(long)row * ldg + n] : 0.f;
+        }
+      }
+    const int r = t >> 4, row = row0 + r, o0 = t & 15;
+    if (tw < a.D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = o0 + 16 * j;
+        if (row < a.B && o < a.nb) dv[j] = QM_G(a.d_adv)[((long)row * a.D + tw) * a.nbp + o];
+      }
+    } else if (o0 == 0 && row < a.B) {
+      dv[0] = QM_G(a.d_v)[(long)row * a.ld_dv];
+    }
+    qc_park_z(s, zm, L);
+#pragma unroll
+    for (int li = 0; li < GRL_MAX_LAYERS; ++li)
+      if (li < L) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.g[li][4 * q + i][n] = gm[li][i];
+      }
+    qc_xin_store(s, xv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.m.o[r][o0 + 16 * j] = dv[j];
+    __syncthreads();
+    qc_wgrad_all(s, rb, L, true);
+    return;
+  }
   const HtHead& h = *a.bwd_tr;
   float xv[8];
   qc_xin_load(*ca.tr, row0, a.B, xv);

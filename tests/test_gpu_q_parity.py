@@ -58,6 +58,27 @@ def test_q_update_separate_loss_and_weight_gradient_launches(name, monkeypatch, 
         np.testing.assert_allclose(outs[0][3][k], outs[1][3][k], rtol=0, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["bdq_reference_shape", "bdq_baseline_config3", "bdq_5_branches"])
+def test_q_update_tower_weight_gradients_at_the_end_of_their_chains(name, monkeypatch):
+    """GRL_TUNE q_chain_late=0: every tower chain forms its weight-gradient slabs itself (what networks without a trunk do);
+    the default for networks with a trunk hands them to workgroups of the trunk launch.  Same tiles, same sums: bit-identical."""
+    import numpy as np
+    outs = []
+    for tune in ("q_chain_late=0", "q_chain_late=1"):
+        monkeypatch.setenv("GRL_TUNE", tune)
+        case = qu.make_q_case(**qu.CASES[name])
+        if tune.endswith("0"):
+            qu.run_and_compare(case)
+        eng = qu.q_engine_setup(case)
+        eng.train(2, case["idx"][:2], case["weights"][:2])
+        outs.append((eng.get_gradients(), eng.get_parameters()))
+        eng.close()
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
 @pytest.mark.parametrize("name", ["dqn_reference_shape", "bdq_reference_shape"])
 def test_q_update_three_launch_apply(name, monkeypatch):
     """GRL_TUNE fused_qapply=0: slab reduction, clip_by_norm and Adam as three launches instead of the fused one."""
