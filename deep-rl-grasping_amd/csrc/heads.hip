@@ -25,7 +25,18 @@ bool q_mfma_built() {
   return true;
 #endif
 }
-bool q_chain_built() { return q_mfma_built(); }
+// the backward chains that form the loss and the weight gradients of their rows (q_chain.h): on the device they are built from
+// the matrix-core stages, so they go with them (mfma); the emulation has a sequential reference form for every shape that
+// fits those stages (fits), whichever forward kernels the plan took
+bool q_chain_available(bool mfma, bool fits) {
+#ifdef GRL_HOSTEMU
+  (void)mfma;
+  return fits;
+#else
+  (void)fits;
+  return mfma;
+#endif
+}
 bool act_mfma_built() { return q_mfma_built(); }
 int device_lds_bytes() {
 #ifdef GRL_HOSTEMU
@@ -77,15 +88,9 @@ void launch_q_bwd(const QFusedArgs& a, hipStream_t s) {
   if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, trunk, dim3(256), 0, s, a);
 }
 void launch_q_bwd_chain(const QChainArgs& a, hipStream_t s) {
-#ifdef GRL_HOSTEMU
-  (void)a; (void)s;
-  fprintf(stderr, "grl: the chained Q backward has no emulation form (q_chain_built() is false there)\n");
-  abort();
-#else
   const dim3 towers((a.f.B + HT_RB - 1) / HT_RB, a.f.D + 1), trunk((a.f.B + HT_RB - 1) / HT_RB, a.late ? a.f.D + 2 : 1);
   hipLaunchKernelGGL(q_bwd_towers_chain_kernel, towers, dim3(256), 0, s, a);
   if (a.f.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_chain_kernel, trunk, dim3(256), 0, s, a);
-#endif
 }
 
 }  // namespace grl

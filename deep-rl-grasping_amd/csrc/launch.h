@@ -38,7 +38,7 @@ void launch_conv_stack_bwd(const ConvStackBwdArgs& a, hipStream_t s);
 // carry no build switches of their own: the g++ emulation build (tests only) has sequential reference forms for the VALU chains
 // and the scalar element-wise kernels, but none for the matrix-core chains or the 16-byte element-wise variants.
 bool q_mfma_built();                 // q_mfma.h: tower / trunk chains on 16x16x4 MFMA stages
-bool q_chain_built();                // q_chain.h: backward chains that form the loss and the weight gradients of their rows
+bool q_chain_available(bool mfma, bool fits);   // q_chain.h: backward chains that form the loss and the weight gradients of their rows
 bool act_mfma_built();               // act_mfma.h: policy head of grl_act on MFMA stages
 int device_lds_bytes();              // shared memory a workgroup may declare on the current device (emulation: no limit)
 enum { HEADS_GENERAL_64 = 0, HEADS_FAST_64 = 1, HEADS_FAST_128 = 2 };

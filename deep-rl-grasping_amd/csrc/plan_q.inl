@@ -347,11 +347,12 @@ int grl_ctx::plan_q() {
       qf.dh_part = wk.f32((int64_t)(D + 1) * B * qf.Ht);
     }
     // matrix-core stages (q_mfma.h) when every chain fits their 64-wide shape; GRL_TUNE q_mfma=0 keeps the VALU chains
-    qf.mfma = want_mfma && trunk_mfma_ok;
+    bool fits64 = trunk_mfma_ok && nb <= QM_W && D + 1 <= QM_MAXP;       // every backward chain fits the 64-wide stage shape
+    for (auto& h : hb) fits64 = fits64 && qm_head_ok(h);
+    qf.mfma = want_mfma && fits64;
     for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h, true, true);
-    for (auto& h : hb) qf.mfma = qf.mfma && qm_head_ok(h);
     if (want_mfma && !qf.mfma) return fail(GRL_ERR_INVALID, "internal: the Q chains were planned for the matrix-core stages and do not fit them");
-    q_chain = qf.mfma && q_chain_built() && tune_int("q_chain", 1) != 0 && tune_int("fused_qapply", 1) != 0 && qc_shape_ok(nb, D, c.obs_dim);
+    q_chain = q_chain_available(qf.mfma != 0, fits64) && tune_int("q_chain", 1) != 0 && tune_int("fused_qapply", 1) != 0 && qc_shape_ok(nb, D, c.obs_dim);
     if (q_chain) {      // nothing reads the trunk's pre-activation gradients from memory any more: its chain keeps them in LDS;
       // the towers' are read back by the weight-gradient workgroups of the trunk launch when there is one (GRL_TUNE q_chain_late=0:
       // every tower chain forms its slabs itself, at its end)

@@ -48,7 +48,9 @@ enum { QC_XW = 2 * QM_W, QC_XLD = QC_XW + 4 };
 static inline bool qc_shape_ok(int n_bins, int D, int obs_dim) { return n_bins <= 64 && D * n_bins <= 256 && obs_dim <= QC_XW; }
 
 #ifndef GRL_HEADS_TYPES_ONLY
-#ifndef GRL_HOSTEMU
+#ifdef GRL_HOSTEMU
+#include "q_chain_ref1.h"   // tests/hostemu: the emulation build only
+#else
 
 // Code size is a cost here: a chain runs its instructions exactly once per launch, so every one of them is a cold
 // instruction-cache line (the first cut, with the loss unrolled over rows and branches, was 70 KB of code and took 38 us for

@@ -13,6 +13,20 @@ def test_q_plan_matches_oracle(hostemu_lib, name):
     qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
 
 
+@pytest.mark.parametrize("name,tune,chained", [("bdq_baseline_config3", "", True), ("bdq_baseline_config3", "q_chain_late=0", True),
+                                               ("bdq_5_branches", "q_chain=0", False), ("dqn", "q_chain=0", False), ("dqn", "", True)])
+def test_q_plan_chained_backward_and_its_fallbacks(hostemu_lib, name, tune, chained, monkeypatch, capfd):
+    """The default plan forms the loss and the weight gradients inside the backward chains (csrc/q_chain.h; slabs per row block
+    summed by the apply launch; with a trunk the towers' slabs by workgroups of the trunk launch) -- the emulation runs the same
+    launch plan through sequential reference kernels (tests/hostemu/q_chain_ref1.h); GRL_TUNE q_chain=0 / q_chain_late=0 keep
+    the other forms.  All against the oracle."""
+    monkeypatch.setenv("GRL_PLAN_DUMP", "1")
+    monkeypatch.setenv("GRL_TUNE", tune)
+    case = qu.make_q_case(**qu.CASES[name])
+    qu.run_and_compare(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+    assert ("inside the backward chains" in capfd.readouterr().err) == chained
+
+
 @pytest.mark.parametrize("name", ["dqn", "bdq_5_branches"])
 def test_q_plan_per_layer_gemm_fallback(hostemu_lib, name, monkeypatch):
     """GRL_TUNE fused_q=0: one GEMM launch per layer instead of the row-local chains of q_kernels.h."""
