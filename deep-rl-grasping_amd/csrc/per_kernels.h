@@ -162,13 +162,18 @@ __device__ __forceinline__ double per_tree_build_regs(double* tr, double l0, dou
   return tr[1];
 }
 // the reference's find_prefixsum_idx over one 1024-leaf tree; every thread walks (LDS broadcasts)
+// (two levels per LDS round trip: the left child and the left children of BOTH children are read together -- the same
+//  comparisons and subtractions in the same order as one level at a time, five dependent reads instead of ten)
 __device__ __forceinline__ int per_tree_walk(const double* tr, double& rem) {
   int i = 1;
 #pragma unroll 1
-  for (int lvl = 0; lvl < 10; ++lvl) {
-    const double left = tr[2 * i];
-    if (left > rem) i = 2 * i;
-    else { rem -= left; i = 2 * i + 1; }
+  for (int lvl = 0; lvl < 10; lvl += 2) {
+    const double left = tr[2 * i], ll = tr[4 * i], rl = tr[4 * i + 2];
+    double next;
+    if (left > rem) { i = 2 * i; next = ll; }
+    else { rem -= left; i = 2 * i + 1; next = rl; }
+    if (next > rem) i = 2 * i;
+    else { rem -= next; i = 2 * i + 1; }
   }
   return i - PER_BLK;
 }
