@@ -251,9 +251,17 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
     gather_row_device(g, k, idx);
     if (g.adam_tick && k == 0 && t == 0) adam_tick_device(g.sc);
   }
+  if (t < 64) {
+    // importance weight (per_weight): its two float64 powers -- a few hundred instructions each -- side by side in lanes 0 and 1
+    // of wave 0 instead of one after the other in lane 0; the same operations on the same values
+    const double beta = a.st->beta;
+    const double base = ((t == 0 ? pmin : a.p[idx]) / total) * (double)size;
+    const double pw = t < 2 ? pow(base, -beta) : 0.0;
+    const double max_weight = __shfl(pw, 0, 64), p_pow = __shfl(pw, 1, 64);
+    if (t == 0) a.w_out[k] = (float)(p_pow / max_weight);
+  }
   if (t == 0) {
     a.idx_out[k] = idx;
-    a.w_out[k] = per_weight(a.p[idx], total, pmin, size, a.st->beta);
     if (k == 0) { a.st->total = total; a.st->total_s = total_s; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }   // q_loss_kernel advances rng_step
   }
 }
