@@ -72,8 +72,12 @@ struct ConvStackBwdArgs {
 enum { CS_P1 = 36, CS_P2 = 68, CS_R2 = 64 * 64, CS_LDS_FLOATS = 225 * CS_P1 + CS_R2 };
 static_assert(CS_R2 >= 36 * CS_P2, "the layer-2 tile lives where the image was");
 // (two image channels: 8192 floats staged, 65 KB per workgroup, two per CU; four channels are not staged -- 64 KB of image per
-//  sample -- and the launch plans keep one implicit-GEMM launch per layer for them: conv_stack_ok)
-constexpr int cs_lds_floats(int C) { return 225 * CS_P1 + (C <= 2 ? CS_R2 * C : 36 * CS_P2); }
+//  sample: see CS_BAND below)
+// (four image channels: 64 KB per sample -- staged in eight BANDS of 16 image rows, channel-planar: CS_BAND floats; 48.9 KB per
+//  workgroup like the one-channel form, three per CU)
+enum { CS_PLANE = 16 * 64 + 4, CS_BAND = 4 * CS_PLANE };
+static_assert(CS_BAND >= 36 * CS_P2, "the layer-2 tile lives where the band was");
+constexpr int cs_lds_floats(int C) { return 225 * CS_P1 + (C <= 2 ? CS_R2 * C : (C == 4 ? CS_BAND : 36 * CS_P2)); }
 
 #ifdef GRL_HOSTEMU
 #include "conv_stack_ref1.h"   // tests/hostemu: the emulation build only
@@ -156,7 +160,7 @@ __device__ __forceinline__ void cs_unit(int B, int n_nets, int& net, int& smp) {
 #endif
 
 template <int C>
-__global__ __launch_bounds__(256, (C == 1 ? CS_WG_PER_CU : 2)) void conv_stack_fwd_kernel(ConvStackArgs a) {
+__global__ __launch_bounds__(256, (C == 1 ? CS_WG_PER_CU : (C == 4 ? 3 : 2))) void conv_stack_fwd_kernel(ConvStackArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[cs_lds_floats(C)];
   float* const act1 = lds;
   float* const act2 = lds + 225 * CS_P1;
@@ -219,6 +223,96 @@ __global__ __launch_bounds__(256, (C == 1 ? CS_WG_PER_CU : 2)) void conv_stack_f
     }
     const float bias0 = net.b[0][c], bias1 = net.b[0][16 + c];
     float* const a1g = net.a1 ? net.a1 + (int64_t)smp * 225 * net.ld1 : nullptr;
+    // bias + ReLU of one 16 x 32 tile into the layer-1 tile in LDS (channels transposed, cs_pos) and, for the networks whose
+    // weight gradients need them, out to memory
+    auto emit_tile = [&](int mt, const cs_f4 (&acc)[2]) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * mt + 4 * q + v;
+        if (row < 225) {
+          act1[row * CS_P1 + cs_pos(c)] = fmaxf(acc[0][v] + bias0, 0.f);
+          act1[row * CS_P1 + 16 + cs_pos(c)] = fmaxf(acc[1][v] + bias1, 0.f);
+        }
+      }
+      if (a1g) {
+        // this wave's 16 x 32 tile goes out as whole 128-byte rows (two 16-byte stores per lane) right away: a burst of all
+        // 225 rows after the barrier queued 14 k cycles behind the other workgroups' stores (scripts/conv_stack_bench.hip
+        // stamps).  LDS operations of one wave execute in order: the fence only keeps the compiler from moving the reads up.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = 16 * mt + 8 * h + (l >> 3), ch = l & 7;
+          if (row < 225) *(cs_f4*)(a1g + (int64_t)row * net.ld1 + 4 * ch) = cs_row4(act1 + row * CS_P1, ch);
+        }
+      }
+    };
+    if constexpr (C == 4) {
+      // ---- RGB-D: the image (64 KB) is staged in eight BANDS of 16 rows, channel-PLANAR: lane group q reads channel q, and the
+      // four taps kw .. kw + 3 of a reduction chunk are 16 contiguous bytes of its plane -- one LDS read per chunk where the
+      // interleaved image needed four.  Round r: row tiles 2 r and 2 r + 1 (outputs 32 r .. 32 r + 31 lie in output rows 2 r ..
+      // 2 r + 2, i.e. image rows 8 r .. 8 r + 15); waves 0 / 1 take the two 16-channel halves of tile 2 r, waves 2 / 3 those of
+      // tile 2 r + 1, so a wave keeps HALF of the 256 x 32 kernel in registers (64 per lane) and three workgroups fit a CU
+      // (with whole tiles per wave -- 128 kernel registers, 24-row bands, two workgroups per CU -- 768 workgroups filled 512
+      // slots one and a half times: 79 us, no better than the three per-layer launches).  The next band travels from memory
+      // while a tile is multiplied.
+      float* const xb = ximg;
+      const int rt = w >> 1, nt = w & 1;
+      float bw4[16][4];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cs_load_b(bw4[j], rsw1, voff1 + 64 * nt, j, 32);
+      const float bias_n = net.b[0][16 * nt + c];
+      cs_f4 pre[4];
+      auto band_load = [&](int r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = t + 256 * e, row = 8 * r + (idx >> 6);
+          pre[e] = row < 64 ? *(const cs_f4*)(x + 4 * (row * 64 + (idx & 63))) : cs_f4{0.f, 0.f, 0.f, 0.f};
+        }
+      };
+      auto band_store = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = t + 256 * e;
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) xb[ch * CS_PLANE + idx] = pre[e][ch];
+        }
+      };
+      band_load(0);
+#pragma unroll 1
+      for (int r = 0; r < 8; ++r) {
+        if (r > 0) __syncthreads();          // every wave is done reading band r - 1
+        band_store();
+        __syncthreads();
+        if (r < 7) band_load(r + 1);
+        const int mt = 2 * r + rt;
+        if (mt < 15) {
+          const int p = 16 * mt + c < 225 ? 16 * mt + c : 224;
+          const int oh = p / 15, ow = p - oh * 15;
+          const float* src = xb + q * CS_PLANE + (4 * oh - 8 * r) * 64 + 4 * ow;
+          cs_f4 acc = {0.f, 0.f, 0.f, 0.f};       // ONE chain: the sum runs in increasing k (the other waves of the SIMD fill the gaps)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const cs_f4 av = *(const cs_f4*)(src + (j >> 1) * 64 + 4 * (j & 1));      // taps (kh = j / 2, kw = 4 (j % 2) .. + 3), channel q
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw4[j][i], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int row = 16 * mt + 4 * q + v;
+            if (row < 225) act1[row * CS_P1 + 16 * nt + cs_pos(c)] = fmaxf(acc[v] + bias_n, 0.f);
+          }
+          if (a1g) {       // this wave's 16 rows x 16 channels go out right away: one 16-byte store per lane (see emit_tile)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int row = 16 * mt + (l >> 2), m = 4 * nt + (l & 3);
+            if (row < 225) *(cs_f4*)(a1g + (int64_t)row * net.ld1 + 4 * m) = cs_row4(act1 + row * CS_P1, m);
+          }
+        }
+      }
+        } else
     for (int mt = w; mt < 15; mt += 4) {
       cs_f4 acc[2] = {cs_f4{0.f, 0.f, 0.f, 0.f}, cs_f4{0.f, 0.f, 0.f, 0.f}};
       if (RES) {
@@ -264,27 +358,7 @@ __global__ __launch_bounds__(256, (C == 1 ? CS_WG_PER_CU : 2)) void conv_stack_f
             for (int i = 0; i < 4; ++i) b0[nt][i] = b1[nt][i];
         }
       }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * mt + 4 * q + v;
-        if (row < 225) {
-          act1[row * CS_P1 + cs_pos(c)] = fmaxf(acc[0][v] + bias0, 0.f);
-          act1[row * CS_P1 + 16 + cs_pos(c)] = fmaxf(acc[1][v] + bias1, 0.f);
-        }
-      }
-      if (a1g) {
-        // this wave's 16 x 32 tile goes out as whole 128-byte rows (two 16-byte stores per lane) right away: a burst of all
-        // 225 rows after the barrier queued 14 k cycles behind the other workgroups' stores (scripts/conv_stack_bench.hip
-        // stamps).  LDS operations of one wave execute in order: the fence only keeps the compiler from moving the reads up.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int row = 16 * mt + 8 * h + (l >> 3), ch = l & 7;
-          if (row < 225) *(cs_f4*)(a1g + (int64_t)row * net.ld1 + 4 * ch) = cs_row4(act1 + row * CS_P1, ch);
-        }
-      }
+      emit_tile(mt, acc);
     }
   }
   // the first kernel chunks of conv2 do not depend on this workgroup's activations: requested before the barrier

@@ -40,11 +40,12 @@ void launch_igemm2_fwd(int key, int n_tiles, hipStream_t s, const IgemmProb* pro
 // one / two image channels (depth with the augmented extractor; nature_cnn on depth + pad channel).  RGB-D (four channels) keeps
 // one launch per layer: its first layer cannot stage the image in LDS, and with the 4-byte patch loads the k-order demands the
 // stack measured 3 657 against 4 156 updates/s (profiles/r05_bench_sac_rgbd_*.json)
-bool conv_stack_ok(int C) { return C == 1 || C == 2; }
+bool conv_stack_ok(int C) { return C == 1 || C == 2 || C == 4; }
 void launch_conv_stack_fwd(int C, const ConvStackArgs& a, hipStream_t s) {
   const dim3 grid(a.B * a.n_nets), block(256);
   if (C == 1) hipLaunchKernelGGL((conv_stack_fwd_kernel<1>), grid, block, 0, s, a);
   else if (C == 2) hipLaunchKernelGGL((conv_stack_fwd_kernel<2>), grid, block, 0, s, a);
+  else if (C == 4) hipLaunchKernelGGL((conv_stack_fwd_kernel<4>), grid, block, 0, s, a);
   else {
     fprintf(stderr, "grl: no conv-stack instantiation for %d image channels\n", C);
     abort();
