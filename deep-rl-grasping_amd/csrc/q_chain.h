@@ -5,9 +5,9 @@
 // At batch 32 - 64 an update is a handful of launches at the launch floor (round 4: seven launches of 6 - 11 us for
 // 0.01 GFLOP).  Two of them only existed because their work had been given a launch of its own:
 //   * the loss (q_loss_kernel, 6.8 us): row-local -- a row's TD target needs the towers of all three networks for THAT row.
-//     Every tower chain of q_bwd_towers forms the loss of its own 16 rows itself (one wavefront per row, the arithmetic of
-//     q_loss_kernel instruction for instruction: same DPP reductions, same results bit for bit) and takes its own tower's
-//     output gradients from it; the value tower's workgroups also write what the rest of the update reads (TD errors,
+//     Every tower chain of q_bwd_towers forms the loss of its own 16 rows itself (one 16-lane group per row, four bins per
+//     lane, the branches a loop over LDS operands; the 64-lane sums of q_loss_kernel are rebuilt from the same four DPP row
+//     sums in the same order: same results bit for bit) and takes its own tower's output gradients from it; the value tower's workgroups also write what the rest of the update reads (TD errors,
 //     priorities, the rows' partial sums of the metrics);
 //   * the weight gradients (q_wgrad, 6.0 us): dW = x^T g over the batch rows is 4 k-steps of a 16x16x4 MFMA per 16 rows and
 //     16x16 tile -- the chain that has just produced g for its 16 rows, with the layer's input rows still at hand, forms the
@@ -52,9 +52,9 @@ static inline bool qc_shape_ok(int n_bins, int D, int obs_dim) { return n_bins <
 #include "q_chain_ref1.h"   // tests/hostemu: the emulation build only
 #else
 
-// Code size is a cost here: a chain runs its instructions exactly once per launch, so every one of them is a cold
-// instruction-cache line (the first cut, with the loss unrolled over rows and branches, was 70 KB of code and took 38 us for
-// the two launches that had taken 13).  Hence real loops over the branches and over the layers, with their operands in LDS.
+// Code size is a cost here: the first cut, with the loss unrolled over rows and branches and a weight-gradient call per stage,
+// was 70 KB of straight-line code and took 38 us for the two launches that had taken 13.  Hence real loops over the branches
+// and over the layers, with their operands in LDS.
 enum { QC_DN = 256 };                      // D * bins of a row the loss staging holds
 struct __attribute__((aligned(16))) QcLds {
   QmLds m;
