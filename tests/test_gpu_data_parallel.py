@@ -345,6 +345,58 @@ def test_in_graph_exchange_on_dqn_and_bdq_handles(tmp_path, world):
                 assert np.array_equal(parts[0][k], p[k]), "replicas diverged (%s): %s" % (name, k)
 
 
+def _q_learn_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GRL_DP_SAME_DEVICE="1", GRL_TUNE="dp_timeout_ms=20000")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from fake_env import FakeGraspEnv
+    from grasp_rl.parallel import DataParallelInGraph
+    from grasp_rl.sb.callbacks import BaseCallback
+    from grasp_rl.sb.dqn import BDQ
+    from grasp_rl.sb.policies import BdqMlpActPolicy
+    from grasp_rl.sb.vec_env import DummyVecEnv
+
+    class StopAt(BaseCallback):
+        calls = 0
+
+        def _on_step(self):
+            StopAt.calls += 1
+            return self.num_timesteps < 300
+
+    env = DummyVecEnv([lambda: FakeGraspEnv(vector_dim=101, act_dim=5, seed=5 + rank)])
+    model = BDQ(BdqMlpActPolicy, env, batch_size=64, buffer_size=512, learning_starts=80, target_network_update_freq=50, seed=3,
+                num_actions_pad=33, prioritized_replay=True, policy_kwargs={"layers": [[64, 64], [32], [32]]}, data_parallel=True)
+    assert isinstance(model._dp, DataParallelInGraph) and model.engine.cfg.batch_size == 32
+    model.learn(10_000, callback=StopAt())
+    P = model.get_parameters()
+    leaves = model.engine.stored_priorities()
+    np.savez(os.path.join(out_dir, "qlearn%d.npz" % rank), steps=model.num_timesteps, updates=model.n_updates, calls=StopAt.calls,
+             replay=model.engine.replay_size(), **{k.replace("/", "|"): v for k, v in P.items()})
+    np.save(os.path.join(out_dir, "qleaves%d.npy" % rank), leaves)
+    model.engine.close()
+    dist.destroy_process_group()
+
+
+def test_bdq_learn_two_replicas_with_prioritised_replay_on_one_gpu(tmp_path):
+    """configs[2] as the bench runs it -- BDQ, 101-d observations, 5 x 33 bins, global batch 64, prioritised replay -- through
+    BDQ(data_parallel=True).learn with two replicas sharing the MI355X: exchange inside the update graph, ONE priority tree per
+    rank (the ranks' leaves differ, their parameters do not), job-level counters, rank 0's callback stopping both loops."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_q_learn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "qlearn0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "qlearn1.npz"))
+    assert int(r0["calls"]) > 0 and int(r1["calls"]) == 0
+    assert int(r0["steps"]) == int(r1["steps"]) == 300 and int(r0["replay"]) == int(r1["replay"]) == 149
+    assert int(r0["updates"]) == int(r1["updates"]) == 2 * (149 - 40)        # job steps 82 .. 298: two updates each
+    for k in r0.files:
+        if k != "calls":
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    l0, l1 = np.load(os.path.join(str(tmp_path), "qleaves0.npy")), np.load(os.path.join(str(tmp_path), "qleaves1.npy"))
+    assert (l0[:149] > 0).all() and (l1[:149] > 0).all() and not np.array_equal(l0, l1)      # trees of their own
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
     """W processes on the box's one MI355X map each other's exchange buffers (hipIpc) and run the data-parallel update with
