@@ -688,9 +688,10 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
                            {&h->ops_act_in[v], &h->ops_act, deterministic ? &h->ops_act_det : &h->ops_act_sto}))
       return e;
   }
-  if (q) HIPCHK(hipMemcpyAsync(h->pin_out, h->q_aout, n_out * 4, hipMemcpyDeviceToHost, h->stream));
+  const bool poll = h->act_done_wgs && !h->prof;
+  if (q && !poll) HIPCHK(hipMemcpyAsync(h->pin_out, h->q_aout, n_out * 4, hipMemcpyDeviceToHost, h->stream));
   bool seen = false;
-  if (!q && h->act_done_wgs && !h->prof) {
+  if (poll) {
     // the last launch counts its workgroups into coherent host memory once their actions are out (act_mfma.h): poll that
     // instead of the stream's completion signal; bounded -- after 2 ms (or on any doubt) the stream is synchronised as before
     h->act_done_seen += h->act_done_wgs;
@@ -703,7 +704,7 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
   }
   if (!seen) HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
-  memcpy(out, q ? h->pin_out : h->a_out, n_out * 4);
+  memcpy(out, q ? (poll ? h->q_act_host : h->pin_out) : h->a_out, n_out * 4);
   return GRL_OK;
 }
 

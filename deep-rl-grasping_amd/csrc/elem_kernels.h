@@ -1021,16 +1021,30 @@ __global__ __launch_bounds__(256) void clip_by_norm_kernel(float* grads, const V
 
 // Q-values of the act path: q[b, d, k] = v[b] + adv[b, d, k] - mean_k adv[b, d, :]
 #ifndef GRL_ELEM_TYPES_ONLY
+// q_host / done (optional): the values also go to page-locked coherent host memory and every workgroup counts itself into
+// `done` once its stores are out -- grl_act polls that instead of a device-to-host copy + stream synchronisation (act_mfma.h)
 __global__ __launch_bounds__(256) void dueling_kernel(const float* adv, const float* v, int rows, int D, int n,
-                                                     float* q) {
+                                                     float* q, float* q_host, unsigned* done) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * D) return;
-  const int b = i / D;
-  const float* a = adv + (long)i * n;
-  float m = 0.f;
-  for (int k = 0; k < n; ++k) m += a[k];
-  m /= (float)n;
-  for (int k = 0; k < n; ++k) q[(long)i * n + k] = v[b] + a[k] - m;
+  if (i < rows * D) {
+    const int b = i / D;
+    const float* a = adv + (long)i * n;
+    float m = 0.f;
+    for (int k = 0; k < n; ++k) m += a[k];
+    m /= (float)n;
+    for (int k = 0; k < n; ++k) {
+      const float val = v[b] + a[k] - m;
+      q[(long)i * n + k] = val;
+      if (q_host) q_host[(long)i * n + k] = val;
+    }
+  }
+#ifndef GRL_HOSTEMU
+  if (done) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#endif
 }
 #endif
 

@@ -260,6 +260,7 @@ struct grl_ctx {
   // act path
   float *ax, *aa1, *aa2, *aa3, *afeat, *a_eps, *a_out;
   float* act_io_host = nullptr;   // SAC: a_eps | a_out live in page-locked host memory (plan_sac.inl)
+  float* q_act_host = nullptr;         // DQN / BDQ: the Q-values of the act path in coherent host memory (plan_q.inl)
   unsigned* act_done_host = nullptr;   // SAC: completion counter of the act path's last launch (coherent host memory), polled by grl_act
   unsigned act_done_wgs = 0, act_done_seen = 0;    // increments per call (0: no counter, synchronise the stream); expected value
   HeadAct ahPI;
@@ -338,6 +339,7 @@ struct grl_ctx {
     if (pin_out) hipHostFree(pin_out);
     if (act_io_host) hipHostFree(act_io_host);
     if (act_done_host) hipHostFree(act_done_host);
+    if (q_act_host) hipHostFree(q_act_host);
     for (int k = 0; k < 2; ++k) {
       if (pin_ob[k]) hipHostFree(pin_ob[k]);
       if (pin_ob_ev[k]) hipEventDestroy(pin_ob_ev[k]);

@@ -669,9 +669,23 @@ int grl_ctx::plan_q() {
     for (auto& v : sh1) add_launch(ops_act, "act_q", 0, v);
     add_launch(ops_act, "act_q", 0, so1);
     const float* adv = aact.adv; const float* vv = aact.v; float* qo = q_aout; const int rows = NA, Dq = D, nq = nb;
+    // the last launch also writes the Q-values to coherent host memory and counts its workgroups there: grl_act polls the
+    // counter instead of copying device -> host and synchronising the stream (GRL_TUNE act_poll=0 keeps that)
+    if (!dry && tune_int("act_poll", 1) != 0 &&
+        hipHostMalloc((void**)&q_act_host, (size_t)NA * D * nb * 4, hipHostMallocCoherent) == hipSuccess) {
+      if (hipHostMalloc((void**)&act_done_host, 64, hipHostMallocCoherent) == hipSuccess) {
+        *act_done_host = 0u;
+        act_done_wgs = (unsigned)((rows * Dq + 255) / 256);
+      } else {
+        (void)hipHostFree(q_act_host);
+        q_act_host = nullptr; act_done_host = nullptr;
+      }
+    }
+    float* qh = act_done_wgs ? q_act_host : nullptr;
+    unsigned* dn = act_done_wgs ? act_done_host : nullptr;
     Op op2; op2.tag = "dueling";
-    op2.run = [adv, vv, qo, rows, Dq, nq](hipStream_t s) {
-      hipLaunchKernelGGL(dueling_kernel, dim3((rows * Dq + 255) / 256), dim3(256), 0, s, adv, vv, rows, Dq, nq, qo);
+    op2.run = [adv, vv, qo, rows, Dq, nq, qh, dn](hipStream_t s) {
+      hipLaunchKernelGGL(dueling_kernel, dim3((rows * Dq + 255) / 256), dim3(256), 0, s, adv, vv, rows, Dq, nq, qo, qh, dn);
     };
     ops_act.push_back(op2);
   }
