@@ -1044,6 +1044,8 @@ __global__ __launch_bounds__(256) void dueling_kernel(const float* adv, const fl
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+#else
+  if (done && threadIdx.x == 0) *done += 1u;      // (emulation: launches run synchronously, the host's poll finds the count at once)
 #endif
 }
 #endif
