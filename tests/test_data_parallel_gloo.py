@@ -131,6 +131,18 @@ def test_running_stats_are_merged_over_ranks(tmp_path):
     assert np.allclose(r0["mean"], allobs.mean(0), atol=1e-4) and np.allclose(r0["var"], allobs.var(0), rtol=1e-3, atol=1e-4)
 
 
+def test_runtime_for_modes_without_a_launch(monkeypatch):
+    """`data_parallel=` of the models: off values and "auto" outside a torchrun launch give no runtime (single-process training);
+    an insisting value without a launch raises instead of training a lone replica silently."""
+    from grasp_rl.parallel import runtime_for
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    for mode in (None, False, "", "0", "off", "auto"):
+        assert runtime_for(mode) is None
+    with pytest.raises(RuntimeError):
+        runtime_for(True)
+
+
 def test_scale_and_bucket_helpers():
     from grasp_rl.parallel import allreduce_mean_scale
     assert allreduce_mean_scale(8) == 0.125
