@@ -824,8 +824,8 @@ __device__ __forceinline__ int q_wave_argmax_dpp(float sv, int si) {
 // One minibatch row of the loss on one wavefront, lane = bin (n <= 64, D <= Q_DM), in two steps: the operands of the row --
 // requested in one burst (one memory round trip instead of 2 D) -- and the arithmetic.  emit_g(d, g, ai, td) receives the
 // loss gradient scale, the stored bin and the TD error of branch d (wave-uniform values, every lane calls it), emit_row(dv,
-// priority, weighted loss, mean selected Q) the row's results.  Shared by q_loss_kernel and the backward chains of
-// q_chain.h, which form the loss of their own rows themselves.
+// priority, weighted loss, mean selected Q) the row's results.  (The backward chains of q_chain.h form the loss of their own
+// rows with the same arithmetic on 16-lane groups: qc_rows_loss.)
 enum { Q_DM = 8 };
 struct QRowIn { float xs[Q_DM], xt[Q_DM], x0[Q_DM]; int ais[Q_DM]; float v2b, v0b, rewb, doneb, w; };
 __device__ __forceinline__ void q_row_load(const QLossArgs& a, int b, int lane, QRowIn& in) {
