@@ -5,8 +5,9 @@ observations, batch 256 per GPU (BASELINE.json metric; configs[1] = config/gripp
 
 One step = draw a minibatch from the HBM-resident replay (device Philox) + normalise + 3 CNN forwards + heads +
 losses + backward through both trainable CNNs + 3 Adam applies + Polyak update, replayed as one hipGraph
-(DESIGN.md section 4).  Inputs are resident in HBM before the timed region.  The timed block (exactly --steps
-updates between barrier + synchronize) is repeated --repeats times; `value` is the MEDIAN block.
+(DESIGN.md section 4).  Inputs are resident in HBM before the timed region.  A timed block is exactly --steps updates
+per call between barrier + synchronize, the call repeated back to back until the block holds >= 50 ms of work
+(`repeats.calls_per_block`); --repeats blocks, `value` is the MEDIAN block.  The timed call shape is warmed untimed.
 
 N > 1: one process per GPU, data parallel, gradients all-reduced over RCCL per update.  Default per-GPU batch 256
 (weak scaling, `value` = N x global steps/s); `--global-batch G` fixes the GLOBAL batch (G/N per GPU, strong
@@ -118,24 +119,49 @@ def fill_replay_on_device(eng, n, seed, device, kind="depth", act_dim=5):
     return st
 
 
+MIN_BLOCK_S = 0.050         # a timed block holds at least this much work (the driver's --steps 20 is 3.6 ms of updates)
+
+
 def timed_blocks(run, barrier, steps, warmup, repeats, world, device):
-    """`repeats` timed blocks of exactly `steps` updates (barrier + synchronize on both sides, MAX over ranks)."""
+    """`repeats` timed blocks (barrier + synchronize on both sides, MAX over ranks).  A block is `calls` back-to-back
+    `run(steps)` calls -- each exactly `steps` updates, the call shape the command line names -- with `calls` chosen so that
+    a block holds >= MIN_BLOCK_S of work (1 when `steps` is large enough on its own).  Returns (seconds per `steps` updates
+    of every block, calls).  Untimed before the first block: `run(warmup)` AND the exact timed shape, `run(steps)`, twice --
+    a `steps`-update call replays hipGraphs of 16 + (steps % 16) updates that a `warmup`-update call never instantiates
+    (round 5: the driver's `--steps 20 --warmup 5` blocks fell 13 % across the five repeats)."""
     import torch
     import torch.distributed as dist
-    run(warmup)
+
+    def over_ranks(v, op):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+    if warmup > 0:
+        run(warmup)
+    run(steps)
+    barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    barrier()
+    est = over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)       # the same `calls` on every rank
+    calls = max(1, min(4096, int(-(-MIN_BLOCK_S // max(est, 1e-6)))))
     times = []
     for _ in range(repeats):
         barrier()
         t0 = time.perf_counter()
-        run(steps)
+        for _c in range(calls):
+            run(steps)
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        times.append(dt)
-    return times
+        times.append(over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX) / calls)
+    return times, calls
+
+
+def block_note(calls, steps):
+    return {"calls_per_block": calls, "updates_per_block": calls * steps,
+            "block_ms_is": "milliseconds per %d updates: a block is %d back-to-back call(s) of exactly %d updates between barrier + "
+                           "synchronize, its time divided by the calls; the timed call shape was warmed untimed" % (steps, calls, steps)}
 
 
 def profile_pass(eng, go, n):
@@ -291,7 +317,7 @@ def cpu_baseline_sac(wl, seconds=12.0):
             orc.step(osac.prepare_batch(spec, {k: tr[k][idx[20 + n]] for k in ("obs", "act", "rew", "next_obs", "done")}, None), eps[20 + n])
             n += 1
         dt = time.perf_counter() - t0
-        return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+        return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
                 "sample": "%d oracle SAC-MLP updates at batch %d (sampling + PyTorch-CPU fp32 step), %.1f s" % (n, B, dt)}
     st = synthetic.load_obs_stats(wl["kind"])
     C = st["mean"].shape[-1]
@@ -303,7 +329,8 @@ def cpu_baseline_sac(wl, seconds=12.0):
     n_tr = 1024 if wl["kind"] == "depth" else 512
     tr = synthetic.make_transitions(n_tr, wl["kind"], A, 0, st)
     idx, eps = synthetic.make_noise(400, B, A, n_tr, 1)
-    cores = min(os.cpu_count() or 1, 16)   # the small convs stop scaling (and oversubscribe) beyond this
+    cores = min(os.cpu_count() or 1, 16)   # threads USED: the small convs stop scaling (and oversubscribe) beyond this;
+    # `host_cores` beside it = what the box has
     torch.set_num_threads(cores)
     stats = {"mean": st["mean"], "var": st["var"], "ret_var": st["ret_var"]} if wl["normalize"] else None
 
@@ -317,7 +344,7 @@ def cpu_baseline_sac(wl, seconds=12.0):
         one(3 + n)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d oracle SAC updates at batch %d (sampling + float64 normalisation + PyTorch-CPU fp32 step), %.1f s"
                       % (n, B, dt)}
 
@@ -346,7 +373,7 @@ def cpu_baseline_bdq(seconds=8.0):
         one()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d oracle BDQ updates at batch 64 (PyTorch-CPU fp32; minibatch handed over, no sum-tree walk), %.1f s" % (n, dt)}
 
 
@@ -365,7 +392,7 @@ def cpu_baseline_ae(seconds=8.0):
         orc.step(x)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "train-steps/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "train-steps/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d oracle auto-encoder training steps at batch 128 (PyTorch-CPU fp32), %.1f s" % (n, dt)}
 
 
@@ -532,7 +559,7 @@ def run_sac(args, wl_name, world, rank, device):
         if world > 1:
             dist.barrier()
 
-    times = timed_blocks(run, barrier, args.steps, args.warmup, args.repeats, world, device)
+    times, calls = timed_blocks(run, barrier, args.steps, args.warmup, args.repeats, world, device)
     dt = float(np.median(times))
     metrics = eng.metrics()
     out = {"metric": wl["metric"] if not strong else "SAC grad-steps/sec (64x64 depth, global batch %d)" % args.global_batch,
@@ -547,7 +574,7 @@ def run_sac(args, wl_name, world, rank, device):
                                                                         % (args.global_batch, world) if strong else ""),
                      "global_batch": wl["batch"] * world, "parallelism": dp_kind,
                      "global_steps_per_s": round(args.steps / dt, 2)}
-    out["repeats"] = {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"}
+    out["repeats"] = {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block", **block_note(calls, args.steps)}
     if args.same_device and world > 1:
         out["config"]["validation_only"] = "all %d ranks share cuda:0 (--same-device): not a scaling measurement" % world
     out["losses"] = {k: round(float(v), 6) for k, v in metrics.items()}
@@ -646,7 +673,7 @@ def run_bdq(args, device):
     def barrier():
         eng.synchronize()
         torch.cuda.synchronize(device)
-    times = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
+    times, calls = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
     dt = float(np.median(times))
     out = {"metric": "BDQ grad-steps/sec (101-d observations, 5 x 33 bins, batch 64, prioritised replay)",
            "value": round(args.steps / dt, 2), "unit": "grad-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -655,7 +682,7 @@ def run_bdq(args, device):
            "config": {"workload": "configs[2]: gripper_grasp.yaml --algo BDQ (layers [[64,64],[32],[32]], num_actions_pad 33, batch "
                                   "64, lr 1e-4, prioritized_replay) on 101-d auto-encoder observations, %d-transition ring + "
                                   "priorities in HBM, device RNG" % replay},
-           "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"},
+           "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block", **block_note(calls, args.steps)},
            "losses": {k: round(float(v), 6) for k, v in eng.metrics().items()}}
     if not args.no_profile:
         prof = profile_pass(eng, go, 50)
@@ -687,7 +714,7 @@ def run_ae(args, device):
         eng.synchronize()
         torch.cuda.synchronize(device)
     eng.be.stream.wait_stream(torch.cuda.current_stream(device))
-    times = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
+    times, calls = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
     dt = float(np.median(times))
     out = {"metric": "auto-encoder train-steps/sec (64x64x1 depth, batch 128)", "value": round(args.steps / dt, 2),
            "unit": "train-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -695,7 +722,7 @@ def run_ae(args, device):
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "SURVEY 8f-3: SimpleAutoEncoder fit step (encoders.py:40-50,70-136; config/encoder.yaml: batch 128, "
                                   "lr 2e-4): encoder + decoder forward, MSE, backward, Keras-Adam; minibatches resident in HBM"},
-           "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block"},
+           "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block", **block_note(calls, args.steps)},
            "losses": {"reconstruction_mse": round(float(eng.metrics()["policy_loss"]), 6)}}
     if not args.no_profile:
         prof = profile_pass(eng, go, 16)

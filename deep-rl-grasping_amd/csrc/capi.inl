@@ -691,18 +691,24 @@ int grl_act(grl_handle h, const float* obs, int n, int flags, const float* eps, 
   const bool poll = h->act_done_wgs && !h->prof;
   if (q && !poll) HIPCHK(hipMemcpyAsync(h->pin_out, h->q_aout, n_out * 4, hipMemcpyDeviceToHost, h->stream));
   bool seen = false;
+  // the last launch counts its workgroups into coherent host memory once their actions are out (act_mfma.h) -- on EVERY call,
+  // polled or not (a call under grl_profile_enable synchronises the stream instead): the expectation advances with it
+  if (h->act_done_wgs) h->act_done_seen += h->act_done_wgs;
   if (poll) {
-    // the last launch counts its workgroups into coherent host memory once their actions are out (act_mfma.h): poll that
-    // instead of the stream's completion signal; bounded -- after 2 ms (or on any doubt) the stream is synchronised as before
-    h->act_done_seen += h->act_done_wgs;
+    // poll the counter instead of the stream's completion signal; bounded -- after 2 ms (or on any doubt) the stream is
+    // synchronised as before.  Wrap-safe and tolerant of a counter that is ahead: (int)(cur - want) >= 0
     const unsigned want = h->act_done_seen;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; ++spin) {
-      if (__atomic_load_n(h->act_done_host, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+      if ((int)(__atomic_load_n(h->act_done_host, __ATOMIC_ACQUIRE) - want) >= 0) { seen = true; break; }
       if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
   }
-  if (!seen) HIPCHK(hipStreamSynchronize(h->stream));
+  if (!seen) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // the stream is idle: whatever the counter says now is what the next call starts from
+    if (h->act_done_wgs) h->act_done_seen = __atomic_load_n(h->act_done_host, __ATOMIC_ACQUIRE);
+  }
   HIPCHK(hipGetLastError());
   memcpy(out, q ? (poll ? h->q_act_host : h->pin_out) : h->a_out, n_out * 4);
   return GRL_OK;

@@ -352,7 +352,12 @@ int grl_ctx::plan_q() {
     qf.mfma = want_mfma && fits64;
     for (auto& h : hf) qf.mfma = qf.mfma && qm_head_ok(h, true, true);
     if (want_mfma && !qf.mfma) return fail(GRL_ERR_INVALID, "internal: the Q chains were planned for the matrix-core stages and do not fit them");
-    q_chain = q_chain_available(qf.mfma != 0, fits64) && tune_int("q_chain", 1) != 0 && tune_int("fused_qapply", 1) != 0 && qc_shape_ok(nb, D, c.obs_dim);
+    // the chained backward leaves its slabs and row sums to the fused apply launch (below): planned only where that launch is
+    // certain to exist -- its LDS (~71 KB) fits the device and no trainable variable outgrows its gradient buffer -- so that a
+    // device / shape that offers less keeps the three-launch form instead of failing at the end of the plan
+    bool qapply_feasible = tune_int("fused_qapply", 1) != 0 && device_lds_bytes() >= (int)(GRL_QAPPLY_MAX * 4 + 1024 * 4 + 3 * 256 * 4);
+    for (auto& v : vars) if (v.trainable && v.numel > GRL_QAPPLY_MAX) qapply_feasible = false;
+    q_chain = q_chain_available(qf.mfma != 0, fits64) && tune_int("q_chain", 1) != 0 && qapply_feasible && qc_shape_ok(nb, D, c.obs_dim);
     if (q_chain) {      // nothing reads the trunk's pre-activation gradients from memory any more: its chain keeps them in LDS;
       // the towers' are read back by the weight-gradient workgroups of the trunk launch when there is one (GRL_TUNE q_chain_late=0:
       // every tower chain forms its slabs itself, at its end)

@@ -255,7 +255,10 @@ class _QModel:
 
     def _learn_loop(self, total_timesteps, callback, log_interval, rt, dp, W, lead, eng, vn, obs, obs_, beta_schedule,
                     episode_rewards, episode_successes, start):
-        while self.num_timesteps < total_timesteps:
+        # stable-baselines: `for _ in range(total_timesteps)` -- a continued run (reset_num_timesteps=False) takes total_timesteps
+        # MORE steps from where the counter stands; the schedules keep reading the counter itself
+        end = self.num_timesteps + total_timesteps
+        while self.num_timesteps < end:
             eps = self.exploration.value(self.num_timesteps)
             if self._rng.random() < eps:
                 bins = self._rng.integers(0, self.bins, self.D)

@@ -48,6 +48,26 @@ _POLICY_NAMES = {"MlpPolicy": pol.SacMlpPolicy, "CnnPolicy": pol.SacCnnPolicy, "
                  "LnCnnPolicy": pol.SacLnCnnPolicy}
 
 
+def resolve_device_norm(setting, user_callback, rt, dp):
+    """Where the VecNormalize statistics live during ``learn``: True = on the device (``grl_observe`` / ``grl_norm_update``).
+    'auto' looks at the callback the USER handed over -- before ``learn`` replaces it by a bare one on ranks > 0 -- and under
+    data parallelism the decision is COLLECTIVE (``rt.all``): with the statistics on the device every env step runs an
+    in-kernel merge that waits for all peers, with them on the host an all_gather on the control group; replicas that chose
+    differently (a script that hands only rank 0 a callback) would wait for each other in two different exchanges."""
+    if setting == "auto":
+        setting = not (user_callback is not None and may_read_observations(as_callback(user_callback)))
+    setting = bool(setting)
+    if rt is not None:
+        if setting and not hasattr(dp, "check"):
+            # the device-side merge of the statistics rides on the in-graph exchange's channel; with the collective
+            # fallback (RCCL / gloo) the handle is not connected and every replica would keep its own observation
+            # statistics: take the host path, whose moments are gathered over the ranks
+            logger.warn("device_norm needs the in-graph exchange; this job fell back to a collective library -> host statistics")
+            setting = False
+        setting = rt.all(setting)
+    return setting
+
+
 class SAC:
     # tests substitute the g++ emulation build here; the product default needs a HIP device
     _engine_factory = staticmethod(lambda cfg, device: SacEngine(cfg, device=device))
@@ -276,18 +296,10 @@ class SAC:
         rt, dp = self._dp_rt, self._dp
         W = 1 if rt is None else rt.world
         lead = rt is None or rt.rank == 0
+        device_norm = resolve_device_norm(self.device_norm, callback, rt, dp)
         callback = as_callback(callback if lead else None)      # data parallel: evaluation / checkpoints / logging on rank 0 only
         callback.init_callback(self)
         eng, vn, N = self.engine, self._vec_normalize_env, self.n_envs
-        device_norm = self.device_norm
-        if device_norm == "auto":
-            device_norm = not may_read_observations(callback)
-        if rt is not None and device_norm and not hasattr(dp, "check"):
-            # the device-side merge of the statistics rides on the in-graph exchange's channel; with the collective
-            # fallback (RCCL / gloo) the handle is not connected and every replica would keep its own observation
-            # statistics: take the host path, whose moments are gathered over the ranks below
-            logger.warn("device_norm needs the in-graph exchange; this job fell back to a collective library -> host statistics")
-            device_norm = False
         if rt is not None and vn is not None:       # running statistics merged over the ranks (ret_rms always on the host)
             from ..parallel import share_running_stats
             share_running_stats(vn, rt.ctrl)
@@ -335,7 +347,10 @@ class SAC:
         callback.on_training_start(locals(), globals())
         callback.on_rollout_start()
         step = 0
-        while self.num_timesteps < total_timesteps:
+        # stable-baselines: `for step in range(total_timesteps)` -- a continued run (reset_num_timesteps=False) takes
+        # total_timesteps MORE environment steps from where the counter stands
+        end = self.num_timesteps + total_timesteps
+        while self.num_timesteps < end:
             raw_obs = vn is not None and vn.hands_out_raw_observations     # (a callback may toggle vn.training)
             if self.num_timesteps < self.learning_starts or self._rng.random() < self.random_exploration:
                 unscaled_action = np.stack([np.asarray(self.action_space.sample(), np.float32) for _ in range(N)])

@@ -841,6 +841,16 @@ def expand_training_env(env, n=None, rank=0, world=1):
     if not isinstance(inner, DummyVecEnv):
         return env
     if inner.fanned_out or (n > 1 and len(getattr(inner, "_env_fns", ())) == 1):
+        if inner.fanned_out and inner.num_envs != n:
+            raise ValueError("this training env already fans out to %d worker environments; GRL_NUM_ENVS now asks for %d per "
+                             "process (another world size?): build a fresh env for the new model" % (inner.num_envs, n))
+        # wrappers built around the single env keep per-env state in its 1-env shape: VecNormalize is re-sized here, any other
+        # wrapper must say how (a `resize_envs(n)` method) -- a silent fan-out would break it on the first step
+        stuck = [type(w).__name__ for w in chain
+                 if not isinstance(w, (VecNormalize, VecBatchedEncoder)) and not hasattr(w, "resize_envs")]
+        if stuck and inner.num_envs != n:
+            raise ValueError("GRL_NUM_ENVS=%d cannot fan out beneath %s: the wrapper holds per-env state sized for one environment "
+                             "and has no resize_envs(n) hook (wrap after the fan-out, or unset GRL_NUM_ENVS)" % (n, ", ".join(stuck)))
         seed = os.environ.get("GRL_ENV_SEED")
         inner.fan_out(n, envs_per_worker=int(os.environ.get("GRL_ENVS_PER_WORKER", "1")),
                       start_method=os.environ.get("GRL_ENV_START_METHOD") or None, first_rank=rank * n,
@@ -850,4 +860,7 @@ def expand_training_env(env, n=None, rank=0, world=1):
             w.num_envs = inner.num_envs
             if isinstance(w, VecNormalize):
                 w.ret = np.zeros(w.num_envs)
+                w.old_obs, w.old_rews = np.array([]), np.array([])      # (the 1-env observation of a reset before the fan-out)
+            elif hasattr(w, "resize_envs"):
+                w.resize_envs(w.num_envs)
     return env

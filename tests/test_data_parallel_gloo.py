@@ -215,6 +215,51 @@ def test_model_learn_as_one_replica_of_two(hostemu_lib, tmp_path):
     assert float(r0["obs_count"]) == pytest.approx(1e-4 + 2 * 2 * 11)   # reset + 10 steps, both ranks' batches merged
 
 
+def _device_norm_vote_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from grasp_rl.parallel import DataParallelRuntime
+    from grasp_rl.sb.callbacks import CheckpointCallback
+    from grasp_rl.sb.sac import resolve_device_norm
+    rt = DataParallelRuntime()
+
+    class InGraph:                      # what SAC sees of a connected in-graph exchange
+        def check(self):
+            pass
+
+    def fn_callback(_locals, _globals):     # a plain function: wrapped in ConvertCallback, may read locals['new_obs']
+        return True
+    got = {
+        # the user's callback is judged BEFORE the rank filter: the same function callback on both ranks -> host statistics
+        "fn_both": resolve_device_norm("auto", fn_callback, rt, InGraph()),
+        # a script that hands only rank 0 a callback: rank 1 alone would choose the device -- the vote says host on both
+        "fn_rank0_only": resolve_device_norm("auto", fn_callback if rank == 0 else None, rt, InGraph()),
+        # nothing reads the observations anywhere: the device on both
+        "none": resolve_device_norm("auto", None, rt, InGraph()),
+        "known": resolve_device_norm("auto", CheckpointCallback(10, "/tmp/x") if rank == 0 else None, rt, InGraph()),
+        # explicit settings that disagree across ranks still end the same on both
+        "explicit_mixed": resolve_device_norm(rank == 0, None, rt, InGraph()),
+        # the collective fallback has no channel for the device-side merge
+        "fallback": resolve_device_norm(True, None, rt, object()),
+    }
+    np.savez(os.path.join(out_dir, "vote%d.npz" % rank), **{k: np.array(v) for k, v in got.items()})
+    dist.destroy_process_group()
+
+
+def test_device_norm_auto_is_decided_collectively(tmp_path):
+    """`device_norm='auto'` was resolved per rank after the rank filter on the callback, so rank 0 with a
+    function callback took the host-statistics path (an all_gather per env step) while ranks > 0 took the device path (an
+    in-kernel merge that waits for every peer): two different exchanges waiting for each other."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_device_norm_vote_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "vote0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "vote1.npz"))
+    want = {"fn_both": False, "fn_rank0_only": False, "none": True, "known": True, "explicit_mixed": False, "fallback": False}
+    for k, v in want.items():
+        assert bool(r0[k]) == bool(r1[k]) == v, (k, bool(r0[k]), bool(r1[k]))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # set-up of the in-graph exchange is collective and fail-safe: whatever fails on whichever rank, every rank executes the
 # same collectives, releases what it had set up and takes the fallback together (ADVICE r4 / VERDICT r4 "Next 1b")

@@ -192,3 +192,38 @@ def _chan(mean, var, count, batch):
     r.mean, r.var, r.count = mean.copy(), var.copy(), count
     r.update(batch)
     return r.mean, r.var, r.count
+
+
+def test_act_latency_survives_a_profiled_call_gpu():
+    """the act path's last launch counts its workgroups into host memory on EVERY call, but `grl_act` advanced its
+    expectation only on polled calls -- one call under grl_profile_enable(1) left the counter permanently ahead, and every
+    later call spun its whole 2 ms bound before falling back to the stream synchronisation (same actions, +2 ms each)."""
+    import time
+    import numpy as np
+    from grasp_rl import _capi
+    from grasp_rl.engine import SacEngine
+    from grasp_rl.init import init_parameters
+    n = 8
+    cfg = _capi.make_config("augmented", obs_channels=2, n_direct=1, act_dim=5, layers=(64, 64), batch_size=32, replay_capacity=64,
+                            normalize=False, act_batch=n)
+    eng = SacEngine(cfg, device="cuda:0")
+    try:
+        eng.set_parameters(init_parameters(eng.table, seed=1))
+        obs = np.random.default_rng(0).uniform(0.1, 1.0, (n, 64, 64, 2)).astype(np.float32)
+
+        def per_call(k=200):
+            eng.act(obs)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                a = eng.act(obs)
+            return (time.perf_counter() - t0) / k, a
+        before, a0 = per_call()
+        eng.profile(True)
+        for _ in range(3):
+            a1 = eng.act(obs)
+        eng.profile(False)
+        after, a2 = per_call()
+        assert np.array_equal(a0, a1) and np.array_equal(a0, a2)
+        assert after < 1e-3 and after < 3 * before + 1e-4, (before, after)
+    finally:
+        eng.close()

@@ -244,6 +244,26 @@ def test_bdq_reference_sequence(tmp_path, emulated_q_engine):
     assert a.shape == (3,) and set(np.round((a + 1) * 2, 5)) <= {0.0, 1.0, 2.0, 3.0, 4.0}     # bin centres
 
 
+def test_continued_training_runs_total_timesteps_more_steps(emulated_engine, emulated_q_engine):
+    """stable-baselines loops `for _ in range(total_timesteps)`: `learn(n, reset_num_timesteps=False)` on a trained model
+    takes n MORE environment steps (`while num_timesteps < total_timesteps` ran n - num_timesteps, i.e. none)."""
+    env = DummyVecEnv([lambda: FakeGraspEnv(seed=0, vector_dim=20, discrete_actions=12)])
+    q = sb.DQN(DQNMlpPolicy, env, batch_size=8, learning_starts=10, target_network_update_freq=10, buffer_size=64)
+    c = CountingCallback()
+    q.learn(total_timesteps=24, callback=c)
+    assert q.num_timesteps == 24 and c.steps == 24
+    q.learn(total_timesteps=24, callback=c, reset_num_timesteps=False)
+    assert q.num_timesteps == 48 and c.steps == 48
+    q.learn(total_timesteps=8, callback=c)                       # default: the counter starts over
+    assert q.num_timesteps == 8 and c.steps == 56
+    env = DummyVecEnv([lambda: FakeGraspEnv(seed=0, vector_dim=20)])
+    m = sb.SAC(sacMlp, env, batch_size=4, buffer_size=64, learning_starts=4, policy_kwargs={"layers": [16, 16]})
+    c = CountingCallback()
+    m.learn(total_timesteps=12, callback=c)
+    m.learn(total_timesteps=12, callback=c, reset_num_timesteps=False)
+    assert m.num_timesteps == 24 and c.steps == 24
+
+
 def test_vecnormalize_flags_are_honoured_separately(emulated_engine, emulated_q_engine):
     """VecNormalize(norm_obs=, norm_reward=) each reach the device gather on their own (stable-baselines honours
     them separately at sample time): the engine's `normalize` mode is 1 both / 2 observations / 3 rewards / 0."""
