@@ -14,6 +14,7 @@ reference's Keras code accepts; `model.npz` (keys = Keras weight names) is writt
 import csv
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -80,7 +81,38 @@ class AeEngine(SacEngine):
         return out.reshape(n, 64, 64, 1)
 
 
+ENV_WORKER_VAR = "GRL_ENV_WORKER"      # set by grasp_rl.sb.vec_env while a fanned-out worker builds its environment
+_LIVE = weakref.WeakSet()              # encoders of THIS process (the parent looks for the template env's here)
+_DEFERRED = []                         # (config, model_dir) of every DeferredEncoder built in THIS (worker) process
+
+
+def defer_in_this_process():
+    """True inside an env worker of ``DummyVecEnv.fan_out`` (GRL_NUM_ENVS) unless GRL_BATCHED_ENCODER=0."""
+    return os.environ.get(ENV_WORKER_VAR) == "1" and os.environ.get("GRL_BATCHED_ENCODER", "1") != "0"
+
+
+def deferred_records():
+    return [dict(r) for r in _DEFERRED]
+
+
+def find_live_encoder(model_dir):
+    """A ``SimpleAutoEncoder`` of this process holding the weights of `model_dir` (the template env's, built by the script
+    before the model existed), or None."""
+    want = os.path.realpath(os.path.expanduser(model_dir)) if model_dir else None
+    for e in list(_LIVE):
+        if want is not None and getattr(e, "model_dir", None) == want:
+            return e
+    return None
+
+
 class SimpleAutoEncoder:
+    def __new__(cls, config=None, *args, **kwargs):
+        # Inside a fanned-out env worker the sensor's `encoders.SimpleAutoEncoder(config)` (sensor.py:190-192) yields the
+        # deferred form: no HIP context and no batch-1 launch per environment -- the parent encodes all of them at once
+        if cls is SimpleAutoEncoder and defer_in_this_process():
+            return DeferredEncoder(config)
+        return super().__new__(cls)
+
     def __init__(self, config, backend=None, lib_path=None, device="cuda:0", seed=0):
         net = config.get("network", [])
         want = [(32, 7, 2), (32, 5, 2), (32, 3, 2)]
@@ -88,11 +120,25 @@ class SimpleAutoEncoder:
         if got != want or config.get("encoding_dim", 100) != 100 or config.get("alpha", 0.1) != 0.1:
             raise NotImplementedError("the HIP engine implements the reference's shipped network (config/encoder.yaml)")
         self.config = config
-        self._mk = lambda bs: AeEngine(bs, float(config.get("learning_rate", 2e-4)), backend=backend, lib_path=lib_path,
-                                       device=device)
+        self.act_batch = 16                # observations one grl_encode call takes (`ensure_act_batch`)
+        self._mk = lambda bs: AeEngine(bs, float(config.get("learning_rate", 2e-4)), act_batch=self.act_batch, backend=backend,
+                                       lib_path=lib_path, device=device)
         self.engine = None
         self._params = glorot_uniform_params(seed)
         self._bs = None
+        self.model_dir = None              # where `load_weights` read from
+        _LIVE.add(self)
+
+    def ensure_act_batch(self, n):
+        """At least n images per `encode` call (vectorised envs: all environments + their terminal observations at once)."""
+        if n > self.act_batch:
+            self.act_batch = int(n)
+            if self.engine is not None:
+                bs = self._bs
+                self._params = self.engine.get_parameters()
+                self.engine.close()
+                self.engine, self._bs = None, None
+                self._engine(bs)
 
     # ------------------------------------------------------------------ engine / weights
     def _engine(self, batch_size):
@@ -109,6 +155,7 @@ class SimpleAutoEncoder:
         return self.engine.get_parameters() if self.engine is not None else dict(self._params)
 
     def set_weights(self, params):
+        self.model_dir = None
         self._params = {k: np.asarray(params[k], np.float32) for k in PARAM_NAMES}
         if self.engine is not None:
             self.engine.set_parameters(self._params)
@@ -128,6 +175,7 @@ class SimpleAutoEncoder:
                 self.set_weights({k: f[k] for k in PARAM_NAMES})
         else:
             raise FileNotFoundError("neither model.h5 nor model.npz in %s" % model_dir)
+        self.model_dir = os.path.realpath(model_dir)
 
     def save_weights(self, model_dir):
         """``model.h5`` in the layout Keras' ``save_weights`` gives this model (layers input_1 / encoder /
@@ -205,8 +253,22 @@ class DeferredEncoder:
     batch-1 launches per step.  This object keeps the sensor code unchanged -- ``encode`` returns the (filtered) depth
     image itself, flattened to 4096 floats, and ``encoding_shape`` says so -- and
     ``grasp_rl.sb.vec_env.VecBatchedEncoder`` in the parent process encodes the images of ALL environments in ONE
-    ``grl_encode`` call per step.  No GPU, no libgrl in the worker."""
+    ``grl_encode`` call per step.  No GPU, no libgrl in the worker.
+
+    Under ``GRL_NUM_ENVS`` nobody writes this by hand: inside a fanned-out worker ``SimpleAutoEncoder(config)`` -- what the
+    reference's sensor constructs (sensor.py:190-192) -- IS this object, ``load_weights(model_dir)`` records where the weights
+    are, and ``DummyVecEnv.fan_out`` asks the workers for those records and puts the batched encoder in front of them."""
     encoding_shape = (64 * 64,)
+
+    def __init__(self, config=None):
+        self.config = dict(config) if config else None
+        self.model_dir = None
+        self._record = {"config": self.config, "model_dir": None}
+        _DEFERRED.append(self._record)
+
+    def load_weights(self, model_dir):
+        self.model_dir = os.path.realpath(os.path.expanduser(model_dir))
+        self._record["model_dir"] = self.model_dir
 
     def encode(self, imgs):
         return np.ascontiguousarray(imgs, np.float32).reshape(-1, 64 * 64)

@@ -46,11 +46,20 @@ class _RankedEnvFn:
 
     def __call__(self):
         from . import monitor
+        from ..autoencoder import ENV_WORKER_VAR
         monitor.ENV_RANK = self.rank
+        # ... and with the marker that turns the sensor's `encoders.SimpleAutoEncoder(config)` (sensor.py:190-192) into the
+        # deferred form while THIS factory runs (grasp_rl.autoencoder): the parent encodes the images of all environments at once
+        before = os.environ.get(ENV_WORKER_VAR)
+        os.environ[ENV_WORKER_VAR] = "1"
         try:
             return self.fn()
         finally:
             monitor.ENV_RANK = 0
+            if before is None:
+                os.environ.pop(ENV_WORKER_VAR, None)
+            else:
+                os.environ[ENV_WORKER_VAR] = before
 
 
 def _drop_empty_monitor_file(env):
@@ -129,11 +138,46 @@ class DummyVecEnv(VecEnv):
                 _drop_empty_monitor_file(env)    # the template's header-only log_file.monitor.csv is nobody's log
         fns = [_RankedEnvFn(self._env_fns[0], first_rank + k) for k in range(n)]
         self._fan = SubprocVecEnv(fns, start_method=start_method, envs_per_worker=envs_per_worker)
+        self._fan = self._batched_encoder(self._fan, n)
         self.num_envs = n
         self._alloc()
         if seed is not None:
             self._fan.seed(int(seed) + first_rank)
         return self
+
+    def _batched_encoder(self, sub, n):
+        """Auto-encoder observations (config/simplified_object_picking.yaml as shipped: `depth_observation: False`,
+        sensor.py:176-222): every worker built its environment with the deferred form of the encoder (``_RankedEnvFn``,
+        ``grasp_rl.autoencoder.SimpleAutoEncoder.__new__``) and hands out [4096 pixels | other sensors]; ONE
+        ``SimpleAutoEncoder`` in this process -- the template environment's own when it is still around, else one built from
+        what the workers recorded -- encodes the images of all n environments in one call per step (``VecBatchedEncoder``).
+        Returns `sub` itself when no worker deferred an encoder."""
+        recs = sub.deferred_encoders()
+        if not any(recs):
+            return sub
+        try:
+            from .. import autoencoder as ae
+            flat = [r for per_env in recs for r in per_env]
+            dirs = {r.get("model_dir") for r in flat}
+            if any(len(per_env) != 1 for per_env in recs) or len(dirs) != 1 or None in dirs:
+                raise ValueError("the worker environments built %s deferred encoders over %s weight directories: the batched encoder "
+                                 "needs exactly one per environment, all of one model_dir (set GRL_BATCHED_ENCODER=0 to keep one "
+                                 "encoder per worker)" % ([len(x) for x in recs], sorted(map(str, dirs))))
+            model_dir = flat[0]["model_dir"]
+            enc = ae.find_live_encoder(model_dir)
+            if enc is None:
+                enc = ae.SimpleAutoEncoder(flat[0]["config"])
+                enc.load_weights(model_dir)
+            enc.ensure_act_batch(2 * n)          # every environment's observation + every terminal observation in one call
+            wrapped = VecBatchedEncoder(sub, enc)
+            if tuple(wrapped.observation_space.shape) != tuple(self.observation_space.shape):
+                raise ValueError("the workers' observations %s encode to %s, the template environment announced %s"
+                                 % (tuple(sub.observation_space.shape), tuple(wrapped.observation_space.shape),
+                                    tuple(self.observation_space.shape)))
+            return wrapped
+        except Exception:
+            sub.close()
+            raise
 
     def step_async(self, actions):
         if self._fan is not None:
@@ -297,6 +341,9 @@ def _subproc_worker(remote, parent_remote, env_fns_pickled, preimport=()):
                 remote.send(None)
             elif cmd == "env_method":
                 remote.send([getattr(envs[k], data[0])(*data[1], **data[2]) for k in data[3]])
+            elif cmd == "deferred_encoders":     # what the DeferredEncoders built with these environments recorded
+                from ..autoencoder import deferred_records
+                remote.send(deferred_records())
             elif cmd == "render":
                 remote.send(envs[0].render(*data[0], **data[1]) if hasattr(envs[0], "render") else None)
             elif cmd == "close":
@@ -508,6 +555,18 @@ class SubprocVecEnv(VecEnv):
                     out[p] = a
         return out
 
+    def deferred_encoders(self):
+        """Per environment: the records of the ``grasp_rl.autoencoder.DeferredEncoder``s its worker process built (a worker that
+        owns several environments reports its list split evenly over them)."""
+        out = []
+        for remote, g in zip(self.remotes, self._groups):
+            remote.send(("deferred_encoders", None))
+            recs = remote.recv()
+            k = len(recs) // len(g) if len(recs) % len(g) == 0 else None
+            for j in range(len(g)):
+                out.append(recs[j * k:(j + 1) * k] if k is not None else list(recs))
+        return out
+
     def get_attr(self, name, indices=None):
         return self._gathered("get_attr", (name,), indices)
 
@@ -583,8 +642,10 @@ class VecBatchedEncoder(VecEnvWrapper):
         rows = [obs] + [np.asarray(infos[i]["terminal_observation"], np.float32).reshape(1, -1) for i in term]
         z = self._encode(np.concatenate([np.asarray(r, np.float32).reshape(-1, self.n_pixels + self.n_extra) for r in rows]))
         n = np.asarray(obs).shape[0]
+        infos = list(infos)
         for k, i in enumerate(term):
             infos[i] = dict(infos[i], terminal_observation=z[n + k])
+        self.buf_infos = infos          # (what `task.buf_infos[0]` of utils.py:76 reads: the ENCODED terminal observations)
         return z[:n], rews, dones, infos
 
 

@@ -69,3 +69,32 @@ class FakeGraspEnv:
 
     def close(self):
         pass
+
+
+class EncodedFakeEnv(FakeGraspEnv):
+    """Observation = [auto-encoder features of a depth image | gripper width] -- the reference env with
+    `depth_observation: False` (robot.py:83-89,185-190): the env's sensor builds `encoders.SimpleAutoEncoder(config)`,
+    loads `<model_dir>/model.h5` and calls `.encode(img[None, :, :, None]).squeeze()` per step (sensor.py:190-192,220-222)."""
+    AE_CONFIG = {"encoding_dim": 100, "learning_rate": 2e-4,
+                 "network": [{"filters": 32, "kernel_size": 7, "strides": 2}, {"filters": 32, "kernel_size": 5, "strides": 2},
+                             {"filters": 32, "kernel_size": 3, "strides": 2}]}
+
+    def __init__(self, model_dir, seed=0, episode_len=5, encoder_factory=None):
+        super().__init__(seed=seed, vector_dim=101, episode_len=episode_len)
+        from grasp_rl import autoencoder
+        self._encoder = (encoder_factory or autoencoder.SimpleAutoEncoder)(dict(self.AE_CONFIG))
+        self._encoder.load_weights(model_dir)
+        dim = int(np.prod(self._encoder.encoding_shape)) + 1
+        self.observation_space = Box(-np.inf, np.inf, shape=(dim,), dtype=np.float32)
+        self.last_image = None
+
+    def is_simplified(self):
+        return True
+
+    def _obs(self):
+        yy, xx = np.mgrid[0:64, 0:64]
+        cx, cy = self._rng.uniform(16, 48, 2)
+        img = (0.3 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / 60.0)).astype(np.float32)
+        self.last_image = img
+        z = self._encoder.encode(img.reshape(1, 64, 64, 1)).squeeze()
+        return np.append(z, 0.05 * (self.episode_step % 3)).astype(np.float32)

@@ -227,3 +227,47 @@ def test_act_latency_survives_a_profiled_call_gpu():
         assert after < 1e-3 and after < 3 * before + 1e-4, (before, after)
     finally:
         eng.close()
+
+
+def test_auto_encoder_features_are_batched_under_grl_num_envs_gpu(tmp_path, monkeypatch):
+    """VERDICT r5 missing 4 on the MI355X: an env whose sensor builds `SimpleAutoEncoder(config)` + `load_weights(dir)` and
+    encodes batch-1 per step (sensor.py:190-192,220-222), handed to SAC as `DummyVecEnv([one factory])` with GRL_NUM_ENVS=4:
+    the workers hold the deferred form (no HIP context there), the parent runs ONE `grl_encode` per vectorised step, and the
+    features equal the per-environment batch-1 path."""
+    import functools
+    import os
+    import numpy as np
+    import stable_baselines as sb
+    from fake_env import EncodedFakeEnv
+    from grasp_rl import autoencoder as gae
+    from grasp_rl.sb.vec_env import SubprocVecEnv, VecBatchedEncoder
+    from stable_baselines.common.vec_env import DummyVecEnv
+    model_dir = str(tmp_path / "enc")
+    src = gae.SimpleAutoEncoder(dict(EncodedFakeEnv.AE_CONFIG), seed=3)
+    src.save_weights(model_dir)
+    monkeypatch.setenv("GRL_NUM_ENVS", "4")
+    env = DummyVecEnv([functools.partial(EncodedFakeEnv, model_dir, None)])      # the script's shape: ONE factory
+    encode_calls, raws, outs = [], [], []
+    real_encode = gae.SimpleAutoEncoder.encode
+    monkeypatch.setattr(gae.SimpleAutoEncoder, "encode",
+                        lambda self, imgs: (encode_calls.append(np.asarray(imgs).reshape(-1, 4096).shape[0]), real_encode(self, imgs))[1])
+    real_wait, real_bwait = SubprocVecEnv.step_wait, VecBatchedEncoder.step_wait
+    monkeypatch.setattr(SubprocVecEnv, "step_wait", lambda self: (lambda o: (raws.append(np.array(o[0], copy=True)), o)[1])(real_wait(self)))
+    monkeypatch.setattr(VecBatchedEncoder, "step_wait", lambda self: (lambda o: (outs.append(np.array(o[0], copy=True)), o)[1])(real_bwait(self)))
+    model = sb.SAC(sacMlp, env, policy_kwargs={"layers": [64, 64], "layer_norm": False}, buffer_size=256, batch_size=16,
+                   learning_starts=16)
+    try:
+        assert isinstance(env._fan, VecBatchedEncoder) and env.num_envs == 4 and model.n_envs == 4
+        n0 = len(encode_calls)
+        model.learn(total_timesteps=80)
+        calls = encode_calls[n0:]
+        assert len(calls) == 1 + 20 and calls[0] == 4 and set(calls[1:]) <= {4, 8} and calls.count(8) == 4     # 5-step episodes
+        assert all(r.shape == (4, 4097) for r in raws) and model.n_updates > 0
+        enc = env._fan.encoder
+        assert enc.model_dir == os.path.realpath(model_dir)
+        for raw, obs in list(zip(raws, outs))[:5]:
+            for k in range(4):
+                z1 = real_encode(enc, raw[k, :4096].reshape(1, 64, 64, 1))[0]
+                assert np.allclose(obs[k, :100], z1, atol=1e-6, rtol=1e-6) and obs[k, 100] == raw[k, 4096]
+    finally:
+        env.close()
