@@ -396,6 +396,8 @@ def cpu_baseline_ae(seconds=8.0):
             "sample": "%d oracle auto-encoder training steps at batch 128 (PyTorch-CPU fp32), %.1f s" % (n, dt)}
 
 
+CONFIGS4_GLOBAL_BATCH = 1024  # BASELINE.json configs[4]
+VERIFY_WAIT_MS = 5000         # wait bound while a freshly set-up in-graph exchange is verified and timed (grl_allreduce_set_timeout)
 OVERLAP_WORTH_MS = 0.040      # the overlapped plan costs ~0.05 ms more than two-shot at world 1 (profiles/r04_dp_overhead.txt)
 IN_GRAPH_VARIANTS = {      # --dp -> [(mode, overlap)] tried in this order
     "auto": [("oneshot", False), ("twoshot", False), ("twoshot", True)],
@@ -403,7 +405,7 @@ IN_GRAPH_VARIANTS = {      # --dp -> [(mode, overlap)] tried in this order
     "ingraph-overlap": [("twoshot", True)]}
 
 
-def make_data_parallel(eng, kind, world, rank, device, init):
+def make_data_parallel(eng, kind, world, rank, device, init, inject_ipc_failure=None):
     """The exchange step for N > 1.  The in-graph all-reduces over IPC-mapped buffers (grasp_rl.parallel.DataParallelInGraph:
     one-shot, two-shot, two-shot with the dense bucket overlapped) are set up, each VERIFIED on three updates (no time-out,
     replicas bit-identical across ranks -- a checksum travels) and, with 'auto', TIMED on 48 updates (max over ranks); the
@@ -426,6 +428,8 @@ def make_data_parallel(eng, kind, world, rank, device, init):
             sys.stderr.write("bench[rank %d]: in-graph exchange, %s: %s\n" % (rank, what, exc))
             return False
 
+    chosen = {"oneshot": "ingraph-oneshot", "twoshot": "ingraph-twoshot"}
+    fell_back = ""
     if kind in IN_GRAPH_VARIANTS:
         box = {}
         # this rank's update WITHOUT an exchange (max over ranks): what every variant's time is read against -- the exchange
@@ -448,10 +452,20 @@ def make_data_parallel(eng, kind, world, rank, device, init):
         eng.set_parameters(init)
         eng.reset_optimizer()
         # (DataParallelInGraph votes after each of its set-up phases: it raises on every rank or on none)
+        if inject_ipc_failure == rank:          # validation aid (--inject-ipc-failure): this rank's peer mapping "fails"
+            def broken(handles, _real=eng.allreduce_connect):
+                _real(handles)
+                raise RuntimeError("injected: hipIpcOpenMemHandle fails on rank %d (--inject-ipc-failure)" % rank)
+            eng.allreduce_connect = broken
         ok = agreed(attempt(lambda: box.setdefault("dp", DataParallelInGraph(eng, mode="twoshot")), "set-up"))
+        if inject_ipc_failure == rank:
+            del eng.allreduce_connect
         good, ms, skipped = [], {}, []
         if ok:
             dp = box["dp"]
+            # a channel that cannot work (flags that never become visible across a link) must cost seconds, not the 120 s a late
+            # peer is granted during training: every wait of the verification / timing updates below is bounded by VERIFY_WAIT_MS
+            eng.allreduce_set_timeout(VERIFY_WAIT_MS)
             for mode, overlap in IN_GRAPH_VARIANTS[kind]:
                 name = mode + ("+overlap" if overlap else "")
                 if overlap and kind == "auto" and plain_ms is not None and ms and min(ms.values()) - plain_ms < OVERLAP_WORTH_MS:
@@ -490,6 +504,8 @@ def make_data_parallel(eng, kind, world, rank, device, init):
                 good.append((mode, overlap))
         eng.set_parameters(init)                   # the timed run starts from the common initial state
         eng.reset_optimizer()
+        if ok:
+            eng.allreduce_set_timeout(0)           # back to the training bound (GRL_TUNE dp_timeout_ms, default 120 s)
         if good:
             mode, overlap = min(good, key=lambda v: ms.get(v, 0.0))
             dp.set_mode(mode, overlap)
@@ -501,33 +517,28 @@ def make_data_parallel(eng, kind, world, rank, device, init):
             if skipped:
                 note += "; " + "; ".join(skipped)
             resolved = mode if mode != "auto" else ("oneshot" if world <= 2 else "twoshot")
-            return dp, "dp%d, %s all-reduce over IPC-mapped buffers inside the update graph%s%s" % (
+            verified = "; verified on 3 updates under a %d ms wait bound (no time-out, replicas bit-identical): %s" % (
+                VERIFY_WAIT_MS, ", ".join(m + ("+overlap" if o else "") for m, o in good))
+            return dp, "dp%d, %s all-reduce over IPC-mapped buffers inside the update graph%s%s%s" % (
                 world, {"oneshot": "one-shot", "twoshot": "two-shot"}[resolved],
-                " (dense bucket on a side lane under the conv backward)" if overlap else "", note)
+                " (dense bucket on a side lane under the conv backward)" if overlap else "", note, verified), (
+                "ingraph-overlap" if overlap else chosen[resolved])
         if kind != "auto":
             raise SystemExit("--dp %s: the in-graph exchange could not be set up / verified on every rank" % kind)
         sys.stderr.write("bench[rank %d]: no in-graph variant verified: falling back to RCCL\n" % rank)
+        fell_back = "in-graph exchange %s on some rank -> every rank fell back together; " % ("could not be set up" if not ok else "did not verify")
     dp = DataParallelSac(eng, overlap=(kind == "rccl-overlap"))
-    return dp, "dp%d, RCCL all-reduce, %s" % (world, "two gradient buckets (dense bucket under the conv backward)" if dp.overlap
-                                              else "one gradient bucket")
+    return dp, "dp%d, %s%s all-reduce, %s" % (world, fell_back, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+                                            "two gradient buckets (dense bucket under the conv backward)" if dp.overlap
+                                            else "one gradient bucket"), ("rccl-overlap" if dp.overlap else "rccl")
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def run_sac(args, wl_name, world, rank, device):
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+def build_sac_engine(wl, replay, rank, device):
+    """Engine of one rank for workload `wl`: parameters identical on every rank, this rank's replay shard filled on the device."""
     from grasp_rl import _capi
     from grasp_rl.engine import SacEngine
     from grasp_rl.init import init_parameters
-    from grasp_rl.parallel import DataParallelSac
-    wl = dict(WORKLOADS[wl_name])
-    strong = args.global_batch is not None
-    if strong:
-        if args.global_batch % world:
-            raise SystemExit("--global-batch must be a multiple of the number of GPUs")
-        wl["batch"] = args.global_batch // world
-    replay = args.replay or wl["replay"]
     C = 5 if wl["kind"] == "rgbd" else 2
     if wl["extractor"] == "mlp":
         cfg = _capi.make_config("mlp", obs_dim=wl["obs_dim"], act_dim=wl["act_dim"], layers=wl.get("layers", (64, 64)), batch_size=wl["batch"],
@@ -543,9 +554,57 @@ def run_sac(args, wl_name, world, rank, device):
     else:
         st = fill_replay_on_device(eng, replay, 100 + rank, device, wl["kind"], wl["act_dim"])
         eng.set_obs_stats(st["mean"], st["var"], st["ret_var"])
-    dp, dp_kind = None, "dp%d" % world
+    return eng
+
+
+def device_identities(world, rank, device, same_device):
+    """What proves that an N-rank record ran on N distinct GPUs: every rank's device (name, PCI address, uuid where the build
+    exposes them) and its row of the peer-access matrix (hipDeviceCanAccessPeer towards every other rank's device), gathered
+    on all ranks (a collective) and reported by rank 0."""
+    import torch
+    import torch.distributed as dist
+    p = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "device": str(device), "name": p.name, "host_pid": os.getpid()}
+    for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+        if hasattr(p, k):
+            mine[k] = int(getattr(p, k))
+    if all(k in mine for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        mine["pci"] = "%04x:%02x:%02x.0" % (mine["pci_domain_id"], mine["pci_bus_id"], mine["pci_device_id"])
+    if hasattr(p, "uuid"):
+        mine["uuid"] = str(p.uuid)
+    if same_device:
+        mine["peer_access"] = "all ranks share cuda:0 (--same-device)"
+    else:
+        n_dev = torch.cuda.device_count()
+        mine["peer_access"] = [None if j == device.index else (bool(torch.cuda.can_device_access_peer(device.index, j)) if j < n_dev else None)
+                               for j in range(world)]      # (one rank per GPU of the node: rank j runs on device j)
+    rows = [None] * world
+    dist.all_gather_object(rows, mine)
+    ids = {r.get("uuid") or r.get("pci") or r["device"] for r in rows}
+    return {"ranks": rows, "distinct_devices": len(ids)}
+
+
+def run_sac(args, wl_name, world, rank, device):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from grasp_rl import _capi
+    from grasp_rl.engine import SacEngine
+    from grasp_rl.init import init_parameters
+    from grasp_rl.parallel import DataParallelSac
+    wl = dict(WORKLOADS[wl_name])
+    strong = args.global_batch is not None
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of GPUs")
+        wl["batch"] = args.global_batch // world
+    replay = args.replay or wl["replay"]
+    eng = build_sac_engine(wl, replay, rank, device)
+    dp, dp_kind, dp_chosen, devices = None, "dp%d" % world, None, None
     if world > 1:
-        dp, dp_kind = make_data_parallel(eng, args.dp, world, rank, device, init_parameters(eng.table, seed=0))
+        devices = device_identities(world, rank, device, args.same_device)
+        dp, dp_kind, dp_chosen = make_data_parallel(eng, args.dp, world, rank, device, init_parameters(eng.table, seed=0),
+                                                    inject_ipc_failure=args.inject_ipc_failure)
 
     def run(n):
         if dp is None:
@@ -599,7 +658,41 @@ def run_sac(args, wl_name, world, rank, device):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_sac(wl)
     out["cpu_baseline"] = cpu
+    if devices is not None:
+        out["config"]["devices"] = devices
+        out["config"]["exchange"] = dp_chosen
+    if dp is not None and hasattr(dp, "close"):
+        dp.close(disconnect=True)      # collective: drained everywhere before any rank unmaps its peers / frees its exchange memory
     eng.close()
+    if world > 1 and not strong and wl_name == "sac_depth" and CONFIGS4_GLOBAL_BATCH % world == 0 and not args.no_configs4:
+        # BASELINE configs[4] is a GLOBAL batch of 1024 (128 per GPU at 8): the driver's one command, `--gpus N`, measures weak
+        # scaling at 256 per GPU -- the same line carries the configs[4] shape too (a second engine per rank, the exchange
+        # variant that was chosen above, the same timed-block protocol), so that an N-GPU record holds both
+        wl4 = dict(WORKLOADS[wl_name], batch=CONFIGS4_GLOBAL_BATCH // world)
+        eng4 = build_sac_engine(wl4, replay, rank, device)
+        try:
+            dp4, kind4, _ = make_data_parallel(eng4, dp_chosen if dp_chosen in IN_GRAPH_VARIANTS else "rccl", world, rank, device,
+                                               init_parameters(eng4.table, seed=0))
+        except SystemExit as exc:       # (collective: raised on every rank after the same votes) -> the collective library
+            sys.stderr.write("bench[rank %d]: configs[4] pass: %s -- falling back to RCCL\n" % (rank, exc))
+            dp4, kind4, _ = make_data_parallel(eng4, "rccl", world, rank, device, init_parameters(eng4.table, seed=0))
+
+        def barrier4():
+            eng4.synchronize()
+            torch.cuda.synchronize(device)
+            dist.barrier()
+        t4, calls4 = timed_blocks(dp4.train, barrier4, args.steps, args.warmup, args.repeats, world, device)
+        d4 = float(np.median(t4))
+        out["config"]["configs4"] = {
+            "workload": wl4["name"] % (wl4["batch"], replay) + " [configs[4]: global batch %d over %d GPU(s)]" % (CONFIGS4_GLOBAL_BATCH, world),
+            "metric": "SAC grad-steps/sec (64x64 depth, global batch %d)" % CONFIGS4_GLOBAL_BATCH, "scaling": "strong",
+            "global_batch": CONFIGS4_GLOBAL_BATCH, "per_gpu_batch": wl4["batch"], "value": round(args.steps / d4, 2),
+            "unit": "grad-steps/s (global updates: each consumes the whole global batch)", "ms_per_step": round(1e3 * d4 / args.steps, 4),
+            "parallelism": kind4,
+            "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in t4], "value_is": "median block", **block_note(calls4, args.steps)}}
+        if hasattr(dp4, "close"):
+            dp4.close(disconnect=True)
+        eng4.close()
     if wl_name == "sac_depth" and rank == 0 and world == 1 and not strong and not args.no_learn_loop:
         from grasp_rl import synthetic
         try:
@@ -752,6 +845,9 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="validation aid: every rank uses cuda:0 (a 1-GPU box); the reported rate is then NOT a scaling number")
     ap.add_argument("--no-success", action="store_true", help="skip the learning run behind `success_rate`")
+    ap.add_argument("--inject-ipc-failure", type=int, default=None, metavar="RANK",
+                    help="validation aid: the in-graph exchange's peer mapping fails on this rank -> every rank must fall back together")
+    ap.add_argument("--no-configs4", action="store_true", help="N > 1: skip the second measurement at BASELINE configs[4]'s global batch of 1024")
     ap.add_argument("--success-steps", type=int, default=80_000)
     args = ap.parse_args()
 

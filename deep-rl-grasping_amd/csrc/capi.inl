@@ -747,7 +747,7 @@ int grl_allreduce_init(grl_handle h, int rank, int world, void* handle_out) {
   }
   if (!h->dp_err_host) {     // page-locked mailbox: a kernel that gives up waiting tells the host without a device read
     HIPCHK(hipHostMalloc((void**)&h->dp_err_host, 64, 0));
-    *h->dp_err_host = 0u;
+    memset(h->dp_err_host, 0, 64);      // word 0: error, word 1: wait bound in ms (0 = the captured default; grl_allreduce_set_timeout)
   }
   HIPCHK(hipDeviceSynchronize());
   hipIpcMemHandle_t mh[2];
@@ -1020,6 +1020,13 @@ int grl_allreduce_set_mode(grl_handle h, int mode) {
   if (mode < 0 || mode > 2) return fail(GRL_ERR_INVALID, "mode: 0 auto, 1 two-shot, 2 one-shot");
   if (mode == 2 && h->cfg.algo != GRL_ALGO_SAC) return fail(GRL_ERR_STATE, "DQN / BDQ handles exchange two-shot (the clipped apply reads the gathered sums)");
   h->dp_mode = mode;
+  return GRL_OK;
+}
+
+int grl_allreduce_set_timeout(grl_handle h, int ms) {
+  if (!h || ms < 0) return fail(GRL_ERR_INVALID, "bad argument");
+  if (!h->dp_err_host) return fail(GRL_ERR_STATE, "call grl_allreduce_init first");
+  __atomic_store_n(h->dp_err_host + 1, (uint32_t)ms, __ATOMIC_RELEASE);     // read by the waiting kernels (dp_wait_all)
   return GRL_OK;
 }
 

@@ -48,6 +48,7 @@
 namespace grl {
 
 enum { DP_MAX_WORLD = 16, DP_MAX_RANGES = 6, DP_CHANNELS = 3 };   // channel 2: running-statistics merge (dp_norm_*)
+enum { DP_LOOK_TICKS = 20000000 };     // 0.2 s of the 100 MHz clock: a wait this long looks at the host's bound (dp_wait_all)
 
 struct DpCtl {
   uint32_t epoch;        // exchanges begun on this channel
@@ -127,7 +128,13 @@ __device__ __forceinline__ bool dp_wait_all(const DpArgs& a, const uint32_t* fla
     while ((int32_t)(dp_load_flag(flags + p) - target) < 0) {
       if ((++polls & 63) == 0) {
         if (dp_load_flag(&mine->error)) { if (a.host_err) dp_store_flag(a.host_err, 1u); return false; }
-        if (dp_clock() - t0 > a.timeout_ticks) { dp_fail(a); return false; }
+        // the bound: `timeout_ticks` as captured (GRL_TUNE dp_timeout_ms), or -- grl_allreduce_set_timeout -- word 1 of the host
+        // mailbox in milliseconds; that word is a read over the bus, so it is looked at only once the wait is already long
+        const uint64_t waited = dp_clock() - t0;
+        if (waited > (a.timeout_ticks < DP_LOOK_TICKS ? a.timeout_ticks : (uint64_t)DP_LOOK_TICKS)) {
+          const uint32_t ms = a.host_err ? dp_load_flag(a.host_err + 1) : 0u;
+          if (waited > (ms ? (uint64_t)ms * 100000ull : a.timeout_ticks)) { dp_fail(a); return false; }
+        }
       }
       dp_sleep();
     }

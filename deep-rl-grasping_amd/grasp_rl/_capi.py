@@ -53,7 +53,7 @@ EXPORTS = [
     "grl_ae_reconstruct", "grl_debug_store", "grl_set_learning_rate", "grl_compute_grads_staged", "grl_grad_ranges",
     "grl_observe", "grl_replay_add_observed",
     "grl_norm_update", "grl_set_running_stats", "grl_set_ret_var", "grl_get_obs_stats",
-    "grl_allreduce_init", "grl_allreduce_connect", "grl_train_step_allreduce", "grl_allreduce_status", "grl_allreduce_set_overlap", "grl_allreduce_set_mode",
+    "grl_allreduce_init", "grl_allreduce_connect", "grl_train_step_allreduce", "grl_allreduce_status", "grl_allreduce_set_overlap", "grl_allreduce_set_mode", "grl_allreduce_set_timeout",
     "grl_allreduce_disconnect",
 ]
 
@@ -102,6 +102,7 @@ def load_library(path=None):
     lib.grl_allreduce_disconnect.argtypes = [vp]
     lib.grl_allreduce_set_overlap.argtypes = [vp, i32]
     lib.grl_allreduce_set_mode.argtypes = [vp, i32]
+    lib.grl_allreduce_set_timeout.argtypes = [vp, i32]
     lib.grl_train_step_allreduce.argtypes = [vp, i32, vp, vp]
     lib.grl_allreduce_status.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
     lib.grl_norm_update.argtypes = [vp, f32p, i32]

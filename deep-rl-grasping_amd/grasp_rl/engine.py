@@ -213,6 +213,10 @@ class SacEngine:
         check(self.lib, self.lib.grl_train_step_allreduce(self.h, n_steps, pi, pe))
         self._keep = [keep]
 
+    def allreduce_set_timeout(self, ms):
+        """Bound of every wait for a peer from now on, in ms (0: the default again); include/grl.h: grl_allreduce_set_timeout."""
+        check(self.lib, self.lib.grl_allreduce_set_timeout(self.h, int(ms)))
+
     def allreduce_status(self):
         n, err = C.c_int64(), C.c_int()
         check(self.lib, self.lib.grl_allreduce_status(self.h, C.byref(n), C.byref(err)))

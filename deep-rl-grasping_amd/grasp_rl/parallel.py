@@ -28,6 +28,12 @@ def allreduce_mean_scale(world):
 
 def allreduce_flat_(flat, group=None):
     """Sum-all-reduce of a flat gradient tensor, in place (one bucket, one collective)."""
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # validation only (ranks sharing one GPU, where RCCL cannot run): gloo moves host buffers
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 

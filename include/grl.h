@@ -241,6 +241,11 @@ int grl_compute_grads_staged(grl_handle h, int stage, const int64_t* idx, const 
      grl_allreduce_status   host (synchronises): exchanges begun; error != 0 (and a negative return) after a time-out;
      grl_allreduce_set_mode 0 (default): one-shot for world <= 2, else two-shot; 1: two-shot; 2: one-shot.  All ranks must
                             choose alike, while no exchange is in flight on any rank;
+     grl_allreduce_set_timeout   host, any time: bound of every wait for a peer in milliseconds from now on (0 = back to the
+                            default, GRL_TUNE dp_timeout_ms or 120 s) -- short while a freshly set-up exchange is being
+                            verified (a channel that cannot work should cost seconds, not minutes: bench.py's
+                            make_data_parallel), long while training (a peer running an evaluation callback is merely late).
+                            Takes effect for waits already in progress; values below 200 ms act as 200 ms;
      grl_allreduce_set_overlap   on = 1: grl_train_step_allreduce runs the staged plan (grl_compute_grads_staged) with BOTH
                             exchanges in its graph -- bucket 0 (dense layers, ~90 % of the bytes) is reduced and exchanged on
                             a side lane of the graph while the backward through the convolutions runs, bucket 1 follows,
@@ -261,6 +266,7 @@ int grl_allreduce_connect(grl_handle h, const void* handles);
 int grl_allreduce_disconnect(grl_handle h);
 int grl_allreduce_set_overlap(grl_handle h, int on);
 int grl_allreduce_set_mode(grl_handle h, int mode);
+int grl_allreduce_set_timeout(grl_handle h, int ms);
 int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, const float* eps);
 int grl_allreduce_status(grl_handle h, int64_t* exchanges, int* error);
 /* contiguous ranges (float offsets into the grads arena) of bucket 0 / 1; returns their number (<= cap) or < 0 */

@@ -164,6 +164,10 @@ def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(host
         b.compute_grads(case["idx"][s:s + 1], case["eps"][s:s + 1])
         b.apply_grads(1.0)
     assert a.allreduce_status() == 3
+    a.allreduce_set_timeout(5000)                  # host-side bound of the waits: any time, graphs untouched; 0 = default again
+    a.allreduce_set_timeout(0)
+    with pytest.raises(RuntimeError):
+        b.allreduce_set_timeout(5000)              # (a handle that was never initialised for the exchange has no mailbox)
     a.allreduce_set_overlap(False)                 # and back to the plain exchange on the same handle
     a.train_allreduce(1, case["idx"][:1], case["eps"][:1])
     b.compute_grads(case["idx"][:1], case["eps"][:1])
