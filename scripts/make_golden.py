@@ -56,7 +56,58 @@ def ent_coef_log_pin():
             "learning_starts": 100, "action_dim": 5}
 
 
+def entropy_log_pin(n_rows=6):
+    """B.8: the first rows of the same log carry THREE columns that only the restated arithmetic ties together: `entropy`
+    (SB: mean of the diagonal Gaussian's entropy, sum(log_std + 0.5 log(2 pi e))), `ent_coef` and `ent_coef_loss`
+    (-mean(log_ent_coef (logp_pi + target_entropy)) with logp_pi the SQUASHED log-likelihood and target_entropy = -A).  Early
+    in training the policy mean is ~0, so the logged entropy fixes log_std, log_std fixes E[logp_pi] through the Gaussian
+    likelihood and the tanh correction log(1 - tanh(u)^2 + eps), and the logged coefficient then fixes the logged loss: row 1
+    to 0.04 %, the first six rows to < 1 %.  Without the tanh correction the loss is 37 % off, with target_entropy = -A/2
+    30 %, with `entropy` = -mean(logp_pi) the log would say 3.4 instead of 6.5."""
+    import csv
+    rows = []
+    with open(REF + "/trained_models/SAC_depth_1mbuffer/logs.csv") as f:
+        for k, r in enumerate(csv.DictReader(f)):
+            if k >= n_rows:
+                break
+            rows.append({"total_timesteps": int(float(r["total_timesteps"])), "ent_coef": float(r["ent_coef"]),
+                         "entropy": float(r["entropy"]), "ent_coef_loss": float(r["ent_coef_loss"])})
+    return {"source": "trained_models/SAC_depth_1mbuffer/logs.csv (first %d rows: entropy, ent_coef, ent_coef_loss)" % n_rows,
+            "rows": rows, "action_dim": 5}
+
+
+def eps_schedule_log_pin():
+    """B.9: the training logs of the shipped DQN / BDQ runs carry `time_spent_exploring` = int(100 * exploration.value(t))
+    (stable-baselines deepq / the BDQ fork log it per episode batch) next to `total_timesteps`: 1 061 + 25 021 rows, 98 / 91
+    distinct values, every one of them equal to int(100 * (1 + min(t / (exploration_fraction * total_timesteps), 1) *
+    (exploration_final_eps - 1))) with the fraction / final epsilon / total of the run's config.yaml (DQN: stable-baselines'
+    defaults 0.1 / 0.02).  Kept: every row where the logged value changes, the row before it, the first and the last."""
+    import csv
+    import yaml
+    out = {}
+    for d, fname, algo in (("DQN_4pads", "logs.csv", "DQN"), ("BDQ_8pads", "logs.full.csv", "BDQ")):
+        cfg = yaml.safe_load(open(REF + "/trained_models/%s/config.yaml" % d))[algo]
+        lines = [l for l in open(REF + "/trained_models/%s/%s" % (d, fname)) if not l.startswith("#")]
+        rows = [(int(float(r["total_timesteps"])), int(r["time_spent_exploring"])) for r in csv.DictReader(lines)]
+        keep = sorted({0, len(rows) - 1} | {k for k in range(1, len(rows)) if rows[k][1] != rows[k - 1][1]}
+                      | {k - 1 for k in range(1, len(rows)) if rows[k][1] != rows[k - 1][1]})
+        out[d] = {"source": "trained_models/%s/%s + config.yaml" % (d, fname), "algo": algo, "n_rows_in_log": len(rows),
+                  "total_timesteps": int(float(cfg["total_timesteps"])),
+                  "exploration_fraction": cfg.get("exploration_fraction"), "exploration_final_eps": cfg.get("exploration_final_eps"),
+                  "rows": [list(rows[k]) for k in keep]}
+    return out
+
+
 def main():
+    if "--pins-r6" in sys.argv:      # add the round-6 pins to the existing file, leave every other fixture as it is
+        with open(GOLD + "/oracle_pins.json") as f:
+            pins = json.load(f)
+        pins["b8_entropy_log"] = entropy_log_pin()
+        pins["b9_eps_schedule_logs"] = eps_schedule_log_pin()
+        with open(GOLD + "/oracle_pins.json", "w") as f:
+            json.dump(pins, f, indent=1, sort_keys=True)
+        print("updated", GOLD + "/oracle_pins.json")
+        return
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(DATA, exist_ok=True)
     pins = {}
@@ -223,6 +274,8 @@ def main():
     pins["bdq_real_obs"]["branch_means_of_Q"] = bm.tolist()
 
     pins["b7_ent_coef_log"] = ent_coef_log_pin()
+    pins["b8_entropy_log"] = entropy_log_pin()
+    pins["b9_eps_schedule_logs"] = eps_schedule_log_pin()
 
     with open(GOLD + "/oracle_pins.json", "w") as f:
         json.dump(pins, f, indent=1, sort_keys=True)

@@ -189,3 +189,69 @@ def test_entropy_coefficient_follows_the_reference_training_log():
         la, lref = float(orc.P[name]), float(np.log(r["ent_coef"]))
         assert abs(la - lref) < 5e-3 * lr * done_steps, (r["total_timesteps"], la, lref)
         assert float(out["ent_loss"]) < 0
+
+
+def test_logged_entropy_and_coefficient_loss_follow_the_restated_policy_arithmetic():
+    """B.8 (scripts/make_golden.py: entropy_log_pin) -- a second pin against numbers the REFERENCE computed.  The first rows of
+    trained_models/SAC_depth_1mbuffer/logs.csv carry `entropy`, `ent_coef` and `ent_coef_loss`.  With the policy's mean at ~0
+    (early training) the logged entropy fixes log_std (entropy = sum(log_std + 0.5 log 2 pi e)), log_std fixes E[logp_pi]
+    through the Gaussian likelihood and the tanh correction, and the logged coefficient then fixes the logged loss
+    (-mean(log_ent_coef (logp_pi + target_entropy)), target_entropy = -A).  The ORACLE's own actor_fwd / forward -- the code
+    every GPU parity test compares against -- is put into exactly that state and must reproduce the log: its `entropy` output
+    equals the logged one, its `ent_loss` the logged `ent_coef_loss` to 0.3 % in row 1 and 1.2 % in the first six rows
+    (without the squash correction: 37 % off; target_entropy = -A / 2: 30 %; entropy taken as -mean(logp_pi): 3.4, not 6.5)."""
+    import json
+    import os
+    pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_pins.json")))["b8_entropy_log"]
+    A = pin["action_dim"]
+    spec = osac.SacSpec(extractor="mlp", obs_dim=4, act_dim=A, layers=[8, 8])
+    assert spec.target_entropy == -A
+    rng = np.random.default_rng(0)
+    B = 1 << 17
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    batch = {"obs": f(rng.normal(size=(B, 4))), "next_obs": f(rng.normal(size=(B, 4))), "act": f(rng.uniform(-1, 1, (B, A))),
+             "rew": f(np.zeros(B)), "done": f(np.zeros(B))}
+    eps = rng.standard_normal((B, A)).astype(np.float32)
+    for k, r in enumerate(pin["rows"]):
+        P = osac.init_params(spec, 0)
+        log_std = (r["entropy"] - A * 0.5 * np.log(2 * np.pi * np.e)) / A
+        P["model/pi/dense/kernel:0"][...] = 0.0          # mean 0, state-independent log_std: the early policy of the log
+        P["model/pi/dense/bias:0"][...] = 0.0
+        P["model/pi/dense_1/kernel:0"][...] = 0.0
+        P["model/pi/dense_1/bias:0"][...] = log_std
+        P["model/log_ent_coef:0"] = np.float32(np.log(r["ent_coef"])).reshape(P["model/log_ent_coef:0"].shape)
+        out = osac.SacOracle(spec, P).forward(batch, eps)
+        assert abs(float(out["entropy"].mean()) - r["entropy"]) < 1e-4
+        got, want = float(out["ent_loss"]), r["ent_coef_loss"]
+        assert abs(got - want) <= (0.003 if k == 0 else 0.012) * abs(want), (r["total_timesteps"], got, want)
+        # the alternatives miss by far more than the tolerance
+        logp = out["logp"].numpy()
+        no_squash = -float(np.log(r["ent_coef"])) * (-r["entropy"] - A)
+        half_target = -float(np.log(r["ent_coef"])) * (float(logp.mean()) - A / 2)
+        assert abs(no_squash - want) > 0.25 * abs(want) and abs(half_target - want) > 0.2 * abs(want)
+        assert abs(-float(logp.mean()) - r["entropy"]) > 2.5          # `entropy` is NOT -mean(logp_pi)
+
+
+def test_exploration_schedule_follows_the_reference_training_logs():
+    """B.9 (scripts/make_golden.py: eps_schedule_log_pin): the shipped DQN_4pads / BDQ_8pads runs logged
+    `time_spent_exploring` = int(100 * exploration.value(total_timesteps)) -- 26 082 rows, every change of the value kept in
+    the fixture.  The host code's LinearSchedule, built the way `DQN.__init__` / `BDQ.__init__` build it from the run's
+    config.yaml (`exploration_fraction`, `exploration_final_eps`, `total_timesteps`; stable-baselines' defaults 0.1 / 0.02
+    where the config is silent), must give the logged integer in every kept row."""
+    import json
+    import os
+    from grasp_rl.sb.dqn import LinearSchedule
+    pins = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_pins.json")))["b9_eps_schedule_logs"]
+    for name, pin in pins.items():
+        frac = 0.1 if pin["exploration_fraction"] is None else pin["exploration_fraction"]
+        final = 0.02 if pin["exploration_final_eps"] is None else pin["exploration_final_eps"]
+        sched = LinearSchedule(int(frac * pin["total_timesteps"]), final, 1.0)
+        seen = set()
+        for t, logged in pin["rows"]:
+            assert int(100 * sched.value(t)) == logged, (name, t, logged, sched.value(t))
+            seen.add(logged)
+        # (BDQ_8pads ends at 9, not 10: 1.0 + 1.0 * (0.1 - 1.0) = 0.09999999999999998 in float64 -- the reference's own rounding)
+        assert len(seen) > 80 and min(seen) == int(100 * sched.value(10 ** 9)) and pin["n_rows_in_log"] > 1000
+        # what else the schedule could have been: a fraction of 0.2, or a final epsilon of 0.05, miss hundreds of the kept rows
+        for alt in (LinearSchedule(int(0.2 * pin["total_timesteps"]), final, 1.0), LinearSchedule(int(frac * pin["total_timesteps"]), 0.05, 1.0)):
+            assert sum(int(100 * alt.value(t)) != logged for t, logged in pin["rows"]) > 100

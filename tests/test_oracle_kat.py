@@ -353,3 +353,12 @@ def test_relu_hints_move_only_sign_ambiguous_units(monkeypatch):
     moved = [a for a in osac.RELU_ALIGNED if a[0] == "model/values_fn" and a[1] == 1]
     assert len(moved) == 3 and all(0 < a[3] <= tol for a in moved)
     assert any(not np.array_equal(ref[0]["grads"][n], d2["grads"][n]) for n in d2["grads"] if "values_fn/cnn1" in n or "values_fn/c1" in n)
+
+
+def test_sign_ambiguity_bounds_are_frozen():
+    """the tolerance within which `compare_first_step` may tell the oracle the engine's side of a ReLU, and the
+    number of units per case that may need it, are test constants -- widening either must fail here first."""
+    import parity_util as pu
+    from oracle import sac as osac
+    assert osac.AMBIG_TOL == pu.AMBIG_TOL_FROZEN == 2e-8
+    assert pu.MAX_HINTED_UNITS == 2
