@@ -806,7 +806,7 @@ static Op dp_k1_op(grl_ctx* self, const grl_ctx::ReducePlan& rp, const DpArgs& d
   if (ga) g = *ga;
   const int gxx = ga ? gx : 0;
   op.run = [dr, rp, la, aa, da, g, gxx](hipStream_t s) {
-    const int nb = rp.n + rp.has_loss + (gxx > 0 ? gxx * g.B * 2 : 0);
+    const int nb = rp.n + rp.has_loss + (gxx > 0 ? gather_blocks(g, gxx) : 0);
     hipLaunchKernelGGL(dp_reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da, g, gxx);
   };
   return op;

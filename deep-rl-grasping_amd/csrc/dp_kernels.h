@@ -170,8 +170,7 @@ __global__ __launch_bounds__(256) void dp_reduce_slabs_kernel(const ReduceDesc* 
     if (before == 0 && threadIdx.x == 0) mine->epoch = mine->epoch + 1u;
     return;
   }
-  const int r = (int)(x - before);
-  gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
+  gather_norm_dispatch(ga, gx, (int)(x - before));
 }
 
 // W: the only kernel that waits.  One wave: announce `ready` (which = 0) or `done` (which = 1) for the current exchange in

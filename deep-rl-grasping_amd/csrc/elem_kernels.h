@@ -92,7 +92,14 @@ struct GatherArgs {
   // rng_ahead = 1 draws with counter rng_step + 1 (the counter still holds update t's value while that launch runs);
   // quiet = 1: neither mark rng_used nor touch the Adam step size -- the update it prepares has not started yet
   int rng_ahead, quiet;
+  // rows > 1 (vec4 only, rows divides B): a workgroup owns one 1024-element tile of `rows` minibatch rows (of obs OR next_obs):
+  // the float64 statistics of its element positions are fetched once, the `rows` replay reads are all in flight before the
+  // first is used (gather_norm_rows_body); grid = tiles per row x (2 B / rows), linearised (gather_blocks)
+  int rows;
 };
+#define GATHER_ROWS_DEFAULT 1     /* rows per workgroup where the plan may choose (GRL_TUNE gather_rows) */
+// workgroups of a gather launch with gx tiles per row
+static inline int gather_blocks(const GatherArgs& a, int gx) { return a.rows > 1 ? gx * (2 * a.B / a.rows) : gx * a.B * 2; }
 
 __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int normalize, double clip,
                                            float scale_div) {
@@ -272,9 +279,154 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
     if (a.adam_tick) adam_tick_device(a.sc);
   }
 }
+// the per-row duties of tile 0 (direct features, action, reward, done flag, the row's index and standard normals in device-RNG
+// mode): what gather_norm_body does under `bx == 0`, for the grouped form
+__device__ __forceinline__ void gather_row_extras(const GatherArgs& a, const int b, const int which, const int64_t src, const uint64_t step) {
+  const int t = threadIdx.x;
+  if (t < a.n_direct) {
+    const float* rp = which ? a.rp_dnext : a.rp_dobs;
+    const float y = norm_elem(rp[src * a.n_direct + t], a.normalize ? a.dmean[t] : 0.0, a.normalize ? a.dstd[t] : 1.0,
+                              a.normalize, a.clip_obs, a.scale_div);
+    if (which) a.d_next[(long)b * a.ldd + t] = y;
+    else { a.d_obs0[(long)b * a.ldd + t] = y; a.d_obs1[(long)b * a.ldd + t] = y; }
+  }
+  if (which) return;
+  if (t < a.act_dim) {
+    const float av = a.rp_act[src * a.act_dim + t];
+    a.act_out[(long)b * a.ld_act + t] = av;
+    if (a.act_out2) a.act_out2[(long)b * a.ld_act2 + t] = av;
+  }
+  if (t == 64) {
+    float r = a.rp_rew[src];
+    if (a.normalize_rew) {
+      double z = (double)r / a.ret_std[0];
+      z = z < -a.clip_rew ? -a.clip_rew : (z > a.clip_rew ? a.clip_rew : z);
+      r = (float)z;
+    }
+    a.rew_out[b] = r;
+  }
+  if (t == 65) a.done_out[b] = a.rp_done[src];
+  if (a.use_rng) {
+    if (t == 66) a.idx_w[b] = src;
+    if (t >= 128 && 2 * (t - 128) < a.n_eps) {   // Box-Muller pairs, as gather_norm_body
+      const int j0 = 2 * (t - 128);
+      uint32_t d[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, (uint32_t)(1 + j0)};
+      philox4x32_10(d, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+      const float u1 = ((float)(d[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+      const float u2 = ((float)(d[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+      const float rad = sqrtf(-2.f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      a.eps_w[b * a.n_eps + j0] = rad * cs;
+      if (j0 + 1 < a.n_eps) a.eps_w[b * a.n_eps + j0 + 1] = rad * sn;
+    }
+  }
+}
+
+#ifndef GRL_HOSTEMU
+// Grouped form (GatherArgs.rows = R > 1): workgroup (bx, grp) moves tile bx -- elements [1024 bx, 1024 bx + 1024) -- of the R
+// row instances grp R .. grp R + R - 1 of the 2 B (obs rows first, then next_obs rows; R divides B, so a group is all obs or all
+// next_obs).  Same arithmetic per element as gather_norm_body (norm_elem), hence the same bits.  What changes is the shape of
+// the latency chain: one Philox draw per lane (lane r holds row r's index, the others read it with a lane broadcast), the
+// statistics of the thread's four element positions loaded ONCE, and the R replay reads issued back to back before the first
+// is consumed -- a workgroup lives about as long as a one-row workgroup does and there are R times fewer of them.
+template <int R>
+__device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const int bx, const int grp) {
+  typedef float gn_f4 __attribute__((ext_vector_type(4)));
+  typedef double gn_d4 __attribute__((ext_vector_type(4)));
+  const int i0 = grp * R, which = i0 >= a.B ? 1 : 0, b0 = i0 - which * a.B;
+  const int lane = (int)(threadIdx.x & 63u);
+  uint64_t step = 0;
+  int64_t mine;
+  if (a.use_rng) {
+    step = a.sc->rng_step + (uint64_t)a.rng_ahead;
+    const int64_t size = a.sc->replay_size;
+    uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)(b0 + (lane % R)), 0u};
+    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const uint64_t u = ((uint64_t)c[0] << 32) | c[1];
+    mine = size > 0 ? (int64_t)__umul64hi(u, (uint64_t)size) : 0;
+  } else {
+    mine = a.idx[b0 + (lane % R)];
+  }
+  int64_t src[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, r);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)mine >> 32), r);
+    src[r] = (int64_t)(((uint64_t)hi << 32) | lo);
+  }
+  const int e4 = (bx * 256 + (int)threadIdx.x) * 4;
+  if (e4 < a.img_elems) {
+    const float* rp = which ? a.rp_next : a.rp_obs;
+    gn_f4 x[R];
+    if (a.rgb_u8) {            // one pixel per thread: colours from the packed dword, depth from the float plane
+      const int hwp = a.img_elems >> 2, px = e4 >> 2;
+      uint32_t w[R];
+      float d[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float* ob = rp + src[r] * (2 * hwp);
+        w[r] = ((const uint32_t*)ob)[px];
+        d[r] = ob[hwp + px];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = gn_f4{(float)(w[r] & 255u), (float)((w[r] >> 8) & 255u), (float)((w[r] >> 16) & 255u), d[r]};
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = *(const gn_f4*)(rp + src[r] * a.img_elems + e4);
+    }
+    gn_d4 mu = {0.0, 0.0, 0.0, 0.0}, sd = {1.0, 1.0, 1.0, 1.0};
+    if (a.normalize) { mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      gn_f4 y;
+      y.x = norm_elem(x[r].x, mu.x, sd.x, a.normalize, a.clip_obs, a.scale_div);
+      y.y = norm_elem(x[r].y, mu.y, sd.y, a.normalize, a.clip_obs, a.scale_div);
+      y.z = norm_elem(x[r].z, mu.z, sd.z, a.normalize, a.clip_obs, a.scale_div);
+      y.w = norm_elem(x[r].w, mu.w, sd.w, a.normalize, a.clip_obs, a.scale_div);
+      const long o = (long)(b0 + r) * a.ldx + e4;
+      if (which) {
+        *(gn_f4*)(a.x_next + o) = y;
+      } else {
+        *(gn_f4*)(a.x_obs + o) = y;
+        if (a.x_obs2) *(gn_f4*)(a.x_obs2 + o) = y;
+      }
+    }
+  }
+  if (bx == 0) {
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) gather_row_extras(a, b0 + r, which, src[r], step);
+    if (grp == 0 && threadIdx.x == 0 && !a.quiet) {
+      if (a.use_rng) a.sc->rng_used = 1u;
+      if (a.adam_tick) adam_tick_device(a.sc);
+    }
+  }
+}
+#endif
+
+// workgroup r of a linearised gather grid (gather_blocks) with gx tiles per row
+__device__ __forceinline__ void gather_norm_dispatch(const GatherArgs& a, const int gx, const int r) {
+#ifndef GRL_HOSTEMU
+  if (a.rows > 1) {
+    const int bx = r % gx, grp = r / gx;
+    switch (a.rows) {
+      case 2: gather_norm_rows_body<2>(a, bx, grp); return;
+      case 4: gather_norm_rows_body<4>(a, bx, grp); return;
+      case 8: gather_norm_rows_body<8>(a, bx, grp); return;
+      default: gather_norm_rows_body<16>(a, bx, grp); return;
+    }
+  }
+#endif
+  gather_norm_body(a, r % gx, (r / gx) % a.B, r / (gx * a.B));
+}
+
 #ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   gather_norm_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+// linearised grid (gather_blocks): the grouped form
+__global__ __launch_bounds__(256) void gather_norm_lin_kernel(GatherArgs a, int gx) {
+  gather_norm_dispatch(a, gx, (int)blockIdx.x);
 }
 #endif
 
@@ -1251,8 +1403,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDe
   const long nb = n_tiles + has_loss, total = (long)gridDim.x, x = (long)blockIdx.x;
   const long before = x * nb / total, upto = (x + 1) * nb / total;
   if (upto > before) { reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)before); return; }
-  const int r = (int)(x - before);
-  gather_norm_body(ga, r % gx, (r / gx) % ga.B, r / (gx * ga.B));
+  gather_norm_dispatch(ga, gx, (int)(x - before));
 }
 #endif
 

@@ -170,14 +170,22 @@ int grl_ctx::plan_sac() {
     ga.adam_tick = fused_heads ? 1 : 0;   // otherwise sac_loss_kernel fixes the step size
     ga.vec4 = elem_vec4_built() && (img_elems % 4 == 0) && (ga.ldx % 4 == 0);
     const int per_block = ga.vec4 ? 1024 : 256;
+    // rows per workgroup of the grouped form (elem_kernels.h: gather_norm_rows_body); GRL_TUNE gather_rows=1 keeps one row each
+    {
+      int rows = tune_int("gather_rows", GATHER_ROWS_DEFAULT);
+      if (!ga.vec4 || (rows != 2 && rows != 4 && rows != 8 && rows != 16) || B % rows) rows = 1;
+      ga.rows = rows;
+    }
     pf_ga = ga;
     pf_gx = (ga.img_elems + per_block - 1) / per_block;
     for (int mode = 0; mode < 2; ++mode) {
       ga.use_rng = mode;
       Op op; op.tag = "gather_norm";
       op.bytes = 2.0 * B * ((double)img_elems * 4 + (double)obs_store * 4 + 4.0 * nd) + B * (4.0 * A + 8) * 2;
-      op.run = [ga, per_block](hipStream_t s) {
-        hipLaunchKernelGGL(gather_norm_kernel, dim3((ga.img_elems + per_block - 1) / per_block, ga.B, 2), dim3(256), 0, s, ga);
+      const int gx0 = pf_gx;
+      op.run = [ga, gx0](hipStream_t s) {
+        if (ga.rows > 1) hipLaunchKernelGGL(gather_norm_lin_kernel, dim3(gather_blocks(ga, gx0)), dim3(256), 0, s, ga, gx0);
+        else hipLaunchKernelGGL(gather_norm_kernel, dim3(gx0, ga.B, 2), dim3(256), 0, s, ga);
       };
       (mode ? ops_rng : ops_gather).push_back(op);
     }
@@ -792,7 +800,10 @@ int grl_ctx::plan_sac() {
         {
           Op op; op.tag = "gather_norm";
           op.bytes = ops_rng[0].bytes;
-          op.run = [g1, gx](hipStream_t s) { hipLaunchKernelGGL(gather_norm_kernel, dim3(gx, g1.B, 2), dim3(256), 0, s, g1); };
+          op.run = [g1, gx](hipStream_t s) {
+            if (g1.rows > 1) hipLaunchKernelGGL(gather_norm_lin_kernel, dim3(gather_blocks(g1, gx)), dim3(256), 0, s, g1, gx);
+            else hipLaunchKernelGGL(gather_norm_kernel, dim3(gx, g1.B, 2), dim3(256), 0, s, g1);
+          };
           ops_pf_first.push_back(op);
         }
         GatherArgs g2 = g1;
@@ -803,7 +814,7 @@ int grl_ctx::plan_sac() {
         ro.join = true;
         ro.bytes = fo.bytes + ops_rng[0].bytes;
         ro.run = [dr, d_rt, ntiles, lk, has_loss, aa, g2, gx](hipStream_t s) {
-          hipLaunchKernelGGL(reduce_slabs_gather_kernel, dim3(ntiles + has_loss + gx * g2.B * 2), dim3(256), 0, s, dr, d_rt, ntiles, lk,
+          hipLaunchKernelGGL(reduce_slabs_gather_kernel, dim3(ntiles + has_loss + gather_blocks(g2, gx)), dim3(256), 0, s, dr, d_rt, ntiles, lk,
                              has_loss, aa, 1, g2, gx);
         };
         for (int v = 0; v < 3; ++v) {     // 0 first, 1 middle, 2 last

@@ -183,13 +183,18 @@ def _ingraph_worker(rank, world, port, out_dir):
         # the smallest SAC there is: a bucket of 84 floats -- not a multiple of 4 * world, rank 6's chunk short, rank 7's EMPTY
         # (capi.inl: chunk = rup(ceil(n / world), 4))
         cases["tiny"] = pu.make_case(extractor="mlp", obs_dim=1, act_dim=1, layers=(4,), B=B, n_replay=48, n_steps=STEPS)
+    t_start = time.time()
+    stamp = (lambda what: print("[W=%d rank 0] %6.1f s  %s" % (world, time.time() - t_start, what), flush=True)) \
+        if rank == 0 and os.environ.get("GRL_TEST_TIMING") == "1" else (lambda what: None)
     for cname, case in cases.items():
+        stamp("case " + cname)
         cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
         cfg.batch_size = B // world
         case["cfg"] = cfg
         lo, hi = rank * (B // world), (rank + 1) * (B // world)
         steps = n_steps[cname]
         Pref = _rank_ordered_reference(case, lo, hi, world, steps)
+        stamp("rank-ordered reference done")
         if world == 2:      # ... and the same two ranks exchanging through gloo (single bucket: compute -> all_reduce -> apply)
             g = pu.engine_setup(case)
             DataParallelSac(g, overlap=False).train(STEPS, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
@@ -205,11 +210,14 @@ def _ingraph_worker(rank, world, port, out_dir):
             if light and cname == "cnn" and not slow and mode != "twoshot":
                 continue
             eng = pu.engine_setup(case)
+            stamp("%s: engine set up" % mode)
             dp = DataParallelInGraph(eng, overlap=overlap, mode=mode)
+            stamp("%s: exchange connected" % mode)
             if cname == "tiny":
                 assert eng.n_trainable == 84
             dp.train(steps, case["idx"][:, lo:hi], case["eps"][:, lo:hi])
             assert dp.check() == steps
+            stamp("%s: %d explicit updates done" % (mode, steps))
             P = eng.get_parameters()
             for k in P:
                 assert np.array_equal(P[k], Pref[k]), "%s / %s%s: differs from the rank-ordered sum: %s" % (cname, mode, "+overlap" if overlap else "", k)
