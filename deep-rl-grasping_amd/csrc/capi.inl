@@ -807,7 +807,8 @@ static Op dp_k1_op(grl_ctx* self, const grl_ctx::ReducePlan& rp, const DpArgs& d
   const int gxx = ga ? gx : 0;
   op.run = [dr, rp, la, aa, da, g, gxx](hipStream_t s) {
     const int nb = rp.n + rp.has_loss + (gxx > 0 ? gather_blocks(g, gxx) : 0);
-    hipLaunchKernelGGL(dp_reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da, g, gxx);
+    if (gxx > 0 && g.rows > 1) hipLaunchKernelGGL(dp_reduce_slabs_kernel<true>, dim3(nb), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da, g, gxx);
+    else hipLaunchKernelGGL(dp_reduce_slabs_kernel<false>, dim3(nb), dim3(256), 0, s, dr, rp.tiles, rp.n, la, rp.has_loss, aa, da, g, gxx);
   };
   return op;
 }

@@ -154,6 +154,7 @@ __device__ __forceinline__ int64_t dp_quad(const DpArgs& a, int64_t vq) {
 // also goes, write-through, into this rank's source array.  The pieces of the channel are exactly what the launch's
 // descriptors cover.  Optionally carries the replay gather of the next update like reduce_slabs_gather_kernel (gx > 0).
 // Block 0 advances the channel's epoch (no thread of this launch reads it).
+template <bool GROUPED>
 __global__ __launch_bounds__(256) void dp_reduce_slabs_kernel(const ReduceDesc* __restrict__ descs, const int2* __restrict__ tiles,
                                                              int n_tiles, LossArgs la, int has_loss, AdamArgs aa, DpArgs a,
                                                              GatherArgs ga, int gx) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void dp_reduce_slabs_kernel(const ReduceDesc* 
     if (before == 0 && threadIdx.x == 0) mine->epoch = mine->epoch + 1u;
     return;
   }
-  gather_norm_dispatch(ga, gx, (int)(x - before));
+  gather_norm_dispatch<GROUPED>(ga, gx, (int)(x - before));
 }
 
 // W: the only kernel that waits.  One wave: announce `ready` (which = 0) or `done` (which = 1) for the current exchange in

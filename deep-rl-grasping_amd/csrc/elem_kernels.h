@@ -97,7 +97,8 @@ struct GatherArgs {
   // first is used (gather_norm_rows_body); grid = tiles per row x (2 B / rows), linearised (gather_blocks)
   int rows;
 };
-#define GATHER_ROWS_DEFAULT 1     /* rows per workgroup where the plan may choose (GRL_TUNE gather_rows) */
+#define GATHER_ROWS_U8 4          /* rows per workgroup of the grouped form, RGB-D ring with byte colours (GRL_TUNE gather_rows) */
+#define GATHER_ROWS_F32 1         /* float32 rings: one row per workgroup measured fastest (profiles/r06_sweep_gather_rows.txt) */
 // workgroups of a gather launch with gx tiles per row
 static inline int gather_blocks(const GatherArgs& a, int gx) { return a.rows > 1 ? gx * (2 * a.B / a.rows) : gx * a.B * 2; }
 
@@ -109,6 +110,26 @@ __device__ __forceinline__ float norm_elem(float x, double mu, double sd, int no
     z = z < -clip ? -clip : (z > clip ? clip : z);
     y = (float)z;
   }
+  return scale_div != 1.f ? y / scale_div : y;
+}
+
+// The same value with the float64 division (x - mu) / sd replaced by two FMA refinement steps on (x - mu) * r, r = RN(1 / sd):
+// q0 = d r; e = fma(-sd, q, d); q = fma(e, r, q), twice.  The first step leaves q within an ulp of d / sd, and with the
+// CORRECTLY ROUNDED reciprocal the second then yields the correctly rounded quotient (Markstein's theorem; the residual
+// e is exact in an FMA) -- the bits of the IEEE division, which a workgroup that owns several rows of the same element
+// positions (gather_norm_rows_body) pays once per position instead of once per element: on gfx950 the division expands to ~13
+// float64 instructions, three of them quarter rate, against these six (sub, mul, four FMAs).  400 000 000 random and adversarial
+// (x, mu, sd) on the host: no mismatch even after ONE step.  Ranges: d, sd, r normal numbers (sd >= sqrt(norm_eps)).
+__device__ __forceinline__ float norm_elem_rcp(float x, double mu, double sd, double r, double clip, float scale_div) {
+#pragma clang fp contract(off)
+  const double d = (double)x - mu;
+  double q = d * r;
+  double e = __builtin_fma(-sd, q, d);
+  q = __builtin_fma(e, r, q);
+  e = __builtin_fma(-sd, q, d);
+  q = __builtin_fma(e, r, q);
+  q = q < -clip ? -clip : (q > clip ? clip : q);
+  const float y = (float)q;
   return scale_div != 1.f ? y / scale_div : y;
 }
 
@@ -375,15 +396,25 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
 #pragma unroll
       for (int r = 0; r < R; ++r) x[r] = *(const gn_f4*)(rp + src[r] * a.img_elems + e4);
     }
-    gn_d4 mu = {0.0, 0.0, 0.0, 0.0}, sd = {1.0, 1.0, 1.0, 1.0};
-    if (a.normalize) { mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4); }
+    gn_d4 mu = {0.0, 0.0, 0.0, 0.0}, sd = {1.0, 1.0, 1.0, 1.0}, rc = {1.0, 1.0, 1.0, 1.0};
+    if (a.normalize) {
+      mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4);
+      rc.x = 1.0 / sd.x; rc.y = 1.0 / sd.y; rc.z = 1.0 / sd.z; rc.w = 1.0 / sd.w;     // IEEE divisions: correctly rounded reciprocals
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       gn_f4 y;
-      y.x = norm_elem(x[r].x, mu.x, sd.x, a.normalize, a.clip_obs, a.scale_div);
-      y.y = norm_elem(x[r].y, mu.y, sd.y, a.normalize, a.clip_obs, a.scale_div);
-      y.z = norm_elem(x[r].z, mu.z, sd.z, a.normalize, a.clip_obs, a.scale_div);
-      y.w = norm_elem(x[r].w, mu.w, sd.w, a.normalize, a.clip_obs, a.scale_div);
+      if (a.normalize) {
+        y.x = norm_elem_rcp(x[r].x, mu.x, sd.x, rc.x, a.clip_obs, a.scale_div);
+        y.y = norm_elem_rcp(x[r].y, mu.y, sd.y, rc.y, a.clip_obs, a.scale_div);
+        y.z = norm_elem_rcp(x[r].z, mu.z, sd.z, rc.z, a.clip_obs, a.scale_div);
+        y.w = norm_elem_rcp(x[r].w, mu.w, sd.w, rc.w, a.clip_obs, a.scale_div);
+      } else {
+        y.x = norm_elem(x[r].x, 0.0, 1.0, 0, a.clip_obs, a.scale_div);
+        y.y = norm_elem(x[r].y, 0.0, 1.0, 0, a.clip_obs, a.scale_div);
+        y.z = norm_elem(x[r].z, 0.0, 1.0, 0, a.clip_obs, a.scale_div);
+        y.w = norm_elem(x[r].w, 0.0, 1.0, 0, a.clip_obs, a.scale_div);
+      }
       const long o = (long)(b0 + r) * a.ldx + e4;
       if (which) {
         *(gn_f4*)(a.x_next + o) = y;
@@ -404,17 +435,19 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
 }
 #endif
 
-// workgroup r of a linearised gather grid (gather_blocks) with gx tiles per row
+// workgroup r of a linearised gather grid (gather_blocks) with gx tiles per row.  GROUPED is a compile-time choice of the
+// LAUNCH (the plan picks the kernel by GatherArgs.rows): a kernel that could take either form is allocated the registers of
+// the larger one -- 69 instead of 64 for the reduction + gather launch, one wave per SIMD less for the one-row form
+template <bool GROUPED>
 __device__ __forceinline__ void gather_norm_dispatch(const GatherArgs& a, const int gx, const int r) {
 #ifndef GRL_HOSTEMU
-  if (a.rows > 1) {
+  if (GROUPED) {
     const int bx = r % gx, grp = r / gx;
-    switch (a.rows) {
-      case 2: gather_norm_rows_body<2>(a, bx, grp); return;
-      case 4: gather_norm_rows_body<4>(a, bx, grp); return;
-      case 8: gather_norm_rows_body<8>(a, bx, grp); return;
-      default: gather_norm_rows_body<16>(a, bx, grp); return;
-    }
+    // (two instantiations only: the launch that carries this body is compiled for the largest of them -- with R = 16 in the
+    // list reduce_slabs_gather_kernel went from 64 to 95 registers and spilled)
+    if (a.rows == 2) gather_norm_rows_body<2>(a, bx, grp);
+    else gather_norm_rows_body<4>(a, bx, grp);
+    return;
   }
 #endif
   gather_norm_body(a, r % gx, (r / gx) % a.B, r / (gx * a.B));
@@ -426,7 +459,7 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
 }
 // linearised grid (gather_blocks): the grouped form
 __global__ __launch_bounds__(256) void gather_norm_lin_kernel(GatherArgs a, int gx) {
-  gather_norm_dispatch(a, gx, (int)blockIdx.x);
+  gather_norm_dispatch<true>(a, gx, (int)blockIdx.x);
 }
 #endif
 
@@ -1212,6 +1245,10 @@ struct AdamArgs {
   float eps;                   // 1e-8 (TF AdamOptimizer), 1e-7 (Keras Adam)
   int64_t src_ofs, n_polyak;   // source range [src_ofs, src_ofs+n_polyak) inside params
   float* target;               // target block
+  // reduce_slabs with the fused apply: 1 = do not write the summed gradients to the bucket (5.4 MB of stores per update).  Only
+  // for the first / middle updates of a multi-update call: no caller can look at their gradients (grl_get_gradients after the
+  // call sees the LAST update's, whose launch keeps the store), and the data-parallel launches publish through `mirror`
+  int skip_bucket = 0;
 };
 
 #ifndef GRL_RS_QUADS
@@ -1335,7 +1372,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
       if (!on[u]) continue;
       // (data parallel: the sums go to the exchange buffer ONLY -- nothing reads this rank's own bucket before the exchange)
       if (mirror) { const float sv[4] = {s[u].x, s[u].y, s[u].z, s[u].w}; st_sys_quad(mirror, ((d.dst + ii[u]) - aa.grads) >> 2, sv); }
-      else *(rs_gqw)(d.dst + ii[u]) = s[u];
+      else if (!(fuse_adam && aa.skip_bucket)) *(rs_gqw)(d.dst + ii[u]) = s[u];
       if (fuse_adam) {
         float pe[4] = {p[u].x, p[u].y, p[u].z, p[u].w}, me[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, ve[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
         const float ge[4] = {s[u].x, s[u].y, s[u].z, s[u].w};
@@ -1374,7 +1411,7 @@ __device__ __forceinline__ void reduce_slabs_body(const ReduceDesc* __restrict__
     }
     for (; k < d.splits; ++k) s += src[(long)k * d.slab_stride];
     if (mirror) st_sys_f1(mirror + ((d.dst + i) - aa.grads), s);
-    else d.dst[i] = s;
+    else if (!(fuse_adam && aa.skip_bucket)) d.dst[i] = s;
     if (fuse_adam) {   // the update every trainable tensor gets from adam_polyak_kernel, element by element
       adam_elem(grad_scaled(s, aa.grad_scale), p, m, v, aa.sc->adam_alpha, aa.eps);
       aa.params[e] = p; aa.m[e] = m; aa.v[e] = v;
@@ -1394,6 +1431,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
 // reader of the minibatch tensors of update t has finished when this last launch of update t starts, and both halves
 // are memory / latency bound -- they overlap instead of paying two launches (engine.hip, "prefetch").
 #ifndef GRL_ELEM_TYPES_ONLY
+template <bool GROUPED>
 __global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDesc* __restrict__ descs,
                                                                  const int2* __restrict__ tiles, int n_tiles,
                                                                  LossArgs la, int has_loss, AdamArgs aa, int fuse_adam,
@@ -1403,7 +1441,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDe
   const long nb = n_tiles + has_loss, total = (long)gridDim.x, x = (long)blockIdx.x;
   const long before = x * nb / total, upto = (x + 1) * nb / total;
   if (upto > before) { reduce_slabs_body(descs, tiles, n_tiles, la, has_loss, aa, fuse_adam, (int)before); return; }
-  gather_norm_dispatch(ga, gx, (int)(x - before));
+  gather_norm_dispatch<GROUPED>(ga, gx, (int)(x - before));
 }
 #endif
 

@@ -172,8 +172,8 @@ int grl_ctx::plan_sac() {
     const int per_block = ga.vec4 ? 1024 : 256;
     // rows per workgroup of the grouped form (elem_kernels.h: gather_norm_rows_body); GRL_TUNE gather_rows=1 keeps one row each
     {
-      int rows = tune_int("gather_rows", GATHER_ROWS_DEFAULT);
-      if (!ga.vec4 || (rows != 2 && rows != 4 && rows != 8 && rows != 16) || B % rows) rows = 1;
+      int rows = tune_int("gather_rows", c.replay_rgb_u8 ? GATHER_ROWS_U8 : GATHER_ROWS_F32);
+      if (!ga.vec4 || (rows != 2 && rows != 4) || B % rows) rows = 1;
       ga.rows = rows;
     }
     pf_ga = ga;
@@ -813,9 +813,13 @@ int grl_ctx::plan_sac() {
         Op ro; ro.tag = "reduce_adam";
         ro.join = true;
         ro.bytes = fo.bytes + ops_rng[0].bytes;
-        ro.run = [dr, d_rt, ntiles, lk, has_loss, aa, g2, gx](hipStream_t s) {
-          hipLaunchKernelGGL(reduce_slabs_gather_kernel, dim3(ntiles + has_loss + gather_blocks(g2, gx)), dim3(256), 0, s, dr, d_rt, ntiles, lk,
-                             has_loss, aa, 1, g2, gx);
+        AdamArgs aq = aa;
+        aq.skip_bucket = tune_int("pf_skip_bucket", 1) != 0;      // (the call's last update -- `fo` -- leaves its gradients in the bucket)
+        ro.bytes -= aq.skip_bucket ? (double)n_train * 4 : 0.0;
+        ro.run = [dr, d_rt, ntiles, lk, has_loss, aq, g2, gx](hipStream_t s) {
+          const dim3 grid(ntiles + has_loss + gather_blocks(g2, gx));
+          if (g2.rows > 1) hipLaunchKernelGGL(reduce_slabs_gather_kernel<true>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lk, has_loss, aq, 1, g2, gx);
+          else hipLaunchKernelGGL(reduce_slabs_gather_kernel<false>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lk, has_loss, aq, 1, g2, gx);
         };
         for (int v = 0; v < 3; ++v) {     // 0 first, 1 middle, 2 last
           std::vector<Op>& dst = v == 0 ? ops_pf_first : (v == 1 ? ops_pf_mid : ops_pf_last);

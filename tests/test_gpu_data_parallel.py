@@ -162,6 +162,7 @@ def _rank_ordered_reference(case, lo, hi, world, group_steps):
 
 
 def _ingraph_worker(rank, world, port, out_dir):
+    t_entry = time.time()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["GRL_TUNE"] = "dp_timeout_ms=20000"
@@ -183,9 +184,10 @@ def _ingraph_worker(rank, world, port, out_dir):
         # the smallest SAC there is: a bucket of 84 floats -- not a multiple of 4 * world, rank 6's chunk short, rank 7's EMPTY
         # (capi.inl: chunk = rup(ceil(n / world), 4))
         cases["tiny"] = pu.make_case(extractor="mlp", obs_dim=1, act_dim=1, layers=(4,), B=B, n_replay=48, n_steps=STEPS)
-    t_start = time.time()
+    t_start = float(os.environ.get("GRL_TEST_T0", t_entry))      # (the parent's clock just before mp.spawn)
     stamp = (lambda what: print("[W=%d rank 0] %6.1f s  %s" % (world, time.time() - t_start, what), flush=True)) \
         if rank == 0 and os.environ.get("GRL_TEST_TIMING") == "1" else (lambda what: None)
+    stamp("worker entered %.1f s after the spawn; process group + cases ready" % (t_entry - t_start))
     for cname, case in cases.items():
         stamp("case " + cname)
         cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
@@ -241,7 +243,9 @@ def _ingraph_worker(rank, world, port, out_dir):
             for k in P:
                 assert np.array_equal(P[k], finals[0][k]), "variants differ after the device-RNG updates: " + k
         np.savez(os.path.join(out_dir, "ig_%s_%d.npz" % (cname, rank)), **{k.replace("/", "|"): v for k, v in finals[0].items()})
+    stamp("all cases done")
     dist.destroy_process_group()
+    stamp("process group destroyed")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -423,7 +427,10 @@ def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    os.environ["GRL_TEST_T0"] = repr(time.time())
     mp.spawn(_ingraph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    if os.environ.get("GRL_TEST_TIMING") == "1":
+        print("[W=%d parent] %6.1f s  spawn joined" % (world, time.time() - float(os.environ["GRL_TEST_T0"])), flush=True)
     for cname in ("cnn", "tiny") if world >= 8 else ("cnn",):
         parts = [np.load(os.path.join(str(tmp_path), "ig_%s_%d.npz" % (cname, r))) for r in range(world)]
         for p in parts[1:]:
