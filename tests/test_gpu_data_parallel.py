@@ -23,9 +23,15 @@ def _case():
     return pu.make_case(extractor="augmented", kind="depth", B=B, n_replay=48, n_steps=STEPS)
 
 
+def _init_gloo(rank, world, out_dir):
+    """gloo over a FILE store: the TCP store's accept path looks every client's host name up, and on the GPU boxes (no resolver)
+    each lookup waits for its time-out -- eight ranks spent 122 s of a 135 s test in `init_process_group` (stamps: GRL_TEST_TIMING)."""
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "gloo_store"), rank=rank, world_size=world)
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_gloo(rank, world, out_dir)
     from grasp_rl.parallel import DataParallelSac
     case = _case()
     cfg = _capi.GrlConfig.from_buffer_copy(case["cfg"])
@@ -166,7 +172,7 @@ def _ingraph_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["GRL_TUNE"] = "dp_timeout_ms=20000"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_gloo(rank, world, out_dir)
     from grasp_rl.parallel import DataParallelInGraph, DataParallelSac
     B = max(16, 4 * world)      # (a per-rank minibatch of at least 4 rows: below that the dense weight gradients leave the
     #                              vectorised kernel and the plan has no staged form to overlap)
@@ -255,7 +261,7 @@ def _q_ingraph_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["GRL_TUNE"] = "dp_timeout_ms=20000"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_gloo(rank, world, out_dir)
     import q_parity_util as qu
     from grasp_rl.engine import GrlError
     from grasp_rl.parallel import DataParallelInGraph
@@ -442,7 +448,7 @@ def _timeout_worker(rank, world, port, out_dir, via="tune"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["GRL_TUNE"] = "dp_timeout_ms=1500" if via == "tune" else "dp_timeout_ms=100000"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_gloo(rank, world, out_dir)
     from grasp_rl._capi import GrlError
     from grasp_rl.parallel import DataParallelInGraph
     case = _case()
