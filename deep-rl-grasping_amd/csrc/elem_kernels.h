@@ -96,13 +96,7 @@ struct GatherArgs {
   // the float64 statistics of its element positions are fetched once, the `rows` replay reads are all in flight before the
   // first is used (gather_norm_rows_body); grid = tiles per row x (2 B / rows), linearised (gather_blocks)
   int rows;
-  // parts: 0 = everything (default); 1 = the image tiles only; 2 = the per-row extras only (direct features, action, reward,
-  // done, index, standard normals -- launched with gx = 1).  The double-buffered prefetch (plan_sac: "pf2") gathers the IMAGES
-  // of update t+1 on a side lane of the graph while update t's backward pass runs and leaves the extras, which that backward
-  // pass still reads, to the reduction launch that ends update t
-  int parts;
 };
-#define GATHER_SIDE_DEFAULT 1     /* double-buffered minibatch images, next gather on a side lane (GRL_TUNE gather_side=0: off) */
 #define GATHER_ROWS_U8 4          /* rows per workgroup of the grouped form, RGB-D ring with byte colours (GRL_TUNE gather_rows) */
 #define GATHER_ROWS_F32 1         /* float32 rings: one row per workgroup measured fastest (profiles/r06_sweep_gather_rows.txt) */
 // workgroups of a gather launch with gx tiles per row
@@ -199,8 +193,7 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
     src = a.idx[b];
   }
 #ifndef GRL_HOSTEMU
-  if (a.parts == 2) {
-  } else if (a.vec4) {
+  if (a.vec4) {
     typedef float gn_f4 __attribute__((ext_vector_type(4)));
     typedef double gn_d4 __attribute__((ext_vector_type(4)));
     const int e4 = (bx * 256 + threadIdx.x) * 4;
@@ -253,7 +246,7 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
     }
   }
   }
-  if (bx == 0 && a.parts != 1) {
+  if (bx == 0) {
     const int t = threadIdx.x;
     if (t < a.n_direct) {
       const float* rp = which ? a.rp_dnext : a.rp_dobs;
@@ -302,7 +295,7 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
   }
   // rng_step itself is advanced by the (single-workgroup) loss reduction later in the update: a counter
   // bumped by the last of these 8192 workgroups would serialise 8192 same-address atomics (~100 us)
-  if (bx == 0 && b == 0 && which == 0 && threadIdx.x == 0 && !a.quiet && a.parts != 1) {
+  if (bx == 0 && b == 0 && which == 0 && threadIdx.x == 0 && !a.quiet) {
     if (a.use_rng) a.sc->rng_used = 1u;
     if (a.adam_tick) adam_tick_device(a.sc);
   }
@@ -384,7 +377,7 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
     src[r] = (int64_t)(((uint64_t)hi << 32) | lo);
   }
   const int e4 = (bx * 256 + (int)threadIdx.x) * 4;
-  if (e4 < a.img_elems && a.parts != 2) {
+  if (e4 < a.img_elems) {
     const float* rp = which ? a.rp_next : a.rp_obs;
     gn_f4 x[R];
     if (a.rgb_u8) {            // one pixel per thread: colours from the packed dword, depth from the float plane
@@ -431,7 +424,7 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
       }
     }
   }
-  if (bx == 0 && a.parts != 1) {
+  if (bx == 0) {
 #pragma unroll 1
     for (int r = 0; r < R; ++r) gather_row_extras(a, b0 + r, which, src[r], step);
     if (grp == 0 && threadIdx.x == 0 && !a.quiet) {

@@ -280,14 +280,7 @@ struct grl_ctx {
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
   // SAC, calls of several updates on the device RNG: the next minibatch is gathered inside the last launch of an update
   std::vector<Op> ops_pf_first, ops_pf_mid, ops_pf_last;
-  // "pf2": the same three kinds of update with the minibatch IMAGES double buffered (x_obs / x_obs_b; flavour f reads buffer f
-  // and gathers update t+1's images into the other one on a side lane of the graph, forked behind the head launch)
-  std::vector<Op> ops_pf2_first, ops_pf2_mid[2], ops_pf2_last[2];
-  bool pf2_ok = false;
-  float* x_obs_b = nullptr;
-  Op wgrad_conv_alt;                    // the merged weight-gradient launch with conv1's operand in x_obs_b
-  ConvStackArgs pf2_conv_args;          // arguments of the forward stack as planned (reading x_obs)
-  bool have_wgrad_conv_alt = false;
+  bool ae_fused_adam = false;           // auto-encoder step: reduction + Keras-Adam as one launch (plan_ae)
   Op pf_heads[2];
   GatherArgs pf_ga;
   int pf_gx = 0;

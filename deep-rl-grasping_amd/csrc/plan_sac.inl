@@ -72,7 +72,6 @@ int grl_ctx::plan_sac() {
   if (cnn) {
     x_obs = wk.f32((int64_t)B * img_elems);
     x_next = wk.f32((int64_t)B * img_elems);
-    x_obs_b = tune_int("gather_side", GATHER_SIDE_DEFAULT) != 0 ? wk.f32((int64_t)B * img_elems) : nullptr;   // second image buffer ("pf2")
     // Layer-1 activations of the two TRAINED networks (and their gradients below) sit side by side, pixel stride 64:
     // pi in columns 0..31, values_fn in 32..63.  Both networks read the same observations, so conv1's weight
     // gradient becomes ONE product obs-patches^T x [dY_pi | dY_vf] (N = 64: full 64x64 tiles, the gathered patches
@@ -224,7 +223,6 @@ int grl_ctx::plan_sac() {
       op.flops = op.flops_exec = 2.0 * B * 3 * (225.0 * 32 * 64 * Ci + 36.0 * 64 * 512 + 16.0 * 64 * 576);
       op.run = [ca, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, ca, s); };
       ops_grads.push_back(op);
-      pf2_conv_args = ca;
     } else {
     const char* tags[3] = {"conv1_fwd", "conv2_fwd", "conv3_fwd"};
     for (int l = 0; l < 3; ++l) {
@@ -685,14 +683,6 @@ int grl_ctx::plan_sac() {
       for (int l = 2; l >= 0; --l) all.insert(all.end(), wgc[l].begin(), wgc[l].end());
       all.insert(all.end(), wg_merged.begin(), wg_merged.end());
       add_launch(wgrad_ops, "wgrad_conv", 2, all);
-      if (x_obs_b && cnn) {      // the same launch reading conv1's input from the second image buffer (flavour 1 of "pf2")
-        bool patched = false;
-        for (auto& p : all)
-          if (p.p_base[0] == x_obs) { p.p_base[0] = x_obs_b; patched = true; }
-        std::vector<Op> tmp;
-        if (patched) add_launch(tmp, "wgrad_conv", 2, all);
-        if (tmp.size() == 1) { wgrad_conv_alt = tmp[0]; have_wgrad_conv_alt = true; }
-      }
     }
   }
   // ---- schedule: every weight-gradient launch directly behind the last producer of its operands
@@ -841,63 +831,6 @@ int grl_ctx::plan_sac() {
         }
         pf_lk = lk; pf_g2 = g2;     // (the data-parallel update builds its own final launches from these at connect)
         prefetch_ok = true;
-        // ---- "pf2": the IMAGES of update t+1 gathered on a side lane while update t's backward pass runs.  What the gather
-        // writes and update t still reads after its forward pass: x_obs (conv1's weight gradient, in the last GEMM launch) --
-        // double buffered, flavour f reads buffer f and gathers into the other; x_next (read by the forward stack only) needs
-        // no second copy; the per-row extras (direct features, action, reward, done: read by the dense weight gradients) stay
-        // with the reduction launch that ends the update, as a gather of parts = 2.  The side lane forks behind the head launch
-        // (which advances the Philox counter the gather draws with) and is joined by the reduction launch: the gather runs in
-        // the shadow of heads_dfeat / fc_bwd / the convolution backward, launches that leave most wave slots empty.
-        if (x_obs_b && conv_stack && have_wgrad_conv_alt && !conv_stack_bwd) {
-          Op conv_alt;                                 // the forward stack reading the observations from x_obs_b
-          bool have_conv_alt = false;
-          for (auto& o : ops_grads_apply)
-            if (o.tag == "conv_stack_fwd") {
-              ConvStackArgs cb = pf2_conv_args;
-              cb.nets[0].x = x_obs_b; cb.nets[1].x = x_obs_b;
-              const int Ci = C_img;
-              conv_alt = o;
-              conv_alt.run = [cb, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, cb, s); };
-              have_conv_alt = true;
-            }
-          if (have_conv_alt) {
-            GatherArgs gx2 = g2;                         // extras of update t+1, carried by update t's reduction launch
-            gx2.parts = 2;
-            Op rx; rx.tag = "reduce_adam";
-            rx.join = true;
-            rx.bytes = fo.bytes - (aq.skip_bucket ? (double)n_train * 4 : 0.0);
-            rx.run = [dr, d_rt, ntiles, lk, has_loss, aq, gx2](hipStream_t s) {
-              const dim3 grid(ntiles + has_loss + gather_blocks(gx2, 1));
-              if (gx2.rows > 1) hipLaunchKernelGGL(reduce_slabs_gather_kernel<true>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lk, has_loss, aq, 1, gx2, 1);
-              else hipLaunchKernelGGL(reduce_slabs_gather_kernel<false>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lk, has_loss, aq, 1, gx2, 1);
-            };
-            for (int f = 0; f < 2; ++f) {
-              GatherArgs gi = g2;                        // images of update t+1 into the buffer flavour f does NOT read
-              gi.parts = 1;
-              gi.x_obs = f ? x_obs : x_obs_b;
-              Op side_g; side_g.tag = "gather_norm";
-              side_g.bytes = ops_rng[0].bytes;
-              side_g.lane = 1; side_g.fork = true;
-              side_g.run = [gi, gx](hipStream_t s) {
-                if (gi.rows > 1) hipLaunchKernelGGL(gather_norm_lin_kernel, dim3(gather_blocks(gi, gx)), dim3(256), 0, s, gi, gx);
-                else hipLaunchKernelGGL(gather_norm_kernel, dim3(gx, gi.B, 2), dim3(256), 0, s, gi);
-              };
-              for (int v = (f ? 1 : 0); v < 3; ++v) {    // (the call's first update is always flavour 0)
-                const std::vector<Op>& src = v == 0 ? ops_pf_first : (v == 1 ? ops_pf_mid : ops_pf_last);
-                std::vector<Op>& dst = v == 0 ? ops_pf2_first : (v == 1 ? ops_pf2_mid[f] : ops_pf2_last[f]);
-                for (size_t k = 0; k < src.size(); ++k) {
-                  const bool last_op = k + 1 == src.size();
-                  if (src[k].tag == "conv_stack_fwd") dst.push_back(f ? conv_alt : src[k]);
-                  else if (src[k].tag == "wgrad_conv") dst.push_back(f ? wgrad_conv_alt : src[k]);
-                  else if (last_op && v != 2) dst.push_back(rx);
-                  else dst.push_back(src[k]);
-                  if (src[k].tag == "heads" && v != 2) dst.push_back(side_g);
-                }
-              }
-            }
-            pf2_ok = true;
-          }
-        }
       }
     }
   }
