@@ -867,6 +867,8 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from grasp_rl.parallel import loopback_gloo
+        loopback_gloo()            # (single node: gloo on the loopback interface, no host-name lookups)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:

@@ -26,6 +26,7 @@ def _case():
 def _init_gloo(rank, world, out_dir):
     """gloo over a FILE store: the TCP store's accept path looks every client's host name up, and on the GPU boxes (no resolver)
     each lookup waits for its time-out -- eight ranks spent 122 s of a 135 s test in `init_process_group` (stamps: GRL_TEST_TIMING)."""
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (and gloo's own device: no lookup of the box's host name either)
     dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "gloo_store"), rank=rank, world_size=world)
 
 
