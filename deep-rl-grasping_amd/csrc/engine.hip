@@ -280,7 +280,6 @@ struct grl_ctx {
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
   // SAC, calls of several updates on the device RNG: the next minibatch is gathered inside the last launch of an update
   std::vector<Op> ops_pf_first, ops_pf_mid, ops_pf_last;
-  bool ae_fused_adam = false;           // auto-encoder step: reduction + Keras-Adam as one launch (plan_ae)
   Op pf_heads[2];
   GatherArgs pf_ga;
   int pf_gx = 0;

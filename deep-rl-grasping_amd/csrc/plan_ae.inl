@@ -162,16 +162,7 @@ int grl_ctx::plan_ae() {
     MseArgs ma{out, ae_x, g_out, partial, (long)B * 4096, g_pad, partial_g};
     const float lr = c.lr;
     DevScalars* scp = sc;
-    // d loss / d bias of the output convolution (sum of the output gradient): with the fused reduction + Adam launch below it
-    // travels as a one-element "slab" like every other gradient, otherwise it goes straight into the bucket
-    ae_fused_adam = tune_int("ae_fused_adam", 1) != 0;
-    float* gb6 = ae_fused_adam ? wk.f32(4) : grads + db[2];
-    if (ae_fused_adam) {
-      ReduceDesc rb;
-      memset(&rb, 0, sizeof(rb));
-      rb.src = gb6; rb.splits = 1; rb.slab_stride = 4; rb.dst = grads + db[2]; rb.n = 1;
-      reduces.push_back(rb);
-    }
+    float* gb6 = grads + db[2];
     elem("ae_mse", [=](hipStream_t s) {
       hipLaunchKernelGGL(mse_kernel, dim3(NPART), dim3(256), 0, s, ma);
       hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, (const float*)partial_g, NPART,
@@ -313,25 +304,11 @@ int grl_ctx::plan_ae() {
     ReduceDesc* dr = d_reduces;
     LossArgs none;
     memset(&none, 0, sizeof(none));
-    if (ae_fused_adam) {
-      // one launch: every trainable element = the sum of its slabs, Keras-Adam applied where the sum is formed (the step size of
-      // this update was fixed by ae_finish_kernel, several launches ago) -- reduce_slabs + adam were two launches, 38 us eager
-      AdamArgs aa;
-      aa.params = params; aa.grads = grads; aa.m = adam_m; aa.v = adam_v;
-      aa.n_train = n_train; aa.sc = sc; aa.grad_scale = 1.f; aa.tau = 0.f; aa.eps = 1e-7f;   // Keras epsilon
-      aa.src_ofs = 0; aa.n_polyak = 0; aa.target = params;
-      Op op; op.tag = "reduce_adam";
-      op.bytes = (double)n_train * 4 * 7;
-      op.run = [=](hipStream_t s) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0, aa, 1);
-      };
-      ops_ae.push_back(op);
-    } else
     elem("reduce_slabs", [=](hipStream_t s) {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ntiles), dim3(256), 0, s, dr, d_rt, ntiles, none, 0, AdamArgs{}, 0);
     });
   }
-  if (!ae_fused_adam) {
+  {
     grl_ctx* self = this;
     elem("adam", [self](hipStream_t s) {
       AdamArgs aa;

@@ -424,7 +424,7 @@ def test_bdq_learn_two_replicas_with_prioritised_replay_on_one_gpu(tmp_path):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
+def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world, monkeypatch):
     """W processes on the box's one MI355X map each other's exchange buffers (hipIpc) and run the data-parallel update with
     the hand-written all-reduces inside the graph -- one-shot, two-shot, two-shot with the dense bucket overlapped: each
     bit-identical to the rank-ordered float32 sum formed on the host (for W = 2 also to the gloo exchange), the replicas
@@ -435,6 +435,10 @@ def test_in_graph_exchange_processes_on_one_gpu(tmp_path, world):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.environ["GRL_TEST_T0"] = repr(time.time())
+    # (the workers build their cases with NumPy: orthogonal initialisation = an SVD of the 1024 x 512 dense kernels.  Eight
+    # processes x one BLAS thread per core of a 256-core box spent 97 of the test's 115 s there: GRL_TEST_TIMING stamps)
+    monkeypatch.setenv("OMP_NUM_THREADS", "4")
+    monkeypatch.setenv("OPENBLAS_NUM_THREADS", "4")
     mp.spawn(_ingraph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     if os.environ.get("GRL_TEST_TIMING") == "1":
         print("[W=%d parent] %6.1f s  spawn joined" % (world, time.time() - float(os.environ["GRL_TEST_T0"])), flush=True)
