@@ -16,6 +16,11 @@ import parity_util as pu
 from grasp_rl import _capi
 
 pytestmark = pytest.mark.gpu
+# The spawned workers build their cases with NumPy (orthogonal initialisation = an SVD of the 1024 x 512 dense kernels): with
+# one BLAS thread per core of a 256-core box in each of 8 processes that took 97 s of a 115 s test (GRL_TEST_TIMING stamps);
+# inherited by the children, no effect on this process (its NumPy is already loaded)
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
 B, STEPS = 16, 3
 
 
