@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256) void gather_norm_kernel(GatherArgs a) {
   gather_norm_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 // linearised grid (gather_blocks): the grouped form
-__global__ __launch_bounds__(256) void gather_norm_lin_kernel(GatherArgs a, int gx) {
+// (8 waves per SIMD = 64 registers: the 2 048 workgroups of an RGB-D minibatch -- 16 tiles x 128 row groups -- then fit the
+//  chip's 2 048 slots in ONE round; at 69 registers, 7 per SIMD, the last 256 ran as a round of their own)
+__global__ __launch_bounds__(256, 8) void gather_norm_lin_kernel(GatherArgs a, int gx) {
   gather_norm_dispatch<true>(a, gx, (int)blockIdx.x);
 }
 #endif
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceDesc* __r
 // are memory / latency bound -- they overlap instead of paying two launches (engine.hip, "prefetch").
 #ifndef GRL_ELEM_TYPES_ONLY
 template <bool GROUPED>
-__global__ __launch_bounds__(256) void reduce_slabs_gather_kernel(const ReduceDesc* __restrict__ descs,
+__global__ __launch_bounds__(256, 8) void reduce_slabs_gather_kernel(const ReduceDesc* __restrict__ descs,
                                                                  const int2* __restrict__ tiles, int n_tiles,
                                                                  LossArgs la, int has_loss, AdamArgs aa, int fuse_adam,
                                                                  GatherArgs ga, int gx) {
