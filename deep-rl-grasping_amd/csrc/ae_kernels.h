@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void mse_kernel(MseArgs a) {
 // T[tap, p] = sum_c W[tap, c] u[p, c] (49 rows instead of N = 1; tap-major so that the reads below are
 // coalesced across the pixels of a wavefront and every T element is read exactly once) followed by
 //   out[n, oh, ow] = b + sum_{kh, kw} T[kh*7+kw, (n, oh+kh-3, ow+kw-3)]      (taps outside the image skipped)
+// half = 1: T was formed over the 32 x 32 pixels of the layer in front of the up-sampling (u[n, ih, iw] = h[n, ih / 2, iw / 2]):
+// the same 49 terms in the same order, read at the source pixel.
 __global__ __launch_bounds__(256) void ae_tapsum_kernel(const float* __restrict__ T, long ldT, const float* __restrict__ bias,
-                                                       float* __restrict__ out, long n_pix) {
+                                                       float* __restrict__ out, long n_pix, int half) {
   const long o = (long)blockIdx.x * 256 + threadIdx.x;
   if (o >= n_pix) return;
   const long n = o >> 12;
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(256) void ae_tapsum_kernel(const float* __restrict_
     for (int kw = 0; kw < 7; ++kw) {
       const int iw = ow + kw - 3;
       if (iw < 0 || iw > 63) continue;
-      s += T[(long)(kh * 7 + kw) * ldT + (n << 12) + (ih << 6) + iw];
+      s += half ? T[(long)(kh * 7 + kw) * ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)]
+                : T[(long)(kh * 7 + kw) * ldT + (n << 12) + (ih << 6) + iw];
     }
   }
   out[o] = s + bias[0];
@@ -143,9 +146,11 @@ __global__ __launch_bounds__(256) void ae_out_kernel_flip(const float* __restric
 __global__ __launch_bounds__(256) void ae_kernel_prep(const float* __restrict__ W6, float* __restrict__ W6p, int C6,
                                                      const float* __restrict__ W1, float* __restrict__ W1p, int C1) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < 7 * 8 * C6) {
+  if (e < 7 * 8 * C6) {       // (four copies one after the other: the folded backward-data GEMM walks the kernel once per 2 x 2 sub-position)
     const int c = e % C6, j = (e / C6) % 8, kh = e / (8 * C6);
-    W6p[e] = j == 0 ? 0.f : W6[(kh * 7 + (7 - j)) * C6 + c];
+    const float v = j == 0 ? 0.f : W6[(kh * 7 + (7 - j)) * C6 + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) W6p[e + k * 7 * 8 * C6] = v;
   }
   if (e < 7 * 8 * C1) {
     const int c = e % C1, j = (e / C1) % 8, kh = e / (8 * C1);

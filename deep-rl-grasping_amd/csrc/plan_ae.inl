@@ -96,7 +96,7 @@ int grl_ctx::plan_ae() {
     });
   };
   // =============================================================== forward
-  float* W6p = wk.f32(56 * 32);       // output kernel flipped + padded (backward-data of the output convolution, below)
+  float* W6p = wk.f32(4 * 56 * 32);   // output kernel flipped + padded, four copies (backward-data of the output convolution, below)
   float* W1p = wk.f32(56 * 32);       // first encoder kernel, rows padded to 8 taps (its forward, here)
   {
     const float *W6 = P + dw[2], *W1 = P + ew[0];
@@ -140,16 +140,20 @@ int grl_ctx::plan_ae() {
   up(d4, u5, 16, 2);
   add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u5, ftd[1], gdv[1], P + dw[1], P + db[1], d5, ACT_LEAKY, LA)});
   up(d5, u6, 32, 0);
-  // output conv (7x7 'same', 32 -> 1): N = 1 wastes the matrix cores, so T[tap, p] = W[tap, :] . u6[p, :] as a
-  // GEMM with M = 49, then a 49-tap gather-sum (ae_kernels.h: ae_tapsum_kernel)
-  const long ldT = (long)B * 4096;
+  // output conv (7x7 'same', 32 -> 1): N = 1 wastes the matrix cores, so T[tap, p] = W[tap, :] . u[p, :] as a GEMM with
+  // M = 49, then a 49-tap gather-sum (ae_kernels.h: ae_tapsum_kernel).  u6 is d5 with every pixel repeated 2 x 2
+  // (UpSampling2D), so T is formed over the pixels of d5 -- a quarter of the columns, the same products -- and the gather-sum
+  // reads T at (ih / 2, iw / 2): 51.9 -> ~13 us for the GEMM (round 5: over the 4096 pixels of u6; GRL_TUNE ae_lowres=0)
+  const bool lowres = tune_int("ae_lowres", 1) != 0;
+  const long ldT = (long)B * (lowres ? 1024 : 4096);
   float* Tt = wk.f32(49 * ldT);
-  add_launch(ops_ae, "ae_out_conv", 1, {dense_bwd({{P + dw[2], 32, 32, u6}}, 49, 0, B * 4096, Tt, (int)ldT, nullptr)});
+  add_launch(ops_ae, "ae_out_conv", 1, {dense_bwd({{P + dw[2], 32, 32, lowres ? d5 : u6}}, 49, 0, (int)ldT, Tt, (int)ldT, nullptr)});
   {
     const long npix = (long)B * 4096;
     const float* b6 = P + db[2];
+    const int half = lowres ? 1 : 0;
     elem("ae_out_tapsum", [=](hipStream_t s) {
-      hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix);
+      hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix, half);
     });
   }
   ae_out = out;
@@ -210,7 +214,31 @@ int grl_ctx::plan_ae() {
     add_wgrad(one, p, dw[2], 0, 49, -1);
     add_launch(ops_ae, "ae_out_wgrad", 0, one);
   }
-  {
+  if (lowres) {
+    // backward-data of the output conv AND of the up-sampling in front of it, in one product: the gradient of a pixel q of d5 is
+    // the sum over its 2 x 2 pixels of u6, each the 7 x 8-tap product of the round-5 launch --
+    //   g_d5[q, c] = LeakyReLU'(d5[q, c]) * sum_{s in 2x2} sum_{kh, j} g_pad[pix(2 q + s) - shift(kh, j)] Wp[(kh, j), c]
+    // a GEMM with M = pixels of d5, N = 32, K = 4 x 56 (the flipped, padded kernel repeated for the four sub-positions:
+    // ae_kernel_prep), the LeakyReLU gradient in its epilogue.  g_u6 -- 67 MB written by one launch and read back by the next at
+    // B = 128 -- no longer exists, and neither does that up-sampling backward launch.
+    float* Wp = W6p;                  // (written by ae_kernel_prep at the start of the step: four copies)
+    std::vector<int32_t> ti((size_t)B * 1024), tr(224);
+    for (int n = 0; n < B; ++n)
+      for (int qy = 0; qy < 32; ++qy)
+        for (int qx = 0; qx < 32; ++qx) ti[((size_t)n * 32 + qy) * 32 + qx] = n * 4900 + (2 * qy + 6) * 70 + (2 * qx + 6);
+    for (int sp = 0; sp < 4; ++sp)
+      for (int kh = 0; kh < 7; ++kh)
+        for (int j = 0; j < 8; ++j) tr[sp * 56 + kh * 8 + j] = (sp >> 1) * 70 + (sp & 1) - kh * 70 - 7 + j;
+    IgemmProb p = blank();
+    p.M = B * 1024; p.N = 32; p.K = 224;
+    p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
+    p.vflags |= VF_P_TABS;                       // 4-runs along the taps, dword-aligned offsets
+    p.q_base[0] = Wp; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
+    p.c = g_d5; p.ldc = 32;
+    p.relu_mask = d5; p.act_alpha = LA;
+    set_split(p, 1);
+    add_launch(ops_ae, "ae_out_conv_bwd", 0, {p});
+  } else {
     // backward-data of the output conv: g_u6[p, c] = sum_{kh,kw} g_pad[p - shift(kh,kw)] W[kh,kw,c], a GEMM with
     // M = pixels, N = 32, K = 7 x 8 taps (each kernel row flipped and padded to 8: ae_kernels.h) on the
     // vectorised kernel -- the taps of a quad are 4 neighbouring gradient pixels
@@ -229,8 +257,8 @@ int grl_ctx::plan_ae() {
     p.c = g_u6; p.ldc = 32;
     set_split(p, 1);
     add_launch(ops_ae, "ae_out_conv_bwd", 0, {p});
+    up_bwd(g_u6, d5, g_d5, 32);
   }
-  up_bwd(g_u6, d5, g_d5, 32);
   cw(u5, ftd[1], gdv[1], g_d5, dw[1], db[1], 32);
   cb("ae_dec_conv_bwd", g_d5, gd[1], P + dw[1], g_u5, nullptr);
   up_bwd(g_u5, d4, g_d4, 16);
