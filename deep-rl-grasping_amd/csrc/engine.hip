@@ -135,6 +135,7 @@ struct ConvBwdClass {
   int M, K;
   bool vec4_p, vec4_q;
   float alg_frac = 1.f;   // existing (row, tap) pairs / (M * tap positions): what the masked form multiplies that is not zero
+  std::vector<int32_t> ct_host;   // host copy of c_tab_i (plans that derive a second row table from it: IgemmProb.m_tab_i)
 };
 
 struct Launch {
@@ -281,6 +282,7 @@ struct grl_ctx {
   // SAC, calls of several updates on the device RNG: the next minibatch is gathered inside the last launch of an update
   std::vector<Op> ops_pf_first, ops_pf_mid, ops_pf_last;
   Op pf_heads[2];
+  float* ae_gp4 = nullptr;               // auto-encoder step: the output gradient's four sub-position planes (plan_ae, MseArgs.gp4)
   GatherArgs pf_ga;
   int pf_gx = 0;
   bool prefetch_ok = false;
@@ -604,6 +606,7 @@ struct grl_ctx {
         c.tab_r = upload_vec(wk, tr);
         c.q_tab_r = upload_vec(wk, qt);
         c.c_tab_i = upload_vec(wk, ct);
+        c.ct_host = ct;
         c.vmask = upload_vec(wk, vm);
         c.tap = upload_vec(wk, tp);
         out.push_back(c);
@@ -677,6 +680,7 @@ struct grl_ctx {
         c.tab_r = upload_vec(wk, tr);
         c.q_tab_r = upload_vec(wk, qt);
         c.c_tab_i = upload_vec(wk, ct);
+        c.ct_host = ct;
         c.vmask = nullptr;
         c.tap = nullptr;
         out.push_back(c);
@@ -935,7 +939,8 @@ struct grl_ctx {
     if (l->v2)   // outputs that can leave as 16-byte stores (igemm2 wide epilogue)
       for (auto& p : l->probs)
         if (al16(p.c) && (p.ldc % 4) == 0 && (p.N % 4) == 0 && (p.slab_stride % 4) == 0 &&
-            (!p.c_tab_i || (p.vflags & VF_CT4)) && (!p.relu_mask || al16(p.relu_mask)) && (!p.bias || al16(p.bias)))
+            (!p.c_tab_i || (p.vflags & VF_CT4)) && (!p.m_tab_i || (p.vflags & VF_CT4)) && (!p.relu_mask || al16(p.relu_mask)) &&
+            (!p.bias || al16(p.bias)))
           p.vflags |= VF_C_VEC;
     // short reductions with a narrow output (first convolution of the extractors): streaming kernel, igemm_sk.h
     {

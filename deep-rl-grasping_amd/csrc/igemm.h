@@ -55,6 +55,8 @@ struct IgemmProb {
   int64_t slab_stride;    // floats between split slabs
   const float* bias;      // + bias[j]
   const float* relu_mask; // value kept where relu_mask[same offset as c] > 0, scaled by act_alpha elsewhere (0: ReLU)
+  const int32_t* m_tab_i; // optional row offsets of relu_mask (mask element of (i, j) = relu_mask[m_tab_i[i] + j]): the mask lives
+                          // in another layout than c (auto-encoder: activations kept only in their zero-bordered form)
   int32_t act;
   float act_alpha;
   int32_t accumulate;     // += existing c
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
   const gci32 cT = (gci32)pb->c_tab_i;
   const gcf32 bias = (gcf32)pb->bias;
   const gcf32 rmask = (gcf32)pb->relu_mask;
+  const gci32 mT = (gci32)pb->m_tab_i;
   const int act = pb->act;
   const float alpha = pb->act_alpha;
   const int accumulate = pb->accumulate;
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmProb* __restrict_
       if (accumulate) v += cbase[off];
       if (act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-      if (rmask) v = rmask[off] > 0.f ? v : alpha * v;
+      if (rmask) v = rmask[mT ? (long)mT[i] + j : off] > 0.f ? v : alpha * v;
       cbase[off] = v;
     }
   }

@@ -329,6 +329,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   const gci32 cT = (gci32)pb->c_tab_i;
   const gcf32 bias = (gcf32)pb->bias;
   const gcf32 rmask = (gcf32)pb->relu_mask;
+  const gci32 mT = (gci32)pb->m_tab_i;
   const int act = pb->act;
   const float alpha = pb->act_alpha;
   const int accumulate = pb->accumulate;
@@ -337,14 +338,21 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
   // after the loop they sit in front of the ReLU-mask loads that need them -- two dependent round trips per tile
   const bool cvec = (pb->vflags & VF_C_VEC) != 0;
   constexpr int EP_NC4 = BN / 4, EP_RSTEP = 256 / EP_NC4, EP_NQ = BM / EP_RSTEP;
-  int ct_pre[EP_NQ];
+  int ct_pre[EP_NQ], mt_pre[EP_NQ];
 #pragma unroll
-  for (int e = 0; e < EP_NQ; ++e) ct_pre[e] = 0;
+  for (int e = 0; e < EP_NQ; ++e) ct_pre[e] = mt_pre[e] = 0;
   if (cT && cvec) {
 #pragma unroll
     for (int e = 0; e < EP_NQ; ++e) {
       const int i = i0 + t / EP_NC4 + e * EP_RSTEP;
       ct_pre[e] = cT[i < M ? i : 0];
+    }
+  }
+  if (mT && cvec) {      // (the ReLU mask's own row offsets, IgemmProb.m_tab_i)
+#pragma unroll
+    for (int e = 0; e < EP_NQ; ++e) {
+      const int i = i0 + t / EP_NC4 + e * EP_RSTEP;
+      mt_pre[e] = mT[i < M ? i : 0];
     }
   }
   I2_STAMP(1);
@@ -482,7 +490,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
     if (accumulate) v += cbase[off];
     if (act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-    if (rmask) v = rmask[off] > 0.f ? v : alpha * v;
+    if (rmask) v = rmask[mT ? (long)mT[i] + j : off] > 0.f ? v : alpha * v;
     cbase[off] = v;
   };
 
@@ -507,7 +515,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
     float mk[16], prev[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
-      mk[x] = (rmask && ok[x]) ? rmask[off[x]] : 1.f;
+      mk[x] = (rmask && ok[x]) ? rmask[mT ? (long)mT[iv[x]] + j : off[x]] : 1.f;
       prev[x] = (accumulate && ok[x]) ? cbase[off[x]] : 0.f;
     }
 #pragma unroll
@@ -552,7 +560,7 @@ __device__ __forceinline__ void igemm2_tile(const IgemmProb* __restrict__ pb, co
     for (int e = 0; e < NQ; ++e) {
       mk[e] = f32x4{1.f, 1.f, 1.f, 1.f};
       prev[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (rmask && ok[e]) mk[e] = *(const GRL_GLOBAL f32x4*)(rmask + off[e]);
+      if (rmask && ok[e]) mk[e] = *(const GRL_GLOBAL f32x4*)(rmask + (mT ? (long)mt_pre[e] + j : off[e]));
       if (accumulate && ok[e]) prev[e] = *(const GRL_GLOBAL f32x4*)(cbase + off[e]);
     }
 #pragma unroll

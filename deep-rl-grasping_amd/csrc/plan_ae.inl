@@ -60,7 +60,6 @@ int grl_ctx::plan_ae() {
   float *g_out = T(64, 1), *g_u6 = T(64, 32), *g_d5 = T(32, 32), *g_u5 = T(32, 32), *g_d4 = T(16, 32), *g_u4 = T(16, 32);
   float *g_dh = T(8, 32), *g_z = wk.f32((int64_t)B * 100), *g_e3 = T(8, 32), *g_e2 = T(16, 32), *g_e1 = T(32, 32);
   const int NPART = 256;
-  float* partial = wk.f32(NPART);
   // geometry: encoder convs 'SAME' stride 2 (TF asymmetric padding: low pad 2 / 1 / 0), decoder convs 'SAME' stride 1
   const ConvGeom ge[3] = {{64, 64, 1, 7, 7, 2, 2, 32, 32, 32}, {32, 32, 32, 5, 5, 2, 1, 16, 16, 32}, {16, 16, 32, 3, 3, 2, 0, 8, 8, 32}};
   const ConvGeom gd[3] = {{16, 16, 32, 3, 3, 1, 1, 16, 16, 32}, {32, 32, 32, 5, 5, 1, 2, 32, 32, 32}, {64, 64, 32, 7, 7, 1, 3, 64, 64, 1}};
@@ -100,15 +99,42 @@ int grl_ctx::plan_ae() {
   float* W1p = wk.f32(56 * 32);       // first encoder kernel, rows padded to 8 taps (its forward, here)
   {
     const float *W6 = P + dw[2], *W1 = P + ew[0];
+    // (one launch with the copy of the minibatch into its bordered buffer: ae_prep_pad_kernel)
+    const int n_prep = (56 * 32 + 255) / 256;
+    const long total = (long)B * 4096;
+    const float* xin = ae_x;
+    float* xpad = x_p;
     elem("ae_kernel_prep", [=](hipStream_t s) {
-      hipLaunchKernelGGL(ae_kernel_prep, dim3((56 * 32 + 255) / 256), dim3(256), 0, s, W6, W6p, 32, W1, W1p, 32);
+      hipLaunchKernelGGL(ae_prep_pad_kernel, dim3((unsigned)(n_prep + (total + 255) / 256)), dim3(256), 0, s, W6, W6p, 32, W1, W1p, 32,
+                         n_prep, xin, xpad, total, 64, 64, 1, 2, 3);
     });
   }
+  // Encoder activations e1 / e2 are consumed in their zero-bordered form (next convolution, weight gradient) and as the
+  // LeakyReLU mask of the backward-data launches.  ae_bordered (GRL_TUNE ae_bordered=0: off): the convolution that produces
+  // them writes the bordered layout directly (output row table, c_tab_i) and the backward-data launches read their mask through
+  // a row table of its own (IgemmProb.m_tab_i) -- the plain copies e1 / e2 and the two pad-copy launches (21 MB read +
+  // written at B = 128) disappear.
+  const bool bordered = tune_int("ae_bordered", 1) != 0;
+  auto bordered_rows = [&](int H, int lo, int hi, int C) {     // output pixel (n, oh, ow) -> its offset in [N, H+lo+hi, W+lo+hi, C]
+    std::vector<int32_t> ct((size_t)B * H * H);
+    const int Hp = H + lo + hi;
+    for (int n = 0; n < B; ++n)
+      for (int oh = 0; oh < H; ++oh)
+        for (int ow = 0; ow < H; ++ow) ct[((size_t)n * H + oh) * H + ow] = ((n * Hp + oh + lo) * Hp + ow + lo) * C;
+    return ct;
+  };
   {
     const float* in[3] = {x_p, e1_p, e2_p};
     float* o[3] = {e1, e2, e3};
-    padcp(ae_x, x_p, 64, 1, 2, 3);
-    for (int l = 0; l < 3; ++l) {
+    float* ob[3] = {e1_p, e2_p, nullptr};
+    const int oH[2] = {32, 16}, olo[2] = {1, 0}, ohi[2] = {2, 1};
+    auto to_bordered = [&](IgemmProb& p, int l) {
+      if (!bordered || l > 1) return;
+      p.c = ob[l];
+      p.c_tab_i = upload_vec(wk, bordered_rows(oH[l], olo[l], ohi[l], 32));
+      p.vflags |= VF_CT4;
+    };
+    for (int l = 0; l < 3; ++l) {      // (x_p was filled by the step's first launch)
       if (l == 0) {
         // 7 x 8 taps over the bordered 69 x 69 image (see ae_kernel_prep): the reduction index is (kh, j), j = 0 .. 7
         std::vector<int32_t> tr(57, 0);
@@ -118,13 +144,16 @@ int grl_ctx::plan_ae() {
         p.K = 56;
         p.p_tab_r = upload_vec(wk, tr);
         p.vflags |= VF_P_TABS;      // 4-runs along the taps at dword-aligned offsets (16-byte buffer loads take them on gfx950)
+        to_bordered(p, 0);
         add_launch(ops_ae, "ae_enc_conv", 0, {p});
-        padcp(e1, e1_p, 32, 32, 1, 2);
+        if (!bordered) padcp(e1, e1_p, 32, 32, 1, 2);
         continue;
       }
-      add_launch(ops_ae, "ae_enc_conv", 0, {conv_fwd(in[l], fte[l], gev[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA)});
-      if (l == 0) padcp(e1, e1_p, 32, 32, 1, 2);
-      if (l == 1) padcp(e2, e2_p, 16, 32, 0, 1);
+      IgemmProb p = conv_fwd(in[l], fte[l], gev[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA);
+      to_bordered(p, l);
+      add_launch(ops_ae, "ae_enc_conv", 0, {p});
+      if (l == 0 && !bordered) padcp(e1, e1_p, 32, 32, 1, 2);
+      if (l == 1 && !bordered) padcp(e2, e2_p, 16, 32, 0, 1);
     }
   }
   {
@@ -139,37 +168,56 @@ int grl_ctx::plan_ae() {
   add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u4, ftd[0], gdv[0], P + dw[0], P + db[0], d4, ACT_LEAKY, LA)});
   up(d4, u5, 16, 2);
   add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u5, ftd[1], gdv[1], P + dw[1], P + db[1], d5, ACT_LEAKY, LA)});
-  up(d5, u6, 32, 0);
+  const bool lowres = tune_int("ae_lowres", 1) != 0;
+  if (!lowres) up(d5, u6, 32, 0);       // (lowres: nothing reads the 64 x 64 x 32 up-sampled image any more -- 67 MB at B = 128)
   // output conv (7x7 'same', 32 -> 1): N = 1 wastes the matrix cores, so T[tap, p] = W[tap, :] . u[p, :] as a GEMM with
   // M = 49, then a 49-tap gather-sum (ae_kernels.h: ae_tapsum_kernel).  u6 is d5 with every pixel repeated 2 x 2
   // (UpSampling2D), so T is formed over the pixels of d5 -- a quarter of the columns, the same products -- and the gather-sum
   // reads T at (ih / 2, iw / 2): 51.9 -> ~13 us for the GEMM (round 5: over the 4096 pixels of u6; GRL_TUNE ae_lowres=0)
-  const bool lowres = tune_int("ae_lowres", 1) != 0;
   const long ldT = (long)B * (lowres ? 1024 : 4096);
   float* Tt = wk.f32(49 * ldT);
   add_launch(ops_ae, "ae_out_conv", 1, {dense_bwd({{P + dw[2], 32, 32, lowres ? d5 : u6}}, 49, 0, (int)ldT, Tt, (int)ldT, nullptr)});
+  // The forward pass ends with the 49-tap gather-sum; a TRAINING step forms the loss and the output gradient in the same launch
+  // (ae_tapsum_mse_kernel: one launch and 6 us less; GRL_TUNE ae_fused_mse=0: two launches), the forward-only path
+  // (Model.predict / evaluate) ends with the plain gather-sum.
+  const long npix = (long)B * 4096;
+  const bool fused_mse = tune_int("ae_fused_mse", 1) != 0;
+  const int n_part = fused_mse ? (int)((npix + 255) / 256) : NPART;
   {
-    const long npix = (long)B * 4096;
     const float* b6 = P + db[2];
     const int half = lowres ? 1 : 0;
-    elem("ae_out_tapsum", [=](hipStream_t s) {
+    Op op; op.tag = "ae_out_tapsum";
+    op.run = [=](hipStream_t s) {
       hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix, half);
-    });
+    };
+    ae_out = out;
+    ops_ae_fwd = ops_ae;            // everything so far + the gather-sum: the forward pass
+    ops_ae_fwd.push_back(op);
+    if (!fused_mse) ops_ae.push_back(op);
   }
-  ae_out = out;
-  ops_ae_fwd = ops_ae;            // everything so far: the forward pass (Model.predict / evaluate)
   // =============================================================== loss
   {
     g_pad = wk.f32((int64_t)B * 4900);
     zero_once.push_back({g_pad, (size_t)B * 4900 * 4});   // the 3-pixel border stays zero
-    float* partial_g = wk.f32(NPART);
-    MseArgs ma{out, ae_x, g_out, partial, (long)B * 4096, g_pad, partial_g};
+    float* part = wk.f32(n_part);
+    float* partial_g = wk.f32(n_part);
+    float* gp4 = nullptr;
+    if (lowres) {
+      gp4 = wk.f32((int64_t)4 * B * 1296);
+      zero_once.push_back({gp4, (size_t)4 * B * 1296 * 4});   // the 2-pixel borders stay zero
+    }
+    ae_gp4 = gp4;
+    MseArgs ma{out, ae_x, g_out, part, npix, g_pad, partial_g, gp4, (long)B * 1296};
     const float lr = c.lr;
     DevScalars* scp = sc;
     float* gb6 = grads + db[2];
-    elem("ae_mse", [=](hipStream_t s) {
-      hipLaunchKernelGGL(mse_kernel, dim3(NPART), dim3(256), 0, s, ma);
-      hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, (const float*)partial_g, NPART,
+    TapMseArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.T = Tt; ta.ldT = ldT; ta.bias = P + db[2]; ta.n_pix = npix; ta.half = lowres ? 1 : 0; ta.m = ma;
+    elem(fused_mse ? "ae_out_tapsum_mse" : "ae_mse", [=](hipStream_t s) {
+      if (fused_mse) hipLaunchKernelGGL(ae_tapsum_mse_kernel, dim3(n_part), dim3(256), 0, s, ta);
+      else hipLaunchKernelGGL(mse_kernel, dim3(n_part), dim3(256), 0, s, ma);
+      hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)part, (const float*)partial_g, n_part,
                          ma.n_total, lr, scp, gb6);
     });
   }
@@ -180,39 +228,98 @@ int grl_ctx::plan_ae() {
     p.c = wk.f32(p.slab_stride * p.split);
     add_wgrad(wgc, p, w_off, 0, g.K(), b_off);
   };
-  auto cb = [&](const char* tag, const float* gy, const ConvGeom& g, const float* w, float* dx, const float* mask) {
+  // mask_lo / mask_hi >= 0: `mask` is the zero-bordered form of the activations ([N, H+lo+hi, W+lo+hi, C]); its rows are found
+  // through a table derived from the class's output row table (offsets in the plain [N, H, W, C] layout of dx)
+  auto cb = [&](const char* tag, const float* gy, const ConvGeom& g, const float* w, float* dx, const float* mask,
+                int mask_lo = -1, int mask_hi = -1) {
     std::vector<IgemmProb> pr;
     for (auto& cl : conv_bwd_tabs(g, B)) {
       IgemmProb p = conv_bwd(gy, cl, g, w, dx, mask);
       p.act_alpha = LA;                                  // LeakyReLU gradient where a mask is given
+      if (mask && mask_lo >= 0) {
+        std::vector<int32_t> mt(cl.ct_host.size());
+        const int Hp = g.H + mask_lo + mask_hi, Wp = g.W + mask_lo + mask_hi;
+        for (size_t i = 0; i < mt.size(); ++i) {
+          const int ct = cl.ct_host[i];
+          if (ct < 0) { mt[i] = 0; continue; }            // (row not stored: its mask is never read)
+          const int pix = ct / g.C, n = pix / (g.H * g.W), y = (pix / g.W) % g.H, x = pix % g.W;
+          mt[i] = ((n * Hp + y + mask_lo) * Wp + x + mask_lo) * g.C;
+        }
+        p.m_tab_i = upload_vec(wk, mt);
+      }
       pr.push_back(p);
     }
     add_launch(ops_ae, tag, 1, pr);
   };
-  // output conv (7x7, 32 -> 1): dW[tap, c] = sum_p g[p - shift(tap)] u6[p, c] -- a GEMM with M = 49 taps, N = 32
-  // channels, K = pixels; g is read from its zero-bordered copy so that no tap needs a mask.  (Its bias
-  // gradient, sum g, comes from the MSE kernel.)
-  {
-    std::vector<int32_t> ti(49), tr((size_t)B * 4096);
-    for (int kh = 0; kh < 7; ++kh)
-      for (int kw = 0; kw < 7; ++kw) ti[kh * 7 + kw] = -((kh - 3) * 70 + (kw - 3));
+  if (lowres) {
+    // output conv (7x7, 32 -> 1), weight gradient: dW[tap, c] = sum_p g[p - shift(tap)] u6[p, c] with u6[p] = d5[p / 2]:
+    //   dW[tap, c] = sum over the four sub-positions s of a 2 x 2 block, sum over pixels q of d5:  g[2 q + s - shift(tap)] d5[q, c]
+    // -- four GEMMs (M = 49 taps, N = 32 channels, K = pixels of d5) whose P operand walks ONE sub-position plane of the
+    // de-interleaved output gradient (MseArgs.gp4) with unit stride: for (s, tap), t = s - shift lands in plane (t mod 2) at
+    // offset floor(t / 2).  Same products as over u6, which is no longer formed; the 4 x 64 slabs are summed as one list.
+    std::vector<int32_t> tr((size_t)B * 1024);
     for (int n = 0; n < B; ++n)
-      for (int oh = 0; oh < 64; ++oh)
-        for (int ow = 0; ow < 64; ++ow) tr[((size_t)n * 64 + oh) * 64 + ow] = n * 4900 + (oh + 3) * 70 + (ow + 3);
-    IgemmProb p = blank();
-    p.M = 49; p.N = 32; p.K = B * 4096;
-    p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
-    p.q_base[0] = u6; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
-    p.ldc = 32;
-    // 4-runs along the pixel index (rows are 64 pixels, quads never straddle one) at offsets that are only
-    // 4-byte aligned: 16-byte buffer loads need no more than dword alignment
-    // (measured: the gfx950 buffer_load_dwordx4 takes them, results match the oracle; 103 -> 50 us)
-    p.vflags |= VF_P_TABS;
-    set_split(p, 256);
-    p.c = wk.f32(p.slab_stride * p.split);
-    std::vector<IgemmProb> one;
-    add_wgrad(one, p, dw[2], 0, 49, -1);
-    add_launch(ops_ae, "ae_out_wgrad", 0, one);
+      for (int qy = 0; qy < 32; ++qy)
+        for (int qx = 0; qx < 32; ++qx) tr[((size_t)n * 32 + qy) * 32 + qx] = n * 1296 + (qy + 2) * 36 + (qx + 2);
+    const int32_t* d_tr = upload_vec(wk, tr);
+    const long plane = (long)B * 1296;
+    std::vector<IgemmProb> four;
+    float* slabs = nullptr;
+    int per = 0;
+    int64_t sstride = 0;
+    for (int sp = 0; sp < 4; ++sp) {
+      std::vector<int32_t> ti(49);
+      for (int kh = 0; kh < 7; ++kh)
+        for (int kw = 0; kw < 7; ++kw) {
+          const int ty = (sp >> 1) - (kh - 3), tx = (sp & 1) - (kw - 3);
+          const int py = ty & 1, px = tx & 1, oy = (ty - py) / 2, ox = (tx - px) / 2;       // t = 2 o + p, p in {0, 1}
+          ti[kh * 7 + kw] = (int32_t)((py * 2 + px) * plane + oy * 36 + ox);
+        }
+      IgemmProb p = blank();
+      p.M = 49; p.N = 32; p.K = B * 1024;
+      p.p_base[0] = ae_gp4; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = d_tr; single_part(p);
+      p.q_base[0] = d5; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
+      p.ldc = 32;
+      p.vflags |= VF_P_TABS;       // 4-runs along the pixel index: rows of 32 pixels, quads never straddle one
+      set_split(p, 64);
+      if (sp == 0) { per = p.split; sstride = p.slab_stride; slabs = wk.f32(sstride * per * 4); }
+      p.c = slabs + (int64_t)sp * per * sstride;
+      four.push_back(p);
+    }
+    {
+      ReduceDesc r;
+      memset(&r, 0, sizeof(r));
+      r.src = slabs; r.splits = 4 * per; r.slab_stride = sstride;
+      r.dst = grads + dw[2]; r.n = 49 * 32;
+      reduces.push_back(r);
+    }
+    add_launch(ops_ae, "ae_out_wgrad", 0, four, "", 0, {}, 3);      // (32 x 64 tiles, 2-way k split: 47.6 against 53.4 us for the N <= 32 default)
+  } else {
+    // output conv (7x7, 32 -> 1): dW[tap, c] = sum_p g[p - shift(tap)] u6[p, c] -- a GEMM with M = 49 taps, N = 32
+    // channels, K = pixels; g is read from its zero-bordered copy so that no tap needs a mask.  (Its bias
+    // gradient, sum g, comes from the MSE kernel.)
+    {
+      std::vector<int32_t> ti(49), tr((size_t)B * 4096);
+      for (int kh = 0; kh < 7; ++kh)
+        for (int kw = 0; kw < 7; ++kw) ti[kh * 7 + kw] = -((kh - 3) * 70 + (kw - 3));
+      for (int n = 0; n < B; ++n)
+        for (int oh = 0; oh < 64; ++oh)
+          for (int ow = 0; ow < 64; ++ow) tr[((size_t)n * 64 + oh) * 64 + ow] = n * 4900 + (oh + 3) * 70 + (ow + 3);
+      IgemmProb p = blank();
+      p.M = 49; p.N = 32; p.K = B * 4096;
+      p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
+      p.q_base[0] = u6; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
+      p.ldc = 32;
+      // 4-runs along the pixel index (rows are 64 pixels, quads never straddle one) at offsets that are only
+      // 4-byte aligned: 16-byte buffer loads need no more than dword alignment
+      // (measured: the gfx950 buffer_load_dwordx4 takes them, results match the oracle; 103 -> 50 us)
+      p.vflags |= VF_P_TABS;
+      set_split(p, 256);
+      p.c = wk.f32(p.slab_stride * p.split);
+      std::vector<IgemmProb> one;
+      add_wgrad(one, p, dw[2], 0, 49, -1);
+      add_launch(ops_ae, "ae_out_wgrad", 0, one);
+    }
   }
   if (lowres) {
     // backward-data of the output conv AND of the up-sampling in front of it, in one product: the gradient of a pixel q of d5 is
@@ -280,9 +387,11 @@ int grl_ctx::plan_ae() {
     add_launch(ops_ae, "ae_dense_bwd", 1, {b2});
   }
   cw(e2_p, fte[2], gev[2], g_e3, ew[2], eb[2], 4);
-  cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2);
+  if (bordered) cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2_p, 0, 1);
+  else cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2);
   cw(e1_p, fte[1], gev[1], g_e2, ew[1], eb[1], 16);
-  cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1);
+  if (bordered) cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1_p, 1, 2);
+  else cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1);
   {
     // weight gradient of the 1-channel first convolution (7x7, stride 2): rows = taps, each kernel row padded to 8
     // so that a quad of rows is 4 neighbouring pixels of the bordered image (16-byte loads at dword alignment);

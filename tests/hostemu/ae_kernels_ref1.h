@@ -11,6 +11,7 @@ inline void mse_kernel(MseArgs a) {
     const float g = 2.f * d / (float)a.n_total;
     a.g_out[i] = g;
     if (a.g_pad) a.g_pad[mse_pad_index(i)] = g;
+    if (a.gp4) a.gp4[mse_gp4_index(i, a.gp4_plane)] = g;
     s += d * d;
     sg += g;
   }

@@ -44,7 +44,7 @@ void igemm2_tile(const IgemmProb* probs, const int4 tl) {   // probs: THIS tile'
       if (pb.accumulate) v += cbase[off];
       if (pb.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (pb.act == ACT_LEAKY) v = v > 0.f ? v : pb.act_alpha * v;
-      if (pb.relu_mask) v = pb.relu_mask[off] > 0.f ? v : pb.act_alpha * v;
+      if (pb.relu_mask) v = pb.relu_mask[pb.m_tab_i ? (long)pb.m_tab_i[i] + j : off] > 0.f ? v : pb.act_alpha * v;
       cbase[off] = v;
     }
   };
