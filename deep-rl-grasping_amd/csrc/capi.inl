@@ -592,7 +592,13 @@ int grl_train_step_per(grl_handle h, int n_steps, double beta, const double* u) 
     return GRL_OK;
   }
   if (!u) {        // device Philox: identical updates, several to a graph
-    if (n_steps >= 2 && !h->ops_grads_apply_per_r.empty() && !h->prof) {
+    if (n_steps >= 2 && h->per_pf_ok && !h->prof) {
+      // four launches per update (plan_q "per_pf"): the sampler of update t + 1 rides on the launch that ends update t
+      if (int e = h->run_seq("per_pf_first", {&h->ops_per_pf_first})) return e;
+      if (n_steps > 2)
+        if (int e = h->run_repeated("per_pf_mid", {&h->ops_per_pf_mid}, n_steps - 2)) return e;
+      if (int e = h->run_seq("per_pf_last", {&h->ops_per_pf_last})) return e;
+    } else if (n_steps >= 2 && !h->ops_grads_apply_per_r.empty() && !h->prof) {
       // nothing but the updates themselves touches the leaves inside one call: the first update sums every block of the
       // ring, each apply launch refreshes the blocks its write-back touched, the later samplers start from those
       if (int e = h->run_seq("per_rng_first", {&h->ops_per_rng_g, &h->ops_grads_apply_per_r})) return e;

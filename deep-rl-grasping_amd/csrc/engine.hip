@@ -287,6 +287,12 @@ struct grl_ctx {
   int pf_gx = 0;
   bool prefetch_ok = false;
   std::vector<Op> ops_grads_apply_per;   // DQN / BDQ with prioritised replay: ... and the priority write-back
+  // ... multi-update calls on the device RNG, FOUR launches per update: write-back + block-sum refresh ride on the trunk launch,
+  // the sampler of the next update on the apply launch (plan_q.inl "per_pf"); the forward launch opens the update
+  std::vector<Op> ops_per_pf_first, ops_per_pf_mid, ops_per_pf_last;
+  bool per_pf_ok = false;
+  Op q_fwd_tick_op, q_bwd_wb_op;
+  bool have_q_fwd_tick = false, have_q_bwd_wb = false;
   // data parallel, staged (grl_compute_grads_staged): stage 0 ends with the dense (fc + head) gradients final in the
   // bucket, stage 1 is the convolution backward + its weight gradients + the loss reductions
   std::vector<Op> ops_stage0, ops_stage1;

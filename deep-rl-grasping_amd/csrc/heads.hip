@@ -88,7 +88,7 @@ void launch_q_bwd(const QFusedArgs& a, hipStream_t s) {
   if (a.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_kernel, trunk, dim3(256), 0, s, a);
 }
 void launch_q_bwd_chain(const QChainArgs& a, hipStream_t s) {
-  const dim3 towers((a.f.B + HT_RB - 1) / HT_RB, a.f.D + 1), trunk((a.f.B + HT_RB - 1) / HT_RB, a.late ? a.f.D + 2 : 1);
+  const dim3 towers((a.f.B + HT_RB - 1) / HT_RB, a.f.D + 1), trunk((a.f.B + HT_RB - 1) / HT_RB, qc_trunk_rows(a));
   hipLaunchKernelGGL(q_bwd_towers_chain_kernel, towers, dim3(256), 0, s, a);
   if (a.f.bwd_tr) hipLaunchKernelGGL(q_bwd_trunk_chain_kernel, trunk, dim3(256), 0, s, a);
 }

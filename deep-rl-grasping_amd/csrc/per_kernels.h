@@ -76,11 +76,15 @@ __device__ __forceinline__ double per_prefix_reduce(const double* tr, int64_t e,
   return fin;
 }
 
+// (GRL_ELEM_TYPES_ONLY: a translation unit that only needs the types and the device bodies -- heads.hip, whose trunk launch can
+//  carry the priority write-back -- the kernels themselves are compiled in engine.hip)
+#ifndef GRL_ELEM_TYPES_ONLY
 // new transitions enter with the maximal priority seen so far
 __global__ __launch_bounds__(256) void per_add_kernel(PerArgs a, int64_t pos, int n, int64_t cap) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k < n) a.p[(pos + k) % cap] = pow((double)a.st->max_priority, a.alpha64);
 }
+#endif
 
 // The sums follow the association order of the reference's SumSegmentTree (stable_baselines/common/
 // segment_tree.py, v2.10.1): a binary tree over the next power of two >= capacity, node = left + right in
@@ -178,6 +182,7 @@ __device__ __forceinline__ int per_tree_walk(const double* tr, double& rem) {
   return i - PER_BLK;
 }
 
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void per_blocksum_kernel(PerArgs a) {
   __shared__ double tr[2 * PER_BLK];
   __shared__ double sm[256];
@@ -208,13 +213,15 @@ __global__ __launch_bounds__(256) void per_blocksum_kernel(PerArgs a) {
   }
 }
 
+#endif
 // g / do_gather: the row's transition is gathered (and VecNormalized) right here once its replay index is known -- the
 // gather launch of the update disappears; the launch also opens the update (Adam step size) when g.adam_tick is set.
-__global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
-  __shared__ double tr[2 * PER_BLK];
-  __shared__ double smin[256];
-  __shared__ double s_total_s;
-  const int t = threadIdx.x, k = blockIdx.x;
+// Sample k by the first 256 threads of a workgroup (`tr`: 2 * PER_BLK doubles, `smin`: 257 doubles of LDS; smin[256] carries
+// total_s): per_sample_kernel's workgroups, or extra workgroups of the launch that ends the update before (q_apply_kernels.h).
+__device__ __forceinline__ void per_sample_body(const PerArgs& a, int n_blocks, const GatherArgs& g, int do_gather, const int k,
+                                                double* tr, double* smin) {
+  double& s_total_s = smin[256];
+  const int t = threadIdx.x;
   const int64_t size = a.sc->replay_size;
   // ---- upper tree: leaves = block sums (zero beyond n_blocks, like the unused leaves of the reference's tree)
   double m = INFINITY, lf[4];
@@ -265,6 +272,13 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks
     if (k == 0) { a.st->total = total; a.st->total_s = total_s; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }   // q_loss_kernel advances rng_step
   }
 }
+#ifndef GRL_ELEM_TYPES_ONLY
+__global__ __launch_bounds__(256) void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
+  __shared__ double tr[2 * PER_BLK];
+  __shared__ double smin[257];
+  per_sample_body(a, n_blocks, g, do_gather, (int)blockIdx.x, tr, smin);
+}
+#endif
 #endif
 
 // Block sums kept current by the launch that writes the priorities back (multi-update calls: between two updates of one
@@ -362,11 +376,13 @@ __device__ __forceinline__ void per_update_body(const PerArgs& a, const int64_t*
   }
   if (t == 0) a.st->max_priority = fmaxf(a.st->max_priority, smax[0]);
 }
+#ifndef GRL_ELEM_TYPES_ONLY
 __global__ __launch_bounds__(256) void per_update_kernel(PerArgs a, const int64_t* idx) {
   __shared__ int64_t sidx[1024];
   __shared__ float smax[256];
   per_update_body(a, idx, sidx, smax);
 }
+#endif
 #endif
 
 }  // namespace grl

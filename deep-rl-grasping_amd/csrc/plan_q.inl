@@ -376,6 +376,13 @@ int grl_ctx::plan_q() {
     const QFusedArgs fa = qf;
     op.run = [fa](hipStream_t s) { launch_q_fwd(fa, s); };
     ops_grads.push_back(op);
+    {      // the same launch opening the update (Adam step size): the "per_pf" updates below
+      QFusedArgs ft = qf;
+      ft.tick_sc = sc;
+      q_fwd_tick_op = op;
+      q_fwd_tick_op.run = [ft](hipStream_t s) { launch_q_fwd(ft, s); };
+      have_q_fwd_tick = true;
+    }
   } else {
     std::vector<std::vector<IgemmProb>> sc_[3], sh_[3];
     std::vector<IgemmProb> so_[3];
@@ -466,6 +473,20 @@ int grl_ctx::plan_q() {
       Op op; op.tag = "q_bwd";
       op.run = [ca](hipStream_t s) { launch_q_bwd_chain(ca, s); };
       ops_grads.push_back(op);
+      if (per_on && Lc > 0 && B <= 1024) {      // the trunk launch carrying the priority write-back + the block-sum refresh ("per_pf")
+        grl_ctx* self = this;
+        const int rows = B;
+        q_bwd_wb_op = op;
+        q_bwd_wb_op.run = [ca, self, rows](hipStream_t s) {
+          QChainArgs c2 = ca;
+          c2.per = self->per;
+          c2.per.prio_in = self->q_prio;
+          c2.per_idx = (const int64_t*)self->idx_buf;
+          c2.per_wb = rows;
+          launch_q_bwd_chain(c2, s);
+        };
+        have_q_bwd_wb = true;
+      }
     } else if (fused_q) {
       const QFusedArgs fa = qf;
       Op op; op.tag = "q_bwd";
@@ -614,8 +635,9 @@ int grl_ctx::plan_q() {
       const int nd = (int)reduces.size();
       const float clip = c.q_grad_clip;
       const float* rp = q_row_part; const int rows = B, fin = q_finish;
-      auto apply_op = [self, dr, nd, clip, rp, rows, fin](bool with_per, bool refresh = false) {
-        return [self, dr, nd, clip, rp, rows, fin, with_per, refresh](hipStream_t s) {
+      auto qga = q_ga;      // (shared with the samplers: the minibatch gather of this plan)
+      auto apply_op = [self, dr, nd, clip, rp, rows, fin, qga](bool with_per, bool refresh = false, bool next_sampler = false) {
+        return [self, dr, nd, clip, rp, rows, fin, with_per, refresh, next_sampler, qga](hipStream_t s) {
           AdamArgs aa;
           aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
           aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
@@ -624,8 +646,17 @@ int grl_ctx::plan_q() {
           q.prio_in = self->q_prio;
           // prioritised replay: one more workgroup writes the new priorities back (per_update_kernel's work)
           // (refresh: one more workgroup per sample rebuilds the block sums its new priority touches, per_refresh_body)
-          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + (with_per ? 2 : 1) + (refresh ? rows : 0)), dim3(1024), 0, s, dr, nd, clip,
-                             aa, rp, rows, fin, q, (const int64_t*)self->idx_buf);
+          // (next_sampler: write-back and refresh rode on the trunk launch; `rows` workgroups draw the NEXT update's minibatch)
+          const int n_extra = next_sampler ? 1 : (with_per ? 2 : 1) + (refresh ? rows : 0);
+          QNextArgs nx;
+          memset(&nx, 0, sizeof(nx));
+          if (next_sampler) {
+            nx.per = q; nx.per.u = nullptr;
+            nx.g = *qga; nx.g.adam_tick = 0;          // (the next update's forward launch fixes its Adam step size)
+            nx.n_sample = rows; nx.n_blocks = self->per_blocks;
+          }
+          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + n_extra + (next_sampler ? rows : 0)), dim3(1024), 0, s, dr, nd, clip,
+                             aa, rp, rows, fin, q, (const int64_t*)self->idx_buf, n_extra, nx);
         };
       };
       op.run = apply_op(false);
@@ -640,6 +671,32 @@ int grl_ctx::plan_q() {
           ops_grads_apply_per_r = ops_grads_apply_per;
           ops_grads_apply_per_r.back().run = apply_op(true, true);
         }
+        // "per_pf": FOUR launches per update inside such a call.  The TD errors are final when the tower chains end, so the
+        // priority write-back and the refresh of the block sums ride on the trunk launch (q_chain.h) and the launch that ends
+        // update t -- reduction, clip, Adam -- carries the sampler of update t + 1 (sum-tree walks, importance weights, the rows'
+        // gather): nothing it writes is read by that launch, the Philox counter was advanced by update t's loss, and the Adam
+        // step size of t + 1 is fixed by its forward launch instead of its sampler (the apply launch of t still reads t's).
+        //   first : sampler (all block sums) | forward | towers | trunk + write-back + refresh | apply + sampler(t + 1)
+        //   middle:                            forward[tick] | towers | trunk + write-back + refresh | apply + sampler(t + 1)
+        //   last  :                            forward[tick] | towers | trunk + write-back + refresh | apply
+        if (tune_int("per_pf", 1) && q_chain && have_q_fwd_tick && have_q_bwd_wb && !ops_per_rng_g.empty()) {
+          ops_per_pf_first = ops_per_rng_g;
+          for (int v = 0; v < 3; ++v) {
+            std::vector<Op>& dst = v == 0 ? ops_per_pf_first : (v == 1 ? ops_per_pf_mid : ops_per_pf_last);
+            for (size_t k = 0; k + 1 < ops_grads_apply_per.size(); ++k) {
+              const Op& o = ops_grads_apply_per[k];
+              if (o.tag == "q_fwd") dst.push_back(v == 0 ? o : q_fwd_tick_op);
+              else if (o.tag == "q_bwd") dst.push_back(q_bwd_wb_op);
+              else dst.push_back(o);
+            }
+            Op ao; ao.tag = "q_apply";
+            ao.run = v == 2 ? apply_op(false) : apply_op(false, false, true);
+            dst.push_back(ao);
+          }
+          per_pf_ok = true;
+        }
+        if (getenv("GRL_PLAN_DUMP"))
+          fprintf(stderr, "grl plan: per_pf        multi-update prioritised calls, four launches per update (sampler on the apply launch): %s\n", per_pf_ok ? "yes" : "no");
       }
       *q_defer = 1;
       if (fin) {     // split compute / apply path of this plan: the batch means as a launch of their own, behind the reduction

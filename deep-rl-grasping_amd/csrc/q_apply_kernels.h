@@ -12,17 +12,30 @@ namespace grl {
 // clip_by_norm_kernel (strided partial sums, tree -- over 1024 instead of 256 threads) and adam_polyak_kernel: three launches at the launch floor
 // (4.8 + 8.6 + 4.8 us under graph replay) become one.
 #define GRL_QAPPLY_MAX 16384   /* floats of LDS for the summed gradient of one variable */
+// QNextArgs: the sampler of the NEXT update riding on this launch (prioritised multi-update calls whose trunk launch has already
+// written this update's priorities back and refreshed the block sums: q_chain.h, QChainArgs.per_wb): n_sample workgroups behind
+// everything else, workgroup k = per_sample_kernel's workgroup k (sum-tree walk, importance weight, the row's gather).
+struct QNextArgs {
+  PerArgs per; GatherArgs g; int n_sample, n_blocks;
+};
 #ifdef GRL_HOSTEMU
 #include "q_apply_kernels_ref1.h"   // tests/hostemu: the emulation build only
 #else
 // (1024 threads: the largest variable of the reference networks, 101 x 64, is then one batch of loads per phase)
 __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDesc* __restrict__ descs, int n_desc, float clip, AdamArgs aa,
-                                                                 const float* row_part, int rows, int finish, PerArgs per, const int64_t* per_idx) {
+                                                                 const float* row_part, int rows, int finish, PerArgs per, const int64_t* per_idx,
+                                                                 int n_extra, QNextArgs nx) {
   __shared__ __attribute__((aligned(16))) float gsum[GRL_QAPPLY_MAX];   // (also the index scratch of the write-back block)
   constexpr int NT = 1024;
   __shared__ float red3[3][256];
   __shared__ float red[NT];
   const int t = threadIdx.x;
+  if ((int)blockIdx.x >= n_desc + n_extra) {      // the next update's sampler (n_extra: the extra workgroups in front of it)
+    if (t >= 256) return;               // (whole waves retire: the barriers below are among the remaining four)
+    static_assert(GRL_QAPPLY_MAX * sizeof(float) >= (2 * PER_BLK + 257) * sizeof(double), "the sampler's trees live in gsum");
+    per_sample_body(nx.per, nx.n_blocks, nx.g, 1, (int)blockIdx.x - n_desc - n_extra, (double*)gsum, (double*)gsum + 2 * PER_BLK);
+    return;
+  }
   if ((int)blockIdx.x == n_desc) {      // extra workgroup: batch means of the loss launch's row sums (deferred q_loss_finish)
     if (finish) q_finish_sums(const_cast<DevScalars*>(aa.sc), row_part, rows, red3);
     return;

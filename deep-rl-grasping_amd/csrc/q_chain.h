@@ -23,6 +23,7 @@
 #pragma once
 #include "q_mfma.h"
 #include "elem_kernels.h"
+#include "per_kernels.h"
 
 namespace grl {
 
@@ -41,7 +42,17 @@ struct QChainArgs {
   const QcHead* tr;       // trunk, or nullptr
   int late;               // 1 (networks with a trunk): the towers' weight gradients are formed by workgroups of their own in the
                           // TRUNK launch, in the shadow of the trunk chain, from the gradient rows the tower chains stored
+  // Prioritised replay, multi-update calls (per_wb > 0: the minibatch size): the TRUNK launch also carries the priority
+  // write-back of this minibatch (one workgroup) and the refresh of the block sums it touches (one workgroup per sample) --
+  // both need only the TD errors the tower chains left behind -- so that the launch that ENDS the update can carry the sampler
+  // of the next one (q_apply_kernels.h): four launches per update instead of five
+  PerArgs per; const int64_t* per_idx; int per_wb;
 };
+// grid rows of the trunk launch: 1 (trunk chain) + D + 1 (late tower slabs) [+ 1 write-back + ceil(B / row blocks) refresh rows]
+static inline int qc_trunk_rows(const QChainArgs& a) {
+  const int nrb = (a.f.B + HT_RB - 1) / HT_RB;
+  return (a.late ? a.f.D + 2 : 1) + (a.per_wb > 0 ? 1 + (a.per_wb + nrb - 1) / nrb : 0);
+}
 enum { QC_XW = 2 * QM_W, QC_XLD = QC_XW + 4 };
 
 // host: the chains stage D x bins <= 256 advantages per row for the loss (bins <= 64: four per lane) and layer-0 inputs up to 128 wide
@@ -362,6 +373,18 @@ __global__ __launch_bounds__(256) void q_bwd_trunk_chain_kernel(QChainArgs ca) {
   __shared__ QcLds s;
   const QFusedArgs& a = ca.f;
   const int rb = blockIdx.x, row0 = rb * HT_RB;
+  const int y_chain = ca.late ? a.D + 2 : 1;       // grid rows of the chain work; behind them the prioritised-replay rows
+  if (ca.per_wb > 0 && (int)blockIdx.y >= y_chain) {
+    static_assert(sizeof(QcLds) >= (2 * PER_BLK + 256) * sizeof(double) + 1024 * sizeof(int64_t), "the chain's LDS doubles as the trees' scratch");
+    double* tr = (double*)&s;
+    if ((int)blockIdx.y == y_chain) {              // priority write-back of this minibatch (per_update_kernel's work)
+      if (rb == 0) per_update_body(ca.per, ca.per_idx, (int64_t*)tr, (float*)(tr + 1024));
+      return;
+    }
+    const int k = ((int)blockIdx.y - y_chain - 1) * (int)gridDim.x + rb;      // block sums the next sampler reads
+    if (k < ca.per_wb) per_refresh_body(ca.per, ca.per_idx, k, tr, tr + 2 * PER_BLK, (int64_t*)(tr + 2 * PER_BLK + 256));
+    return;
+  }
   if (blockIdx.y > 0) {
     // ---- grid row 1 + tw: the weight gradients of tower tw for this row block, from what the tower chains left in memory
     // (activations, gradient rows, output gradients): one batch of loads, the rows parked in LDS, qc_wgrad_all

@@ -28,6 +28,9 @@ struct QFusedArgs {
   float* dh_part;         // [D+1][B, Ht]: gradient w.r.t. the trunk output, one partial per tower
   float trunk_scale;
   int mfma;               // every chain fits q_mfma.h's 64-wide MFMA stages: the launchers take those kernels
+  DevScalars* tick_sc;    // forward launch only, optional: this launch OPENS the update -- one thread fixes the Adam step size and
+                          // advances the beta powers (adam_tick_device).  Prioritised multi-update calls: the sampler of update
+                          // t + 1 rides on the apply launch of update t, which still reads update t's step size
 };
 
 #ifndef GRL_HEADS_TYPES_ONLY
@@ -36,6 +39,7 @@ struct QFusedArgs {
 #else
 __global__ __launch_bounds__(256) void q_fwd_fused_kernel(QFusedArgs a) {
   __shared__ HtLds s;
+  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) adam_tick_device(a.tick_sc);
   const HtHead& h = a.fwd[blockIdx.y * (a.D + 1) + blockIdx.z];
   ht_fwd_head(h, blockIdx.x * HT_RB, a.B, s, false);
 }

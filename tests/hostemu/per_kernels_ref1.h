@@ -30,8 +30,9 @@ inline void per_blocksum_kernel(PerArgs a) {
   const int64_t e = size - 2;
   if (e >= 0 && e / PER_BLK == (int64_t)blockIdx.x) a.st->tail_w = per_prefix_reduce(tr, e % PER_BLK, 1, [] { return 0.0; });
 }
-inline void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
-  const int k = blockIdx.x;
+// sample k (run by every emulated thread of the workgroup that owns it; threads beyond 255 stay out)
+inline void per_sample_ref(const PerArgs& a, int n_blocks, const GatherArgs& g, int do_gather, const int k) {
+  if (threadIdx.x >= 256) return;
   const int64_t size = a.sc->replay_size;
   static thread_local double tr[2 * PER_BLK];
   double pmin = INFINITY;
@@ -56,4 +57,7 @@ inline void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gath
   a.idx_out[k] = i;
   a.w_out[k] = per_weight(a.p[i], total, pmin, size, a.st->beta);
   if (k == 0) { a.st->total = total; a.st->total_s = total_s; a.st->p_min = pmin; if (!a.u) a.sc->rng_used = 1u; }
+}
+inline void per_sample_kernel(PerArgs a, int n_blocks, GatherArgs g, int do_gather) {
+  per_sample_ref(a, n_blocks, g, do_gather, (int)blockIdx.x);
 }

@@ -10,7 +10,11 @@ inline void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
   if (threadIdx.x == 0) q_finish_ref(sc, row_part, rows);
 }
 inline void q_reduce_clip_adam_kernel(const ReduceDesc* descs, int n_desc, float clip, AdamArgs aa, const float* row_part, int rows,
-                                      int finish, PerArgs per, const int64_t* per_idx) {
+                                      int finish, PerArgs per, const int64_t* per_idx, int n_extra, QNextArgs nx) {
+  if ((int)blockIdx.x >= n_desc + n_extra) {   // the next update's sampler rides on this launch
+    per_sample_ref(nx.per, nx.n_blocks, nx.g, 1, (int)blockIdx.x - n_desc - n_extra);
+    return;
+  }
   if ((int)blockIdx.x == n_desc + 1) {   // priority write-back (prioritised replay)
     if (threadIdx.x == 0) per_update_ref(per, per_idx);
     return;

@@ -91,6 +91,16 @@ inline void q_bwd_trunk_chain_kernel(QChainArgs ca) {
   if (threadIdx.x != 0) return;
   const QFusedArgs& a = ca.f;
   const int rb = blockIdx.x;
+  const int y_chain = ca.late ? a.D + 2 : 1;
+  if (ca.per_wb > 0 && (int)blockIdx.y >= y_chain) {      // prioritised replay: write-back and block-sum refresh ride on this launch
+    if ((int)blockIdx.y == y_chain) {
+      if (rb == 0) per_update_ref(ca.per, ca.per_idx);
+      return;
+    }
+    const int k = ((int)blockIdx.y - y_chain - 1) * (int)gridDim.x + rb;
+    if (k < ca.per_wb) per_refresh_ref(ca.per, ca.per_idx, k);
+    return;
+  }
   if (blockIdx.y > 0) {        // the weight gradients of tower blockIdx.y - 1 from the gradient rows its chain stored
     const int tw = blockIdx.y - 1;
     const HtHead& h = a.bwd_tw[tw];
