@@ -914,15 +914,21 @@ __device__ __forceinline__ void q_loss_row(const QLossArgs& a, int b, float* s3)
 }
 
 // batch means of the row partial sums + RNG tick (the part of q_loss_finish that does not feed the optimiser)
-__device__ __forceinline__ void q_metrics(DevScalars* sc, int B, float loss, float qm, float tdm) {
+// the Philox counter moves on once the minibatch it drew has been consumed
+__device__ __forceinline__ void q_rng_tick(DevScalars* sc) {
+  if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch was drawn by the device RNG
+}
+// tick_rng = false: the counter was advanced earlier in the update (prioritised multi-update calls, "per_pf": the launch these
+// sums are formed in also carries the NEXT update's sampler, which reads the counter and marks rng_used again)
+__device__ __forceinline__ void q_metrics(DevScalars* sc, int B, float loss, float qm, float tdm, bool tick_rng = true) {
   const float invB = 1.f / (float)B;
   sc->policy_loss = loss * invB;     // reported as the TD loss
   sc->mean_qf1 = qm * invB;
   sc->value_loss = tdm * invB;       // mean |td|
-  if (sc->rng_used) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch was drawn by the device RNG
+  if (tick_rng) q_rng_tick(sc);
 }
 // deferred form: one workgroup (256 threads) sums row_part in the fixed tree order of q_loss_kernel's last workgroup
-__device__ __forceinline__ void q_finish_sums(DevScalars* sc, const float* row_part, int B, float (*red)[256]) {
+__device__ __forceinline__ void q_finish_sums(DevScalars* sc, const float* row_part, int B, float (*red)[256], bool tick_rng = true) {
   const int t = threadIdx.x;           // workgroups of 256 threads or more: the first 256 carry the sums, all reach the barriers
   if (t < 256) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -935,7 +941,7 @@ __device__ __forceinline__ void q_finish_sums(DevScalars* sc, const float* row_p
       for (int k = 0; k < 3; ++k) red[k][t] += red[k][t + off];
     __syncthreads();
   }
-  if (t == 0) q_metrics(sc, B, red[0][0], red[1][0], red[2][0]);
+  if (t == 0) q_metrics(sc, B, red[0][0], red[1][0], red[2][0], tick_rng);
 }
 
 __device__ __forceinline__ void q_loss_finish(const QLossArgs& a, float loss, float qm, float tdm) {

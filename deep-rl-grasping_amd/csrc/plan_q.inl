@@ -655,8 +655,9 @@ int grl_ctx::plan_q() {
             nx.g = *qga; nx.g.adam_tick = 0;          // (the next update's forward launch fixes its Adam step size)
             nx.n_sample = rows; nx.n_blocks = self->per_blocks;
           }
+          // (finish bit 1 = leave the Philox counter alone: the trunk launch advanced it, the sampler on this launch reads it)
           hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + n_extra + (next_sampler ? rows : 0)), dim3(1024), 0, s, dr, nd, clip,
-                             aa, rp, rows, fin, q, (const int64_t*)self->idx_buf, n_extra, nx);
+                             aa, rp, rows, fin | (next_sampler ? 2 : 0), q, (const int64_t*)self->idx_buf, n_extra, nx);
         };
       };
       op.run = apply_op(false);

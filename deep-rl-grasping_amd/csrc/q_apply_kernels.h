@@ -37,7 +37,8 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
     return;
   }
   if ((int)blockIdx.x == n_desc) {      // extra workgroup: batch means of the loss launch's row sums (deferred q_loss_finish)
-    if (finish) q_finish_sums(const_cast<DevScalars*>(aa.sc), row_part, rows, red3);
+    // (finish bit 1: the Philox counter was advanced by the trunk launch -- the sampler riding on THIS launch reads it)
+    if (finish & 1) q_finish_sums(const_cast<DevScalars*>(aa.sc), row_part, rows, red3, (finish & 2) == 0);
     return;
   }
   if ((int)blockIdx.x == n_desc + 1) {  // second extra workgroup (prioritised replay): priority write-back of this minibatch

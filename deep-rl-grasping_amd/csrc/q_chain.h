@@ -378,7 +378,12 @@ __global__ __launch_bounds__(256) void q_bwd_trunk_chain_kernel(QChainArgs ca) {
     static_assert(sizeof(QcLds) >= (2 * PER_BLK + 256) * sizeof(double) + 1024 * sizeof(int64_t), "the chain's LDS doubles as the trees' scratch");
     double* tr = (double*)&s;
     if ((int)blockIdx.y == y_chain) {              // priority write-back of this minibatch (per_update_kernel's work)
-      if (rb == 0) per_update_body(ca.per, ca.per_idx, (int64_t*)tr, (float*)(tr + 1024));
+      if (rb == 0) {
+        per_update_body(ca.per, ca.per_idx, (int64_t*)tr, (float*)(tr + 1024));
+        // the minibatch is consumed (the tower chains formed its loss): the Philox counter moves on HERE, a launch before the
+        // next update's sampler reads it on the apply launch (whose own sums then leave it alone: finish bit 1)
+        if (threadIdx.x == 0) q_rng_tick(ca.per.sc);
+      }
       return;
     }
     const int k = ((int)blockIdx.y - y_chain - 1) * (int)gridDim.x + rb;      // block sums the next sampler reads

@@ -1,10 +1,10 @@
 // q_apply_kernels_ref1.h -- TEST-ONLY reference form of the kernels of csrc/q_apply_kernels.h: sequential loops over
 // the same descriptors, included by that header ONLY in the g++ emulation build (-DGRL_HOSTEMU -I tests/hostemu,
 // tests/conftest.py).  Never part of libgrl.so.  No include guard: it is pasted once, inside namespace grl.
-inline void q_finish_ref(DevScalars* sc, const float* row_part, int rows) {
+inline void q_finish_ref(DevScalars* sc, const float* row_part, int rows, bool tick_rng = true) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (int r = 0; r < rows; ++r) { s0 += row_part[3 * r]; s1 += row_part[3 * r + 1]; s2 += row_part[3 * r + 2]; }
-  q_metrics(sc, rows, s0, s1, s2);
+  q_metrics(sc, rows, s0, s1, s2, tick_rng);
 }
 inline void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
   if (threadIdx.x == 0) q_finish_ref(sc, row_part, rows);
@@ -25,7 +25,7 @@ inline void q_reduce_clip_adam_kernel(const ReduceDesc* descs, int n_desc, float
   }
   if (threadIdx.x != 0) return;
   if ((int)blockIdx.x == n_desc) {
-    if (finish) q_finish_ref(const_cast<DevScalars*>(aa.sc), row_part, rows);
+    if (finish & 1) q_finish_ref(const_cast<DevScalars*>(aa.sc), row_part, rows, (finish & 2) == 0);
     return;
   }
   const ReduceDesc d = descs[blockIdx.x];

@@ -94,7 +94,7 @@ inline void q_bwd_trunk_chain_kernel(QChainArgs ca) {
   const int y_chain = ca.late ? a.D + 2 : 1;
   if (ca.per_wb > 0 && (int)blockIdx.y >= y_chain) {      // prioritised replay: write-back and block-sum refresh ride on this launch
     if ((int)blockIdx.y == y_chain) {
-      if (rb == 0) per_update_ref(ca.per, ca.per_idx);
+      if (rb == 0) { per_update_ref(ca.per, ca.per_idx); q_rng_tick(ca.per.sc); }
       return;
     }
     const int k = ((int)blockIdx.y - y_chain - 1) * (int)gridDim.x + rb;
