@@ -29,19 +29,6 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
 }
 
-// copy [N, H, W, C] into the interior of a zero-bordered [N, H+lo+hi, W+lo+hi, C] buffer (same purpose)
-__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ x, float* __restrict__ xp, long total,
-                                                      int H, int W, int C, int lo, int hi) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;          // element index over [N, H, W, C]
-  if (e >= total) return;
-  const int c = (int)(e % C);
-  long r = e / C;
-  const int w = (int)(r % W); r /= W;
-  const int hh = (int)(r % H);
-  const long n = r / H;
-  xp[((n * (H + lo + hi) + hh + lo) * (W + lo + hi) + w + lo) * C + c] = x[e];
-}
-
 // backward of UpSampling2D(2) fused with the LeakyReLU gradient of the layer that produced h:
 // g_h[n,i,j,c] = (h > 0 ? 1 : alpha) * sum_{a,b} g_u[n, 2i+a, 2j+b, c]   (fixed order a-major)
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ gu, const float* __restrict__ h,
@@ -85,42 +72,14 @@ __device__ __forceinline__ long mse_pad_index(long i) {   // i over [N, 64, 64] 
   const int r = (int)(i & 4095);
   return n * 4900 + ((r >> 6) + 3) * 70 + (r & 63) + 3;
 }
-#ifdef GRL_HOSTEMU
-#include "ae_kernels_ref1.h"   // tests/hostemu: the emulation build only
-#else
-__global__ __launch_bounds__(256) void mse_kernel(MseArgs a) {
-  __shared__ float red[256], redg[256];
-  const long per = (a.n_total + gridDim.x - 1) / gridDim.x;
-  const long i0 = (long)blockIdx.x * per, i1 = min(a.n_total, i0 + per);
-  const float inv = 2.f / (float)a.n_total;
-  float s = 0.f, sg = 0.f;
-  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float d = a.out[i] - a.x[i];
-    const float g = d * inv;
-    a.g_out[i] = g;
-    if (a.g_pad) a.g_pad[mse_pad_index(i)] = g;
-    if (a.gp4) a.gp4[mse_gp4_index(i, a.gp4_plane)] = g;
-    s += d * d;
-    sg += g;
-  }
-  red[threadIdx.x] = s; redg[threadIdx.x] = sg;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) { red[threadIdx.x] += red[threadIdx.x + off]; redg[threadIdx.x] += redg[threadIdx.x + off]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { a.partial[blockIdx.x] = red[0]; a.partial_g[blockIdx.x] = redg[0]; }
-}
-#endif
-
 // Output convolution 7x7 'same', 32 -> 1 channel, restructured for the matrix cores: the GEMM
 // T[tap, p] = sum_c W[tap, c] u[p, c] (49 rows instead of N = 1; tap-major so that the reads below are
 // coalesced across the pixels of a wavefront and every T element is read exactly once) followed by
 //   out[n, oh, ow] = b + sum_{kh, kw} T[kh*7+kw, (n, oh+kh-3, ow+kw-3)]      (taps outside the image skipped)
-// half = 1: T was formed over the 32 x 32 pixels of the layer in front of the up-sampling (u[n, ih, iw] = h[n, ih / 2, iw / 2]):
-// the same 49 terms in the same order, read at the source pixel.
+// T is formed over the 32 x 32 pixels of the layer in FRONT of the up-sampling (u[n, ih, iw] = h[n, ih / 2, iw / 2]): the same 49
+// terms in the same order as over the up-sampled image, read at the source pixel.
 __global__ __launch_bounds__(256) void ae_tapsum_kernel(const float* __restrict__ T, long ldT, const float* __restrict__ bias,
-                                                       float* __restrict__ out, long n_pix, int half) {
+                                                       float* __restrict__ out, long n_pix) {
   const long o = (long)blockIdx.x * 256 + threadIdx.x;
   if (o >= n_pix) return;
   const long n = o >> 12;
@@ -132,19 +91,18 @@ __global__ __launch_bounds__(256) void ae_tapsum_kernel(const float* __restrict_
     for (int kw = 0; kw < 7; ++kw) {
       const int iw = ow + kw - 3;
       if (iw < 0 || iw > 63) continue;
-      s += half ? T[(long)(kh * 7 + kw) * ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)]
-                : T[(long)(kh * 7 + kw) * ldT + (n << 12) + (ih << 6) + iw];
+      s += T[(long)(kh * 7 + kw) * ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)];
     }
   }
   out[o] = s + bias[0];
 }
 
-// The gather-sum above and the MSE kernel behind it as ONE launch (training steps; the forward-only path keeps the plain
-// gather-sum): thread = output pixel; it forms out[o] exactly as ae_tapsum_kernel does, then the pixel's loss term and output
-// gradient (g_out and its bordered / de-interleaved copies) exactly as mse_kernel does; the workgroup's sums of (out - x)^2 and
+// The gather-sum above and the MSE behind it as ONE launch (training steps; the forward-only path keeps the plain gather-sum):
+// thread = output pixel; it forms out[o] exactly as ae_tapsum_kernel does, then the pixel's loss term 2 (out - x) / n and output
+// gradient (g_out and its bordered / de-interleaved copies); the workgroup's sums of (out - x)^2 and
 // of g go to partial[blockIdx.x] -- n_pix / 256 of them, added up by ae_finish_kernel.
 struct TapMseArgs {
-  const float* T; long ldT; const float* bias; long n_pix; int half;
+  const float* T; long ldT; const float* bias; long n_pix;
   MseArgs m;          // m.out is written here; m.n_total == n_pix
 };
 #ifdef GRL_HOSTEMU
@@ -164,8 +122,7 @@ __global__ __launch_bounds__(256) void ae_tapsum_mse_kernel(TapMseArgs a) {
       for (int kw = 0; kw < 7; ++kw) {
         const int iw = ow + kw - 3;
         if (iw < 0 || iw > 63) continue;
-        s += a.half ? a.T[(long)(kh * 7 + kw) * a.ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)]
-                    : a.T[(long)(kh * 7 + kw) * a.ldT + (n << 12) + (ih << 6) + iw];
+        s += a.T[(long)(kh * 7 + kw) * a.ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)];
       }
     }
     const float ov = s + a.bias[0];

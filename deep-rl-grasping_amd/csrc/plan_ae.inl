@@ -43,8 +43,8 @@ int grl_ctx::plan_ae() {
   // activations [B, H, W, C] (NHWC) and their gradients
   auto T = [&](int h, int ch) { return wk.f32((int64_t)B * h * h * ch); };
   ae_x = T(64, 1);
-  float *e1 = T(32, 32), *e2 = T(16, 32), *e3 = T(8, 32), *z = wk.f32((int64_t)B * 100), *dh = T(8, 32);
-  float *d4 = T(16, 32), *d5 = T(32, 32), *u6 = T(64, 32), *out = T(64, 1);
+  float *e3 = T(8, 32), *z = wk.f32((int64_t)B * 100), *dh = T(8, 32);      // (e1 / e2 exist only in their bordered form, below)
+  float *d4 = T(16, 32), *d5 = T(32, 32), *out = T(64, 1);
   // inputs of the padded convolutions live in zero-bordered buffers (border written once): the 'same'
   // convolution becomes a 'valid' one over the bordered image, so neither the forward GEMM nor the weight
   // gradient needs per-tap bounds masks and both run on the vectorised kernel
@@ -57,9 +57,8 @@ int grl_ctx::plan_ae() {
   float *x_p = TP(64, 2, 3, 1), *e1_p = TP(32, 1, 2, 32), *e2_p = TP(16, 0, 1, 32);
   float *u4 = TP(16, 1, 1, 32), *u5 = TP(32, 2, 2, 32);
   float* g_pad = nullptr;
-  float *g_out = T(64, 1), *g_u6 = T(64, 32), *g_d5 = T(32, 32), *g_u5 = T(32, 32), *g_d4 = T(16, 32), *g_u4 = T(16, 32);
+  float *g_out = T(64, 1), *g_d5 = T(32, 32), *g_u5 = T(32, 32), *g_d4 = T(16, 32), *g_u4 = T(16, 32);
   float *g_dh = T(8, 32), *g_z = wk.f32((int64_t)B * 100), *g_e3 = T(8, 32), *g_e2 = T(16, 32), *g_e1 = T(32, 32);
-  const int NPART = 256;
   // geometry: encoder convs 'SAME' stride 2 (TF asymmetric padding: low pad 2 / 1 / 0), decoder convs 'SAME' stride 1
   const ConvGeom ge[3] = {{64, 64, 1, 7, 7, 2, 2, 32, 32, 32}, {32, 32, 32, 5, 5, 2, 1, 16, 16, 32}, {16, 16, 32, 3, 3, 2, 0, 8, 8, 32}};
   const ConvGeom gd[3] = {{16, 16, 32, 3, 3, 1, 1, 16, 16, 32}, {32, 32, 32, 5, 5, 1, 2, 32, 32, 32}, {64, 64, 32, 7, 7, 1, 3, 64, 64, 1}};
@@ -79,12 +78,6 @@ int grl_ctx::plan_ae() {
       const long quads = (long)Bn * 2 * H * 2 * H * 8;
       hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, h, u, Bn, H, H, 32,
                          border, border);
-    });
-  };
-  auto padcp = [&](const float* x, float* xp, int H, int C, int lo, int hi) {
-    const long total = (long)B * H * H * C;
-    elem("ae_pad_copy", [=](hipStream_t s) {
-      hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, xp, total, H, H, C, lo, hi);
     });
   };
   auto up_bwd = [&](const float* gu, const float* h, float* gh, int H) {
@@ -110,11 +103,9 @@ int grl_ctx::plan_ae() {
     });
   }
   // Encoder activations e1 / e2 are consumed in their zero-bordered form (next convolution, weight gradient) and as the
-  // LeakyReLU mask of the backward-data launches.  ae_bordered (GRL_TUNE ae_bordered=0: off): the convolution that produces
-  // them writes the bordered layout directly (output row table, c_tab_i) and the backward-data launches read their mask through
-  // a row table of its own (IgemmProb.m_tab_i) -- the plain copies e1 / e2 and the two pad-copy launches (21 MB read +
-  // written at B = 128) disappear.
-  const bool bordered = tune_int("ae_bordered", 1) != 0;
+  // LeakyReLU mask of the backward-data launches: the convolution that produces them writes the bordered layout directly (output
+  // row table, c_tab_i) and the backward-data launches read their mask through a row table of its own (IgemmProb.m_tab_i) -- no
+  // plain copies, no pad-copy launches (round 5: two launches, 21 MB read + written at B = 128).
   auto bordered_rows = [&](int H, int lo, int hi, int C) {     // output pixel (n, oh, ow) -> its offset in [N, H+lo+hi, W+lo+hi, C]
     std::vector<int32_t> ct((size_t)B * H * H);
     const int Hp = H + lo + hi;
@@ -125,11 +116,11 @@ int grl_ctx::plan_ae() {
   };
   {
     const float* in[3] = {x_p, e1_p, e2_p};
-    float* o[3] = {e1, e2, e3};
+    float* o[3] = {nullptr, nullptr, e3};
     float* ob[3] = {e1_p, e2_p, nullptr};
     const int oH[2] = {32, 16}, olo[2] = {1, 0}, ohi[2] = {2, 1};
     auto to_bordered = [&](IgemmProb& p, int l) {
-      if (!bordered || l > 1) return;
+      if (l > 1) return;
       p.c = ob[l];
       p.c_tab_i = upload_vec(wk, bordered_rows(oH[l], olo[l], ohi[l], 32));
       p.vflags |= VF_CT4;
@@ -146,14 +137,11 @@ int grl_ctx::plan_ae() {
         p.vflags |= VF_P_TABS;      // 4-runs along the taps at dword-aligned offsets (16-byte buffer loads take them on gfx950)
         to_bordered(p, 0);
         add_launch(ops_ae, "ae_enc_conv", 0, {p});
-        if (!bordered) padcp(e1, e1_p, 32, 32, 1, 2);
         continue;
       }
       IgemmProb p = conv_fwd(in[l], fte[l], gev[l], P + ew[l], P + eb[l], o[l], ACT_LEAKY, LA);
       to_bordered(p, l);
       add_launch(ops_ae, "ae_enc_conv", 0, {p});
-      if (l == 0 && !bordered) padcp(e1, e1_p, 32, 32, 1, 2);
-      if (l == 1 && !bordered) padcp(e2, e2_p, 16, 32, 0, 1);
     }
   }
   {
@@ -168,32 +156,28 @@ int grl_ctx::plan_ae() {
   add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u4, ftd[0], gdv[0], P + dw[0], P + db[0], d4, ACT_LEAKY, LA)});
   up(d4, u5, 16, 2);
   add_launch(ops_ae, "ae_dec_conv", 0, {conv_fwd(u5, ftd[1], gdv[1], P + dw[1], P + db[1], d5, ACT_LEAKY, LA)});
-  const bool lowres = tune_int("ae_lowres", 1) != 0;
-  if (!lowres) up(d5, u6, 32, 0);       // (lowres: nothing reads the 64 x 64 x 32 up-sampled image any more -- 67 MB at B = 128)
+  // (no up(d5): nothing reads the 64 x 64 x 32 up-sampled image any more -- 67 MB at B = 128, round 5)
   // output conv (7x7 'same', 32 -> 1): N = 1 wastes the matrix cores, so T[tap, p] = W[tap, :] . u[p, :] as a GEMM with
   // M = 49, then a 49-tap gather-sum (ae_kernels.h: ae_tapsum_kernel).  u6 is d5 with every pixel repeated 2 x 2
   // (UpSampling2D), so T is formed over the pixels of d5 -- a quarter of the columns, the same products -- and the gather-sum
-  // reads T at (ih / 2, iw / 2): 51.9 -> ~13 us for the GEMM (round 5: over the 4096 pixels of u6; GRL_TUNE ae_lowres=0)
-  const long ldT = (long)B * (lowres ? 1024 : 4096);
+  // reads T at (ih / 2, iw / 2): 51.9 -> 13.5 us for the GEMM (round 5: over the 4096 pixels of u6)
+  const long ldT = (long)B * 1024;
   float* Tt = wk.f32(49 * ldT);
-  add_launch(ops_ae, "ae_out_conv", 1, {dense_bwd({{P + dw[2], 32, 32, lowres ? d5 : u6}}, 49, 0, (int)ldT, Tt, (int)ldT, nullptr)});
+  add_launch(ops_ae, "ae_out_conv", 1, {dense_bwd({{P + dw[2], 32, 32, d5}}, 49, 0, (int)ldT, Tt, (int)ldT, nullptr)});
   // The forward pass ends with the 49-tap gather-sum; a TRAINING step forms the loss and the output gradient in the same launch
-  // (ae_tapsum_mse_kernel: one launch and 6 us less; GRL_TUNE ae_fused_mse=0: two launches), the forward-only path
+  // (ae_tapsum_mse_kernel: one launch and 6 us less than gather-sum + MSE), the forward-only path
   // (Model.predict / evaluate) ends with the plain gather-sum.
   const long npix = (long)B * 4096;
-  const bool fused_mse = tune_int("ae_fused_mse", 1) != 0;
-  const int n_part = fused_mse ? (int)((npix + 255) / 256) : NPART;
+  const int n_part = (int)((npix + 255) / 256);
   {
     const float* b6 = P + db[2];
-    const int half = lowres ? 1 : 0;
     Op op; op.tag = "ae_out_tapsum";
     op.run = [=](hipStream_t s) {
-      hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix, half);
+      hipLaunchKernelGGL(ae_tapsum_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float*)Tt, ldT, b6, out, npix);
     };
     ae_out = out;
     ops_ae_fwd = ops_ae;            // everything so far + the gather-sum: the forward pass
     ops_ae_fwd.push_back(op);
-    if (!fused_mse) ops_ae.push_back(op);
   }
   // =============================================================== loss
   {
@@ -201,11 +185,8 @@ int grl_ctx::plan_ae() {
     zero_once.push_back({g_pad, (size_t)B * 4900 * 4});   // the 3-pixel border stays zero
     float* part = wk.f32(n_part);
     float* partial_g = wk.f32(n_part);
-    float* gp4 = nullptr;
-    if (lowres) {
-      gp4 = wk.f32((int64_t)4 * B * 1296);
-      zero_once.push_back({gp4, (size_t)4 * B * 1296 * 4});   // the 2-pixel borders stay zero
-    }
+    float* gp4 = wk.f32((int64_t)4 * B * 1296);
+    zero_once.push_back({gp4, (size_t)4 * B * 1296 * 4});   // the 2-pixel borders stay zero
     ae_gp4 = gp4;
     MseArgs ma{out, ae_x, g_out, part, npix, g_pad, partial_g, gp4, (long)B * 1296};
     const float lr = c.lr;
@@ -213,10 +194,9 @@ int grl_ctx::plan_ae() {
     float* gb6 = grads + db[2];
     TapMseArgs ta;
     memset(&ta, 0, sizeof(ta));
-    ta.T = Tt; ta.ldT = ldT; ta.bias = P + db[2]; ta.n_pix = npix; ta.half = lowres ? 1 : 0; ta.m = ma;
-    elem(fused_mse ? "ae_out_tapsum_mse" : "ae_mse", [=](hipStream_t s) {
-      if (fused_mse) hipLaunchKernelGGL(ae_tapsum_mse_kernel, dim3(n_part), dim3(256), 0, s, ta);
-      else hipLaunchKernelGGL(mse_kernel, dim3(n_part), dim3(256), 0, s, ma);
+    ta.T = Tt; ta.ldT = ldT; ta.bias = P + db[2]; ta.n_pix = npix; ta.m = ma;
+    elem("ae_out_tapsum_mse", [=](hipStream_t s) {
+      hipLaunchKernelGGL(ae_tapsum_mse_kernel, dim3(n_part), dim3(256), 0, s, ta);
       hipLaunchKernelGGL(ae_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)part, (const float*)partial_g, n_part,
                          ma.n_total, lr, scp, gb6);
     });
@@ -251,7 +231,7 @@ int grl_ctx::plan_ae() {
     }
     add_launch(ops_ae, tag, 1, pr);
   };
-  if (lowres) {
+  {
     // output conv (7x7, 32 -> 1), weight gradient: dW[tap, c] = sum_p g[p - shift(tap)] u6[p, c] with u6[p] = d5[p / 2]:
     //   dW[tap, c] = sum over the four sub-positions s of a 2 x 2 block, sum over pixels q of d5:  g[2 q + s - shift(tap)] d5[q, c]
     // -- four GEMMs (M = 49 taps, N = 32 channels, K = pixels of d5) whose P operand walks ONE sub-position plane of the
@@ -294,34 +274,8 @@ int grl_ctx::plan_ae() {
       reduces.push_back(r);
     }
     add_launch(ops_ae, "ae_out_wgrad", 0, four, "", 0, {}, 3);      // (32 x 64 tiles, 2-way k split: 47.6 against 53.4 us for the N <= 32 default)
-  } else {
-    // output conv (7x7, 32 -> 1): dW[tap, c] = sum_p g[p - shift(tap)] u6[p, c] -- a GEMM with M = 49 taps, N = 32
-    // channels, K = pixels; g is read from its zero-bordered copy so that no tap needs a mask.  (Its bias
-    // gradient, sum g, comes from the MSE kernel.)
-    {
-      std::vector<int32_t> ti(49), tr((size_t)B * 4096);
-      for (int kh = 0; kh < 7; ++kh)
-        for (int kw = 0; kw < 7; ++kw) ti[kh * 7 + kw] = -((kh - 3) * 70 + (kw - 3));
-      for (int n = 0; n < B; ++n)
-        for (int oh = 0; oh < 64; ++oh)
-          for (int ow = 0; ow < 64; ++ow) tr[((size_t)n * 64 + oh) * 64 + ow] = n * 4900 + (oh + 3) * 70 + (ow + 3);
-      IgemmProb p = blank();
-      p.M = 49; p.N = 32; p.K = B * 4096;
-      p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
-      p.q_base[0] = u6; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
-      p.ldc = 32;
-      // 4-runs along the pixel index (rows are 64 pixels, quads never straddle one) at offsets that are only
-      // 4-byte aligned: 16-byte buffer loads need no more than dword alignment
-      // (measured: the gfx950 buffer_load_dwordx4 takes them, results match the oracle; 103 -> 50 us)
-      p.vflags |= VF_P_TABS;
-      set_split(p, 256);
-      p.c = wk.f32(p.slab_stride * p.split);
-      std::vector<IgemmProb> one;
-      add_wgrad(one, p, dw[2], 0, 49, -1);
-      add_launch(ops_ae, "ae_out_wgrad", 0, one);
-    }
   }
-  if (lowres) {
+  {
     // backward-data of the output conv AND of the up-sampling in front of it, in one product: the gradient of a pixel q of d5 is
     // the sum over its 2 x 2 pixels of u6, each the 7 x 8-tap product of the round-5 launch --
     //   g_d5[q, c] = LeakyReLU'(d5[q, c]) * sum_{s in 2x2} sum_{kh, j} g_pad[pix(2 q + s) - shift(kh, j)] Wp[(kh, j), c]
@@ -345,26 +299,6 @@ int grl_ctx::plan_ae() {
     p.relu_mask = d5; p.act_alpha = LA;
     set_split(p, 1);
     add_launch(ops_ae, "ae_out_conv_bwd", 0, {p});
-  } else {
-    // backward-data of the output conv: g_u6[p, c] = sum_{kh,kw} g_pad[p - shift(kh,kw)] W[kh,kw,c], a GEMM with
-    // M = pixels, N = 32, K = 7 x 8 taps (each kernel row flipped and padded to 8: ae_kernels.h) on the
-    // vectorised kernel -- the taps of a quad are 4 neighbouring gradient pixels
-    float* Wp = W6p;                  // (written by ae_kernel_prep at the start of the step)
-    std::vector<int32_t> ti((size_t)B * 4096), tr(56);
-    for (int n = 0; n < B; ++n)
-      for (int ih = 0; ih < 64; ++ih)
-        for (int iw = 0; iw < 64; ++iw) ti[((size_t)n * 64 + ih) * 64 + iw] = n * 4900 + (ih + 6) * 70 + (iw + 6);
-    for (int kh = 0; kh < 7; ++kh)
-      for (int j = 0; j < 8; ++j) tr[kh * 8 + j] = -kh * 70 - 7 + j;
-    IgemmProb p = blank();
-    p.M = B * 4096; p.N = 32; p.K = 56;
-    p.p_base[0] = g_pad; p.p_tab_i = upload_vec(wk, ti); p.p_tab_r = upload_vec(wk, tr); single_part(p);
-    p.vflags |= VF_P_TABS;                       // 4-runs along the taps, dword-aligned offsets
-    p.q_base[0] = Wp; p.q_ld_r[0] = 32; p.q_ld_j[0] = 1;
-    p.c = g_u6; p.ldc = 32;
-    set_split(p, 1);
-    add_launch(ops_ae, "ae_out_conv_bwd", 0, {p});
-    up_bwd(g_u6, d5, g_d5, 32);
   }
   cw(u5, ftd[1], gdv[1], g_d5, dw[1], db[1], 32);
   cb("ae_dec_conv_bwd", g_d5, gd[1], P + dw[1], g_u5, nullptr);
@@ -387,11 +321,9 @@ int grl_ctx::plan_ae() {
     add_launch(ops_ae, "ae_dense_bwd", 1, {b2});
   }
   cw(e2_p, fte[2], gev[2], g_e3, ew[2], eb[2], 4);
-  if (bordered) cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2_p, 0, 1);
-  else cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2);
+  cb("ae_enc_conv_bwd", g_e3, ge[2], P + ew[2], g_e2, e2_p, 0, 1);
   cw(e1_p, fte[1], gev[1], g_e2, ew[1], eb[1], 16);
-  if (bordered) cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1_p, 1, 2);
-  else cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1);
+  cb("ae_enc_conv_bwd", g_e2, ge[1], P + ew[1], g_e1, e1_p, 1, 2);
   {
     // weight gradient of the 1-channel first convolution (7x7, stride 2): rows = taps, each kernel row padded to 8
     // so that a quad of rows is 4 neighbouring pixels of the bordered image (16-byte loads at dword alignment);

@@ -814,8 +814,8 @@ int grl_ctx::plan_sac() {
         ro.join = true;
         ro.bytes = fo.bytes + ops_rng[0].bytes;
         AdamArgs aq = aa;
-        aq.skip_bucket = tune_int("pf_skip_bucket", 1) != 0;      // (the call's last update -- `fo` -- leaves its gradients in the bucket)
-        ro.bytes -= aq.skip_bucket ? (double)n_train * 4 : 0.0;
+        aq.skip_bucket = 1;                 // (the call's last update -- `fo` -- leaves its gradients in the bucket)
+        ro.bytes -= (double)n_train * 4;
         ro.run = [dr, d_rt, ntiles, lk, has_loss, aq, g2, gx](hipStream_t s) {
           const dim3 grid(ntiles + has_loss + gather_blocks(g2, gx));
           if (g2.rows > 1) hipLaunchKernelGGL(reduce_slabs_gather_kernel<true>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lk, has_loss, aq, 1, g2, gx);

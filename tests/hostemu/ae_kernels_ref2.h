@@ -16,8 +16,7 @@ inline void ae_tapsum_mse_kernel(TapMseArgs a) {
       for (int kw = 0; kw < 7; ++kw) {
         const int iw = ow + kw - 3;
         if (iw < 0 || iw > 63) continue;
-        s += a.half ? a.T[(long)(kh * 7 + kw) * a.ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)]
-                    : a.T[(long)(kh * 7 + kw) * a.ldT + (n << 12) + (ih << 6) + iw];
+        s += a.T[(long)(kh * 7 + kw) * a.ldT + (n << 10) + ((ih >> 1) << 5) + (iw >> 1)];
       }
     }
     const float ov = s + a.bias[0];
