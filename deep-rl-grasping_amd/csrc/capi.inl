@@ -530,6 +530,35 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
+  if (!idx && n_steps >= 2 && h->ride_ok && !h->prof) {
+    // device RNG, several updates, double-buffered images (plan_sac "gather_ride"): update j of the call reads image buffer j % 2
+    // and its head launch gathers the images of update j + 1 into the other one
+    const int max_group = std::max(1, std::min(64, tune_int("graph_updates", 16)));
+    if (n_steps <= 32 && max_group != 1) {        // short calls (SAC.learn: n = number of environments): ONE graph, cached per n
+      std::vector<std::vector<Op>*> seq;
+      seq.push_back(&h->ops_ride_first);
+      for (int j = 1; j + 1 < n_steps; ++j) seq.push_back(&h->ops_ride_mid[j & 1]);
+      seq.push_back(&h->ops_ride_last[(n_steps - 1) & 1]);
+      if (int e = h->run_seq("ride_call_" + std::to_string(n_steps), seq)) return e;
+      HIPCHK(hipGetLastError());
+      return GRL_OK;
+    }
+    if (int e = h->run_seq("ride_first", {&h->ops_ride_first})) return e;
+    int j = 1;                                     // index of the next update within the call
+    while (j + 1 < n_steps) {
+      const int left = n_steps - 1 - j;
+      int group = 1;
+      while (2 * group <= max_group && 2 * group <= left) group *= 2;
+      std::vector<std::vector<Op>*> seq;
+      for (int g = 0; g < group; ++g) seq.push_back(&h->ops_ride_mid[(j + g) & 1]);
+      // (groups are powers of two: every group of two or more starts at the parity of its first update and ends on the other)
+      if (int e = h->run_seq("ride_mid_p" + std::to_string(j & 1) + "_x" + std::to_string(group), seq)) return e;
+      j += group;
+    }
+    if (int e = h->run_seq("ride_last_p" + std::to_string((n_steps - 1) & 1), {&h->ops_ride_last[(n_steps - 1) & 1]})) return e;
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
   if (!idx && n_steps >= 2 && h->prefetch_ok && !h->prof) {   // device RNG, several updates: prefetching sequences (plan_sac)
     // short calls (what SAC.learn issues: n = number of environments) are ONE graph, cached per n
     if (n_steps <= 32 && tune_int("graph_updates", 16) != 1) {

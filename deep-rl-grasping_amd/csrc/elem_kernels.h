@@ -24,7 +24,10 @@ struct DevScalars {
   // metrics of the last update
   float policy_loss, qf1_loss, qf2_loss, value_loss, ent_loss, ent_coef, entropy, mean_qf1, mean_v;
   float lr;                         // learning rate of the current update (grl_set_learning_rate; starts at cfg.lr)
-  float pad1[2];
+  // Philox counter of the minibatch whose IMAGES the head launch gathers ahead (plan_sac "gather_ride"): set to rng_step + 1 by
+  // the gather that opens a multi-update call, advanced by the reduction launch that ends each update -- a word of its own
+  // because the head launch advances rng_step while its riders draw
+  uint64_t rng_img;
   uint64_t rng_step;                // Philox counter (one per drawn minibatch)
   int64_t replay_size;              // transitions currently stored
 };
@@ -96,7 +99,14 @@ struct GatherArgs {
   // the float64 statistics of its element positions are fetched once, the `rows` replay reads are all in flight before the
   // first is used (gather_norm_rows_body); grid = tiles per row x (2 B / rows), linearised (gather_blocks)
   int rows;
+  // parts: 0 = everything (default); 1 = the image tiles only; 2 = the per-row extras only (direct features, action, reward,
+  // done, index, standard normals -- launched with gx = 1).  Multi-update calls with double-buffered images (plan_sac
+  // "gather_ride") gather the IMAGES of update t+1 inside update t's head launch and leave the extras, which update t's
+  // backward pass still reads, to the reduction launch that ends update t.
+  // img_ctr = 1: draw with the counter DevScalars.rng_img (the riders of the head launch); set_img = 1: leave rng_step + 1 there
+  int parts, img_ctr, set_img;
 };
+#define GATHER_RIDE_ROWS 16       /* row instances per rider workgroup of the head launch (gather_images_rider) */
 #define GATHER_ROWS_U8 4          /* rows per workgroup of the grouped form, RGB-D ring with byte colours (GRL_TUNE gather_rows) */
 #define GATHER_ROWS_F32 1         /* float32 rings: one row per workgroup measured fastest (profiles/r06_sweep_gather_rows.txt) */
 // workgroups of a gather launch with gx tiles per row
@@ -196,7 +206,7 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
   int64_t src;
   uint64_t step = 0;
   if (a.use_rng) {
-    step = a.sc->rng_step + (uint64_t)a.rng_ahead;
+    step = a.img_ctr ? a.sc->rng_img : a.sc->rng_step + (uint64_t)a.rng_ahead;
     const int64_t size = a.sc->replay_size;
     uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)b, 0u};
     philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
@@ -206,7 +216,8 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
     src = a.idx[b];
   }
 #ifndef GRL_HOSTEMU
-  if (a.vec4) {
+  if (a.parts == 2) {
+  } else if (a.vec4) {
     typedef float gn_f4 __attribute__((ext_vector_type(4)));
     typedef double gn_d4 __attribute__((ext_vector_type(4)));
     const int e4 = (bx * 256 + threadIdx.x) * 4;
@@ -239,7 +250,7 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
 #endif
   {
   const int e = bx * 256 + threadIdx.x;
-  if (e < a.img_elems) {
+  if (e < a.img_elems && a.parts != 2) {
     const float* rp = which ? a.rp_next : a.rp_obs;
     float x;
     if (a.rgb_u8) {
@@ -259,7 +270,7 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
     }
   }
   }
-  if (bx == 0) {
+  if (bx == 0 && a.parts != 1) {
     const int t = threadIdx.x;
     if (t < a.n_direct) {
       const float* rp = which ? a.rp_dnext : a.rp_dobs;
@@ -308,8 +319,9 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
   }
   // rng_step itself is advanced by the (single-workgroup) loss reduction later in the update: a counter
   // bumped by the last of these 8192 workgroups would serialise 8192 same-address atomics (~100 us)
-  if (bx == 0 && b == 0 && which == 0 && threadIdx.x == 0 && !a.quiet) {
+  if (bx == 0 && b == 0 && which == 0 && threadIdx.x == 0 && !a.quiet && a.parts != 1) {
     if (a.use_rng) a.sc->rng_used = 1u;
+    if (a.use_rng && a.set_img) a.sc->rng_img = step + 1;
     if (a.adam_tick) adam_tick_device(a.sc);
   }
 }
@@ -373,7 +385,7 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
   uint64_t step = 0;
   int64_t mine;
   if (a.use_rng) {
-    step = a.sc->rng_step + (uint64_t)a.rng_ahead;
+    step = a.img_ctr ? a.sc->rng_img : a.sc->rng_step + (uint64_t)a.rng_ahead;
     const int64_t size = a.sc->replay_size;
     uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), (uint32_t)(b0 + (lane % R)), 0u};
     philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
@@ -390,7 +402,7 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
     src[r] = (int64_t)(((uint64_t)hi << 32) | lo);
   }
   const int e4 = (bx * 256 + (int)threadIdx.x) * 4;
-  if (e4 < a.img_elems) {
+  if (e4 < a.img_elems && a.parts != 2) {
     const float* rp = which ? a.rp_next : a.rp_obs;
     gn_f4 x[R];
     if (a.rgb_u8) {            // one pixel per thread: colours from the packed dword, depth from the float plane
@@ -437,16 +449,35 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
       }
     }
   }
-  if (bx == 0) {
+  if (bx == 0 && a.parts != 1) {
 #pragma unroll 1
     for (int r = 0; r < R; ++r) gather_row_extras(a, b0 + r, which, src[r], step);
     if (grp == 0 && threadIdx.x == 0 && !a.quiet) {
       if (a.use_rng) a.sc->rng_used = 1u;
+      if (a.use_rng && a.set_img) a.sc->rng_img = step + 1;
       if (a.adam_tick) adam_tick_device(a.sc);
     }
   }
 }
 #endif
+
+// Workgroup r of the image gather that rides on the head launch (heads_mfma.h; GatherArgs.parts == 1, vec4, B a multiple of
+// GATHER_RIDE_ROWS): tile r % gx of the GATHER_RIDE_ROWS row instances of group r / gx -- the head kernel is compiled for one
+// wave per SIMD (245 registers), so a rider workgroup is alone on its CU and keeps 16 replay reads in flight per lane instead of
+// relying on neighbours to hide its latency.  Same arithmetic per element as every other form of the gather.
+static inline int gather_rider_blocks(const GatherArgs& a, int gx) { return gx * (2 * a.B / a.rows); }
+__device__ __forceinline__ void gather_images_rider(const GatherArgs& a, const int gx, const int r) {
+#ifndef GRL_HOSTEMU
+  if (a.rows == 16) gather_norm_rows_body<16>(a, r % gx, r / gx);
+  else if (a.rows == 8) gather_norm_rows_body<8>(a, r % gx, r / gx);
+  else gather_norm_rows_body<4>(a, r % gx, r / gx);
+#else
+  for (int k = 0; k < a.rows; ++k) {
+    const int i = (r / gx) * a.rows + k;
+    gather_norm_body(a, r % gx, i % a.B, i / a.B);
+  }
+#endif
+}
 
 // workgroup r of a linearised gather grid (gather_blocks) with gx tiles per row.  GROUPED is a compile-time choice of the
 // LAUNCH (the plan picks the kernel by GatherArgs.rows): a kernel that could take either form is allocated the registers of
@@ -767,6 +798,7 @@ struct LossArgs {
   // one trainable scalar whose gradient is produced here
   float* ent_param; float* ent_m; float* ent_v;
   int keep_rng;   // 1: leave rng_step alone (multi-update calls whose head launch advances the counter, engine.hip "prefetch")
+  int bump_img;   // 1: advance DevScalars.rng_img (the riders of the NEXT head launch draw the minibatch after the next)
 };
 
 #ifdef GRL_HOSTEMU
@@ -829,6 +861,7 @@ __device__ __forceinline__ void sac_loss_body(const LossArgs& a, int fuse_adam =
     }
     if (fuse_adam) adam_elem(a.g_log_ent_coef[0], a.ent_param[0], a.ent_m[0], a.ent_v[0], sc->adam_alpha, 1e-8f);
     if (sc->rng_used && !a.keep_rng) { sc->rng_step += 1; sc->rng_used = 0u; }   // this minibatch came from the device RNG
+    if (a.bump_img) sc->rng_img += 1;
   }
 }
 #ifndef GRL_ELEM_TYPES_ONLY

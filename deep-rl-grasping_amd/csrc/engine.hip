@@ -281,6 +281,19 @@ struct grl_ctx {
   std::vector<Op> ops_grads_apply; // SAC: ops_grads with Adam + Polyak fused into the slab-reduction launch (full updates)
   // SAC, calls of several updates on the device RNG: the next minibatch is gathered inside the last launch of an update
   std::vector<Op> ops_pf_first, ops_pf_mid, ops_pf_last;
+  // "gather_ride": the same three kinds of update with the minibatch IMAGES double buffered (x_obs / x_obs_b).  Flavour f reads
+  // buffer f; its head launch carries the image gather of update t+1 into the other buffer as extra workgroups (heads_mfma.h),
+  // its reduction launch the per-row extras of update t+1 (GatherArgs.parts)
+  std::vector<Op> ops_ride_first, ops_ride_mid[2], ops_ride_last[2];
+  bool ride_ok = false;
+  float* x_obs_b = nullptr;
+  Op wgrad_conv_alt;                    // the merged weight-gradient launch with conv1's operand in x_obs_b
+  bool have_wgrad_conv_alt = false;
+  ConvStackArgs ride_conv_args;         // arguments of the forward stack as planned (reading x_obs)
+  const HeadsFusedArgs* ride_heads_args = nullptr;   // [3] argument blocks of the head launch (plain, first, later updates)
+  int ride_heads_shape = 0, ride_heads_nblk = 0;
+  LossArgs ride_lk;                     // loss arguments / extras gather the riding reductions carry (data-parallel connect)
+  GatherArgs ride_g2;
   Op pf_heads[2];
   float* ae_gp4 = nullptr;               // auto-encoder step: the output gradient's four sub-position planes (plan_ae, MseArgs.gp4)
   GatherArgs pf_ga;

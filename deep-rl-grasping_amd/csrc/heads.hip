@@ -8,15 +8,21 @@
 #endif
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define GRL_ELEM_TYPES_ONLY     // (the element-wise kernels are compiled in engine.hip)
 #include "launch.h"
 
 namespace grl {
 
-void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args) {
-  if (shape == HEADS_FAST_128) hipLaunchKernelGGL((heads_fused_kernel<128, true>), dim3(nblk, 4), dim3(256), 0, s, args);
-  else if (shape == HEADS_FAST_64) hipLaunchKernelGGL((heads_fused_kernel<64, true>), dim3(nblk, 4), dim3(256), 0, s, args);
-  else hipLaunchKernelGGL((heads_fused_kernel<64, false>), dim3(nblk, 4), dim3(256), 0, s, args);
+void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args, const GatherArgs* ride, int ride_gx) {
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  int n_ride = 0;
+  if (ride) { g = *ride; n_ride = gather_rider_blocks(g, ride_gx); }
+  const dim3 grid(nblk, 4 + (n_ride + nblk - 1) / nblk);
+  if (shape == HEADS_FAST_128) hipLaunchKernelGGL((heads_fused_kernel<128, true>), grid, dim3(256), 0, s, args, g, ride_gx, n_ride);
+  else if (shape == HEADS_FAST_64) hipLaunchKernelGGL((heads_fused_kernel<64, true>), grid, dim3(256), 0, s, args, g, ride_gx, n_ride);
+  else hipLaunchKernelGGL((heads_fused_kernel<64, false>), grid, dim3(256), 0, s, args, g, ride_gx, n_ride);
 }
 bool q_mfma_built() {
 #ifdef GRL_HOSTEMU

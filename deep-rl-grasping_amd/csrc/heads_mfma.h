@@ -750,8 +750,17 @@ __device__ __forceinline__ void heads_fused_body(const HeadsFusedArgs* __restric
   stamp();
 }
 
+// gp / gx / n_ride: the image gather of the NEXT update riding on this launch (plan_sac "gather_ride"; gather_images_rider):
+// n_ride workgroups behind the 4 rows of head workgroups, linearised over blockIdx.y >= 4.  The head chains leave three CUs in
+// four idle for 16 us; the images land in the buffer this update does not read.
 template <int W, bool FAST>
-__global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* __restrict__ ap) {
+__global__ __launch_bounds__(256) void heads_fused_kernel(const HeadsFusedArgs* __restrict__ ap, const GatherArgs g, const int gx,
+                                                         const int n_ride) {
+  if (blockIdx.y >= 4) {
+    const int r = ((int)blockIdx.y - 4) * (int)gridDim.x + (int)blockIdx.x;
+    if (r < n_ride) gather_images_rider(g, gx, r);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) HmLds<W> s;
   if constexpr (W == 128) {      // (the same split of the 64-wide fast kernel measured neutral: 5 780 / 5 758 against 5 776 / 5 759)
     if (blockIdx.y == 0) heads_fused_body<W, FAST, 0>(ap, s);

@@ -42,7 +42,8 @@ bool q_chain_available(bool mfma, bool fits);   // q_chain.h: backward chains th
 bool act_mfma_built();               // act_mfma.h: policy head of grl_act on MFMA stages
 int device_lds_bytes();              // shared memory a workgroup may declare on the current device (emulation: no limit)
 enum { HEADS_GENERAL_64 = 0, HEADS_FAST_64 = 1, HEADS_FAST_128 = 2 };
-void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args);
+// ride: the next update's image gather as extra workgroups (NULL: none); ride_gx tiles per row
+void launch_heads_fused(int shape, int nblk, hipStream_t s, const HeadsFusedArgs* args, const GatherArgs* ride = nullptr, int ride_gx = 0);
 size_t heads_fused_lds_bytes(int shape);
 void launch_heads_fwd(const HeadsFwdArgs& a, hipStream_t s);
 void launch_heads_bwd(const HeadsBwdArgs& a, hipStream_t s);

@@ -72,6 +72,9 @@ int grl_ctx::plan_sac() {
   if (cnn) {
     x_obs = wk.f32((int64_t)B * img_elems);
     x_next = wk.f32((int64_t)B * img_elems);
+    // second image buffer ("gather_ride" below).  Default: float32 rings only -- on the byte-colour ring (RGB-D, 50 MB per gather) the
+    // riders' traffic doubles the latency of the head chains they share the launch with: 4 480 against 4 720 updates/s
+    x_obs_b = tune_int("gather_ride", c.replay_rgb_u8 ? 0 : 1) != 0 ? wk.f32((int64_t)B * img_elems) : nullptr;
     // Layer-1 activations of the two TRAINED networks (and their gradients below) sit side by side, pixel stride 64:
     // pi in columns 0..31, values_fn in 32..63.  Both networks read the same observations, so conv1's weight
     // gradient becomes ONE product obs-patches^T x [dY_pi | dY_vf] (N = 64: full 64x64 tiles, the gathered patches
@@ -223,6 +226,7 @@ int grl_ctx::plan_sac() {
       op.flops = op.flops_exec = 2.0 * B * 3 * (225.0 * 32 * 64 * Ci + 36.0 * 64 * 512 + 16.0 * 64 * 576);
       op.run = [ca, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, ca, s); };
       ops_grads.push_back(op);
+      ride_conv_args = ca;
     } else {
     const char* tags[3] = {"conv1_fwd", "conv2_fwd", "conv3_fwd"};
     for (int l = 0; l < 3; ++l) {
@@ -334,6 +338,7 @@ int grl_ctx::plan_sac() {
         op.run = [dv, nblk, shape](hipStream_t s) { launch_heads_fused(shape, nblk, s, dv); };
         if (v == 0) ops_grads.push_back(op);
         else pf_heads[v - 1] = op;
+        ride_heads_args = d_ha; ride_heads_shape = shape; ride_heads_nblk = nblk;
       }
     } else {
     Op op; op.tag = "heads_fwd";
@@ -683,6 +688,14 @@ int grl_ctx::plan_sac() {
       for (int l = 2; l >= 0; --l) all.insert(all.end(), wgc[l].begin(), wgc[l].end());
       all.insert(all.end(), wg_merged.begin(), wg_merged.end());
       add_launch(wgrad_ops, "wgrad_conv", 2, all);
+      if (x_obs_b && cnn) {      // the same launch reading conv1's input from the second image buffer (flavour 1 of "gather_ride")
+        bool patched = false;
+        for (auto& p : all)
+          if (p.p_base[0] == x_obs) { p.p_base[0] = x_obs_b; patched = true; }
+        std::vector<Op> tmp;
+        if (patched) add_launch(tmp, "wgrad_conv", 2, all);
+        if (tmp.size() == 1) { wgrad_conv_alt = tmp[0]; have_wgrad_conv_alt = true; }
+      }
     }
   }
   // ---- schedule: every weight-gradient launch directly behind the last producer of its operands
@@ -831,6 +844,89 @@ int grl_ctx::plan_sac() {
         }
         pf_lk = lk; pf_g2 = g2;     // (the data-parallel update builds its own final launches from these at connect)
         prefetch_ok = true;
+        // ---- "gather_ride": the IMAGES of update t+1 gathered by extra workgroups of update t's HEAD launch -- 64 workgroups of
+        // row-local chains on 256 CUs for 16 us -- instead of the reduction launch, which is memory bound itself.  What the
+        // gather writes and update t still reads after its head launch: x_obs (conv1's weight gradient, in the last GEMM launch)
+        // -- double buffered, flavour f reads buffer f and gathers into the other; x_next (read by the forward stack only) needs
+        // no second copy; the per-row extras (direct features, action, reward, done, index, noise: read by the head launch and
+        // the dense weight gradients) stay with the reduction launch that ends the update, as a gather of parts = 2.  Counters:
+        // the riders draw with DevScalars.rng_img (the head launch itself advances rng_step), which the call's first gather
+        // sets and every riding reduction advances.
+        //   first : gather[rng_img = c + 1] | body(A), heads[tick; images(t+1) -> B] | reduce + Adam + extras(t+1) [rng_img += 1]
+        //   middle: body(f), heads[tick, counter += 1; images(t+1) -> other] | reduce + Adam + extras(t+1) [rng_img += 1]
+        //   last  : body(f), heads[tick, counter += 1]                        | reduce + Adam (counter += 1)
+        if (x_obs_b && conv_stack && have_wgrad_conv_alt && !conv_stack_bwd && (g2.vec4 || !elem_vec4_built()) && B % GATHER_RIDE_ROWS == 0 &&
+            ride_heads_args) {      // (the emulation build has no 16-byte form: its riders walk the rows element by element)
+          Op conv_alt;                                 // the forward stack reading the observations from x_obs_b
+          bool have_conv_alt = false;
+          for (auto& o : ops_grads_apply)
+            if (o.tag == "conv_stack_fwd") {
+              ConvStackArgs cb = ride_conv_args;
+              cb.nets[0].x = x_obs_b; cb.nets[1].x = x_obs_b;
+              const int Ci = C_img;
+              conv_alt = o;
+              conv_alt.run = [cb, Ci](hipStream_t s) { launch_conv_stack_fwd(Ci, cb, s); };
+              have_conv_alt = true;
+            }
+          int ride_rows = tune_int("ride_rows", GATHER_RIDE_ROWS);
+          if (ride_rows != 4 && ride_rows != 8 && ride_rows != 16) ride_rows = GATHER_RIDE_ROWS;
+          if (have_conv_alt) {
+            GatherArgs gx2 = g2;                         // extras of update t+1, carried by update t's reduction launch
+            gx2.parts = 2;
+            LossArgs lr3 = lk;
+            lr3.bump_img = 1;
+            Op rx; rx.tag = "reduce_adam";
+            rx.join = true;
+            rx.bytes = ro.bytes - ops_rng[0].bytes;
+            rx.run = [dr, d_rt, ntiles, lr3, has_loss, aq, gx2](hipStream_t s) {
+              const dim3 grid(ntiles + has_loss + gather_blocks(gx2, 1));
+              if (gx2.rows > 1) hipLaunchKernelGGL(reduce_slabs_gather_kernel<true>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lr3, has_loss, aq, 1, gx2, 1);
+              else hipLaunchKernelGGL(reduce_slabs_gather_kernel<false>, grid, dim3(256), 0, s, dr, d_rt, ntiles, lr3, has_loss, aq, 1, gx2, 1);
+            };
+            ride_lk = lr3; ride_g2 = gx2;
+            Op first_g = ops_pf_first[0];                // the call's own gather, leaving rng_img behind
+            {
+              GatherArgs g0 = g1;
+              g0.set_img = 1;
+              first_g.run = [g0, gx](hipStream_t s) {
+                if (g0.rows > 1) hipLaunchKernelGGL(gather_norm_lin_kernel, dim3(gather_blocks(g0, gx)), dim3(256), 0, s, g0, gx);
+                else hipLaunchKernelGGL(gather_norm_kernel, dim3(gx, g0.B, 2), dim3(256), 0, s, g0);
+              };
+            }
+            const HeadsFusedArgs* d_ha = ride_heads_args;
+            const int hshape = ride_heads_shape, hnblk = ride_heads_nblk;
+            for (int f = 0; f < 2; ++f) {
+              GatherArgs gi = g2;                        // images of update t+1 into the buffer flavour f does NOT read
+              gi.parts = 1; gi.img_ctr = 1; gi.rng_ahead = 0; gi.quiet = 1;
+              gi.rows = ride_rows;
+              gi.x_obs = f ? x_obs : x_obs_b;
+              Op heads_ride[2];                          // [0] the call's first update, [1] later ones (see pf_heads)
+              for (int v = 0; v < 2; ++v) {
+                heads_ride[v] = pf_heads[v];
+                const HeadsFusedArgs* dv = d_ha + 1 + v;
+                heads_ride[v].bytes = ops_rng[0].bytes;
+                heads_ride[v].run = [dv, hnblk, hshape, gi, gx](hipStream_t s) { launch_heads_fused(hshape, hnblk, s, dv, &gi, gx); };
+              }
+              for (int v = (f ? 1 : 0); v < 3; ++v) {    // (the call's first update is always flavour 0)
+                const std::vector<Op>& src = v == 0 ? ops_pf_first : (v == 1 ? ops_pf_mid : ops_pf_last);
+                std::vector<Op>& dst = v == 0 ? ops_ride_first : (v == 1 ? ops_ride_mid[f] : ops_ride_last[f]);
+                for (size_t k = 0; k < src.size(); ++k) {
+                  const bool last_op = k + 1 == src.size();
+                  if (v == 0 && k == 0) dst.push_back(first_g);
+                  else if (src[k].tag == "conv_stack_fwd") dst.push_back(f ? conv_alt : src[k]);
+                  else if (src[k].tag == "wgrad_conv") dst.push_back(f ? wgrad_conv_alt : src[k]);
+                  else if (src[k].tag == "heads" && v != 2) dst.push_back(heads_ride[v == 0 ? 0 : 1]);
+                  else if (last_op && v != 2) dst.push_back(rx);
+                  else dst.push_back(src[k]);
+                }
+              }
+            }
+            ride_ok = true;
+            if (getenv("GRL_PLAN_DUMP"))
+              fprintf(stderr, "grl plan: gather_ride  %d image-gather workgroups of the next update ride on the head launch (%d tiles per row, %d rows each); extras on the reduction launch\n",
+                      gx * (2 * B / ride_rows), gx, ride_rows);
+          }
+        }
       }
     }
   }

@@ -33,5 +33,6 @@ inline void sac_loss_body(const LossArgs& a, int fuse_adam = 0) {
   }
   if (fuse_adam) adam_elem(-mean_lp_h, a.ent_param[0], a.ent_m[0], a.ent_v[0], sc->adam_alpha, 1e-8f);
   if (sc->rng_used && !a.keep_rng) { sc->rng_step += 1; sc->rng_used = 0u; }
+  if (a.bump_img) sc->rng_img += 1;
 }
 inline void sac_loss_kernel(LossArgs a) { sac_loss_body(a); }

@@ -63,7 +63,12 @@ inline void hm_ref_bwd(const HtHead& h, int row, const float* zs, const float* d
 }
 
 template <int W, bool FAST>
-void heads_fused_kernel(const HeadsFusedArgs* ap) {
+void heads_fused_kernel(const HeadsFusedArgs* ap, const GatherArgs g, const int gx, const int n_ride) {
+  if (blockIdx.y >= 4) {      // the next update's image gather riding on the launch (every thread takes part)
+    const int r = ((int)blockIdx.y - 4) * (int)gridDim.x + (int)blockIdx.x;
+    if (r < n_ride) gather_images_rider(g, gx, r);
+    return;
+  }
   if (threadIdx.x != 0) return;
   const HeadsFusedArgs& a = *ap;
   if (blockIdx.x == 0 && blockIdx.y == 0 && a.sc) {

@@ -310,6 +310,38 @@ def test_multi_update_call_prefetch_is_bit_identical_b256(monkeypatch):
         assert ref[4] == got[4]
 
 
+@pytest.mark.parametrize("kw", [dict(kind="depth"), dict(kind="rgbd", rgb_u8=True)], ids=["depth", "rgbd_u8"])
+def test_image_gather_riding_on_the_head_launch_is_bit_identical_b256(monkeypatch, kw):
+    """plan_sac "gather_ride" at the bench shapes (depth float32 ring, RGB-D byte-colour ring): the images of minibatch t+1 are
+    gathered by extra workgroups of update t's head launch into the second image buffer.  Calls of 3 / 4 updates (both buffer
+    parities), a call longer than one graph (37 = 1 + 32 + 2 + 1 + 1: grouped sequences of both parities) and the same with the
+    rider switched off must all leave the bits of single-update calls."""
+    case = pu.make_case(extractor="augmented", B=256, n_replay=512, n_steps=1, **kw)
+
+    def run(split, tune=None):
+        if tune:
+            monkeypatch.setenv("GRL_TUNE", tune)
+        eng = pu.engine_setup(case)
+        for n in split:
+            eng.train(n)
+        out = (eng.get_parameters(), eng.fetch("adam_m").copy(), eng.fetch("adam_v").copy(), eng.fetch("idx_raw").copy(),
+               eng.fetch("x_obs").copy(), eng.metrics())
+        eng.close()
+        if tune:
+            monkeypatch.delenv("GRL_TUNE")
+        return out
+    ref = run([1] * 7)
+    for got in (run([3, 4], tune="gather_ride=1"), run([7], tune="gather_ride=0")):     # (the byte-colour ring's default is off)
+        assert all(np.array_equal(ref[0][n], got[0][n]) for n in ref[0])
+        assert all(np.array_equal(a, b) for a, b in zip(ref[1:4], got[1:4]))
+        assert ref[5] == got[5]
+    long_ref = run([37], tune="gather_ride=0")
+    got = run([37], tune="gather_ride=1")
+    assert all(np.array_equal(long_ref[0][n], got[0][n]) for n in long_ref[0])
+    assert all(np.array_equal(a, b) for a, b in zip(long_ref[1:4], got[1:4]))
+    assert long_ref[5] == got[5]
+
+
 def test_conv_stack_is_bit_identical_to_the_per_layer_launches_where_the_order_is_the_same(monkeypatch):
     """csrc/conv_stack.h sums every output in increasing k, one fmaf per step -- the order of the per-layer implicit-GEMM
     launches whose reduction stays in one wave (conv1, conv2; conv3's per-layer launch adds the partial sums of wave pairs).

@@ -150,6 +150,37 @@ def test_multi_update_calls_prefetch_the_next_minibatch_bit_identically(hostemu_
     assert all(np.array_equal(outs[0][n], outs[1][n]) for n in outs[0])
 
 
+def test_image_gather_riding_on_the_head_launch_is_bit_identical(hostemu_lib, monkeypatch, capfd):
+    """plan_sac "gather_ride" (CNN policies, batch a multiple of 16): the images of minibatch t+1 are gathered by extra workgroups
+    of update t's head launch into the image buffer update t does not read, the per-row extras by the reduction launch; the
+    riders draw with DevScalars.rng_img.  Calls of 2 .. 5 updates (both buffer parities at the end of a call, calls that start on
+    either) must leave the parameters, the Adam state, the last minibatch's indices and the metrics of single-update calls."""
+    case = pu.make_case(extractor="augmented", kind="depth", B=16, n_replay=48, n_steps=1)
+
+    def run(split, tune=None):
+        if tune:
+            monkeypatch.setenv("GRL_TUNE", tune)
+        eng = pu.engine_setup(case, backend=NumpyHostBackend(), lib_path=hostemu_lib)
+        for n in split:
+            eng.train(n)
+        out = (eng.get_parameters(), [eng.fetch("adam_m").copy(), eng.fetch("adam_v").copy(), eng.fetch("idx_raw").copy()], eng.metrics())
+        eng.close()
+        if tune:
+            monkeypatch.delenv("GRL_TUNE")
+        return out
+    monkeypatch.setenv("GRL_PLAN_DUMP", "1")
+    Pa, xa, ma = run([1, 1, 1, 1, 1])
+    assert "gather_ride" in capfd.readouterr().err
+    monkeypatch.delenv("GRL_PLAN_DUMP")
+    for split in ([5], [2, 3], [4, 1]):
+        Pb, xb, mb = run(split)
+        assert all(np.array_equal(Pa[n], Pb[n]) for n in Pa), split
+        assert all(np.array_equal(a, b) for a, b in zip(xa, xb)), split
+        assert ma == mb, split
+    Pc, xc, mc = run([5], tune="gather_ride=0")
+    assert all(np.array_equal(Pa[n], Pc[n]) for n in Pa) and all(np.array_equal(a, b) for a, b in zip(xa, xc)) and ma == mc
+
+
 def test_overlapped_in_graph_exchange_with_one_rank_equals_the_fused_update(hostemu_lib):
     """grl_allreduce_set_overlap with world = 1: the staged plan, the dense pieces of the bucket exchanged on channel 0 and
     the convolution pieces on channel 1 (several disjoint ranges each), Adam waiting for both -- exactly the parameters of
