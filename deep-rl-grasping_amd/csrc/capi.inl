@@ -530,32 +530,8 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
   if ((idx == nullptr) != (eps == nullptr)) return fail(GRL_ERR_INVALID, "idx and eps must both be given or both be NULL");
   if (h->rp_size < 1) return fail(GRL_ERR_STATE, "replay buffer is empty");
   h->grad_scale = 1.f;
-  if (!idx && n_steps >= 2 && h->ride_ok && !h->prof) {
-    // device RNG, several updates, double-buffered images (plan_sac "gather_ride"): update j of the call reads image buffer j % 2
-    // and its head launch gathers the images of update j + 1 into the other one
-    const int max_group = std::max(1, std::min(64, tune_int("graph_updates", 16)));
-    if (n_steps <= 32 && max_group != 1) {        // short calls (SAC.learn: n = number of environments): ONE graph, cached per n
-      std::vector<std::vector<Op>*> seq;
-      seq.push_back(&h->ops_ride_first);
-      for (int j = 1; j + 1 < n_steps; ++j) seq.push_back(&h->ops_ride_mid[j & 1]);
-      seq.push_back(&h->ops_ride_last[(n_steps - 1) & 1]);
-      if (int e = h->run_seq("ride_call_" + std::to_string(n_steps), seq)) return e;
-      HIPCHK(hipGetLastError());
-      return GRL_OK;
-    }
-    if (int e = h->run_seq("ride_first", {&h->ops_ride_first})) return e;
-    int j = 1;                                     // index of the next update within the call
-    while (j + 1 < n_steps) {
-      const int left = n_steps - 1 - j;
-      int group = 1;
-      while (2 * group <= max_group && 2 * group <= left) group *= 2;
-      std::vector<std::vector<Op>*> seq;
-      for (int g = 0; g < group; ++g) seq.push_back(&h->ops_ride_mid[(j + g) & 1]);
-      // (groups are powers of two: every group of two or more starts at the parity of its first update and ends on the other)
-      if (int e = h->run_seq("ride_mid_p" + std::to_string(j & 1) + "_x" + std::to_string(group), seq)) return e;
-      j += group;
-    }
-    if (int e = h->run_seq("ride_last_p" + std::to_string((n_steps - 1) & 1), {&h->ops_ride_last[(n_steps - 1) & 1]})) return e;
+  if (!idx && n_steps >= 2 && h->ride_ok && !h->prof) {     // device RNG, several updates, double-buffered images (plan_sac "gather_ride")
+    if (int e = h->run_ride("ride", &h->ops_ride_first, h->ops_ride_mid, h->ops_ride_last, n_steps)) return e;
     HIPCHK(hipGetLastError());
     return GRL_OK;
   }
@@ -967,6 +943,22 @@ int grl_allreduce_connect(grl_handle h, const void* handles) {
         for (size_t k = 1; k < tail.size(); ++k) pf[v]->push_back(tail[k]);
       }
     }
+    // ... or, with double-buffered images, the image gather riding on the head launch and the extras on K1 (plan_sac "gather_ride")
+    for (int f = 0; f < 2; ++f) { h->ops_ridedp_mid[one][f].clear(); h->ops_ridedp_last[one][f].clear(); }
+    h->ops_ridedp_first[one].clear();
+    if (h->ride_ok) {
+      auto close = [&](const std::vector<Op>& src, std::vector<Op>& dst, bool last) {
+        dst.assign(src.begin(), src.end() - 1);
+        if (last) dst.push_back(dp_k1_op(h, h->red_all, d, h->loss_args, nullptr, 0, "reduce_publish"));
+        else dst.push_back(dp_k1_op(h, h->red_all, d, h->ride_lk, &h->ride_g2, 1, "reduce_publish"));
+        for (size_t k = 1; k < tail.size(); ++k) dst.push_back(tail[k]);
+      };
+      close(h->ops_ride_first, h->ops_ridedp_first[one], false);
+      for (int f = 0; f < 2; ++f) {
+        close(h->ops_ride_mid[f], h->ops_ridedp_mid[one][f], false);
+        close(h->ops_ride_last[f], h->ops_ridedp_last[one][f], true);
+      }
+    }
   }
   // ---- the overlapped update (grl_allreduce_set_overlap): the staged plan (grl_compute_grads_staged) with both exchanges in
   // the graph.  After heads_dfeat a SIDE LANE forms the dense layers' weight gradients, reduces them (publishing) and
@@ -1031,6 +1023,10 @@ int grl_allreduce_disconnect(grl_handle h) {
   for (auto* v : {&h->ops_dp, &h->ops_dp1, &h->ops_pfdp_first, &h->ops_pfdp_mid, &h->ops_pfdp_last, &h->ops_pfdp1_first,
                   &h->ops_pfdp1_mid, &h->ops_pfdp1_last, &h->dp_body, &h->dp_body_per, &h->ops_dp_overlap})
     v->clear();
+  for (int one = 0; one < 2; ++one) {
+    h->ops_ridedp_first[one].clear();
+    for (int f = 0; f < 2; ++f) { h->ops_ridedp_mid[one][f].clear(); h->ops_ridedp_last[one][f].clear(); }
+  }
   for (int p = 0; p < 2 * DP_MAX_WORLD; ++p)
     if (h->dp_peer[p]) { (void)hipIpcCloseMemHandle(h->dp_peer[p]); h->dp_peer[p] = nullptr; }
   if (h->dp_buf) (void)hipFree(h->dp_buf);
@@ -1084,7 +1080,11 @@ int grl_train_step_allreduce(grl_handle h, int n_steps, const int64_t* idx, cons
   const std::string sfx = one ? "1" : "";
   std::vector<Op>* pf[3] = {one ? &h->ops_pfdp1_first : &h->ops_pfdp_first, one ? &h->ops_pfdp1_mid : &h->ops_pfdp_mid,
                             one ? &h->ops_pfdp1_last : &h->ops_pfdp_last};
-  if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !pf[1]->empty() && tune_int("gather_prefetch", 1)) {
+  if (!idx && n_steps >= 2 && !h->dp_overlap && h->ride_ok && !h->prof && !h->ops_ridedp_first[one ? 1 : 0].empty()) {
+    // plain exchange on the device RNG, double-buffered images: the image gather of update t+1 rides on update t's head launch
+    const int o = one ? 1 : 0;
+    if (int e = h->run_ride("dpr" + sfx, &h->ops_ridedp_first[o], h->ops_ridedp_mid[o], h->ops_ridedp_last[o], n_steps)) return e;
+  } else if (!idx && n_steps >= 2 && !h->dp_overlap && h->prefetch_ok && !h->prof && !pf[1]->empty() && tune_int("gather_prefetch", 1)) {
     // plain exchange on the device RNG: the prefetching sequences (the gather of update t+1 rides on the reduction of update t)
     if (int e = h->run_seq("dpp_first" + sfx, {pf[0]})) return e;
     if (n_steps > 2)

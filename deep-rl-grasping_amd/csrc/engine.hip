@@ -330,6 +330,8 @@ struct grl_ctx {
   std::vector<Op> ops_dp1;               // one-shot: reduce + publish | sum of all ranks + Adam + Polyak
   std::vector<Op> ops_pfdp_first, ops_pfdp_mid, ops_pfdp_last;      // prefetching sequences ending in the two-shot exchange (built at connect)
   std::vector<Op> ops_pfdp1_first, ops_pfdp1_mid, ops_pfdp1_last;   // ... in the one-shot exchange
+  // ... and the "gather_ride" sequences ending in the exchange: [0] two-shot, [1] one-shot; flavour = image buffer the update reads
+  std::vector<Op> ops_ridedp_first[2], ops_ridedp_mid[2][2], ops_ridedp_last[2][2];
   LossArgs pf_lk;                        // loss arguments / gather of the NEXT update as the prefetching reductions carry them (plan_sac)
   GatherArgs pf_g2;
   std::vector<Op> dp_body;               // ops_grads without its final reduction (the exchange's first kernel forms the sums)
@@ -423,6 +425,33 @@ struct grl_ctx {
       count -= group;
     }
     return GRL_OK;
+  }
+
+  // A call of n >= 2 updates with double-buffered minibatch images (plan_sac "gather_ride"): update j reads image buffer j % 2
+  // and its head launch gathers the images of update j + 1 into the other one.  first: the call's first update (flavour 0);
+  // mid[f] / last[f]: later updates reading buffer f.
+  int run_ride(const std::string& key, std::vector<Op>* first, std::vector<Op>* mid, std::vector<Op>* last, int n_steps) {
+    const int max_group = std::max(1, std::min(64, tune_int("graph_updates", 16)));
+    if (n_steps <= 32 && max_group != 1) {        // short calls (SAC.learn: n = number of environments): ONE graph, cached per n
+      std::vector<std::vector<Op>*> seq;
+      seq.push_back(first);
+      for (int j = 1; j + 1 < n_steps; ++j) seq.push_back(&mid[j & 1]);
+      seq.push_back(&last[(n_steps - 1) & 1]);
+      return run_seq(key + "_call_" + std::to_string(n_steps), seq);
+    }
+    if (int e = run_seq(key + "_first", {first})) return e;
+    int j = 1;                                     // index of the next update within the call
+    while (j + 1 < n_steps) {
+      const int left = n_steps - 1 - j;
+      int group = 1;
+      while (2 * group <= max_group && 2 * group <= left) group *= 2;
+      std::vector<std::vector<Op>*> seq;
+      for (int g = 0; g < group; ++g) seq.push_back(&mid[(j + g) & 1]);
+      // (groups are powers of two: every group of two or more starts at the parity of its first update and ends on the other)
+      if (int e = run_seq(key + "_mid_p" + std::to_string(j & 1) + "_x" + std::to_string(group), seq)) return e;
+      j += group;
+    }
+    return run_seq(key + "_last_p" + std::to_string((n_steps - 1) & 1), {&last[(n_steps - 1) & 1]});
   }
 
   // ---------------------------------------------------------------- helpers
