@@ -156,6 +156,35 @@ __device__ __forceinline__ float norm_elem_rcp(float x, double mu, double sd, do
   return scale_elem((float)q, scale_div);
 }
 
+// The same for the shape every CNN policy has -- normalised, divisor 255, clip <= 2^22 (so |y| is inside scale_elem's exact range
+// by construction) -- WITHOUT the per-element branch to the general division: that branch ends the basic block after every
+// element, so the compiler cannot interleave the float64 chains of the independent elements a thread holds (10 dependent float64
+// instructions each).  Measured on the riders of the head launch, one wave per SIMD: ~350 cycles per element with the branch.
+__device__ __forceinline__ bool norm_fast255(int normalize, double clip, float scale_div) {
+  return normalize && scale_div == 255.f && clip >= 0.0 && clip <= 4194304.0;
+}
+__device__ __forceinline__ float norm_elem_div255(float x, double mu, double sd, double clip) {      // (the division itself)
+#pragma clang fp contract(off)
+  double q = ((double)x - mu) / sd;
+  q = __builtin_fmax(__builtin_fmin(q, clip), -clip);
+  const float y = (float)q, r255 = 1.f / 255.f;
+  const float t = y * r255;
+  return __builtin_fmaf(__builtin_fmaf(-255.f, t, y), r255, t);
+}
+__device__ __forceinline__ float norm_elem_rcp255(float x, double mu, double sd, double r, double clip) {
+#pragma clang fp contract(off)
+  const double d = (double)x - mu;
+  double q = d * r;
+  double e = __builtin_fma(-sd, q, d);
+  q = __builtin_fma(e, r, q);
+  e = __builtin_fma(-sd, q, d);
+  q = __builtin_fma(e, r, q);
+  q = __builtin_fmax(__builtin_fmin(q, clip), -clip);
+  const float y = (float)q, r255 = 1.f / 255.f;
+  const float t = y * r255;
+  return __builtin_fmaf(__builtin_fmaf(-255.f, t, y), r255, t);
+}
+
 // One minibatch row (observation, next observation, action, reward, done) by the 256 threads of a workgroup: what the
 // blocks (*, b, 0..1) of gather_norm_kernel do for row b, element by element -- for launches that already own a row
 // (the prioritised sampler knows the replay index of its row and gathers it on the spot, per_kernels.h).
@@ -235,10 +264,17 @@ __device__ __forceinline__ void gather_norm_body(const GatherArgs& a, const int 
       gn_d4 mu = {0.0, 0.0, 0.0, 0.0}, sd = {1.0, 1.0, 1.0, 1.0};
       if (a.normalize) { mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4); }
       gn_f4 y;
+      if (norm_fast255(a.normalize, a.clip_obs, a.scale_div)) {      // (uniform; four independent chains, no branch between them)
+        y.x = norm_elem_div255(x.x, mu.x, sd.x, a.clip_obs);
+        y.y = norm_elem_div255(x.y, mu.y, sd.y, a.clip_obs);
+        y.z = norm_elem_div255(x.z, mu.z, sd.z, a.clip_obs);
+        y.w = norm_elem_div255(x.w, mu.w, sd.w, a.clip_obs);
+      } else {
       y.x = norm_elem(x.x, mu.x, sd.x, a.normalize, a.clip_obs, a.scale_div);
       y.y = norm_elem(x.y, mu.y, sd.y, a.normalize, a.clip_obs, a.scale_div);
       y.z = norm_elem(x.z, mu.z, sd.z, a.normalize, a.clip_obs, a.scale_div);
       y.w = norm_elem(x.w, mu.w, sd.w, a.normalize, a.clip_obs, a.scale_div);
+      }
       if (which) {
         *(gn_f4*)(a.x_next + (long)b * a.ldx + e4) = y;
       } else {
@@ -376,7 +412,10 @@ __device__ __forceinline__ void gather_row_extras(const GatherArgs& a, const int
 // the latency chain: one Philox draw per lane (lane r holds row r's index, the others read it with a lane broadcast), the
 // statistics of the thread's four element positions loaded ONCE, and the R replay reads issued back to back before the first
 // is consumed -- a workgroup lives about as long as a one-row workgroup does and there are R times fewer of them.
-template <int R>
+// BRANCH_FREE: take norm_elem_rcp255's loop when the arguments allow it.  It keeps all R results live (the point: R x 4 chains
+// in flight), which the kernels built for 8 waves per SIMD cannot afford (reduce_slabs_gather_kernel: 36 bytes of scratch per
+// lane and 4 660 against 4 740 updates/s on the RGB-D ring): those keep the one-element-at-a-time loop.
+template <int R, bool BRANCH_FREE = false>
 __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const int bx, const int grp) {
   typedef float gn_f4 __attribute__((ext_vector_type(4)));
   typedef double gn_d4 __attribute__((ext_vector_type(4)));
@@ -426,6 +465,27 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
       mu = *(const gn_d4*)(a.mean + e4); sd = *(const gn_d4*)(a.stdv + e4);
       rc.x = 1.0 / sd.x; rc.y = 1.0 / sd.y; rc.z = 1.0 / sd.z; rc.w = 1.0 / sd.w;     // IEEE divisions: correctly rounded reciprocals
     }
+    const bool fast = BRANCH_FREE && norm_fast255(a.normalize, a.clip_obs, a.scale_div);      // (uniform: one branch around the loop, none inside)
+    if (fast) {
+      gn_f4 y[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        y[r].x = norm_elem_rcp255(x[r].x, mu.x, sd.x, rc.x, a.clip_obs);
+        y[r].y = norm_elem_rcp255(x[r].y, mu.y, sd.y, rc.y, a.clip_obs);
+        y[r].z = norm_elem_rcp255(x[r].z, mu.z, sd.z, rc.z, a.clip_obs);
+        y[r].w = norm_elem_rcp255(x[r].w, mu.w, sd.w, rc.w, a.clip_obs);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const long o = (long)(b0 + r) * a.ldx + e4;
+        if (which) {
+          *(gn_f4*)(a.x_next + o) = y[r];
+        } else {
+          *(gn_f4*)(a.x_obs + o) = y[r];
+          if (a.x_obs2) *(gn_f4*)(a.x_obs2 + o) = y[r];
+        }
+      }
+    } else
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       gn_f4 y;
@@ -468,9 +528,9 @@ __device__ __forceinline__ void gather_norm_rows_body(const GatherArgs& a, const
 static inline int gather_rider_blocks(const GatherArgs& a, int gx) { return gx * (2 * a.B / a.rows); }
 __device__ __forceinline__ void gather_images_rider(const GatherArgs& a, const int gx, const int r) {
 #ifndef GRL_HOSTEMU
-  if (a.rows == 16) gather_norm_rows_body<16>(a, r % gx, r / gx);
-  else if (a.rows == 8) gather_norm_rows_body<8>(a, r % gx, r / gx);
-  else gather_norm_rows_body<4>(a, r % gx, r / gx);
+  if (a.rows == 16) gather_norm_rows_body<16, true>(a, r % gx, r / gx);
+  else if (a.rows == 8) gather_norm_rows_body<8, true>(a, r % gx, r / gx);
+  else gather_norm_rows_body<4, true>(a, r % gx, r / gx);
 #else
   for (int k = 0; k < a.rows; ++k) {
     const int i = (r / gx) * a.rows + k;

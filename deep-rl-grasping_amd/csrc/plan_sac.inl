@@ -72,9 +72,7 @@ int grl_ctx::plan_sac() {
   if (cnn) {
     x_obs = wk.f32((int64_t)B * img_elems);
     x_next = wk.f32((int64_t)B * img_elems);
-    // second image buffer ("gather_ride" below).  Default: float32 rings only -- on the byte-colour ring (RGB-D, 50 MB per gather) the
-    // riders' traffic doubles the latency of the head chains they share the launch with: 4 480 against 4 720 updates/s
-    x_obs_b = tune_int("gather_ride", c.replay_rgb_u8 ? 0 : 1) != 0 ? wk.f32((int64_t)B * img_elems) : nullptr;
+    x_obs_b = tune_int("gather_ride", 1) != 0 ? wk.f32((int64_t)B * img_elems) : nullptr;     // second image buffer ("gather_ride" below)
     // Layer-1 activations of the two TRAINED networks (and their gradients below) sit side by side, pixel stride 64:
     // pi in columns 0..31, values_fn in 32..63.  Both networks read the same observations, so conv1's weight
     // gradient becomes ONE product obs-patches^T x [dY_pi | dY_vf] (N = 64: full 64x64 tiles, the gathered patches
