@@ -18,6 +18,7 @@ Other workloads (`--workload`), each with its own roofline and CPU-oracle baseli
   sac_nature  configs[0] on the GPU: default nature_cnn over both channels, A=3, batch 64, no VecNormalize
   sac_depth_128  the shipped table-clearing SAC config with layers [128,128], batch 64
   sac_mlp     configs[0] as shipped (depth_observation False): sacMlp on 100-d auto-encoder features, A=3, batch 64
+  bdq_uniform configs[2] as gripper_grasp.yaml ships it (prioritized_replay: False): the same network on uniform replay
   bdq_per     configs[2]: BDQ 5 branches x 33 bins on 101-d observations, batch 64, prioritised replay over 1 M
   ae_train    auto-encoder training step, batch 128 (config/encoder.yaml)
 
@@ -734,14 +735,14 @@ def run_sac(args, wl_name, world, rank, device):
     return out
 
 
-def run_bdq(args, device):
+def run_bdq(args, device, prioritized=True):
     import numpy as np
     import torch
     from grasp_rl import _capi
     from grasp_rl.engine import QEngine
     replay = args.replay or 1_000_000
     cfg = _capi.make_q_config("bdq", 101, 5, 33, common=(64, 64), branch_hidden=(32,), value_hidden=(32,), batch_size=64,
-                              replay_capacity=replay, lr=1e-4, prioritized=True)
+                              replay_capacity=replay, lr=1e-4, prioritized=prioritized)
     eng = QEngine(cfg, device=str(device))
     rng = np.random.default_rng(0)
     P = {}
@@ -761,25 +762,26 @@ def run_bdq(args, device):
                                   torch.randn(m, generator=g, device=device), torch.randn((m, 101), generator=g, device=device),
                                   (torch.rand(m, generator=g, device=device) < 1.0 / 15.0).float())
         eng.be.stream.synchronize()
-    go = lambda n: eng.train_per(n, beta=0.4)
+    go = (lambda n: eng.train_per(n, beta=0.4)) if prioritized else (lambda n: eng.train_device(n))
 
     def barrier():
         eng.synchronize()
         torch.cuda.synchronize(device)
     times, calls = timed_blocks(go, barrier, args.steps, args.warmup, args.repeats, 1, device)
     dt = float(np.median(times))
-    out = {"metric": "BDQ grad-steps/sec (101-d observations, 5 x 33 bins, batch 64, prioritised replay)",
+    out = {"metric": "BDQ grad-steps/sec (101-d observations, 5 x 33 bins, batch 64, %s replay)" % ("prioritised" if prioritized else "uniform"),
            "value": round(args.steps / dt, 2), "unit": "grad-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[2]: gripper_grasp.yaml --algo BDQ (layers [[64,64],[32],[32]], num_actions_pad 33, batch "
-                                  "64, lr 1e-4, prioritized_replay) on 101-d auto-encoder observations, %d-transition ring + "
-                                  "priorities in HBM, device RNG" % replay},
+                                  "64, lr 1e-4, %s) on 101-d auto-encoder observations, %d-transition ring%s in HBM, device RNG"
+                                  % ("prioritized_replay: True" if prioritized else "prioritized_replay: False as gripper_grasp.yaml:106 ships it", replay,
+                                     " + priorities" if prioritized else "")},
            "repeats": {"n": args.repeats, "block_ms": [round(1e3 * t, 3) for t in times], "value_is": "median block", **block_note(calls, args.steps)},
            "losses": {k: round(float(v), 6) for k, v in eng.metrics().items()}}
     if not args.no_profile:
         prof = profile_pass(eng, go, 50)
-        out["roofline"] = roofline_of(prof, 50, dt / args.steps, "bdq_per")
+        out["roofline"] = roofline_of(prof, 50, dt / args.steps, "bdq_per" if prioritized else "bdq_uniform")
         out["roofline"]["note"] = "every launch of this update is latency-bound (0.01 GFLOP, < 5 MB): fractions are informational"
     out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_bdq()
     eng.close()
@@ -831,7 +833,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps updates; value = median block")
-    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_depth_128", "sac_nature", "sac_mlp", "bdq_per", "ae_train"])
+    ap.add_argument("--workload", default="sac_depth", choices=["sac_depth", "sac_rgbd", "sac_depth_128", "sac_nature", "sac_mlp", "bdq_per", "bdq_uniform", "ae_train"])
     ap.add_argument("--global-batch", type=int, default=None, help="fix the GLOBAL batch (strong scaling); per-GPU batch = G / N")
     ap.add_argument("--replay", type=int, default=None)
     ap.add_argument("--learn-iters", type=int, default=200)
@@ -875,8 +877,8 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     if args.workload.startswith("sac_"):
         out = run_sac(args, args.workload, world, rank, device)
-    elif args.workload == "bdq_per":
-        out = run_bdq(args, device)
+    elif args.workload in ("bdq_per", "bdq_uniform"):
+        out = run_bdq(args, device, prioritized=args.workload == "bdq_per")
     else:
         out = run_ae(args, device)
     if rank == 0:

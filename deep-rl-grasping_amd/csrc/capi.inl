@@ -554,6 +554,23 @@ int grl_train_step(grl_handle h, int n_steps, const int64_t* idx, const float* e
     HIPCHK(hipGetLastError());
     return GRL_OK;
   }
+  if (!idx && n_steps >= 2 && h->q_pf_ok && !h->prof) {      // DQN / BDQ, uniform replay: prefetching sequences (plan_q "q_pf")
+    if (n_steps <= 32 && tune_int("graph_updates", 16) != 1) {
+      std::vector<std::vector<Op>*> seq;
+      seq.push_back(&h->ops_q_pf_first);
+      for (int s = 0; s < n_steps - 2; ++s) seq.push_back(&h->ops_q_pf_mid);
+      seq.push_back(&h->ops_q_pf_last);
+      if (int e = h->run_seq("q_pf_call_" + std::to_string(n_steps), seq)) return e;
+      HIPCHK(hipGetLastError());
+      return GRL_OK;
+    }
+    if (int e = h->run_seq("q_pf_first", {&h->ops_q_pf_first})) return e;
+    if (n_steps > 2)
+      if (int e = h->run_repeated("q_pf_mid", {&h->ops_q_pf_mid}, n_steps - 2)) return e;
+    if (int e = h->run_seq("q_pf_last", {&h->ops_q_pf_last})) return e;
+    HIPCHK(hipGetLastError());
+    return GRL_OK;
+  }
   if (!idx) {      // device RNG: identical updates, several to a graph
     if (!h->ops_grads_apply.empty()) {
       if (int e = h->run_repeated("full_rng", {&h->ops_rng, &h->ops_grads_apply}, n_steps)) return e;

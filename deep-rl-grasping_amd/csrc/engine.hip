@@ -303,6 +303,9 @@ struct grl_ctx {
   // ... multi-update calls on the device RNG, FOUR launches per update: write-back + block-sum refresh ride on the trunk launch,
   // the sampler of the next update on the apply launch (plan_q.inl "per_pf"); the forward launch opens the update
   std::vector<Op> ops_per_pf_first, ops_per_pf_mid, ops_per_pf_last;
+  // ... and uniform replay: the next update's index draw + gather ride on the apply launch (plan_q.inl "q_pf"), four launches per update
+  std::vector<Op> ops_q_pf_first, ops_q_pf_mid, ops_q_pf_last;
+  bool q_pf_ok = false;
   bool per_pf_ok = false;
   Op q_fwd_tick_op, q_bwd_wb_op;
   bool have_q_fwd_tick = false, have_q_bwd_wb = false;

@@ -636,8 +636,9 @@ int grl_ctx::plan_q() {
       const float clip = c.q_grad_clip;
       const float* rp = q_row_part; const int rows = B, fin = q_finish;
       auto qga = q_ga;      // (shared with the samplers: the minibatch gather of this plan)
-      auto apply_op = [self, dr, nd, clip, rp, rows, fin, qga](bool with_per, bool refresh = false, bool next_sampler = false) {
-        return [self, dr, nd, clip, rp, rows, fin, with_per, refresh, next_sampler, qga](hipStream_t s) {
+      const int q_gx = (img_elems + 255) / 256;      // tiles per row of gather_norm_kernel on this plan (scalar form)
+      auto apply_op = [self, dr, nd, clip, rp, rows, fin, qga, q_gx](bool with_per, bool refresh = false, bool next_sampler = false, bool next_uniform = false) {
+        return [self, dr, nd, clip, rp, rows, fin, with_per, refresh, next_sampler, next_uniform, qga, q_gx](hipStream_t s) {
           AdamArgs aa;
           aa.params = self->params; aa.grads = self->grads; aa.m = self->adam_m; aa.v = self->adam_v;
           aa.n_train = self->n_train; aa.sc = self->sc; aa.grad_scale = self->grad_scale; aa.tau = 0.f; aa.eps = 1e-8f;
@@ -647,17 +648,27 @@ int grl_ctx::plan_q() {
           // prioritised replay: one more workgroup writes the new priorities back (per_update_kernel's work)
           // (refresh: one more workgroup per sample rebuilds the block sums its new priority touches, per_refresh_body)
           // (next_sampler: write-back and refresh rode on the trunk launch; `rows` workgroups draw the NEXT update's minibatch)
-          const int n_extra = next_sampler ? 1 : (with_per ? 2 : 1) + (refresh ? rows : 0);
+          const int n_extra = (next_sampler || next_uniform) ? 1 : (with_per ? 2 : 1) + (refresh ? rows : 0);
           QNextArgs nx;
           memset(&nx, 0, sizeof(nx));
+          int n_next = 0;
           if (next_sampler) {
             nx.per = q; nx.per.u = nullptr;
             nx.g = *qga; nx.g.adam_tick = 0;          // (the next update's forward launch fixes its Adam step size)
             nx.n_sample = rows; nx.n_blocks = self->per_blocks;
+            n_next = rows;
+          } else if (next_uniform) {
+            // the riders draw row b's index with counter + 1 themselves (the draw of rng_kernel) and leave it in idx_buf; the
+            // importance weights stay the ones the call's first update wrote
+            nx.g = *qga; nx.g.adam_tick = 0; nx.g.use_rng = 1; nx.g.rng_ahead = 1; nx.g.quiet = 1;
+            nx.g.seed = self->cfg.seed; nx.g.idx_w = self->idx_buf; nx.g.n_eps = 0;
+            nx.uniform_gx = q_gx;
+            n_next = q_gx * nx.g.B * 2;
           }
-          // (finish bit 1 = leave the Philox counter alone: the trunk launch advanced it, the sampler on this launch reads it)
-          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + n_extra + (next_sampler ? rows : 0)), dim3(1024), 0, s, dr, nd, clip,
-                             aa, rp, rows, fin | (next_sampler ? 2 : 0), q, (const int64_t*)self->idx_buf, n_extra, nx);
+          // (finish bit 1 = leave the Philox counter alone: the riders of this launch read it; prioritised: the trunk launch
+          //  advanced it already; uniform: the next update's forward launch will)
+          hipLaunchKernelGGL(q_reduce_clip_adam_kernel, dim3(nd + n_extra + n_next), dim3(1024), 0, s, dr, nd, clip,
+                             aa, rp, rows, fin | ((next_sampler || next_uniform) ? 2 : 0), q, (const int64_t*)self->idx_buf, n_extra, nx);
         };
       };
       op.run = apply_op(false);
@@ -698,6 +709,36 @@ int grl_ctx::plan_q() {
         }
         if (getenv("GRL_PLAN_DUMP"))
           fprintf(stderr, "grl plan: per_pf        multi-update prioritised calls, four launches per update (sampler on the apply launch): %s\n", per_pf_ok ? "yes" : "no");
+      }
+      // "q_pf": uniform replay, calls of several updates on the device RNG -- FOUR launches per update instead of six: the index draw
+      // and the gather of update t + 1 (rng_kernel + gather_norm_kernel) ride on the launch that ends update t, whose forward launch
+      // is the first reader of the minibatch tensors; the forward launch of t + 1 opens the update (counter += 1, Adam step size).
+      //   first : rng | gather | forward | towers | trunk | apply + draw / gather(t + 1)
+      //   middle:                forward[counter += 1, tick] | towers | trunk | apply + draw / gather(t + 1)
+      //   last  :                forward[counter += 1, tick] | towers | trunk | apply (counter += 1)
+      if (!per_on && tune_int("q_pf", 1) && have_q_fwd_tick && fin && B <= 1024) {
+        Op fwd_adv = q_fwd_tick_op;
+        {
+          QFusedArgs ft = qf;
+          ft.tick_sc = sc; ft.tick_rng = 1;
+          fwd_adv.run = [ft](hipStream_t s) { launch_q_fwd(ft, s); };
+        }
+        ops_q_pf_first = ops_rng;
+        for (int v = 0; v < 3; ++v) {
+          std::vector<Op>& dst = v == 0 ? ops_q_pf_first : (v == 1 ? ops_q_pf_mid : ops_q_pf_last);
+          for (size_t k = 0; k + 1 < ops_grads_apply.size(); ++k) {
+            const Op& o = ops_grads_apply[k];
+            if (o.tag == "gather_norm") { if (v == 0) dst.push_back(o); }
+            else if (o.tag == "q_fwd") dst.push_back(v == 0 ? o : fwd_adv);
+            else dst.push_back(o);
+          }
+          Op ao; ao.tag = "q_apply";
+          ao.run = v == 2 ? apply_op(false) : apply_op(false, false, false, true);
+          dst.push_back(ao);
+        }
+        q_pf_ok = true;
+        if (getenv("GRL_PLAN_DUMP"))
+          fprintf(stderr, "grl plan: q_pf          multi-update uniform calls, four launches per update (draw + gather on the apply launch)\n");
       }
       *q_defer = 1;
       if (fin) {     // split compute / apply path of this plan: the batch means as a launch of their own, behind the reduction

@@ -15,8 +15,11 @@ namespace grl {
 // QNextArgs: the sampler of the NEXT update riding on this launch (prioritised multi-update calls whose trunk launch has already
 // written this update's priorities back and refreshed the block sums: q_chain.h, QChainArgs.per_wb): n_sample workgroups behind
 // everything else, workgroup k = per_sample_kernel's workgroup k (sum-tree walk, importance weight, the row's gather).
+// uniform_gx > 0 (uniform replay, plan_q "q_pf"): the riders are the workgroups of gather_norm_kernel instead -- uniform_gx x B x 2,
+// each drawing its row's index itself (GatherArgs.use_rng with rng_ahead = 1: the counter still holds this update's value)
 struct QNextArgs {
   PerArgs per; GatherArgs g; int n_sample, n_blocks;
+  int uniform_gx;
 };
 #ifdef GRL_HOSTEMU
 #include "q_apply_kernels_ref1.h"   // tests/hostemu: the emulation build only
@@ -32,6 +35,11 @@ __global__ __launch_bounds__(1024) void q_reduce_clip_adam_kernel(const ReduceDe
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= n_desc + n_extra) {      // the next update's sampler (n_extra: the extra workgroups in front of it)
     if (t >= 256) return;               // (whole waves retire: the barriers below are among the remaining four)
+    if (nx.uniform_gx > 0) {
+      const int k = (int)blockIdx.x - n_desc - n_extra, gx = nx.uniform_gx;
+      gather_norm_body(nx.g, k % gx, (k / gx) % nx.g.B, k / (gx * nx.g.B));
+      return;
+    }
     static_assert(GRL_QAPPLY_MAX * sizeof(float) >= (2 * PER_BLK + 257) * sizeof(double), "the sampler's trees live in gsum");
     per_sample_body(nx.per, nx.n_blocks, nx.g, 1, (int)blockIdx.x - n_desc - n_extra, (double*)gsum, (double*)gsum + 2 * PER_BLK);
     return;

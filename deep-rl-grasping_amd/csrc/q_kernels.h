@@ -31,6 +31,8 @@ struct QFusedArgs {
   DevScalars* tick_sc;    // forward launch only, optional: this launch OPENS the update -- one thread fixes the Adam step size and
                           // advances the beta powers (adam_tick_device).  Prioritised multi-update calls: the sampler of update
                           // t + 1 rides on the apply launch of update t, which still reads update t's step size
+  int tick_rng;           // ... and advances the Philox counter first (uniform multi-update calls, plan_q "q_pf": this update's
+                          // minibatch was drawn with counter + 1 by riders of the previous update's apply launch)
 };
 
 #ifndef GRL_HEADS_TYPES_ONLY
@@ -39,7 +41,7 @@ struct QFusedArgs {
 #else
 __global__ __launch_bounds__(256) void q_fwd_fused_kernel(QFusedArgs a) {
   __shared__ HtLds s;
-  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) adam_tick_device(a.tick_sc);
+  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) { if (a.tick_rng) a.tick_sc->rng_step += 1; adam_tick_device(a.tick_sc); }
   const HtHead& h = a.fwd[blockIdx.y * (a.D + 1) + blockIdx.z];
   ht_fwd_head(h, blockIdx.x * HT_RB, a.B, s, false);
 }

@@ -80,7 +80,7 @@ __device__ __forceinline__ void qm_zero(QmLds& s) {
 // grid (B/16, 3 nets, D+1 towers): shared trunk (recomputed per tower, stored by tower 0) -> tower -> advantage / value
 __global__ __launch_bounds__(256) void q_fwd_mfma_kernel(QFusedArgs a) {
   __shared__ QmLds s;
-  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) adam_tick_device(a.tick_sc);
+  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) { if (a.tick_rng) a.tick_sc->rng_step += 1; adam_tick_device(a.tick_sc); }
   const HtHead& h = a.fwd[blockIdx.y * (a.D + 1) + blockIdx.z];
   const int t = threadIdx.x, w = t >> 6, l = t & 63, c = l & 15, q = l >> 4;
   const int n = 16 * w + c, row0 = blockIdx.x * HT_RB, B = a.B, L = h.L;

@@ -11,7 +11,12 @@ inline void q_finish_kernel(DevScalars* sc, const float* row_part, int rows) {
 }
 inline void q_reduce_clip_adam_kernel(const ReduceDesc* descs, int n_desc, float clip, AdamArgs aa, const float* row_part, int rows,
                                       int finish, PerArgs per, const int64_t* per_idx, int n_extra, QNextArgs nx) {
-  if ((int)blockIdx.x >= n_desc + n_extra) {   // the next update's sampler rides on this launch
+  if ((int)blockIdx.x >= n_desc + n_extra) {   // the next update's sampler / uniform gather rides on this launch
+    if (nx.uniform_gx > 0) {
+      const int k = (int)blockIdx.x - n_desc - n_extra, gx = nx.uniform_gx;
+      if (threadIdx.x < 256) gather_norm_body(nx.g, k % gx, (k / gx) % nx.g.B, k / (gx * nx.g.B));
+      return;
+    }
     per_sample_ref(nx.per, nx.n_blocks, nx.g, 1, (int)blockIdx.x - n_desc - n_extra);
     return;
   }

@@ -3,7 +3,7 @@
 // Never part of libgrl.so.  No include guard: it is pasted once, inside namespace grl.
 inline void q_fwd_fused_kernel(QFusedArgs a) {
   if (threadIdx.x != 0) return;
-  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) adam_tick_device(a.tick_sc);
+  if (a.tick_sc && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) { if (a.tick_rng) a.tick_sc->rng_step += 1; adam_tick_device(a.tick_sc); }
   const HtHead& h = a.fwd[blockIdx.y * (a.D + 1) + blockIdx.z];
   for (int row = blockIdx.x * HT_RB; row < std::min(a.B, (int)blockIdx.x * HT_RB + HT_RB); ++row)
     ht_ref_fwd_head(h, row, nullptr);

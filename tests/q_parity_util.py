@@ -187,6 +187,31 @@ def per_check(backend=None, lib_path=None, cap=3000, n_store=2500, B=16, n_steps
     return tot
 
 
+def uniform_multi_update_check(monkeypatch, name, n_store, backend=None, lib_path=None, n=7):
+    """Uniform replay on the device RNG (what gripper_grasp.yaml:106 selects for BDQ): ONE call of n updates -- the index draw and
+    the gather of update t + 1 ride on the apply launch of update t, the forward launch opens each update (plan_q "q_pf", four
+    launches per update) -- == n calls of one update == the same with GRL_TUNE q_pf=0: parameters, Adam moments, the last drawn
+    indices and the metrics bit for bit."""
+    def run(split, env=None):
+        if env:
+            monkeypatch.setenv("GRL_TUNE", env)
+        case = make_q_case(n_replay=n_store, n_steps=1, **dict(CASES[name]))
+        eng = q_engine_setup(case, backend, lib_path)
+        for k in split:
+            eng.train_device(k)
+        out = (eng.get_parameters(), eng.fetch("adam_m").copy(), eng.fetch("adam_v").copy(), eng.sampled_indices(), eng.metrics())
+        eng.close()
+        if env:
+            monkeypatch.delenv("GRL_TUNE")
+        return out
+    ref = run([1] * n)
+    for got in (run([n]), run([2, n - 2]), run([n - 3, 1, 2]), run([n], env="q_pf=0")):
+        for k in ref[0]:
+            assert np.array_equal(ref[0][k], got[0][k]), k
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+        assert np.array_equal(ref[3], got[3]) and ref[4] == got[4]
+
+
 def per_multi_update_check(monkeypatch, name, cap, n_store, backend=None, lib_path=None, n=9):
     """Prioritised replay on the device RNG: ONE call of n updates (the first sums every block of the ring, every apply
     launch rebuilds the blocks its priority write-back touched, the later samplers start from those -- per_refresh_body) ==

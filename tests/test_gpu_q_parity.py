@@ -162,3 +162,11 @@ def test_per_multi_update_call_keeps_the_block_sums_current(name, cap, n_store, 
     """Prioritised replay on the device RNG: ONE call of n updates == n calls of one update, bit for bit
     (q_parity_util.per_multi_update_check; the CPU suite runs it on the emulation build)."""
     qu.per_multi_update_check(monkeypatch, name, cap, n_store)
+
+
+@pytest.mark.parametrize("name", ["bdq_baseline_config3_uniform", "dqn_reference_shape"])
+def test_uniform_multi_update_call_prefetches_the_next_minibatch(name, monkeypatch):
+    """configs[2] as gripper_grasp.yaml selects it (uniform replay) and the reference's DQN shape: one call of n updates -- draw +
+    gather of the next minibatch on the apply launch, four launches per update -- == n single-update calls, bit for bit
+    (q_parity_util.uniform_multi_update_check; the CPU suite runs it on the emulation build)."""
+    qu.uniform_multi_update_check(monkeypatch, name, 3000, n=9)

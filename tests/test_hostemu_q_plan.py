@@ -69,3 +69,12 @@ def test_multi_update_per_call_keeps_the_block_sums_current(hostemu_lib, monkeyp
     emulation build: the launch sequences of capi.inl / plan_q.inl and the refresh's ownership rule, bit for bit."""
     from hostemu_backend import NumpyHostBackend
     qu.per_multi_update_check(monkeypatch, "bdq", 2100, 2050, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=6)
+
+
+@pytest.mark.parametrize("name", ["bdq", "dqn"])
+def test_multi_update_uniform_call_prefetches_the_next_minibatch(hostemu_lib, monkeypatch, name, capfd):
+    """plan_q "q_pf" on the emulation build: one call of n uniform-replay updates == n single-update calls, bit for bit."""
+    from hostemu_backend import NumpyHostBackend
+    monkeypatch.setenv("GRL_PLAN_DUMP", "1")
+    qu.uniform_multi_update_check(monkeypatch, name, 300, backend=NumpyHostBackend(), lib_path=hostemu_lib, n=6)
+    assert "q_pf " in capfd.readouterr().err
